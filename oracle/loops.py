@@ -1,0 +1,105 @@
+"""Meta-loop control flow restated on the oracle model (test infrastructure).
+
+Follows the loop structure of model_zoo/mamdr.py:41-108 (MAMDR = DN + DR),
+model_zoo/domain_negotiation.py:37-88, model_zoo/reptile.py:40-99 and the
+alternate training of model_zoo/DeepCTR/deepctr.py:63-93.  The reference drives
+these with the unseeded python `random` module (mamdr.py:46,68;
+domain_negotiation.py:42), so the domain order and the DR support-domain
+samples are INJECTED through `plan`, and the per-pass shuffle through
+`perm_fn(domain) -> int32 permutation`.  Each function returns a trace of
+(phase, domain, n_steps) tuples so the host's control flow can be compared.
+"""
+import numpy as np
+
+from . import outer
+
+F32 = np.float32
+
+
+def _pass(model, data, perm_fn, d, batch_size, trace, phase, max_steps=0):
+    perm = perm_fn(d)
+    losses = model.train_pass(data[d], perm, batch_size, max_steps)
+    trace.append((phase, d, len(losses)))
+    return losses
+
+
+def alternate_epoch(model, data, seq, perm_fn, batch_size):
+    """deepctr.py:70-78: one full pass per domain in shuffled order."""
+    trace = []
+    for d in seq:
+        _pass(model, data, perm_fn, d, batch_size, trace, "alt")
+    return trace
+
+
+def dn_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, meta_train_step=0):
+    """domain_negotiation.py:49-88: theta set once, sequential passes without
+    reset, then theta += beta (theta~ - theta) and model := theta."""
+    trace = []
+    model.set_flat(theta)
+    for d in seq:
+        _pass(model, data, perm_fn, d, batch_size, trace, "dn", meta_train_step)
+    outer.dn_update(theta, model.get_flat(), meta_lr)
+    model.set_flat(theta)
+    return trace
+
+
+def reptile_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
+                  meta_train_step=0):
+    """reptile.py:45-99."""
+    trace = []
+    acc = np.zeros_like(theta)
+    for d in seq:
+        model.set_flat(theta)
+        _pass(model, data, perm_fn, d, batch_size, trace, "reptile", meta_train_step)
+        if batch_variant:
+            outer.reptile_accumulate(acc, model.get_flat(), theta)
+        else:
+            outer.dn_update(theta, model.get_flat(), meta_lr)
+    if batch_variant:
+        outer.reptile_apply(theta, acc, meta_lr)
+    model.set_flat(theta)
+    return trace
+
+
+def mamdr_epoch(model, theta, phis, data, plan, perm_fn, batch_size, meta_lr, merged_method="plus",
+                domain_regulation_step=0, batch_variant=False, sample_num=None):
+    """mamdr.py:44-108.  plan = {"seq": [...], "dr": [(query, [support...]), ...]}
+    (support list already contains the query domain when add_query_domain)."""
+    trace = []
+    # --- DN phase (mamdr.py:48-57)
+    model.set_flat(theta)
+    for d in plan["seq"]:
+        _pass(model, data, perm_fn, d, batch_size, trace, "dn")
+    outer.mamdr_update(theta, model.get_flat(), theta, meta_lr)
+    # --- DR phase (mamdr.py:59-108)
+    for query, support in plan["dr"]:
+        merged = outer.merge(theta, phis[query], merged_method)
+        acc = np.zeros_like(theta)
+        for j in support:
+            model.set_flat(merged)
+            _pass(model, data, perm_fn, j, batch_size, trace, "dr_support")
+            _pass(model, data, perm_fn, query, batch_size, trace, "dr_query", domain_regulation_step)
+            if batch_variant:
+                outer.mamdr_accumulate(acc, model.get_flat(), merged, theta, merged_method)
+            else:
+                outer.mamdr_update(phis[query], model.get_flat(), merged, meta_lr)
+                merged = outer.merge(theta, phis[query], merged_method)
+        if batch_variant:
+            outer.mamdr_apply_grads(phis[query], acc, sample_num, meta_lr)
+    return trace
+
+
+def evaluate_domains(model, data_split, batch_size, weights_for_domain, auc_fn):
+    """base_model.py:111-144 / specific_base_model.py:64-97: per-domain
+    (loss, AUC); averages are plain means over domains (base_model.py:138-139)."""
+    domain_loss, domain_auc = {}, {}
+    for d in sorted(data_split.keys()):
+        w = weights_for_domain(d)
+        if w is not None:
+            model.set_flat(w)
+        loss, preds = model.evaluate(data_split[d], batch_size)
+        domain_loss[d] = float(loss)
+        domain_auc[d] = float(auc_fn(data_split[d]["label"], preds, batch_size))
+    avg_loss = sum(domain_loss.values()) / len(domain_loss)
+    avg_auc = sum(domain_auc.values()) / len(domain_auc)
+    return avg_loss, avg_auc, domain_loss, domain_auc

@@ -1,0 +1,70 @@
+"""Outer (meta) parameter updates restated in numpy fp32 (test infrastructure).
+
+The reference does these on the host in numpy between `K.batch_get_value`
+(model_zoo/maml.py:194) and `SetVarOp.__call__` (utils/tool.py:36-45).  Each
+function names the reference lines it follows; every arithmetic step is one
+fp32 rounding (numpy keeps fp32 when an fp32 array meets a python scalar), in
+the reference's order, so the HIP kernels can be compared bit-for-bit.
+Pinned by tests/golden/outer_goldens.npz (generated from the reference's own
+methods by tests/golden/make_outer_goldens.py).
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def dn_update(theta, new, meta_lr):
+    """model_zoo/domain_negotiation.py:118-123 == model_zoo/reptile.py:127-132:
+    old += (new - old) * meta_lr."""
+    theta += ((new - theta) * F32(meta_lr)).astype(F32)
+    return theta
+
+
+def reptile_accumulate(acc, new, old):
+    """model_zoo/reptile.py:134-137: acc += new - old."""
+    acc += (new - old).astype(F32)
+    return acc
+
+
+def reptile_apply(theta, acc, meta_lr):
+    """model_zoo/reptile.py:139-142: old += acc * meta_lr; acc = 0."""
+    theta += (acc * F32(meta_lr)).astype(F32)
+    acc[...] = 0
+    return theta
+
+
+def merge(theta, phi, method="plus"):
+    """model_zoo/specific_base_model.py:164-172."""
+    if method == "plus":
+        return (theta + phi).astype(F32)
+    elif method == "times":
+        return (theta * phi).astype(F32)
+    raise ValueError(method)
+
+
+def mamdr_update(update, new, old, meta_lr):
+    """model_zoo/mamdr.py:173-180: update += (new - old) * meta_lr, with
+    old = merged weights (DR) or `update` itself (DN)."""
+    update += ((new - old) * F32(meta_lr)).astype(F32)
+    return update
+
+
+def mamdr_domain_weights(new, merged):
+    """model_zoo/mamdr.py:168-171: phi = new - merged."""
+    return (new - merged).astype(F32)
+
+
+def mamdr_accumulate(acc, new, old, shared, method="plus", train_step=1):
+    """model_zoo/mamdr.py:182-191 (batch variant)."""
+    if method == "plus":
+        acc += ((new - old) / F32(train_step)).astype(F32)
+    elif method == "times":
+        acc += ((new - old) * shared / F32(train_step)).astype(F32)
+    return acc
+
+
+def mamdr_apply_grads(old, grads, sample_num, meta_lr):
+    """model_zoo/mamdr.py:193-196: old += grads / sample_num * meta_lr; grads = 0."""
+    old += (grads / F32(sample_num) * F32(meta_lr)).astype(F32)
+    grads[...] = 0
+    return old

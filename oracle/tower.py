@@ -1,0 +1,271 @@
+"""fp32 numpy restatement of the reference's inner step (test infrastructure).
+
+One "domain-step"  = `model.train_on_batch(iter)` at
+model_zoo/mamdr.py:54,86,97, model_zoo/domain_negotiation.py:72,
+model_zoo/reptile.py:70, model_zoo/DeepCTR/deepctr.py:76 on the model built by
+model_zoo/DeepCTR/deepctr.py:95-136 and compiled at deepctr.py:54-60.
+
+PARITY UNPINNED: the arithmetic below lives in tensorflow-gpu==1.12.0 /
+deepctr==0.9.0 (requirements.txt:1,6; not in the tree, not installable).  It
+restates their published algorithms:
+
+* tower      deepctr.py:118-136 -> concat(user, item, domain 128-d rows) ->
+             deepctr `DNN(256,128,64, relu, dropout)` -> Dense(1, no bias) ->
+             PredictionLayer('binary') (= + global_bias, sigmoid)
+* regulariser deepctr.py:119,125-126 l2_reg_embedding=1e-5 on all three tables
+* loss       deepctr.py:59 Keras binary_crossentropy (clip 1e-7, logit form)
+* optimiser  deepctr.py:55 tf.train.AdamOptimizer (ApplyAdam kernel form);
+             finetune: GradientDescentOptimizer (specific_base_model.py:120,
+             base_model.py:69)
+"""
+import numpy as np
+
+from . import rng
+
+F32 = np.float32
+EPS_CLIP = F32(1e-7)        # K.epsilon()
+BETA1 = F32(0.9)
+BETA2 = F32(0.999)
+ADAM_EPS = F32(1e-8)
+L2_EMB = F32(1e-5)          # deepctr.py:118 l2_reg_embedding
+
+DENSE_NAMES = ("W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
+
+
+def param_names(emb_trainable):
+    """Flat meta-vector order = Keras `trainable_weights` order:
+    trainable embeddings in feature order (deepctr.py:102), DNN kernels, DNN
+    biases, final dense kernel, global bias."""
+    emb = ("user_emb", "item_emb", "domain_emb") if emb_trainable else ("domain_emb",)
+    return emb + DENSE_NAMES
+
+
+def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64),
+                pretrained=True):
+    """Injected initial tensors (TF initialiser streams are unreproducible, A.2).
+    glorot-normal-like kernels, zero biases, N(0,1e-4^2) domain table, N(0,0.1^2)
+    'pretrained' user/item tables."""
+    p = {}
+    sd = 0.1 if pretrained else 1e-4
+    p["user_emb"] = (rs.standard_normal((n_user, emb_dim)) * sd).astype(F32)
+    p["item_emb"] = (rs.standard_normal((n_item, emb_dim)) * sd).astype(F32)
+    p["domain_emb"] = (rs.standard_normal((n_domain, emb_dim)) * 1e-4).astype(F32)
+    dims = (3 * emb_dim,) + tuple(hidden)
+    for l in range(3):
+        s = np.sqrt(2.0 / (dims[l] + dims[l + 1]))
+        p["W%d" % l] = (np.clip(rs.standard_normal((dims[l], dims[l + 1])), -2, 2) * s).astype(F32)
+        p["b%d" % l] = np.zeros(dims[l + 1], F32)
+    s = np.sqrt(2.0 / (dims[3] + 1))
+    p["wo"] = (np.clip(rs.standard_normal((dims[3], 1)), -2, 2) * s).astype(F32)
+    p["gb"] = np.zeros(1, F32)
+    return p
+
+
+def flatten(params, names):
+    return np.concatenate([params[n].ravel() for n in names]).astype(F32)
+
+
+def unflatten(vec, params, names):
+    """write `vec` back into the arrays of `params` (in place)."""
+    o = 0
+    for n in names:
+        a = params[n]
+        a[...] = vec[o:o + a.size].reshape(a.shape)
+        o += a.size
+    assert o == vec.size
+
+
+def sigmoid(z):
+    z = z.astype(F32)
+    out = np.empty_like(z)
+    pos = z >= 0
+    ez = np.exp(-z[pos], dtype=F32)
+    out[pos] = F32(1) / (F32(1) + ez)
+    ez = np.exp(z[~pos], dtype=F32)
+    out[~pos] = ez / (F32(1) + ez)
+    return out
+
+
+def bce_per_row(p, y):
+    """Keras binary_crossentropy (A.4): clip, back to logits, stable CE."""
+    pc = np.clip(p, EPS_CLIP, F32(1) - EPS_CLIP).astype(F32)
+    z = np.log(pc / (F32(1) - pc), dtype=F32)
+    return (np.maximum(z, F32(0)) - z * y + np.log1p(np.exp(-np.abs(z), dtype=F32), dtype=F32)).astype(F32)
+
+
+def reg_loss(params):
+    """deepctr l2_reg_embedding * sum(W^2) on every table, frozen or not (A.3)."""
+    r = F32(0)
+    for n in ("user_emb", "item_emb", "domain_emb"):
+        r = F32(r + L2_EMB * F32(np.sum(np.square(params[n], dtype=F32), dtype=np.float64)))
+    return F32(r)
+
+
+def gather(params, uid, pid, dom):
+    """K1: x[b] = [U[uid_b] | I[pid_b] | Dm[dom_b]] (deepctr.py:102 feature order)."""
+    return np.concatenate([params["user_emb"][uid], params["item_emb"][pid],
+                           params["domain_emb"][dom]], axis=1)
+
+
+def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1)):
+    """returns (p, cache). masks: 3 float32 keep masks or None (inference)."""
+    x = gather(params, uid, pid, dom)
+    hs = [x]
+    h = x
+    for l in range(3):
+        z = (h @ params["W%d" % l] + params["b%d" % l]).astype(F32)
+        a = np.maximum(z, F32(0))
+        if masks is not None:
+            a = (a * keep_scale * masks[l]).astype(F32)
+        hs.append(a)
+        h = a
+    logit = (h @ params["wo"]).astype(F32)[:, 0] + params["gb"][0]
+    p = sigmoid(logit)
+    return p, hs
+
+
+def train_masks(seed, step, n_rows, hidden, rate):
+    return [rng.dropout_mask(seed, step, l, n_rows, hidden[l], rate) for l in range(3)]
+
+
+def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable):
+    """one batch: total loss (BCE mean + regularisers) and dense gradients."""
+    B = uid.shape[0]
+    keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
+    p, hs = forward(params, uid, pid, dom, masks, keep_scale)
+    y = label.astype(F32)
+    loss = F32(np.mean(bce_per_row(p, y), dtype=np.float64)) + reg_loss(params)
+    inside = ((p >= EPS_CLIP) & (p <= F32(1) - EPS_CLIP)).astype(F32)
+    dlogit = ((p - y) * inside / F32(B)).astype(F32)
+    g = {}
+    g["wo"] = (hs[3].T @ dlogit[:, None]).astype(F32)
+    g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
+    dh = (dlogit[:, None] * params["wo"][:, 0][None, :]).astype(F32)
+    for l in (2, 1, 0):
+        gate = (hs[l + 1] > 0).astype(F32) * keep_scale     # relu' * dropout mask * 1/keep
+        dz = (dh * gate).astype(F32)
+        g["W%d" % l] = (hs[l].T @ dz).astype(F32)
+        g["b%d" % l] = np.sum(dz, axis=0, dtype=np.float64).astype(F32)
+        dh = (dz @ params["W%d" % l].T).astype(F32)
+    E = params["domain_emb"].shape[1]
+    two_l2 = F32(2) * L2_EMB
+    gd = np.zeros_like(params["domain_emb"], dtype=np.float64)
+    np.add.at(gd, dom, dh[:, 2 * E:3 * E].astype(np.float64))
+    g["domain_emb"] = (gd.astype(F32) + two_l2 * params["domain_emb"]).astype(F32)
+    if emb_trainable:
+        gu = np.zeros_like(params["user_emb"], dtype=np.float64)
+        np.add.at(gu, uid, dh[:, 0:E].astype(np.float64))
+        g["user_emb"] = (gu.astype(F32) + two_l2 * params["user_emb"]).astype(F32)
+        gi = np.zeros_like(params["item_emb"], dtype=np.float64)
+        np.add.at(gi, pid, dh[:, E:2 * E].astype(np.float64))
+        g["item_emb"] = (gi.astype(F32) + two_l2 * params["item_emb"]).astype(F32)
+    return loss, g, p
+
+
+def beta_powers(t):
+    """fp32 running products beta^t as TF keeps them (beta1_power variable)."""
+    b1, b2 = F32(1), F32(1)
+    for _ in range(t):
+        b1 = F32(b1 * BETA1)
+        b2 = F32(b2 * BETA2)
+    return b1, b2
+
+
+class Optimizer(object):
+    """TF1 Adam (A.5): one (m, v) slot per variable and one step count for the
+    whole run -- never reset by weight assignment, between domains, between DN
+    and DR, or across epochs."""
+
+    def __init__(self, params, names):
+        self.names = names
+        self.m = {n: np.zeros_like(params[n]) for n in names}
+        self.v = {n: np.zeros_like(params[n]) for n in names}
+        self.t = 0
+        self.b1p = F32(1)
+        self.b2p = F32(1)
+
+    def adam(self, params, grads, lr):
+        self.t += 1
+        self.b1p = F32(self.b1p * BETA1)
+        self.b2p = F32(self.b2p * BETA2)
+        alpha = F32(F32(lr) * np.sqrt(F32(1) - self.b2p, dtype=F32) / (F32(1) - self.b1p))
+        omb1 = F32(F32(1) - BETA1)
+        omb2 = F32(F32(1) - BETA2)
+        for n in self.names:
+            gr = grads[n]
+            m, v = self.m[n], self.v[n]
+            m += ((gr - m) * omb1).astype(F32)
+            v += ((gr * gr - v) * omb2).astype(F32)
+            params[n] -= ((m * alpha) / (np.sqrt(v, dtype=F32) + ADAM_EPS)).astype(F32)
+
+    def sgd(self, params, grads, lr):
+        for n in self.names:
+            params[n] -= (grads[n] * F32(lr)).astype(F32)
+
+
+class OracleModel(object):
+    """Stand-in for the compiled Keras model: train_on_batch / evaluate."""
+
+    def __init__(self, params, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64),
+                 dropout_seed=1024):
+        self.params = params
+        self.emb_trainable = emb_trainable
+        self.names = param_names(emb_trainable)
+        self.opt = Optimizer(params, self.names)
+        self.rate = float(dropout)
+        self.lr = lr
+        self.hidden = hidden
+        self.seed = dropout_seed
+        self.step = 0          # global inner-step counter (dropout stream + Adam t)
+        self.use_sgd = False
+
+    # weights in / out (maml.py:181-194, utils/tool.py:36-45)
+    def get_flat(self):
+        return flatten(self.params, self.names)
+
+    def set_flat(self, vec):
+        unflatten(vec, self.params, self.names)
+
+    def train_on_batch(self, uid, pid, dom, label):
+        B = uid.shape[0]
+        masks = train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else \
+            [np.ones((B, h), F32) for h in self.hidden]
+        loss, g, _ = loss_and_grads(self.params, uid, pid, dom, label, masks, self.rate, self.emb_trainable)
+        if self.use_sgd:
+            self.opt.sgd(self.params, g, self.lr)
+        else:
+            self.opt.adam(self.params, g, self.lr)
+        self.step += 1
+        return loss
+
+    def train_pass(self, data, perm, batch_size, max_steps=0):
+        """one pass over one domain's train split in `perm` order; final partial
+        batch kept (utils/dataset.py:25)."""
+        n = perm.shape[0]
+        n_step = -(-n // batch_size)
+        if max_steps > 0:
+            n_step = min(n_step, max_steps)
+        losses = []
+        for s in range(n_step):
+            idx = perm[s * batch_size:(s + 1) * batch_size]
+            losses.append(self.train_on_batch(data["uid"][idx], data["pid"][idx], data["domain"][idx],
+                                              data["label"][idx]))
+        return losses
+
+    def predict(self, uid, pid, dom):
+        p, _ = forward(self.params, uid, pid, dom, None)
+        return p
+
+    def evaluate(self, data, batch_size):
+        """Keras evaluate (A.6): loss = mean over batches of batch-mean loss (+reg),
+        predictions for the AUC over all rows in file order."""
+        n = data["uid"].shape[0]
+        reg = reg_loss(self.params)
+        batch_losses = []
+        preds = np.empty(n, F32)
+        for s in range(0, n, batch_size):
+            sl = slice(s, min(n, s + batch_size))
+            p = self.predict(data["uid"][sl], data["pid"][sl], data["domain"][sl])
+            preds[sl] = p
+            batch_losses.append(F32(np.mean(bce_per_row(p, data["label"][sl].astype(F32)), dtype=np.float64)) + reg)
+        return F32(np.mean(np.array(batch_losses, np.float64))), preds
