@@ -1,0 +1,193 @@
+/*
+ * mamdr_hip.h -- C ABI of libmamdr_hip.so: the MI355X (gfx950) hot path of MAMDR.
+ *
+ * The reference (RManLuo/MAMDR) has no FFI; its de-facto boundary is the handful
+ * of Keras/TF calls through which the meta-learning wrappers touch numerics
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface
+ * it replaces (file:line under /root/reference).  The reference-side binding a
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no torch/HIP types in signatures; `stream` is a hipStream_t passed
+ *    as void* (NULL = the null stream).
+ *  - every pointer named d_* is a DEVICE pointer owned by the caller and must
+ *    stay valid while bound; the library allocates only its private workspace.
+ *  - return 0 on success, negative MAMDR_E* on failure; mamdr_last_error() gives
+ *    the text (thread-local).  No internal threads; a context is not re-entrant.
+ *  - all launches are asynchronous on the context's stream; nothing here
+ *    synchronises the device except mamdr_profile_read().
+ */
+#ifndef MAMDR_HIP_H
+#define MAMDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAMDR_ABI_VERSION 1
+
+enum {
+    MAMDR_OK = 0,
+    MAMDR_EINVAL = -1,      /* bad argument / unsupported configuration */
+    MAMDR_ESTATE = -2,      /* call out of order (state/tables/data not bound) */
+    MAMDR_EHIP = -3,        /* a HIP runtime call failed */
+    MAMDR_ENOTBUILT = -4    /* feature named by the reference but not built in this round */
+};
+
+/* tower kinds: run.py:37-47 + model_zoo/DeepCTR/deepctr.py:24-50 name registry */
+enum { MAMDR_TOWER_MLP = 0, MAMDR_TOWER_DEEPFM = 1, MAMDR_TOWER_STAR = 2 };
+/* data splits: utils/dataset.py:79-92 */
+enum { MAMDR_SPLIT_TRAIN = 0, MAMDR_SPLIT_VAL = 1, MAMDR_SPLIT_TEST = 2 };
+/* optimisers: deepctr.py:55 (Adam) / specific_base_model.py:120, base_model.py:69 (SGD finetune) */
+enum { MAMDR_OPT_ADAM = 0, MAMDR_OPT_SGD = 1 };
+/* merged_method: model_zoo/specific_base_model.py:164-172 */
+enum { MAMDR_MERGE_PLUS = 0, MAMDR_MERGE_TIMES = 1 };
+/* segments of the flat trainable vector, in Keras trainable_weights order */
+enum {
+    MAMDR_SEG_USER_EMB = 0, MAMDR_SEG_ITEM_EMB = 1, MAMDR_SEG_DOMAIN_EMB = 2,
+    MAMDR_SEG_W0 = 3, MAMDR_SEG_W1 = 4, MAMDR_SEG_W2 = 5,
+    MAMDR_SEG_B0 = 6, MAMDR_SEG_B1 = 7, MAMDR_SEG_B2 = 8,
+    MAMDR_SEG_WO = 9, MAMDR_SEG_GB = 10, MAMDR_SEG_COUNT = 11
+};
+/* kernels whose device time can be profiled (mamdr_profile_*) */
+enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
+       MAMDR_KERNEL_EVAL = 3, MAMDR_KERNEL_GATHER = 4, MAMDR_KERNEL_COUNT = 5 };
+
+typedef struct mamdr_ctx mamdr_ctx;
+
+/* Model / step configuration.  Replaces the `model` + `train` sections consumed by
+ * DeepCTR.__init__/build_model (model_zoo/base_model.py:14-33,
+ * model_zoo/DeepCTR/deepctr.py:20-61,95-136). */
+typedef struct mamdr_config {
+    int32_t abi_version;     /* MAMDR_ABI_VERSION */
+    int32_t tower;           /* MAMDR_TOWER_* */
+    int32_t n_user;          /* dataset.n_uid, utils/dataset.py:50-52 */
+    int32_t n_item;          /* dataset.n_pid, utils/dataset.py:53-55 */
+    int32_t n_domain;        /* utils/dataset.py:63-65 */
+    int32_t emb_dim;         /* model.user_dim == item_dim == domain_dim (128) */
+    int32_t hidden[3];       /* model.hidden_dim (256,128,64) */
+    int32_t max_batch;       /* dataset.batch_size */
+    int32_t emb_trainable;   /* train.emb_trainable: user/item tables join the trainable vector */
+    float dropout;           /* model.dropout (rate) */
+    float l2_emb;            /* deepctr.py:118 l2_reg_embedding = 1e-5 */
+    float adam_beta1, adam_beta2, adam_eps; /* tf.train.AdamOptimizer defaults 0.9/0.999/1e-8 */
+} mamdr_config;
+
+const char* mamdr_last_error(void);
+int mamdr_abi_version(void);
+
+/* --- lifetime: replaces DeepCTR(dataset, config) / build_model + compile
+ *     (model_zoo/DeepCTR/deepctr.py:20-61). */
+int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out);
+int mamdr_destroy(mamdr_ctx* ctx);
+
+/* --- flat trainable vector ("meta parameters"): replaces
+ *     MAML._get_model_meta_parms with meta_parms ["all"] (model_zoo/maml.py:153-179).
+ *     mamdr_param_count = number of floats of the flat vector INCLUDING alignment
+ *     padding (padding elements stay 0).  Layout per segment via mamdr_param_segment;
+ *     a segment absent from the vector (frozen tables) reports count 0. */
+int64_t mamdr_param_count(const mamdr_ctx* ctx);
+int mamdr_param_segment(const mamdr_ctx* ctx, int seg, int64_t* offset, int64_t* count);
+
+/* Bind the live model state (caller-owned device memory, mamdr_param_count floats
+ * each): weights, Adam m, Adam v.  Replaces the TF variables + optimizer slots
+ * created at deepctr.py:55-60.  Adam slots are NOT reset by weight assignment
+ * (SURVEY A.5); mamdr_optimizer_reset zeroes m, v and the step count. */
+int mamdr_bind_state(mamdr_ctx* ctx, float* d_params, float* d_adam_m, float* d_adam_v);
+int mamdr_optimizer_reset(mamdr_ctx* ctx);
+int64_t mamdr_optimizer_steps(const mamdr_ctx* ctx);
+
+/* Bind the frozen user / item tables (row-major [rows, emb_dim] fp32).  Replaces
+ * DeepCTR.build_emb with a Constant initializer, trainable=False
+ * (deepctr.py:104-116).  seg = MAMDR_SEG_USER_EMB or MAMDR_SEG_ITEM_EMB.  With
+ * emb_trainable the tables live inside the flat vector and this is an error. */
+int mamdr_bind_table(mamdr_ctx* ctx, int seg, const float* d_rows, int64_t n_rows);
+
+/* Bind one domain's split: int32 uid/pid/domain columns and fp32 label column of
+ * n rows, in file order.  Replaces get_dataset / make_csv_dataset + expand_dim
+ * (utils/dataset.py:12-38,79-92): columns uid,pid,domain,label. */
+int mamdr_bind_domain_data(mamdr_ctx* ctx, int domain, int split, const int32_t* d_uid,
+                           const int32_t* d_pid, const int32_t* d_domain, const float* d_label,
+                           int64_t n_rows);
+
+/* Run n_steps consecutive inner optimisation steps ("domain-steps") on one
+ * domain's TRAIN split, entirely device-side.  Replaces the loops
+ *   for step in range(train_step): model.train_on_batch(train_iter)
+ * (model_zoo/mamdr.py:85-86,96-97, domain_negotiation.py:71-72, reptile.py:69-70)
+ * and model.fit(iter, steps_per_epoch=n) (mamdr.py:54, deepctr.py:76).
+ *   d_perm     row order of this pass (the shuffled iterator, utils/dataset.py:27-37),
+ *              n_rows int32, or NULL for file order
+ *   first_step first batch index within the pass; batch s covers
+ *              perm[s*batch .. min(n_rows,(s+1)*batch))  (final partial batch kept,
+ *              utils/dataset.py:25)
+ *   dropout_seed seed of the counter-based dropout stream (step index = the
+ *              context's global inner-step counter)
+ *   d_loss_out optional device array of n_steps floats: total loss per step
+ *              (BCE mean + regularisers), what train_on_batch returns as `loss`. */
+int mamdr_train_steps(mamdr_ctx* ctx, int domain, const int32_t* d_perm, int64_t first_step,
+                      int64_t n_steps, int32_t batch, uint32_t dropout_seed, int32_t optimizer,
+                      float lr, float* d_loss_out);
+
+/* Evaluate one domain's split with the live weights, dropout off.  Replaces
+ * model.evaluate(data, steps=n_step) (model_zoo/base_model.py:131,
+ * specific_base_model.py:84).
+ *   d_loss_out  1 float: mean over batches of the batch-mean loss (+ regularisers)
+ *   d_hist      2*501 uint32 (zeroed by this call): d_hist[c*501 + k] = number of
+ *               rows with (label != 0) == c whose prediction exceeds exactly k of
+ *               the 500 AUC thresholds (utils/auc.py:118-126).  The confusion
+ *               counts of utils/metrics_utils.py:297-354 are suffix sums of it.
+ *   d_pred_out  optional n_rows floats: predictions in file order. */
+int mamdr_eval_domain(mamdr_ctx* ctx, int domain, int split, int32_t batch, float* d_loss_out,
+                      uint32_t* d_hist, float* d_pred_out);
+
+/* Standalone embedding gather (K1 of SURVEY 2.2): out[r] = [U[uid]|I[pid]|Dm[dom]]
+ * for n rows of a bound split in d_perm order.  Same code path the step kernel
+ * uses for its tiles; exported for parity tests and bandwidth measurement. */
+int mamdr_gather_rows(mamdr_ctx* ctx, int domain, int split, const int32_t* d_perm,
+                      int64_t first_row, int64_t n_rows, float* d_out);
+
+/* --- outer (meta) updates on flat vectors; stateless, any stream.  Each op is
+ *     evaluated with one fp32 rounding per arithmetic step in the reference's
+ *     order (no FMA contraction) and matches its numpy result bit-for-bit.
+ *
+ * dst[i] += (a[i] - b[i]) * scale
+ *   DN / Reptile: model_zoo/domain_negotiation.py:118-123, reptile.py:127-132
+ *   MAMDR:        model_zoo/mamdr.py:173-180 (b = merged or dst itself) */
+int mamdr_interp(float* d_dst, const float* d_a, const float* d_b, float scale, int64_t n,
+                 void* stream);
+/* dst[i] = theta[i] + phi[i]  or  theta[i] * phi[i]  (specific_base_model.py:164-172) */
+int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t mode, int64_t n,
+                void* stream);
+/* dst[i] = a[i] - b[i]   (mamdr.py:168-171) */
+int mamdr_sub(float* d_dst, const float* d_a, const float* d_b, int64_t n, void* stream);
+/* acc[i] += (a[i] - b[i]) [* shared[i]] / divisor   (reptile.py:134-137 with shared NULL,
+ * divisor 1; mamdr.py:182-191) */
+int mamdr_accumulate(float* d_acc, const float* d_a, const float* d_b, const float* d_shared,
+                     float divisor, int64_t n, void* stream);
+/* dst[i] += acc[i] / divisor * scale; acc[i] = 0   (mamdr.py:193-196; reptile.py:139-142
+ * with divisor <= 0 meaning "no division") */
+int mamdr_apply_accumulated(float* d_dst, float* d_acc, float divisor, float scale, int64_t n,
+                            void* stream);
+/* dst[i] = src[i]: SetVarOp.__call__ / K.batch_get_value without the host round
+ * trip (utils/tool.py:36-45, maml.py:189-194) */
+int mamdr_copy(float* d_dst, const float* d_src, int64_t n, void* stream);
+
+/* --- host-side helper: tf.data shuffle(buffer_size) order of range(n)
+ *     (utils/dataset.py:27-37), splitmix64-driven; writes n int32 to HOST memory. */
+int mamdr_shuffle_perm(int64_t n, int64_t buffer_size, uint64_t seed, int32_t* h_out);
+
+/* --- profiling: per-kernel device time from HIP events on the context's stream.
+ *     enable != 0 brackets every launch of the listed kernels with events.
+ *     mamdr_profile_read synchronises the stream, returns the summed milliseconds
+ *     and launch count since the last reset. */
+int mamdr_profile_enable(mamdr_ctx* ctx, int32_t enable);
+int mamdr_profile_reset(mamdr_ctx* ctx);
+int mamdr_profile_read(mamdr_ctx* ctx, int32_t kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAMDR_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libmamdr_hip.so (C ABI: include/mamdr_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a symbol is absent
+the import of the product path fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
+
+ABI_VERSION = 1
+OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
+TOWER_MLP, TOWER_DEEPFM, TOWER_STAR = 0, 1, 2
+SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
+OPT_ADAM, OPT_SGD = 0, 1
+MERGE_PLUS, MERGE_TIMES = 0, 1
+(SEG_USER_EMB, SEG_ITEM_EMB, SEG_DOMAIN_EMB, SEG_W0, SEG_W1, SEG_W2, SEG_B0, SEG_B1, SEG_B2, SEG_WO,
+ SEG_GB) = range(11)
+SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
+KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER = range(5)
+KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather")
+
+
+class MamdrError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, "libmamdr_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+class NotBuiltError(MamdrError, NotImplementedError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("tower", C.c_int32), ("n_user", C.c_int32), ("n_item", C.c_int32),
+        ("n_domain", C.c_int32), ("emb_dim", C.c_int32), ("hidden", C.c_int32 * 3), ("max_batch", C.c_int32),
+        ("emb_trainable", C.c_int32), ("dropout", C.c_float), ("l2_emb", C.c_float),
+        ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+    ]
+
+
+_VP, _I32, _I64, _U32, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/mamdr_hip.h declares
+SIGNATURES = {
+    "mamdr_last_error": (C.c_char_p, []),
+    "mamdr_abi_version": (C.c_int, []),
+    "mamdr_create": (C.c_int, [C.POINTER(Config), _VP, C.POINTER(_VP)]),
+    "mamdr_destroy": (C.c_int, [_VP]),
+    "mamdr_param_count": (_I64, [_VP]),
+    "mamdr_param_segment": (C.c_int, [_VP, C.c_int, C.POINTER(_I64), C.POINTER(_I64)]),
+    "mamdr_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "mamdr_optimizer_reset": (C.c_int, [_VP]),
+    "mamdr_optimizer_steps": (_I64, [_VP]),
+    "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
+    "mamdr_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),
+    "mamdr_train_steps": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
+    "mamdr_eval_domain": (C.c_int, [_VP, C.c_int, C.c_int, _I32, _VP, _VP, _VP]),
+    "mamdr_gather_rows": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _I64, _I64, _VP]),
+    "mamdr_interp": (C.c_int, [_VP, _VP, _VP, _F, _I64, _VP]),
+    "mamdr_merge": (C.c_int, [_VP, _VP, _VP, _I32, _I64, _VP]),
+    "mamdr_sub": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
+    "mamdr_accumulate": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I64, _VP]),
+    "mamdr_apply_accumulated": (C.c_int, [_VP, _VP, _F, _F, _I64, _VP]),
+    "mamdr_copy": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "mamdr_shuffle_perm": (C.c_int, [_I64, _I64, _U64, _VP]),
+    "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
+    "mamdr_profile_reset": (C.c_int, [_VP]),
+    "mamdr_profile_read": (C.c_int, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and type every entry point. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the MAMDR hot path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mamdr_abi_version() != ABI_VERSION:
+        raise ImportError("libmamdr_hip.so ABI %d != binding ABI %d" % (lib.mamdr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != OK:
+        text = load().mamdr_last_error().decode("utf-8", "replace")
+        if code == ENOTBUILT:
+            raise NotBuiltError(code, text)
+        raise MamdrError(code, text)
+    return code

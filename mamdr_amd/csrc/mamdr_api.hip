@@ -1,0 +1,641 @@
+// C ABI of libmamdr_hip.so (declared in include/mamdr_hip.h).
+//
+// Host-side state is tiny: bound pointers, the Adam step count with its fp32
+// running beta powers (TF keeps them as beta1_power / beta2_power variables), the
+// global inner-step counter that indexes the dropout stream, and a private
+// workspace sized for max_batch.  Everything numeric runs in the kernels of
+// step_kernels.hip / outer_kernels.hip on the context's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mamdr_hip.h"
+#include "mamdr_kernels.h"
+
+using namespace mamdr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(MAMDR_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct SplitData {
+    const int32_t* uid = nullptr;
+    const int32_t* pid = nullptr;
+    const int32_t* dom = nullptr;
+    const float* label = nullptr;
+    int64_t n = 0;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mamdr_ctx {
+    mamdr_config cfg;
+    hipStream_t stream = nullptr;
+    DenseLayout L;
+    int64_t table_floats = 0;   // trainable user+item floats in front of the dense block
+    int64_t n_params = 0;       // floats of the flat vector (incl. padding)
+    // bound state
+    float* params = nullptr;
+    float* adam_m = nullptr;
+    float* adam_v = nullptr;
+    const float* user_tab = nullptr;
+    const float* item_tab = nullptr;
+    std::vector<SplitData> data;   // [domain*3 + split]
+    // optimiser / stream counters (host side)
+    int64_t adam_t = 0;
+    float b1p = 1.0f, b2p = 1.0f;
+    uint32_t global_step = 0;
+    // workspace
+    int rows_pad_max = 0;
+    float* acts = nullptr;
+    float* dz = nullptr;
+    float* dlogit = nullptr;
+    float* dxe = nullptr;
+    int32_t* domrow = nullptr;
+    float* loss_part = nullptr;     // train: per tile of a batch
+    float* eval_part = nullptr;     // eval: per tile of a split (grown on bind)
+    int64_t eval_part_cap = 0;
+    float* slabs = nullptr;
+    int max_groups = 16;
+    TileDesc* tiles = nullptr;
+    int n_tiles = 0;
+    float* thresholds = nullptr;
+    float* frozen_sumsq = nullptr;  // [2]
+    float* sumsq_partials = nullptr;
+    // profiling
+    bool profile = false;
+    std::vector<EventPair> ev[MAMDR_KERNEL_COUNT];
+};
+
+namespace {
+
+std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain) {
+    std::vector<TileDesc> t;
+    struct G { int a_off, M, b_off, N, dst; };
+    // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
+    const G gemms[3] = {{0, XDIM, 0, H1, L.w0}, {XDIM, H1, H1, H2, L.w1}, {XDIM + H1, H2, H1 + H2, H3, L.w2}};
+    for (const G& g : gemms)
+        for (int m0 = 0; m0 < g.M; m0 += 32)
+            for (int n0 = 0; n0 < g.N; n0 += 32)
+                t.push_back(TileDesc{0, g.a_off + m0, 0, g.b_off + n0, g.dst + m0 * g.N + n0, g.N, 32, 32});
+    // biases = column sums of dz (A = ones in row 0)
+    const int boff[3] = {L.b0, L.b1, L.b2}, bn[3] = {H1, H2, H3}, zoff[3] = {0, H1, H1 + H2};
+    for (int l = 0; l < 3; ++l)
+        for (int n0 = 0; n0 < bn[l]; n0 += 32) t.push_back(TileDesc{1, 0, 0, zoff[l] + n0, boff[l] + n0, 0, 1, 32});
+    // output unit: dwo = h3^T dlogit, dgb = sum dlogit
+    for (int m0 = 0; m0 < H3; m0 += 32) t.push_back(TileDesc{0, XDIM + H1 + H2 + m0, 1, 0, L.wo + m0, 1, 32, 1});
+    t.push_back(TileDesc{1, 0, 1, 0, L.gb, 0, 1, 1});
+    // domain table: dDm = onehot(domain)^T dxe  (segmented sum, fixed order)
+    for (int m0 = 0; m0 < n_domain; m0 += 32)
+        for (int n0 = 0; n0 < EMB; n0 += 32) {
+            const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
+            t.push_back(TileDesc{2, m0, 2, n0, L.dm + m0 * EMB + n0, EMB, mv, 32});
+        }
+    return t;
+}
+
+int check_ctx(const mamdr_ctx* c) {
+    if (!c) return fail(MAMDR_EINVAL, "null context");
+    return MAMDR_OK;
+}
+
+SplitData* split_of(mamdr_ctx* c, int domain, int split) {
+    if (domain < 0 || domain >= c->cfg.n_domain || split < 0 || split > 2) return nullptr;
+    return &c->data[(size_t)domain * 3 + split];
+}
+
+struct Prof {
+    mamdr_ctx* c;
+    int k;
+    EventPair e{nullptr, nullptr};
+    Prof(mamdr_ctx* c_, int k_) : c(c_), k(k_) {
+        if (c->profile && c->ev[k].size() < 200000) {
+            hipEventCreate(&e.a);
+            hipEventCreate(&e.b);
+            hipEventRecord(e.a, c->stream);
+        }
+    }
+    ~Prof() {
+        if (e.a) {
+            hipEventRecord(e.b, c->stream);
+            c->ev[k].push_back(e);
+        }
+    }
+};
+
+void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
+    memset(&a, 0, sizeof(a));
+    a.user_tab = c->cfg.emb_trainable ? c->params : c->user_tab;
+    a.item_tab = c->cfg.emb_trainable ? c->params + (size_t)c->cfg.n_user * EMB : c->item_tab;
+    a.dense = c->params + c->table_floats;
+    a.L = c->L;
+    a.n_user = c->cfg.n_user;
+    a.n_item = c->cfg.n_item;
+    a.n_domain = c->cfg.n_domain;
+    a.uid = d.uid;
+    a.pid = d.pid;
+    a.dom = d.dom;
+    a.label = d.label;
+    a.n_rows_split = d.n;
+    a.thresholds = c->thresholds;
+}
+
+int ready(const mamdr_ctx* c) {
+    if (!c->params) return fail(MAMDR_ESTATE, "mamdr_bind_state has not been called");
+    if (!c->cfg.emb_trainable && (!c->user_tab || !c->item_tab))
+        return fail(MAMDR_ESTATE, "frozen user/item tables are not bound (mamdr_bind_table)");
+    return MAMDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mamdr_last_error(void) { return g_err; }
+int mamdr_abi_version(void) { return MAMDR_ABI_VERSION; }
+
+int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
+    if (!cfg || !out) return fail(MAMDR_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != MAMDR_ABI_VERSION)
+        return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
+    if (cfg->tower != MAMDR_TOWER_MLP)
+        return fail(MAMDR_ENOTBUILT, "tower kind %d is not built yet (only the mlp tower is)", cfg->tower);
+    if (cfg->emb_trainable)
+        return fail(MAMDR_ENOTBUILT, "emb_trainable=true (trainable user/item tables) is not built yet");
+    if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
+        return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
+                    cfg->emb_dim, cfg->hidden[0], cfg->hidden[1], cfg->hidden[2]);
+    if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0)
+        return fail(MAMDR_EINVAL, "n_user/n_item/n_domain must be positive");
+    if (cfg->max_batch <= 0 || cfg->max_batch % TILE_ROWS != 0)
+        return fail(MAMDR_EINVAL, "max_batch must be a positive multiple of %d", TILE_ROWS);
+    if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
+
+    mamdr_ctx* c = new (std::nothrow) mamdr_ctx();
+    if (!c) return fail(MAMDR_EINVAL, "out of host memory");
+    c->cfg = *cfg;
+    c->stream = (hipStream_t)stream;
+    c->L = DenseLayout::make(cfg->n_domain);
+    c->table_floats = cfg->emb_trainable ? ((int64_t)cfg->n_user + cfg->n_item) * EMB : 0;
+    c->n_params = c->table_floats + c->L.alloc;
+    c->data.resize((size_t)cfg->n_domain * 3);
+    c->rows_pad_max = cfg->max_batch;
+
+    const size_t rp = (size_t)c->rows_pad_max;
+    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain);
+    c->n_tiles = (int)tiles.size();
+    float thr[500];
+    thr[0] = (float)(0.0 - 1e-7);
+    for (int i = 0; i < 498; ++i) thr[i + 1] = (float)((double)(i + 1) * 1.0 / (double)(500 - 1));
+    thr[499] = (float)(1.0 + 1e-7);
+
+#define ALLOC(ptr, bytes)                                                        \
+    do {                                                                         \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                      \
+        if (e_ != hipSuccess) {                                                  \
+            mamdr_destroy(c);                                                    \
+            return fail(MAMDR_EHIP, "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                                        \
+    } while (0)
+    ALLOC(c->acts, rp * ACT_LD * sizeof(float));
+    ALLOC(c->dz, rp * DZ_LD * sizeof(float));
+    ALLOC(c->dlogit, rp * sizeof(float));
+    ALLOC(c->dxe, rp * EMB * sizeof(float));
+    ALLOC(c->domrow, rp * sizeof(int32_t));
+    ALLOC(c->loss_part, (rp / TILE_ROWS) * sizeof(float));
+    ALLOC(c->slabs, (size_t)c->max_groups * c->L.alloc * sizeof(float));
+    ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
+    ALLOC(c->thresholds, sizeof(thr));
+    ALLOC(c->frozen_sumsq, 2 * sizeof(float));
+    ALLOC(c->sumsq_partials, 1024 * sizeof(float));
+#undef ALLOC
+    hipError_t e = hipMemsetAsync(c->slabs, 0, (size_t)c->max_groups * c->L.alloc * sizeof(float), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->frozen_sumsq, 0, 2 * sizeof(float), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->thresholds, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // host staging buffers go out of scope
+    if (e != hipSuccess) {
+        mamdr_destroy(c);
+        return fail(MAMDR_EHIP, "workspace initialisation: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MAMDR_OK;
+}
+
+int mamdr_destroy(mamdr_ctx* c) {
+    if (!c) return MAMDR_OK;
+    for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k)
+        for (EventPair& p : c->ev[k]) {
+            hipEventDestroy(p.a);
+            hipEventDestroy(p.b);
+        }
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->dxe, c->domrow, c->loss_part, c->eval_part, c->slabs,
+                    c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete c;
+    return MAMDR_OK;
+}
+
+int64_t mamdr_param_count(const mamdr_ctx* c) { return c ? c->n_params : 0; }
+
+int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* count) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (!offset || !count) return fail(MAMDR_EINVAL, "null argument");
+    const DenseLayout& L = c->L;
+    const int64_t base = c->table_floats;
+    int64_t off = 0, cnt = 0;
+    switch (seg) {
+        case MAMDR_SEG_USER_EMB: off = 0; cnt = c->cfg.emb_trainable ? (int64_t)c->cfg.n_user * EMB : 0; break;
+        case MAMDR_SEG_ITEM_EMB:
+            off = c->cfg.emb_trainable ? (int64_t)c->cfg.n_user * EMB : 0;
+            cnt = c->cfg.emb_trainable ? (int64_t)c->cfg.n_item * EMB : 0;
+            break;
+        case MAMDR_SEG_DOMAIN_EMB: off = base + L.dm; cnt = (int64_t)c->cfg.n_domain * EMB; break;
+        case MAMDR_SEG_W0: off = base + L.w0; cnt = XDIM * H1; break;
+        case MAMDR_SEG_W1: off = base + L.w1; cnt = H1 * H2; break;
+        case MAMDR_SEG_W2: off = base + L.w2; cnt = H2 * H3; break;
+        case MAMDR_SEG_B0: off = base + L.b0; cnt = H1; break;
+        case MAMDR_SEG_B1: off = base + L.b1; cnt = H2; break;
+        case MAMDR_SEG_B2: off = base + L.b2; cnt = H3; break;
+        case MAMDR_SEG_WO: off = base + L.wo; cnt = H3; break;
+        case MAMDR_SEG_GB: off = base + L.gb; cnt = 1; break;
+        default: return fail(MAMDR_EINVAL, "unknown segment %d", seg);
+    }
+    *offset = off;
+    *count = cnt;
+    return MAMDR_OK;
+}
+
+int mamdr_bind_state(mamdr_ctx* c, float* d_params, float* d_adam_m, float* d_adam_v) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (!d_params || !d_adam_m || !d_adam_v) return fail(MAMDR_EINVAL, "null state pointer");
+    if (((uintptr_t)d_params | (uintptr_t)d_adam_m | (uintptr_t)d_adam_v) & 15)
+        return fail(MAMDR_EINVAL, "state pointers must be 16-byte aligned");
+    c->params = d_params;
+    c->adam_m = d_adam_m;
+    c->adam_v = d_adam_v;
+    return MAMDR_OK;
+}
+
+int mamdr_optimizer_reset(mamdr_ctx* c) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (!c->adam_m) return fail(MAMDR_ESTATE, "mamdr_bind_state has not been called");
+    HIP_TRY(hipMemsetAsync(c->adam_m, 0, (size_t)c->n_params * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->adam_v, 0, (size_t)c->n_params * sizeof(float), c->stream));
+    c->adam_t = 0;
+    c->b1p = 1.0f;
+    c->b2p = 1.0f;
+    return MAMDR_OK;
+}
+
+int64_t mamdr_optimizer_steps(const mamdr_ctx* c) { return c ? c->adam_t : 0; }
+
+int mamdr_bind_table(mamdr_ctx* c, int seg, const float* d_rows, int64_t n_rows) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (c->cfg.emb_trainable) return fail(MAMDR_ESTATE, "tables are trainable: they live in the flat vector");
+    if (!d_rows || ((uintptr_t)d_rows & 15)) return fail(MAMDR_EINVAL, "table pointer null or not 16-byte aligned");
+    if (seg == MAMDR_SEG_USER_EMB) {
+        if (n_rows != c->cfg.n_user) return fail(MAMDR_EINVAL, "user table has %lld rows, config says %d", (long long)n_rows, c->cfg.n_user);
+        c->user_tab = d_rows;
+        launch_sumsq(d_rows, n_rows * EMB, c->sumsq_partials, c->frozen_sumsq + 0, c->stream);
+    } else if (seg == MAMDR_SEG_ITEM_EMB) {
+        if (n_rows != c->cfg.n_item) return fail(MAMDR_EINVAL, "item table has %lld rows, config says %d", (long long)n_rows, c->cfg.n_item);
+        c->item_tab = d_rows;
+        launch_sumsq(d_rows, n_rows * EMB, c->sumsq_partials, c->frozen_sumsq + 1, c->stream);
+    } else {
+        return fail(MAMDR_EINVAL, "segment %d is not a bindable table", seg);
+    }
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+
+int mamdr_bind_domain_data(mamdr_ctx* c, int domain, int split, const int32_t* d_uid, const int32_t* d_pid,
+                           const int32_t* d_domain, const float* d_label, int64_t n_rows) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    SplitData* d = split_of(c, domain, split);
+    if (!d) return fail(MAMDR_EINVAL, "domain %d / split %d out of range", domain, split);
+    if (n_rows < 0 || n_rows > 0x7fffffff) return fail(MAMDR_EINVAL, "n_rows out of range");
+    if (n_rows > 0 && (!d_uid || !d_pid || !d_domain || !d_label)) return fail(MAMDR_EINVAL, "null column pointer");
+    d->uid = d_uid;
+    d->pid = d_pid;
+    d->dom = d_domain;
+    d->label = d_label;
+    d->n = n_rows;
+    const int64_t tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    if (tiles > c->eval_part_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->eval_part) HIP_TRY(hipFree(c->eval_part));
+        c->eval_part = nullptr;
+        HIP_TRY(hipMalloc((void**)&c->eval_part, (size_t)tiles * sizeof(float)));
+        c->eval_part_cap = tiles;
+    }
+    return MAMDR_OK;
+}
+
+int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t first_step, int64_t n_steps,
+                      int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr, float* d_loss_out) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (ready(c)) return MAMDR_ESTATE;
+    SplitData* d = split_of(c, domain, MAMDR_SPLIT_TRAIN);
+    if (!d || !d->uid) return fail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
+    if (batch <= 0 || batch > c->cfg.max_batch) return fail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, c->cfg.max_batch);
+    if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD) return fail(MAMDR_EINVAL, "unknown optimizer %d", optimizer);
+    if (first_step < 0 || n_steps < 0) return fail(MAMDR_EINVAL, "negative step range");
+    const int64_t pass_steps = (d->n + batch - 1) / batch;
+    if (first_step + n_steps > pass_steps)
+        return fail(MAMDR_EINVAL, "steps [%lld,%lld) exceed the %lld batches of domain %d", (long long)first_step,
+                    (long long)(first_step + n_steps), (long long)pass_steps, domain);
+
+    const float rate = c->cfg.dropout;
+    double thr = (double)rate * 4294967296.0;
+    const uint32_t drop_thresh = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(int64_t)thr;
+    const float keep_scale = (float)(1.0 / (1.0 - (double)rate));
+    const float omb1 = 1.0f - c->cfg.adam_beta1, omb2 = 1.0f - c->cfg.adam_beta2;
+
+    for (int64_t s = 0; s < n_steps; ++s) {
+        const int64_t row_base = (first_step + s) * batch;
+        const int rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
+        const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+
+        TowerArgs ta;
+        fill_tower_common(c, *d, ta);
+        ta.perm = d_perm;
+        ta.row_base = row_base;
+        ta.rows = rows;
+        ta.batch = rows;
+        ta.seed = dropout_seed;
+        ta.step = c->global_step;
+        ta.drop_thresh = drop_thresh;
+        ta.keep_scale = keep_scale;
+        ta.use_dropout = rate > 0.f ? 1 : 0;
+        ta.acts = c->acts;
+        ta.dz = c->dz;
+        ta.dlogit = c->dlogit;
+        ta.dxe = c->dxe;
+        ta.domrow = c->domrow;
+        ta.loss_part = c->loss_part;
+        {
+            Prof p(c, MAMDR_KERNEL_FWD_BWD);
+            launch_tower_train(ta, c->stream);
+        }
+
+        WgradArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.acts = c->acts;
+        wa.dz = c->dz;
+        wa.dlogit = c->dlogit;
+        wa.dxe = c->dxe;
+        wa.domrow = c->domrow;
+        wa.tiles = c->tiles;
+        wa.n_tiles = c->n_tiles;
+        wa.rows_pad = rows_pad;
+        int rpg = rows_pad <= 2048 ? 256 : 512;
+        int groups = (rows_pad + rpg - 1) / rpg;
+        if (groups > c->max_groups) {
+            rpg = ((rows_pad + c->max_groups - 1) / c->max_groups + 7) / 8 * 8;
+            groups = (rows_pad + rpg - 1) / rpg;
+        }
+        wa.n_groups = groups;
+        wa.rows_per_group = rpg;
+        wa.slabs = c->slabs;
+        wa.slab_ld = c->L.alloc;
+        wa.loss_part = c->loss_part;
+        wa.n_loss_tiles = rows_pad / TILE_ROWS;
+        wa.rows = rows;
+        wa.dense = c->params + c->table_floats;
+        wa.dm_count = c->cfg.n_domain * EMB;
+        wa.l2_emb = c->cfg.l2_emb;
+        wa.frozen_sumsq = c->frozen_sumsq;
+        wa.loss_out = d_loss_out ? d_loss_out + s : nullptr;
+        {
+            Prof p(c, MAMDR_KERNEL_WGRAD);
+            launch_wgrad(wa, c->stream);
+        }
+
+        UpdateArgs ua;
+        memset(&ua, 0, sizeof(ua));
+        ua.p = c->params + c->table_floats;
+        ua.m = c->adam_m + c->table_floats;
+        ua.v = c->adam_v + c->table_floats;
+        ua.slabs = c->slabs;
+        ua.n_groups = groups;
+        ua.slab_ld = c->L.alloc;
+        ua.count4 = c->L.alloc / 4;
+        ua.dm_count = c->cfg.n_domain * EMB;
+        ua.two_l2 = 2.0f * c->cfg.l2_emb;
+        ua.optimizer = optimizer;
+        if (optimizer == MAMDR_OPT_ADAM) {
+            c->adam_t += 1;
+            c->b1p = c->b1p * c->cfg.adam_beta1;
+            c->b2p = c->b2p * c->cfg.adam_beta2;
+            ua.alpha = lr * sqrtf(1.0f - c->b2p) / (1.0f - c->b1p);
+        } else {
+            ua.alpha = lr;
+        }
+        ua.omb1 = omb1;
+        ua.omb2 = omb2;
+        ua.eps = c->cfg.adam_eps;
+        {
+            Prof p(c, MAMDR_KERNEL_UPDATE);
+            launch_update(ua, c->stream);
+        }
+        c->global_step += 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+
+int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float* d_loss_out, uint32_t* d_hist,
+                      float* d_pred_out) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (ready(c)) return MAMDR_ESTATE;
+    SplitData* d = split_of(c, domain, split);
+    if (!d || !d->uid) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
+    if (!d_loss_out || !d_hist) return fail(MAMDR_EINVAL, "null output pointer");
+    if (batch <= 0 || batch % TILE_ROWS != 0) return fail(MAMDR_EINVAL, "eval batch must be a positive multiple of %d", TILE_ROWS);
+    if (d->n <= 0) return fail(MAMDR_EINVAL, "split %d of domain %d is empty", split, domain);
+    HIP_TRY(hipMemsetAsync(d_hist, 0, 2 * 501 * sizeof(uint32_t), c->stream));
+    TowerArgs ta;
+    fill_tower_common(c, *d, ta);
+    ta.perm = nullptr;
+    ta.row_base = 0;
+    ta.rows = (int)d->n;
+    ta.batch = batch;
+    ta.loss_part = c->eval_part;
+    ta.hist = d_hist;
+    ta.pred_out = d_pred_out;
+    {
+        Prof p(c, MAMDR_KERNEL_EVAL);
+        launch_tower_eval(ta, c->stream);
+    }
+    launch_eval_finish(c->eval_part, d->n, batch, c->params + c->table_floats, c->cfg.n_domain * EMB, c->cfg.l2_emb,
+                       c->frozen_sumsq, d_loss_out, c->stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+
+int mamdr_gather_rows(mamdr_ctx* c, int domain, int split, const int32_t* d_perm, int64_t first_row,
+                      int64_t n_rows, float* d_out) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (ready(c)) return MAMDR_ESTATE;
+    SplitData* d = split_of(c, domain, split);
+    if (!d || !d->uid) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
+    if (!d_out) return fail(MAMDR_EINVAL, "null output pointer");
+    if (first_row < 0 || n_rows < 0 || first_row + n_rows > d->n) return fail(MAMDR_EINVAL, "row range outside the split");
+    if (n_rows == 0) return MAMDR_OK;
+    TowerArgs ta;
+    fill_tower_common(c, *d, ta);
+    ta.perm = d_perm;
+    ta.row_base = first_row;
+    ta.rows = (int)n_rows;
+    {
+        Prof p(c, MAMDR_KERNEL_GATHER);
+        launch_gather(ta, d_out, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+
+// ---- outer updates
+static int check_vec(const void* p, const char* name) {
+    if (!p) return fail(MAMDR_EINVAL, "%s is null", name);
+    if ((uintptr_t)p & 15) return fail(MAMDR_EINVAL, "%s is not 16-byte aligned", name);
+    return MAMDR_OK;
+}
+#define CHECK_VEC(p) do { if (check_vec((p), #p)) return MAMDR_EINVAL; } while (0)
+
+int mamdr_interp(float* d_dst, const float* d_a, const float* d_b, float scale, int64_t n, void* stream) {
+    CHECK_VEC(d_dst); CHECK_VEC(d_a); CHECK_VEC(d_b);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    launch_interp(d_dst, d_a, d_b, scale, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t mode, int64_t n, void* stream) {
+    CHECK_VEC(d_dst); CHECK_VEC(d_theta); CHECK_VEC(d_phi);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (mode != MAMDR_MERGE_PLUS && mode != MAMDR_MERGE_TIMES) return fail(MAMDR_EINVAL, "unknown merge mode %d", mode);
+    launch_merge(d_dst, d_theta, d_phi, mode, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+int mamdr_sub(float* d_dst, const float* d_a, const float* d_b, int64_t n, void* stream) {
+    CHECK_VEC(d_dst); CHECK_VEC(d_a); CHECK_VEC(d_b);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    launch_sub(d_dst, d_a, d_b, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+int mamdr_accumulate(float* d_acc, const float* d_a, const float* d_b, const float* d_shared, float divisor,
+                     int64_t n, void* stream) {
+    CHECK_VEC(d_acc); CHECK_VEC(d_a); CHECK_VEC(d_b);
+    if (d_shared && ((uintptr_t)d_shared & 15)) return fail(MAMDR_EINVAL, "d_shared is not 16-byte aligned");
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (divisor == 0.f) return fail(MAMDR_EINVAL, "divisor must be non-zero");
+    launch_accumulate(d_acc, d_a, d_b, d_shared, divisor, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+int mamdr_apply_accumulated(float* d_dst, float* d_acc, float divisor, float scale, int64_t n, void* stream) {
+    CHECK_VEC(d_dst); CHECK_VEC(d_acc);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    launch_apply_accumulated(d_dst, d_acc, divisor, scale, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+int mamdr_copy(float* d_dst, const float* d_src, int64_t n, void* stream) {
+    if (!d_dst || !d_src) return fail(MAMDR_EINVAL, "null pointer");
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MAMDR_OK;
+}
+
+// ---- host helper: tf.data shuffle-buffer order (restated in oracle/rng.py)
+int mamdr_shuffle_perm(int64_t n, int64_t buffer_size, uint64_t seed, int32_t* h_out) {
+    if (n < 0 || n > 0x7fffffff) return fail(MAMDR_EINVAL, "n out of range");
+    if (n == 0) return MAMDR_OK;
+    if (!h_out) return fail(MAMDR_EINVAL, "null output");
+    if (buffer_size < 1) buffer_size = 1;
+    int64_t filled = n < buffer_size ? n : buffer_size;
+    std::vector<int32_t> buf((size_t)filled);
+    for (int64_t i = 0; i < filled; ++i) buf[(size_t)i] = (int32_t)i;
+    int64_t next = filled;
+    uint64_t state = seed;
+    for (int64_t i = 0; i < n; ++i) {
+        state += 0x9E3779B97F4A7C15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const uint64_t j = ((z >> 32) * (uint64_t)filled) >> 32;
+        h_out[i] = buf[(size_t)j];
+        if (next < n) {
+            buf[(size_t)j] = (int32_t)next++;
+        } else {
+            buf[(size_t)j] = buf[(size_t)filled - 1];
+            --filled;
+        }
+    }
+    return MAMDR_OK;
+}
+
+// ---- profiling
+int mamdr_profile_enable(mamdr_ctx* c, int32_t enable) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    c->profile = enable != 0;
+    return MAMDR_OK;
+}
+int mamdr_profile_reset(mamdr_ctx* c) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k) {
+        for (EventPair& p : c->ev[k]) {
+            hipEventDestroy(p.a);
+            hipEventDestroy(p.b);
+        }
+        c->ev[k].clear();
+    }
+    return MAMDR_OK;
+}
+int mamdr_profile_read(mamdr_ctx* c, int32_t kernel, double* total_ms, int64_t* launches) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (kernel < 0 || kernel >= MAMDR_KERNEL_COUNT || !total_ms || !launches) return fail(MAMDR_EINVAL, "bad argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (EventPair& p : c->ev[kernel]) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)c->ev[kernel].size();
+    return MAMDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Device-side helpers shared by the MAMDR gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mamdr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- fixed architecture of the hot path (model_zoo/DeepCTR/deepctr.py:95-136 with
+//      the BASELINE configs: three 128-d embeddings -> 384 -> 256 -> 128 -> 64 -> 1)
+constexpr int EMB = 128;
+constexpr int XDIM = 3 * EMB;   // 384
+constexpr int H1 = 256;
+constexpr int H2 = 128;
+constexpr int H3 = 64;
+constexpr int ACT_LD = XDIM + H1 + H2 + H3;   // 832: [x | h1 | h2 | h3] per row
+constexpr int DZ_LD = H1 + H2 + H3;           // 448: [dz1 | dz2 | dz3] per row
+constexpr int TILE_ROWS = 16;                 // batch rows per workgroup in the step kernel
+
+// dense block of the flat trainable vector, relative to the domain table start
+struct DenseLayout {
+    int dm, w0, w1, w2, b0, b1, b2, wo, gb, count, alloc;
+    __host__ __device__ static DenseLayout make(int n_domain) {
+        DenseLayout L;
+        L.dm = 0;
+        L.w0 = n_domain * EMB;
+        L.w1 = L.w0 + XDIM * H1;
+        L.w2 = L.w1 + H1 * H2;
+        L.b0 = L.w2 + H2 * H3;
+        L.b1 = L.b0 + H1;
+        L.b2 = L.b1 + H2;
+        L.wo = L.b2 + H3;
+        L.gb = L.wo + H3;
+        L.count = L.gb + 1;
+        L.alloc = (L.count + 3) & ~3;
+        return L;
+    }
+};
+
+// ---- counter-based dropout stream (restated in oracle/rng.py)
+__host__ __device__ inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline uint32_t dropout_layer_key(uint32_t seed, uint32_t step, uint32_t layer) {
+    uint32_t k0 = fmix32(seed + 0x9E3779B9u * (step + 1u));
+    return fmix32(k0 ^ (0x85EBCA6Bu * (layer + 1u)));
+}
+__device__ __forceinline__ uint32_t mamdr_dropout_u32(uint32_t key, uint32_t elem) {
+    return fmix32(key + 0x9E3779B9u * elem);
+}
+
+#define MAMDR_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MAMDR_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+}  // namespace mamdr

@@ -1,0 +1,113 @@
+// Internal launch interface between the C ABI (mamdr_api.hip) and the kernel
+// translation units.  Not part of the public boundary (include/mamdr_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mamdr_device.h"
+
+namespace mamdr {
+
+// One launch of the fused tower kernel: gather -> MLP forward -> BCE -> (train:
+// backward activation chain) over a contiguous range of positions of one split.
+struct TowerArgs {
+    // tables and dense parameters
+    const float* user_tab;
+    const float* item_tab;
+    const float* dense;        // dense block base (domain table first)
+    DenseLayout L;
+    int n_user, n_item, n_domain;
+    // bound split columns
+    const int32_t* uid;
+    const int32_t* pid;
+    const int32_t* dom;
+    const float* label;
+    const int32_t* perm;       // nullable
+    int64_t row_base;          // position (in perm order) of row 0 of this launch
+    int64_t n_rows_split;      // rows in the bound split (for clamping)
+    int rows;                  // rows covered by this launch (train: rows of the batch)
+    int batch;                 // eval: batch size (loss is averaged per batch); train: == rows
+    // dropout stream
+    uint32_t seed, step, drop_thresh;
+    float keep_scale;
+    int use_dropout;
+    // train outputs (workspace)
+    float* acts;               // [rows_pad][ACT_LD]
+    float* dz;                 // [rows_pad][DZ_LD]
+    float* dlogit;             // [rows_pad]
+    float* dxe;                // [rows_pad][EMB]   d loss / d domain-embedding row
+    int32_t* domrow;           // [rows_pad]
+    float* loss_part;          // [tiles] sum of per-row BCE of the tile
+    // eval outputs
+    const float* thresholds;   // 500 fp32 AUC thresholds
+    uint32_t* hist;            // [2][501]
+    float* pred_out;           // nullable, [n_rows] in position order
+};
+
+// weight-gradient GEMMs (K = batch rows) + bias / output-layer / domain-table sums
+struct TileDesc {
+    int a_kind, a_off;         // 0: acts column block, 1: ones (row 0), 2: one-hot(domain) rows a_off..
+    int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0), 2: dxe column block
+    int dst_off, dst_ld;       // destination in the dense-block gradient slab
+    int m_valid, n_valid;      // valid rows / cols of the 32x32 tile
+};
+
+struct WgradArgs {
+    const float* acts;
+    const float* dz;
+    const float* dlogit;
+    const float* dxe;
+    const int32_t* domrow;
+    const TileDesc* tiles;
+    int n_tiles;
+    int rows_pad;              // batch rows rounded up to TILE_ROWS
+    int n_groups;              // K-split groups (one gradient slab each)
+    int rows_per_group;        // multiple of 8
+    float* slabs;              // [n_groups][slab_ld]
+    int slab_ld;
+    // loss of the step (optional)
+    const float* loss_part;
+    int n_loss_tiles;
+    int rows;                  // actual batch rows
+    const float* dense;        // for the domain-table regulariser
+    int dm_count;
+    float l2_emb;
+    const float* frozen_sumsq; // [2] sum of squares of frozen user / item tables (0 if trainable)
+    float* loss_out;           // nullable: 1 float
+};
+
+struct UpdateArgs {
+    float* p;                  // dense block of params
+    float* m;
+    float* v;
+    const float* slabs;
+    int n_groups;
+    int slab_ld;
+    int count4;                // float4 elements
+    int dm_count;              // elements [0, dm_count) get the 2*l2*p regulariser gradient
+    float two_l2;
+    int optimizer;             // 0 adam, 1 sgd
+    float alpha;               // adam: lr*sqrt(1-b2^t)/(1-b1^t); sgd: lr
+    float omb1, omb2, eps;
+};
+
+void launch_tower_train(const TowerArgs& a, hipStream_t s);
+void launch_tower_eval(const TowerArgs& a, hipStream_t s);
+void launch_eval_finish(const float* loss_part, int64_t n_rows, int batch, const float* dense, int dm_count,
+                        float l2_emb, const float* frozen_sumsq, float* loss_out, hipStream_t s);
+void launch_wgrad(const WgradArgs& a, hipStream_t s);
+void launch_update(const UpdateArgs& a, hipStream_t s);
+void launch_gather(const TowerArgs& a, float* out, hipStream_t s);
+void launch_sumsq(const float* x, int64_t n, float* partials /*>=1024 floats*/, float* out, hipStream_t s);
+
+size_t tower_lds_bytes();
+
+// outer_kernels.hip (compiled with -ffp-contract=off)
+void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s);
+void launch_merge(float* dst, const float* t, const float* p, int mode, int64_t n, hipStream_t s);
+void launch_sub(float* dst, const float* a, const float* b, int64_t n, hipStream_t s);
+void launch_accumulate(float* acc, const float* a, const float* b, const float* shared, float divisor, int64_t n,
+                       hipStream_t s);
+void launch_apply_accumulated(float* dst, float* acc, float divisor, float scale, int64_t n, hipStream_t s);
+
+}  // namespace mamdr

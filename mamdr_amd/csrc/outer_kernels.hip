@@ -1,0 +1,149 @@
+// Outer (meta) parameter updates as HBM-bound elementwise kernels for gfx950.
+//
+// The reference does these in numpy on the host (model_zoo/domain_negotiation.py:118-123,
+// reptile.py:127-142, mamdr.py:168-196, specific_base_model.py:164-172); every
+// arithmetic step there is a separately rounded fp32 op.  This file is compiled
+// with -ffp-contract=off and uses the __f*_rn intrinsics so that no multiply-add is
+// fused: results match numpy bit-for-bit.  16 B per lane, grid-stride, <= 2048 blocks.
+#include "mamdr_kernels.h"
+
+namespace mamdr {
+
+namespace {
+constexpr int BLOCK = 256;
+inline int grid_for(int64_t n4) {
+    int64_t b = (n4 + BLOCK - 1) / BLOCK;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// Apply F elementwise over n floats: float4 body + scalar tail, pointers 16-B aligned
+// (flat vectors are torch allocations) -- checked by the caller.
+template <typename F>
+__global__ __launch_bounds__(BLOCK) void k_elementwise(int64_t n, F f) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) f.vec(i);
+    const int64_t tail0 = n4 << 2;
+    for (int64_t i = tail0 + (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) f.one(i);
+}
+
+struct Interp {   // dst += (a - b) * scale
+    float* dst; const float* a; const float* b; float scale;
+    __device__ __forceinline__ float op(float d, float x, float y) const {
+        return __fadd_rn(d, __fmul_rn(__fsub_rn(x, y), scale));
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+        const f32x4 y = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 d = reinterpret_cast<f32x4*>(dst)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = op(d[c], x[c], y[c]);
+        reinterpret_cast<f32x4*>(dst)[i] = d;
+    }
+    __device__ __forceinline__ void one(int64_t i) const { dst[i] = op(dst[i], a[i], b[i]); }
+};
+
+template <int MODE>
+struct Merge {    // dst = t + p | t * p
+    float* dst; const float* t; const float* p;
+    __device__ __forceinline__ float op(float x, float y) const {
+        return MODE == 0 ? __fadd_rn(x, y) : __fmul_rn(x, y);
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        const f32x4 x = reinterpret_cast<const f32x4*>(t)[i];
+        const f32x4 y = reinterpret_cast<const f32x4*>(p)[i];
+        f32x4 d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = op(x[c], y[c]);
+        reinterpret_cast<f32x4*>(dst)[i] = d;
+    }
+    __device__ __forceinline__ void one(int64_t i) const { dst[i] = op(t[i], p[i]); }
+};
+
+struct Sub {      // dst = a - b
+    float* dst; const float* a; const float* b;
+    __device__ __forceinline__ void vec(int64_t i) const {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+        const f32x4 y = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = __fsub_rn(x[c], y[c]);
+        reinterpret_cast<f32x4*>(dst)[i] = d;
+    }
+    __device__ __forceinline__ void one(int64_t i) const { dst[i] = __fsub_rn(a[i], b[i]); }
+};
+
+template <bool SHARED>
+struct Accumulate {   // acc += (a - b) [* shared] / divisor
+    float* acc; const float* a; const float* b; const float* shared; float divisor;
+    __device__ __forceinline__ float op(float d, float x, float y, float s) const {
+        float g = __fsub_rn(x, y);
+        if (SHARED) g = __fmul_rn(g, s);
+        return __fadd_rn(d, __fdiv_rn(g, divisor));
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+        const f32x4 y = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (SHARED) s = reinterpret_cast<const f32x4*>(shared)[i];
+        f32x4 d = reinterpret_cast<f32x4*>(acc)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = op(d[c], x[c], y[c], s[c]);
+        reinterpret_cast<f32x4*>(acc)[i] = d;
+    }
+    __device__ __forceinline__ void one(int64_t i) const {
+        acc[i] = op(acc[i], a[i], b[i], SHARED ? shared[i] : 0.f);
+    }
+};
+
+template <bool DIVIDE>
+struct ApplyAcc {     // dst += acc [/ divisor] * scale; acc = 0
+    float* dst; float* acc; float divisor; float scale;
+    __device__ __forceinline__ float op(float d, float g) const {
+        if (DIVIDE) g = __fdiv_rn(g, divisor);
+        return __fadd_rn(d, __fmul_rn(g, scale));
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        const f32x4 g = reinterpret_cast<f32x4*>(acc)[i];
+        f32x4 d = reinterpret_cast<f32x4*>(dst)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = op(d[c], g[c]);
+        reinterpret_cast<f32x4*>(dst)[i] = d;
+        reinterpret_cast<f32x4*>(acc)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void one(int64_t i) const {
+        dst[i] = op(dst[i], acc[i]);
+        acc[i] = 0.f;
+    }
+};
+
+template <typename F>
+void run(int64_t n, const F& f, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_elementwise<F>, dim3(grid_for(n >> 2)), dim3(BLOCK), 0, s, n, f);
+}
+}  // namespace
+
+void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s) {
+    run(n, Interp{dst, a, b, scale}, s);
+}
+void launch_merge(float* dst, const float* t, const float* p, int mode, int64_t n, hipStream_t s) {
+    if (mode == 0) run(n, Merge<0>{dst, t, p}, s);
+    else run(n, Merge<1>{dst, t, p}, s);
+}
+void launch_sub(float* dst, const float* a, const float* b, int64_t n, hipStream_t s) {
+    run(n, Sub{dst, a, b}, s);
+}
+void launch_accumulate(float* acc, const float* a, const float* b, const float* shared, float divisor, int64_t n,
+                       hipStream_t s) {
+    if (shared) run(n, Accumulate<true>{acc, a, b, shared, divisor}, s);
+    else run(n, Accumulate<false>{acc, a, b, nullptr, divisor}, s);
+}
+void launch_apply_accumulated(float* dst, float* acc, float divisor, float scale, int64_t n, hipStream_t s) {
+    if (divisor > 0.f) run(n, ApplyAcc<true>{dst, acc, divisor, scale}, s);
+    else run(n, ApplyAcc<false>{dst, acc, 1.f, scale}, s);
+}
+
+}  // namespace mamdr

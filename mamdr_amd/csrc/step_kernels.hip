@@ -1,0 +1,563 @@
+// Inner-step kernels of the MAMDR hot path for gfx950 (MI355X).
+//
+//   k_tower<TRAIN>  one workgroup = 16 batch rows: embedding gather (coalesced 512-B
+//                   rows staged in LDS) -> 384-256-128-64-1 MLP on fp32 MFMA
+//                   (v_mfma_f32_16x16x4_f32, weights streamed from L2 with 16-B
+//                   loads, activations in LDS) -> sigmoid/BCE -> backward activation
+//                   chain (dz3, dz2, dz1, d domain-embedding row).
+//   k_wgrad         all weight-gradient contractions (K = batch rows) on
+//                   v_mfma_f32_32x32x2_f32, split-K over row groups, one partial
+//                   slab per group, fixed summation order (no float atomics).
+//   k_update        slab reduction + regulariser gradient + TF1 Adam / SGD.
+//
+// Replaces `model.train_on_batch` / `model.evaluate` of the compiled Keras model
+// (model_zoo/DeepCTR/deepctr.py:54-60,118-136; call sites model_zoo/mamdr.py:54,86,97).
+#include "mamdr_kernels.h"
+
+namespace mamdr {
+
+// ------------------------------------------------------------------ LDS map (floats)
+constexpr int XS_LD = XDIM + 4;   // 388: row stride = 4 (mod 64) banks -> b128 reads spread
+constexpr int H1_LD = H1 + 4;     // 260
+constexpr int H2_LD = H2 + 4;     // 132
+constexpr int H3_LD = H3 + 4;     // 68
+// The x tile is dead after layer 0; its region is reused by the backward chain:
+// dz3 (dead once dz2 exists) and dz1 share the front, dz2 sits behind them.
+constexpr int XS_OFF = 0;
+constexpr int DZ1S_OFF = XS_OFF;
+constexpr int DZ3S_OFF = XS_OFF;
+constexpr int DZ2S_OFF = XS_OFF + TILE_ROWS * H1_LD;                // 4160
+constexpr int XREGION = DZ2S_OFF + TILE_ROWS * H2_LD;               // 6272 >= 16*388
+constexpr int H1S_OFF = XS_OFF + XREGION;                           // 6272
+constexpr int H2S_OFF = H1S_OFF + TILE_ROWS * H1_LD;                // 10432
+constexpr int H3S_OFF = H2S_OFF + TILE_ROWS * H2_LD;                // 12544
+constexpr int ROWI_OFF = H3S_OFF + TILE_ROWS * H3_LD;               // 13632
+constexpr int LDS_FLOATS = ROWI_OFF + 8 * TILE_ROWS;                // 13760 floats = 55,040 B
+static_assert(XREGION >= TILE_ROWS * XS_LD, "x tile must fit in its region");
+static_assert(LDS_FLOATS * 4 <= 65536, "stay under the 64 KiB dynamic-LDS default");
+
+size_t tower_lds_bytes() { return LDS_FLOATS * sizeof(float); }
+
+template <int N> struct VecT;
+template <> struct VecT<4> { typedef f32x4 type; };
+template <> struct VecT<2> { typedef f32x2 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int TPW>
+__device__ __forceinline__ void load_b_rows(float (&b)[4][TPW], const float* __restrict__ p, int ld) {
+    typedef typename VecT<TPW>::type V;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        V v = *reinterpret_cast<const V*>(p + (size_t)s * ld);
+        if constexpr (TPW == 1) {
+            b[s][0] = v;
+        } else {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) b[s][t] = v[t];
+        }
+    }
+}
+
+template <int TPW>
+__device__ __forceinline__ void mfma_fwd_chunk(f32x4 (&acc)[TPW], const f32x4 a, const float (&b)[4][TPW]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b[s][t], acc[t]);
+}
+
+// H[16 x N] = relu(A[16 x K] . W[K x N] + bias) (* dropout).  Wave w owns N/4
+// consecutive columns; lane (j = lane & 15) owns TPW consecutive columns of them, so
+// one 4/8/16-byte load per k row feeds TPW MFMAs, and the k index inside each
+// 16-deep chunk is permuted identically for A and B (slot k' of sub-step s is
+// k = kk0 + 4 k' + s), which turns the A fragment into one ds_read_b128.
+template <int K, int N, int LDA, int LDO, bool TRAIN>
+__device__ __forceinline__ void fwd_layer(const float* __restrict__ W, const float* __restrict__ bias,
+                                          const float* As, float* Os, float* gout, uint32_t key,
+                                          uint32_t thresh, float scale, bool use_dropout, int row0) {
+    constexpr int TPW = N / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int ncol = w * (16 * TPW) + TPW * j;
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const float bv = bias[ncol + t];
+        acc[t] = (f32x4){bv, bv, bv, bv};
+    }
+    const float* wp = W + (size_t)(4 * kq) * N + ncol;
+    const float* ap = As + j * LDA + 4 * kq;
+    float b0[4][TPW], b1[4][TPW];
+    load_b_rows<TPW>(b0, wp, N);
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < K; kk0 += 32) {
+        load_b_rows<TPW>(b1, wp + (size_t)(kk0 + 16) * N, N);
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk0);
+        mfma_fwd_chunk<TPW>(acc, a, b0);
+        if (kk0 + 32 < K) load_b_rows<TPW>(b0, wp + (size_t)(kk0 + 32) * N, N);
+        a = *reinterpret_cast<const f32x4*>(ap + kk0 + 16);
+        mfma_fwd_chunk<TPW>(acc, a, b1);
+    }
+    typedef typename VecT<TPW>::type V;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+        float h[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            float z = fmaxf(acc[t][r], 0.0f);
+            if (TRAIN && use_dropout) {
+                const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(row0 + row) * (uint32_t)N + (uint32_t)(ncol + t));
+                z = (u >= thresh) ? z * scale : 0.0f;
+            }
+            h[t] = z;
+        }
+        V v;
+        if constexpr (TPW == 1) {
+            v = h[0];
+        } else {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) v[t] = h[t];
+        }
+        *reinterpret_cast<V*>(Os + row * LDO + ncol) = v;
+        if (TRAIN) *reinterpret_cast<V*>(gout + (size_t)row * ACT_LD + ncol) = v;
+    }
+}
+
+// dH[16 x N] = dZ[16 x K] . W^T, W stored [N][LDW] with the reduction index contiguous.
+// Lane (j, k') loads 16 B of row (n0 + 16 t + j) at k = kk0 + 4 k' .. +3: sub-step s uses
+// component s, the same k permutation as the A fragment.
+template <int K, int N, int LDW, int LDA, typename Epi>
+__device__ __forceinline__ void bwd_layer(const float* __restrict__ W, const float* As, Epi epi) {
+    constexpr int TPW = N / 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nbase = w * (16 * TPW);
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (size_t)(nbase + j) * LDW + 4 * kq;
+    const float* ap = As + j * LDA + 4 * kq;
+    f32x4 b0[TPW], b1[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) b0[t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t) * LDW);
+#pragma unroll 1
+    for (int kk0 = 0; kk0 < K; kk0 += 32) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+            b1[t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t) * LDW + kk0 + 16);
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b0[t][s], acc[t]);
+        if (kk0 + 32 < K) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                b0[t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t) * LDW + kk0 + 32);
+        }
+        a = *reinterpret_cast<const f32x4*>(ap + kk0 + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b1[t][s], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epi(4 * kq + r, nbase + 16 * t + j, acc[t][r]);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// row bookkeeping + embedding gather of one 16-row tile into LDS (and optionally global)
+__device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int r0, float* gx, int gx_ld) {
+    int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
+    float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;
+    const int tid = threadIdx.x;
+    if (tid < TILE_ROWS) {
+        const bool valid = (r0 + tid) < a.rows;
+        int64_t pos = a.row_base + r0 + tid;
+        int64_t src = 0;
+        if (valid) {
+            src = a.perm ? (int64_t)a.perm[pos] : pos;
+            if (src < 0) src = 0;
+            if (src >= a.n_rows_split) src = a.n_rows_split - 1;
+        }
+        rowi[tid] = clampi(a.uid[src], 0, a.n_user - 1);
+        rowi[TILE_ROWS + tid] = clampi(a.pid[src], 0, a.n_item - 1);
+        rowi[2 * TILE_ROWS + tid] = clampi(a.dom[src], 0, a.n_domain - 1);
+        rowi[3 * TILE_ROWS + tid] = valid ? 1 : 0;
+        rowf[tid] = a.label[src];
+    }
+    __syncthreads();
+    // 16 rows x 96 float4: 32 consecutive lanes read one 512-B embedding row
+    float* xs = smem + XS_OFF;
+#pragma unroll
+    for (int e = tid; e < TILE_ROWS * (XDIM / 4); e += 256) {
+        const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
+        const int seg = c4 >> 5, off = (c4 & 31) * 4;
+        const float* src;
+        if (seg == 0) src = a.user_tab + (size_t)rowi[row] * EMB;
+        else if (seg == 1) src = a.item_tab + (size_t)rowi[TILE_ROWS + row] * EMB;
+        else src = a.dense + a.L.dm + (size_t)rowi[2 * TILE_ROWS + row] * EMB;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (rowi[3 * TILE_ROWS + row]) v = *reinterpret_cast<const f32x4*>(src + off);
+        *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v;
+        if (gx) *reinterpret_cast<f32x4*>(gx + (size_t)row * gx_ld + c4 * 4) = v;
+    }
+    __syncthreads();
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int r0 = tile * TILE_ROWS;
+    int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
+    float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;   // [0,16) label, [16,32) dlogit
+    float* acts_t = TRAIN ? a.acts + (size_t)r0 * ACT_LD : nullptr;
+
+    gather_tile(a, smem, r0, acts_t, ACT_LD);
+
+    const float* P = a.dense;
+    const float scale = a.use_dropout ? a.keep_scale : 1.0f;
+    // row index inside the batch seeds the dropout stream (eval: unused)
+    const int row0 = r0;
+    const uint32_t key0 = TRAIN ? dropout_layer_key(a.seed, a.step, 0) : 0u;
+    const uint32_t key1 = TRAIN ? dropout_layer_key(a.seed, a.step, 1) : 0u;
+    const uint32_t key2 = TRAIN ? dropout_layer_key(a.seed, a.step, 2) : 0u;
+
+    fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(P + a.L.w0, P + a.L.b0, smem + XS_OFF, smem + H1S_OFF,
+                                             TRAIN ? acts_t + XDIM : nullptr, key0, a.drop_thresh, scale,
+                                             a.use_dropout != 0, row0);
+    __syncthreads();
+    fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN>(P + a.L.w1, P + a.L.b1, smem + H1S_OFF, smem + H2S_OFF,
+                                           TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
+                                           a.use_dropout != 0, row0);
+    __syncthreads();
+    fwd_layer<H2, H3, H2_LD, H3_LD, TRAIN>(P + a.L.w2, P + a.L.b2, smem + H2S_OFF, smem + H3S_OFF,
+                                           TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh, scale,
+                                           a.use_dropout != 0, row0);
+    __syncthreads();
+
+    // ---- output unit, sigmoid, Keras BCE (wave 0): lane (i, q) sums 16 of the 64 terms
+    if (w == 0) {
+        const int i = lane & 15, q = lane >> 4;
+        const float* h3 = smem + H3S_OFF + i * H3_LD + q * 16;
+        const float* wo = P + a.L.wo + q * 16;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s = fmaf(h3[c], wo[c], s);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const float logit = s + P[a.L.gb];
+        float p;
+        if (logit >= 0.f) {
+            p = 1.0f / (1.0f + expf(-logit));
+        } else {
+            const float ez = expf(logit);
+            p = ez / (1.0f + ez);
+        }
+        const bool valid = rowi[3 * TILE_ROWS + i] != 0;
+        const float y = rowf[i];
+        const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+        const float pc = fminf(fmaxf(p, lo), hi);
+        const float zc = logf(pc / (1.0f - pc));
+        float loss = fmaxf(zc, 0.f) - zc * y + log1pf(expf(-fabsf(zc)));
+        if (!valid) loss = 0.f;
+        if (TRAIN) {
+            const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
+            const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
+            if (q == 0) {
+                rowf[TILE_ROWS + i] = dl;
+                a.dlogit[r0 + i] = dl;
+                a.domrow[r0 + i] = rowi[2 * TILE_ROWS + i];
+            }
+        } else if (q == 0 && valid) {
+            // AUC bin = number of thresholds strictly below p (utils/metrics_utils.py:309: pred > thr)
+            int blo = 0, bhi = 500;
+            while (blo < bhi) {
+                const int mid = (blo + bhi) >> 1;
+                if (a.thresholds[mid] < p) blo = mid + 1; else bhi = mid;
+            }
+            atomicAdd(a.hist + (y != 0.f ? 501 : 0) + blo, 1u);
+            if (a.pred_out) a.pred_out[a.row_base + r0 + i] = p;
+        }
+        // tile loss: rows 0..15 live in lanes 0..15
+        loss += __shfl_xor(loss, 8);
+        loss += __shfl_xor(loss, 4);
+        loss += __shfl_xor(loss, 2);
+        loss += __shfl_xor(loss, 1);
+        if (lane == 0) a.loss_part[tile] = loss;
+    }
+    if (!TRAIN) return;
+    __syncthreads();
+
+    // ---- backward activation chain.  gate = relu'(z) * dropout mask / keep = (h_post > 0) * scale
+    float* dz_t = a.dz + (size_t)r0 * DZ_LD;
+    {
+        const int i = tid >> 4, n4 = (tid & 15) * 4;
+        const float dl = rowf[TILE_ROWS + i];
+        const f32x4 wo = *reinterpret_cast<const f32x4*>(P + a.L.wo + n4);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(smem + H3S_OFF + i * H3_LD + n4);
+        f32x4 d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
+        *reinterpret_cast<f32x4*>(smem + DZ3S_OFF + i * H3_LD + n4) = d;
+        *reinterpret_cast<f32x4*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n4) = d;
+    }
+    __syncthreads();
+    {
+        float* dzs = smem + DZ2S_OFF;
+        const float* hs = smem + H2S_OFF;
+        bwd_layer<H3, H2, H3, H3_LD>(P + a.L.w2, smem + DZ3S_OFF, [&](int row, int col, float v) {
+            const float d = (hs[row * H2_LD + col] > 0.f) ? v * scale : 0.f;
+            dzs[row * H2_LD + col] = d;
+            dz_t[(size_t)row * DZ_LD + H1 + col] = d;
+        });
+    }
+    __syncthreads();
+    {
+        float* dzs = smem + DZ1S_OFF;
+        const float* hs = smem + H1S_OFF;
+        bwd_layer<H2, H1, H2, H2_LD>(P + a.L.w1, smem + DZ2S_OFF, [&](int row, int col, float v) {
+            const float d = (hs[row * H1_LD + col] > 0.f) ? v * scale : 0.f;
+            dzs[row * H1_LD + col] = d;
+            dz_t[(size_t)row * DZ_LD + col] = d;
+        });
+    }
+    __syncthreads();
+    {
+        // d loss / d domain-embedding row = dz1 . W0[256:384, :]^T
+        float* dxe_t = a.dxe + (size_t)r0 * EMB;
+        bwd_layer<H1, EMB, H1, H1_LD>(P + a.L.w0 + (size_t)(2 * EMB) * H1, smem + DZ1S_OFF,
+                                     [&](int row, int col, float v) { dxe_t[(size_t)row * EMB + col] = v; });
+    }
+}
+
+void launch_tower_train(const TowerArgs& a, hipStream_t s) {
+    const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(k_tower<true>, dim3(tiles), dim3(256), tower_lds_bytes(), s, a);
+}
+void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
+    const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(k_tower<false>, dim3(tiles), dim3(256), tower_lds_bytes(), s, a);
+}
+
+// ------------------------------------------------------------------ standalone gather
+__global__ __launch_bounds__(256) void k_gather(const TowerArgs a, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r0 = blockIdx.x * TILE_ROWS;
+    gather_tile(a, smem, r0, nullptr, 0);
+    const float* xs = smem + XS_OFF;
+    for (int e = threadIdx.x; e < TILE_ROWS * (XDIM / 4); e += 256) {
+        const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
+        if (r0 + row < a.rows)
+            *reinterpret_cast<f32x4*>(out + (size_t)(r0 + row) * XDIM + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(xs + row * XS_LD + c4 * 4);
+    }
+}
+void launch_gather(const TowerArgs& a, float* out, hipStream_t s) {
+    const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(k_gather, dim3(tiles), dim3(256), tower_lds_bytes(), s, a, out);
+}
+
+// ------------------------------------------------------------------ eval loss epilogue
+// Keras evaluate: mean over batches of (batch-mean BCE + regularisers)
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    // fixed-order tree: wave shuffle then 4 partials in order
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_eval_finish(const float* loss_part, int64_t n_rows, int batch,
+                                                     const float* dense, int dm_count, float l2_emb,
+                                                     const float* frozen_sumsq, float* loss_out) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < dm_count; e += 256) ss = fmaf(dense[e], dense[e], ss);
+    ss = block_sum_256(ss, red);
+    const float reg = l2_emb * frozen_sumsq[0] + l2_emb * frozen_sumsq[1] + l2_emb * ss;
+    const int64_t n_batches = (n_rows + batch - 1) / batch;
+    const int tiles_per_batch = batch / TILE_ROWS;
+    const int64_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    float acc = 0.f;
+    for (int64_t b = threadIdx.x; b < n_batches; b += 256) {
+        const int64_t t0 = b * tiles_per_batch;
+        const int64_t t1 = (t0 + tiles_per_batch < n_tiles) ? t0 + tiles_per_batch : n_tiles;
+        float s = 0.f;
+        for (int64_t t = t0; t < t1; ++t) s += loss_part[t];
+        const int64_t rows_b = (b == n_batches - 1) ? (n_rows - b * (int64_t)batch) : batch;
+        acc += s / (float)rows_b + reg;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) loss_out[0] = acc / (float)n_batches;
+}
+void launch_eval_finish(const float* loss_part, int64_t n_rows, int batch, const float* dense, int dm_count,
+                        float l2_emb, const float* frozen_sumsq, float* loss_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(256), 0, s, loss_part, n_rows, batch, dense, dm_count, l2_emb,
+                       frozen_sumsq, loss_out);
+}
+
+// ------------------------------------------------------------------ sum of squares (frozen tables)
+__global__ __launch_bounds__(256) void k_sumsq_part(const float* x, int64_t n, float* partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        s = fmaf(x[e], x[e], s);
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_sumsq_final(const float* partials, int n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) s += partials[e];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+void launch_sumsq(const float* x, int64_t n, float* partials, float* out, hipStream_t s) {
+    const int blocks = 1024;
+    hipLaunchKernelGGL(k_sumsq_part, dim3(blocks), dim3(256), 0, s, x, n, partials);
+    hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(256), 0, s, partials, blocks, out);
+}
+
+// ------------------------------------------------------------------ weight gradients
+// One workgroup = one 32x32 output tile x one row group; its 4 waves split the group's
+// rows and are summed through LDS in wave order.  Operands are fetched straight from
+// the row-major activation / gradient workspaces: lane (c = lane & 31, kk = lane >> 5)
+// reads element c of row b + kk, i.e. one full 128-B line per half wave.
+template <int AK>
+__device__ __forceinline__ float fetch_a(const WgradArgs& g, const TileDesc& t, int b, int c) {
+    if (AK == 0) return g.acts[(size_t)b * ACT_LD + t.a_off + c];
+    if (AK == 1) return c == 0 ? 1.0f : 0.0f;
+    return (g.domrow[b] == t.a_off + c) ? 1.0f : 0.0f;
+}
+template <int BK>
+__device__ __forceinline__ float fetch_b(const WgradArgs& g, const TileDesc& t, int b, int c) {
+    if (BK == 0) return g.dz[(size_t)b * DZ_LD + t.b_off + c];
+    if (BK == 1) return c == 0 ? g.dlogit[b] : 0.0f;
+    return g.dxe[(size_t)b * EMB + t.b_off + c];
+}
+
+template <int AK, int BK>
+__device__ __forceinline__ void wgrad_rows(const WgradArgs& g, const TileDesc& t, int b0, int b1, f32x16& acc) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, kk = lane >> 5;
+    int b = b0;
+    // 8 rows (4 MFMA k-steps) per iteration: all loads issued before the MFMAs
+    for (; b + 8 <= b1; b += 8) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = fetch_a<AK>(g, t, b + 2 * u + kk, c);
+            bv[u] = fetch_b<BK>(g, t, b + 2 * u + kk, c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = MAMDR_MFMA32(av[u], bv[u], acc);
+    }
+    for (; b + 2 <= b1; b += 2) {
+        const float av = fetch_a<AK>(g, t, b + kk, c);
+        const float bv = fetch_b<BK>(g, t, b + kk, c);
+        acc = MAMDR_MFMA32(av, bv, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n_work = g.n_tiles * g.n_groups;
+    if ((int)blockIdx.x >= n_work) {
+        // ---- one extra workgroup: loss of the step = mean BCE + regularisers
+        if (g.loss_out == nullptr) return;
+        float* r4 = red;
+        float ss = 0.f;
+        for (int e = tid; e < g.dm_count; e += 256) ss = fmaf(g.dense[e], g.dense[e], ss);
+        ss = block_sum_256(ss, r4);
+        float ls = 0.f;
+        for (int e = tid; e < g.n_loss_tiles; e += 256) ls += g.loss_part[e];
+        ls = block_sum_256(ls, r4);
+        if (tid == 0)
+            g.loss_out[0] = ls / (float)g.rows +
+                            (g.l2_emb * g.frozen_sumsq[0] + g.l2_emb * g.frozen_sumsq[1] + g.l2_emb * ss);
+        return;
+    }
+    const int tile = blockIdx.x % g.n_tiles, grp = blockIdx.x / g.n_tiles;
+    const TileDesc t = g.tiles[tile];
+    const int gb0 = grp * g.rows_per_group;
+    const int gb1 = min(gb0 + g.rows_per_group, g.rows_pad);
+    // split the group's rows over the 4 waves in multiples of 2
+    const int span = gb1 > gb0 ? gb1 - gb0 : 0;
+    const int per = ((span + 7) / 8) * 2;
+    const int b0 = min(gb0 + w * per, gb1), b1 = min(b0 + per, gb1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (t.a_kind == 0 && t.b_kind == 0) wgrad_rows<0, 0>(g, t, b0, b1, acc);
+    else if (t.a_kind == 1 && t.b_kind == 0) wgrad_rows<1, 0>(g, t, b0, b1, acc);
+    else if (t.a_kind == 0 && t.b_kind == 1) wgrad_rows<0, 1>(g, t, b0, b1, acc);
+    else if (t.a_kind == 1 && t.b_kind == 1) wgrad_rows<1, 1>(g, t, b0, b1, acc);
+    else wgrad_rows<2, 2>(g, t, b0, b1, acc);
+    // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    {
+        const int col = lane & 31, rb = 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[w * 1024 + ((r & 3) + 8 * (r >> 2) + rb) * 32 + col] = acc[r];
+    }
+    __syncthreads();
+    float* slab = g.slabs + (size_t)grp * g.slab_ld;
+#pragma unroll
+    for (int e = tid; e < 1024; e += 256) {
+        const int row = e >> 5, col = e & 31;
+        if (row < t.m_valid && col < t.n_valid) {
+            const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+            slab[t.dst_off + row * t.dst_ld + col] = v;
+        }
+    }
+}
+void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ slab reduce + optimiser
+// TF1 ApplyAdam: m += (g - m)(1-b1); v += (g^2 - v)(1-b2);
+// p -= (m * alpha) / (sqrt(v) + eps), alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host.
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
+    const int e4 = blockIdx.x * 256 + threadIdx.x;
+    if (e4 >= u.count4) return;
+    const size_t e = (size_t)e4 * 4;
+    f32x4 gsum = *reinterpret_cast<const f32x4*>(u.slabs + e);
+    for (int s = 1; s < u.n_groups; ++s) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(u.slabs + (size_t)s * u.slab_ld + e);
+        gsum += t;
+    }
+    f32x4 p = *reinterpret_cast<const f32x4*>(u.p + e);
+    if ((int)e < u.dm_count) gsum += u.two_l2 * p;
+    if (u.optimizer == 0) {
+        f32x4 m = *reinterpret_cast<const f32x4*>(u.m + e);
+        f32x4 v = *reinterpret_cast<const f32x4*>(u.v + e);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gc = gsum[c];
+            m[c] = m[c] + (gc - m[c]) * u.omb1;
+            v[c] = v[c] + (gc * gc - v[c]) * u.omb2;
+            p[c] = p[c] - (m[c] * u.alpha) / (sqrtf(v[c]) + u.eps);
+        }
+        *reinterpret_cast<f32x4*>(u.m + e) = m;
+        *reinterpret_cast<f32x4*>(u.v + e) = v;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = p[c] - gsum[c] * u.alpha;
+    }
+    *reinterpret_cast<f32x4*>(u.p + e) = p;
+}
+void launch_update(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_update, dim3((a.count4 + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace mamdr

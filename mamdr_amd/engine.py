@@ -1,0 +1,252 @@
+"""Device-resident tower: the compiled-Keras-model stand-in over libmamdr_hip.so.
+
+`TowerEngine` owns (through torch, used purely as the device allocator / stream
+provider) the flat trainable vector with its Adam slots, the frozen tables and
+the per-domain split columns, and forwards every numeric operation to the C ABI
+(include/mamdr_hip.h).  It exposes what the reference's wrappers use of the
+Keras model:
+
+    train_on_batch / fit        -> train_pass / train_steps   (mamdr.py:54,86,97)
+    evaluate                    -> evaluate                   (base_model.py:131)
+    K.batch_get_value(vars)     -> get_weights / weights      (maml.py:189-194)
+    SetVarOp(vars)(values)      -> set_weights                (utils/tool.py:36-45)
+
+plus the outer-update primitives on flat vectors.  No CPU fallback exists.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def auc_thresholds(num_thresholds=500):
+    """utils/auc.py:118-126 (python doubles -> fp32 constant)."""
+    inner = [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)]
+    return np.array([0.0 - 1e-7] + inner + [1.0 + 1e-7], dtype=np.float32)
+
+
+def auc_from_histogram(hist):
+    """AUC(num_thresholds=500) from the kernel's exact integer histogram.
+
+    hist[c, k] = rows of class c whose prediction exceeds exactly k thresholds, so
+    the confusion counts of utils/metrics_utils.py:297-354 are suffix sums:
+    tp[t] = #{pos: pred > thr_t} = sum_{k > t} hist[1, k].  The Riemann sum follows
+    utils/auc.py:248-281 in fp32 (counts are exact in fp32 below 2^24, as in the
+    reference's fp32 accumulators).
+    """
+    hist = np.asarray(hist, dtype=np.int64).reshape(2, 501)
+    suffix = np.cumsum(hist[:, ::-1], axis=1)[:, ::-1]      # suffix[c, k] = sum_{k' >= k}
+    tp = suffix[1, 1:].astype(np.float32)                    # t = 0..499 -> k >= t+1
+    fp = suffix[0, 1:].astype(np.float32)
+    fn = (hist[1].sum() - suffix[1, 1:]).astype(np.float32)
+    tn = (hist[0].sum() - suffix[0, 1:]).astype(np.float32)
+
+    def div_no_nan(a, b):
+        out = np.zeros_like(a)
+        nz = b != 0
+        out[nz] = a[nz] / b[nz]
+        return out
+
+    recall = div_no_nan(tp, tp + fn)
+    fpr = div_no_nan(fp, fp + tn)
+    heights = (recall[:-1] + recall[1:]) / np.float32(2.0)
+    return float(np.sum((fpr[:-1] - fpr[1:]) * heights, dtype=np.float32)), (tp, fp, tn, fn)
+
+
+class TowerEngine(object):
+    def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False,
+                 tower="mlp", emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None,
+                 dropout_seed=1024):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("TowerEngine needs a HIP device (no CPU fallback for the MAMDR hot path)")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.n_user, self.n_item, self.n_domain = int(n_user), int(n_item), int(n_domain)
+        self.batch_size = int(batch_size)
+        self.dropout_seed = int(dropout_seed) & 0xFFFFFFFF
+        tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR}[tower]
+        max_batch = (self.batch_size + 15) // 16 * 16
+        cfg = L.Config(L.ABI_VERSION, tower_id, self.n_user, self.n_item, self.n_domain, emb_dim,
+                       (C.c_int32 * 3)(*hidden), max_batch, 1 if emb_trainable else 0, float(dropout),
+                       float(l2_emb), 0.9, 0.999, 1e-8)
+        self.eval_batch = max_batch
+        handle = C.c_void_p()
+        L.check(self.lib.mamdr_create(C.byref(cfg), C.c_void_p(self.stream.cuda_stream), C.byref(handle)))
+        self.ctx = handle
+        self.emb_trainable = bool(emb_trainable)
+        self.n_params = int(self.lib.mamdr_param_count(self.ctx))
+        self.segments = {}
+        for seg, name in enumerate(L.SEG_NAMES):
+            off, cnt = C.c_int64(), C.c_int64()
+            L.check(self.lib.mamdr_param_segment(self.ctx, seg, C.byref(off), C.byref(cnt)))
+            if cnt.value:
+                self.segments[name] = (off.value, cnt.value)
+        # live state: weights + Adam slots (one set for the whole run)
+        self.weights = self.new_vector()
+        self.adam_m = self.new_vector()
+        self.adam_v = self.new_vector()
+        L.check(self.lib.mamdr_bind_state(self.ctx, _ptr(self.weights), _ptr(self.adam_m), _ptr(self.adam_v)))
+        self.tables = {}
+        self.data = {}          # (domain, split) -> dict of device columns
+        self._hist = torch.zeros(2 * 501, dtype=torch.int32, device=self.device)
+        self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.mamdr_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ flat vectors
+    def new_vector(self, like=None):
+        if like is not None:
+            return like.clone()
+        return torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+
+    def pack(self, named):
+        """numpy dict {segment name: array} -> flat device vector (padding zero)."""
+        host = np.zeros(self.n_params, np.float32)
+        for name, (off, cnt) in self.segments.items():
+            a = np.asarray(named[name], np.float32).ravel()
+            if a.size != cnt:
+                raise ValueError("segment %s has %d elements, expected %d" % (name, a.size, cnt))
+            host[off:off + cnt] = a
+        return torch.from_numpy(host).to(self.device)
+
+    def unpack(self, vec):
+        host = vec.detach().cpu().numpy()
+        return {name: host[off:off + cnt].copy() for name, (off, cnt) in self.segments.items()}
+
+    def set_weights(self, vec):
+        """SetVarOp.__call__ (utils/tool.py:36-45): device copy into the live weights."""
+        L.check(self.lib.mamdr_copy(_ptr(self.weights), _ptr(vec), self.n_params, self._s()))
+
+    def get_weights(self, out=None):
+        """K.batch_get_value (maml.py:189-194): snapshot of the live weights."""
+        if out is None:
+            out = torch.empty_like(self.weights)
+        L.check(self.lib.mamdr_copy(_ptr(out), _ptr(self.weights), self.n_params, self._s()))
+        return out
+
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    # outer updates (bit-exact vs the reference's numpy, see include/mamdr_hip.h)
+    def interp(self, dst, a, b, scale):
+        L.check(self.lib.mamdr_interp(_ptr(dst), _ptr(a), _ptr(b), float(scale), dst.numel(), self._s()))
+
+    def merge(self, dst, theta, phi, method="plus"):
+        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        L.check(self.lib.mamdr_merge(_ptr(dst), _ptr(theta), _ptr(phi), mode, dst.numel(), self._s()))
+
+    def sub(self, dst, a, b):
+        L.check(self.lib.mamdr_sub(_ptr(dst), _ptr(a), _ptr(b), dst.numel(), self._s()))
+
+    def accumulate(self, acc, a, b, shared=None, divisor=1.0):
+        L.check(self.lib.mamdr_accumulate(_ptr(acc), _ptr(a), _ptr(b), _ptr(shared), float(divisor),
+                                          acc.numel(), self._s()))
+
+    def apply_accumulated(self, dst, acc, divisor, scale):
+        L.check(self.lib.mamdr_apply_accumulated(_ptr(dst), _ptr(acc), float(divisor), float(scale),
+                                                 dst.numel(), self._s()))
+
+    # ------------------------------------------------------------ binding
+    def bind_table(self, name, rows):
+        """frozen pretrained table (deepctr.py:104-116), numpy [n, 128] fp32."""
+        seg = {"user_emb": L.SEG_USER_EMB, "item_emb": L.SEG_ITEM_EMB}[name]
+        t = torch.from_numpy(np.ascontiguousarray(rows, np.float32)).to(self.device)
+        self.tables[name] = t
+        L.check(self.lib.mamdr_bind_table(self.ctx, seg, _ptr(t), t.shape[0]))
+
+    def bind_domain_data(self, domain, split, uid, pid, dom, label):
+        split_id = {"train": L.SPLIT_TRAIN, "val": L.SPLIT_VAL, "test": L.SPLIT_TEST}[split]
+        uid = np.ascontiguousarray(uid, np.int32)
+        pid = np.ascontiguousarray(pid, np.int32)
+        dom = np.ascontiguousarray(dom, np.int32)
+        if uid.size:
+            if uid.min() < 0 or uid.max() >= self.n_user or pid.min() < 0 or pid.max() >= self.n_item \
+                    or dom.min() < 0 or dom.max() >= self.n_domain:
+                raise ValueError("domain %d %s: id out of range" % (domain, split))
+        cols = {
+            "uid": torch.from_numpy(uid).to(self.device),
+            "pid": torch.from_numpy(pid).to(self.device),
+            "domain": torch.from_numpy(dom).to(self.device),
+            "label": torch.from_numpy(np.ascontiguousarray(label, np.float32)).to(self.device),
+        }
+        self.data[(domain, split)] = cols
+        L.check(self.lib.mamdr_bind_domain_data(self.ctx, domain, split_id, _ptr(cols["uid"]), _ptr(cols["pid"]),
+                                                _ptr(cols["domain"]), _ptr(cols["label"]), uid.shape[0]))
+
+    def n_rows(self, domain, split):
+        return int(self.data[(domain, split)]["uid"].shape[0])
+
+    # ------------------------------------------------------------ the hot path
+    def train_steps(self, domain, perm=None, first_step=0, n_steps=None, lr=1e-3, optimizer="adam",
+                    loss_out=None, batch_size=None):
+        """n_steps x train_on_batch on one domain, device-side. perm: int32 device tensor or None."""
+        bs = batch_size or self.batch_size
+        n = self.n_rows(domain, "train")
+        if n_steps is None:
+            n_steps = -(-n // bs) - first_step
+        opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD}[optimizer]
+        L.check(self.lib.mamdr_train_steps(self.ctx, domain, _ptr(perm), first_step, n_steps, bs,
+                                           self.dropout_seed, opt, float(lr), _ptr(loss_out)))
+        return n_steps
+
+    def evaluate(self, domain, split, want_preds=False):
+        """model.evaluate(data, steps=n_step) -> (loss, auc[, preds]); syncs to read back."""
+        n = self.n_rows(domain, split)
+        preds = torch.empty(n, dtype=torch.float32, device=self.device) if want_preds else None
+        split_id = {"train": L.SPLIT_TRAIN, "val": L.SPLIT_VAL, "test": L.SPLIT_TEST}[split]
+        L.check(self.lib.mamdr_eval_domain(self.ctx, domain, split_id, self.eval_batch, _ptr(self._loss1),
+                                           _ptr(self._hist), _ptr(preds)))
+        hist = self._hist.cpu().numpy().astype(np.int64)
+        loss = float(self._loss1.cpu().numpy()[0])
+        auc, _ = auc_from_histogram(hist)
+        if want_preds:
+            return loss, auc, hist.reshape(2, 501), preds.cpu().numpy()
+        return loss, auc
+
+    def gather(self, domain, split, perm=None, first_row=0, n_rows=None, out=None):
+        n = self.n_rows(domain, split) if n_rows is None else n_rows
+        if out is None:
+            out = torch.empty((n, 384), dtype=torch.float32, device=self.device)
+        split_id = {"train": L.SPLIT_TRAIN, "val": L.SPLIT_VAL, "test": L.SPLIT_TEST}[split]
+        L.check(self.lib.mamdr_gather_rows(self.ctx, domain, split_id, _ptr(perm), first_row, n, _ptr(out)))
+        return out
+
+    def optimizer_reset(self):
+        L.check(self.lib.mamdr_optimizer_reset(self.ctx))
+
+    # ------------------------------------------------------------ profiling
+    def profile(self, enable):
+        L.check(self.lib.mamdr_profile_enable(self.ctx, 1 if enable else 0))
+
+    def profile_reset(self):
+        L.check(self.lib.mamdr_profile_reset(self.ctx))
+
+    def profile_read(self, kernel):
+        ms, cnt = C.c_double(), C.c_int64()
+        L.check(self.lib.mamdr_profile_read(self.ctx, kernel, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+def shuffle_perm(n, buffer_size, seed):
+    """host: tf.data shuffle-buffer order (utils/dataset.py:27-37) via the C ABI."""
+    out = np.empty(n, np.int32)
+    L.check(L.load().mamdr_shuffle_perm(n, buffer_size, seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data))
+    return out

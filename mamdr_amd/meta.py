@@ -1,0 +1,113 @@
+"""Meta-loop epochs on the device-resident tower (host control flow only).
+
+These are the numeric cores of the reference's wrapper `train()` loops with the
+python-RNG decisions factored out: the caller supplies the domain order, the DR
+support domains and the per-pass shuffle, so that the loop is reproducible and
+shardable.  Loop structure follows
+
+    alternate_epoch  model_zoo/DeepCTR/deepctr.py:70-78
+    dn_epoch         model_zoo/domain_negotiation.py:49-88
+    reptile_epoch    model_zoo/reptile.py:45-99
+    mamdr_epoch      model_zoo/mamdr.py:44-108   (DN phase then DR phase)
+
+Weights never leave the GPU: the reference's K.batch_get_value -> numpy ->
+SetVarOp round trips (maml.py:189-194, utils/tool.py:36-45) become device copies
+and elementwise kernels on flat vectors.  Every function returns the trace of
+(phase, domain, n_steps) it executed.
+"""
+import torch
+
+
+def _upload_perm(eng, perm):
+    if perm is None:
+        return None
+    if isinstance(perm, torch.Tensor):
+        return perm
+    return torch.from_numpy(perm).to(eng.device, non_blocking=True)
+
+
+def run_pass(eng, d, perm_fn, batch_size, lr, trace, phase, max_steps=0, optimizer="adam"):
+    """one pass over domain d's train split = re-initialised iterator + n_step x train_on_batch."""
+    perm = _upload_perm(eng, perm_fn(d) if perm_fn is not None else None)
+    n = eng.n_rows(d, "train")
+    n_steps = -(-n // batch_size)
+    if max_steps and max_steps > 0:
+        n_steps = min(n_steps, max_steps)
+    eng.train_steps(d, perm=perm, first_step=0, n_steps=n_steps, lr=lr, optimizer=optimizer,
+                    batch_size=batch_size)
+    trace.append((phase, d, n_steps))
+    return n_steps
+
+
+def alternate_epoch(eng, seq, perm_fn, batch_size, lr):
+    trace = []
+    for d in seq:
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "alt")
+    return trace
+
+
+def dn_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, meta_train_step=0):
+    trace = []
+    eng.set_weights(theta)
+    for d in seq:
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
+    eng.interp(theta, eng.weights, theta, meta_lr)     # theta += (theta~ - theta) * beta
+    eng.set_weights(theta)
+    return trace
+
+
+def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False, meta_train_step=0,
+                  acc=None):
+    trace = []
+    if batch_variant and acc is None:
+        acc = torch.zeros_like(theta)
+    for d in seq:
+        eng.set_weights(theta)
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
+        if batch_variant:
+            eng.accumulate(acc, eng.weights, theta)
+        else:
+            eng.interp(theta, eng.weights, theta, meta_lr)
+    if batch_variant:
+        eng.apply_accumulated(theta, acc, 0.0, meta_lr)
+    eng.set_weights(theta)
+    return trace
+
+
+def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, trace, merged,
+             merged_method="plus", domain_regulation_step=0, batch_variant=False, sample_num=None, acc=None):
+    """DR for one query domain (mamdr.py:60-108): phi is updated in place.  Reads theta
+    (fixed during DR) and writes only phi -- the unit that shards across GPUs."""
+    eng.merge(merged, theta, phi, merged_method)
+    if batch_variant:
+        acc.zero_()
+    for j in support:
+        eng.set_weights(merged)
+        run_pass(eng, j, perm_fn, batch_size, lr, trace, "dr_support")
+        run_pass(eng, query, perm_fn, batch_size, lr, trace, "dr_query", domain_regulation_step)
+        if batch_variant:
+            shared = theta if merged_method == "times" else None
+            eng.accumulate(acc, eng.weights, merged, shared, 1.0)
+        else:
+            eng.interp(phi, eng.weights, merged, meta_lr)      # phi += (theta~ - merged) * gamma
+            eng.merge(merged, theta, phi, merged_method)
+    if batch_variant:
+        eng.apply_accumulated(phi, acc, float(sample_num), meta_lr)
+
+
+def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
+                domain_regulation_step=0, batch_variant=False, sample_num=None, scratch=None):
+    """plan = {"seq": [...], "dr": [(query, [support...]), ...]}."""
+    trace = []
+    # DN phase (mamdr.py:48-57)
+    eng.set_weights(theta)
+    for d in plan["seq"]:
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
+    eng.interp(theta, eng.weights, theta, meta_lr)
+    # DR phase (mamdr.py:59-108)
+    merged = scratch if scratch is not None else torch.empty_like(theta)
+    acc = torch.zeros_like(theta) if batch_variant else None
+    for query, support in plan["dr"]:
+        dr_query(eng, theta, phis[query], query, support, perm_fn, batch_size, lr, meta_lr, trace, merged,
+                 merged_method, domain_regulation_step, batch_variant, sample_num, acc)
+    return trace

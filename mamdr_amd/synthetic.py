@@ -1,0 +1,80 @@
+"""Synthetic Taobao-/Amazon-shaped click logs.
+
+The real datasets are not in the reference tree and cannot be downloaded, so
+throughput and parity are measured on generated logs with the published shapes
+(slides p.24 Table I): number of domains / users / items and train/val/test
+totals; long-tailed domain sizes (Zipf s=1 over domains, each >= one batch);
+per-domain positive rate r/(1+r) with r = round(U[0.2,0.5], 2)
+(dataset/Taobao/split.py:110-112,50); every domain draws users and items from
+its own subset; labels are Bernoulli draws from a planted model
+sigma(s <u,i> + b_d) over the "pretrained" tables, so AUC is well above 0.5.
+Columns match the reference's csv header uid,pid,domain,label (split.py:21).
+"""
+import numpy as np
+
+# slides p.24 Table I
+SHAPES = {
+    "taobao10": dict(name="Taobao", split="split_by_theme_10", n_domain=10, n_user=23778, n_item=6932,
+                     n_train=92137, n_val=37645, n_test=43502, pretrained=True),
+    "taobao20": dict(name="Taobao", split="split_by_theme_20", n_domain=20, n_user=58190, n_item=16319,
+                     n_train=243592, n_val=96591, n_test=106500, pretrained=True),
+    "taobao30": dict(name="Taobao", split="split_by_theme_30", n_domain=30, n_user=99143, n_item=29945,
+                     n_train=394805, n_val=151369, n_test=179252, pretrained=True),
+    "amazon6": dict(name="Amazon", split="split_by_category_6", n_domain=6, n_user=445789, n_item=172653,
+                    n_train=9968333, n_val=3372666, n_test=3585877, pretrained=False),
+    "amazon13": dict(name="Amazon", split="split_by_category_13", n_domain=13, n_user=502222, n_item=215403,
+                     n_train=11999607, n_val=4100756, n_test=4339523, pretrained=False),
+}
+
+
+def _domain_sizes(total, n_domain, min_size, rs):
+    w = 1.0 / np.arange(1, n_domain + 1)
+    w = w[rs.permutation(n_domain)]
+    sizes = np.maximum(np.floor(w / w.sum() * total).astype(np.int64), min_size)
+    # give the rounding remainder (or take the excess) to/from the largest domain
+    sizes[np.argmax(sizes)] += total - sizes.sum()
+    if sizes.min() < 1:
+        raise ValueError("total %d too small for %d domains" % (total, n_domain))
+    return sizes
+
+
+def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128, signal=10.0):
+    """returns dict(tables, data, info).  scale < 1 shrinks users/items/rows (tests)."""
+    spec = dict(SHAPES[shape]) if isinstance(shape, str) else dict(shape)
+    rs = np.random.RandomState(seed)
+    D = spec["n_domain"]
+    n_user = max(int(spec["n_user"] * scale), 4 * D)
+    n_item = max(int(spec["n_item"] * scale), 4 * D)
+    user_emb = (rs.standard_normal((n_user, emb_dim)) * 0.1).astype(np.float32)
+    item_emb = (rs.standard_normal((n_item, emb_dim)) * 0.1).astype(np.float32)
+    min_size = max(1, int(batch_size * min(1.0, scale))) if scale < 1.0 else batch_size
+    sizes = {}
+    for split in ("train", "val", "test"):
+        total = max(int(spec["n_" + split] * scale), D * min_size)
+        sizes[split] = _domain_sizes(total, D, min_size, np.random.RandomState(seed + 1))
+    data = {"train": {}, "val": {}, "test": {}}
+    info = {"n_user": n_user, "n_item": n_item}
+    totals = {"train": 0, "val": 0, "test": 0}
+    for d in range(D):
+        r = round(rs.uniform(0.2, 0.5), 2)
+        rate = r / (1.0 + r)
+        bias = np.log(rate / (1.0 - rate))
+        # per-domain subsets (overlapping across domains)
+        n_u_d = max(8, int(n_user * min(1.0, 3.0 / D)))
+        n_i_d = max(8, int(n_item * min(1.0, 3.0 / D)))
+        users = rs.choice(n_user, n_u_d, replace=False)
+        items = rs.choice(n_item, n_i_d, replace=False)
+        info[d] = {"ctr_ratio": r}
+        for split in ("train", "val", "test"):
+            n = int(sizes[split][d])
+            uid = users[rs.randint(0, n_u_d, n)].astype(np.int32)
+            pid = items[rs.randint(0, n_i_d, n)].astype(np.int32)
+            logit = signal * np.einsum("ij,ij->i", user_emb[uid], item_emb[pid]).astype(np.float64) + bias
+            label = (rs.uniform(size=n) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+            data[split][d] = {"uid": uid, "pid": pid, "domain": np.full(n, d, np.int32), "label": label}
+            info[d]["n_" + split] = n
+            totals[split] += n
+    info["total_train"], info["total_val"], info["total_test"] = totals["train"], totals["val"], totals["test"]
+    tables = {"user_emb": user_emb, "item_emb": item_emb}
+    return {"spec": spec, "tables": tables, "data": data, "info": info, "n_user": n_user, "n_item": n_item,
+            "n_domain": D, "batch_size": batch_size}

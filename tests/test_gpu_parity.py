@@ -1,0 +1,324 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Bars (BASELINE.json north_star): bit-exact for index paths (embedding gather, AUC
+binning) and for the outer updates (vs goldens produced by the reference's own
+numpy); fp32 contractions within the tolerances written below; per-domain
+AUC within 1e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import auc as oauc          # noqa: E402
+from oracle import loops as oloops      # noqa: E402
+from oracle import outer as oouter      # noqa: E402
+from oracle import rng as orng          # noqa: E402
+from oracle import tower as otower      # noqa: E402
+
+F32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import engine, synthetic
+    return engine, synthetic
+
+
+def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao10"):
+    engine, synthetic = env
+    g = synthetic.generate(shape, batch_size=batch, seed=seed, scale=scale)
+    rs = np.random.RandomState(seed)
+    params = otower.init_params(rs, g["n_user"], g["n_item"], g["n_domain"])
+    params["user_emb"] = g["tables"]["user_emb"].copy()
+    params["item_emb"] = g["tables"]["item_emb"].copy()
+    params["domain_emb"] = (rs.standard_normal(params["domain_emb"].shape) * 0.05).astype(F32)
+    for l in range(3):
+        params["b%d" % l] = (rs.standard_normal(params["b%d" % l].shape) * 0.05).astype(F32)
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=dropout)
+    eng.bind_table("user_emb", params["user_emb"])
+    eng.bind_table("item_emb", params["item_emb"])
+    for split in ("train", "val", "test"):
+        for d in range(g["n_domain"]):
+            c = g["data"][split][d]
+            eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
+    eng.set_weights(eng.pack(params))
+    model = otower.OracleModel({k: v.copy() for k, v in params.items()}, emb_trainable=False, dropout=dropout,
+                               lr=1e-3, dropout_seed=eng.dropout_seed)
+    return g, eng, model
+
+
+def same_bits(a, b):
+    return np.array_equal(np.asarray(a, F32).view(np.uint32), np.asarray(b, F32).view(np.uint32))
+
+
+# ------------------------------------------------------------------ K1 gather: bit-exact
+def test_gather_bit_exact(env):
+    g, eng, model = make_problem(env)
+    for d in (0, 3):
+        cols = g["data"]["train"][d]
+        n = cols["uid"].shape[0]
+        perm = orng.shuffle_perm(n, 10000, seed=5 + d)
+        out = eng.gather(d, "train", perm=torch.from_numpy(perm).to(eng.device)).cpu().numpy()
+        want = otower.gather(model.params, cols["uid"][perm], cols["pid"][perm], cols["domain"][perm])
+        assert same_bits(out, want)
+        # ragged window, file order
+        out = eng.gather(d, "train", first_row=3, n_rows=21).cpu().numpy()
+        want = otower.gather(model.params, cols["uid"][3:24], cols["pid"][3:24], cols["domain"][3:24])
+        assert same_bits(out, want)
+    eng.close()
+
+
+def test_shuffle_perm_matches_oracle(env):
+    engine, _ = env
+    for n, buf, seed in ((1, 10, 1), (100, 10, 2), (1000, 10000, 3), (5000, 128, 2 ** 63 + 5)):
+        assert np.array_equal(engine.shuffle_perm(n, buf, seed), orng.shuffle_perm(n, buf, seed))
+
+
+# ------------------------------------------------------------------ K7 outer updates: bit-exact
+def _flat(G, prefix, pad_to=None):
+    v = np.concatenate([G["%s_%d" % (prefix, i)].ravel() for i in range(int(G["n_tensors"]))])
+    return v
+
+
+def test_outer_updates_bit_exact_vs_reference_goldens(env, golden_dir):
+    engine, _ = env
+    G = np.load(os.path.join(golden_dir, "outer_goldens.npz"))
+    g, eng, _ = make_problem(env, scale=0.02)
+    dev = eng.device
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a, F32)).to(dev)
+
+    theta, new, new2, phi = (_flat(G, k) for k in ("theta", "new", "new2", "phi"))
+    n = theta.size                     # 2753: not a multiple of 4 -> exercises the scalar tail
+    assert n % 4 != 0
+    for lr_name, lr in (("lr0p1", 0.1), ("lr1", 1.0), ("lr0p5", 0.5)):
+        t = T(theta)
+        eng.interp(t, T(new), t, lr)                      # DN / Reptile / MAMDR-DN
+        assert same_bits(t.cpu().numpy(), _flat(G, "dn_" + lr_name))
+        assert same_bits(t.cpu().numpy(), _flat(G, "mamdr_dn_" + lr_name))
+        for method in ("plus", "times"):
+            merged = torch.empty(n, device=dev)
+            eng.merge(merged, T(theta), T(phi), method)
+            assert same_bits(merged.cpu().numpy(), _flat(G, "merged_" + method))
+            p = T(phi)
+            eng.interp(p, T(new), merged, lr)             # MAMDR DR: phi += (new - merged) * lr
+            assert same_bits(p.cpu().numpy(), _flat(G, "mamdr_dr_%s_%s" % (method, lr_name)))
+    # Reptile batch variant
+    acc = torch.zeros(n, device=dev)
+    t = T(theta)
+    eng.accumulate(acc, T(new), t)
+    eng.accumulate(acc, T(new2), t)
+    assert same_bits(acc.cpu().numpy(), _flat(G, "reptile_acc"))
+    eng.apply_accumulated(t, acc, 0.0, 0.1)
+    assert same_bits(t.cpu().numpy(), _flat(G, "reptile_batch"))
+    assert not acc.cpu().numpy().any()
+    # MAMDR batch variant + phi = new - merged
+    for method in ("plus", "times"):
+        merged = torch.empty(n, device=dev)
+        eng.merge(merged, T(theta), T(phi), method)
+        acc = torch.zeros(n, device=dev)
+        shared = T(theta) if method == "times" else None
+        eng.accumulate(acc, T(new), merged, shared, 1.0)
+        eng.accumulate(acc, T(new2), merged, shared, 1.0)
+        assert same_bits(acc.cpu().numpy(), _flat(G, "mamdr_acc_" + method))
+        p = T(phi)
+        eng.apply_accumulated(p, acc, 5.0, 0.1)
+        assert same_bits(p.cpu().numpy(), _flat(G, "mamdr_batch_" + method))
+        dw = torch.empty(n, device=dev)
+        eng.sub(dw, T(new), merged)
+        assert same_bits(dw.cpu().numpy(), _flat(G, "mamdr_domain_weights_" + method))
+    eng.close()
+
+
+def test_outer_updates_random_vs_oracle_large(env):
+    """full flat-vector size, random data, vs oracle/outer.py (itself pinned to the goldens)."""
+    g, eng, _ = make_problem(env, scale=0.02)
+    rs = np.random.RandomState(3)
+    n = eng.n_params
+    a, b, c = ((rs.standard_normal(n) * 0.1).astype(F32) for _ in range(3))
+    ta, tb, tc = (torch.from_numpy(x).to(eng.device) for x in (a, b, c))
+    t = ta.clone()
+    eng.interp(t, tb, tc, 0.1)
+    assert same_bits(t.cpu().numpy(), oouter.mamdr_update(a.copy(), b, c, 0.1))
+    # scale 0 is the identity, bit-for-bit
+    t = ta.clone()
+    eng.interp(t, tb, tc, 0.0)
+    assert same_bits(t.cpu().numpy(), a)
+    eng.close()
+
+
+# ------------------------------------------------------------------ inner step vs oracle
+def _grad_via_sgd(eng, d, perm_t, step, bs):
+    """SGD with lr=1 turns the update into p_old - p_new = gradient."""
+    before = eng.get_weights().cpu().numpy()
+    eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", batch_size=bs)
+    after = eng.get_weights().cpu().numpy()
+    return before - after
+
+
+@pytest.mark.parametrize("dropout", [0.5, 0.0])
+def test_one_step_gradients_match_oracle(env, dropout):
+    g, eng, model = make_problem(env, batch=256, dropout=dropout)
+    d = 5
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=11)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    bs = 256
+    n_step = -(-n // bs)
+    for step in (0, n_step - 1):          # a full batch and the final (partial) batch
+        idx = perm[step * bs:(step + 1) * bs]
+        masks = otower.train_masks(model.seed, model.step, len(idx), model.hidden, dropout) if dropout > 0 else None
+        if masks is None:
+            masks = [np.ones((len(idx), h), F32) for h in model.hidden]
+        loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx],
+                                               cols["domain"][idx], cols["label"][idx], masks, dropout, False)
+        want = eng.pack({**{k: np.zeros_like(v) for k, v in model.params.items()}, **grads}).cpu().numpy()
+        loss_t = torch.zeros(1, device=eng.device)
+        w0 = eng.get_weights()
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", batch_size=bs,
+                        loss_out=loss_t)
+        got = (w0 - eng.get_weights()).cpu().numpy()
+        eng.set_weights(w0)               # undo the lr=1 step; dropout counter advanced by 1
+        model.step += 1
+        # tolerance: fp32 contractions with different summation order; gradients are O(1e-3)
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6 * max(scale, 1e-3))
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    eng.close()
+
+
+def test_adam_pass_matches_oracle(env):
+    """a whole shuffled pass (incl. the partial batch) with Adam + dropout."""
+    g, eng, model = make_problem(env, batch=256, dropout=0.5)
+    d = 9
+    cols = g["data"]["train"][d]
+    perm = orng.shuffle_perm(cols["uid"].shape[0], 10000, seed=3)
+    n_steps = min(6, -(-perm.shape[0] // 256))
+    losses_t = torch.zeros(n_steps, device=eng.device)
+    eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), n_steps=n_steps, lr=1e-3, loss_out=losses_t)
+    want_losses = model.train_pass(cols, perm, 256, max_steps=n_steps)
+    got = eng.unpack(eng.get_weights())
+    np.testing.assert_allclose(losses_t.cpu().numpy(), np.array(want_losses, F32), rtol=2e-5, atol=2e-6)
+    # Adam normalises the step to ~lr per element, so compare in units of lr: after k steps
+    # two fp32 evaluations stay within a small fraction of k*lr of each other.
+    for name in model.names:
+        diff = np.abs(got[name].reshape(model.params[name].shape) - model.params[name]).max()
+        assert diff < 0.05 * n_steps * 1e-3, (name, diff)
+    assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == n_steps == model.opt.t
+    eng.close()
+
+
+# ------------------------------------------------------------------ eval: loss, AUC bins
+def test_eval_matches_oracle_and_auc_bins_exact(env):
+    g, eng, model = make_problem(env, batch=256, dropout=0.5)
+    thr = oauc.thresholds(500)
+    for d in (0, 5):
+        cols = g["data"]["val"][d]
+        loss, auc, hist, preds = eng.evaluate(d, "val", want_preds=True)
+        want_loss, want_preds = model.evaluate(cols, 256)
+        np.testing.assert_allclose(preds, want_preds, rtol=2e-5, atol=2e-6)
+        assert abs(loss - float(want_loss)) < 2e-6 * max(1.0, abs(float(want_loss)))
+        # AUC confusion counts are exact integers for the kernel's own predictions
+        tp, fp, tn, fn = oauc.confusion_counts(cols["label"], preds, thr)
+        from mamdr_amd.engine import auc_from_histogram
+        got_auc, (gtp, gfp, gtn, gfn) = auc_from_histogram(hist)
+        for a, b in ((tp, gtp), (fp, gfp), (tn, gtn), (fn, gfn)):
+            assert np.array_equal(a, b)
+        assert got_auc == float(oauc.auc_from_counts(tp, fp, tn, fn))
+        # and the AUC of the two paths agrees far inside the 1e-3 bar
+        assert abs(auc - float(oauc.auc500(cols["label"], want_preds, 256))) < 1e-4
+    eng.close()
+
+
+# ------------------------------------------------------------------ meta loop: AUC within 1e-3
+def test_mamdr_epoch_auc_parity(env):
+    """one DN+DR epoch on a small 4-domain problem, same sequences / perms / masks."""
+    engine, synthetic = env
+    from mamdr_amd import meta
+    shape = dict(synthetic.SHAPES["taobao10"], n_domain=4)
+    g, eng, model = make_problem(env, scale=0.03, batch=256, dropout=0.5, shape=shape)
+    D = g["n_domain"]
+    plan = {"seq": [2, 0, 3, 1], "dr": [(2, [0, 3, 2]), (0, [1, 2, 0]), (3, [2, 1, 3]), (1, [3, 0, 1])]}
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+
+    def make_perm_fn():
+        counter = [0]
+
+        def perm_fn(d):
+            counter[0] += 1
+            return orng.shuffle_perm(sizes[d], 10000, seed=1000 + counter[0])
+        return perm_fn
+
+    rs = np.random.RandomState(5)
+    theta0 = model.get_flat().copy()
+    phis0 = [(rs.standard_normal(theta0.size) * 0.01).astype(F32) for _ in range(D)]
+    # --- oracle
+    theta_o = theta0.copy()
+    phis_o = [p.copy() for p in phis0]
+    trace_o = oloops.mamdr_epoch(model, theta_o, phis_o, g["data"]["train"], plan, make_perm_fn(), 256, 0.1)
+    # --- HIP path
+    def to_dev(flat):
+        named, o = {}, 0
+        for nme in model.names:
+            sz = model.params[nme].size
+            named[nme] = flat[o:o + sz]
+            o += sz
+        return eng.pack(named)
+
+    theta_g = to_dev(theta0)
+    phis_g = [to_dev(p) for p in phis0]
+    trace_g = meta.mamdr_epoch(eng, theta_g, phis_g, plan, make_perm_fn(), 256, lr=1e-3, meta_lr=0.1)
+    assert trace_g == trace_o
+    # per-domain val AUC with merged weights theta + phi_d
+    merged = eng.new_vector()
+    for d in range(D):
+        eng.merge(merged, theta_g, phis_g[d], "plus")
+        eng.set_weights(merged)
+        _, auc_g = eng.evaluate(d, "val")
+        model.set_flat(oouter.merge(theta_o, phis_o[d], "plus"))
+        _, preds = model.evaluate(g["data"]["val"][d], 256)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+    eng.close()
+
+
+# ------------------------------------------------------------------ full size: size-independent properties
+def test_full_size_properties_taobao10(env):
+    """BASELINE config sizes (Taobao-10, bs 1024): bit-exact gather, bitwise run-to-run
+    determinism of a pass (no float atomics), loss goes down, AUC leaves 0.5."""
+    g, eng, model = make_problem(env, scale=1.0, batch=1024, dropout=0.5)
+    d = 5                                     # the largest domain (31k rows)
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=77)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    out = eng.gather(d, "train", perm=perm_t).cpu().numpy()
+    assert same_bits(out, otower.gather(model.params, cols["uid"][perm], cols["pid"][perm], cols["domain"][perm]))
+    n_steps = -(-n // 1024)
+    losses = torch.zeros(n_steps, device=eng.device)
+    _, auc_before = eng.evaluate(d, "val")
+    eng.train_steps(d, perm=perm_t, lr=1e-3, loss_out=losses)
+    w1 = eng.get_weights().cpu().numpy()
+    _, auc_after = eng.evaluate(d, "val")
+    assert np.isfinite(w1).all()
+    l = losses.cpu().numpy()
+    assert l[-3:].mean() < l[:3].mean()
+    assert auc_after > max(0.55, auc_before - 0.02)
+    eng.close()
+    # determinism without dropout: two engines, same inputs -> same bits after a full pass
+    outs = []
+    for _ in range(2):
+        g2, e2, _ = make_problem(env, scale=1.0, batch=1024, dropout=0.0)
+        e2.train_steps(d, perm=perm_t, lr=1e-3)
+        outs.append(e2.get_weights().cpu().numpy())
+        e2.close()
+    assert same_bits(outs[0], outs[1])
