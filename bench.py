@@ -1,0 +1,252 @@
+"""bench.py -- domain-steps/sec of the MAMDR hot path on N MI355X GPUs of one node.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
+launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): mlp_meta_mamdr, Taobao-10 shaped synthetic
+click logs, batch 1024, pretrained 128-d tables frozen, Adam lr 1e-3, dropout 0.5,
+meta lr 0.1, 5 sampled support domains + the query domain (config/Taobao-10/
+deepctr_DN+DR.json).  ONE bench "step" = one full MAMDR meta-epoch (DN phase over all
+domains, then the DR phase: for every query domain and every support domain, a pass
+over the support domain and a pass over the query domain, with all outer updates),
+i.e. `domain_steps_per_epoch` inner optimisation steps (gather + MLP fwd/bwd + BCE +
+Adam).  value = inner domain-steps executed by all ranks / wall time of the K epochs
+(max over ranks), inputs resident in HBM, per-pass shuffles generated and uploaded
+inside the timed region, no eval inside it.
+
+N > 1: query domains (DR) and the DN sub-sequences are sharded over the ranks with a
+single all-reduce of the DN displacement per epoch (mamdr_amd/parallel.py); total
+work is fixed -> "scaling": "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector peak)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+# algorithmic flops per batch row of k_tower<train> (kernel table):
+#   forward 384*256 + 256*128 + 128*64 + 64 MACs, backward chain 64*128 + 128*256 + 256*128 MACs
+TOWER_TRAIN_FLOPS_PER_ROW = 2 * ((384 * 256 + 256 * 128 + 128 * 64 + 64) + (64 * 128 + 128 * 256 + 256 * 128))
+GATHER_BYTES_PER_ROW = 3 * 128 * 4 * 2 + 16   # read 3 rows + write 384 floats + 4 index/label words
+
+WORKLOADS = {
+    "taobao10": dict(shape="taobao10", batch=1024, name="mlp_meta_mamdr Taobao-10 bs=1024 (frozen pretrained tables)"),
+    "taobao30": dict(shape="taobao30", batch=4096, name="mlp_meta_mamdr Taobao-30 bs=4096 (frozen pretrained tables)"),
+}
+TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
+             merged_method="plus", shuffle_buffer_size=10000, seed=123)
+
+
+def init_params(g, seed=1024):
+    """random-init weights of the reference architecture (deepctr.py:118-136 initialisers)."""
+    rs = np.random.RandomState(seed)
+    p = {"domain_emb": (rs.standard_normal((g["n_domain"], 128)) * 1e-4).astype(np.float32)}
+    dims = (384, 256, 128, 64)
+    for l in range(3):
+        s = np.sqrt(2.0 / (dims[l] + dims[l + 1]))
+        p["W%d" % l] = (np.clip(rs.standard_normal((dims[l], dims[l + 1])), -2, 2) * s).astype(np.float32)
+        p["b%d" % l] = np.zeros(dims[l + 1], np.float32)
+    p["wo"] = (np.clip(rs.standard_normal((64, 1)), -2, 2) * np.sqrt(2.0 / 65)).astype(np.float32)
+    p["gb"] = np.zeros(1, np.float32)
+    return p
+
+
+def setup_engine(g, batch):
+    from mamdr_amd import engine
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=TRAIN["dropout"])
+    eng.bind_table("user_emb", g["tables"]["user_emb"])
+    eng.bind_table("item_emb", g["tables"]["item_emb"])
+    for d in range(g["n_domain"]):
+        c = g["data"]["train"][d]
+        eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+    return eng
+
+
+def cpu_baseline(g, batch, budget_s=15.0):
+    """the oracle (numpy restatement of the TF1.12 path) timed on this box's host cores on
+    the first domain-steps of the same workload; TF itself is not installable."""
+    from oracle import rng as orng
+    from oracle import tower as otower
+    params = init_params(g)
+    params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
+    model = otower.OracleModel(params, emb_trainable=False, dropout=TRAIN["dropout"], lr=TRAIN["learning_rate"])
+    d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, TRAIN["shuffle_buffer_size"], 1)
+    steps, t0 = 0, time.time()
+    while time.time() - t0 < budget_s:
+        for s in range(-(-n // batch)):
+            idx = perm[s * batch:(s + 1) * batch]
+            model.train_on_batch(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
+            steps += 1
+            if time.time() - t0 >= budget_s:
+                break
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": steps / dt, "unit": "domain-steps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d inner steps (bs=%d, domain %d of the same synthetic workload) of the numpy fp32 oracle "
+                      "in %.1f s; restatement of the TF1.12 CPU path, not TF" % (steps, batch, d, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed MAMDR meta-epochs")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="taobao10", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    from mamdr_amd import _lib as L
+    from mamdr_amd import meta, parallel, plan as mplan, synthetic
+
+    wl = WORKLOADS[args.workload]
+    batch = wl["batch"]
+    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"])
+    D = g["n_domain"]
+    eng = setup_engine(g, batch)
+    sizes = [eng.n_rows(d, "train") for d in range(D)]
+    steps_per_domain = [-(-n // batch) for n in sizes]
+    theta = eng.pack(init_params(g))
+    owner = parallel.lpt_partition(sizes, world)
+    # phi_d starts as a second random init of the whole model (mamdr.py:31-33)
+    phis = {d: eng.pack(init_params(g, seed=2000 + d)) for d in range(D) if owner[d] == rank}
+    bufs = {"delta": eng.new_vector(), "zero": eng.new_vector(), "merged": eng.new_vector()}
+    planner = mplan.EpochPlanner(range(D), TRAIN["sample_num"], TRAIN["add_query_domain"], True, TRAIN["seed"])
+    shuffler = mplan.PassShuffler(sizes, TRAIN["shuffle_buffer_size"], TRAIN["seed"] + rank)
+
+    def epoch():
+        p = planner.next_epoch()          # same seed on every rank -> same global plan
+        tr = parallel.mamdr_epoch_sharded(eng, meta, theta, phis, p, owner, shuffler, batch,
+                                          TRAIN["learning_rate"], TRAIN["meta_learning_rate"], bufs,
+                                          TRAIN["merged_method"])
+        return tr, mplan.plan_steps(p, steps_per_domain)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        epoch()
+    barrier()
+    t0 = time.perf_counter()
+    local_steps, global_steps = 0, 0
+    for _ in range(args.steps):
+        tr, b = epoch()
+        local_steps += sum(t[2] for t in tr)
+        global_steps += b
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, float(local_steps)], dtype=torch.float64, device=eng.device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        assert int(round(float(t[1]))) == global_steps, (float(t[1]), global_steps)
+
+    # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
+    #      the same workload; reported for the dominant kernel, k_tower<train>
+    roofline, gather_info, kernels = None, None, {}
+    if not args.no_profile:
+        eng.profile(True)
+        eng.profile_reset()
+        prof_trace, _ = epoch()
+        for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE):
+            ms, cnt = eng.profile_read(k)
+            kernels[L.KERNEL_NAMES[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
+        roofline_ms, cnt = eng.profile_read(L.KERNEL_FWD_BWD)
+        eng.profile(False)
+        eng.profile_reset()
+        # every launch is one batch; a pass of n_steps launches covers min(rows of the domain, n_steps*batch) rows
+        prof_rows = sum(min(sizes[d], n * batch) for (_, d, n) in prof_trace)
+        assert cnt == sum(n for (_, _, n) in prof_trace)
+        roofline = finish_roofline("k_tower<train>", roofline_ms, cnt, prof_rows)
+        # gather kernel on a pass-sized batch (largest domain, shuffled order)
+        dbig = max(range(D), key=lambda k: sizes[k])
+        perm = torch.from_numpy(shuffler(dbig)).to(eng.device)
+        out = torch.empty((sizes[dbig], 384), dtype=torch.float32, device=eng.device)
+        for _ in range(3):
+            eng.gather(dbig, "train", perm=perm, out=out)
+        eng.profile(True)
+        eng.profile_reset()
+        for _ in range(20):
+            eng.gather(dbig, "train", perm=perm, out=out)
+        gms, gcnt = eng.profile_read(L.KERNEL_GATHER)
+        eng.profile(False)
+        eng.profile_reset()
+        gbytes = sizes[dbig] * GATHER_BYTES_PER_ROW
+        gach = gbytes / (gms / gcnt * 1e-3) / 1e9
+        gather_info = {"kernel": "k_gather", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": gach / PEAK_HBM_GBS, "traffic": None, "rows_per_launch": sizes[dbig],
+                       "note": "standalone pass-sized gather of the same tile code the step kernel uses; "
+                               "Taobao tables (15.7 MB) are cache-resident, the 48 MB output is not"}
+    result = None
+    if rank == 0:
+        cpu = cpu_baseline(g, batch, args.cpu_budget) if args.cpu_budget > 0 else None
+        result = {
+            "metric": "domain-steps/sec", "value": global_steps / dt, "unit": "domain-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "global_batch": batch, "domains": D,
+                       "domain_steps_per_epoch": global_steps / args.steps,
+                       "step_definition": "one MAMDR meta-epoch (DN + DR phases, all outer updates)",
+                       "parallelism": "domain-sharded x%d, 1 all-reduce of the DN displacement per epoch" % world
+                       if world > 1 else "single GPU"},
+            "us_per_domain_step": dt / global_steps * 1e6 * world,
+            "roofline": roofline, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
+        }
+        if cpu:
+            result["gpu_over_cpu"] = result["value"] / cpu["value"]
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return result
+
+
+def finish_roofline(kernel, total_ms, launches, rows):
+    """achieved = algorithmic flops of all profiled launches / their summed device time
+    (= flops per average launch / average launch duration)."""
+    flops = rows * TOWER_TRAIN_FLOPS_PER_ROW
+    ach = flops / (total_ms * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches": launches,
+            "avg_us": total_ms / max(launches, 1) * 1e3, "rows_per_launch": rows / max(launches, 1),
+            "flops_per_row": TOWER_TRAIN_FLOPS_PER_ROW}
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it carries its own libamdhip64; loading ours afterwards binds to that
+    # same runtime instance, which sharing streams and device pointers with torch requires
+    # (two HIP runtimes in one process -> "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the MAMDR hot path)" % LIB_PATH)

@@ -1,0 +1,80 @@
+"""Host-side randomness of the meta loops, made explicit and seedable.
+
+The reference draws the domain order and the DR support domains from python's
+unseeded `random` module (model_zoo/mamdr.py:45-46,65-70,
+domain_negotiation.py:41-42, reptile.py:45) and reshuffles every pass through
+tf.data (utils/dataset.py:27-37).  Here the same decisions come from a seeded
+`random.Random`, so runs are reproducible and the oracle can replay them.
+"""
+import random
+
+from . import engine as _engine
+
+
+class EpochPlanner(object):
+    """per-epoch domain order + DR support samples (mamdr.py:44-70)."""
+
+    def __init__(self, domains, sample_num=5, add_query_domain=True, shuffle_sequence=True, seed=123):
+        self.seq = list(domains)
+        self.sample_num = int(sample_num)
+        self.add_query_domain = bool(add_query_domain)
+        self.shuffle_sequence = bool(shuffle_sequence)
+        self.rng = random.Random(seed)
+
+    def next_sequence(self):
+        """random.shuffle(train_sequence) (mamdr.py:45-46): shuffles the persistent list in place."""
+        if self.shuffle_sequence:
+            self.rng.shuffle(self.seq)
+        return list(self.seq)
+
+    def next_epoch(self, with_dr=True):
+        seq = self.next_sequence()
+        plan = {"seq": seq, "dr": []}
+        if with_dr:
+            for idx in seq:
+                cand = list(seq)
+                cand.remove(idx)                                     # mamdr.py:66-67
+                aux = self.rng.sample(cand, k=min(self.sample_num, len(cand)))
+                if self.add_query_domain:
+                    aux.append(idx)                                  # mamdr.py:69-70
+                plan["dr"].append((idx, aux))
+        return plan
+
+
+def _mix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+class PassShuffler(object):
+    """perm_fn(d): a fresh tf.data-style shuffle of domain d's train rows for every pass
+    (iterator re-initialisation, mamdr.py:52-53,81-82,92-93).  Seeds are
+    mix(base_seed, pass counter); `shuffle_fn` lets the oracle substitute its own
+    restatement of the same stream."""
+
+    def __init__(self, sizes, buffer_size=10000, seed=123, shuffle=True, shuffle_fn=None):
+        self.sizes = sizes
+        self.buffer_size = int(buffer_size)
+        self.seed = int(seed)
+        self.counter = 0
+        self.shuffle = shuffle
+        self.shuffle_fn = shuffle_fn or _engine.shuffle_perm
+
+    def __call__(self, d):
+        if not self.shuffle:
+            return None
+        self.counter += 1
+        return self.shuffle_fn(self.sizes[d], self.buffer_size, _mix64(self.seed * 0x10001 + self.counter))
+
+
+def plan_steps(plan, steps_per_domain, domain_regulation_step=0):
+    """number of domain-steps a plan executes (metric accounting)."""
+    n = sum(steps_per_domain[d] for d in plan["seq"])
+    for q, support in plan["dr"]:
+        qs = steps_per_domain[q]
+        if domain_regulation_step and domain_regulation_step > 0:
+            qs = min(qs, domain_regulation_step)
+        n += sum(steps_per_domain[j] + qs for j in support)
+    return n

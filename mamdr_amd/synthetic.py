@@ -6,8 +6,10 @@ throughput and parity are measured on generated logs with the published shapes
 totals; long-tailed domain sizes (Zipf s=1 over domains, each >= one batch);
 per-domain positive rate r/(1+r) with r = round(U[0.2,0.5], 2)
 (dataset/Taobao/split.py:110-112,50); every domain draws users and items from
-its own subset; labels are Bernoulli draws from a planted model
-sigma(s <u,i> + b_d) over the "pretrained" tables, so AUC is well above 0.5.
+its own subset; labels are Bernoulli draws from a planted model over the
+"pretrained" tables, sigma(s (<a_d,u> + <b_d,i>) + s/2 <u,i> + c_d) with a_d, b_d a
+shared direction plus a domain-specific one, so that AUC is well above 0.5 and
+domains are related but not identical.
 Columns match the reference's csv header uid,pid,domain,label (split.py:21).
 """
 import numpy as np
@@ -47,6 +49,7 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
     n_item = max(int(spec["n_item"] * scale), 4 * D)
     user_emb = (rs.standard_normal((n_user, emb_dim)) * 0.1).astype(np.float32)
     item_emb = (rs.standard_normal((n_item, emb_dim)) * 0.1).astype(np.float32)
+    dir_shared = rs.standard_normal((2, emb_dim)) / np.sqrt(emb_dim)
     min_size = max(1, int(batch_size * min(1.0, scale))) if scale < 1.0 else batch_size
     sizes = {}
     for split in ("train", "val", "test"):
@@ -65,11 +68,13 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
         users = rs.choice(n_user, n_u_d, replace=False)
         items = rs.choice(n_item, n_i_d, replace=False)
         info[d] = {"ctr_ratio": r}
+        dir_d = dir_shared + 0.7 * rs.standard_normal((2, emb_dim)) / np.sqrt(emb_dim)
         for split in ("train", "val", "test"):
             n = int(sizes[split][d])
             uid = users[rs.randint(0, n_u_d, n)].astype(np.int32)
             pid = items[rs.randint(0, n_i_d, n)].astype(np.int32)
-            logit = signal * np.einsum("ij,ij->i", user_emb[uid], item_emb[pid]).astype(np.float64) + bias
+            ue, ie = user_emb[uid].astype(np.float64), item_emb[pid].astype(np.float64)
+            logit = signal * (ue @ dir_d[0] + ie @ dir_d[1]) + 0.5 * signal * np.einsum("ij,ij->i", ue, ie) + bias
             label = (rs.uniform(size=n) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
             data[split][d] = {"uid": uid, "pid": pid, "domain": np.full(n, d, np.int32), "label": label}
             info[d]["n_" + split] = n

@@ -307,6 +307,8 @@ def test_full_size_properties_taobao10(env):
     losses = torch.zeros(n_steps, device=eng.device)
     _, auc_before = eng.evaluate(d, "val")
     eng.train_steps(d, perm=perm_t, lr=1e-3, loss_out=losses)
+    for _ in range(3):
+        eng.train_steps(d, perm=perm_t, lr=1e-3)
     w1 = eng.get_weights().cpu().numpy()
     _, auc_after = eng.evaluate(d, "val")
     assert np.isfinite(w1).all()
