@@ -85,6 +85,9 @@ struct mamdr_ctx {
     float* thresholds = nullptr;
     float* frozen_sumsq = nullptr;  // [2]
     float* sumsq_partials = nullptr;
+#ifdef MAMDR_STAMPS
+    unsigned long long* stamps = nullptr;
+#endif
     // profiling
     bool profile = false;
     std::vector<EventPair> ev[MAMDR_KERNEL_COUNT];
@@ -399,6 +402,9 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.dxe = c->dxe;
         ta.domrow = c->domrow;
         ta.loss_part = c->loss_part;
+#ifdef MAMDR_STAMPS
+        ta.stamps = c->stamps;
+#endif
         {
             Prof p(c, MAMDR_KERNEL_FWD_BWD);
             launch_tower_train(ta, c->stream);
@@ -604,6 +610,14 @@ int mamdr_shuffle_perm(int64_t n, int64_t buffer_size, uint64_t seed, int32_t* h
     }
     return MAMDR_OK;
 }
+
+#ifdef MAMDR_STAMPS
+// diagnostic build only (tools/stamp_tower.py)
+int mamdr_debug_set_stamps(mamdr_ctx* c, unsigned long long* d_stamps) {
+    c->stamps = d_stamps;
+    return MAMDR_OK;
+}
+#endif
 
 // ---- profiling
 int mamdr_profile_enable(mamdr_ctx* c, int32_t enable) {

@@ -42,6 +42,9 @@ struct TowerArgs {
     const float* thresholds;   // 500 fp32 AUC thresholds
     uint32_t* hist;            // [2][501]
     float* pred_out;           // nullable, [n_rows] in position order
+#ifdef MAMDR_STAMPS
+    unsigned long long* stamps; // diagnostic build only: [tiles][16] s_memtime stamps
+#endif
 };
 
 // weight-gradient GEMMs (K = batch rows) + bias / output-layer / domain-table sums

@@ -65,39 +65,89 @@ __device__ __forceinline__ void mfma_fwd_chunk(f32x4 (&acc)[TPW], const f32x4 a,
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b[s][t], acc[t]);
 }
+// one tile per wave (the 64-wide layer): a single accumulator would serialise on the
+// 40-cycle dependent latency of v_mfma_f32_16x16x4_f32, so even / odd sub-steps use two chains
+__device__ __forceinline__ void mfma_fwd_chunk2(f32x4& acc0, f32x4& acc1, const f32x4 a, const float (&b)[4][1]) {
+    acc0 = MAMDR_MFMA16(a[0], b[0][0], acc0);
+    acc1 = MAMDR_MFMA16(a[1], b[1][0], acc1);
+    acc0 = MAMDR_MFMA16(a[2], b[2][0], acc0);
+    acc1 = MAMDR_MFMA16(a[3], b[3][0], acc1);
+}
 
-// H[16 x N] = relu(A[16 x K] . W[K x N] + bias) (* dropout).  Wave w owns N/4
-// consecutive columns; lane (j = lane & 15) owns TPW consecutive columns of them, so
-// one 4/8/16-byte load per k row feeds TPW MFMAs, and the k index inside each
+// ---- forward layer: H[16 x N] = relu(A[16 x K] . W[K x N] + bias) (* dropout).
+// Wave w owns N/4 consecutive columns; lane (j = lane & 15) owns TPW consecutive columns of
+// them, so one 4/8/16-byte load per k row feeds TPW MFMAs, and the k index inside each
 // 16-deep chunk is permuted identically for A and B (slot k' of sub-step s is
 // k = kk0 + 4 k' + s), which turns the A fragment into one ds_read_b128.
-template <int K, int N, int LDA, int LDO, bool TRAIN>
-__device__ __forceinline__ void fwd_layer(const float* __restrict__ W, const float* __restrict__ bias,
-                                          const float* As, float* Os, float* gout, uint32_t key,
-                                          uint32_t thresh, float scale, bool use_dropout, int row0) {
+// The weight stream is independent of the activations: a PF-deep register ring keeps PF
+// chunks (PF x 4 KiB per wave for the widest layer) in flight from L2, and the first PF
+// chunks of a layer are requested before the barrier that publishes its input.
+template <int K, int N, int PF>
+struct FwdW {
+    static constexpr int TPW = N / 64;
+    static constexpr int NC = K / 16;
+    float b[PF][4][TPW];
+    const float* wp;
+    int ncol;
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        ncol = w * (16 * TPW) + TPW * (lane & 15);
+        wp = W + (size_t)(4 * (lane >> 4)) * N + ncol;
+#pragma unroll
+        for (int c = 0; c < PF && c < NC; ++c) load_b_rows<TPW>(b[c], wp + (size_t)(16 * c) * N, N);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <int K, int N, int LDA, int LDO, bool TRAIN, int PF>
+__device__ __forceinline__ void fwd_layer(FwdW<K, N, PF>& fw, const float* __restrict__ bias, const float* As,
+                                          float* Os, float* gout, uint32_t key, uint32_t thresh, float scale,
+                                          bool use_dropout, int row0) {
     constexpr int TPW = N / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NC = K / 16;
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
-    const int ncol = w * (16 * TPW) + TPW * j;
+    const int ncol = fw.ncol;
     f32x4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float bv = bias[ncol + t];
         acc[t] = (f32x4){bv, bv, bv, bv};
     }
-    const float* wp = W + (size_t)(4 * kq) * N + ncol;
     const float* ap = As + j * LDA + 4 * kq;
-    float b0[4][TPW], b1[4][TPW];
-    load_b_rows<TPW>(b0, wp, N);
+    static_assert(NC % PF == 0, "chunk count must be a multiple of the ring depth");
+    // main groups: compute chunk c0+u from ring slot u, then refill the slot with chunk
+    // c0+u+PF.  sched_barrier pins each refill right behind its chunk (the scheduler
+    // otherwise sinks the loads to their use and serialises on vmcnt(0)).
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(ap);
+    f32x4 acc_odd = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int kk0 = 0; kk0 < K; kk0 += 32) {
-        load_b_rows<TPW>(b1, wp + (size_t)(kk0 + 16) * N, N);
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk0);
-        mfma_fwd_chunk<TPW>(acc, a, b0);
-        if (kk0 + 32 < K) load_b_rows<TPW>(b0, wp + (size_t)(kk0 + 32) * N, N);
-        a = *reinterpret_cast<const f32x4*>(ap + kk0 + 16);
-        mfma_fwd_chunk<TPW>(acc, a, b1);
+    for (int c0 = 0; c0 < NC - PF; c0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            // A fragment of the NEXT chunk is requested before this chunk's MFMAs
+            const f32x4 a_next = *reinterpret_cast<const f32x4*>(ap + 16 * (c0 + u + 1));
+            __builtin_amdgcn_sched_barrier(0);   // keep the read ahead of the MFMAs
+            if constexpr (TPW == 1) mfma_fwd_chunk2(acc[0], acc_odd, a_cur, fw.b[u]);
+            else mfma_fwd_chunk<TPW>(acc, a_cur, fw.b[u]);
+#ifndef MAMDR_ABLATE_LOADS   // diagnostic builds only: time the loop without its weight stream
+            load_b_rows<TPW>(fw.b[u], fw.wp + (size_t)(16 * (c0 + u + PF)) * N, N);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            a_cur = a_next;
+        }
     }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        f32x4 a_next = a_cur;
+        if (u + 1 < PF) a_next = *reinterpret_cast<const f32x4*>(ap + 16 * (NC - PF + u + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TPW == 1) mfma_fwd_chunk2(acc[0], acc_odd, a_cur, fw.b[u]);
+        else mfma_fwd_chunk<TPW>(acc, a_cur, fw.b[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_next;
+    }
+    if constexpr (TPW == 1) acc[0] += acc_odd;
     typedef typename VecT<TPW>::type V;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -124,48 +174,94 @@ __device__ __forceinline__ void fwd_layer(const float* __restrict__ W, const flo
     }
 }
 
-// dH[16 x N] = dZ[16 x K] . W^T, W stored [N][LDW] with the reduction index contiguous.
-// Lane (j, k') loads 16 B of row (n0 + 16 t + j) at k = kk0 + 4 k' .. +3: sub-step s uses
-// component s, the same k permutation as the A fragment.
-template <int K, int N, int LDW, int LDA, typename Epi>
-__device__ __forceinline__ void bwd_layer(const float* __restrict__ W, const float* As, Epi epi) {
+// ---- backward layer: dH[16 x N] = dZ[16 x K] . W^T, W stored [N][LDW] with the reduction
+// index contiguous.  Chunks are 32 deep: lane (j, k') loads the 32 B at row (n0 + 16 t + j),
+// k = kk0 + 8 k' .. +7 as two 16-B loads, so the four k' lanes of a row consume one whole
+// 128-B line; sub-step s of the chunk uses component s (slot k' <-> k = kk0 + 8 k' + s), the
+// same permutation as the A fragment (two ds_read_b128).
+template <int K, int N, int LDW, int PF>
+struct BwdW {
+    static constexpr int TPW = N / 64;
+    static constexpr int NC = K / 32;
+    f32x4 b[PF][TPW][2];
+    const float* wp;
+    int nbase;
+    __device__ __forceinline__ void load(int slot, int c) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const float* q = wp + (size_t)(16 * t) * LDW + 32 * c;
+            b[slot][t][0] = *reinterpret_cast<const f32x4*>(q);
+            b[slot][t][1] = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        nbase = w * (16 * TPW);
+        wp = W + (size_t)(nbase + (lane & 15)) * LDW + 8 * (lane >> 4);
+#pragma unroll
+        for (int c = 0; c < PF && c < NC; ++c) load(c, c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <int TPW>
+__device__ __forceinline__ void mfma_bwd_chunk(f32x4 (&acc)[TPW], const f32x4 a0, const f32x4 a1,
+                                               const f32x4 (&b)[TPW][2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a0[s], b[t][0][s], acc[t]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a1[s], b[t][1][s], acc[t]);
+}
+
+template <int K, int N, int LDW, int LDA, int PF, typename Epi>
+__device__ __forceinline__ void bwd_layer(BwdW<K, N, LDW, PF>& bw, const float* As, Epi epi) {
     constexpr int TPW = N / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NC = K / 32;
+    static_assert(NC % PF == 0, "chunk count must be a multiple of the ring depth");
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
-    const int nbase = w * (16 * TPW);
     f32x4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wp = W + (size_t)(nbase + j) * LDW + 4 * kq;
-    const float* ap = As + j * LDA + 4 * kq;
-    f32x4 b0[TPW], b1[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) b0[t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t) * LDW);
+    const float* ap = As + j * LDA + 8 * kq;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
 #pragma unroll 1
-    for (int kk0 = 0; kk0 < K; kk0 += 32) {
+    for (int c0 = 0; c0 < NC - PF; c0 += PF) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
-            b1[t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t) * LDW + kk0 + 16);
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b0[t][s], acc[t]);
-        if (kk0 + 32 < K) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                b0[t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t) * LDW + kk0 + 32);
+        for (int u = 0; u < PF; ++u) {
+            const f32x4 n0 = *reinterpret_cast<const f32x4*>(ap + 32 * (c0 + u + 1));
+            const f32x4 n1 = *reinterpret_cast<const f32x4*>(ap + 32 * (c0 + u + 1) + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_bwd_chunk<TPW>(acc, a0, a1, bw.b[u]);
+#ifndef MAMDR_ABLATE_LOADS
+            bw.load(u, c0 + u + PF);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0;
+            a1 = n1;
         }
-        a = *reinterpret_cast<const f32x4*>(ap + kk0 + 16);
+    }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b1[t][s], acc[t]);
+    for (int u = 0; u < PF; ++u) {
+        f32x4 n0 = a0, n1 = a1;
+        if (u + 1 < PF) {
+            n0 = *reinterpret_cast<const f32x4*>(ap + 32 * (NC - PF + u + 1));
+            n1 = *reinterpret_cast<const f32x4*>(ap + 32 * (NC - PF + u + 1) + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_bwd_chunk<TPW>(acc, a0, a1, bw.b[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0;
+        a1 = n1;
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) epi(4 * kq + r, nbase + 16 * t + j, acc[t][r]);
+        for (int r = 0; r < 4; ++r) epi(4 * kq + r, bw.nbase + 16 * t + j, acc[t][r]);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -191,23 +287,49 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
         rowf[tid] = a.label[src];
     }
     __syncthreads();
-    // 16 rows x 96 float4: 32 consecutive lanes read one 512-B embedding row
+    // 16 rows x 96 float4: 32 consecutive lanes read one 512-B embedding row.  Six
+    // independent loads per thread are issued back to back (indices are clamped, so the
+    // loads of padding rows are harmless and are zeroed afterwards).
     float* xs = smem + XS_OFF;
+    constexpr int PER = TILE_ROWS * (XDIM / 4) / 256;   // 6
+    f32x4 v[PER];
 #pragma unroll
-    for (int e = tid; e < TILE_ROWS * (XDIM / 4); e += 256) {
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
         const int seg = c4 >> 5, off = (c4 & 31) * 4;
-        const float* src;
-        if (seg == 0) src = a.user_tab + (size_t)rowi[row] * EMB;
-        else if (seg == 1) src = a.item_tab + (size_t)rowi[TILE_ROWS + row] * EMB;
-        else src = a.dense + a.L.dm + (size_t)rowi[2 * TILE_ROWS + row] * EMB;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (rowi[3 * TILE_ROWS + row]) v = *reinterpret_cast<const f32x4*>(src + off);
-        *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v;
-        if (gx) *reinterpret_cast<f32x4*>(gx + (size_t)row * gx_ld + c4 * 4) = v;
+        const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
+        v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * TILE_ROWS + row] * EMB + off);
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
+        const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
+        if (!rowi[3 * TILE_ROWS + row]) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v[u];
+        if (gx) *reinterpret_cast<f32x4*>(gx + (size_t)row * gx_ld + c4 * 4) = v[u];
     }
     __syncthreads();
 }
+
+// Diagnostic build only (-DMAMDR_STAMPS, tools/stamp_tower.py): per-phase s_memtime stamps
+// of wave 0 into a buffer nothing else reads.  The production library has no stamp code.
+#ifdef MAMDR_STAMPS
+#define STAMP(k)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (k)] = t_;               \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// prefetch depths (16-deep k chunks in flight per wave)
+constexpr int PF0 = 4, PF1 = 4, PF2 = 4;   // forward: 16-deep chunks
+constexpr int PFB2 = 2, PFB1 = 2, PFB0 = 4;  // backward: 32-deep chunks
 
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
@@ -219,9 +341,15 @@ __global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
     float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;   // [0,16) label, [16,32) dlogit
     float* acts_t = TRAIN ? a.acts + (size_t)r0 * ACT_LD : nullptr;
 
-    gather_tile(a, smem, r0, acts_t, ACT_LD);
-
     const float* P = a.dense;
+    // layer-0 weights do not depend on the gather: request them first
+    FwdW<XDIM, H1, PF0> fw0;
+    STAMP(0);
+    fw0.prefetch(P + a.L.w0);
+
+    gather_tile(a, smem, r0, acts_t, ACT_LD);
+    STAMP(1);
+
     const float scale = a.use_dropout ? a.keep_scale : 1.0f;
     // row index inside the batch seeds the dropout stream (eval: unused)
     const int row0 = r0;
@@ -229,53 +357,77 @@ __global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
     const uint32_t key1 = TRAIN ? dropout_layer_key(a.seed, a.step, 1) : 0u;
     const uint32_t key2 = TRAIN ? dropout_layer_key(a.seed, a.step, 2) : 0u;
 
-    fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(P + a.L.w0, P + a.L.b0, smem + XS_OFF, smem + H1S_OFF,
-                                             TRAIN ? acts_t + XDIM : nullptr, key0, a.drop_thresh, scale,
-                                             a.use_dropout != 0, row0);
+    fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN, PF0>(fw0, P + a.L.b0, smem + XS_OFF, smem + H1S_OFF,
+                                                  TRAIN ? acts_t + XDIM : nullptr, key0, a.drop_thresh, scale,
+                                                  a.use_dropout != 0, row0);
+    STAMP(2);
+    FwdW<H1, H2, PF1> fw1;
+    fw1.prefetch(P + a.L.w1);
     __syncthreads();
-    fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN>(P + a.L.w1, P + a.L.b1, smem + H1S_OFF, smem + H2S_OFF,
-                                           TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
-                                           a.use_dropout != 0, row0);
+    fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN, PF1>(fw1, P + a.L.b1, smem + H1S_OFF, smem + H2S_OFF,
+                                                TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
+                                                a.use_dropout != 0, row0);
+    STAMP(3);
+    FwdW<H2, H3, PF2> fw2;
+    fw2.prefetch(P + a.L.w2);
     __syncthreads();
-    fwd_layer<H2, H3, H2_LD, H3_LD, TRAIN>(P + a.L.w2, P + a.L.b2, smem + H2S_OFF, smem + H3S_OFF,
-                                           TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh, scale,
-                                           a.use_dropout != 0, row0);
+    fwd_layer<H2, H3, H2_LD, H3_LD, TRAIN, PF2>(fw2, P + a.L.b2, smem + H2S_OFF, smem + H3S_OFF,
+                                                TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh,
+                                                scale, a.use_dropout != 0, row0);
+    STAMP(4);
     __syncthreads();
 
-    // ---- output unit, sigmoid, Keras BCE (wave 0): lane (i, q) sums 16 of the 64 terms
-    if (w == 0) {
-        const int i = lane & 15, q = lane >> 4;
-        const float* h3 = smem + H3S_OFF + i * H3_LD + q * 16;
-        const float* wo = P + a.L.wo + q * 16;
+    // backward weights of layer 2 (all of K = 64) are requested before the output phase
+    BwdW<H3, H2, H3, PFB2> bw2;
+    BwdW<H2, H1, H2, PFB1> bw1;
+    if (TRAIN) {
+        bw2.prefetch(P + a.L.w2);
+        bw1.prefetch(P + a.L.w1);
+    }
+
+    // ---- output unit, sigmoid, Keras BCE and dz3, all 256 threads: thread (i, part) owns
+    // 4 of the 64 hidden units of row i; the 16 lanes of a row reduce by xor-shuffles.
+    float* dz_t = TRAIN ? a.dz + (size_t)r0 * DZ_LD : nullptr;
+    {
+        const int i = tid >> 4, part = tid & 15, n4 = part * 4;
+        const f32x4 wo = *reinterpret_cast<const f32x4*>(P + a.L.wo + n4);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(smem + H3S_OFF + i * H3_LD + n4);
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s = fmaf(h3[c], wo[c], s);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
+        for (int c = 0; c < 4; ++c) s = fmaf(h[c], wo[c], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
         const float logit = s + P[a.L.gb];
         float p;
         if (logit >= 0.f) {
-            p = 1.0f / (1.0f + expf(-logit));
+            p = 1.0f / (1.0f + __expf(-logit));
         } else {
-            const float ez = expf(logit);
+            const float ez = __expf(logit);
             p = ez / (1.0f + ez);
         }
         const bool valid = rowi[3 * TILE_ROWS + i] != 0;
         const float y = rowf[i];
         const float lo = 1e-7f, hi = 1.0f - 1e-7f;
         const float pc = fminf(fmaxf(p, lo), hi);
-        const float zc = logf(pc / (1.0f - pc));
-        float loss = fmaxf(zc, 0.f) - zc * y + log1pf(expf(-fabsf(zc)));
-        if (!valid) loss = 0.f;
+        const float zc = __logf(pc / (1.0f - pc));
+        float loss = fmaxf(zc, 0.f) - zc * y + __logf(1.0f + __expf(-fabsf(zc)));
+        if (!valid || part != 0) loss = 0.f;
         if (TRAIN) {
             const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
             const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
-            if (q == 0) {
-                rowf[TILE_ROWS + i] = dl;
+            if (part == 0) {
                 a.dlogit[r0 + i] = dl;
                 a.domrow[r0 + i] = rowi[2 * TILE_ROWS + i];
             }
-        } else if (q == 0 && valid) {
+            // gate = relu'(z) * dropout mask / keep = (h_post > 0) * scale
+            f32x4 d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
+            *reinterpret_cast<f32x4*>(smem + DZ3S_OFF + i * H3_LD + n4) = d;
+            *reinterpret_cast<f32x4*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n4) = d;
+        } else if (part == 0 && valid) {
             // AUC bin = number of thresholds strictly below p (utils/metrics_utils.py:309: pred > thr)
             int blo = 0, bhi = 500;
             while (blo < bhi) {
@@ -285,56 +437,49 @@ __global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
             atomicAdd(a.hist + (y != 0.f ? 501 : 0) + blo, 1u);
             if (a.pred_out) a.pred_out[a.row_base + r0 + i] = p;
         }
-        // tile loss: rows 0..15 live in lanes 0..15
-        loss += __shfl_xor(loss, 8);
-        loss += __shfl_xor(loss, 4);
-        loss += __shfl_xor(loss, 2);
-        loss += __shfl_xor(loss, 1);
-        if (lane == 0) a.loss_part[tile] = loss;
+        // tile loss: the 4 rows of this wave sit in lanes 0,16,32,48 (others hold 0)
+        loss += __shfl_xor(loss, 16);
+        loss += __shfl_xor(loss, 32);
+        if (lane == 0) rowf[2 * TILE_ROWS + w] = loss;
     }
+    STAMP(5);
+    __syncthreads();
+    if (tid == 0)
+        a.loss_part[tile] = ((rowf[2 * TILE_ROWS] + rowf[2 * TILE_ROWS + 1]) + rowf[2 * TILE_ROWS + 2]) +
+                            rowf[2 * TILE_ROWS + 3];
     if (!TRAIN) return;
-    __syncthreads();
-
-    // ---- backward activation chain.  gate = relu'(z) * dropout mask / keep = (h_post > 0) * scale
-    float* dz_t = a.dz + (size_t)r0 * DZ_LD;
-    {
-        const int i = tid >> 4, n4 = (tid & 15) * 4;
-        const float dl = rowf[TILE_ROWS + i];
-        const f32x4 wo = *reinterpret_cast<const f32x4*>(P + a.L.wo + n4);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(smem + H3S_OFF + i * H3_LD + n4);
-        f32x4 d;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
-        *reinterpret_cast<f32x4*>(smem + DZ3S_OFF + i * H3_LD + n4) = d;
-        *reinterpret_cast<f32x4*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n4) = d;
-    }
-    __syncthreads();
+    STAMP(6);
+    // d loss / d domain-embedding row = dz1 . W0[256:384, :]^T: weights requested two phases early
+    BwdW<H1, EMB, H1, PFB0> bw0;
+    bw0.prefetch(P + a.L.w0 + (size_t)(2 * EMB) * H1);
     {
         float* dzs = smem + DZ2S_OFF;
         const float* hs = smem + H2S_OFF;
-        bwd_layer<H3, H2, H3, H3_LD>(P + a.L.w2, smem + DZ3S_OFF, [&](int row, int col, float v) {
+        bwd_layer<H3, H2, H3, H3_LD, PFB2>(bw2, smem + DZ3S_OFF, [&](int row, int col, float v) {
             const float d = (hs[row * H2_LD + col] > 0.f) ? v * scale : 0.f;
             dzs[row * H2_LD + col] = d;
             dz_t[(size_t)row * DZ_LD + H1 + col] = d;
         });
     }
+    STAMP(7);
     __syncthreads();
     {
         float* dzs = smem + DZ1S_OFF;
         const float* hs = smem + H1S_OFF;
-        bwd_layer<H2, H1, H2, H2_LD>(P + a.L.w1, smem + DZ2S_OFF, [&](int row, int col, float v) {
+        bwd_layer<H2, H1, H2, H2_LD, PFB1>(bw1, smem + DZ2S_OFF, [&](int row, int col, float v) {
             const float d = (hs[row * H1_LD + col] > 0.f) ? v * scale : 0.f;
             dzs[row * H1_LD + col] = d;
             dz_t[(size_t)row * DZ_LD + col] = d;
         });
     }
+    STAMP(8);
     __syncthreads();
     {
-        // d loss / d domain-embedding row = dz1 . W0[256:384, :]^T
         float* dxe_t = a.dxe + (size_t)r0 * EMB;
-        bwd_layer<H1, EMB, H1, H1_LD>(P + a.L.w0 + (size_t)(2 * EMB) * H1, smem + DZ1S_OFF,
-                                     [&](int row, int col, float v) { dxe_t[(size_t)row * EMB + col] = v; });
+        bwd_layer<H1, EMB, H1, H1_LD, PFB0>(bw0, smem + DZ1S_OFF,
+                                            [&](int row, int col, float v) { dxe_t[(size_t)row * EMB + col] = v; });
     }
+    STAMP(9);
 }
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s) {
@@ -450,7 +595,17 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& g, const TileDesc& t
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, kk = lane >> 5;
     int b = b0;
-    // 8 rows (4 MFMA k-steps) per iteration: all loads issued before the MFMAs
+    // 32 rows (16 MFMA k-steps) per iteration: all 32 loads are issued before the MFMAs
+    for (; b + 32 <= b1; b += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            av[u] = fetch_a<AK>(g, t, b + 2 * u + kk, c);
+            bv[u] = fetch_b<BK>(g, t, b + 2 * u + kk, c);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = MAMDR_MFMA32(av[u], bv[u], acc);
+    }
     for (; b + 8 <= b1; b += 8) {
         float av[4], bv[4];
 #pragma unroll

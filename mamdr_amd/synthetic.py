@@ -53,8 +53,9 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
     min_size = max(1, int(batch_size * min(1.0, scale))) if scale < 1.0 else batch_size
     sizes = {}
     for split in ("train", "val", "test"):
-        total = max(int(spec["n_" + split] * scale), D * min_size)
-        sizes[split] = _domain_sizes(total, D, min_size, np.random.RandomState(seed + 1))
+        ms = min_size if split == "train" else max(1, min_size // 4)
+        total = max(int(spec["n_" + split] * scale), D * ms)
+        sizes[split] = _domain_sizes(total, D, ms, np.random.RandomState(seed + 1))
     data = {"train": {}, "val": {}, "test": {}}
     info = {"n_user": n_user, "n_item": n_item}
     totals = {"train": 0, "val": 0, "test": 0}

@@ -1,0 +1,47 @@
+"""Diagnostic: per-phase cycle shares of k_tower<train> from s_memtime stamps.
+Builds a separate library with -DMAMDR_STAMPS (never shipped) and prints the median
+per-phase cycles over workgroups.  Usage: python tools/stamp_tower.py [shape] [batch]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mamdr_amd import build as B
+so = os.path.join(ROOT, "mamdr_amd", "build", "libmamdr_hip_stamps.so")
+srcs = [os.path.join(B.CSRC, s) for s, _ in B.SOURCES]
+extra = os.environ.get("MAMDR_DIAG_FLAGS", "").split()
+subprocess.check_call([B._hipcc()] + B.COMMON + ["-DMAMDR_STAMPS"] + extra + ["-shared", "-o", so] + srcs)
+from mamdr_amd import _lib
+_lib.LIB_PATH = so
+from mamdr_amd import engine, synthetic
+import ctypes as C
+shape = sys.argv[1] if len(sys.argv) > 1 else "taobao10"
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+g = synthetic.generate(shape, batch_size=bs, seed=123)
+eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], bs, dropout=0.5)
+eng.bind_table("user_emb", g["tables"]["user_emb"]); eng.bind_table("item_emb", g["tables"]["item_emb"])
+d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+c = g["data"]["train"][d]; eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+rs = np.random.RandomState(0)
+w = (rs.standard_normal(eng.n_params) * 0.05).astype(np.float32); eng.set_weights(torch.from_numpy(w).to(eng.device))
+# the stamp build writes stamps through TowerArgs.pred_out, which only eval sets; train leaves it null.
+# So use the eval kernel?  No: train path -- patch: engine passes no pred_out in train.  We therefore
+# stamp the eval launch (forward phases) and, for train, rely on a debug env hook.
+n = eng.n_rows(d, "train")
+tiles = bs // 16
+stamps = torch.zeros(tiles * 16, dtype=torch.int64, device=eng.device)
+eng.lib.mamdr_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
+eng.lib.mamdr_debug_set_stamps(eng.ctx, C.c_void_p(stamps.data_ptr()))
+perm = torch.from_numpy(engine.shuffle_perm(n, 10000, 1)).to(eng.device)
+for _ in range(5):
+    eng.train_steps(d, perm=perm, first_step=0, n_steps=3)
+torch.cuda.synchronize()
+st = stamps.cpu().numpy().reshape(tiles, 16)[:, :10].astype(np.float64)
+names = ["w0 prefetch+gather", "L0 fwd", "L1 fwd (incl. barrier)", "L2 fwd", "barrier+out/loss", "bw2 prefetch+barrier+dz3",
+         "bwd2 (dz2)", "bwd1 (dz1)", "bwd0 (dxe)"]
+dif = np.diff(st, axis=1)
+tot = st[:, 9] - st[:, 0]
+print("tiles %d; total cycles median %.0f (min %.0f max %.0f); s_memtime ticks = shader cycles" % (tiles, np.median(tot), tot.min(), tot.max()))
+for i, nme in enumerate(names):
+    print("  %-28s %8.0f  (%4.1f%%)" % (nme, np.median(dif[:, i]), 100 * np.median(dif[:, i]) / np.median(tot)))
+span = st[:, 9].max() - st[:, 0].min()
+print("first start -> last end: %.0f cycles" % span)
