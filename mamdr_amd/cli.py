@@ -1,0 +1,80 @@
+"""`run.py --config <json>` surface and the name registry (mirror of the reference's run.py).
+
+Dispatch is by substring of config.model.name, in the reference's order (run.py:37-85):
+  tower    'star' -> Star | any of mlp,wdl,nfm,autoint,ccpm,pnn,deepfm -> DeepCTR |
+           shared_bottom,mmoe,ple -> DeepMTLCTR
+  wrappers 'uncertainty_weight', 'pcgrad', then 'meta' + (domain_negotiation | mamdr |
+           reptile | mldg | <else> MAML)
+  modes    'separate' -> per-domain training; otherwise train() + val_and_test("test");
+           'finetune' -> load best + separate_train_val_test(init_parms=False)
+Entries outside the hot path stay in the registry and raise
+NotImplementedError naming why.
+"""
+import argparse
+import json
+
+DEEP_CTR_LIST = ["mlp", "wdl", "nfm", "autoint", "ccpm", "pnn", "deepfm"]
+MTL_DEEP_CTR_LIST = ["shared_bottom", "mmoe", "ple"]
+
+
+def in_name_list(x, name_list):
+    return any(n in x for n in name_list)
+
+
+def build_model(config, dataset, engine_factory=None):
+    from .model_zoo import MAML, MAMDR, DeepCTR, DomainNegotiation, Reptile
+    name = config["model"]["name"]
+    if "star" in name:
+        raise NotImplementedError("Star tower (PartitionedNorm + StarFCN, model_zoo/Star) is on the hot-path "
+                                  "list (SURVEY.md section 8 a13) but not built in this round")
+    elif in_name_list(name, DEEP_CTR_LIST):
+        model = DeepCTR(dataset, config, engine_factory)
+    elif in_name_list(name, MTL_DEEP_CTR_LIST):
+        raise NotImplementedError("DeepMTLCTR towers (shared_bottom / mmoe / ple) are comparison baselines "
+                                  "outside the hot path (SURVEY.md section 2.1 #15)")
+    else:
+        raise ValueError("model: {} not found".format(name))
+    if "uncertainty_weight" in name:
+        raise NotImplementedError("UncertaintyWeight is a comparison baseline outside the hot path")
+    if "pcgrad" in name:
+        raise NotImplementedError("PCGrad is a comparison baseline outside the hot path")
+    if "meta" in name:
+        if "domain_negotiation" in name:
+            model = DomainNegotiation(model)
+        elif "mamdr" in name:
+            model = MAMDR(model)
+        elif "reptile" in name:
+            model = Reptile(model)
+        elif "mldg" in name:
+            raise NotImplementedError("MLDG is a comparison baseline outside the hot path")
+        else:
+            model = MAML(model)
+    return model
+
+
+def main(config, engine_factory=None):
+    from .utils import MultiDomainDataset
+    dataset = MultiDomainDataset(config["dataset"])
+    model = build_model(config, dataset, engine_factory)
+    name = config["model"]["name"]
+    if "separate" in name:
+        avg_loss, avg_auc, domain_loss, domain_auc = model.separate_train_val_test()
+    else:
+        model.train()
+        print("Test Result: ")
+        avg_loss, avg_auc, domain_loss, domain_auc = model.val_and_test("test")
+    if "finetune" in name:
+        model.load_model(model.checkpoint_path)
+        print("Finetune: ")
+        avg_loss, avg_auc, domain_loss, domain_auc = model.separate_train_val_test(init_parms=False)
+    model.save_result(avg_loss, avg_auc, domain_loss, domain_auc)
+    return avg_loss, avg_auc, domain_loss, domain_auc
+
+
+def cli(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", type=str, help="Train config file", required=True)
+    args = parser.parse_args(argv)
+    with open(args.config, "r") as f:
+        config = json.load(f)
+    return main(config)

@@ -1,0 +1,117 @@
+"""DeepCTR tower -- host-side mirror of model_zoo/DeepCTR/deepctr.py.
+
+`build_model` keeps the reference's substring registry (deepctr.py:24-50): names
+containing `mlp` build the 3 x 128-d embedding -> DNN(hidden_dim) -> Dense(1) -> sigmoid
+tower (deepctr.py:95-136) on the HIP engine; `deepfm` is named by BASELINE.json but not
+built in this round; wdl / nfm / autoint / ccpm / pnn are out of scope
+and raise.  Initial tensors follow the reference's initialisers (glorot normal for the
+kernels, zeros for biases, N(0, 1e-4^2) for the domain table and for user/item tables
+without pretraining, constants from the pretrained tables otherwise) drawn from a numpy
+stream seeded with dataset.seed -- TF's own streams are not reproducible.
+"""
+import random
+
+import numpy as np
+
+from .base_model import BaseModel
+
+OUT_OF_SCOPE = ("wdl", "nfm", "autoint", "ccpm", "pnn")
+
+
+def glorot_normal(rs, fan_in, fan_out, shape):
+    """Keras glorot_normal: truncated normal (2 sigma), stddev = sqrt(2 / (fan_in + fan_out))."""
+    std = np.sqrt(2.0 / (fan_in + fan_out))
+    x = rs.standard_normal(shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rs.standard_normal(int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * std).astype(np.float32)
+
+
+def initial_tensors(rs, n_user, n_item, n_domain, emb_dim, hidden, user_emb=None, item_emb=None):
+    """every initializer of the model, in layer order (what `init_layer` re-runs,
+    specific_base_model.py:174-178)."""
+    t = {}
+    t["user_emb"] = user_emb if user_emb is not None else (rs.standard_normal((n_user, emb_dim)) * 1e-4).astype(np.float32)
+    t["item_emb"] = item_emb if item_emb is not None else (rs.standard_normal((n_item, emb_dim)) * 1e-4).astype(np.float32)
+    t["domain_emb"] = (rs.standard_normal((n_domain, emb_dim)) * 1e-4).astype(np.float32)
+    dims = (3 * emb_dim,) + tuple(hidden)
+    for l in range(3):
+        t["W%d" % l] = glorot_normal(rs, dims[l], dims[l + 1], (dims[l], dims[l + 1]))
+        t["b%d" % l] = np.zeros(dims[l + 1], np.float32)
+    t["wo"] = glorot_normal(rs, dims[3], 1, (dims[3], 1))
+    t["gb"] = np.zeros(1, np.float32)
+    return t
+
+
+class DeepCTR(BaseModel):
+    def __init__(self, dataset, config, engine_factory=None):
+        super(DeepCTR, self).__init__(dataset, config, engine_factory)
+
+    def build_model(self):
+        name = self.model_config["name"]
+        if "mlp" in name:
+            tower = "mlp"
+        elif any(k in name for k in OUT_OF_SCOPE):
+            raise NotImplementedError("tower '%s': deepctr WDL/NFM/AutoInt/CCPM/PNN are outside the hot path "
+                                      "(SURVEY.md section 2.1) and are not built" % name)
+        elif "deepfm" in name:
+            tower = "deepfm"
+        else:
+            raise ValueError("model: {} not found".format(name))
+        mc, tc = self.model_config, self.train_config
+        if not (mc["user_dim"] == mc["item_dim"] == mc["domain_dim"]):
+            raise ValueError("user_dim, item_dim and domain_dim must be equal")
+        factory = self.engine_factory
+        if factory is None:
+            from ..engine import TowerEngine
+            factory = TowerEngine
+        eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
+                      emb_trainable=bool(tc["emb_trainable"]), tower=tower, emb_dim=mc["user_dim"],
+                      hidden=tuple(mc["hidden_dim"]))
+        self.init_rs = np.random.RandomState(self.dataset.seed)
+        pre = bool(tc["load_pretrain_emb"])
+        self.pretrained = (self.dataset.user_emb, self.dataset.item_emb) if pre else (None, None)
+        if pre and self.pretrained[0] is None:
+            raise ValueError("load_pretrain_emb is set but the dataset has no pretrained tables")
+        tensors = self.draw_initial_tensors()
+        if not tc["emb_trainable"]:
+            eng.bind_table("user_emb", tensors["user_emb"])
+            eng.bind_table("item_emb", tensors["item_emb"])
+        for split, store in (("train", self.dataset.train_dataset), ("val", self.dataset.val_dataset),
+                             ("test", self.dataset.test_dataset)):
+            for d, v in store.items():
+                c = v["data"]
+                eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
+        eng.set_weights(eng.pack(tensors))
+        self.optimizer = tc["optimizer"]
+        if self.optimizer != "adam":
+            raise NotImplementedError("optimizer '%s': the reference configs all use adam (deepctr.py:54-57)"
+                                      % self.optimizer)
+        if tc["loss"] != "binary_crossentropy":
+            raise NotImplementedError("loss '%s': only binary_crossentropy is on the hot path" % tc["loss"])
+        return eng
+
+    def draw_initial_tensors(self):
+        mc = self.model_config
+        return initial_tensors(self.init_rs, self.n_uid, self.n_pid, self.n_domain, mc["user_dim"],
+                               tuple(mc["hidden_dim"]), self.pretrained[0], self.pretrained[1])
+
+    def train(self):
+        """alternate ('joint') training, deepctr.py:63-93."""
+        self.model.optimizer_reset()
+        train_sequence = list(range(self.n_domain))
+        rng = random.Random(self.dataset.seed)
+        for epoch in range(self.train_config["epoch"]):
+            print("Epoch: {}".format(epoch), "-" * 30)
+            rng.shuffle(train_sequence)
+            for idx in train_sequence:
+                self.fit_domain(idx, phase="alt")
+            print("Val Result: ")
+            avg_loss, avg_auc, domain_loss, domain_auc = self.val_and_test("val")
+            if self.early_stop_step(avg_auc):
+                break
+            print("Test Result: ")
+            # as in the reference, this reloads the best checkpoint into the live model
+            self.val_and_test("test")

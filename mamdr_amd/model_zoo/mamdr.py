@@ -1,0 +1,57 @@
+"""MAMDR wrapper: Domain Negotiation + Domain Regularization (mirror of model_zoo/mamdr.py).
+
+Per epoch (mamdr.py:41-166):
+  DN  set model := theta; one pass per domain in shuffled order, no reset;
+      theta += beta * (theta~ - theta)
+  DR  for every query domain i (same order): sample `sample_num` support domains
+      (+ i itself if add_query_domain); merged = theta (+|*) phi_i; for each support j:
+      model := merged, pass over j, pass over i (capped by domain_regulation_step),
+      phi_i += gamma * (theta~ - merged), merged recomputed  -- gamma = meta_learning_rate
+      (`domain_meta_learning_rate` is dead in the reference)
+  val with merged weights, early stop on the average val AUC, test with the best theta / phi.
+phi_d starts as a fresh random initialisation of the whole model (mamdr.py:31-33), theta as
+the model's own initial weights (mamdr.py:29).  The reference draws order and samples from
+the unseeded global `random`; here they come from a `random.Random(dataset.seed)`.
+"""
+from .. import meta
+from ..plan import EpochPlanner
+from .specific_base_model import SpecificBase
+
+
+class MAMDR(SpecificBase):
+    def __init__(self, base_model):
+        super(MAMDR, self).__init__(base_model)
+
+    def train(self):
+        print("Start MAMDR on model: {}".format(self.model_config["name"]))
+        tc = self.train_config
+        if tc["target_domain"] >= 0:
+            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        if tc["finetune_every_epoch"]:
+            raise NotImplementedError("finetune_every_epoch (mamdr.py:110-143) is not built in this round")
+        self._get_model_meta_parms()
+        self.meta_weights = self._get_meta_weights()
+        self.domain_weights = {}
+        for domain_idx in range(self.n_domain):
+            self.domain_weights[domain_idx] = self.model.pack(self.base_model.draw_initial_tensors())
+        self.model.optimizer_reset()
+        planner = EpochPlanner(self.build_meta_sequence(), tc["sample_num"], tc["add_query_domain"],
+                               tc["shuffle_sequence"], seed=self.dataset.seed)
+        planner.rng = self.rng
+        batch_variant = "batch" in self.model_config["name"]
+        scratch = self.model.new_vector()
+        self.trace = []
+        for epoch in range(tc["epoch"]):
+            print("Epoch: {}".format(epoch), "-" * 30)
+            plan = planner.next_epoch()
+            self.trace += meta.mamdr_epoch(self.model, self.meta_weights, self.domain_weights, plan,
+                                           self.shuffler, self.batch_size, self.learning_rate,
+                                           tc["meta_learning_rate"], tc["merged_method"],
+                                           tc["domain_regulation_step"], batch_variant, tc["sample_num"],
+                                           scratch)
+            if epoch % tc["val_every_step"] == 0:
+                _, val_avg_auc, _, val_domain_auc = self.val()
+                if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):
+                    break
+                print("Test Result: ")
+                self.val_and_test("test")

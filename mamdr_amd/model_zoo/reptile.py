@@ -1,0 +1,38 @@
+"""Reptile wrapper (mirror of model_zoo/reptile.py).
+
+Per epoch (reptile.py:40-125): shuffle all domains; for each, reset the model to theta,
+run one pass, then either theta += beta * (theta~ - theta) immediately, or (names
+containing "batch") accumulate theta~ - theta and apply the sum once per epoch.
+"""
+from .. import meta
+from .maml import MAML
+
+
+class Reptile(MAML):
+    def __init__(self, base_model):
+        super(Reptile, self).__init__(base_model)
+
+    def train(self):
+        print("Start reptile on model: {}".format(self.model_config["name"]))
+        tc = self.train_config
+        if tc["target_domain"] >= 0:
+            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        self._get_model_meta_parms()
+        meta_weights = self._get_meta_weights()
+        self.model.optimizer_reset()
+        train_sequence = list(range(self.n_domain))
+        batch_variant = "batch" in self.model_config["name"]
+        self.trace = []
+        for epoch in range(tc["epoch"]):
+            print("Epoch: {}".format(epoch), "-" * 30)
+            self.rng.shuffle(train_sequence)
+            self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
+                                             self.batch_size, self.learning_rate, tc["meta_learning_rate"],
+                                             batch_variant, tc["meta_train_step"])
+            if epoch % tc["val_every_step"] == 0:
+                _, val_avg_auc, _, val_domain_auc = self.val()
+                if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):
+                    break
+                print("Test Result: ")
+                self.val_and_test("test")
+                self._set_model_meta_parms(meta_weights)

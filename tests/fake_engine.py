@@ -1,0 +1,121 @@
+"""CPU stand-in for mamdr_amd.engine.TowerEngine, built on the oracle (tests only).
+
+Lets the host logic (registry, wrappers, meta loops, sharding, result writing) run in the
+`-m "not gpu"` suite.  It is NOT a product fallback: mamdr_amd never imports it.
+"""
+import numpy as np
+import torch
+
+from oracle import auc as oauc
+from oracle import outer as oouter
+from oracle import tower as otower
+
+F32 = np.float32
+
+
+class FakeEngine(object):
+    def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False, tower="mlp",
+                 emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None, dropout_seed=1024):
+        if tower != "mlp":
+            raise NotImplementedError(tower)
+        self.n_user, self.n_item, self.n_domain = n_user, n_item, n_domain
+        self.batch_size = batch_size
+        self.device = torch.device("cpu")
+        self.dropout_seed = dropout_seed
+        rs = np.random.RandomState(0)
+        params = otower.init_params(rs, n_user, n_item, n_domain, emb_dim, hidden)
+        self.oracle = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=dropout, hidden=hidden,
+                                         dropout_seed=dropout_seed)
+        self.segments = {}
+        off = 0
+        for name in self.oracle.names:
+            self.segments[name] = (off, params[name].size)
+            off += params[name].size
+        self.n_params = off
+        self.data = {}
+        self.calls = []
+
+    # flat vectors
+    def new_vector(self, like=None):
+        return like.clone() if like is not None else torch.zeros(self.n_params, dtype=torch.float32)
+
+    def pack(self, named):
+        return torch.from_numpy(np.concatenate([np.asarray(named[n], F32).ravel() for n in self.segments]))
+
+    def unpack(self, vec):
+        h = vec.numpy()
+        return {n: h[o:o + c].copy() for n, (o, c) in self.segments.items()}
+
+    @property
+    def weights(self):
+        return torch.from_numpy(self.oracle.get_flat())
+
+    def set_weights(self, vec):
+        self.oracle.set_flat(vec.numpy().copy())
+
+    def get_weights(self, out=None):
+        w = self.weights
+        if out is None:
+            return w
+        out.copy_(w)
+        return out
+
+    def interp(self, dst, a, b, scale):
+        an, bn = a.numpy().copy(), b.numpy().copy()
+        oouter.mamdr_update(dst.numpy(), an, bn, scale)
+
+    def merge(self, dst, theta, phi, method="plus"):
+        dst.copy_(torch.from_numpy(oouter.merge(theta.numpy(), phi.numpy(), method)))
+
+    def sub(self, dst, a, b):
+        dst.copy_(torch.from_numpy(oouter.mamdr_domain_weights(a.numpy(), b.numpy())))
+
+    def accumulate(self, acc, a, b, shared=None, divisor=1.0):
+        oouter.mamdr_accumulate(acc.numpy(), a.numpy().copy(), b.numpy().copy(),
+                                None if shared is None else shared.numpy(), "times" if shared is not None else "plus",
+                                divisor)
+
+    def apply_accumulated(self, dst, acc, divisor, scale):
+        if divisor > 0:
+            oouter.mamdr_apply_grads(dst.numpy(), acc.numpy(), divisor, scale)
+        else:
+            oouter.reptile_apply(dst.numpy(), acc.numpy(), scale)
+
+    # binding
+    def bind_table(self, name, rows):
+        self.oracle.params[name] = np.ascontiguousarray(rows, F32)
+
+    def bind_domain_data(self, domain, split, uid, pid, dom, label):
+        self.data[(domain, split)] = {"uid": np.asarray(uid, np.int32), "pid": np.asarray(pid, np.int32),
+                                      "domain": np.asarray(dom, np.int32), "label": np.asarray(label, F32)}
+
+    def n_rows(self, domain, split):
+        return int(self.data[(domain, split)]["uid"].shape[0])
+
+    # hot path
+    def train_steps(self, domain, perm=None, first_step=0, n_steps=None, lr=1e-3, optimizer="adam", loss_out=None,
+                    batch_size=None):
+        bs = batch_size or self.batch_size
+        cols = self.data[(domain, "train")]
+        n = cols["uid"].shape[0]
+        p = np.arange(n, dtype=np.int32) if perm is None else np.asarray(perm)
+        if n_steps is None:
+            n_steps = -(-n // bs) - first_step
+        self.oracle.lr = lr
+        self.oracle.use_sgd = optimizer == "sgd"
+        for s in range(first_step, first_step + n_steps):
+            idx = p[s * bs:(s + 1) * bs]
+            self.oracle.train_on_batch(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
+        self.calls.append((domain, n_steps, optimizer, lr))
+        return n_steps
+
+    def evaluate(self, domain, split, want_preds=False):
+        cols = self.data[(domain, split)]
+        loss, preds = self.oracle.evaluate(cols, self.batch_size)
+        return float(loss), float(oauc.auc500(cols["label"], preds, self.batch_size))
+
+    def optimizer_reset(self):
+        self.oracle.opt = otower.Optimizer(self.oracle.params, self.oracle.names)
+
+    def close(self):
+        pass

@@ -1,0 +1,140 @@
+"""C-ABI export check (no GPU calls) and the N>1 path on CPU (gloo, world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_library_exports_every_declared_symbol():
+    from mamdr_amd import _lib
+    header = open(os.path.join(ROOT, "include", "mamdr_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(mamdr_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mamdr_abi_version() == _lib.ABI_VERSION
+    # error path without a device: bad config is rejected before any HIP call
+    import ctypes as C
+    cfg = _lib.Config(_lib.ABI_VERSION, _lib.TOWER_MLP, 10, 10, 2, 64, (C.c_int32 * 3)(256, 128, 64), 1024, 0, 0.5,
+                      1e-5, 0.9, 0.999, 1e-8)
+    h = C.c_void_p()
+    assert lib.mamdr_create(C.byref(cfg), None, C.byref(h)) == _lib.EINVAL
+    assert b"emb_dim 128" in lib.mamdr_last_error()
+    cfg.emb_dim, cfg.tower = 128, _lib.TOWER_STAR
+    assert lib.mamdr_create(C.byref(cfg), None, C.byref(h)) == _lib.ENOTBUILT
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.ENOTBUILT)
+
+
+def test_product_path_does_not_import_oracle():
+    """the oracle is test infrastructure: nothing under mamdr_amd/, run.py may import it."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "mamdr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad
+    assert "oracle" not in open(os.path.join(ROOT, "run.py")).read()
+
+
+def test_lpt_and_plan_sharding():
+    from mamdr_amd import parallel
+    sizes = [4493, 3495, 7864, 5242, 6291, 31462, 3145, 10485, 3932, 15728]
+    for n in (1, 2, 4, 8):
+        owner = parallel.lpt_partition(sizes, n)
+        assert set(owner) <= set(range(n)) and len(owner) == 10
+        loads = [sum(s for s, o in zip(sizes, owner) if o == r) for r in range(n)]
+        assert max(loads) <= max(max(sizes), sum(sizes) / n * 4 / 3 + 1)       # LPT bound
+    plan = {"seq": [3, 1, 2, 0], "dr": [(3, [1, 3]), (1, [0, 1]), (2, [3, 2]), (0, [2, 0])]}
+    owner = [0, 1, 0, 1]
+    s0, s1 = parallel.shard_plan(plan, owner, 0), parallel.shard_plan(plan, owner, 1)
+    assert s0["seq"] == [2, 0] and s1["seq"] == [3, 1]                           # order preserved
+    assert [q for q, _ in s0["dr"]] == [2, 0] and [q for q, _ in s1["dr"]] == [3, 1]
+    assert sorted(s0["dr"] + s1["dr"]) == sorted(plan["dr"])                     # a partition
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import numpy as np, torch, torch.distributed as dist
+from fake_engine import FakeEngine
+from mamdr_amd import meta, parallel, plan as mplan, synthetic
+from oracle import rng as orng
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = synthetic.generate({{"name": "Taobao", "split": "s", "n_domain": 4, "n_user": 300, "n_item": 200, "n_train": 1200,
+                        "n_val": 400, "n_test": 400, "pretrained": True}}, batch_size=64, seed=5, emb_dim=8)
+eng = FakeEngine(g["n_user"], g["n_item"], 4, 64, emb_dim=8, hidden=(16, 8, 4))
+eng.bind_table("user_emb", g["tables"]["user_emb"]); eng.bind_table("item_emb", g["tables"]["item_emb"])
+for d in range(4):
+    c = g["data"]["train"][d]; eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+sizes = [eng.n_rows(d, "train") for d in range(4)]
+owner = parallel.lpt_partition(sizes, world)
+theta0 = eng.oracle.get_flat().copy()
+theta = torch.from_numpy(theta0.copy())
+phis = {{d: torch.zeros(eng.n_params) for d in range(4) if owner[d] == rank}}
+bufs = {{"delta": eng.new_vector(), "zero": eng.new_vector(), "merged": eng.new_vector()}}
+plan = {{"seq": [2, 0, 3, 1], "dr": [(2, [0, 2]), (0, [1, 0]), (3, [2, 3]), (1, [3, 1])]}}
+shuf = mplan.PassShuffler(sizes, 10000, 77 + rank, shuffle_fn=orng.shuffle_perm)
+# reference point: what this rank's DN sub-sequence alone produces
+local = parallel.shard_plan(plan, owner, rank)
+eng.set_weights(theta)
+probe = mplan.PassShuffler(sizes, 10000, 77 + rank, shuffle_fn=orng.shuffle_perm)
+for d in local["seq"]:
+    meta.run_pass(eng, d, probe, 64, 1e-3, [], "dn")
+my_delta = eng.oracle.get_flat() - theta0
+eng.optimizer_reset(); eng.oracle.step = 0
+trace = parallel.mamdr_epoch_sharded(eng, meta, theta, phis, plan, owner, shuf, 64, 1e-3, 0.1, bufs)
+# every rank must hold the same theta = theta0 + 0.1 * sum_g delta_g
+deltas = [torch.zeros(eng.n_params) for _ in range(world)]
+dist.all_gather(deltas, torch.from_numpy(my_delta.astype(np.float32)))
+total = deltas[0].numpy().copy()
+for t in deltas[1:]:
+    total = (total + t.numpy()).astype(np.float32)
+want = (theta0 + (total * np.float32(0.1)).astype(np.float32)).astype(np.float32)
+assert np.array_equal(theta.numpy(), want), np.abs(theta.numpy() - want).max()
+thetas = [torch.zeros(eng.n_params) for _ in range(world)]
+dist.all_gather(thetas, theta)
+assert all(torch.equal(thetas[0], t) for t in thetas)
+# DR ran only for the owned query domains, and only those phis moved
+assert sorted(set(t[1] for t in trace if t[0] == "dr_query")) == sorted(d for d in range(4) if owner[d] == rank)
+assert all(float(p.abs().max()) > 0 for p in phis.values())
+steps = torch.tensor([float(sum(t[2] for t in trace))])
+dist.all_reduce(steps)
+spd = [-(-n // 64) for n in sizes]
+assert int(steps.item()) == mplan.plan_steps(plan, spd)
+losses, aucs = parallel.gather_domain_scalars({{d: (0.5 + d, 0.6 + 0.01 * d) for d in phis}}, 4, torch.device("cpu"))
+assert sorted(aucs) == [0, 1, 2, 3] and abs(aucs[3] - 0.63) < 1e-12
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_mamdr_epoch_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, here=HERE))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in out, out[-3000:]

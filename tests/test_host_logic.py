@@ -1,0 +1,228 @@
+"""Host logic on CPU: registry, wrappers, meta loops, planner, dataset formats, result files.
+The tower is replaced by tests/fake_engine.FakeEngine (oracle-backed)."""
+import copy
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fake_engine import FakeEngine
+from mamdr_amd import cli, meta, plan as mplan, synthetic
+from mamdr_amd.utils import dataset as mds
+from oracle import loops as oloops
+from oracle import rng as orng
+from oracle import tower as otower
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def tiny_config(tmp_path, name="mlp_meta_mamdr_finetune", epochs=2):
+    with open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
+        cfg = json.load(f)
+    cfg = copy.deepcopy(cfg)
+    cfg["model"]["name"] = name
+    cfg["model"]["hidden_dim"] = [16, 8, 4]
+    for k in ("user_dim", "item_dim", "domain_dim"):
+        cfg["model"][k] = 8
+    cfg["train"].update(epoch=epochs, patience=1, sample_num=2, result_save_path=str(tmp_path / "result"),
+                        checkpoint_path=str(tmp_path / "checkpoint"))
+    cfg["dataset"].update(batch_size=64, synthetic={"name": "Taobao", "split": "s", "n_domain": 3, "n_user": 300,
+                                                    "n_item": 200, "n_train": 900, "n_val": 300, "n_test": 300,
+                                                    "pretrained": True})
+    return cfg
+
+
+def small_gen(emb_dim=8):
+    return synthetic.generate({"name": "Taobao", "split": "s", "n_domain": 3, "n_user": 300, "n_item": 200,
+                               "n_train": 900, "n_val": 300, "n_test": 300, "pretrained": True},
+                              batch_size=64, seed=5, emb_dim=emb_dim)
+
+
+def patch_emb_dim(monkeypatch):
+    """tiny tables for CPU speed: synthetic.generate(emb_dim=8) through the dataset layer."""
+    real = synthetic.generate
+    monkeypatch.setattr(synthetic, "generate", lambda *a, **k: real(*a, **dict(k, emb_dim=8)))
+
+
+# ------------------------------------------------------------------ registry (run.py:37-85)
+def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
+    patch_emb_dim(monkeypatch)
+    from mamdr_amd.model_zoo import MAML, MAMDR, DeepCTR, DomainNegotiation, Reptile
+    ds = mds.MultiDomainDataset(tiny_config(tmp_path)["dataset"])
+    for name, cls in (("mlp", DeepCTR), ("mlp_meta_mamdr_finetune", MAMDR), ("mlp_meta_reptile", Reptile),
+                      ("mlp_meta_domain_negotiation_finetune", DomainNegotiation), ("mlp_meta", MAML)):
+        cfg = tiny_config(tmp_path, name)
+        assert type(cli.build_model(cfg, ds, FakeEngine)) is cls
+    # substring order: 'domain_negotiation' wins over 'mamdr' (run.py:55-58)
+    assert type(cli.build_model(tiny_config(tmp_path, "mlp_meta_domain_negotiation_mamdr"), ds, FakeEngine)) \
+        is DomainNegotiation
+    for bad in ("star_meta_mamdr", "mmoe", "mlp_pcgrad", "mlp_uncertainty_weight", "mlp_meta_mldg", "wdl"):
+        with pytest.raises(NotImplementedError):
+            cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
+    with pytest.raises(ValueError):
+        cli.build_model(tiny_config(tmp_path, "nonsense"), ds, FakeEngine)
+
+
+# ------------------------------------------------------------------ meta loops vs oracle loops
+def test_meta_epochs_follow_oracle_loops():
+    g = small_gen()
+    sizes = {d: g["data"]["train"][d]["uid"].shape[0] for d in range(3)}
+
+    def fresh():
+        eng = FakeEngine(g["n_user"], g["n_item"], 3, 64, emb_dim=8, hidden=(16, 8, 4))
+        eng.bind_table("user_emb", g["tables"]["user_emb"])
+        eng.bind_table("item_emb", g["tables"]["item_emb"])
+        for d in range(3):
+            c = g["data"]["train"][d]
+            eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+        return eng
+
+    def perm_fn_factory():
+        return mplan.PassShuffler(sizes, 10000, 9, shuffle_fn=orng.shuffle_perm)
+
+    plan = {"seq": [1, 2, 0], "dr": [(1, [0, 1]), (2, [1, 2]), (0, [2, 0])]}
+    rs = np.random.RandomState(1)
+    # MAMDR
+    e1, e2 = fresh(), fresh()
+    theta0 = e1.oracle.get_flat().copy()
+    phis0 = [(rs.standard_normal(theta0.size) * 0.01).astype(np.float32) for _ in range(3)]
+    th_o, ph_o = theta0.copy(), [p.copy() for p in phis0]
+    tr_o = oloops.mamdr_epoch(e1.oracle, th_o, ph_o, g["data"]["train"], plan, perm_fn_factory(), 64, 0.1)
+    th_g, ph_g = torch.from_numpy(theta0.copy()), [torch.from_numpy(p.copy()) for p in phis0]
+    tr_g = meta.mamdr_epoch(e2, th_g, ph_g, plan, perm_fn_factory(), 64, lr=1e-3, meta_lr=0.1)
+    assert tr_g == tr_o
+    assert np.array_equal(th_g.numpy(), th_o)
+    for a, b in zip(ph_g, ph_o):
+        assert np.array_equal(a.numpy(), b)
+    # steps accounting
+    spd = [-(-sizes[d] // 64) for d in range(3)]
+    assert sum(t[2] for t in tr_g) == mplan.plan_steps(plan, spd)
+    # DN and Reptile (both variants)
+    for fn_g, fn_o, kw in ((meta.dn_epoch, oloops.dn_epoch, {}), (meta.reptile_epoch, oloops.reptile_epoch, {}),
+                           (meta.reptile_epoch, oloops.reptile_epoch, {"batch_variant": True})):
+        e1, e2 = fresh(), fresh()
+        th_o = theta0.copy()
+        tr_o = fn_o(e1.oracle, th_o, g["data"]["train"], [2, 0, 1], perm_fn_factory(), 64, 0.1, **kw)
+        th_g = torch.from_numpy(theta0.copy())
+        tr_g = fn_g(e2, th_g, [2, 0, 1], perm_fn_factory(), 64, 1e-3, 0.1, **kw)
+        assert tr_g == tr_o and np.array_equal(th_g.numpy(), th_o)
+        assert np.array_equal(e2.oracle.get_flat(), th_o)       # model left at theta
+
+
+def test_epoch_planner_semantics():
+    p = mplan.EpochPlanner(range(6), sample_num=3, add_query_domain=True, seed=1)
+    plan = p.next_epoch()
+    assert sorted(plan["seq"]) == list(range(6))
+    assert [q for q, _ in plan["dr"]] == plan["seq"]            # DR visits queries in the DN order
+    for q, support in plan["dr"]:
+        assert support[-1] == q and len(support) == 4 and q not in support[:-1]
+        assert len(set(support)) == 4
+    plan2 = mplan.EpochPlanner(range(6), 3, True, seed=1).next_epoch()
+    assert plan2 == plan                                         # seeded -> reproducible
+    p3 = mplan.EpochPlanner(range(3), sample_num=5, add_query_domain=False, shuffle_sequence=False)
+    plan3 = p3.next_epoch()
+    assert plan3["seq"] == [0, 1, 2] and all(len(s) == 2 for _, s in plan3["dr"])
+
+
+# ------------------------------------------------------------------ run.py end to end (CPU stand-in tower)
+@pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation_finetune",
+                                  "mlp_meta_reptile_batch", "mlp"])
+def test_run_main_end_to_end(tmp_path, monkeypatch, name):
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, name)
+    avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg, FakeEngine)
+    assert set(domain_auc) == {0, 1, 2} and 0.0 <= avg_auc <= 1.0 and np.isfinite(avg_loss)
+    assert abs(avg_auc - sum(domain_auc.values()) / 3) < 1e-12
+    # result directory layout (base_model.py:183-200)
+    rdir = os.path.join(cfg["train"]["result_save_path"], name, "Taobao", cfg["dataset"]["domain_split_path"])
+    runs = os.listdir(rdir)
+    assert len(runs) == 1 and re.match(r"loss_\d+\.\d{3}_auc_\d+\.\d{3}_", runs[0])
+    files = set(os.listdir(os.path.join(rdir, runs[0])))
+    assert {"dataset_info.json", "config.json.example", "result.json", "model_parameters.npz"} <= files
+    with open(os.path.join(rdir, runs[0], "result.json")) as f:
+        res = json.load(f)
+    assert set(res) == {"avg_loss", "avg_auc", "domain_loss", "domain_auc"} and set(res["domain_auc"]) == {"0", "1", "2"}
+    with open(os.path.join(rdir, runs[0], "dataset_info.json")) as f:
+        info = json.load(f)
+    assert info["total_train"] == sum(info[str(d)]["n_train"] for d in range(3))
+
+
+def test_mamdr_wrapper_quirks(tmp_path, monkeypatch):
+    """phi_d = fresh random init of the whole model; finetune = SGD lr 0.001 from best merged weights."""
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "mlp_meta_mamdr_finetune", epochs=1)
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    model = cli.build_model(cfg, ds, FakeEngine)
+    model.train()
+    phi0 = model.domain_weights[0].numpy()
+    assert np.abs(phi0).max() > 0.05                              # glorot-scale kernels, not zeros
+    assert not np.array_equal(phi0, model.domain_weights[1].numpy())
+    assert model.best_shared_weights is not None and set(model.best_domain_weights) == {0, 1, 2}
+    model.model.calls.clear()
+    model.separate_train_val_test(init_parms=False)
+    assert model.model.calls and all(c[2] == "sgd" and c[3] == 0.001 for c in model.model.calls)
+    # every DR pass pair: support pass then query pass; DN first
+    phases = [t[0] for t in model.trace]
+    n_dom = 3
+    assert phases[:n_dom] == ["dn"] * n_dom
+    assert phases[n_dom:] == ["dr_support", "dr_query"] * ((len(phases) - n_dom) // 2)
+
+
+def test_early_stop_counts_ties(tmp_path, monkeypatch):
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "mlp")
+    cfg["train"]["patience"] = 2
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    m = cli.build_model(cfg, ds, FakeEngine)
+    assert m.early_stop_step(0.7) is False
+    assert m.early_stop_step(0.7) is False and m.counter == 1     # equal counts as no improvement
+    assert m.early_stop_step(0.8) is False and m.counter == 0
+    assert m.early_stop_step(0.75) is False
+    assert m.early_stop_step(0.8) is True
+
+
+# ------------------------------------------------------------------ dataset formats (utils/dataset.py)
+def test_reference_layout_round_trip(tmp_path):
+    g = small_gen()
+    root = str(tmp_path / "dataset" / "Taobao")
+    mds.write_reference_layout(g, root, "split_by_theme_3")
+    conf = {"name": "Taobao", "dataset_path": root, "domain_split_path": "split_by_theme_3", "batch_size": 64,
+            "shuffle_buffer_size": 10000, "num_parallel_reads": 8, "seed": 5}
+    for attempt in range(2):                                     # second pass reads the .npz cache
+        ds = mds.MultiDomainDataset(conf)
+        assert (ds.n_uid, ds.n_pid, ds.n_domain) == (g["n_user"], g["n_item"], 3)
+        for d in range(3):
+            for split, store in (("train", ds.train_dataset), ("val", ds.val_dataset), ("test", ds.test_dataset)):
+                for c in mds.COLUMNS:
+                    assert np.array_equal(store[d]["data"][c], g["data"][split][d][c])
+                n = g["data"][split][d]["uid"].shape[0]
+                assert store[d]["n_data"] == n and store[d]["n_step"] == -(-n // 64)
+            assert ds.ctr_ratio[d] == g["info"][d]["ctr_ratio"]
+        assert np.array_equal(ds.user_emb, g["tables"]["user_emb"])
+        assert np.array_equal(ds.item_emb, g["tables"]["item_emb"])
+    info = ds.dataset_info
+    assert info["n_user"] == g["n_user"] and info["total_val"] == sum(info[d]["n_val"] for d in range(3))
+
+
+def test_missing_dataset_is_a_clear_error(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        mds.MultiDomainDataset({"name": "Taobao", "dataset_path": str(tmp_path), "domain_split_path": "nope",
+                                "batch_size": 64, "shuffle_buffer_size": 10, "num_parallel_reads": 1, "seed": 1})
+
+
+def test_synthetic_shapes_match_table_one():
+    g = synthetic.generate("taobao10", batch_size=1024)
+    assert g["n_domain"] == 10 and g["n_user"] == 23778 and g["n_item"] == 6932
+    assert g["info"]["total_train"] == 92137 and g["info"]["total_val"] == 37645 and g["info"]["total_test"] == 43502
+    sizes = [g["info"][d]["n_train"] for d in range(10)]
+    assert min(sizes) >= 1024 and max(sizes) > 5 * min(sizes)     # long tail, every domain >= one batch
+    for d in range(10):
+        c = g["data"]["train"][d]
+        assert c["uid"].dtype == np.int32 and c["label"].dtype == np.float32
+        assert set(np.unique(c["label"])) <= {0.0, 1.0} and np.all(c["domain"] == d)
+        r = g["info"][d]["ctr_ratio"]
+        assert 0.2 <= r <= 0.5
