@@ -73,13 +73,14 @@ struct mamdr_ctx {
     float* acts = nullptr;
     float* dz = nullptr;
     float* dlogit = nullptr;
-    float* dxe = nullptr;
+    float* w0dom_copy = nullptr;
     int32_t* domrow = nullptr;
     float* loss_part = nullptr;     // train: per tile of a batch
     float* eval_part = nullptr;     // eval: per tile of a split (grown on bind)
     int64_t eval_part_cap = 0;
     float* slabs = nullptr;
     int max_groups = 16;
+    int slab_ld = 0;            // dense block + S region ([n_domain][256])
     TileDesc* tiles = nullptr;
     int n_tiles = 0;
     float* thresholds = nullptr;
@@ -111,11 +112,12 @@ std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain) {
     // output unit: dwo = h3^T dlogit, dgb = sum dlogit
     for (int m0 = 0; m0 < H3; m0 += 32) t.push_back(TileDesc{0, XDIM + H1 + H2 + m0, 1, 0, L.wo + m0, 1, 32, 1});
     t.push_back(TileDesc{1, 0, 1, 0, L.gb, 0, 1, 1});
-    // domain table: dDm = onehot(domain)^T dxe  (segmented sum, fixed order)
+    // domain table, by linearity: S = onehot(domain)^T dz1 ([n_domain][256], behind the dense block in
+    // the slab); k_update turns it into dDm = S . W0[256:384,:]^T
     for (int m0 = 0; m0 < n_domain; m0 += 32)
-        for (int n0 = 0; n0 < EMB; n0 += 32) {
+        for (int n0 = 0; n0 < H1; n0 += 32) {
             const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
-            t.push_back(TileDesc{2, m0, 2, n0, L.dm + m0 * EMB + n0, EMB, mv, 32});
+            t.push_back(TileDesc{2, m0, 0, n0, L.alloc + m0 * H1 + n0, H1, mv, 32});
         }
     return t;
 }
@@ -207,6 +209,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     c->n_params = c->table_floats + c->L.alloc;
     c->data.resize((size_t)cfg->n_domain * 3);
     c->rows_pad_max = cfg->max_batch;
+    c->slab_ld = c->L.alloc + cfg->n_domain * H1;
 
     const size_t rp = (size_t)c->rows_pad_max;
     std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain);
@@ -227,16 +230,16 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->acts, rp * ACT_LD * sizeof(float));
     ALLOC(c->dz, rp * DZ_LD * sizeof(float));
     ALLOC(c->dlogit, rp * sizeof(float));
-    ALLOC(c->dxe, rp * EMB * sizeof(float));
+    ALLOC(c->w0dom_copy, (size_t)EMB * H1 * sizeof(float));
     ALLOC(c->domrow, rp * sizeof(int32_t));
     ALLOC(c->loss_part, (rp / TILE_ROWS) * sizeof(float));
-    ALLOC(c->slabs, (size_t)c->max_groups * c->L.alloc * sizeof(float));
+    ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
     ALLOC(c->frozen_sumsq, 2 * sizeof(float));
     ALLOC(c->sumsq_partials, 1024 * sizeof(float));
 #undef ALLOC
-    hipError_t e = hipMemsetAsync(c->slabs, 0, (size_t)c->max_groups * c->L.alloc * sizeof(float), c->stream);
+    hipError_t e = hipMemsetAsync(c->slabs, 0, (size_t)c->max_groups * c->slab_ld * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->frozen_sumsq, 0, 2 * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->thresholds, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream);
@@ -256,7 +259,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->dxe, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -399,7 +402,6 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.acts = c->acts;
         ta.dz = c->dz;
         ta.dlogit = c->dlogit;
-        ta.dxe = c->dxe;
         ta.domrow = c->domrow;
         ta.loss_part = c->loss_part;
 #ifdef MAMDR_STAMPS
@@ -415,7 +417,6 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         wa.acts = c->acts;
         wa.dz = c->dz;
         wa.dlogit = c->dlogit;
-        wa.dxe = c->dxe;
         wa.domrow = c->domrow;
         wa.tiles = c->tiles;
         wa.n_tiles = c->n_tiles;
@@ -429,7 +430,9 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         wa.n_groups = groups;
         wa.rows_per_group = rpg;
         wa.slabs = c->slabs;
-        wa.slab_ld = c->L.alloc;
+        wa.slab_ld = c->slab_ld;
+        wa.w0dom = c->params + c->table_floats + c->L.w0 + (size_t)(2 * EMB) * H1;
+        wa.w0dom_copy = c->w0dom_copy;
         wa.loss_part = c->loss_part;
         wa.n_loss_tiles = rows_pad / TILE_ROWS;
         wa.rows = rows;
@@ -450,7 +453,9 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ua.v = c->adam_v + c->table_floats;
         ua.slabs = c->slabs;
         ua.n_groups = groups;
-        ua.slab_ld = c->L.alloc;
+        ua.slab_ld = c->slab_ld;
+        ua.s_off = c->L.alloc;
+        ua.w0dom_copy = c->w0dom_copy;
         ua.count4 = c->L.alloc / 4;
         ua.dm_count = c->cfg.n_domain * EMB;
         ua.two_l2 = 2.0f * c->cfg.l2_emb;

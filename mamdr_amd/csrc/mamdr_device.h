@@ -53,7 +53,11 @@ __device__ __forceinline__ uint32_t mamdr_dropout_u32(uint32_t key, uint32_t ele
     return fmix32(key + 0x9E3779B9u * elem);
 }
 
+#ifdef MAMDR_ABLATE_MFMA   // diagnostic builds only: keep the operands live, skip the matrix op
+#define MAMDR_MFMA16(a, b, c) ((c) + (f32x4){(a), (b), (a), (b)})
+#else
 #define MAMDR_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
 #define MAMDR_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 }  // namespace mamdr

@@ -35,7 +35,6 @@ struct TowerArgs {
     float* acts;               // [rows_pad][ACT_LD]
     float* dz;                 // [rows_pad][DZ_LD]
     float* dlogit;             // [rows_pad]
-    float* dxe;                // [rows_pad][EMB]   d loss / d domain-embedding row
     int32_t* domrow;           // [rows_pad]
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
     // eval outputs
@@ -50,7 +49,7 @@ struct TowerArgs {
 // weight-gradient GEMMs (K = batch rows) + bias / output-layer / domain-table sums
 struct TileDesc {
     int a_kind, a_off;         // 0: acts column block, 1: ones (row 0), 2: one-hot(domain) rows a_off..
-    int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0), 2: dxe column block
+    int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0)
     int dst_off, dst_ld;       // destination in the dense-block gradient slab
     int m_valid, n_valid;      // valid rows / cols of the 32x32 tile
 };
@@ -59,7 +58,6 @@ struct WgradArgs {
     const float* acts;
     const float* dz;
     const float* dlogit;
-    const float* dxe;
     const int32_t* domrow;
     const TileDesc* tiles;
     int n_tiles;
@@ -77,6 +75,8 @@ struct WgradArgs {
     float l2_emb;
     const float* frozen_sumsq; // [2] sum of squares of frozen user / item tables (0 if trainable)
     float* loss_out;           // nullable: 1 float
+    const float* w0dom;        // W0[256:384, :] (live weights)
+    float* w0dom_copy;         // its pre-update snapshot, read by k_update
 };
 
 struct UpdateArgs {
@@ -87,7 +87,9 @@ struct UpdateArgs {
     int n_groups;
     int slab_ld;
     int count4;                // float4 elements
-    int dm_count;              // elements [0, dm_count) get the 2*l2*p regulariser gradient
+    int dm_count;              // elements [0, dm_count): domain table, gradient = S . W0dom^T + 2*l2*p
+    int s_off;                 // offset of S = onehot(domain)^T dz1 ([n_domain][256]) inside a slab
+    const float* w0dom_copy;
     float two_l2;
     int optimizer;             // 0 adam, 1 sgd
     float alpha;               // adam: lr*sqrt(1-b2^t)/(1-b1^t); sgd: lr

@@ -43,6 +43,9 @@ template <> struct VecT<4> { typedef f32x4 type; };
 template <> struct VecT<2> { typedef f32x2 type; };
 template <> struct VecT<1> { typedef float type; };
 
+constexpr int TOWER_THREADS = 512;   // 8 waves = 2 per SIMD: one wave's epilogue / waits overlap the other's MFMAs
+constexpr int TOWER_WAVES = TOWER_THREADS / 64;
+
 template <int TPW>
 __device__ __forceinline__ void load_b_rows(float (&b)[4][TPW], const float* __restrict__ p, int ld) {
     typedef typename VecT<TPW>::type V;
@@ -58,80 +61,99 @@ __device__ __forceinline__ void load_b_rows(float (&b)[4][TPW], const float* __r
     }
 }
 
+// 16-deep chunk of the forward contraction.  With one tile per wave a single accumulator
+// would chain on the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32, so even / odd
+// sub-steps use two chains (acc[0], odd).
 template <int TPW>
-__device__ __forceinline__ void mfma_fwd_chunk(f32x4 (&acc)[TPW], const f32x4 a, const float (&b)[4][TPW]) {
+__device__ __forceinline__ void mfma_fwd_chunk(f32x4 (&acc)[TPW], f32x4& odd, const f32x4 a, const float (&b)[4][TPW]) {
+    if constexpr (TPW == 1) {
+        acc[0] = MAMDR_MFMA16(a[0], b[0][0], acc[0]);
+        odd = MAMDR_MFMA16(a[1], b[1][0], odd);
+        acc[0] = MAMDR_MFMA16(a[2], b[2][0], acc[0]);
+        odd = MAMDR_MFMA16(a[3], b[3][0], odd);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b[s][t], acc[t]);
-}
-// one tile per wave (the 64-wide layer): a single accumulator would serialise on the
-// 40-cycle dependent latency of v_mfma_f32_16x16x4_f32, so even / odd sub-steps use two chains
-__device__ __forceinline__ void mfma_fwd_chunk2(f32x4& acc0, f32x4& acc1, const f32x4 a, const float (&b)[4][1]) {
-    acc0 = MAMDR_MFMA16(a[0], b[0][0], acc0);
-    acc1 = MAMDR_MFMA16(a[1], b[1][0], acc1);
-    acc0 = MAMDR_MFMA16(a[2], b[2][0], acc0);
-    acc1 = MAMDR_MFMA16(a[3], b[3][0], acc1);
+            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a[s], b[s][t], acc[t]);
+    }
 }
 
 // ---- forward layer: H[16 x N] = relu(A[16 x K] . W[K x N] + bias) (* dropout).
-// Wave w owns N/4 consecutive columns; lane (j = lane & 15) owns TPW consecutive columns of
-// them, so one 4/8/16-byte load per k row feeds TPW MFMAs, and the k index inside each
+// NW waves split the N columns (16 TPW each); lane (j = lane & 15) owns TPW consecutive
+// columns, so one 4/8/16-byte load per k row feeds TPW MFMAs, and the k index inside each
 // 16-deep chunk is permuted identically for A and B (slot k' of sub-step s is
 // k = kk0 + 4 k' + s), which turns the A fragment into one ds_read_b128.
 // The weight stream is independent of the activations: a PF-deep register ring keeps PF
-// chunks (PF x 4 KiB per wave for the widest layer) in flight from L2, and the first PF
-// chunks of a layer are requested before the barrier that publishes its input.
-template <int K, int N, int PF>
+// chunks in flight from L2, pinned with sched_barrier (the scheduler otherwise sinks the
+// loads to their use and serialises on vmcnt(0)); the first PF chunks and the bias (rewritten
+// by k_update every step = an L2 miss) are requested one phase early by `prefetch`.
+template <int K, int N, int PF, int NW>
 struct FwdW {
-    static constexpr int TPW = N / 64;
+    static constexpr int TPW = N / (16 * NW);
     static constexpr int NC = K / 16;
+    static_assert(TPW >= 1 && N == 16 * NW * TPW, "columns must split evenly over the active waves");
     float b[PF][4][TPW];
-    const float* wp;
-    int ncol;
-    __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        ncol = w * (16 * TPW) + TPW * (lane & 15);
-        wp = W + (size_t)(4 * (lane >> 4)) * N + ncol;
+    float bias[TPW];
+    // (only register arrays live in the struct: scalar members captured through the `mid`
+    // lambdas would be kept in scratch memory)
+    static __device__ __forceinline__ bool active() { return (int)(threadIdx.x >> 6) < NW; }
+    static __device__ __forceinline__ int ncol() {
+        return (int)(threadIdx.x >> 6) * (16 * TPW) + TPW * (int)(threadIdx.x & 15);
+    }
+    static __device__ __forceinline__ const float* wptr(const float* __restrict__ W) {
+        return W + (size_t)(4 * ((threadIdx.x & 63) >> 4)) * N + ncol();
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W, const float* __restrict__ bias_ptr) {
+        if (!active()) return;
+        const int ncol = this->ncol();
+        const float* wp = wptr(W);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bias[t] = bias_ptr[ncol + t];
 #pragma unroll
         for (int c = 0; c < PF && c < NC; ++c) load_b_rows<TPW>(b[c], wp + (size_t)(16 * c) * N, N);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
 
-template <int K, int N, int LDA, int LDO, bool TRAIN, int PF>
-__device__ __forceinline__ void fwd_layer(FwdW<K, N, PF>& fw, const float* __restrict__ bias, const float* As,
-                                          float* Os, float* gout, uint32_t key, uint32_t thresh, float scale,
-                                          bool use_dropout, int row0) {
-    constexpr int TPW = N / 64;
+// `mid()` runs between the K loop and the epilogue: the caller requests the NEXT layer's
+// weights there, so that those loads are older than this epilogue's global stores (vmcnt
+// retires in issue order: a load queued behind the stores would wait for all of them).
+template <int K, int N, int LDA, int LDO, bool TRAIN, int PF, int NW, typename Mid>
+__device__ __forceinline__ void fwd_layer(FwdW<K, N, PF, NW>& fw, const float* __restrict__ W, const float* As,
+                                          float* Os, float* gout,
+                                          uint32_t key, uint32_t thresh, float scale, bool use_dropout, int row0,
+                                          Mid mid) {
+    constexpr int TPW = FwdW<K, N, PF, NW>::TPW;
     constexpr int NC = K / 16;
+    static_assert(NC % PF == 0, "chunk count must be a multiple of the ring depth");
+    if (!FwdW<K, N, PF, NW>::active()) {
+        mid();
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
-    const int ncol = fw.ncol;
+    const int ncol = FwdW<K, N, PF, NW>::ncol();
+    const float* wp = FwdW<K, N, PF, NW>::wptr(W);
     f32x4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const float bv = bias[ncol + t];
+        const float bv = fw.bias[t];
         acc[t] = (f32x4){bv, bv, bv, bv};
     }
+    f32x4 odd = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* ap = As + j * LDA + 4 * kq;
-    static_assert(NC % PF == 0, "chunk count must be a multiple of the ring depth");
-    // main groups: compute chunk c0+u from ring slot u, then refill the slot with chunk
-    // c0+u+PF.  sched_barrier pins each refill right behind its chunk (the scheduler
-    // otherwise sinks the loads to their use and serialises on vmcnt(0)).
     f32x4 a_cur = *reinterpret_cast<const f32x4*>(ap);
-    f32x4 acc_odd = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int c0 = 0; c0 < NC - PF; c0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             // A fragment of the NEXT chunk is requested before this chunk's MFMAs
             const f32x4 a_next = *reinterpret_cast<const f32x4*>(ap + 16 * (c0 + u + 1));
-            __builtin_amdgcn_sched_barrier(0);   // keep the read ahead of the MFMAs
-            if constexpr (TPW == 1) mfma_fwd_chunk2(acc[0], acc_odd, a_cur, fw.b[u]);
-            else mfma_fwd_chunk<TPW>(acc, a_cur, fw.b[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_fwd_chunk<TPW>(acc, odd, a_cur, fw.b[u]);
 #ifndef MAMDR_ABLATE_LOADS   // diagnostic builds only: time the loop without its weight stream
-            load_b_rows<TPW>(fw.b[u], fw.wp + (size_t)(16 * (c0 + u + PF)) * N, N);
+            load_b_rows<TPW>(fw.b[u], wp + (size_t)(16 * (c0 + u + PF)) * N, N);
 #endif
             __builtin_amdgcn_sched_barrier(0);
             a_cur = a_next;
@@ -142,12 +164,12 @@ __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF>& fw, const float* __res
         f32x4 a_next = a_cur;
         if (u + 1 < PF) a_next = *reinterpret_cast<const f32x4*>(ap + 16 * (NC - PF + u + 1));
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TPW == 1) mfma_fwd_chunk2(acc[0], acc_odd, a_cur, fw.b[u]);
-        else mfma_fwd_chunk<TPW>(acc, a_cur, fw.b[u]);
+        mfma_fwd_chunk<TPW>(acc, odd, a_cur, fw.b[u]);
         __builtin_amdgcn_sched_barrier(0);
         a_cur = a_next;
     }
-    if constexpr (TPW == 1) acc[0] += acc_odd;
+    if constexpr (TPW == 1) acc[0] += odd;
+    mid();
     typedef typename VecT<TPW>::type V;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -156,10 +178,12 @@ __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF>& fw, const float* __res
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             float z = fmaxf(acc[t][r], 0.0f);
+#ifndef MAMDR_ABLATE_HASH
             if (TRAIN && use_dropout) {
                 const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(row0 + row) * (uint32_t)N + (uint32_t)(ncol + t));
                 z = (u >= thresh) ? z * scale : 0.0f;
             }
+#endif
             h[t] = z;
         }
         V v;
@@ -170,7 +194,9 @@ __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF>& fw, const float* __res
             for (int t = 0; t < TPW; ++t) v[t] = h[t];
         }
         *reinterpret_cast<V*>(Os + row * LDO + ncol) = v;
+#ifndef MAMDR_ABLATE_STORES
         if (TRAIN) *reinterpret_cast<V*>(gout + (size_t)row * ACT_LD + ncol) = v;
+#endif
     }
 }
 
@@ -179,14 +205,18 @@ __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF>& fw, const float* __res
 // k = kk0 + 8 k' .. +7 as two 16-B loads, so the four k' lanes of a row consume one whole
 // 128-B line; sub-step s of the chunk uses component s (slot k' <-> k = kk0 + 8 k' + s), the
 // same permutation as the A fragment (two ds_read_b128).
-template <int K, int N, int LDW, int PF>
+template <int K, int N, int LDW, int PF, int NW>
 struct BwdW {
-    static constexpr int TPW = N / 64;
+    static constexpr int TPW = N / (16 * NW);
     static constexpr int NC = K / 32;
+    static_assert(TPW >= 1 && N == 16 * NW * TPW, "columns must split evenly over the active waves");
     f32x4 b[PF][TPW][2];
-    const float* wp;
-    int nbase;
-    __device__ __forceinline__ void load(int slot, int c) {
+    static __device__ __forceinline__ bool active() { return (int)(threadIdx.x >> 6) < NW; }
+    static __device__ __forceinline__ int nbase() { return (int)(threadIdx.x >> 6) * (16 * TPW); }
+    static __device__ __forceinline__ const float* wptr(const float* __restrict__ W) {
+        return W + (size_t)(nbase() + (int)(threadIdx.x & 15)) * LDW + 8 * ((threadIdx.x & 63) >> 4);
+    }
+    __device__ __forceinline__ void load(int slot, int c, const float* wp) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             const float* q = wp + (size_t)(16 * t) * LDW + 32 * c;
@@ -195,38 +225,58 @@ struct BwdW {
         }
     }
     __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        nbase = w * (16 * TPW);
-        wp = W + (size_t)(nbase + (lane & 15)) * LDW + 8 * (lane >> 4);
+        if (!active()) return;
+        const float* wp = wptr(W);
 #pragma unroll
-        for (int c = 0; c < PF && c < NC; ++c) load(c, c);
+        for (int c = 0; c < PF && c < NC; ++c) load(c, c, wp);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
 
 template <int TPW>
-__device__ __forceinline__ void mfma_bwd_chunk(f32x4 (&acc)[TPW], const f32x4 a0, const f32x4 a1,
+__device__ __forceinline__ void mfma_bwd_chunk(f32x4 (&acc)[TPW], f32x4& odd, const f32x4 a0, const f32x4 a1,
                                                const f32x4 (&b)[TPW][2]) {
+    if constexpr (TPW == 1) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; s += 2) {
+            acc[0] = MAMDR_MFMA16(a0[s], b[0][0][s], acc[0]);
+            odd = MAMDR_MFMA16(a0[s + 1], b[0][0][s + 1], odd);
+        }
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a0[s], b[t][0][s], acc[t]);
+        for (int s = 0; s < 4; s += 2) {
+            acc[0] = MAMDR_MFMA16(a1[s], b[0][1][s], acc[0]);
+            odd = MAMDR_MFMA16(a1[s + 1], b[0][1][s + 1], odd);
+        }
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a1[s], b[t][1][s], acc[t]);
+            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a0[s], b[t][0][s], acc[t]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = MAMDR_MFMA16(a1[s], b[t][1][s], acc[t]);
+    }
 }
 
-template <int K, int N, int LDW, int LDA, int PF, typename Epi>
-__device__ __forceinline__ void bwd_layer(BwdW<K, N, LDW, PF>& bw, const float* As, Epi epi) {
-    constexpr int TPW = N / 64;
+template <int K, int N, int LDW, int LDA, int PF, int NW, typename Mid, typename Epi>
+__device__ __forceinline__ void bwd_layer(BwdW<K, N, LDW, PF, NW>& bw, const float* __restrict__ W, const float* As,
+                                          Mid mid, Epi epi) {
+    constexpr int TPW = BwdW<K, N, LDW, PF, NW>::TPW;
     constexpr int NC = K / 32;
     static_assert(NC % PF == 0, "chunk count must be a multiple of the ring depth");
+    if (!BwdW<K, N, LDW, PF, NW>::active()) {
+        mid();
+        return;
+    }
+    const float* wp = BwdW<K, N, LDW, PF, NW>::wptr(W);
+    const int nbase = BwdW<K, N, LDW, PF, NW>::nbase();
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, kq = lane >> 4;
     f32x4 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 odd = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* ap = As + j * LDA + 8 * kq;
     f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
 #pragma unroll 1
@@ -236,9 +286,9 @@ __device__ __forceinline__ void bwd_layer(BwdW<K, N, LDW, PF>& bw, const float* 
             const f32x4 n0 = *reinterpret_cast<const f32x4*>(ap + 32 * (c0 + u + 1));
             const f32x4 n1 = *reinterpret_cast<const f32x4*>(ap + 32 * (c0 + u + 1) + 4);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_bwd_chunk<TPW>(acc, a0, a1, bw.b[u]);
+            mfma_bwd_chunk<TPW>(acc, odd, a0, a1, bw.b[u]);
 #ifndef MAMDR_ABLATE_LOADS
-            bw.load(u, c0 + u + PF);
+            bw.load(u, c0 + u + PF, wp);
 #endif
             __builtin_amdgcn_sched_barrier(0);
             a0 = n0;
@@ -253,15 +303,17 @@ __device__ __forceinline__ void bwd_layer(BwdW<K, N, LDW, PF>& bw, const float* 
             n1 = *reinterpret_cast<const f32x4*>(ap + 32 * (NC - PF + u + 1) + 4);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_bwd_chunk<TPW>(acc, a0, a1, bw.b[u]);
+        mfma_bwd_chunk<TPW>(acc, odd, a0, a1, bw.b[u]);
         __builtin_amdgcn_sched_barrier(0);
         a0 = n0;
         a1 = n1;
     }
+    if constexpr (TPW == 1) acc[0] += odd;
+    mid();
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) epi(4 * kq + r, bw.nbase + 16 * t + j, acc[t][r]);
+        for (int r = 0; r < 4; ++r) epi(4 * kq + r, nbase + 16 * t + j, acc[t][r]);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -287,15 +339,15 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
         rowf[tid] = a.label[src];
     }
     __syncthreads();
-    // 16 rows x 96 float4: 32 consecutive lanes read one 512-B embedding row.  Six
-    // independent loads per thread are issued back to back (indices are clamped, so the
-    // loads of padding rows are harmless and are zeroed afterwards).
+    // 16 rows x 96 float4: 32 consecutive lanes read one 512-B embedding row.  The loads of a
+    // thread are independent and issued back to back (indices are clamped, so the loads of
+    // padding rows are harmless and are zeroed afterwards).
     float* xs = smem + XS_OFF;
-    constexpr int PER = TILE_ROWS * (XDIM / 4) / 256;   // 6
+    constexpr int PER = TILE_ROWS * (XDIM / 4) / TOWER_THREADS;   // 3
     f32x4 v[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + TOWER_THREADS * u;
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
         const int seg = c4 >> 5, off = (c4 & 31) * 4;
         const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
@@ -303,7 +355,7 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int e = tid + 256 * u;
+        const int e = tid + TOWER_THREADS * u;
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
         if (!rowi[3 * TILE_ROWS + row]) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v[u];
@@ -327,79 +379,78 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
 #define STAMP(k) do { } while (0)
 #endif
 
-// prefetch depths (16-deep k chunks in flight per wave)
-constexpr int PF0 = 4, PF1 = 4, PF2 = 4;   // forward: 16-deep chunks
-constexpr int PFB2 = 2, PFB1 = 2, PFB0 = 4;  // backward: 32-deep chunks
+// ring depths: forward in 16-deep chunks, backward in 32-deep chunks
+constexpr int PF0 = 4, PF1 = 4, PF2 = 4;
+constexpr int PFB2 = 2, PFB1 = 2;
 
 template <bool TRAIN>
-__global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
+__global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
     const int r0 = tile * TILE_ROWS;
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
-    float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;   // [0,16) label, [16,32) dlogit
+    float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;   // [0,16) label, [32,40) per-wave loss
     float* acts_t = TRAIN ? a.acts + (size_t)r0 * ACT_LD : nullptr;
 
     const float* P = a.dense;
-    // layer-0 weights do not depend on the gather: request them first
-    FwdW<XDIM, H1, PF0> fw0;
+    // layer-0 weights and the output-unit parameters do not depend on the gather: request them first
+    FwdW<XDIM, H1, PF0, 8> fw0;
+    FwdW<H1, H2, PF1, 8> fw1;
+    FwdW<H2, H3, PF2, 4> fw2;
+    BwdW<H3, H2, H3, PFB2, 8> bw2;
+    BwdW<H2, H1, H2, PFB1, 8> bw1;
     STAMP(0);
-    fw0.prefetch(P + a.L.w0);
+    fw0.prefetch(P + a.L.w0, P + a.L.b0);
+    const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
+    const float gb_reg = P[a.L.gb];
 
     gather_tile(a, smem, r0, acts_t, ACT_LD);
     STAMP(1);
 
     const float scale = a.use_dropout ? a.keep_scale : 1.0f;
-    // row index inside the batch seeds the dropout stream (eval: unused)
-    const int row0 = r0;
+    const int row0 = r0;   // row index inside the batch seeds the dropout stream
     const uint32_t key0 = TRAIN ? dropout_layer_key(a.seed, a.step, 0) : 0u;
     const uint32_t key1 = TRAIN ? dropout_layer_key(a.seed, a.step, 1) : 0u;
     const uint32_t key2 = TRAIN ? dropout_layer_key(a.seed, a.step, 2) : 0u;
 
-    fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN, PF0>(fw0, P + a.L.b0, smem + XS_OFF, smem + H1S_OFF,
-                                                  TRAIN ? acts_t + XDIM : nullptr, key0, a.drop_thresh, scale,
-                                                  a.use_dropout != 0, row0);
+    fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(fw0, P + a.L.w0, smem + XS_OFF, smem + H1S_OFF, TRAIN ? acts_t + XDIM : nullptr,
+                                             key0, a.drop_thresh, scale, a.use_dropout != 0, row0,
+                                             [&]() { fw1.prefetch(P + a.L.w1, P + a.L.b1); });
     STAMP(2);
-    FwdW<H1, H2, PF1> fw1;
-    fw1.prefetch(P + a.L.w1);
     __syncthreads();
-    fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN, PF1>(fw1, P + a.L.b1, smem + H1S_OFF, smem + H2S_OFF,
-                                                TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
-                                                a.use_dropout != 0, row0);
+    fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN>(fw1, P + a.L.w1, smem + H1S_OFF, smem + H2S_OFF,
+                                           TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
+                                           a.use_dropout != 0, row0,
+                                           [&]() { fw2.prefetch(P + a.L.w2, P + a.L.b2); });
     STAMP(3);
-    FwdW<H2, H3, PF2> fw2;
-    fw2.prefetch(P + a.L.w2);
     __syncthreads();
-    fwd_layer<H2, H3, H2_LD, H3_LD, TRAIN, PF2>(fw2, P + a.L.b2, smem + H2S_OFF, smem + H3S_OFF,
-                                                TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh,
-                                                scale, a.use_dropout != 0, row0);
+    // the backward weights are requested ahead of layer 2's epilogue stores
+    fwd_layer<H2, H3, H2_LD, H3_LD, TRAIN>(fw2, P + a.L.w2, smem + H2S_OFF, smem + H3S_OFF,
+                                           TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh, scale,
+                                           a.use_dropout != 0, row0, [&]() {
+                                               if (TRAIN) {
+                                                   bw2.prefetch(P + a.L.w2);
+                                                   bw1.prefetch(P + a.L.w1);
+                                               }
+                                           });
     STAMP(4);
     __syncthreads();
 
-    // backward weights of layer 2 (all of K = 64) are requested before the output phase
-    BwdW<H3, H2, H3, PFB2> bw2;
-    BwdW<H2, H1, H2, PFB1> bw1;
-    if (TRAIN) {
-        bw2.prefetch(P + a.L.w2);
-        bw1.prefetch(P + a.L.w1);
-    }
-
-    // ---- output unit, sigmoid, Keras BCE and dz3, all 256 threads: thread (i, part) owns
-    // 4 of the 64 hidden units of row i; the 16 lanes of a row reduce by xor-shuffles.
+    // ---- output unit, sigmoid, Keras BCE and dz3, all 512 threads: thread (i, part) owns
+    // 2 of the 64 hidden units of row i; the 32 lanes of a row reduce by xor-shuffles.
     float* dz_t = TRAIN ? a.dz + (size_t)r0 * DZ_LD : nullptr;
     {
-        const int i = tid >> 4, part = tid & 15, n4 = part * 4;
-        const f32x4 wo = *reinterpret_cast<const f32x4*>(P + a.L.wo + n4);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(smem + H3S_OFF + i * H3_LD + n4);
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s = fmaf(h[c], wo[c], s);
+        const int i = tid >> 5, part = tid & 31, n2 = part * 2;
+        const f32x2 wo = wo_reg;
+        const f32x2 h = *reinterpret_cast<const f32x2*>(smem + H3S_OFF + i * H3_LD + n2);
+        float s = fmaf(h[1], wo[1], h[0] * wo[0]);
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 8);
-        const float logit = s + P[a.L.gb];
+        s += __shfl_xor(s, 16);
+        const float logit = s + gb_reg;
         float p;
         if (logit >= 0.f) {
             p = 1.0f / (1.0f + __expf(-logit));
@@ -422,11 +473,11 @@ __global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
                 a.domrow[r0 + i] = rowi[2 * TILE_ROWS + i];
             }
             // gate = relu'(z) * dropout mask / keep = (h_post > 0) * scale
-            f32x4 d;
+            f32x2 d;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
-            *reinterpret_cast<f32x4*>(smem + DZ3S_OFF + i * H3_LD + n4) = d;
-            *reinterpret_cast<f32x4*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n4) = d;
+            for (int c = 0; c < 2; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
+            *reinterpret_cast<f32x2*>(smem + DZ3S_OFF + i * H3_LD + n2) = d;
+            *reinterpret_cast<f32x2*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n2) = d;
         } else if (part == 0 && valid) {
             // AUC bin = number of thresholds strictly below p (utils/metrics_utils.py:309: pred > thr)
             int blo = 0, bhi = 500;
@@ -437,67 +488,63 @@ __global__ __launch_bounds__(256) void k_tower(const TowerArgs a) {
             atomicAdd(a.hist + (y != 0.f ? 501 : 0) + blo, 1u);
             if (a.pred_out) a.pred_out[a.row_base + r0 + i] = p;
         }
-        // tile loss: the 4 rows of this wave sit in lanes 0,16,32,48 (others hold 0)
-        loss += __shfl_xor(loss, 16);
+        // tile loss: the 2 rows of this wave sit in lanes 0 and 32 (others hold 0)
         loss += __shfl_xor(loss, 32);
         if (lane == 0) rowf[2 * TILE_ROWS + w] = loss;
     }
     STAMP(5);
     __syncthreads();
-    if (tid == 0)
-        a.loss_part[tile] = ((rowf[2 * TILE_ROWS] + rowf[2 * TILE_ROWS + 1]) + rowf[2 * TILE_ROWS + 2]) +
-                            rowf[2 * TILE_ROWS + 3];
+    if (tid == 0) {
+        const float* lp = rowf + 2 * TILE_ROWS;
+        a.loss_part[tile] = (((lp[0] + lp[1]) + (lp[2] + lp[3])) + ((lp[4] + lp[5]) + (lp[6] + lp[7])));
+    }
     if (!TRAIN) return;
     STAMP(6);
-    // d loss / d domain-embedding row = dz1 . W0[256:384, :]^T: weights requested two phases early
-    BwdW<H1, EMB, H1, PFB0> bw0;
-    bw0.prefetch(P + a.L.w0 + (size_t)(2 * EMB) * H1);
     {
         float* dzs = smem + DZ2S_OFF;
         const float* hs = smem + H2S_OFF;
-        bwd_layer<H3, H2, H3, H3_LD, PFB2>(bw2, smem + DZ3S_OFF, [&](int row, int col, float v) {
+        bwd_layer<H3, H2, H3, H3_LD>(bw2, P + a.L.w2, smem + DZ3S_OFF, []() {}, [&](int row, int col, float v) {
             const float d = (hs[row * H2_LD + col] > 0.f) ? v * scale : 0.f;
             dzs[row * H2_LD + col] = d;
+#ifndef MAMDR_ABLATE_STORES
             dz_t[(size_t)row * DZ_LD + H1 + col] = d;
+#endif
         });
     }
     STAMP(7);
     __syncthreads();
     {
-        float* dzs = smem + DZ1S_OFF;
+        // dz1 is only stored: the gradient of the domain-embedding rows follows from it by
+        // linearity in k_wgrad / k_update (dDm = onehot(domain)^T dz1 . W0[256:384,:]^T), so no
+        // per-row contraction with W0 is needed while the user / item tables are frozen.
         const float* hs = smem + H1S_OFF;
-        bwd_layer<H2, H1, H2, H2_LD, PFB1>(bw1, smem + DZ2S_OFF, [&](int row, int col, float v) {
+        bwd_layer<H2, H1, H2, H2_LD>(bw1, P + a.L.w1, smem + DZ2S_OFF, []() {}, [&](int row, int col, float v) {
             const float d = (hs[row * H1_LD + col] > 0.f) ? v * scale : 0.f;
-            dzs[row * H1_LD + col] = d;
+#ifndef MAMDR_ABLATE_STORES
             dz_t[(size_t)row * DZ_LD + col] = d;
+#endif
         });
     }
     STAMP(8);
-    __syncthreads();
-    {
-        float* dxe_t = a.dxe + (size_t)r0 * EMB;
-        bwd_layer<H1, EMB, H1, H1_LD, PFB0>(bw0, smem + DZ1S_OFF,
-                                            [&](int row, int col, float v) { dxe_t[(size_t)row * EMB + col] = v; });
-    }
     STAMP(9);
 }
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(k_tower<true>, dim3(tiles), dim3(256), tower_lds_bytes(), s, a);
+    hipLaunchKernelGGL(k_tower<true>, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(k_tower<false>, dim3(tiles), dim3(256), tower_lds_bytes(), s, a);
+    hipLaunchKernelGGL(k_tower<false>, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
 }
 
 // ------------------------------------------------------------------ standalone gather
-__global__ __launch_bounds__(256) void k_gather(const TowerArgs a, float* out) {
+__global__ __launch_bounds__(TOWER_THREADS) void k_gather(const TowerArgs a, float* out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r0 = blockIdx.x * TILE_ROWS;
     gather_tile(a, smem, r0, nullptr, 0);
     const float* xs = smem + XS_OFF;
-    for (int e = threadIdx.x; e < TILE_ROWS * (XDIM / 4); e += 256) {
+    for (int e = threadIdx.x; e < TILE_ROWS * (XDIM / 4); e += TOWER_THREADS) {
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
         if (r0 + row < a.rows)
             *reinterpret_cast<f32x4*>(out + (size_t)(r0 + row) * XDIM + c4 * 4) =
@@ -506,7 +553,7 @@ __global__ __launch_bounds__(256) void k_gather(const TowerArgs a, float* out) {
 }
 void launch_gather(const TowerArgs& a, float* out, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(k_gather, dim3(tiles), dim3(256), tower_lds_bytes(), s, a, out);
+    hipLaunchKernelGGL(k_gather, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a, out);
 }
 
 // ------------------------------------------------------------------ eval loss epilogue
@@ -576,7 +623,9 @@ void launch_sumsq(const float* x, int64_t n, float* partials, float* out, hipStr
 // One workgroup = one 32x32 output tile x one row group; its 4 waves split the group's
 // rows and are summed through LDS in wave order.  Operands are fetched straight from
 // the row-major activation / gradient workspaces: lane (c = lane & 31, kk = lane >> 5)
-// reads element c of row b + kk, i.e. one full 128-B line per half wave.
+// reads element c of row b + kk, i.e. one full 128-B line per half wave.  The loop is
+// latency-bound (two 4-byte loads per MFMA), so loads run one 16-row block ahead of the
+// MFMAs in a second register set, pinned with sched_barrier.
 template <int AK>
 __device__ __forceinline__ float fetch_a(const WgradArgs& g, const TileDesc& t, int b, int c) {
     if (AK == 0) return g.acts[(size_t)b * ACT_LD + t.a_off + c];
@@ -586,8 +635,17 @@ __device__ __forceinline__ float fetch_a(const WgradArgs& g, const TileDesc& t, 
 template <int BK>
 __device__ __forceinline__ float fetch_b(const WgradArgs& g, const TileDesc& t, int b, int c) {
     if (BK == 0) return g.dz[(size_t)b * DZ_LD + t.b_off + c];
-    if (BK == 1) return c == 0 ? g.dlogit[b] : 0.0f;
-    return g.dxe[(size_t)b * EMB + t.b_off + c];
+    return c == 0 ? g.dlogit[b] : 0.0f;
+}
+
+template <int AK, int BK>
+__device__ __forceinline__ void wgrad_load16(const WgradArgs& g, const TileDesc& t, int b, int kk, int c,
+                                             float (&av)[8], float (&bv)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        av[u] = fetch_a<AK>(g, t, b + 2 * u + kk, c);
+        bv[u] = fetch_b<BK>(g, t, b + 2 * u + kk, c);
+    }
 }
 
 template <int AK, int BK>
@@ -595,26 +653,34 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& g, const TileDesc& t
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, kk = lane >> 5;
     int b = b0;
-    // 32 rows (16 MFMA k-steps) per iteration: all 32 loads are issued before the MFMAs
-    for (; b + 32 <= b1; b += 32) {
-        float av[16], bv[16];
+    if (b + 16 <= b1) {
+        float a0[8], v0[8], a1[8], v1[8];
+        wgrad_load16<AK, BK>(g, t, b, kk, c, a0, v0);
+        __builtin_amdgcn_sched_barrier(0);
+        // two register sets alternate: while one feeds the MFMAs the other is in flight
+        for (; b + 48 <= b1; b += 32) {
+            wgrad_load16<AK, BK>(g, t, b + 16, kk, c, a1, v1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            av[u] = fetch_a<AK>(g, t, b + 2 * u + kk, c);
-            bv[u] = fetch_b<BK>(g, t, b + 2 * u + kk, c);
+            for (int u = 0; u < 8; ++u) acc = MAMDR_MFMA32(a0[u], v0[u], acc);
+            wgrad_load16<AK, BK>(g, t, b + 32, kk, c, a0, v0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = MAMDR_MFMA32(a1[u], v1[u], acc);
         }
+        if (b + 32 <= b1) {
+            wgrad_load16<AK, BK>(g, t, b + 16, kk, c, a1, v1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc = MAMDR_MFMA32(av[u], bv[u], acc);
-    }
-    for (; b + 8 <= b1; b += 8) {
-        float av[4], bv[4];
+            for (int u = 0; u < 8; ++u) acc = MAMDR_MFMA32(a0[u], v0[u], acc);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            av[u] = fetch_a<AK>(g, t, b + 2 * u + kk, c);
-            bv[u] = fetch_b<BK>(g, t, b + 2 * u + kk, c);
+            for (int u = 0; u < 8; ++u) acc = MAMDR_MFMA32(a1[u], v1[u], acc);
+            b += 32;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = MAMDR_MFMA32(a0[u], v0[u], acc);
+            b += 16;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = MAMDR_MFMA32(av[u], bv[u], acc);
     }
     for (; b + 2 <= b1; b += 2) {
         const float av = fetch_a<AK>(g, t, b + kk, c);
@@ -623,11 +689,20 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& g, const TileDesc& t
     }
 }
 
+constexpr int W0DOM_FLOAT4 = EMB * H1 / 4;               // rows 256..383 of W0
+constexpr int W0DOM_COPY_WGS = W0DOM_FLOAT4 / 256;        // 32
+
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n_work = g.n_tiles * g.n_groups;
-    if ((int)blockIdx.x >= n_work) {
+    if ((int)blockIdx.x > n_work) {
+        // ---- snapshot of W0[256:384, :] (pre-update) for the domain-table gradient in k_update
+        const int e = ((int)blockIdx.x - n_work - 1) * 256 + tid;
+        reinterpret_cast<f32x4*>(g.w0dom_copy)[e] = reinterpret_cast<const f32x4*>(g.w0dom)[e];
+        return;
+    }
+    if ((int)blockIdx.x == n_work) {
         // ---- one extra workgroup: loss of the step = mean BCE + regularisers
         if (g.loss_out == nullptr) return;
         float* r4 = red;
@@ -657,7 +732,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     else if (t.a_kind == 1 && t.b_kind == 0) wgrad_rows<1, 0>(g, t, b0, b1, acc);
     else if (t.a_kind == 0 && t.b_kind == 1) wgrad_rows<0, 1>(g, t, b0, b1, acc);
     else if (t.a_kind == 1 && t.b_kind == 1) wgrad_rows<1, 1>(g, t, b0, b1, acc);
-    else wgrad_rows<2, 2>(g, t, b0, b1, acc);
+    else wgrad_rows<2, 0>(g, t, b0, b1, acc);
     // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     {
         const int col = lane & 31, rb = 4 * (lane >> 5);
@@ -676,43 +751,75 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     }
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------ slab reduce + optimiser
 // TF1 ApplyAdam: m += (g - m)(1-b1); v += (g^2 - v)(1-b2);
 // p -= (m * alpha) / (sqrt(v) + eps), alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host.
-__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
-    const int e4 = blockIdx.x * 256 + threadIdx.x;
-    if (e4 >= u.count4) return;
-    const size_t e = (size_t)e4 * 4;
-    f32x4 gsum = *reinterpret_cast<const f32x4*>(u.slabs + e);
-    for (int s = 1; s < u.n_groups; ++s) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(u.slabs + (size_t)s * u.slab_ld + e);
-        gsum += t;
-    }
-    f32x4 p = *reinterpret_cast<const f32x4*>(u.p + e);
-    if ((int)e < u.dm_count) gsum += u.two_l2 * p;
+__device__ __forceinline__ void optimizer_step(const UpdateArgs& u, float g, float& p, float& m, float& v) {
     if (u.optimizer == 0) {
+        m = m + (g - m) * u.omb1;
+        v = v + (g * g - v) * u.omb2;
+        p = p - (m * u.alpha) / (sqrtf(v) + u.eps);
+    } else {
+        p = p - g * u.alpha;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
+    const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
+    if ((int)blockIdx.x < n_vec_wgs) {
+        // dense weights behind the domain table: float4 per thread
+        const int e4 = u.dm_count / 4 + blockIdx.x * 256 + threadIdx.x;
+        if (e4 >= u.count4) return;
+        const size_t e = (size_t)e4 * 4;
+        f32x4 gsum = *reinterpret_cast<const f32x4*>(u.slabs + e);
+        for (int s = 1; s < u.n_groups; ++s) gsum += *reinterpret_cast<const f32x4*>(u.slabs + (size_t)s * u.slab_ld + e);
+        f32x4 p = *reinterpret_cast<const f32x4*>(u.p + e);
         f32x4 m = *reinterpret_cast<const f32x4*>(u.m + e);
         f32x4 v = *reinterpret_cast<const f32x4*>(u.v + e);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float gc = gsum[c];
-            m[c] = m[c] + (gc - m[c]) * u.omb1;
-            v[c] = v[c] + (gc * gc - v[c]) * u.omb2;
-            p[c] = p[c] - (m[c] * u.alpha) / (sqrtf(v[c]) + u.eps);
+            float pc = p[c], mc = m[c], vc = v[c];
+            optimizer_step(u, gsum[c], pc, mc, vc);
+            p[c] = pc;
+            m[c] = mc;
+            v[c] = vc;
         }
-        *reinterpret_cast<f32x4*>(u.m + e) = m;
-        *reinterpret_cast<f32x4*>(u.v + e) = v;
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) p[c] = p[c] - gsum[c] * u.alpha;
+        if (u.optimizer == 0) {
+            *reinterpret_cast<f32x4*>(u.m + e) = m;
+            *reinterpret_cast<f32x4*>(u.v + e) = v;
+        }
+        *reinterpret_cast<f32x4*>(u.p + e) = p;
+        return;
     }
-    *reinterpret_cast<f32x4*>(u.p + e) = p;
+    // domain table: one wave per element (d, c):
+    //   g = sum_k S[d][k] * W0[256 + c][k] + 2 l2 p,   S = onehot(domain)^T dz1 summed over the slabs
+    const int lane = threadIdx.x & 63;
+    const int el = ((int)blockIdx.x - n_vec_wgs) * 4 + (threadIdx.x >> 6);
+    if (el >= u.dm_count) return;
+    const int d = el / EMB, c = el - d * EMB;
+    const size_t so = (size_t)u.s_off + (size_t)d * H1 + 4 * lane;
+    f32x4 sv = *reinterpret_cast<const f32x4*>(u.slabs + so);
+    for (int s = 1; s < u.n_groups; ++s) sv += *reinterpret_cast<const f32x4*>(u.slabs + (size_t)s * u.slab_ld + so);
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
+    float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
+    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+    if (lane == 0) {
+        float p = u.p[el], m = u.m[el], v = u.v[el];
+        g += u.two_l2 * p;
+        optimizer_step(u, g, p, m, v);
+        if (u.optimizer == 0) {
+            u.m[el] = m;
+            u.v[el] = v;
+        }
+        u.p[el] = p;
+    }
 }
 void launch_update(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_update, dim3((a.count4 + 255) / 256), dim3(256), 0, s, a);
+    const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
+    hipLaunchKernelGGL(k_update, dim3(n_vec_wgs + (a.dm_count + 3) / 4), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr
