@@ -36,8 +36,9 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector peak)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 # algorithmic flops per batch row of k_tower<train> (kernel table):
-#   forward 384*256 + 256*128 + 128*64 + 64 MACs, backward chain 64*128 + 128*256 + 256*128 MACs
-TOWER_TRAIN_FLOPS_PER_ROW = 2 * ((384 * 256 + 256 * 128 + 128 * 64 + 64) + (64 * 128 + 128 * 256 + 256 * 128))
+#   forward 384*256 + 256*128 + 128*64 + 64 MACs, backward chain dz3->dz2->dz1: 64*128 + 128*256 MACs
+#   (the per-row contraction with W0[256:384] is gone: the domain-table gradient uses linearity)
+TOWER_TRAIN_FLOPS_PER_ROW = 2 * ((384 * 256 + 256 * 128 + 128 * 64 + 64) + (64 * 128 + 128 * 256))
 GATHER_BYTES_PER_ROW = 3 * 128 * 4 * 2 + 16   # read 3 rows + write 384 floats + 4 index/label words
 
 WORKLOADS = {

@@ -93,11 +93,17 @@ def bce_per_row(p, y):
     return (np.maximum(z, F32(0)) - z * y + np.log1p(np.exp(-np.abs(z), dtype=F32), dtype=F32)).astype(F32)
 
 
-def reg_loss(params):
-    """deepctr l2_reg_embedding * sum(W^2) on every table, frozen or not (A.3)."""
+def table_sumsq(table):
+    return F32(np.sum(np.square(table, dtype=F32), dtype=np.float64))
+
+
+def reg_loss(params, frozen_sumsq=None):
+    """deepctr l2_reg_embedding * sum(W^2) on every table, frozen or not (A.3).
+    frozen_sumsq: optional {name: sum of squares} of tables that never change (computed once)."""
     r = F32(0)
     for n in ("user_emb", "item_emb", "domain_emb"):
-        r = F32(r + L2_EMB * F32(np.sum(np.square(params[n], dtype=F32), dtype=np.float64)))
+        ss = frozen_sumsq[n] if frozen_sumsq and n in frozen_sumsq else table_sumsq(params[n])
+        r = F32(r + L2_EMB * ss)
     return F32(r)
 
 
@@ -128,13 +134,13 @@ def train_masks(seed, step, n_rows, hidden, rate):
     return [rng.dropout_mask(seed, step, l, n_rows, hidden[l], rate) for l in range(3)]
 
 
-def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable):
+def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None):
     """one batch: total loss (BCE mean + regularisers) and dense gradients."""
     B = uid.shape[0]
     keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
     p, hs = forward(params, uid, pid, dom, masks, keep_scale)
     y = label.astype(F32)
-    loss = F32(np.mean(bce_per_row(p, y), dtype=np.float64)) + reg_loss(params)
+    loss = F32(np.mean(bce_per_row(p, y), dtype=np.float64)) + reg_loss(params, frozen_sumsq)
     inside = ((p >= EPS_CLIP) & (p <= F32(1) - EPS_CLIP)).astype(F32)
     dlogit = ((p - y) * inside / F32(B)).astype(F32)
     g = {}
@@ -149,8 +155,9 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable):
         dh = (dz @ params["W%d" % l].T).astype(F32)
     E = params["domain_emb"].shape[1]
     two_l2 = F32(2) * L2_EMB
-    gd = np.zeros_like(params["domain_emb"], dtype=np.float64)
-    np.add.at(gd, dom, dh[:, 2 * E:3 * E].astype(np.float64))
+    # segmented sum over the few domain rows as a one-hot contraction (float64 accumulation)
+    onehot = (dom[:, None] == np.arange(params["domain_emb"].shape[0])[None, :]).astype(np.float64)
+    gd = onehot.T @ dh[:, 2 * E:3 * E].astype(np.float64)
     g["domain_emb"] = (gd.astype(F32) + two_l2 * params["domain_emb"]).astype(F32)
     if emb_trainable:
         gu = np.zeros_like(params["user_emb"], dtype=np.float64)
@@ -218,6 +225,7 @@ class OracleModel(object):
         self.seed = dropout_seed
         self.step = 0          # global inner-step counter (dropout stream + Adam t)
         self.use_sgd = False
+        self._frozen = None    # (ids of the frozen tables, their sums of squares)
 
     # weights in / out (maml.py:181-194, utils/tool.py:36-45)
     def get_flat(self):
@@ -230,13 +238,23 @@ class OracleModel(object):
         B = uid.shape[0]
         masks = train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else \
             [np.ones((B, h), F32) for h in self.hidden]
-        loss, g, _ = loss_and_grads(self.params, uid, pid, dom, label, masks, self.rate, self.emb_trainable)
+        loss, g, _ = loss_and_grads(self.params, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
+                                    self.frozen_sumsq())
         if self.use_sgd:
             self.opt.sgd(self.params, g, self.lr)
         else:
             self.opt.adam(self.params, g, self.lr)
         self.step += 1
         return loss
+
+    def frozen_sumsq(self):
+        """sums of squares of the frozen tables, recomputed only when a table object is replaced."""
+        if self.emb_trainable:
+            return None
+        key = (id(self.params["user_emb"]), id(self.params["item_emb"]))
+        if self._frozen is None or self._frozen[0] != key:
+            self._frozen = (key, {n: table_sumsq(self.params[n]) for n in ("user_emb", "item_emb")})
+        return self._frozen[1]
 
     def train_pass(self, data, perm, batch_size, max_steps=0):
         """one pass over one domain's train split in `perm` order; final partial
@@ -260,7 +278,7 @@ class OracleModel(object):
         """Keras evaluate (A.6): loss = mean over batches of batch-mean loss (+reg),
         predictions for the AUC over all rows in file order."""
         n = data["uid"].shape[0]
-        reg = reg_loss(self.params)
+        reg = reg_loss(self.params, self.frozen_sumsq())
         batch_losses = []
         preds = np.empty(n, F32)
         for s in range(0, n, batch_size):
