@@ -211,6 +211,7 @@ def main():
         gach = gbytes / (gms / gcnt * 1e-3) / 1e9
         gather_info = {"kernel": "k_gather", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": gach / PEAK_HBM_GBS, "traffic": None, "rows_per_launch": sizes[dbig],
+                       "bytes_per_row": GATHER_BYTES_PER_ROW,
                        "note": "standalone pass-sized gather of the same tile code the step kernel uses; "
                                "Taobao tables (15.7 MB) are cache-resident, the 48 MB output is not"}
     result = None
@@ -238,13 +239,26 @@ def main():
     return result
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/summarize_pmc.py, gfx950 corrections applied); None if no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel_key]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def finish_roofline(kernel, total_ms, launches, rows):
     """achieved = algorithmic flops of all profiled launches / their summed device time
     (= flops per average launch / average launch duration)."""
     flops = rows * TOWER_TRAIN_FLOPS_PER_ROW
     ach = flops / (total_ms * 1e-3) / 1e12
     return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches": launches,
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("k_tower<true>"),
+            "traffic_unit": "HBM bytes per launch (profiles/pmc_hbm_latest.json: separate rocprofv3 --pmc passes)",
+            "launches": launches,
             "avg_us": total_ms / max(launches, 1) * 1e3, "rows_per_launch": rows / max(launches, 1),
             "flops_per_row": TOWER_TRAIN_FLOPS_PER_ROW}
 
