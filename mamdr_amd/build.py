@@ -15,6 +15,7 @@ BUILD = os.path.join(HERE, "build")
 # (source, extra flags).  outer_kernels must not fuse multiply-adds (bit-exact vs numpy).
 SOURCES = [
     ("step_kernels.hip", []),
+    ("emb_kernels.hip", []),
     ("outer_kernels.hip", ["-ffp-contract=off"]),
     ("mamdr_api.hip", []),
 ]

@@ -74,6 +74,14 @@ struct mamdr_ctx {
     float* dz = nullptr;
     float* dlogit = nullptr;
     float* w0dom_copy = nullptr;
+    // trainable user / item tables
+    float* dxe = nullptr;
+    int32_t* urow = nullptr;
+    int32_t* irow = nullptr;
+    int32_t* map_u = nullptr;
+    int32_t* map_i = nullptr;
+    float* gbuf_u = nullptr;
+    float* gbuf_i = nullptr;
     int32_t* domrow = nullptr;
     float* loss_part = nullptr;     // train: per tile of a batch
     float* eval_part = nullptr;     // eval: per tile of a split (grown on bind)
@@ -189,8 +197,6 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
     if (cfg->tower != MAMDR_TOWER_MLP)
         return fail(MAMDR_ENOTBUILT, "tower kind %d is not built yet (only the mlp tower is)", cfg->tower);
-    if (cfg->emb_trainable)
-        return fail(MAMDR_ENOTBUILT, "emb_trainable=true (trainable user/item tables) is not built yet");
     if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
         return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
                     cfg->emb_dim, cfg->hidden[0], cfg->hidden[1], cfg->hidden[2]);
@@ -231,6 +237,15 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->dz, rp * DZ_LD * sizeof(float));
     ALLOC(c->dlogit, rp * sizeof(float));
     ALLOC(c->w0dom_copy, (size_t)EMB * H1 * sizeof(float));
+    if (cfg->emb_trainable) {
+        ALLOC(c->dxe, rp * 2 * EMB * sizeof(float));
+        ALLOC(c->urow, rp * sizeof(int32_t));
+        ALLOC(c->irow, rp * sizeof(int32_t));
+        ALLOC(c->map_u, (size_t)cfg->n_user * sizeof(int32_t));
+        ALLOC(c->map_i, (size_t)cfg->n_item * sizeof(int32_t));
+        ALLOC(c->gbuf_u, rp * EMB * sizeof(float));
+        ALLOC(c->gbuf_i, rp * EMB * sizeof(float));
+    }
     ALLOC(c->domrow, rp * sizeof(int32_t));
     ALLOC(c->loss_part, (rp / TILE_ROWS) * sizeof(float));
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
@@ -241,6 +256,10 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
 #undef ALLOC
     hipError_t e = hipMemsetAsync(c->slabs, 0, (size_t)c->max_groups * c->slab_ld * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->frozen_sumsq, 0, 2 * sizeof(float), c->stream);
+    if (cfg->emb_trainable) {
+        launch_emb_map_init(c->map_u, cfg->n_user, c->stream);
+        launch_emb_map_init(c->map_i, cfg->n_item, c->stream);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(c->tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->thresholds, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // host staging buffers go out of scope
@@ -259,7 +278,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -403,6 +422,9 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.dz = c->dz;
         ta.dlogit = c->dlogit;
         ta.domrow = c->domrow;
+        ta.dxe = c->dxe;
+        ta.urow = c->urow;
+        ta.irow = c->irow;
         ta.loss_part = c->loss_part;
 #ifdef MAMDR_STAMPS
         ta.stamps = c->stamps;
@@ -412,6 +434,12 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             launch_tower_train(ta, c->stream);
         }
 
+        if (c->cfg.emb_trainable && d_loss_out) {
+            // the regulariser of the reported loss needs the current tables' sums of squares
+            launch_sumsq(c->params, (int64_t)c->cfg.n_user * EMB, c->sumsq_partials, c->frozen_sumsq + 0, c->stream);
+            launch_sumsq(c->params + (size_t)c->cfg.n_user * EMB, (int64_t)c->cfg.n_item * EMB, c->sumsq_partials,
+                         c->frozen_sumsq + 1, c->stream);
+        }
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
         wa.acts = c->acts;
@@ -475,6 +503,36 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             Prof p(c, MAMDR_KERNEL_UPDATE);
             launch_update(ua, c->stream);
         }
+        if (c->cfg.emb_trainable) {
+            EmbStepArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.dxe = c->dxe;
+            ea.rows = rows;
+            ea.opt.optimizer = ua.optimizer;
+            ea.opt.alpha = ua.alpha;
+            ea.opt.omb1 = ua.omb1;
+            ea.opt.omb2 = ua.omb2;
+            ea.opt.eps = ua.eps;
+            ea.opt.two_l2 = ua.two_l2;
+            ea.p = c->params;
+            ea.m = c->adam_m;
+            ea.v = c->adam_v;
+            ea.n_rows = c->cfg.n_user;
+            ea.brow = c->urow;
+            ea.dx_off = 0;
+            ea.map = c->map_u;
+            ea.gbuf = c->gbuf_u;
+            launch_emb_step(ea, c->stream);
+            ea.p = c->params + (size_t)c->cfg.n_user * EMB;
+            ea.m = c->adam_m + (size_t)c->cfg.n_user * EMB;
+            ea.v = c->adam_v + (size_t)c->cfg.n_user * EMB;
+            ea.n_rows = c->cfg.n_item;
+            ea.brow = c->irow;
+            ea.dx_off = EMB;
+            ea.map = c->map_i;
+            ea.gbuf = c->gbuf_i;
+            launch_emb_step(ea, c->stream);
+        }
         c->global_step += 1;
     }
     HIP_TRY(hipGetLastError());
@@ -503,6 +561,11 @@ int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float*
     {
         Prof p(c, MAMDR_KERNEL_EVAL);
         launch_tower_eval(ta, c->stream);
+    }
+    if (c->cfg.emb_trainable) {
+        launch_sumsq(c->params, (int64_t)c->cfg.n_user * EMB, c->sumsq_partials, c->frozen_sumsq + 0, c->stream);
+        launch_sumsq(c->params + (size_t)c->cfg.n_user * EMB, (int64_t)c->cfg.n_item * EMB, c->sumsq_partials,
+                     c->frozen_sumsq + 1, c->stream);
     }
     launch_eval_finish(c->eval_part, d->n, batch, c->params + c->table_floats, c->cfg.n_domain * EMB, c->cfg.l2_emb,
                        c->frozen_sumsq, d_loss_out, c->stream);

@@ -8,6 +8,15 @@
 
 namespace mamdr {
 
+// optimiser hyper-parameters of one step (shared by the dense and the table paths)
+struct OptArgsLite {
+    int optimizer;             // 0 adam, 1 sgd
+    float alpha;               // adam: lr*sqrt(1-b2^t)/(1-b1^t); sgd: lr
+    float omb1, omb2, eps;
+    float two_l2;
+};
+constexpr int32_t EMB_UNTOUCHED = 0x7fffffff;
+
 // One launch of the fused tower kernel: gather -> MLP forward -> BCE -> (train:
 // backward activation chain) over a contiguous range of positions of one split.
 struct TowerArgs {
@@ -36,6 +45,10 @@ struct TowerArgs {
     float* dz;                 // [rows_pad][DZ_LD]
     float* dlogit;             // [rows_pad]
     int32_t* domrow;           // [rows_pad]
+    // trainable user / item tables only (null otherwise)
+    float* dxe;                // [rows_pad][256]  d loss / d [user | item] embedding row
+    int32_t* urow;             // [rows_pad] user row of each batch position (-1 = padding)
+    int32_t* irow;             // [rows_pad]
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
     // eval outputs
     const float* thresholds;   // 500 fp32 AUC thresholds
@@ -106,6 +119,23 @@ void launch_gather(const TowerArgs& a, float* out, hipStream_t s);
 void launch_sumsq(const float* x, int64_t n, float* partials /*>=1024 floats*/, float* out, hipStream_t s);
 
 size_t tower_lds_bytes();
+
+// emb_kernels.hip: trainable embedding tables (TF1 dense Adam over every row)
+struct EmbStepArgs {
+    float* p;                  // table [n_rows][EMB] inside the flat vector
+    float* m;
+    float* v;
+    int64_t n_rows;
+    const int32_t* brow;       // [rows] table row of each batch position (-1 = padding)
+    const float* dxe;          // [rows][256]
+    int dx_off;                // 0 = user slice, EMB = item slice
+    int rows;                  // batch rows
+    int32_t* map;              // [n_rows] first batch position touching the row, EMB_UNTOUCHED otherwise
+    float* gbuf;               // [rows][EMB] summed row gradients, indexed by representative position
+    OptArgsLite opt;
+};
+void launch_emb_step(const EmbStepArgs& a, hipStream_t s);
+void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s);
 
 // outer_kernels.hip (compiled with -ffp-contract=off)
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s);

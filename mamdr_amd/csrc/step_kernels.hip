@@ -381,9 +381,11 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
 
 // ring depths: forward in 16-deep chunks, backward in 32-deep chunks
 constexpr int PF0 = 4, PF1 = 4, PF2 = 4;
-constexpr int PFB2 = 2, PFB1 = 2;
+constexpr int PFB2 = 2, PFB1 = 2, PFB0 = 4;
 
-template <bool TRAIN>
+// DX: the user / item tables are trainable, so every row also needs d loss / d [user | item]
+// embedding = dz1 . W0[0:256, :]^T (the frozen-table path replaces that contraction by linearity).
+template <bool TRAIN, bool DX>
 __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     FwdW<H2, H3, PF2, 4> fw2;
     BwdW<H3, H2, H3, PFB2, 8> bw2;
     BwdW<H2, H1, H2, PFB1, 8> bw1;
+    BwdW<H1, 2 * EMB, H1, PFB0, 8> bw0;
     STAMP(0);
     fw0.prefetch(P + a.L.w0, P + a.L.b0);
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
@@ -471,6 +474,10 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
             if (part == 0) {
                 a.dlogit[r0 + i] = dl;
                 a.domrow[r0 + i] = rowi[2 * TILE_ROWS + i];
+                if (DX) {
+                    a.urow[r0 + i] = valid ? rowi[i] : -1;
+                    a.irow[r0 + i] = valid ? rowi[TILE_ROWS + i] : -1;
+                }
             }
             // gate = relu'(z) * dropout mask / keep = (h_post > 0) * scale
             f32x2 d;
@@ -503,7 +510,8 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     {
         float* dzs = smem + DZ2S_OFF;
         const float* hs = smem + H2S_OFF;
-        bwd_layer<H3, H2, H3, H3_LD>(bw2, P + a.L.w2, smem + DZ3S_OFF, []() {}, [&](int row, int col, float v) {
+        bwd_layer<H3, H2, H3, H3_LD>(bw2, P + a.L.w2, smem + DZ3S_OFF, [&]() { if (DX) bw0.prefetch(P + a.L.w0); },
+                                     [&](int row, int col, float v) {
             const float d = (hs[row * H2_LD + col] > 0.f) ? v * scale : 0.f;
             dzs[row * H2_LD + col] = d;
 #ifndef MAMDR_ABLATE_STORES
@@ -518,24 +526,35 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
         // linearity in k_wgrad / k_update (dDm = onehot(domain)^T dz1 . W0[256:384,:]^T), so no
         // per-row contraction with W0 is needed while the user / item tables are frozen.
         const float* hs = smem + H1S_OFF;
+        float* dzs = smem + DZ1S_OFF;
         bwd_layer<H2, H1, H2, H2_LD>(bw1, P + a.L.w1, smem + DZ2S_OFF, []() {}, [&](int row, int col, float v) {
             const float d = (hs[row * H1_LD + col] > 0.f) ? v * scale : 0.f;
+            if (DX) dzs[row * H1_LD + col] = d;
 #ifndef MAMDR_ABLATE_STORES
             dz_t[(size_t)row * DZ_LD + col] = d;
 #endif
         });
     }
     STAMP(8);
+    if (DX) {
+        __syncthreads();
+        float* dxe_t = a.dxe + (size_t)r0 * (2 * EMB);
+        bwd_layer<H1, 2 * EMB, H1, H1_LD>(bw0, P + a.L.w0, smem + DZ1S_OFF, []() {},
+                                          [&](int row, int col, float v) { dxe_t[(size_t)row * (2 * EMB) + col] = v; });
+    }
     STAMP(9);
 }
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(k_tower<true>, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    if (a.dxe)
+        hipLaunchKernelGGL((k_tower<true, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL((k_tower<true, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(k_tower<false>, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    hipLaunchKernelGGL((k_tower<false, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
 }
 
 // ------------------------------------------------------------------ standalone gather

@@ -31,7 +31,7 @@ def env():
     return engine, synthetic
 
 
-def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao10"):
+def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao10", emb_trainable=False):
     engine, synthetic = env
     g = synthetic.generate(shape, batch_size=batch, seed=seed, scale=scale)
     rs = np.random.RandomState(seed)
@@ -41,15 +41,17 @@ def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao1
     params["domain_emb"] = (rs.standard_normal(params["domain_emb"].shape) * 0.05).astype(F32)
     for l in range(3):
         params["b%d" % l] = (rs.standard_normal(params["b%d" % l].shape) * 0.05).astype(F32)
-    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=dropout)
-    eng.bind_table("user_emb", params["user_emb"])
-    eng.bind_table("item_emb", params["item_emb"])
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=dropout,
+                             emb_trainable=emb_trainable)
+    if not emb_trainable:
+        eng.bind_table("user_emb", params["user_emb"])
+        eng.bind_table("item_emb", params["item_emb"])
     for split in ("train", "val", "test"):
         for d in range(g["n_domain"]):
             c = g["data"][split][d]
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
     eng.set_weights(eng.pack(params))
-    model = otower.OracleModel({k: v.copy() for k, v in params.items()}, emb_trainable=False, dropout=dropout,
+    model = otower.OracleModel({k: v.copy() for k, v in params.items()}, emb_trainable=emb_trainable, dropout=dropout,
                                lr=1e-3, dropout_seed=eng.dropout_seed)
     return g, eng, model
 
@@ -214,6 +216,56 @@ def test_adam_pass_matches_oracle(env):
         diff = np.abs(got[name].reshape(model.params[name].shape) - model.params[name]).max()
         assert diff < 0.05 * n_steps * 1e-3, (name, diff)
     assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == n_steps == model.opt.t
+    eng.close()
+
+
+# ------------------------------------------------------------------ trainable user / item tables
+def test_trainable_tables_gradients_and_adam(env):
+    """emb_trainable: scatter-add of row gradients + dense regulariser on EVERY row, dense Adam
+    over the whole table (TF1 semantics); rows repeated inside a batch included."""
+    g, eng, model = make_problem(env, scale=0.1, batch=256, dropout=0.5, emb_trainable=True)
+    assert "user_emb" in eng.segments and eng.n_params == 128 * (g["n_user"] + g["n_item"]) + 139777 + 128 * 10 + 3
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=4)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    idx = perm[:256]
+    assert len(np.unique(cols["uid"][idx])) < 256          # repeated rows exercise the segment sum
+    masks = otower.train_masks(model.seed, model.step, 256, model.hidden, 0.5)
+    loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                           cols["label"][idx], masks, 0.5, True)
+    want = eng.pack(grads).cpu().numpy()
+    w0 = eng.get_weights()
+    loss_t = torch.zeros(1, device=eng.device)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+    got = (w0 - eng.get_weights()).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6 * max(np.abs(want).max(), 1e-3))
+    assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    # untouched rows still move by the regulariser: g = 2 * l2 * w
+    untouched = np.setdiff1d(np.arange(g["n_user"]), cols["uid"][idx])[:5]
+    off = eng.segments["user_emb"][0]
+    for r in untouched:
+        # (p_old - p_new recovers g only to ~ulp(p) = 1e-8 for p ~ 0.1)
+        np.testing.assert_allclose(got[off + r * 128: off + (r + 1) * 128], 2e-5 * model.params["user_emb"][r],
+                                   rtol=1e-3, atol=2e-8)
+    # a few Adam steps, including the partial last batch
+    eng.set_weights(w0)
+    model.step = 1
+    n_steps = -(-n // 256)
+    first = max(0, n_steps - 3)
+    eng.train_steps(d, perm=perm_t, first_step=first, n_steps=n_steps - first, lr=1e-3)
+    for s_ in range(first, n_steps):
+        ii = perm[s_ * 256:(s_ + 1) * 256]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        diff = np.abs(got[name].reshape(model.params[name].shape) - model.params[name]).max()
+        assert diff < 0.05 * 3 * 1e-3, (name, diff)
+    # eval uses the live tables (regulariser term of the loss recomputed)
+    loss_g, auc_g = eng.evaluate(d, "val")
+    loss_o, preds = model.evaluate(g["data"]["val"][d], 256)
+    assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
     eng.close()
 
 
