@@ -44,6 +44,10 @@ GATHER_BYTES_PER_ROW = 3 * 128 * 4 * 2 + 16   # read 3 rows + write 384 floats +
 WORKLOADS = {
     "taobao10": dict(shape="taobao10", batch=1024, name="mlp_meta_mamdr Taobao-10 bs=1024 (frozen pretrained tables)"),
     "taobao30": dict(shape="taobao30", batch=4096, name="mlp_meta_mamdr Taobao-30 bs=4096 (frozen pretrained tables)"),
+    # trainable 128-d tables (79 M parameters): every step ends with TF1's dense Adam over all rows
+    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.02,
+                    name="mlp_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
+                         "2% of the rows per epoch)"),
 }
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
@@ -63,25 +67,29 @@ def init_params(g, seed=1024):
     return p
 
 
-def setup_engine(g, batch):
+def setup_engine(g, batch, emb_trainable=False):
     from mamdr_amd import engine
-    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=TRAIN["dropout"])
-    eng.bind_table("user_emb", g["tables"]["user_emb"])
-    eng.bind_table("item_emb", g["tables"]["item_emb"])
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=TRAIN["dropout"],
+                             emb_trainable=emb_trainable)
+    if not emb_trainable:
+        eng.bind_table("user_emb", g["tables"]["user_emb"])
+        eng.bind_table("item_emb", g["tables"]["item_emb"])
     for d in range(g["n_domain"]):
         c = g["data"]["train"][d]
         eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
     return eng
 
 
-def cpu_baseline(g, batch, budget_s=15.0):
+def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False):
     """the oracle (numpy restatement of the TF1.12 path) timed on this box's host cores on
     the first domain-steps of the same workload; TF itself is not installable."""
     from oracle import rng as orng
     from oracle import tower as otower
-    params = init_params(g)
-    params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
-    model = otower.OracleModel(params, emb_trainable=False, dropout=TRAIN["dropout"], lr=TRAIN["learning_rate"])
+    if params is None:
+        params = init_params(g)
+        params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
+    model = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
+                               lr=TRAIN["learning_rate"])
     d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     cols = g["data"]["train"][d]
     n = cols["uid"].shape[0]
@@ -133,20 +141,38 @@ def main():
 
     wl = WORKLOADS[args.workload]
     batch = wl["batch"]
-    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"])
+    trainable = bool(wl.get("emb_trainable"))
+    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=wl.get("row_scale", 1.0))
     D = g["n_domain"]
-    eng = setup_engine(g, batch)
+    eng = setup_engine(g, batch, trainable)
+
+    def full_params(seed=1024):
+        p = init_params(g, seed)
+        if trainable:      # Amazon: no pretraining, N(0, 1e-4^2) tables (deepctr.py:115 SparseFeat default)
+            rs_ = np.random.RandomState(seed + 7)
+            p["user_emb"] = (rs_.standard_normal((g["n_user"], 128)) * 1e-4).astype(np.float32)
+            p["item_emb"] = (rs_.standard_normal((g["n_item"], 128)) * 1e-4).astype(np.float32)
+        return p
     sizes = [eng.n_rows(d, "train") for d in range(D)]
     steps_per_domain = [-(-n // batch) for n in sizes]
-    theta = eng.pack(init_params(g))
+    theta = eng.pack(full_params())
     owner = parallel.lpt_partition(sizes, world)
     # phi_d starts as a second random init of the whole model (mamdr.py:31-33)
-    phis = {d: eng.pack(init_params(g, seed=2000 + d)) for d in range(D) if owner[d] == rank}
+    wrapper = wl.get("wrapper", "mamdr")
+    phis = {d: eng.pack(full_params(seed=2000 + d)) for d in range(D) if owner[d] == rank} if wrapper == "mamdr" else {}
     bufs = {"delta": eng.new_vector(), "zero": eng.new_vector(), "merged": eng.new_vector()}
     planner = mplan.EpochPlanner(range(D), TRAIN["sample_num"], TRAIN["add_query_domain"], True, TRAIN["seed"])
     shuffler = mplan.PassShuffler(sizes, TRAIN["shuffle_buffer_size"], TRAIN["seed"] + rank)
 
     def epoch():
+        if wrapper == "dn":               # Domain Negotiation only (domain_negotiation.py:37-88)
+            p = planner.next_epoch(with_dr=False)
+            tr = []
+            parallel.dn_phase_sharded(eng, meta, theta, parallel.shard_plan(p, owner, rank)["seq"], shuffler, batch,
+                                      TRAIN["learning_rate"], TRAIN["meta_learning_rate"], tr, bufs["delta"],
+                                      bufs["zero"])
+            eng.set_weights(theta)
+            return tr, mplan.plan_steps(p, steps_per_domain)
         p = planner.next_epoch()          # same seed on every rank -> same global plan
         tr = parallel.mamdr_epoch_sharded(eng, meta, theta, phis, p, owner, shuffler, batch,
                                           TRAIN["learning_rate"], TRAIN["meta_learning_rate"], bufs,
@@ -179,14 +205,25 @@ def main():
 
     # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
     #      the same workload; reported for the dominant kernel, k_tower<train>
-    roofline, gather_info, kernels = None, None, {}
+    roofline, gather_info, kernels, sweep_info = None, None, {}, None
     if not args.no_profile:
         eng.profile(True)
         eng.profile_reset()
         prof_trace, _ = epoch()
-        for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE):
+        for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE, L.KERNEL_EMB_SWEEP):
             ms, cnt = eng.profile_read(k)
-            kernels[L.KERNEL_NAMES[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
+            if cnt:
+                kernels[L.KERNEL_NAMES[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
+        if trainable:
+            # HBM-bound dense optimiser pass: 24 B per table element (read p, m, v; write p, m, v) + 4 B
+            # of row map per 512-B row, two launches per step (user table, item table)
+            ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
+            sweep_bytes = (g["n_user"] + g["n_item"]) * (128 * 24 + 4) * (cnt // 2)
+            ach = sweep_bytes / (ms * 1e-3) / 1e9
+            sweep_info = {"kernel": "k_emb_sweep", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
+                          "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("k_emb_sweep"),
+                          "avg_us": ms / max(cnt, 1) * 1e3, "launches": cnt,
+                          "bytes_per_step": (g["n_user"] + g["n_item"]) * (128 * 24 + 4)}
         roofline_ms, cnt = eng.profile_read(L.KERNEL_FWD_BWD)
         eng.profile(False)
         eng.profile_reset()
@@ -216,7 +253,8 @@ def main():
                                "Taobao tables (15.7 MB) are cache-resident, the 48 MB output is not"}
     result = None
     if rank == 0:
-        cpu = cpu_baseline(g, batch, args.cpu_budget) if args.cpu_budget > 0 else None
+        cpu = cpu_baseline(g, batch, args.cpu_budget, full_params() if trainable else None, trainable) \
+            if args.cpu_budget > 0 else None
         result = {
             "metric": "domain-steps/sec", "value": global_steps / dt, "unit": "domain-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,7 +266,8 @@ def main():
                        "parallelism": "domain-sharded x%d, 1 all-reduce of the DN displacement per epoch" % world
                        if world > 1 else "single GPU"},
             "us_per_domain_step": dt / global_steps * 1e6 * world,
-            "roofline": roofline, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
+            "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0))
+            else roofline, "tower": roofline, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
         }
         if cpu:
             result["gpu_over_cpu"] = result["value"] / cpu["value"]

@@ -54,7 +54,7 @@ enum {
 };
 /* kernels whose device time can be profiled (mamdr_profile_*) */
 enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
-       MAMDR_KERNEL_EVAL = 3, MAMDR_KERNEL_GATHER = 4, MAMDR_KERNEL_COUNT = 5 };
+       MAMDR_KERNEL_EVAL = 3, MAMDR_KERNEL_GATHER = 4, MAMDR_KERNEL_EMB_SWEEP = 5, MAMDR_KERNEL_COUNT = 6 };
 
 typedef struct mamdr_ctx mamdr_ctx;
 

@@ -18,8 +18,8 @@ MERGE_PLUS, MERGE_TIMES = 0, 1
 (SEG_USER_EMB, SEG_ITEM_EMB, SEG_DOMAIN_EMB, SEG_W0, SEG_W1, SEG_W2, SEG_B0, SEG_B1, SEG_B2, SEG_WO,
  SEG_GB) = range(11)
 SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
-KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER = range(5)
-KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather")
+KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP = range(6)
+KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep")
 
 
 class MamdrError(RuntimeError):

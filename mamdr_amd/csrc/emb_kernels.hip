@@ -89,15 +89,19 @@ __global__ __launch_bounds__(256) void k_emb_unmark(const EmbStepArgs a) {
     if (r >= 0) a.map[r] = EMB_UNTOUCHED;
 }
 
-void launch_emb_step(const EmbStepArgs& a, hipStream_t s) {
+void launch_emb_scatter(const EmbStepArgs& a, hipStream_t s) {
     const int pb = (a.rows + 255) / 256;
     hipLaunchKernelGGL(k_emb_mark, dim3(pb), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_emb_reduce, dim3(a.rows), dim3(EMB), (size_t)a.rows * sizeof(int32_t), s, a);
+}
+void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s) {
     const int64_t n4 = a.n_rows * (EMB / 4);
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;       // grid-stride beyond 16 workgroups per CU
     hipLaunchKernelGGL(k_emb_sweep, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_emb_unmark, dim3(pb), dim3(256), 0, s, a);
+}
+void launch_emb_unmark(const EmbStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_unmark, dim3((a.rows + 255) / 256), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

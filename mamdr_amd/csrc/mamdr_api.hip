@@ -522,7 +522,12 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             ea.dx_off = 0;
             ea.map = c->map_u;
             ea.gbuf = c->gbuf_u;
-            launch_emb_step(ea, c->stream);
+            launch_emb_scatter(ea, c->stream);
+            {
+                Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
+                launch_emb_sweep(ea, c->stream);
+            }
+            launch_emb_unmark(ea, c->stream);
             ea.p = c->params + (size_t)c->cfg.n_user * EMB;
             ea.m = c->adam_m + (size_t)c->cfg.n_user * EMB;
             ea.v = c->adam_v + (size_t)c->cfg.n_user * EMB;
@@ -531,7 +536,12 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             ea.dx_off = EMB;
             ea.map = c->map_i;
             ea.gbuf = c->gbuf_i;
-            launch_emb_step(ea, c->stream);
+            launch_emb_scatter(ea, c->stream);
+            {
+                Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
+                launch_emb_sweep(ea, c->stream);
+            }
+            launch_emb_unmark(ea, c->stream);
         }
         c->global_step += 1;
     }

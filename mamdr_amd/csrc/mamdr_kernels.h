@@ -134,7 +134,9 @@ struct EmbStepArgs {
     float* gbuf;               // [rows][EMB] summed row gradients, indexed by representative position
     OptArgsLite opt;
 };
-void launch_emb_step(const EmbStepArgs& a, hipStream_t s);
+void launch_emb_scatter(const EmbStepArgs& a, hipStream_t s);
+void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s);
+void launch_emb_unmark(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s);
 
 // outer_kernels.hip (compiled with -ffp-contract=off)

@@ -40,8 +40,9 @@ def _domain_sizes(total, n_domain, min_size, rs):
     return sizes
 
 
-def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128, signal=10.0):
-    """returns dict(tables, data, info).  scale < 1 shrinks users/items/rows (tests)."""
+def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128, signal=10.0, row_scale=1.0):
+    """returns dict(tables, data, info).  scale < 1 shrinks users/items/rows (tests);
+    row_scale < 1 shrinks only the number of rows (full-size tables, shorter epochs)."""
     spec = dict(SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     rs = np.random.RandomState(seed)
     D = spec["n_domain"]
@@ -54,7 +55,7 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
     sizes = {}
     for split in ("train", "val", "test"):
         ms = min_size if split == "train" else max(1, min_size // 4)
-        total = max(int(spec["n_" + split] * scale), D * ms)
+        total = max(int(spec["n_" + split] * scale * row_scale), D * ms)
         sizes[split] = _domain_sizes(total, D, ms, np.random.RandomState(seed + 1))
     data = {"train": {}, "val": {}, "test": {}}
     info = {"n_user": n_user, "n_item": n_item}
@@ -74,8 +75,11 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
             n = int(sizes[split][d])
             uid = users[rs.randint(0, n_u_d, n)].astype(np.int32)
             pid = items[rs.randint(0, n_i_d, n)].astype(np.int32)
-            ue, ie = user_emb[uid].astype(np.float64), item_emb[pid].astype(np.float64)
-            logit = signal * (ue @ dir_d[0] + ie @ dir_d[1]) + 0.5 * signal * np.einsum("ij,ij->i", ue, ie) + bias
+            logit = np.empty(n, np.float64)
+            for c0 in range(0, n, 1 << 18):          # chunked: the gathered rows are 1 KiB per sample
+                sl = slice(c0, min(n, c0 + (1 << 18)))
+                ue, ie = user_emb[uid[sl]].astype(np.float64), item_emb[pid[sl]].astype(np.float64)
+                logit[sl] = signal * (ue @ dir_d[0] + ie @ dir_d[1]) + 0.5 * signal * np.einsum("ij,ij->i", ue, ie) + bias
             label = (rs.uniform(size=n) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
             data[split][d] = {"uid": uid, "pid": pid, "domain": np.full(n, d, np.int32), "label": label}
             info[d]["n_" + split] = n
