@@ -129,8 +129,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # MAMDR_BENCH_SHARE_GPU=1 (testing on a 1-GPU box only): all ranks use device 0 and gloo
+        share = os.environ.get("MAMDR_BENCH_SHARE_GPU") == "1"
+        torch.cuda.set_device(0 if share else local_rank)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:
+                dist.init_process_group("nccl")
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:

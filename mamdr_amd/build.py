@@ -16,6 +16,7 @@ BUILD = os.path.join(HERE, "build")
 SOURCES = [
     ("step_kernels.hip", []),
     ("emb_kernels.hip", []),
+    ("tower4_kernels.hip", []),
     ("outer_kernels.hip", ["-ffp-contract=off"]),
     ("mamdr_api.hip", []),
 ]

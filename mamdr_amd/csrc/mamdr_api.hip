@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -74,6 +75,8 @@ struct mamdr_ctx {
     float* dz = nullptr;
     float* dlogit = nullptr;
     float* w0dom_copy = nullptr;
+    float* wT = nullptr;            // transposed W1 / W2 (k_tower4)
+    int tower_tile = 0;             // 0 auto, 4 / 16 forced (env MAMDR_TOWER_TILE)
     // trainable user / item tables
     float* dxe = nullptr;
     int32_t* urow = nullptr;
@@ -215,6 +218,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     c->n_params = c->table_floats + c->L.alloc;
     c->data.resize((size_t)cfg->n_domain * 3);
     c->rows_pad_max = cfg->max_batch;
+    if (const char* tt = getenv("MAMDR_TOWER_TILE")) c->tower_tile = atoi(tt);
     c->slab_ld = c->L.alloc + cfg->n_domain * H1;
 
     const size_t rp = (size_t)c->rows_pad_max;
@@ -247,7 +251,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->gbuf_i, rp * EMB * sizeof(float));
     }
     ALLOC(c->domrow, rp * sizeof(int32_t));
-    ALLOC(c->loss_part, (rp / TILE_ROWS) * sizeof(float));
+    ALLOC(c->loss_part, (rp / 4) * sizeof(float));
+    ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
@@ -278,7 +283,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -402,6 +407,11 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
     const float keep_scale = (float)(1.0 / (1.0 - (double)rate));
     const float omb1 = 1.0f - c->cfg.adam_beta1, omb2 = 1.0f - c->cfg.adam_beta2;
 
+    // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
+    // refreshed here because the caller may have assigned new weights, kept current by k_update
+    const bool may_use4 = !c->cfg.emb_trainable && c->tower_tile != 16;
+    if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
+
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
@@ -429,9 +439,12 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
 #ifdef MAMDR_STAMPS
         ta.stamps = c->stamps;
 #endif
+        const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
+        ta.wT = c->wT;
         {
             Prof p(c, MAMDR_KERNEL_FWD_BWD);
-            launch_tower_train(ta, c->stream);
+            if (use4) launch_tower4_train(ta, c->stream);
+            else launch_tower_train(ta, c->stream);
         }
 
         if (c->cfg.emb_trainable && d_loss_out) {
@@ -462,7 +475,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         wa.w0dom = c->params + c->table_floats + c->L.w0 + (size_t)(2 * EMB) * H1;
         wa.w0dom_copy = c->w0dom_copy;
         wa.loss_part = c->loss_part;
-        wa.n_loss_tiles = rows_pad / TILE_ROWS;
+        wa.n_loss_tiles = use4 ? rows_pad / 4 : rows_pad / TILE_ROWS;
         wa.rows = rows;
         wa.dense = c->params + c->table_floats;
         wa.dm_count = c->cfg.n_domain * EMB;
@@ -499,6 +512,9 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ua.omb1 = omb1;
         ua.omb2 = omb2;
         ua.eps = c->cfg.adam_eps;
+        ua.wT = may_use4 ? c->wT : nullptr;
+        ua.w1_off = c->L.w1;
+        ua.w2_off = c->L.w2;
         {
             Prof p(c, MAMDR_KERNEL_UPDATE);
             launch_update(ua, c->stream);

@@ -19,6 +19,10 @@ constexpr int H3 = 64;
 constexpr int ACT_LD = XDIM + H1 + H2 + H3;   // 832: [x | h1 | h2 | h3] per row
 constexpr int DZ_LD = H1 + H2 + H3;           // 448: [dz1 | dz2 | dz3] per row
 constexpr int TILE_ROWS = 16;                 // batch rows per workgroup in the step kernel
+// transposed copies of W1 / W2 for the 4-row tower's backward layers (workspace, kept by k_update)
+constexpr int W1T_OFF = 0;                    // [128][256]
+constexpr int W2T_OFF = H1 * H2;              // [64][128]
+constexpr int WT_FLOATS = H1 * H2 + H2 * H3;
 
 // dense block of the flat trainable vector, relative to the domain table start
 struct DenseLayout {

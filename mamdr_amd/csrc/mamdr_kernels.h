@@ -50,6 +50,7 @@ struct TowerArgs {
     int32_t* urow;             // [rows_pad] user row of each batch position (-1 = padding)
     int32_t* irow;             // [rows_pad]
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
+    const float* wT;           // k_tower4 only: transposed W1 / W2 copies
     // eval outputs
     const float* thresholds;   // 500 fp32 AUC thresholds
     uint32_t* hist;            // [2][501]
@@ -107,10 +108,14 @@ struct UpdateArgs {
     int optimizer;             // 0 adam, 1 sgd
     float alpha;               // adam: lr*sqrt(1-b2^t)/(1-b1^t); sgd: lr
     float omb1, omb2, eps;
+    float* wT;                 // nullable: transposed W1 / W2 copies to keep current
+    int w1_off, w2_off;        // offsets of W1 / W2 in the dense block
 };
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s);
 void launch_tower_eval(const TowerArgs& a, hipStream_t s);
+void launch_tower4_train(const TowerArgs& a, hipStream_t s);
+void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s);
 void launch_eval_finish(const float* loss_part, int64_t n_rows, int batch, const float* dense, int dm_count,
                         float l2_emb, const float* frozen_sumsq, float* loss_out, hipStream_t s);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);

@@ -811,6 +811,18 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
             *reinterpret_cast<f32x4*>(u.v + e) = v;
         }
         *reinterpret_cast<f32x4*>(u.p + e) = p;
+        if (u.wT) {     // keep the transposed copies used by k_tower4's backward layers current
+            const int e0 = (int)e;
+            if (e0 >= u.w1_off && e0 < u.w1_off + H1 * H2) {
+                const int f = e0 - u.w1_off, r = f / H2, c = f - r * H2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u.wT[W1T_OFF + (c + k) * H1 + r] = p[k];
+            } else if (e0 >= u.w2_off && e0 < u.w2_off + H2 * H3) {
+                const int f = e0 - u.w2_off, r = f / H3, c = f - r * H3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u.wT[W2T_OFF + (c + k) * H2 + r] = p[k];
+            }
+        }
         return;
     }
     // domain table: one wave per element (d, c):

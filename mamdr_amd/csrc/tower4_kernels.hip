@@ -1,0 +1,325 @@
+// k_tower4: the training tower for SMALL batches (rows <= 2048) on gfx950.
+//
+// With 16-row tiles (k_tower, step_kernels.hip) a batch of 1024 rows occupies only 64 of the
+// 256 CUs.  This variant gives every workgroup 4 batch rows (256 tiles at 1024 rows) and runs
+// the contractions on v_mfma_f32_4x4x1_16b_f32: 16 blocks of (4 rows x 1 k) x (1 k x 4 cols),
+// i.e. one instruction = 4 batch rows x 64 output columns x one k at the full fp32 MFMA rate
+// (measured 9.5 cycles / instruction, tools/mfma4x4.hip).  Lane l supplies B = W[k][n0 + l]
+// (a fully coalesced row of W), the A operand x[row][k] is broadcast from block 0 (cbsz = 4),
+// and D register r of lane l is out[row r][n0 + l].
+//
+// A wave covers ALL columns of a layer with one 16/8/4-byte load per k (col = V * lane + t), so
+// the 8 waves split the reduction index k instead and are summed through LDS in wave order
+// (fixed order, no atomics).  The backward layers use transposed copies of W1 / W2 kept
+// current by k_update, so they stream rows exactly like the forward layers.  The dropout
+// stream, loss, and workspace layout are identical to k_tower; results differ only by fp32
+// summation order.  Replaces the same reference call sites (model_zoo/mamdr.py:54,86,97).
+#include "mamdr_kernels.h"
+
+namespace mamdr {
+
+constexpr int T4_ROWS = 4;
+constexpr int T4_THREADS = 512;
+constexpr int T4_WAVES = 8;
+constexpr int T4_PF = 8;                 // k rows in flight per wave
+
+// LDS map (floats)
+constexpr int T4_XS = 0;                               // [4][384]
+constexpr int T4_H1 = T4_XS + T4_ROWS * XDIM;          // [4][256]
+constexpr int T4_H2 = T4_H1 + T4_ROWS * H1;            // [4][128]
+constexpr int T4_H3 = T4_H2 + T4_ROWS * H2;            // [4][64]
+constexpr int T4_DZ3 = T4_H3 + T4_ROWS * H3;           // [4][64]
+constexpr int T4_DZ2 = T4_DZ3 + T4_ROWS * H3;          // [4][128]
+constexpr int T4_RED = T4_DZ2 + T4_ROWS * H2;          // [8 waves][4][256] split-k partials
+constexpr int T4_ROWI = T4_RED + T4_WAVES * T4_ROWS * H1;
+constexpr int T4_LDS_FLOATS = T4_ROWI + 64;
+
+size_t tower4_lds_bytes() { return T4_LDS_FLOATS * sizeof(float); }
+
+#define MAMDR_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, 0, 0)
+
+template <int V> struct Vec4T;
+template <> struct Vec4T<4> { typedef f32x4 type; };
+template <> struct Vec4T<2> { typedef f32x2 type; };
+template <> struct Vec4T<1> { typedef float type; };
+
+template <int V>
+__device__ __forceinline__ void t4_load(float (&b)[V], const float* __restrict__ p) {
+    typedef typename Vec4T<V>::type T;
+    const T v = *reinterpret_cast<const T*>(p);
+    if constexpr (V == 1) {
+        b[0] = v;
+    } else {
+#pragma unroll
+        for (int t = 0; t < V; ++t) b[t] = v[t];
+    }
+}
+
+// weight ring of one layer: W is [K][N] row-major, this wave owns k in [w*K/8, (w+1)*K/8)
+template <int K, int N>
+struct T4W {
+    static constexpr int V = N / 64;
+    static constexpr int KW = K / T4_WAVES;
+    static constexpr int PF = KW < T4_PF ? KW : T4_PF;
+    float b[PF][V];
+    static __device__ __forceinline__ const float* wptr(const float* __restrict__ W) {
+        return W + (size_t)((threadIdx.x >> 6) * KW) * N + V * (threadIdx.x & 63);
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
+        const float* wp = wptr(W);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) t4_load<V>(b[u], wp + (size_t)u * N);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+// partial[w][4][N] = A[4][k-range of wave w] . W[k-range][N]   (into LDS `red`)
+template <int K, int N, typename Mid>
+__device__ __forceinline__ void t4_contract(T4W<K, N>& tw, const float* __restrict__ W, const float* As, int lda,
+                                            float* red, Mid mid) {
+    constexpr int V = T4W<K, N>::V, KW = T4W<K, N>::KW, PF = T4W<K, N>::PF;
+    static_assert(KW % 4 == 0 && KW % PF == 0, "k range of a wave must be a multiple of 4 and of the ring depth");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* wp = T4W<K, N>::wptr(W);
+    const float* ap = As + (lane & 3) * lda + w * KW;
+    f32x4 acc[V];
+#pragma unroll
+    for (int t = 0; t < V; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int k0 = 0; k0 < KW - PF; k0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; q += 4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + k0 + q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < V; ++t) acc[t] = MAMDR_MFMA4(a4[u], tw.b[q + u][t], acc[t]);
+                t4_load<V>(tw.b[q + u], wp + (size_t)(k0 + q + u + PF) * N);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PF; q += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + (KW - PF) + q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < V; ++t) acc[t] = MAMDR_MFMA4(a4[u], tw.b[q + u][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mid();
+    // D register r of lane l = row r, column V*l + t
+    typedef typename Vec4T<V>::type T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T v;
+        if constexpr (V == 1) {
+            v = acc[0][r];
+        } else {
+#pragma unroll
+            for (int t = 0; t < V; ++t) v[t] = acc[t][r];
+        }
+        *reinterpret_cast<T*>(red + (w * T4_ROWS + r) * N + V * lane) = v;
+    }
+}
+
+// sum of the 8 wave partials of output (row, col), wave order
+template <int N>
+__device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
+    float s = red[row * N + col];
+#pragma unroll
+    for (int w = 1; w < T4_WAVES; ++w) s += red[(w * T4_ROWS + row) * N + col];
+    return s;
+}
+
+__device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int r0 = tile * T4_ROWS;
+    int* rowi = reinterpret_cast<int*>(smem + T4_ROWI);          // [0,4) uid [4,8) pid [8,12) dom [12,16) valid
+    float* rowf = smem + T4_ROWI + 16;                           // [0,4) label, [4,8) loss of the row
+    float* red = smem + T4_RED;
+    const float* P = a.dense;
+    float* acts_t = a.acts + (size_t)r0 * ACT_LD;
+    float* dz_t = a.dz + (size_t)r0 * DZ_LD;
+
+    // weights and small parameters first: they do not depend on the gather
+    T4W<XDIM, H1> w0;
+    T4W<H1, H2> w1;
+    T4W<H2, H3> w2;
+    T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
+    T4W<H2, H1> v1;      // backward: dz2 . W1^T through W1T [128][256]
+    w0.prefetch(P + a.L.w0);
+    const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
+    const float b0r = P[a.L.b0 + ecol];
+    const float b1r = P[a.L.b1 + (tid & 127)];
+    const float b2r = P[a.L.b2 + (tid & 63)];
+    const float wor = P[a.L.wo + (tid & 63)];
+    const float gbr = P[a.L.gb];
+
+    // ---- row bookkeeping + embedding gather (4 rows x 96 float4)
+    if (tid < T4_ROWS) {
+        const bool valid = (r0 + tid) < a.rows;
+        int64_t pos = a.row_base + r0 + tid;
+        int64_t src = 0;
+        if (valid) {
+            src = a.perm ? (int64_t)a.perm[pos] : pos;
+            if (src < 0) src = 0;
+            if (src >= a.n_rows_split) src = a.n_rows_split - 1;
+        }
+        rowi[tid] = t4_clamp(a.uid[src], 0, a.n_user - 1);
+        rowi[4 + tid] = t4_clamp(a.pid[src], 0, a.n_item - 1);
+        rowi[8 + tid] = t4_clamp(a.dom[src], 0, a.n_domain - 1);
+        rowi[12 + tid] = valid ? 1 : 0;
+        rowf[tid] = a.label[src];
+    }
+    __syncthreads();
+    if (tid < T4_ROWS * (XDIM / 4)) {
+        const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
+        const int seg = c4 >> 5, off = (c4 & 31) * 4;
+        const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * 4 + row] * EMB + off);
+        if (!rowi[12 + row]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    const float scale = a.use_dropout ? a.keep_scale : 1.0f;
+    const bool drop = a.use_dropout != 0;
+
+    // ---- layer 0: 384 -> 256
+    t4_contract<XDIM, H1>(w0, P + a.L.w0, smem + T4_XS, XDIM, red, [&]() { w1.prefetch(P + a.L.w1); });
+    if (tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream
+        const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
+        *reinterpret_cast<f32x4*>(acts_t + (size_t)row * ACT_LD + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(smem + T4_XS + row * XDIM + c4 * 4);
+    }
+    __syncthreads();
+    {
+        const uint32_t key = dropout_layer_key(a.seed, a.step, 0);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = erow2 + 2 * rr;
+            float h = fmaxf(t4_sum<H1>(red, row, ecol) + b0r, 0.f);
+            if (drop) {
+                const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H1 + (uint32_t)ecol);
+                h = (u >= a.drop_thresh) ? h * scale : 0.f;
+            }
+            smem[T4_H1 + row * H1 + ecol] = h;
+            acts_t[(size_t)row * ACT_LD + XDIM + ecol] = h;
+        }
+    }
+    __syncthreads();
+
+    // ---- layer 1: 256 -> 128
+    t4_contract<H1, H2>(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
+    __syncthreads();
+    {
+        const uint32_t key = dropout_layer_key(a.seed, a.step, 1);
+        const int row = tid >> 7, col = tid & 127;
+        float h = fmaxf(t4_sum<H2>(red, row, col) + b1r, 0.f);
+        if (drop) {
+            const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H2 + (uint32_t)col);
+            h = (u >= a.drop_thresh) ? h * scale : 0.f;
+        }
+        smem[T4_H2 + row * H2 + col] = h;
+        acts_t[(size_t)row * ACT_LD + XDIM + H1 + col] = h;
+    }
+    __syncthreads();
+
+    // ---- layer 2: 128 -> 64 (the backward weights are requested behind its K loop)
+    t4_contract<H2, H3>(w2, P + a.L.w2, smem + T4_H2, H2, red, [&]() {
+        v2.prefetch(a.wT + W2T_OFF);
+        v1.prefetch(a.wT + W1T_OFF);
+    });
+    __syncthreads();
+    // ---- epilogue of layer 2 + output unit + sigmoid / Keras BCE + dz3: wave r owns row r
+    if (w < T4_ROWS) {
+        const uint32_t key = dropout_layer_key(a.seed, a.step, 2);
+        const int row = w, col = lane;
+        float h = fmaxf(t4_sum<H3>(red, row, col) + b2r, 0.f);
+        if (drop) {
+            const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H3 + (uint32_t)col);
+            h = (u >= a.drop_thresh) ? h * scale : 0.f;
+        }
+        acts_t[(size_t)row * ACT_LD + XDIM + H1 + H2 + col] = h;
+        float s = h * wor;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float logit = s + gbr;
+        float p;
+        if (logit >= 0.f) {
+            p = 1.0f / (1.0f + __expf(-logit));
+        } else {
+            const float ez = __expf(logit);
+            p = ez / (1.0f + ez);
+        }
+        const bool valid = rowi[12 + row] != 0;
+        const float y = rowf[row];
+        const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+        const float pc = fminf(fmaxf(p, lo), hi);
+        const float zc = __logf(pc / (1.0f - pc));
+        const float loss = fmaxf(zc, 0.f) - zc * y + __logf(1.0f + __expf(-fabsf(zc)));
+        const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
+        const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
+        if (lane == 0) {
+            a.dlogit[r0 + row] = dl;
+            a.domrow[r0 + row] = rowi[8 + row];
+            rowf[4 + row] = valid ? loss : 0.f;
+        }
+        const float d = (h > 0.f) ? (dl * wor) * scale : 0.f;
+        smem[T4_DZ3 + row * H3 + col] = d;
+        dz_t[(size_t)row * DZ_LD + H1 + H2 + col] = d;
+    }
+    __syncthreads();
+    if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
+
+    // ---- backward: dz2 = (dz3 . W2^T) * gate(h2)
+    t4_contract<H3, H2>(v2, a.wT + W2T_OFF, smem + T4_DZ3, H3, red, []() {});
+    __syncthreads();
+    {
+        const int row = tid >> 7, col = tid & 127;
+        const float v = t4_sum<H2>(red, row, col);
+        const float d = (smem[T4_H2 + row * H2 + col] > 0.f) ? v * scale : 0.f;
+        smem[T4_DZ2 + row * H2 + col] = d;
+        dz_t[(size_t)row * DZ_LD + H1 + col] = d;
+    }
+    __syncthreads();
+    // ---- dz1 = (dz2 . W1^T) * gate(h1); the domain-table gradient follows from dz1 by linearity
+    t4_contract<H2, H1>(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, []() {});
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = erow2 + 2 * rr;
+        const float v = t4_sum<H1>(red, row, ecol);
+        dz_t[(size_t)row * DZ_LD + ecol] = (smem[T4_H1 + row * H1 + ecol] > 0.f) ? v * scale : 0.f;
+    }
+}
+
+void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
+    const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
+    hipLaunchKernelGGL(k_tower4, dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+}
+
+// W1T / W2T from the live weights (start of every mamdr_train_steps call; k_update keeps them current)
+__global__ __launch_bounds__(256) void k_transpose_w(const float* dense, DenseLayout L, float* wT) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < H1 * H2) {
+        const int r = e / H2, c = e - r * H2;               // W1[r][c], r < 256, c < 128
+        wT[W1T_OFF + c * H1 + r] = dense[L.w1 + e];
+    } else if (e < H1 * H2 + H2 * H3) {
+        const int f = e - H1 * H2;
+        const int r = f / H3, c = f - r * H3;               // W2[r][c], r < 128, c < 64
+        wT[W2T_OFF + c * H2 + r] = dense[L.w2 + f];
+    }
+}
+void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_w, dim3((H1 * H2 + H2 * H3 + 255) / 256), dim3(256), 0, s, dense, L, wT);
+}
+
+}  // namespace mamdr
