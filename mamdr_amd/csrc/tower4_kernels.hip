@@ -135,6 +135,19 @@ __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
     return s;
 }
 
+#ifdef MAMDR_STAMPS   // diagnostic build only (tools/stamp_tower.py)
+#define T4STAMP(k)                                                                            \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (k)] = t_;               \
+    } while (0)
+#else
+#define T4STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
@@ -155,6 +168,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     T4W<H2, H3> w2;
     T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
     T4W<H2, H1> v1;      // backward: dz2 . W1^T through W1T [128][256]
+    T4STAMP(0);
     w0.prefetch(P + a.L.w0);
     const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
     const float b0r = P[a.L.b0 + ecol];
@@ -190,11 +204,13 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
     __syncthreads();
 
+    T4STAMP(1);
     const float scale = a.use_dropout ? a.keep_scale : 1.0f;
     const bool drop = a.use_dropout != 0;
 
     // ---- layer 0: 384 -> 256
     t4_contract<XDIM, H1>(w0, P + a.L.w0, smem + T4_XS, XDIM, red, [&]() { w1.prefetch(P + a.L.w1); });
+    T4STAMP(2);
     if (tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream
         const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
         *reinterpret_cast<f32x4*>(acts_t + (size_t)row * ACT_LD + c4 * 4) =
@@ -217,9 +233,11 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
     __syncthreads();
 
+    T4STAMP(3);
     // ---- layer 1: 256 -> 128
     t4_contract<H1, H2>(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
     __syncthreads();
+    T4STAMP(4);
     {
         const uint32_t key = dropout_layer_key(a.seed, a.step, 1);
         const int row = tid >> 7, col = tid & 127;
@@ -233,12 +251,14 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
     __syncthreads();
 
+    T4STAMP(5);
     // ---- layer 2: 128 -> 64 (the backward weights are requested behind its K loop)
     t4_contract<H2, H3>(w2, P + a.L.w2, smem + T4_H2, H2, red, [&]() {
         v2.prefetch(a.wT + W2T_OFF);
         v1.prefetch(a.wT + W1T_OFF);
     });
     __syncthreads();
+    T4STAMP(6);
     // ---- epilogue of layer 2 + output unit + sigmoid / Keras BCE + dz3: wave r owns row r
     if (w < T4_ROWS) {
         const uint32_t key = dropout_layer_key(a.seed, a.step, 2);
@@ -279,6 +299,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     __syncthreads();
     if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
 
+    T4STAMP(7);
     // ---- backward: dz2 = (dz3 . W2^T) * gate(h2)
     t4_contract<H3, H2>(v2, a.wT + W2T_OFF, smem + T4_DZ3, H3, red, []() {});
     __syncthreads();
@@ -290,6 +311,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         dz_t[(size_t)row * DZ_LD + H1 + col] = d;
     }
     __syncthreads();
+    T4STAMP(8);
     // ---- dz1 = (dz2 . W1^T) * gate(h1); the domain-table gradient follows from dz1 by linearity
     t4_contract<H2, H1>(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, []() {});
     __syncthreads();
@@ -299,6 +321,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         const float v = t4_sum<H1>(red, row, ecol);
         dz_t[(size_t)row * DZ_LD + ecol] = (smem[T4_H1 + row * H1 + ecol] > 0.f) ? v * scale : 0.f;
     }
+    T4STAMP(9);
 }
 
 void launch_tower4_train(const TowerArgs& a, hipStream_t s) {

@@ -27,7 +27,7 @@ w = (rs.standard_normal(eng.n_params) * 0.05).astype(np.float32); eng.set_weight
 # So use the eval kernel?  No: train path -- patch: engine passes no pred_out in train.  We therefore
 # stamp the eval launch (forward phases) and, for train, rely on a debug env hook.
 n = eng.n_rows(d, "train")
-tiles = bs // 16
+tiles = bs // (4 if os.environ.get('MAMDR_TOWER_TILE') != '16' else 16)
 stamps = torch.zeros(tiles * 16, dtype=torch.int64, device=eng.device)
 eng.lib.mamdr_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 eng.lib.mamdr_debug_set_stamps(eng.ctx, C.c_void_p(stamps.data_ptr()))
@@ -36,12 +36,15 @@ for _ in range(5):
     eng.train_steps(d, perm=perm, first_step=0, n_steps=3)
 torch.cuda.synchronize()
 st = stamps.cpu().numpy().reshape(tiles, 16)[:, :10].astype(np.float64)
+if os.environ.get('MAMDR_TOWER_TILE') != '16':
+    names4 = ["prefetch+gather", "L0 contract", "x store+barrier+L0 epilogue", "L1 contract", "barrier+L1 epilogue",
+              "L2 contract", "barrier+L2 epi+out/loss/dz3", "bwd2 contract+epilogue", "bwd1 contract+epilogue"]
 names = ["w0 prefetch+gather", "L0 fwd", "L1 fwd (incl. barrier)", "L2 fwd", "barrier+out/loss", "bw2 prefetch+barrier+dz3",
          "bwd2 (dz2)", "bwd1 (dz1)", "bwd0 (dxe)"]
 dif = np.diff(st, axis=1)
 tot = st[:, 9] - st[:, 0]
 print("tiles %d; total cycles median %.0f (min %.0f max %.0f); s_memtime ticks = shader cycles" % (tiles, np.median(tot), tot.min(), tot.max()))
-for i, nme in enumerate(names):
+for i, nme in enumerate(names4 if os.environ.get('MAMDR_TOWER_TILE') != '16' else names):
     print("  %-28s %8.0f  (%4.1f%%)" % (nme, np.median(dif[:, i]), 100 * np.median(dif[:, i]) / np.median(tot)))
 span = st[:, 9].max() - st[:, 0].min()
 print("first start -> last end: %.0f cycles" % span)
