@@ -482,6 +482,9 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         wa.l2_emb = c->cfg.l2_emb;
         wa.frozen_sumsq = c->frozen_sumsq;
         wa.loss_out = d_loss_out ? d_loss_out + s : nullptr;
+#ifdef MAMDR_STAMPS
+        wa.stamps = c->stamps ? c->stamps + 65536 : nullptr;
+#endif
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
             launch_wgrad(wa, c->stream);

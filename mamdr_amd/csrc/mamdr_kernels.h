@@ -91,6 +91,9 @@ struct WgradArgs {
     float* loss_out;           // nullable: 1 float
     const float* w0dom;        // W0[256:384, :] (live weights)
     float* w0dom_copy;         // its pre-update snapshot, read by k_update
+#ifdef MAMDR_STAMPS
+    unsigned long long* stamps; // diagnostic build only
+#endif
 };
 
 struct UpdateArgs {

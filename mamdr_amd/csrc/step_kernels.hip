@@ -711,6 +711,19 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& g, const TileDesc& t
 constexpr int W0DOM_FLOAT4 = EMB * H1 / 4;               // rows 256..383 of W0
 constexpr int W0DOM_COPY_WGS = W0DOM_FLOAT4 / 256;        // 32
 
+#ifdef MAMDR_STAMPS
+#define WSTAMP(k)                                                                             \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (g.stamps && threadIdx.x == 0 && blockIdx.x < 1024) g.stamps[blockIdx.x * 8 + (k)] = t_; \
+    } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     __shared__ __attribute__((aligned(16))) float red[4 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -736,8 +749,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
                             (g.l2_emb * g.frozen_sumsq[0] + g.l2_emb * g.frozen_sumsq[1] + g.l2_emb * ss);
         return;
     }
+    WSTAMP(0);
     const int tile = blockIdx.x % g.n_tiles, grp = blockIdx.x / g.n_tiles;
     const TileDesc t = g.tiles[tile];
+    WSTAMP(1);
     const int gb0 = grp * g.rows_per_group;
     const int gb1 = min(gb0 + g.rows_per_group, g.rows_pad);
     // split the group's rows over the 4 waves in multiples of 2
@@ -752,6 +767,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     else if (t.a_kind == 0 && t.b_kind == 1) wgrad_rows<0, 1>(g, t, b0, b1, acc);
     else if (t.a_kind == 1 && t.b_kind == 1) wgrad_rows<1, 1>(g, t, b0, b1, acc);
     else wgrad_rows<2, 0>(g, t, b0, b1, acc);
+    WSTAMP(2);
     // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     {
         const int col = lane & 31, rb = 4 * (lane >> 5);
@@ -759,6 +775,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
         for (int r = 0; r < 16; ++r) red[w * 1024 + ((r & 3) + 8 * (r >> 2) + rb) * 32 + col] = acc[r];
     }
     __syncthreads();
+    WSTAMP(3);
     float* slab = g.slabs + (size_t)grp * g.slab_ld;
 #pragma unroll
     for (int e = tid; e < 1024; e += 256) {
@@ -768,6 +785,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
             slab[t.dst_off + row * t.dst_ld + col] = v;
         }
     }
+    WSTAMP(4);
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS), dim3(256), 0, s, a);

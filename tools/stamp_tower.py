@@ -28,14 +28,15 @@ w = (rs.standard_normal(eng.n_params) * 0.05).astype(np.float32); eng.set_weight
 # stamp the eval launch (forward phases) and, for train, rely on a debug env hook.
 n = eng.n_rows(d, "train")
 tiles = bs // (4 if os.environ.get('MAMDR_TOWER_TILE') != '16' else 16)
-stamps = torch.zeros(tiles * 16, dtype=torch.int64, device=eng.device)
+stamps = torch.zeros(65536 + 8192, dtype=torch.int64, device=eng.device)
 eng.lib.mamdr_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 eng.lib.mamdr_debug_set_stamps(eng.ctx, C.c_void_p(stamps.data_ptr()))
 perm = torch.from_numpy(engine.shuffle_perm(n, 10000, 1)).to(eng.device)
 for _ in range(5):
     eng.train_steps(d, perm=perm, first_step=0, n_steps=3)
 torch.cuda.synchronize()
-st = stamps.cpu().numpy().reshape(tiles, 16)[:, :10].astype(np.float64)
+allst = stamps.cpu().numpy()
+st = allst[:tiles * 16].reshape(tiles, 16)[:, :10].astype(np.float64)
 if os.environ.get('MAMDR_TOWER_TILE') != '16':
     names4 = ["prefetch+gather", "L0 contract", "x store+barrier+L0 epilogue", "L1 contract", "barrier+L1 epilogue",
               "L2 contract", "barrier+L2 epi+out/loss/dz3", "bwd2 contract+epilogue", "bwd1 contract+epilogue"]
@@ -48,3 +49,11 @@ for i, nme in enumerate(names4 if os.environ.get('MAMDR_TOWER_TILE') != '16' els
     print("  %-28s %8.0f  (%4.1f%%)" % (nme, np.median(dif[:, i]), 100 * np.median(dif[:, i]) / np.median(tot)))
 span = st[:, 9].max() - st[:, 0].min()
 print("first start -> last end: %.0f cycles" % span)
+
+ws = allst[65536:65536 + 8 * 544].reshape(544, 8)[:, :5].astype(np.float64)
+ws = ws[ws[:, 0] > 0]
+wd = np.diff(ws, axis=1)
+print("k_wgrad: %d tile workgroups stamped; lifetime median %.0f cycles" % (len(ws), np.median(ws[:, 4] - ws[:, 0])))
+for i, nme in enumerate(["tile descriptor load", "row loads + MFMAs (wave 0)", "LDS write + barrier", "reduce + slab store"]):
+    print("  %-28s %8.0f" % (nme, np.median(wd[:, i])))
+print("  first start -> last end: %.0f cycles; start spread %.0f" % (ws[:, 4].max() - ws[:, 0].min(), ws[:, 0].max() - ws[:, 0].min()))
