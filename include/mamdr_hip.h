@@ -42,7 +42,10 @@ enum { MAMDR_TOWER_MLP = 0, MAMDR_TOWER_DEEPFM = 1, MAMDR_TOWER_STAR = 2 };
 /* data splits: utils/dataset.py:79-92 */
 enum { MAMDR_SPLIT_TRAIN = 0, MAMDR_SPLIT_VAL = 1, MAMDR_SPLIT_TEST = 2 };
 /* optimisers: deepctr.py:55 (Adam) / specific_base_model.py:120, base_model.py:69 (SGD finetune) */
-enum { MAMDR_OPT_ADAM = 0, MAMDR_OPT_SGD = 1 };
+enum { MAMDR_OPT_ADAM = 0, MAMDR_OPT_SGD = 1,
+       /* no update: add d total_loss / d theta of the batch (dropout off) to the bound accumulator --
+          the meta pass of first-order MAML, model_zoo/maml.py:107-109,196-229 */
+       MAMDR_OPT_ACCUMULATE = 2 };
 /* merged_method: model_zoo/specific_base_model.py:164-172 */
 enum { MAMDR_MERGE_PLUS = 0, MAMDR_MERGE_TIMES = 1 };
 /* segments of the flat trainable vector, in Keras trainable_weights order */
@@ -98,6 +101,9 @@ int mamdr_param_segment(const mamdr_ctx* ctx, int seg, int64_t* offset, int64_t*
  * (SURVEY A.5); mamdr_optimizer_reset zeroes m, v and the step count. */
 int mamdr_bind_state(mamdr_ctx* ctx, float* d_params, float* d_adam_m, float* d_adam_v);
 int mamdr_optimizer_reset(mamdr_ctx* ctx);
+/* Bind the meta-gradient accumulator (mamdr_param_count floats, caller-owned, caller zeroes it):
+ * target of MAMDR_OPT_ACCUMULATE steps.  Replaces `self.accum_grads` (model_zoo/maml.py:202). */
+int mamdr_bind_accumulator(mamdr_ctx* ctx, float* d_acc);
 int64_t mamdr_optimizer_steps(const mamdr_ctx* ctx);
 
 /* Bind the frozen user / item tables (row-major [rows, emb_dim] fp32).  Replaces
@@ -171,6 +177,14 @@ int mamdr_accumulate(float* d_acc, const float* d_a, const float* d_b, const flo
  * with divisor <= 0 meaning "no division") */
 int mamdr_apply_accumulated(float* d_dst, float* d_acc, float divisor, float scale, int64_t n,
                             void* stream);
+/* TF1 Adam on flat vectors with caller-owned slots: the OUTER optimiser of MAML
+ * (`self.meta_optimizer.apply_gradients`, model_zoo/maml.py:201,215,236-243).
+ *   alpha = lr * sqrt(1 - beta2_power) / (1 - beta1_power), powers AFTER this step's update
+ *   m += (g - m)(1 - beta1); v += (g*g - v)(1 - beta2); p -= m * alpha / (sqrt(v) + eps);
+ *   grad_scale multiplies g first (average_meta_grad = "mean", maml.py:208-210; 1 otherwise). */
+int mamdr_adam_apply(float* d_p, float* d_m, float* d_v, const float* d_g, float grad_scale, float lr,
+                     float beta1, float beta2, float eps, float beta1_power, float beta2_power, int64_t n,
+                     void* stream);
 /* dst[i] = src[i]: SetVarOp.__call__ / K.batch_get_value without the host round
  * trip (utils/tool.py:36-45, maml.py:189-194) */
 int mamdr_copy(float* d_dst, const float* d_src, int64_t n, void* stream);

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR = 0, 1, 2
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
-OPT_ADAM, OPT_SGD = 0, 1
+OPT_ADAM, OPT_SGD, OPT_ACCUMULATE = 0, 1, 2
 MERGE_PLUS, MERGE_TIMES = 0, 1
 (SEG_USER_EMB, SEG_ITEM_EMB, SEG_DOMAIN_EMB, SEG_W0, SEG_W1, SEG_W2, SEG_B0, SEG_B1, SEG_B2, SEG_WO,
  SEG_GB) = range(11)
@@ -54,6 +54,7 @@ SIGNATURES = {
     "mamdr_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_optimizer_steps": (_I64, [_VP]),
+    "mamdr_bind_accumulator": (C.c_int, [_VP, _VP]),
     "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
     "mamdr_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),
     "mamdr_train_steps": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "mamdr_sub": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
     "mamdr_accumulate": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I64, _VP]),
     "mamdr_apply_accumulated": (C.c_int, [_VP, _VP, _F, _F, _I64, _VP]),
+    "mamdr_adam_apply": (C.c_int, [_VP, _VP, _VP, _VP, _F, _F, _F, _F, _F, _F, _F, _I64, _VP]),
     "mamdr_copy": (C.c_int, [_VP, _VP, _I64, _VP]),
     "mamdr_shuffle_perm": (C.c_int, [_I64, _I64, _U64, _VP]),
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),

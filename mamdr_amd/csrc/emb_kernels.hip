@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
         f32x4 g = a.opt.two_l2 * p;
         const int rep = a.map[row];
         if (rep != EMB_UNTOUCHED) g += reinterpret_cast<const f32x4*>(a.gbuf + (size_t)rep * EMB)[c4];
+        if (a.opt.optimizer == 2) {          // accumulate only (MAML meta pass): a.m is the accumulator
+            f32x4 acc = reinterpret_cast<const f32x4*>(a.m)[e4];
+            acc += g;
+            reinterpret_cast<f32x4*>(a.m)[e4] = acc;
+            continue;
+        }
         if (a.opt.optimizer == 0) {
             f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
             f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];

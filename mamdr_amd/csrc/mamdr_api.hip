@@ -62,6 +62,7 @@ struct mamdr_ctx {
     float* params = nullptr;
     float* adam_m = nullptr;
     float* adam_v = nullptr;
+    float* accum = nullptr;         // meta-gradient accumulator (MAMDR_OPT_ACCUMULATE)
     const float* user_tab = nullptr;
     const float* item_tab = nullptr;
     std::vector<SplitData> data;   // [domain*3 + split]
@@ -345,6 +346,13 @@ int mamdr_optimizer_reset(mamdr_ctx* c) {
 
 int64_t mamdr_optimizer_steps(const mamdr_ctx* c) { return c ? c->adam_t : 0; }
 
+int mamdr_bind_accumulator(mamdr_ctx* c, float* d_acc) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (!d_acc || ((uintptr_t)d_acc & 15)) return fail(MAMDR_EINVAL, "accumulator pointer null or not 16-byte aligned");
+    c->accum = d_acc;
+    return MAMDR_OK;
+}
+
 int mamdr_bind_table(mamdr_ctx* c, int seg, const float* d_rows, int64_t n_rows) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (c->cfg.emb_trainable) return fail(MAMDR_ESTATE, "tables are trainable: they live in the flat vector");
@@ -394,7 +402,10 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
     SplitData* d = split_of(c, domain, MAMDR_SPLIT_TRAIN);
     if (!d || !d->uid) return fail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
     if (batch <= 0 || batch > c->cfg.max_batch) return fail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, c->cfg.max_batch);
-    if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD) return fail(MAMDR_EINVAL, "unknown optimizer %d", optimizer);
+    if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD && optimizer != MAMDR_OPT_ACCUMULATE)
+        return fail(MAMDR_EINVAL, "unknown optimizer %d", optimizer);
+    if (optimizer == MAMDR_OPT_ACCUMULATE && !c->accum)
+        return fail(MAMDR_ESTATE, "MAMDR_OPT_ACCUMULATE needs mamdr_bind_accumulator first");
     if (first_step < 0 || n_steps < 0) return fail(MAMDR_EINVAL, "negative step range");
     const int64_t pass_steps = (d->n + batch - 1) / batch;
     if (first_step + n_steps > pass_steps)
@@ -427,7 +438,8 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.step = c->global_step;
         ta.drop_thresh = drop_thresh;
         ta.keep_scale = keep_scale;
-        ta.use_dropout = rate > 0.f ? 1 : 0;
+        // the meta pass runs with the Keras learning phase at its default (0): dropout off
+        ta.use_dropout = (rate > 0.f && optimizer != MAMDR_OPT_ACCUMULATE) ? 1 : 0;
         ta.acts = c->acts;
         ta.dz = c->dz;
         ta.dlogit = c->dlogit;
@@ -493,7 +505,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         UpdateArgs ua;
         memset(&ua, 0, sizeof(ua));
         ua.p = c->params + c->table_floats;
-        ua.m = c->adam_m + c->table_floats;
+        ua.m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
         ua.v = c->adam_v + c->table_floats;
         ua.slabs = c->slabs;
         ua.n_groups = groups;
@@ -515,7 +527,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ua.omb1 = omb1;
         ua.omb2 = omb2;
         ua.eps = c->cfg.adam_eps;
-        ua.wT = may_use4 ? c->wT : nullptr;
+        ua.wT = (may_use4 && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
         ua.w1_off = c->L.w1;
         ua.w2_off = c->L.w2;
         {
@@ -534,7 +546,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             ea.opt.eps = ua.eps;
             ea.opt.two_l2 = ua.two_l2;
             ea.p = c->params;
-            ea.m = c->adam_m;
+            ea.m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
             ea.v = c->adam_v;
             ea.n_rows = c->cfg.n_user;
             ea.brow = c->urow;
@@ -548,7 +560,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             }
             launch_emb_unmark(ea, c->stream);
             ea.p = c->params + (size_t)c->cfg.n_user * EMB;
-            ea.m = c->adam_m + (size_t)c->cfg.n_user * EMB;
+            ea.m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + (size_t)c->cfg.n_user * EMB;
             ea.v = c->adam_v + (size_t)c->cfg.n_user * EMB;
             ea.n_rows = c->cfg.n_item;
             ea.brow = c->irow;
@@ -668,6 +680,15 @@ int mamdr_apply_accumulated(float* d_dst, float* d_acc, float divisor, float sca
     CHECK_VEC(d_dst); CHECK_VEC(d_acc);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
     launch_apply_accumulated(d_dst, d_acc, divisor, scale, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+int mamdr_adam_apply(float* d_p, float* d_m, float* d_v, const float* d_g, float grad_scale, float lr, float beta1,
+                     float beta2, float eps, float beta1_power, float beta2_power, int64_t n, void* stream) {
+    CHECK_VEC(d_p); CHECK_VEC(d_m); CHECK_VEC(d_v); CHECK_VEC(d_g);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    const float alpha = lr * sqrtf(1.0f - beta2_power) / (1.0f - beta1_power);
+    launch_adam_apply(d_p, d_m, d_v, d_g, grad_scale, alpha, 1.0f - beta1, 1.0f - beta2, eps, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }

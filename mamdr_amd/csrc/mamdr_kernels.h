@@ -154,5 +154,7 @@ void launch_sub(float* dst, const float* a, const float* b, int64_t n, hipStream
 void launch_accumulate(float* acc, const float* a, const float* b, const float* shared, float divisor, int64_t n,
                        hipStream_t s);
 void launch_apply_accumulated(float* dst, float* acc, float divisor, float scale, int64_t n, hipStream_t s);
+void launch_adam_apply(float* p, float* m, float* v, const float* g, float gscale, float alpha, float omb1, float omb2,
+                       float eps, int64_t n, hipStream_t s);
 
 }  // namespace mamdr

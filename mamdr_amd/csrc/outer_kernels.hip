@@ -119,6 +119,30 @@ struct ApplyAcc {     // dst += acc [/ divisor] * scale; acc = 0
     }
 };
 
+struct AdamApply {    // TF1 ApplyAdam on a flat vector (outer optimiser of MAML)
+    float* p; float* m; float* v; const float* g; float gscale, alpha, omb1, omb2, eps;
+    __device__ __forceinline__ void step(float& pp, float& mm, float& vv, float gg) const {
+        gg = gg * gscale;
+        mm = mm + (gg - mm) * omb1;
+        vv = vv + (gg * gg - vv) * omb2;
+        pp = pp - (mm * alpha) / (sqrtf(vv) + eps);
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = pp[c], b = mm[c], d = vv[c];
+            step(a, b, d, gg[c]);
+            pp[c] = a; mm[c] = b; vv[c] = d;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    __device__ __forceinline__ void one(int64_t i) const { step(p[i], m[i], v[i], g[i]); }
+};
+
 template <typename F>
 void run(int64_t n, const F& f, hipStream_t s) {
     if (n <= 0) return;
@@ -144,6 +168,11 @@ void launch_accumulate(float* acc, const float* a, const float* b, const float* 
 void launch_apply_accumulated(float* dst, float* acc, float divisor, float scale, int64_t n, hipStream_t s) {
     if (divisor > 0.f) run(n, ApplyAcc<true>{dst, acc, divisor, scale}, s);
     else run(n, ApplyAcc<false>{dst, acc, 1.f, scale}, s);
+}
+
+void launch_adam_apply(float* p, float* m, float* v, const float* g, float gscale, float alpha, float omb1, float omb2,
+                       float eps, int64_t n, hipStream_t s) {
+    run(n, AdamApply{p, m, v, g, gscale, alpha, omb1, omb2, eps}, s);
 }
 
 }  // namespace mamdr

@@ -794,13 +794,16 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------ slab reduce + optimiser
 // TF1 ApplyAdam: m += (g - m)(1-b1); v += (g^2 - v)(1-b2);
 // p -= (m * alpha) / (sqrt(v) + eps), alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host.
+// optimizer 2 = accumulate only: `m` points at the meta-gradient accumulator, p and v are untouched
 __device__ __forceinline__ void optimizer_step(const UpdateArgs& u, float g, float& p, float& m, float& v) {
     if (u.optimizer == 0) {
         m = m + (g - m) * u.omb1;
         v = v + (g * g - v) * u.omb2;
         p = p - (m * u.alpha) / (sqrtf(v) + u.eps);
-    } else {
+    } else if (u.optimizer == 1) {
         p = p - g * u.alpha;
+    } else {
+        m = m + g;
     }
 }
 
@@ -823,6 +826,10 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
             p[c] = pc;
             m[c] = mc;
             v[c] = vc;
+        }
+        if (u.optimizer == 2) {
+            *reinterpret_cast<f32x4*>(u.m + e) = m;
+            return;
         }
         if (u.optimizer == 0) {
             *reinterpret_cast<f32x4*>(u.m + e) = m;
@@ -859,6 +866,10 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
         float p = u.p[el], m = u.m[el], v = u.v[el];
         g += u.two_l2 * p;
         optimizer_step(u, g, p, m, v);
+        if (u.optimizer == 2) {
+            u.m[el] = m;
+            return;
+        }
         if (u.optimizer == 0) {
             u.m[el] = m;
             u.v[el] = v;

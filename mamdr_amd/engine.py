@@ -202,7 +202,7 @@ class TowerEngine(object):
         n = self.n_rows(domain, "train")
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
-        opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD}[optimizer]
+        opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD, "accumulate": L.OPT_ACCUMULATE}[optimizer]
         L.check(self.lib.mamdr_train_steps(self.ctx, domain, _ptr(perm), first_step, n_steps, bs,
                                            self.dropout_seed, opt, float(lr), _ptr(loss_out)))
         return n_steps
@@ -228,6 +228,16 @@ class TowerEngine(object):
         split_id = {"train": L.SPLIT_TRAIN, "val": L.SPLIT_VAL, "test": L.SPLIT_TEST}[split]
         L.check(self.lib.mamdr_gather_rows(self.ctx, domain, split_id, _ptr(perm), first_row, n, _ptr(out)))
         return out
+
+    def bind_accumulator(self, acc):
+        """meta-gradient accumulator of the MAML meta pass (maml.py:202); optimizer="accumulate" adds to it."""
+        self._acc = acc
+        L.check(self.lib.mamdr_bind_accumulator(self.ctx, _ptr(acc)))
+
+    def adam_apply(self, p, m, v, g, lr, beta1_power, beta2_power, grad_scale=1.0):
+        """outer TF1 Adam on flat vectors (maml.py:236-243)."""
+        L.check(self.lib.mamdr_adam_apply(_ptr(p), _ptr(m), _ptr(v), _ptr(g), float(grad_scale), float(lr), 0.9, 0.999,
+                                          1e-8, float(beta1_power), float(beta2_power), p.numel(), self._s()))
 
     def optimizer_reset(self):
         L.check(self.lib.mamdr_optimizer_reset(self.ctx))

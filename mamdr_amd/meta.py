@@ -9,6 +9,7 @@ shardable.  Loop structure follows
     dn_epoch         model_zoo/domain_negotiation.py:49-88
     reptile_epoch    model_zoo/reptile.py:45-99
     mamdr_epoch      model_zoo/mamdr.py:44-108   (DN phase then DR phase)
+    maml_epoch       model_zoo/maml.py:62-116    (first-order MAML, outer Adam)
 
 Weights never leave the GPU: the reference's K.batch_get_value -> numpy ->
 SetVarOp round trips (maml.py:189-194, utils/tool.py:36-45) become device copies
@@ -70,6 +71,41 @@ def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_varia
             eng.interp(theta, eng.weights, theta, meta_lr)
     if batch_variant:
         eng.apply_accumulated(theta, acc, 0.0, meta_lr)
+    eng.set_weights(theta)
+    return trace
+
+
+class OuterAdamState(object):
+    """slots of MAML's separate outer tf.train.AdamOptimizer (maml.py:201): device m, v and the
+    fp32 running beta powers TF keeps as variables."""
+
+    def __init__(self, eng):
+        import numpy as np
+        self.m = eng.new_vector()
+        self.v = eng.new_vector()
+        self.b1p = np.float32(1.0)
+        self.b2p = np.float32(1.0)
+
+    def apply(self, eng, theta, acc, lr, grad_scale=1.0):
+        import numpy as np
+        self.b1p = np.float32(self.b1p * np.float32(0.9))
+        self.b2p = np.float32(self.b2p * np.float32(0.999))
+        eng.adam_apply(theta, self.m, self.v, acc, lr, float(self.b1p), float(self.b2p), grad_scale)
+        acc.zero_()
+
+
+def maml_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False,
+               meta_train_step=0, grad_scale=1.0):
+    """acc must be bound with eng.bind_accumulator(acc) and zero on entry."""
+    trace = []
+    for d in seq:
+        eng.set_weights(theta)
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_train", meta_train_step)
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_meta", meta_train_step, optimizer="accumulate")
+        if not batch_variant:
+            outer.apply(eng, theta, acc, meta_lr, grad_scale)
+    if batch_variant:
+        outer.apply(eng, theta, acc, meta_lr, grad_scale)
     eng.set_weights(theta)
     return trace
 

@@ -6,9 +6,9 @@ write (maml.py:181-194) and `val()` (maml.py:343-353).  In the reference these m
 numpy copies through the host; here `_get_meta_weights` returns a device snapshot of
 the flat trainable vector and `_set_model_meta_parms` is a device copy.
 
-The first-order MAML loop itself (maml.py:35-151,196-243: meta-gradient accumulation
-on a second data split + an outer Adam) is the "second wave" of SURVEY.md section 8
-(a8b): named by the north star, used by no BASELINE config, not built in this round.
+`train()` is the first-order MAML loop itself (maml.py:35-151,196-243): the meta pass runs the
+step kernels in accumulate mode (no update, dropout off) and the outer tf.train.AdamOptimizer
+is `mamdr_adam_apply` on the flat vector with its own slots.
 """
 import random
 
@@ -60,5 +60,43 @@ class MAML(object):
         return val_domain_auc[t] if t >= 0 else val_avg_auc
 
     def train(self):
-        raise NotImplementedError("the first-order MAML loop (maml.py:35-151) is second-wave scope "
-                                  "(SURVEY.md section 8 a8b) and is not built in this round")
+        """first-order MAML (maml.py:35-151): per domain reset to theta, inner Adam pass on the train
+        iterator, meta pass accumulating d total_loss / d theta at the adapted weights, outer Adam
+        (lr = meta_learning_rate) on theta -- per domain, or once per epoch for "batch" names."""
+        from .. import meta
+        print("Start MAML training on model: {}".format(self.model_config["name"]))
+        tc = self.train_config
+        if tc["target_domain"] >= 0:
+            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        if tc["meta_split"] != "train-train":
+            raise NotImplementedError("meta_split '%s': only the 'train-train' split of the reference configs "
+                                      "(maml.py:325-330) is built" % tc["meta_split"])
+        avg = tc["average_meta_grad"]
+        if avg == "mean" and tc["meta_train_step"] > 0:
+            grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])          # maml.py:208-210
+        elif avg in ("moving_mean", "drop"):
+            raise NotImplementedError("average_meta_grad '%s' (maml.py:218-229) is not built" % avg)
+        else:
+            grad_scale = 1.0
+        self._get_model_meta_parms()
+        meta_weights = self._get_meta_weights()
+        self.model.optimizer_reset()
+        outer = meta.OuterAdamState(self.model)
+        acc = self.model.new_vector()
+        self.model.bind_accumulator(acc)
+        train_sequence = list(range(self.n_domain))
+        batch_variant = "batch" in self.model_config["name"]
+        self.trace = []
+        for epoch in range(tc["epoch"]):
+            print("Epoch: {}".format(epoch), "-" * 30)
+            self.rng.shuffle(train_sequence)
+            self.trace += meta.maml_epoch(self.model, meta_weights, outer, acc, list(train_sequence), self.shuffler,
+                                          self.batch_size, self.learning_rate, tc["meta_learning_rate"],
+                                          batch_variant, tc["meta_train_step"], grad_scale)
+            if epoch % tc["val_every_step"] == 0:
+                _, val_avg_auc, _, val_domain_auc = self.val()
+                if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):
+                    break
+                print("Test Result: ")
+                self.val_and_test("test")
+                self._set_model_meta_parms(meta_weights)

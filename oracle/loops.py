@@ -16,9 +16,9 @@ from . import outer
 F32 = np.float32
 
 
-def _pass(model, data, perm_fn, d, batch_size, trace, phase, max_steps=0):
+def _pass(model, data, perm_fn, d, batch_size, trace, phase, max_steps=0, accumulate_into=None):
     perm = perm_fn(d)
-    losses = model.train_pass(data[d], perm, batch_size, max_steps)
+    losses = model.train_pass(data[d], perm, batch_size, max_steps, accumulate_into)
     trace.append((phase, d, len(losses)))
     return losses
 
@@ -57,6 +57,29 @@ def reptile_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, batch_v
             outer.dn_update(theta, model.get_flat(), meta_lr)
     if batch_variant:
         outer.reptile_apply(theta, acc, meta_lr)
+    model.set_flat(theta)
+    return trace
+
+
+def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
+               meta_train_step=0, grad_scale=1.0):
+    """first-order MAML, model_zoo/maml.py:62-116 with meta_split "train-train": per domain reset
+    to theta, inner Adam pass, meta pass that only accumulates gradients at the adapted weights,
+    then (per domain, or once per epoch for "batch" names) the outer Adam step on theta."""
+    trace = []
+
+    def outer_step():
+        outer.apply(theta, acc, meta_lr, grad_scale)
+        acc[...] = 0
+
+    for d in seq:
+        model.set_flat(theta)
+        _pass(model, data, perm_fn, d, batch_size, trace, "maml_train", meta_train_step)
+        _pass(model, data, perm_fn, d, batch_size, trace, "maml_meta", meta_train_step, accumulate_into=acc)
+        if not batch_variant:
+            outer_step()
+    if batch_variant:
+        outer_step()
     model.set_flat(theta)
     return trace
 

@@ -256,7 +256,16 @@ class OracleModel(object):
             self._frozen = (key, {n: table_sumsq(self.params[n]) for n in ("user_emb", "item_emb")})
         return self._frozen[1]
 
-    def train_pass(self, data, perm, batch_size, max_steps=0):
+    def accumulate_on_batch(self, acc, uid, pid, dom, label):
+        """meta pass of first-order MAML (model_zoo/maml.py:107-109,196-229): add
+        d total_loss / d theta at the current weights to `acc` (a flat vector); no update,
+        learning phase 0 = dropout off.  The dropout counter still advances (one per step)."""
+        _, g, _ = loss_and_grads(self.params, uid, pid, dom, label, None, 0.0, self.emb_trainable,
+                                 self.frozen_sumsq())
+        acc += flatten(g, self.names)
+        self.step += 1
+
+    def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
         """one pass over one domain's train split in `perm` order; final partial
         batch kept (utils/dataset.py:25)."""
         n = perm.shape[0]
@@ -266,9 +275,15 @@ class OracleModel(object):
         losses = []
         for s in range(n_step):
             idx = perm[s * batch_size:(s + 1) * batch_size]
-            losses.append(self.train_on_batch(data["uid"][idx], data["pid"][idx], data["domain"][idx],
-                                              data["label"][idx]))
+            if accumulate_into is not None:
+                self.accumulate_on_batch(accumulate_into, data["uid"][idx], data["pid"][idx], data["domain"][idx],
+                                         data["label"][idx])
+                losses.append(None)
+            else:
+                losses.append(self.train_on_batch(data["uid"][idx], data["pid"][idx], data["domain"][idx],
+                                                  data["label"][idx]))
         return losses
+
 
     def predict(self, uid, pid, dom):
         p, _ = forward(self.params, uid, pid, dom, None)
@@ -287,3 +302,22 @@ class OracleModel(object):
             preds[sl] = p
             batch_losses.append(F32(np.mean(bce_per_row(p, data["label"][sl].astype(F32)), dtype=np.float64)) + reg)
         return F32(np.mean(np.array(batch_losses, np.float64))), preds
+
+
+class OuterAdam(object):
+    """the separate tf.train.AdamOptimizer(meta_learning_rate) of MAML (model_zoo/maml.py:201)."""
+
+    def __init__(self, n):
+        self.m = np.zeros(n, F32)
+        self.v = np.zeros(n, F32)
+        self.b1p = F32(1)
+        self.b2p = F32(1)
+
+    def apply(self, theta, grad, lr, grad_scale=1.0):
+        self.b1p = F32(self.b1p * BETA1)
+        self.b2p = F32(self.b2p * BETA2)
+        alpha = F32(F32(lr) * np.sqrt(F32(1) - self.b2p, dtype=F32) / (F32(1) - self.b1p))
+        g = (grad * F32(grad_scale)).astype(F32)
+        self.m += ((g - self.m) * F32(F32(1) - BETA1)).astype(F32)
+        self.v += ((g * g - self.v) * F32(F32(1) - BETA2)).astype(F32)
+        theta -= ((self.m * alpha) / (np.sqrt(self.v, dtype=F32) + ADAM_EPS)).astype(F32)

@@ -105,6 +105,10 @@ class FakeEngine(object):
         self.oracle.use_sgd = optimizer == "sgd"
         for s in range(first_step, first_step + n_steps):
             idx = p[s * bs:(s + 1) * bs]
+            if optimizer == "accumulate":
+                self.oracle.accumulate_on_batch(self._acc.numpy(), cols["uid"][idx], cols["pid"][idx],
+                                                cols["domain"][idx], cols["label"][idx])
+                continue
             self.oracle.train_on_batch(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
         self.calls.append((domain, n_steps, optimizer, lr))
         return n_steps
@@ -113,6 +117,20 @@ class FakeEngine(object):
         cols = self.data[(domain, split)]
         loss, preds = self.oracle.evaluate(cols, self.batch_size)
         return float(loss), float(oauc.auc500(cols["label"], preds, self.batch_size))
+
+    def bind_accumulator(self, acc):
+        self._acc = acc
+
+    def adam_apply(self, p, m, v, g, lr, beta1_power, beta2_power, grad_scale=1.0):
+        o = otower.OuterAdam(p.numel())
+        o.m, o.v = m.numpy(), v.numpy()
+        # powers arrive AFTER this step's update: rewind one step so that OuterAdam.apply reproduces them
+        o.b1p, o.b2p = F32(beta1_power), F32(beta2_power)
+        alpha = F32(F32(lr) * np.sqrt(F32(1) - o.b2p, dtype=F32) / (F32(1) - o.b1p))
+        gg = (g.numpy() * F32(grad_scale)).astype(F32)
+        o.m += ((gg - o.m) * F32(F32(1) - otower.BETA1)).astype(F32)
+        o.v += ((gg * gg - o.v) * F32(F32(1) - otower.BETA2)).astype(F32)
+        p.numpy()[...] -= ((o.m * alpha) / (np.sqrt(o.v, dtype=F32) + otower.ADAM_EPS)).astype(F32)
 
     def optimizer_reset(self):
         self.oracle.opt = otower.Optimizer(self.oracle.params, self.oracle.names)

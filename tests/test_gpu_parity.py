@@ -354,6 +354,65 @@ def test_mamdr_epoch_auc_parity(env):
     eng.close()
 
 
+# ------------------------------------------------------------------ MAML: accumulate mode + outer Adam
+def test_maml_epoch_matches_oracle(env):
+    """first-order MAML epoch (maml.py:62-116): inner Adam pass, meta pass accumulating gradients with
+    dropout off, outer TF1 Adam on theta with its own slots."""
+    engine, synthetic = env
+    from mamdr_amd import meta
+    shape = dict(synthetic.SHAPES["taobao10"], n_domain=3)
+    g, eng, model = make_problem(env, scale=0.05, batch=256, dropout=0.5, shape=shape)
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(3)]
+
+    def make_perm_fn():
+        k = [0]
+
+        def f(d):
+            k[0] += 1
+            return orng.shuffle_perm(sizes[d], 10000, seed=500 + k[0])
+        return f
+
+    # accumulate mode alone: one batch, gradient at the current weights, dropout off, no update
+    acc = eng.new_vector()
+    eng.bind_accumulator(acc)
+    w0 = eng.get_weights().cpu().numpy()
+    perm = orng.shuffle_perm(sizes[0], 10000, seed=3)
+    eng.train_steps(0, perm=torch.from_numpy(perm).to(eng.device), first_step=0, n_steps=2, optimizer="accumulate")
+    acc_o = np.zeros(model.get_flat().size, F32)
+    cols = g["data"]["train"][0]
+    for s_ in range(2):
+        ii = perm[s_ * 256:(s_ + 1) * 256]
+        model.accumulate_on_batch(acc_o, cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(acc)
+    want = {}
+    o = 0
+    for nme in model.names:
+        want[nme] = acc_o[o:o + model.params[nme].size]
+        o += model.params[nme].size
+    for nme in model.names:
+        np.testing.assert_allclose(got[nme], want[nme], rtol=2e-4, atol=2e-6 * max(np.abs(want[nme]).max(), 1e-3))
+    assert np.array_equal(eng.get_weights().cpu().numpy(), w0)            # weights untouched
+    assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == 0
+    # a full epoch, per-domain outer steps
+    acc.zero_()
+    theta_o = model.get_flat().copy()
+    tr_o = oloops.maml_epoch(model, theta_o, otower.OuterAdam(theta_o.size), np.zeros_like(theta_o), g["data"]["train"],
+                             [2, 0, 1], make_perm_fn(), 256, 0.01)
+    theta_g = eng.get_weights()
+    tr_g = meta.maml_epoch(eng, theta_g, meta.OuterAdamState(eng), acc, [2, 0, 1], make_perm_fn(), 256, lr=1e-3,
+                           meta_lr=0.01)
+    assert tr_g == tr_o
+    got = eng.unpack(theta_g)
+    o = 0
+    for nme in model.names:
+        sz = model.params[nme].size
+        diff = np.abs(got[nme] - theta_o[o:o + sz]).max()
+        # three outer Adam steps of size ~meta_lr each: agreement within a small fraction of that
+        assert diff < 0.1 * 3 * 0.01, (nme, diff)
+        o += sz
+    eng.close()
+
+
 # ------------------------------------------------------------------ full size: size-independent properties
 def test_full_size_properties_taobao10(env):
     """BASELINE config sizes (Taobao-10, bs 1024): bit-exact gather, bitwise run-to-run

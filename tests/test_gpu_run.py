@@ -11,7 +11,8 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation", "mlp_meta_reptile", "mlp"])
+@pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation", "mlp_meta_reptile", "mlp",
+                                  "mlp_meta_maml"])
 def test_run_config_on_gpu(tmp_path, name):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -21,6 +22,8 @@ def test_run_config_on_gpu(tmp_path, name):
     cfg["model"]["name"] = name
     cfg["train"].update(epoch=3, patience=1, sample_num=2, meta_learning_rate=0.5,
                         result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    if "maml" in name:      # MAML's meta_learning_rate is the step of an outer ADAM, not an interpolation weight
+        cfg["train"]["meta_learning_rate"] = 0.003
     cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
     avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg)
     assert len(domain_auc) == 10 and np.isfinite(avg_loss)

@@ -101,6 +101,21 @@ def test_meta_epochs_follow_oracle_loops():
     # steps accounting
     spd = [-(-sizes[d] // 64) for d in range(3)]
     assert sum(t[2] for t in tr_g) == mplan.plan_steps(plan, spd)
+    # MAML (per-domain and batch outer steps)
+    for bv in (False, True):
+        e1, e2 = fresh(), fresh()
+        th_o = theta0.copy()
+        acc_o = np.zeros_like(th_o)
+        tr_o = oloops.maml_epoch(e1.oracle, th_o, otower.OuterAdam(th_o.size), acc_o, g["data"]["train"], [1, 0, 2],
+                                 perm_fn_factory(), 64, 0.1, batch_variant=bv)
+        th_g = torch.from_numpy(theta0.copy())
+        acc_g = torch.zeros(th_g.numel())
+        e2.bind_accumulator(acc_g)
+        tr_g = meta.maml_epoch(e2, th_g, meta.OuterAdamState(e2), acc_g, [1, 0, 2], perm_fn_factory(), 64, 1e-3, 0.1,
+                               batch_variant=bv)
+        assert tr_g == tr_o and [t[0] for t in tr_g[:2]] == ["maml_train", "maml_meta"]
+        assert np.array_equal(th_g.numpy(), th_o) and not acc_g.numpy().any()
+        assert np.abs(th_o - theta0).max() > 1e-3                # the outer Adam moved theta by ~meta_lr
     # DN and Reptile (both variants)
     for fn_g, fn_o, kw in ((meta.dn_epoch, oloops.dn_epoch, {}), (meta.reptile_epoch, oloops.reptile_epoch, {}),
                            (meta.reptile_epoch, oloops.reptile_epoch, {"batch_variant": True})):
@@ -130,7 +145,7 @@ def test_epoch_planner_semantics():
 
 # ------------------------------------------------------------------ run.py end to end (CPU stand-in tower)
 @pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation_finetune",
-                                  "mlp_meta_reptile_batch", "mlp"])
+                                  "mlp_meta_reptile_batch", "mlp", "mlp_meta_maml_finetune"])
 def test_run_main_end_to_end(tmp_path, monkeypatch, name):
     patch_emb_dim(monkeypatch)
     cfg = tiny_config(tmp_path, name)
