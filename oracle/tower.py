@@ -28,16 +28,23 @@ BETA1 = F32(0.9)
 BETA2 = F32(0.999)
 ADAM_EPS = F32(1e-8)
 L2_EMB = F32(1e-5)          # deepctr.py:118 l2_reg_embedding
+L2_LIN = F32(1e-5)          # deepctr DeepFM l2_reg_linear default
 
 DENSE_NAMES = ("W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
 
 
-def param_names(emb_trainable):
+def param_names(emb_trainable, deepfm=False):
     """Flat meta-vector order = Keras `trainable_weights` order:
     trainable embeddings in feature order (deepctr.py:102), DNN kernels, DNN
-    biases, final dense kernel, global bias."""
-    emb = ("user_emb", "item_emb", "domain_emb") if emb_trainable else ("domain_emb",)
-    return emb + DENSE_NAMES
+    biases, final dense kernel, global bias.  DeepFM (A.8) adds the 1-d linear
+    tables; the user / item ones inherit `trainable` from their feature column
+    (deepctr create_embedding_dict), so they stay frozen at their zero
+    initialisation unless emb_trainable.  (Their position in Keras' order is [dep];
+    here: user/item linear tables behind the embedding tables, the domain one last.)"""
+    emb = ("user_emb", "item_emb") if emb_trainable else ()
+    lin = ("lin_user", "lin_item") if (emb_trainable and deepfm) else ()
+    tail = ("lin_domain",) if deepfm else ()
+    return emb + lin + ("domain_emb",) + DENSE_NAMES + tail
 
 
 def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64),
@@ -58,6 +65,10 @@ def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64)
     s = np.sqrt(2.0 / (dims[3] + 1))
     p["wo"] = (np.clip(rs.standard_normal((dims[3], 1)), -2, 2) * s).astype(F32)
     p["gb"] = np.zeros(1, F32)
+    # DeepFM linear tables: Zeros initialiser (deepctr get_linear_logit)
+    p["lin_user"] = np.zeros(n_user, F32)
+    p["lin_item"] = np.zeros(n_item, F32)
+    p["lin_domain"] = np.zeros(n_domain, F32)
     return p
 
 
@@ -97,13 +108,17 @@ def table_sumsq(table):
     return F32(np.sum(np.square(table, dtype=F32), dtype=np.float64))
 
 
-def reg_loss(params, frozen_sumsq=None):
-    """deepctr l2_reg_embedding * sum(W^2) on every table, frozen or not (A.3).
+def reg_loss(params, frozen_sumsq=None, deepfm=False):
+    """deepctr l2_reg_embedding * sum(W^2) on every table, frozen or not (A.3); DeepFM adds
+    l2_reg_linear * sum(w^2) on its three linear tables (A.8).
     frozen_sumsq: optional {name: sum of squares} of tables that never change (computed once)."""
     r = F32(0)
     for n in ("user_emb", "item_emb", "domain_emb"):
         ss = frozen_sumsq[n] if frozen_sumsq and n in frozen_sumsq else table_sumsq(params[n])
         r = F32(r + L2_EMB * ss)
+    if deepfm:
+        for n in ("lin_user", "lin_item", "lin_domain"):
+            r = F32(r + L2_LIN * table_sumsq(params[n]))
     return F32(r)
 
 
@@ -113,7 +128,17 @@ def gather(params, uid, pid, dom):
                            params["domain_emb"][dom]], axis=1)
 
 
-def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1)):
+def fm_and_linear(params, x, uid, pid, dom):
+    """DeepFM extras (A.8): sum_f w_f[id_f] + 1/2 sum_k [(sum_f e_fk)^2 - sum_f e_fk^2] over the three
+    128-d fields = sum_k (u i + u d + i d)_k."""
+    E = params["domain_emb"].shape[1]
+    u, i, d = x[:, :E], x[:, E:2 * E], x[:, 2 * E:]
+    fm = np.sum((u * i + u * d + i * d).astype(np.float64), axis=1).astype(F32)
+    lin = (params["lin_user"][uid] + params["lin_item"][pid] + params["lin_domain"][dom]).astype(F32)
+    return (fm + lin).astype(F32)
+
+
+def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1), deepfm=False):
     """returns (p, cache). masks: 3 float32 keep masks or None (inference)."""
     x = gather(params, uid, pid, dom)
     hs = [x]
@@ -126,6 +151,8 @@ def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1)):
         hs.append(a)
         h = a
     logit = (h @ params["wo"]).astype(F32)[:, 0] + params["gb"][0]
+    if deepfm:
+        logit = (logit + fm_and_linear(params, x, uid, pid, dom)).astype(F32)
     p = sigmoid(logit)
     return p, hs
 
@@ -134,13 +161,13 @@ def train_masks(seed, step, n_rows, hidden, rate):
     return [rng.dropout_mask(seed, step, l, n_rows, hidden[l], rate) for l in range(3)]
 
 
-def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None):
+def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, deepfm=False):
     """one batch: total loss (BCE mean + regularisers) and dense gradients."""
     B = uid.shape[0]
     keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
-    p, hs = forward(params, uid, pid, dom, masks, keep_scale)
+    p, hs = forward(params, uid, pid, dom, masks, keep_scale, deepfm)
     y = label.astype(F32)
-    loss = F32(np.mean(bce_per_row(p, y), dtype=np.float64)) + reg_loss(params, frozen_sumsq)
+    loss = F32(np.mean(bce_per_row(p, y), dtype=np.float64)) + reg_loss(params, frozen_sumsq, deepfm)
     inside = ((p >= EPS_CLIP) & (p <= F32(1) - EPS_CLIP)).astype(F32)
     dlogit = ((p - y) * inside / F32(B)).astype(F32)
     g = {}
@@ -155,6 +182,23 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
         dh = (dz @ params["W%d" % l].T).astype(F32)
     E = params["domain_emb"].shape[1]
     two_l2 = F32(2) * L2_EMB
+    if deepfm:
+        # d fm / d e_f = sum of the other two fields' embeddings; d linear / d w_f[id] = 1
+        x = hs[0]
+        u, it, d = x[:, :E], x[:, E:2 * E], x[:, 2 * E:]
+        dh = dh.copy()
+        dh[:, :E] += dlogit[:, None] * (it + d)
+        dh[:, E:2 * E] += dlogit[:, None] * (u + d)
+        dh[:, 2 * E:] += dlogit[:, None] * (u + it)
+        two_l2_lin = F32(2) * L2_LIN
+        nd = params["lin_domain"].shape[0]
+        gl = np.bincount(dom, weights=dlogit.astype(np.float64), minlength=nd)
+        g["lin_domain"] = (gl.astype(F32) + two_l2_lin * params["lin_domain"]).astype(F32)
+        if emb_trainable:
+            gl = np.bincount(uid, weights=dlogit.astype(np.float64), minlength=params["lin_user"].shape[0])
+            g["lin_user"] = (gl.astype(F32) + two_l2_lin * params["lin_user"]).astype(F32)
+            gl = np.bincount(pid, weights=dlogit.astype(np.float64), minlength=params["lin_item"].shape[0])
+            g["lin_item"] = (gl.astype(F32) + two_l2_lin * params["lin_item"]).astype(F32)
     # segmented sum over the few domain rows as a one-hot contraction (float64 accumulation)
     onehot = (dom[:, None] == np.arange(params["domain_emb"].shape[0])[None, :]).astype(np.float64)
     gd = onehot.T @ dh[:, 2 * E:3 * E].astype(np.float64)
@@ -214,10 +258,11 @@ class OracleModel(object):
     """Stand-in for the compiled Keras model: train_on_batch / evaluate."""
 
     def __init__(self, params, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64),
-                 dropout_seed=1024):
+                 dropout_seed=1024, tower="mlp"):
         self.params = params
         self.emb_trainable = emb_trainable
-        self.names = param_names(emb_trainable)
+        self.deepfm = tower == "deepfm"
+        self.names = param_names(emb_trainable, self.deepfm)
         self.opt = Optimizer(params, self.names)
         self.rate = float(dropout)
         self.lr = lr
@@ -239,7 +284,7 @@ class OracleModel(object):
         masks = train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else \
             [np.ones((B, h), F32) for h in self.hidden]
         loss, g, _ = loss_and_grads(self.params, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
-                                    self.frozen_sumsq())
+                                    self.frozen_sumsq(), self.deepfm)
         if self.use_sgd:
             self.opt.sgd(self.params, g, self.lr)
         else:
@@ -261,7 +306,7 @@ class OracleModel(object):
         d total_loss / d theta at the current weights to `acc` (a flat vector); no update,
         learning phase 0 = dropout off.  The dropout counter still advances (one per step)."""
         _, g, _ = loss_and_grads(self.params, uid, pid, dom, label, None, 0.0, self.emb_trainable,
-                                 self.frozen_sumsq())
+                                 self.frozen_sumsq(), self.deepfm)
         acc += flatten(g, self.names)
         self.step += 1
 
@@ -286,14 +331,14 @@ class OracleModel(object):
 
 
     def predict(self, uid, pid, dom):
-        p, _ = forward(self.params, uid, pid, dom, None)
+        p, _ = forward(self.params, uid, pid, dom, None, deepfm=self.deepfm)
         return p
 
     def evaluate(self, data, batch_size):
         """Keras evaluate (A.6): loss = mean over batches of batch-mean loss (+reg),
         predictions for the AUC over all rows in file order."""
         n = data["uid"].shape[0]
-        reg = reg_loss(self.params, self.frozen_sumsq())
+        reg = reg_loss(self.params, self.frozen_sumsq(), self.deepfm)
         batch_losses = []
         preds = np.empty(n, F32)
         for s in range(0, n, batch_size):

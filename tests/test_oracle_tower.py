@@ -53,6 +53,48 @@ def test_gradients_match_finite_differences():
             assert abs(fd - float(g[name][idx])) < 2e-4 + 2e-3 * abs(fd), (name, idx, fd, g[name][idx])
 
 
+def loss64_deepfm(q, uid, pid, dom, y, masks, scale):
+    """q: float64 copies of the parameters (perturbed in float64, not in fp32 storage)"""
+    u, it, d = q["user_emb"][uid], q["item_emb"][pid], q["domain_emb"][dom]
+    h = np.concatenate([u, it, d], 1)
+    for l in range(3):
+        h = np.maximum(h @ q["W%d" % l] + q["b%d" % l], 0) * scale * masks[l]
+    z = (h @ q["wo"])[:, 0] + q["gb"][0]
+    s = u + it + d
+    z = z + 0.5 * ((s * s).sum(1) - (u * u).sum(1) - (it * it).sum(1) - (d * d).sum(1))
+    z = z + q["lin_user"][uid] + q["lin_item"][pid] + q["lin_domain"][dom]
+    ce = np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
+    reg = 1e-5 * sum((q[n] ** 2).sum() for n in ("user_emb", "item_emb", "domain_emb", "lin_user", "lin_item", "lin_domain"))
+    return ce.mean() + reg
+
+
+def test_deepfm_gradients_match_finite_differences():
+    p, uid, pid, dom, y, hidden = small_problem(seed=4)
+    rs = np.random.RandomState(9)
+    for n in ("lin_user", "lin_item", "lin_domain"):
+        p[n] = (rs.standard_normal(p[n].shape) * 0.1).astype(F32)
+    for n in ("user_emb", "item_emb", "domain_emb"):
+        p[n] = (p[n] * 3).astype(F32)
+    masks = tower.train_masks(7, 3, len(uid), hidden, 0.5)
+    loss, g, _ = tower.loss_and_grads(p, uid, pid, dom, y, masks, 0.5, True, None, True)
+    q = {k: v.astype(np.float64) for k, v in p.items()}
+    assert abs(float(loss) - loss64_deepfm(q, uid, pid, dom, y, masks, 2.0)) < 1e-5
+    assert set(tower.param_names(True, True)) == set(g) and tower.param_names(False, True)[-1] == "lin_domain"
+    for name in tower.param_names(True, True):
+        a = q[name]
+        for _ in range(6):
+            idx = tuple(rs.randint(0, s_) for s_ in a.shape)
+            old = a[idx]
+            h = 1e-6
+            a[idx] = old + h
+            lp = loss64_deepfm(q, uid, pid, dom, y, masks, 2.0)
+            a[idx] = old - h
+            lm = loss64_deepfm(q, uid, pid, dom, y, masks, 2.0)
+            a[idx] = old
+            fd = (lp - lm) / (2 * h)
+            assert abs(fd - float(g[name][idx])) < 2e-4 + 2e-3 * abs(fd), (name, idx, fd, g[name][idx])
+
+
 def test_adam_first_step_closed_form():
     p, uid, pid, dom, y, hidden = small_problem(seed=2)
     m = tower.OracleModel(p, emb_trainable=False, dropout=0.0, lr=1e-3, hidden=hidden)
