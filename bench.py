@@ -238,7 +238,10 @@ def main():
         # every launch is one batch; a pass of n_steps launches covers min(rows of the domain, n_steps*batch) rows
         prof_rows = sum(min(sizes[d], n * batch) for (_, d, n) in prof_trace)
         assert cnt == sum(n for (_, _, n) in prof_trace)
-        roofline = finish_roofline("k_tower<train>", roofline_ms, cnt, prof_rows)
+        # frozen tables and batches <= 2048 rows launch the 4-row-tile kernel (mamdr_api.hip: use4)
+        use4 = (not trainable) and batch <= 2048 and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
+        roofline = finish_roofline("k_tower4" if use4 else ("k_tower<true, true>" if trainable else "k_tower<true, false>"),
+                                   roofline_ms, cnt, prof_rows)
         # gather kernel on a pass-sized batch (largest domain, shuffled order)
         dbig = max(range(D), key=lambda k: sizes[k])
         perm = torch.from_numpy(shuffler(dbig)).to(eng.device)
@@ -303,7 +306,7 @@ def finish_roofline(kernel, total_ms, launches, rows):
     flops = rows * TOWER_TRAIN_FLOPS_PER_ROW
     ach = flops / (total_ms * 1e-3) / 1e12
     return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("k_tower<true>"),
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(kernel),
             "traffic_unit": "HBM bytes per launch (profiles/pmc_hbm_latest.json: separate rocprofv3 --pmc passes)",
             "launches": launches,
             "avg_us": total_ms / max(launches, 1) * 1e3, "rows_per_launch": rows / max(launches, 1),

@@ -8,7 +8,7 @@ import collections, csv, glob, json, sys
 
 
 def avg_per_kernel(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
