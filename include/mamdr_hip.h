@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 1
+#define MAMDR_ABI_VERSION 2
 
 enum {
     MAMDR_OK = 0,
@@ -53,7 +53,12 @@ enum {
     MAMDR_SEG_USER_EMB = 0, MAMDR_SEG_ITEM_EMB = 1, MAMDR_SEG_DOMAIN_EMB = 2,
     MAMDR_SEG_W0 = 3, MAMDR_SEG_W1 = 4, MAMDR_SEG_W2 = 5,
     MAMDR_SEG_B0 = 6, MAMDR_SEG_B1 = 7, MAMDR_SEG_B2 = 8,
-    MAMDR_SEG_WO = 9, MAMDR_SEG_GB = 10, MAMDR_SEG_COUNT = 11
+    MAMDR_SEG_WO = 9, MAMDR_SEG_GB = 10,
+    /* DeepFM 1-d linear tables (deepctr get_linear_logit): the user / item ones are in the
+       vector only when emb_trainable (they inherit the feature column's `trainable`), behind the
+       embedding tables; the domain one follows the global bias */
+    MAMDR_SEG_LIN_USER = 11, MAMDR_SEG_LIN_ITEM = 12, MAMDR_SEG_LIN_DOMAIN = 13,
+    MAMDR_SEG_COUNT = 14
 };
 /* kernels whose device time can be profiled (mamdr_profile_*) */
 enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
@@ -76,6 +81,7 @@ typedef struct mamdr_config {
     int32_t emb_trainable;   /* train.emb_trainable: user/item tables join the trainable vector */
     float dropout;           /* model.dropout (rate) */
     float l2_emb;            /* deepctr.py:118 l2_reg_embedding = 1e-5 */
+    float l2_linear;         /* DeepFM l2_reg_linear (deepctr default 1e-5); ignored by the mlp tower */
     float adam_beta1, adam_beta2, adam_eps; /* tf.train.AdamOptimizer defaults 0.9/0.999/1e-8 */
 } mamdr_config;
 

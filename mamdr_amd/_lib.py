@@ -9,15 +9,16 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR = 0, 1, 2
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
 OPT_ADAM, OPT_SGD, OPT_ACCUMULATE = 0, 1, 2
 MERGE_PLUS, MERGE_TIMES = 0, 1
 (SEG_USER_EMB, SEG_ITEM_EMB, SEG_DOMAIN_EMB, SEG_W0, SEG_W1, SEG_W2, SEG_B0, SEG_B1, SEG_B2, SEG_WO,
- SEG_GB) = range(11)
-SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
+ SEG_GB, SEG_LIN_USER, SEG_LIN_ITEM, SEG_LIN_DOMAIN) = range(14)
+SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb",
+             "lin_user", "lin_item", "lin_domain")
 KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP = range(6)
 KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep")
 
@@ -36,7 +37,7 @@ class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("tower", C.c_int32), ("n_user", C.c_int32), ("n_item", C.c_int32),
         ("n_domain", C.c_int32), ("emb_dim", C.c_int32), ("hidden", C.c_int32 * 3), ("max_batch", C.c_int32),
-        ("emb_trainable", C.c_int32), ("dropout", C.c_float), ("l2_emb", C.c_float),
+        ("emb_trainable", C.c_int32), ("dropout", C.c_float), ("l2_emb", C.c_float), ("l2_linear", C.c_float),
         ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
     ]
 

@@ -41,6 +41,12 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     for (int i = b; i < a.rows; ++i)           // positions before b cannot share the row (b is the minimum)
         if (rows_lds[i] == r) acc += a.dxe[(size_t)i * (2 * EMB) + a.dx_off + c];
     a.gbuf[(size_t)b * EMB + c] = acc;
+    if (a.lin_p && c == 0) {                   // DeepFM: the 1-d linear table's row gradient = sum of dlogit
+        float accl = 0.f;
+        for (int i = b; i < a.rows; ++i)
+            if (rows_lds[i] == r) accl += a.dlogit[i];
+        a.glin[b] = accl;
+    }
 }
 
 __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {
@@ -85,6 +91,27 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
             for (int k = 0; k < 4; ++k) p[k] = p[k] - g[k] * a.opt.alpha;
         }
         reinterpret_cast<f32x4*>(a.p)[e4] = p;
+    }
+    if (a.lin_p == nullptr) return;
+    // DeepFM 1-d linear table of the same feature: one scalar per table row, same update rule
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (int64_t)gridDim.x * 256) {
+        float p = a.lin_p[row];
+        float g = a.two_l2_lin * p;
+        const int rep = a.map[row];
+        if (rep != EMB_UNTOUCHED) g += a.glin[rep];
+        if (a.opt.optimizer == 2) {
+            a.lin_m[row] += g;
+            continue;
+        }
+        if (a.opt.optimizer == 0) {
+            float m = a.lin_m[row], v = a.lin_v[row];
+            opt_step(a.opt, g, p, m, v);
+            a.lin_m[row] = m;
+            a.lin_v[row] = v;
+        } else {
+            p = p - g * a.opt.alpha;
+        }
+        a.lin_p[row] = p;
     }
 }
 

@@ -57,6 +57,9 @@ struct mamdr_ctx {
     hipStream_t stream = nullptr;
     DenseLayout L;
     int64_t table_floats = 0;   // trainable user+item floats in front of the dense block
+    bool deepfm = false;
+    int64_t lin_user_off = 0;   // DeepFM + trainable tables: 1-d linear tables behind the embedding tables
+    int64_t lin_item_off = 0;
     int64_t n_params = 0;       // floats of the flat vector (incl. padding)
     // bound state
     float* params = nullptr;
@@ -86,17 +89,21 @@ struct mamdr_ctx {
     int32_t* map_i = nullptr;
     float* gbuf_u = nullptr;
     float* gbuf_i = nullptr;
+    float* fmq = nullptr;           // DeepFM: [rows_pad][EMB]
+    float* glin_u = nullptr;        // DeepFM + trainable tables: [rows_pad]
+    float* glin_i = nullptr;
     int32_t* domrow = nullptr;
     float* loss_part = nullptr;     // train: per tile of a batch
     float* eval_part = nullptr;     // eval: per tile of a split (grown on bind)
     int64_t eval_part_cap = 0;
     float* slabs = nullptr;
     int max_groups = 16;
-    int slab_ld = 0;            // dense block + S region ([n_domain][256])
+    int slab_ld = 0;            // dense block + S region ([n_domain][256]) (+ DeepFM S2 region [n_domain][128])
+    int s2_off = 0;
     TileDesc* tiles = nullptr;
     int n_tiles = 0;
     float* thresholds = nullptr;
-    float* frozen_sumsq = nullptr;  // [2]
+    float* frozen_sumsq = nullptr;  // [4] user, item table; DeepFM linear user, item table
     float* sumsq_partials = nullptr;
 #ifdef MAMDR_STAMPS
     unsigned long long* stamps = nullptr;
@@ -108,7 +115,7 @@ struct mamdr_ctx {
 
 namespace {
 
-std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain) {
+std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off) {
     std::vector<TileDesc> t;
     struct G { int a_off, M, b_off, N, dst; };
     // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
@@ -130,6 +137,14 @@ std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain) {
         for (int n0 = 0; n0 < H1; n0 += 32) {
             const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
             t.push_back(TileDesc{2, m0, 0, n0, L.alloc + m0 * H1 + n0, H1, mv, 32});
+        }
+    if (deepfm)
+        for (int m0 = 0; m0 < n_domain; m0 += 32) {
+            const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
+            // FM part of the domain-table gradient: S2 = onehot(domain)^T (dlogit * (u + i))
+            for (int n0 = 0; n0 < EMB; n0 += 32) t.push_back(TileDesc{2, m0, 2, n0, s2_off + m0 * EMB + n0, EMB, mv, 32});
+            // linear domain table: onehot(domain)^T dlogit
+            t.push_back(TileDesc{2, m0, 1, 0, L.ld + m0, 1, mv, 1});
         }
     return t;
 }
@@ -178,6 +193,11 @@ void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
     a.label = d.label;
     a.n_rows_split = d.n;
     a.thresholds = c->thresholds;
+    a.deepfm = c->deepfm ? 1 : 0;
+    if (c->deepfm && c->cfg.emb_trainable) {
+        a.lin_user = c->params + c->lin_user_off;
+        a.lin_item = c->params + c->lin_item_off;
+    }
 }
 
 int ready(const mamdr_ctx* c) {
@@ -199,8 +219,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     *out = nullptr;
     if (cfg->abi_version != MAMDR_ABI_VERSION)
         return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
-    if (cfg->tower != MAMDR_TOWER_MLP)
-        return fail(MAMDR_ENOTBUILT, "tower kind %d is not built yet (only the mlp tower is)", cfg->tower);
+    if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM)
+        return fail(MAMDR_ENOTBUILT, "tower kind %d is not built yet (the mlp and deepfm towers are)", cfg->tower);
     if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
         return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
                     cfg->emb_dim, cfg->hidden[0], cfg->hidden[1], cfg->hidden[2]);
@@ -214,16 +234,27 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (!c) return fail(MAMDR_EINVAL, "out of host memory");
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
-    c->L = DenseLayout::make(cfg->n_domain);
+    c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM;
+    c->L = DenseLayout::make(cfg->n_domain, c->deepfm);
     c->table_floats = cfg->emb_trainable ? ((int64_t)cfg->n_user + cfg->n_item) * EMB : 0;
+    if (c->deepfm && cfg->emb_trainable) {
+        // each 1-d table padded to 4 floats so that the dense block stays 16-B aligned
+        c->lin_user_off = c->table_floats;
+        c->lin_item_off = c->lin_user_off + (((int64_t)cfg->n_user + 3) & ~(int64_t)3);
+        c->table_floats = c->lin_item_off + (((int64_t)cfg->n_item + 3) & ~(int64_t)3);
+    }
     c->n_params = c->table_floats + c->L.alloc;
     c->data.resize((size_t)cfg->n_domain * 3);
     c->rows_pad_max = cfg->max_batch;
     if (const char* tt = getenv("MAMDR_TOWER_TILE")) c->tower_tile = atoi(tt);
     c->slab_ld = c->L.alloc + cfg->n_domain * H1;
+    if (c->deepfm) {
+        c->s2_off = c->slab_ld;
+        c->slab_ld += cfg->n_domain * EMB;
+    }
 
     const size_t rp = (size_t)c->rows_pad_max;
-    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain);
+    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off);
     c->n_tiles = (int)tiles.size();
     float thr[500];
     thr[0] = (float)(0.0 - 1e-7);
@@ -250,18 +281,23 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->map_i, (size_t)cfg->n_item * sizeof(int32_t));
         ALLOC(c->gbuf_u, rp * EMB * sizeof(float));
         ALLOC(c->gbuf_i, rp * EMB * sizeof(float));
+        if (c->deepfm) {
+            ALLOC(c->glin_u, rp * sizeof(float));
+            ALLOC(c->glin_i, rp * sizeof(float));
+        }
     }
+    if (c->deepfm) ALLOC(c->fmq, rp * EMB * sizeof(float));
     ALLOC(c->domrow, rp * sizeof(int32_t));
     ALLOC(c->loss_part, (rp / 4) * sizeof(float));
     ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
-    ALLOC(c->frozen_sumsq, 2 * sizeof(float));
+    ALLOC(c->frozen_sumsq, 4 * sizeof(float));
     ALLOC(c->sumsq_partials, 1024 * sizeof(float));
 #undef ALLOC
     hipError_t e = hipMemsetAsync(c->slabs, 0, (size_t)c->max_groups * c->slab_ld * sizeof(float), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->frozen_sumsq, 0, 2 * sizeof(float), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->frozen_sumsq, 0, 4 * sizeof(float), c->stream);
     if (cfg->emb_trainable) {
         launch_emb_map_init(c->map_u, cfg->n_user, c->stream);
         launch_emb_map_init(c->map_i, cfg->n_item, c->stream);
@@ -284,7 +320,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->fmq, c->glin_u, c->glin_i, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -315,6 +351,15 @@ int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* c
         case MAMDR_SEG_B2: off = base + L.b2; cnt = H3; break;
         case MAMDR_SEG_WO: off = base + L.wo; cnt = H3; break;
         case MAMDR_SEG_GB: off = base + L.gb; cnt = 1; break;
+        case MAMDR_SEG_LIN_USER:
+            off = c->lin_user_off;
+            cnt = (c->deepfm && c->cfg.emb_trainable) ? c->cfg.n_user : 0;
+            break;
+        case MAMDR_SEG_LIN_ITEM:
+            off = c->lin_item_off;
+            cnt = (c->deepfm && c->cfg.emb_trainable) ? c->cfg.n_item : 0;
+            break;
+        case MAMDR_SEG_LIN_DOMAIN: off = base + L.ld; cnt = L.ld_count; break;
         default: return fail(MAMDR_EINVAL, "unknown segment %d", seg);
     }
     *offset = off;
@@ -420,7 +465,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
 
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
-    const bool may_use4 = !c->cfg.emb_trainable && c->tower_tile != 16;
+    const bool may_use4 = !c->cfg.emb_trainable && !c->deepfm && c->tower_tile != 16;
     if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
 
     for (int64_t s = 0; s < n_steps; ++s) {
@@ -448,6 +493,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.urow = c->urow;
         ta.irow = c->irow;
         ta.loss_part = c->loss_part;
+        ta.fmq = c->fmq;
 #ifdef MAMDR_STAMPS
         ta.stamps = c->stamps;
 #endif
@@ -464,6 +510,10 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             launch_sumsq(c->params, (int64_t)c->cfg.n_user * EMB, c->sumsq_partials, c->frozen_sumsq + 0, c->stream);
             launch_sumsq(c->params + (size_t)c->cfg.n_user * EMB, (int64_t)c->cfg.n_item * EMB, c->sumsq_partials,
                          c->frozen_sumsq + 1, c->stream);
+            if (c->deepfm) {
+                launch_sumsq(c->params + c->lin_user_off, c->cfg.n_user, c->sumsq_partials, c->frozen_sumsq + 2, c->stream);
+                launch_sumsq(c->params + c->lin_item_off, c->cfg.n_item, c->sumsq_partials, c->frozen_sumsq + 3, c->stream);
+            }
         }
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
@@ -471,6 +521,10 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         wa.dz = c->dz;
         wa.dlogit = c->dlogit;
         wa.domrow = c->domrow;
+        wa.fmq = c->fmq;
+        wa.ld_off = c->L.ld;
+        wa.ld_count = c->L.ld_count;
+        wa.l2_lin = c->cfg.l2_linear;
         wa.tiles = c->tiles;
         wa.n_tiles = c->n_tiles;
         wa.rows_pad = rows_pad;
@@ -515,6 +569,10 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ua.count4 = c->L.alloc / 4;
         ua.dm_count = c->cfg.n_domain * EMB;
         ua.two_l2 = 2.0f * c->cfg.l2_emb;
+        ua.s2_off = c->s2_off;
+        ua.ld_off = c->L.ld;
+        ua.ld_count = c->L.ld_count;
+        ua.two_l2_lin = 2.0f * c->cfg.l2_linear;
         ua.optimizer = optimizer;
         if (optimizer == MAMDR_OPT_ADAM) {
             c->adam_t += 1;
@@ -545,8 +603,17 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             ea.opt.omb2 = ua.omb2;
             ea.opt.eps = ua.eps;
             ea.opt.two_l2 = ua.two_l2;
+            float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
+            ea.dlogit = c->dlogit;
+            ea.two_l2_lin = 2.0f * c->cfg.l2_linear;
+            if (c->deepfm) {
+                ea.lin_p = c->params + c->lin_user_off;
+                ea.lin_m = slot_m + c->lin_user_off;
+                ea.lin_v = c->adam_v + c->lin_user_off;
+                ea.glin = c->glin_u;
+            }
             ea.p = c->params;
-            ea.m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
+            ea.m = slot_m;
             ea.v = c->adam_v;
             ea.n_rows = c->cfg.n_user;
             ea.brow = c->urow;
@@ -559,8 +626,14 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
                 launch_emb_sweep(ea, c->stream);
             }
             launch_emb_unmark(ea, c->stream);
+            if (c->deepfm) {
+                ea.lin_p = c->params + c->lin_item_off;
+                ea.lin_m = slot_m + c->lin_item_off;
+                ea.lin_v = c->adam_v + c->lin_item_off;
+                ea.glin = c->glin_i;
+            }
             ea.p = c->params + (size_t)c->cfg.n_user * EMB;
-            ea.m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + (size_t)c->cfg.n_user * EMB;
+            ea.m = slot_m + (size_t)c->cfg.n_user * EMB;
             ea.v = c->adam_v + (size_t)c->cfg.n_user * EMB;
             ea.n_rows = c->cfg.n_item;
             ea.brow = c->irow;
@@ -607,9 +680,24 @@ int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float*
         launch_sumsq(c->params, (int64_t)c->cfg.n_user * EMB, c->sumsq_partials, c->frozen_sumsq + 0, c->stream);
         launch_sumsq(c->params + (size_t)c->cfg.n_user * EMB, (int64_t)c->cfg.n_item * EMB, c->sumsq_partials,
                      c->frozen_sumsq + 1, c->stream);
+        if (c->deepfm) {
+            launch_sumsq(c->params + c->lin_user_off, c->cfg.n_user, c->sumsq_partials, c->frozen_sumsq + 2, c->stream);
+            launch_sumsq(c->params + c->lin_item_off, c->cfg.n_item, c->sumsq_partials, c->frozen_sumsq + 3, c->stream);
+        }
     }
-    launch_eval_finish(c->eval_part, d->n, batch, c->params + c->table_floats, c->cfg.n_domain * EMB, c->cfg.l2_emb,
-                       c->frozen_sumsq, d_loss_out, c->stream);
+    EvalFinishArgs fa;
+    fa.loss_part = c->eval_part;
+    fa.n_rows = d->n;
+    fa.batch = batch;
+    fa.dense = c->params + c->table_floats;
+    fa.dm_count = c->cfg.n_domain * EMB;
+    fa.l2_emb = c->cfg.l2_emb;
+    fa.frozen_sumsq = c->frozen_sumsq;
+    fa.ld_off = c->L.ld;
+    fa.ld_count = c->L.ld_count;
+    fa.l2_lin = c->cfg.l2_linear;
+    fa.loss_out = d_loss_out;
+    launch_eval_finish(fa, c->stream);
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }

@@ -25,9 +25,10 @@ constexpr int W2T_OFF = H1 * H2;              // [64][128]
 constexpr int WT_FLOATS = H1 * H2 + H2 * H3;
 
 // dense block of the flat trainable vector, relative to the domain table start
+// (DeepFM appends its 1-d linear table of the domain feature, `ld`, behind the global bias)
 struct DenseLayout {
-    int dm, w0, w1, w2, b0, b1, b2, wo, gb, count, alloc;
-    __host__ __device__ static DenseLayout make(int n_domain) {
+    int dm, w0, w1, w2, b0, b1, b2, wo, gb, ld, ld_count, count, alloc;
+    __host__ __device__ static DenseLayout make(int n_domain, bool deepfm = false) {
         DenseLayout L;
         L.dm = 0;
         L.w0 = n_domain * EMB;
@@ -38,7 +39,9 @@ struct DenseLayout {
         L.b2 = L.b1 + H2;
         L.wo = L.b2 + H3;
         L.gb = L.wo + H3;
-        L.count = L.gb + 1;
+        L.ld = L.gb + 1;
+        L.ld_count = deepfm ? n_domain : 0;
+        L.count = L.ld + L.ld_count;
         L.alloc = (L.count + 3) & ~3;
         return L;
     }

@@ -50,6 +50,11 @@ struct TowerArgs {
     int32_t* urow;             // [rows_pad] user row of each batch position (-1 = padding)
     int32_t* irow;             // [rows_pad]
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
+    // DeepFM: logit += FM second-order term + linear tables
+    int deepfm;
+    const float* lin_user;     // [n_user] / [n_item] 1-d tables; null = frozen at their zero initialisation
+    const float* lin_item;
+    float* fmq;                // train: [rows_pad][EMB] dlogit * (user + item embedding), for the domain-table gradient
     const float* wT;           // k_tower4 only: transposed W1 / W2 copies
     // eval outputs
     const float* thresholds;   // 500 fp32 AUC thresholds
@@ -63,7 +68,7 @@ struct TowerArgs {
 // weight-gradient GEMMs (K = batch rows) + bias / output-layer / domain-table sums
 struct TileDesc {
     int a_kind, a_off;         // 0: acts column block, 1: ones (row 0), 2: one-hot(domain) rows a_off..
-    int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0)
+    int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0), 2: fmq column block
     int dst_off, dst_ld;       // destination in the dense-block gradient slab
     int m_valid, n_valid;      // valid rows / cols of the 32x32 tile
 };
@@ -73,6 +78,7 @@ struct WgradArgs {
     const float* dz;
     const float* dlogit;
     const int32_t* domrow;
+    const float* fmq;          // DeepFM only
     const TileDesc* tiles;
     int n_tiles;
     int rows_pad;              // batch rows rounded up to TILE_ROWS
@@ -87,7 +93,9 @@ struct WgradArgs {
     const float* dense;        // for the domain-table regulariser
     int dm_count;
     float l2_emb;
-    const float* frozen_sumsq; // [2] sum of squares of frozen user / item tables (0 if trainable)
+    const float* frozen_sumsq; // [4] sums of squares: user, item table; DeepFM linear user, item table
+    int ld_off, ld_count;      // DeepFM: linear domain table inside the dense block (regulariser l2_lin)
+    float l2_lin;
     float* loss_out;           // nullable: 1 float
     const float* w0dom;        // W0[256:384, :] (live weights)
     float* w0dom_copy;         // its pre-update snapshot, read by k_update
@@ -107,6 +115,9 @@ struct UpdateArgs {
     int dm_count;              // elements [0, dm_count): domain table, gradient = S . W0dom^T + 2*l2*p
     int s_off;                 // offset of S = onehot(domain)^T dz1 ([n_domain][256]) inside a slab
     const float* w0dom_copy;
+    int s2_off;                // DeepFM: offset of S2 = onehot(domain)^T fmq ([n_domain][EMB]) inside a slab, 0 = none
+    int ld_off, ld_count;      // DeepFM: linear domain table (gradient += 2 l2_lin p)
+    float two_l2_lin;
     float two_l2;
     int optimizer;             // 0 adam, 1 sgd
     float alpha;               // adam: lr*sqrt(1-b2^t)/(1-b1^t); sgd: lr
@@ -119,8 +130,19 @@ void launch_tower_train(const TowerArgs& a, hipStream_t s);
 void launch_tower_eval(const TowerArgs& a, hipStream_t s);
 void launch_tower4_train(const TowerArgs& a, hipStream_t s);
 void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s);
-void launch_eval_finish(const float* loss_part, int64_t n_rows, int batch, const float* dense, int dm_count,
-                        float l2_emb, const float* frozen_sumsq, float* loss_out, hipStream_t s);
+struct EvalFinishArgs {
+    const float* loss_part;
+    int64_t n_rows;
+    int batch;
+    const float* dense;
+    int dm_count;
+    float l2_emb;
+    const float* frozen_sumsq; // [4]
+    int ld_off, ld_count;
+    float l2_lin;
+    float* loss_out;
+};
+void launch_eval_finish(const EvalFinishArgs& a, hipStream_t s);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 void launch_update(const UpdateArgs& a, hipStream_t s);
 void launch_gather(const TowerArgs& a, float* out, hipStream_t s);
@@ -140,6 +162,13 @@ struct EmbStepArgs {
     int rows;                  // batch rows
     int32_t* map;              // [n_rows] first batch position touching the row, EMB_UNTOUCHED otherwise
     float* gbuf;               // [rows][EMB] summed row gradients, indexed by representative position
+    // DeepFM 1-d linear table of the same feature (null otherwise): gradient = scatter-add of dlogit
+    float* lin_p;
+    float* lin_m;
+    float* lin_v;
+    const float* dlogit;       // [rows]
+    float* glin;               // [rows] summed dlogit, indexed by representative position
+    float two_l2_lin;
     OptArgsLite opt;
 };
 void launch_emb_scatter(const EmbStepArgs& a, hipStream_t s);

@@ -385,14 +385,16 @@ constexpr int PFB2 = 2, PFB1 = 2, PFB0 = 4;
 
 // DX: the user / item tables are trainable, so every row also needs d loss / d [user | item]
 // embedding = dz1 . W0[0:256, :]^T (the frozen-table path replaces that contraction by linearity).
-template <bool TRAIN, bool DX>
+// FM: DeepFM tower: logit += sum_f w_f[id_f] + sum_k (u i + u d + i d)_k.
+template <bool TRAIN, bool DX, bool FM>
 __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
     const int r0 = tile * TILE_ROWS;
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
-    float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;   // [0,16) label, [32,40) per-wave loss
+    // [0,16) label, [16,32) DeepFM fm + linear term, [32,40) per-wave loss, [48,64) DeepFM dlogit
+    float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;
     float* acts_t = TRAIN ? a.acts + (size_t)r0 * ACT_LD : nullptr;
 
     const float* P = a.dense;
@@ -410,6 +412,29 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
 
     gather_tile(a, smem, r0, acts_t, ACT_LD);
     STAMP(1);
+    // DeepFM: thread (i, part) owns columns 4 part .. +3 of row i's three fields.  u + i stays in
+    // registers for the domain-table gradient (the x tile is overwritten by the backward chain).
+    f32x4 fm_ui = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (FM) {
+        const int i = tid >> 5, part = tid & 31;
+        const float* xr = smem + XS_OFF + i * XS_LD + 4 * part;
+        const f32x4 u = *reinterpret_cast<const f32x4*>(xr);
+        const f32x4 it = *reinterpret_cast<const f32x4*>(xr + EMB);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(xr + 2 * EMB);
+        fm_ui = u + it;
+        const f32x4 t = u * it + fm_ui * d;
+        float s = (t[0] + t[1]) + (t[2] + t[3]);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        if (part == 0) {
+            float lin = P[a.L.ld + rowi[2 * TILE_ROWS + i]];
+            if (a.lin_user) lin = (a.lin_user[rowi[i]] + a.lin_item[rowi[TILE_ROWS + i]]) + lin;
+            rowf[TILE_ROWS + i] = s + lin;
+        }
+    }
 
     const float scale = a.use_dropout ? a.keep_scale : 1.0f;
     const int row0 = r0;   // row index inside the batch seeds the dropout stream
@@ -453,7 +478,8 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
         s += __shfl_xor(s, 4);
         s += __shfl_xor(s, 8);
         s += __shfl_xor(s, 16);
-        const float logit = s + gb_reg;
+        float logit = s + gb_reg;
+        if (FM) logit += rowf[TILE_ROWS + i];
         float p;
         if (logit >= 0.f) {
             p = 1.0f / (1.0f + __expf(-logit));
@@ -485,6 +511,11 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
             for (int c = 0; c < 2; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
             *reinterpret_cast<f32x2*>(smem + DZ3S_OFF + i * H3_LD + n2) = d;
             *reinterpret_cast<f32x2*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n2) = d;
+            if (FM) {
+                // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
+                *reinterpret_cast<f32x4*>(a.fmq + (size_t)(r0 + i) * EMB + 4 * part) = dl * fm_ui;
+                if (DX && part == 0) rowf[3 * TILE_ROWS + i] = dl;
+            }
         } else if (part == 0 && valid) {
             // AUC bin = number of thresholds strictly below p (utils/metrics_utils.py:309: pred > thr)
             int blo = 0, bhi = 500;
@@ -539,22 +570,39 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     if (DX) {
         __syncthreads();
         float* dxe_t = a.dxe + (size_t)r0 * (2 * EMB);
-        bwd_layer<H1, 2 * EMB, H1, H1_LD>(bw0, P + a.L.w0, smem + DZ1S_OFF, []() {},
-                                          [&](int row, int col, float v) { dxe_t[(size_t)row * (2 * EMB) + col] = v; });
+        bwd_layer<H1, 2 * EMB, H1, H1_LD>(bw0, P + a.L.w0, smem + DZ1S_OFF, []() {}, [&](int row, int col, float v) {
+            if (FM) {
+                // d fm / d e_f = sum of the other two fields (x re-read from the activation workspace)
+                const float* xr = acts_t + (size_t)row * ACT_LD;
+                const int k = col & (EMB - 1);
+                const float other = (col < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
+                v = fmaf(rowf[3 * TILE_ROWS + row], other, v);
+            }
+            dxe_t[(size_t)row * (2 * EMB) + col] = v;
+        });
     }
     STAMP(9);
 }
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    if (a.dxe)
-        hipLaunchKernelGGL((k_tower<true, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
-    else
-        hipLaunchKernelGGL((k_tower<true, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    if (a.deepfm) {
+        if (a.dxe)
+            hipLaunchKernelGGL((k_tower<true, true, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        else
+            hipLaunchKernelGGL((k_tower<true, false, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    } else if (a.dxe) {
+        hipLaunchKernelGGL((k_tower<true, true, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    } else {
+        hipLaunchKernelGGL((k_tower<true, false, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    }
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL((k_tower<false, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    if (a.deepfm)
+        hipLaunchKernelGGL((k_tower<false, false, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    else
+        hipLaunchKernelGGL((k_tower<false, false, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
 }
 
 // ------------------------------------------------------------------ standalone gather
@@ -587,14 +635,28 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_eval_finish(const float* loss_part, int64_t n_rows, int batch,
-                                                     const float* dense, int dm_count, float l2_emb,
-                                                     const float* frozen_sumsq, float* loss_out) {
-    __shared__ float red[4];
+// regularisers of the reported loss: l2_emb on the three embedding tables (frozen or not)
+// and, for DeepFM, l2_lin on the three linear tables (A.8); same order as the oracle's reg_loss
+__device__ __forceinline__ float reg_terms(const float* dense, int dm_count, float l2_emb, const float* frozen_sumsq,
+                                           int ld_off, int ld_count, float l2_lin, float* red) {
     float ss = 0.f;
     for (int e = threadIdx.x; e < dm_count; e += 256) ss = fmaf(dense[e], dense[e], ss);
     ss = block_sum_256(ss, red);
-    const float reg = l2_emb * frozen_sumsq[0] + l2_emb * frozen_sumsq[1] + l2_emb * ss;
+    float reg = l2_emb * frozen_sumsq[0] + l2_emb * frozen_sumsq[1] + l2_emb * ss;
+    if (ld_count > 0) {
+        float sl = 0.f;
+        for (int e = threadIdx.x; e < ld_count; e += 256) sl = fmaf(dense[ld_off + e], dense[ld_off + e], sl);
+        sl = block_sum_256(sl, red);
+        reg = ((reg + l2_lin * frozen_sumsq[2]) + l2_lin * frozen_sumsq[3]) + l2_lin * sl;
+    }
+    return reg;
+}
+
+__global__ __launch_bounds__(256) void k_eval_finish(const EvalFinishArgs a) {
+    __shared__ float red[4];
+    const float reg = reg_terms(a.dense, a.dm_count, a.l2_emb, a.frozen_sumsq, a.ld_off, a.ld_count, a.l2_lin, red);
+    const int64_t n_rows = a.n_rows;
+    const int batch = a.batch;
     const int64_t n_batches = (n_rows + batch - 1) / batch;
     const int tiles_per_batch = batch / TILE_ROWS;
     const int64_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
@@ -603,17 +665,15 @@ __global__ __launch_bounds__(256) void k_eval_finish(const float* loss_part, int
         const int64_t t0 = b * tiles_per_batch;
         const int64_t t1 = (t0 + tiles_per_batch < n_tiles) ? t0 + tiles_per_batch : n_tiles;
         float s = 0.f;
-        for (int64_t t = t0; t < t1; ++t) s += loss_part[t];
+        for (int64_t t = t0; t < t1; ++t) s += a.loss_part[t];
         const int64_t rows_b = (b == n_batches - 1) ? (n_rows - b * (int64_t)batch) : batch;
         acc += s / (float)rows_b + reg;
     }
     acc = block_sum_256(acc, red);
-    if (threadIdx.x == 0) loss_out[0] = acc / (float)n_batches;
+    if (threadIdx.x == 0) a.loss_out[0] = acc / (float)n_batches;
 }
-void launch_eval_finish(const float* loss_part, int64_t n_rows, int batch, const float* dense, int dm_count,
-                        float l2_emb, const float* frozen_sumsq, float* loss_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(256), 0, s, loss_part, n_rows, batch, dense, dm_count, l2_emb,
-                       frozen_sumsq, loss_out);
+void launch_eval_finish(const EvalFinishArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------ sum of squares (frozen tables)
@@ -654,6 +714,7 @@ __device__ __forceinline__ float fetch_a(const WgradArgs& g, const TileDesc& t, 
 template <int BK>
 __device__ __forceinline__ float fetch_b(const WgradArgs& g, const TileDesc& t, int b, int c) {
     if (BK == 0) return g.dz[(size_t)b * DZ_LD + t.b_off + c];
+    if (BK == 2) return g.fmq[(size_t)b * EMB + t.b_off + c];
     return c == 0 ? g.dlogit[b] : 0.0f;
 }
 
@@ -738,15 +799,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
         // ---- one extra workgroup: loss of the step = mean BCE + regularisers
         if (g.loss_out == nullptr) return;
         float* r4 = red;
-        float ss = 0.f;
-        for (int e = tid; e < g.dm_count; e += 256) ss = fmaf(g.dense[e], g.dense[e], ss);
-        ss = block_sum_256(ss, r4);
+        const float reg = reg_terms(g.dense, g.dm_count, g.l2_emb, g.frozen_sumsq, g.ld_off, g.ld_count, g.l2_lin, r4);
         float ls = 0.f;
         for (int e = tid; e < g.n_loss_tiles; e += 256) ls += g.loss_part[e];
         ls = block_sum_256(ls, r4);
-        if (tid == 0)
-            g.loss_out[0] = ls / (float)g.rows +
-                            (g.l2_emb * g.frozen_sumsq[0] + g.l2_emb * g.frozen_sumsq[1] + g.l2_emb * ss);
+        if (tid == 0) g.loss_out[0] = ls / (float)g.rows + reg;
         return;
     }
     WSTAMP(0);
@@ -766,7 +823,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     else if (t.a_kind == 1 && t.b_kind == 0) wgrad_rows<1, 0>(g, t, b0, b1, acc);
     else if (t.a_kind == 0 && t.b_kind == 1) wgrad_rows<0, 1>(g, t, b0, b1, acc);
     else if (t.a_kind == 1 && t.b_kind == 1) wgrad_rows<1, 1>(g, t, b0, b1, acc);
-    else wgrad_rows<2, 0>(g, t, b0, b1, acc);
+    else if (t.b_kind == 0) wgrad_rows<2, 0>(g, t, b0, b1, acc);
+    else if (t.b_kind == 1) wgrad_rows<2, 1>(g, t, b0, b1, acc);    // DeepFM: linear domain table
+    else wgrad_rows<2, 2>(g, t, b0, b1, acc);                        // DeepFM: S2 = onehot(domain)^T fmq
     WSTAMP(2);
     // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     {
@@ -822,6 +881,8 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float pc = p[c], mc = m[c], vc = v[c];
+            const int ec = (int)e + c;
+            if (ec >= u.ld_off && ec < u.ld_off + u.ld_count) gsum[c] += u.two_l2_lin * pc;
             optimizer_step(u, gsum[c], pc, mc, vc);
             p[c] = pc;
             m[c] = mc;
@@ -864,6 +925,11 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
     for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
     if (lane == 0) {
         float p = u.p[el], m = u.m[el], v = u.v[el];
+        if (u.s2_off) {
+            float g2 = u.slabs[(size_t)u.s2_off + el];
+            for (int s = 1; s < u.n_groups; ++s) g2 += u.slabs[(size_t)s * u.slab_ld + u.s2_off + el];
+            g += g2;
+        }
         g += u.two_l2 * p;
         optimizer_step(u, g, p, m, v);
         if (u.optimizer == 2) {

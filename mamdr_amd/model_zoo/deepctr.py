@@ -2,9 +2,9 @@
 
 `build_model` keeps the reference's substring registry (deepctr.py:24-50): names
 containing `mlp` build the 3 x 128-d embedding -> DNN(hidden_dim) -> Dense(1) -> sigmoid
-tower (deepctr.py:95-136) on the HIP engine; `deepfm` is named by BASELINE.json but not
-built in this round; wdl / nfm / autoint / ccpm / pnn are out of scope
-and raise.  Initial tensors follow the reference's initialisers (glorot normal for the
+tower (deepctr.py:95-136) on the HIP engine; names containing `deepfm` add the linear
+tables and the FM second-order term to the logit (deepctr.py:36-38, SURVEY A.8);
+wdl / nfm / autoint / ccpm / pnn are out of scope and raise.  Initial tensors follow the reference's initialisers (glorot normal for the
 kernels, zeros for biases, N(0, 1e-4^2) for the domain table and for user/item tables
 without pretraining, constants from the pretrained tables otherwise) drawn from a numpy
 stream seeded with dataset.seed -- TF's own streams are not reproducible.
@@ -42,6 +42,10 @@ def initial_tensors(rs, n_user, n_item, n_domain, emb_dim, hidden, user_emb=None
         t["b%d" % l] = np.zeros(dims[l + 1], np.float32)
     t["wo"] = glorot_normal(rs, dims[3], 1, (dims[3], 1))
     t["gb"] = np.zeros(1, np.float32)
+    # DeepFM 1-d linear tables: Zeros initialiser (deepctr get_linear_logit); unused by the mlp tower
+    t["lin_user"] = np.zeros(n_user, np.float32)
+    t["lin_item"] = np.zeros(n_item, np.float32)
+    t["lin_domain"] = np.zeros(n_domain, np.float32)
     return t
 
 

@@ -15,9 +15,10 @@ F32 = np.float32
 
 class FakeEngine(object):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False, tower="mlp",
-                 emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None, dropout_seed=1024):
-        if tower != "mlp":
+                 emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5):
+        if tower not in ("mlp", "deepfm"):
             raise NotImplementedError(tower)
+        self.tower = tower
         self.n_user, self.n_item, self.n_domain = n_user, n_item, n_domain
         self.batch_size = batch_size
         self.device = torch.device("cpu")
@@ -25,7 +26,7 @@ class FakeEngine(object):
         rs = np.random.RandomState(0)
         params = otower.init_params(rs, n_user, n_item, n_domain, emb_dim, hidden)
         self.oracle = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=dropout, hidden=hidden,
-                                         dropout_seed=dropout_seed)
+                                         dropout_seed=dropout_seed, tower=tower)
         self.segments = {}
         off = 0
         for name in self.oracle.names:

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     # error path without a device: bad config is rejected before any HIP call
     import ctypes as C
     cfg = _lib.Config(_lib.ABI_VERSION, _lib.TOWER_MLP, 10, 10, 2, 64, (C.c_int32 * 3)(256, 128, 64), 1024, 0, 0.5,
-                      1e-5, 0.9, 0.999, 1e-8)
+                      1e-5, 1e-5, 0.9, 0.999, 1e-8)
     h = C.c_void_p()
     assert lib.mamdr_create(C.byref(cfg), None, C.byref(h)) == _lib.EINVAL
     assert b"emb_dim 128" in lib.mamdr_last_error()

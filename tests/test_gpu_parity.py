@@ -31,7 +31,8 @@ def env():
     return engine, synthetic
 
 
-def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao10", emb_trainable=False):
+def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao10", emb_trainable=False,
+                 tower="mlp"):
     engine, synthetic = env
     g = synthetic.generate(shape, batch_size=batch, seed=seed, scale=scale)
     rs = np.random.RandomState(seed)
@@ -41,8 +42,13 @@ def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao1
     params["domain_emb"] = (rs.standard_normal(params["domain_emb"].shape) * 0.05).astype(F32)
     for l in range(3):
         params["b%d" % l] = (rs.standard_normal(params["b%d" % l].shape) * 0.05).astype(F32)
+    if tower == "deepfm":      # non-zero linear tables so that every term of the logit is exercised
+        params["lin_domain"] = (rs.standard_normal(g["n_domain"]) * 0.05).astype(F32)
+        if emb_trainable:
+            params["lin_user"] = (rs.standard_normal(g["n_user"]) * 0.05).astype(F32)
+            params["lin_item"] = (rs.standard_normal(g["n_item"]) * 0.05).astype(F32)
     eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=dropout,
-                             emb_trainable=emb_trainable)
+                             emb_trainable=emb_trainable, tower=tower)
     if not emb_trainable:
         eng.bind_table("user_emb", params["user_emb"])
         eng.bind_table("item_emb", params["item_emb"])
@@ -52,8 +58,23 @@ def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao1
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
     eng.set_weights(eng.pack(params))
     model = otower.OracleModel({k: v.copy() for k, v in params.items()}, emb_trainable=emb_trainable, dropout=dropout,
-                               lr=1e-3, dropout_seed=eng.dropout_seed)
+                               lr=1e-3, dropout_seed=eng.dropout_seed, tower=tower)
     return g, eng, model
+
+
+def assert_adam_close(got, want, n_steps, lr, name):
+    """k Adam steps of two fp32 evaluations.  Adam normalises every update to ~lr, so an element whose
+    gradient is within rounding of zero -- or a hidden unit whose pre-activation sits within rounding of
+    the relu kink (a handful per batch once the weights differ by 1e-5) -- can legitimately move by up to
+    lr per step in different directions (a flipped unit drags the small-gradient elements of its whole
+    weight column along).  Bar: all but 1e-3 of the elements within 5 % of k*lr, none
+    beyond the 2*k*lr Adam can produce, and the typical element far tighter."""
+    diff = np.abs(np.asarray(got, F32).ravel() - np.asarray(want, F32).ravel())
+    bound = 0.05 * n_steps * lr
+    frac = float(np.mean(diff > bound))
+    assert frac <= 1e-3, (name, "fraction beyond %.1e: %.2e" % (bound, frac), float(diff.max()))
+    assert diff.max() <= 2.02 * n_steps * lr, (name, float(diff.max()))
+    assert float(np.median(diff)) < 0.002 * n_steps * lr, (name, float(np.median(diff)))
 
 
 def same_bits(a, b):
@@ -266,6 +287,61 @@ def test_trainable_tables_gradients_and_adam(env):
     loss_g, auc_g = eng.evaluate(d, "val")
     loss_o, preds = model.evaluate(g["data"]["val"][d], 256)
     assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+    eng.close()
+
+
+# ------------------------------------------------------------------ DeepFM tower (BASELINE config 3)
+@pytest.mark.parametrize("emb_trainable", [False, True])
+def test_deepfm_gradients_adam_eval(env, emb_trainable):
+    """logit += linear tables + FM second-order term: gradients of every segment (incl. the FM part of
+    the embedding gradients and the 1-d linear tables), a few Adam steps, eval."""
+    g, eng, model = make_problem(env, scale=0.1, batch=256, dropout=0.5, emb_trainable=emb_trainable, tower="deepfm")
+    assert "lin_domain" in eng.segments and ("lin_user" in eng.segments) == emb_trainable
+    assert [n for n in model.names if n not in eng.segments] == []
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=4)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_steps = -(-n // 256)
+    # a few Adam steps, including the partial last batch
+    first = max(0, n_steps - 3)
+    eng.train_steps(d, perm=perm_t, first_step=first, n_steps=n_steps - first, lr=1e-3)
+    for s_ in range(first, n_steps):
+        ii = perm[s_ * 256:(s_ + 1) * 256]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], n_steps - first, 1e-3, name)
+    eng.set_weights(eng.pack(model.params))      # re-synchronise before the tight gradient comparison
+    for step in (0, n_steps - 1):          # a full batch and the final (partial) batch
+        idx = perm[step * 256:(step + 1) * 256]
+        masks = otower.train_masks(model.seed, model.step, len(idx), model.hidden, 0.5)
+        loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                               cols["label"][idx], masks, 0.5, emb_trainable, None, True)
+        want = eng.pack({**{k: np.zeros_like(v) for k, v in model.params.items()}, **grads}).cpu().numpy()
+        w0 = eng.get_weights()
+        loss_t = torch.zeros(1, device=eng.device)
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = (w0 - eng.get_weights()).cpu().numpy()
+        eng.set_weights(w0)
+        model.step += 1
+        for name, (off, cnt) in eng.segments.items():
+            w = want[off:off + cnt]
+            # (p_old - p_new recovers g only to ~ulp(p): up to 6e-8 for table values up to 0.5)
+            floor = 6e-8 if name in ("user_emb", "item_emb") else 1e-8      # W0 ~0.1: ulp 7e-9
+            np.testing.assert_allclose(got[off:off + cnt], w, rtol=2e-4,
+                                       atol=max(2e-6 * max(np.abs(w).max(), 1e-3), floor), err_msg=name)
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    assert np.abs(grads["lin_domain"]).max() > 0
+    # eval: predictions carry the FM + linear terms
+    loss_g, auc_g, hist, preds = eng.evaluate(d, "val", want_preds=True)
+    loss_o, preds_o = model.evaluate(g["data"]["val"][d], 256)
+    np.testing.assert_allclose(preds, preds_o, rtol=2e-4, atol=2e-5)
+    assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+    mlp_p, _ = otower.forward(model.params, g["data"]["val"][d]["uid"], g["data"]["val"][d]["pid"],
+                              g["data"]["val"][d]["domain"])
+    assert np.abs(mlp_p - preds_o).max() > 1e-3      # the extra terms change the predictions
     eng.close()
 
 
