@@ -45,8 +45,9 @@ WORKLOADS = {
     "taobao10": dict(shape="taobao10", batch=1024, name="mlp_meta_mamdr Taobao-10 bs=1024 (frozen pretrained tables)"),
     "taobao30": dict(shape="taobao30", batch=4096, name="mlp_meta_mamdr Taobao-30 bs=4096 (frozen pretrained tables)"),
     # trainable 128-d tables (79 M parameters): every step ends with TF1's dense Adam over all rows
-    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.02,
-                    name="mlp_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
+    # (BASELINE.json configs[2]: DeepFM tower under Domain Negotiation)
+    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.02, tower="deepfm",
+                    name="deepfm_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
                          "2% of the rows per epoch)"),
 }
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
@@ -64,13 +65,17 @@ def init_params(g, seed=1024):
         p["b%d" % l] = np.zeros(dims[l + 1], np.float32)
     p["wo"] = (np.clip(rs.standard_normal((64, 1)), -2, 2) * np.sqrt(2.0 / 65)).astype(np.float32)
     p["gb"] = np.zeros(1, np.float32)
+    # DeepFM 1-d linear tables start at zero (deepctr get_linear_logit); ignored by the mlp tower
+    p["lin_user"] = np.zeros(g["n_user"], np.float32)
+    p["lin_item"] = np.zeros(g["n_item"], np.float32)
+    p["lin_domain"] = np.zeros(g["n_domain"], np.float32)
     return p
 
 
-def setup_engine(g, batch, emb_trainable=False):
+def setup_engine(g, batch, emb_trainable=False, tower="mlp"):
     from mamdr_amd import engine
     eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=TRAIN["dropout"],
-                             emb_trainable=emb_trainable)
+                             emb_trainable=emb_trainable, tower=tower)
     if not emb_trainable:
         eng.bind_table("user_emb", g["tables"]["user_emb"])
         eng.bind_table("item_emb", g["tables"]["item_emb"])
@@ -80,7 +85,7 @@ def setup_engine(g, batch, emb_trainable=False):
     return eng
 
 
-def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False):
+def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, tower="mlp"):
     """the oracle (numpy restatement of the TF1.12 path) timed on this box's host cores on
     the first domain-steps of the same workload; TF itself is not installable."""
     from oracle import rng as orng
@@ -89,7 +94,7 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False):
         params = init_params(g)
         params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
     model = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
-                               lr=TRAIN["learning_rate"])
+                               lr=TRAIN["learning_rate"], tower=tower)
     d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     cols = g["data"]["train"][d]
     n = cols["uid"].shape[0]
@@ -152,7 +157,8 @@ def main():
     trainable = bool(wl.get("emb_trainable"))
     g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=wl.get("row_scale", 1.0))
     D = g["n_domain"]
-    eng = setup_engine(g, batch, trainable)
+    tower = wl.get("tower", "mlp")
+    eng = setup_engine(g, batch, trainable, tower)
 
     def full_params(seed=1024):
         p = init_params(g, seed)
@@ -226,6 +232,7 @@ def main():
             # HBM-bound dense optimiser pass: 24 B per table element (read p, m, v; write p, m, v) + 4 B
             # of row map per 512-B row, two launches per step (user table, item table)
             ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
+            # (DeepFM's 1-d linear tables ride in the same launches: 24 more bytes per row, < 1 %, not counted)
             sweep_bytes = (g["n_user"] + g["n_item"]) * (128 * 24 + 4) * (cnt // 2)
             ach = sweep_bytes / (ms * 1e-3) / 1e9
             sweep_info = {"kernel": "k_emb_sweep", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
@@ -240,7 +247,9 @@ def main():
         assert cnt == sum(n for (_, _, n) in prof_trace)
         # frozen tables and batches <= 2048 rows launch the 4-row-tile kernel (mamdr_api.hip: use4)
         use4 = (not trainable) and batch <= 2048 and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
-        roofline = finish_roofline("k_tower4" if use4 else ("k_tower<true, true>" if trainable else "k_tower<true, false>"),
+        fm = ", true>" if tower == "deepfm" else ", false>"
+        use4 = use4 and tower == "mlp"
+        roofline = finish_roofline("k_tower4" if use4 else ("k_tower<true, true" if trainable else "k_tower<true, false") + fm,
                                    roofline_ms, cnt, prof_rows)
         # gather kernel on a pass-sized batch (largest domain, shuffled order)
         dbig = max(range(D), key=lambda k: sizes[k])
@@ -264,7 +273,7 @@ def main():
                                "Taobao tables (15.7 MB) are cache-resident, the 48 MB output is not"}
     result = None
     if rank == 0:
-        cpu = cpu_baseline(g, batch, args.cpu_budget, full_params() if trainable else None, trainable) \
+        cpu = cpu_baseline(g, batch, args.cpu_budget, full_params() if trainable else None, trainable, tower) \
             if args.cpu_budget > 0 else None
         result = {
             "metric": "domain-steps/sec", "value": global_steps / dt, "unit": "domain-steps/s",

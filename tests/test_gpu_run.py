@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation", "mlp_meta_reptile", "mlp",
-                                  "mlp_meta_maml"])
+                                  "mlp_meta_maml", "deepfm_meta_domain_negotiation_finetune"])
 def test_run_config_on_gpu(tmp_path, name):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -34,4 +34,25 @@ def test_run_config_on_gpu(tmp_path, name):
         res = json.load(f)
     assert abs(res["avg_auc"] - avg_auc) < 1e-12
     z = np.load(os.path.join(rdir, run, "model_parameters.npz"))
-    assert z["weights"].shape[0] == 139777 + 128 * 10 + 3 and np.isfinite(z["weights"]).all()
+    # dense block: 139777 tower weights + domain table (+ DeepFM's linear domain table), padded to 4 floats
+    n_dense = 139777 + 128 * 10 + (10 if "deepfm" in name else 0)
+    assert z["weights"].shape[0] == (n_dense + 3) // 4 * 4 and np.isfinite(z["weights"]).all()
+
+
+def test_run_amazon6_deepfm_config_trainable_tables(tmp_path):
+    """BASELINE config 3 (deepfm_meta_domain_negotiation, trainable 128-d tables, no pretraining) through
+    run.py's entry, on a small synthetic slice instead of the 79 M-parameter Amazon-6 tables."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import cli
+    with open(os.path.join(ROOT, "config", "Amazon_6", "deepfm_DN.json")) as f:
+        cfg = json.load(f)
+    assert cfg["model"]["name"] == "deepfm_meta_domain_negotiation" and cfg["train"]["emb_trainable"]
+    cfg["train"].update(epoch=2, patience=1, meta_learning_rate=0.5,
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
+    avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg)
+    assert len(domain_auc) == 10 and np.isfinite(avg_loss) and 0.0 <= avg_auc <= 1.0
+    rdir = os.path.join(cfg["train"]["result_save_path"], cfg["model"]["name"], "Amazon", "split_by_category_6")
+    z = np.load(os.path.join(rdir, os.listdir(rdir)[0], "model_parameters.npz"))
+    assert np.isfinite(z["weights"]).all() and z["weights"].shape[0] > 128 * 1000
