@@ -230,10 +230,10 @@ def main():
                 kernels[L.KERNEL_NAMES[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
         if trainable:
             # HBM-bound dense optimiser pass: 24 B per table element (read p, m, v; write p, m, v) + 4 B
-            # of row map per 512-B row, two launches per step (user table, item table)
+            # of row map per 512-B row, one launch per step over both tables
             ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
             # (DeepFM's 1-d linear tables ride in the same launches: 24 more bytes per row, < 1 %, not counted)
-            sweep_bytes = (g["n_user"] + g["n_item"]) * (128 * 24 + 4) * (cnt // 2)
+            sweep_bytes = (g["n_user"] + g["n_item"]) * (128 * 24 + 4) * cnt
             ach = sweep_bytes / (ms * 1e-3) / 1e9
             sweep_info = {"kernel": "k_emb_sweep", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
                           "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("k_emb_sweep"),

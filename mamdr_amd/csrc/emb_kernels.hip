@@ -2,12 +2,14 @@
 //
 // TF1 semantics: the table gradient is the scatter-add of the batch's row
 // gradients PLUS the dense regulariser term 2*l2*W on every row, and tf.train.AdamOptimizer
-// updates every element every step.  Four kernels per table and step:
-//   k_emb_mark    map[row] = min batch position touching the row          (integer atomics: exact)
-//   k_emb_reduce  the representative position sums the gradients of all positions of its row in
-//                 ascending order -> bitwise reproducible, no float atomics
-//   k_emb_sweep   HBM-bound pass over the whole table: g = 2 l2 p (+ gbuf[map[row]]), Adam / SGD
-//   k_emb_unmark  map[row] = untouched
+// updates every element every step.  Per step, for both tables at once:
+//   (k_tower)     map[row] = min batch position touching the row          (integer atomicMin: exact)
+//   k_emb_reduce  the representative position gathers the positions of its row in ascending order
+//                 (parallel compare + prefix sum) and sums their gradients in that order
+//                 -> bitwise reproducible, no float atomics
+//   k_emb_sweep   HBM-bound pass over both tables: g = 2 l2 p (+ gbuf[map[row]]), Adam / SGD /
+//                 accumulate; resets map[row] on the way
+//   k_lin_sweep   DeepFM only: the 1-d linear tables of the same two features, same rule
 #include "mamdr_kernels.h"
 
 namespace mamdr {
@@ -22,30 +24,48 @@ void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_fill, dim3(blocks), dim3(256), 0, s, map, n, EMB_UNTOUCHED);
 }
 
-__global__ __launch_bounds__(256) void k_emb_mark(const EmbStepArgs a) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= a.rows) return;
-    const int r = a.brow[b];
-    if (r >= 0) atomicMin(a.map + r, b);
-}
-
-// one 128-thread workgroup per batch position; only representatives do work
+// One 128-thread workgroup per (batch position, table); only representatives do work.
+// Thread t checks the contiguous positions [t*per, (t+1)*per); an exclusive prefix sum of the match
+// counts (wave shuffles + one LDS hand-over between the two waves) places the matches in ascending
+// order in `list`, then thread c sums column c of the listed positions in that order.
 __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
-    extern __shared__ int32_t rows_lds[];
-    const int b = blockIdx.x, c = threadIdx.x;
-    const int r = a.brow[b];
-    if (r < 0 || a.map[r] != b) return;       // uniform over the workgroup
-    for (int i = c; i < a.rows; i += EMB) rows_lds[i] = a.brow[i];
+    extern __shared__ int32_t list[];          // [rows] worst case: every position hits the same row
+    __shared__ int wave0_total, n_list;
+    const EmbTable& T = a.t[blockIdx.y];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int r = T.brow[b];
+    if (r < 0 || T.map[r] != b) return;        // uniform over the workgroup
+    const int per = (a.rows + EMB - 1) / EMB;
+    const int p0 = max(t * per, b + 1), p1 = min((t + 1) * per, a.rows);   // b is the minimum position
+    int cnt = 0;
+    for (int i = p0; i < p1; ++i) cnt += (T.brow[i] == r) ? 1 : 0;
+    if (__syncthreads_count(cnt) == 0) {       // the common case: no other position shares the row
+        T.gbuf[(size_t)b * EMB + t] = a.dxe[(size_t)b * (2 * EMB) + T.dx_off + t];
+        if (T.lin_p && t == 0) T.glin[b] = a.dlogit[b];
+        return;
+    }
+    int incl = cnt;
+    const int lane = t & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (t == 63) wave0_total = incl;
     __syncthreads();
-    float acc = 0.f;
-    for (int i = b; i < a.rows; ++i)           // positions before b cannot share the row (b is the minimum)
-        if (rows_lds[i] == r) acc += a.dxe[(size_t)i * (2 * EMB) + a.dx_off + c];
-    a.gbuf[(size_t)b * EMB + c] = acc;
-    if (a.lin_p && c == 0) {                   // DeepFM: the 1-d linear table's row gradient = sum of dlogit
-        float accl = 0.f;
-        for (int i = b; i < a.rows; ++i)
-            if (rows_lds[i] == r) accl += a.dlogit[i];
-        a.glin[b] = accl;
+    int off = incl - cnt + (t >= 64 ? wave0_total : 0);
+    for (int i = p0; i < p1; ++i)
+        if (T.brow[i] == r) list[off++] = i;
+    if (t == EMB - 1) n_list = off;            // the last thread's end offset is the total
+    __syncthreads();
+    const int n = n_list;
+    float acc = a.dxe[(size_t)b * (2 * EMB) + T.dx_off + t];
+    for (int k = 0; k < n; ++k) acc += a.dxe[(size_t)list[k] * (2 * EMB) + T.dx_off + t];
+    T.gbuf[(size_t)b * EMB + t] = acc;
+    if (T.lin_p && t == 0) {                   // DeepFM: the 1-d linear table's row gradient = sum of dlogit
+        float accl = a.dlogit[b];
+        for (int k = 0; k < n; ++k) accl += a.dlogit[list[k]];
+        T.glin[b] = accl;
     }
 }
 
@@ -59,30 +79,44 @@ __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p
     }
 }
 
-// 16 B per lane; a wave covers two 512-B rows, so map[] is read once per half wave
+// 16 B per lane over [user table | item table] (contiguous in the flat vector); a wave covers two
+// 512-B rows, so map[] is read once per half wave.  Without the DeepFM pass, the lane that owns a
+// row's first float4 resets the row's map entry (the other 31 lanes of the row read it in the same
+// instruction, no other thread ever does).  OPT: 0 Adam, 1 SGD, 2 accumulate (a.m = accumulator);
+// all streaming loads of an element are issued before the (rare) dependent gbuf fetch.
+template <int OPT>
 __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
-    const int64_t n4 = a.n_rows * (EMB / 4);
+    const int64_t n0 = a.t[0].n_rows;
+    const int64_t n4 = (n0 + a.t[1].n_rows) * (EMB / 4);
+    const bool reset = a.t[0].lin_p == nullptr;
     for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < n4; e4 += (int64_t)gridDim.x * 256) {
         const int64_t row = e4 >> 5;
         const int c4 = (int)(e4 & 31);
+        // (explicit selects: indexing a.t[] with a per-lane value would spill the struct to scratch)
+        const bool second = row >= n0;
+        int32_t* map = second ? a.t[1].map : a.t[0].map;
+        const float* gbuf = second ? a.t[1].gbuf : a.t[0].gbuf;
+        const int64_t lrow = second ? row - n0 : row;
+        const int rep = map[lrow];
         f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
+        f32x4 m = (f32x4){0.f, 0.f, 0.f, 0.f}, v = m;
+        if (OPT != 1) m = reinterpret_cast<const f32x4*>(a.m)[e4];
+        if (OPT == 0) v = reinterpret_cast<const f32x4*>(a.v)[e4];
         f32x4 g = a.opt.two_l2 * p;
-        const int rep = a.map[row];
-        if (rep != EMB_UNTOUCHED) g += reinterpret_cast<const f32x4*>(a.gbuf + (size_t)rep * EMB)[c4];
-        if (a.opt.optimizer == 2) {          // accumulate only (MAML meta pass): a.m is the accumulator
-            f32x4 acc = reinterpret_cast<const f32x4*>(a.m)[e4];
-            acc += g;
-            reinterpret_cast<f32x4*>(a.m)[e4] = acc;
+        if (rep != EMB_UNTOUCHED) {
+            g += reinterpret_cast<const f32x4*>(gbuf + (size_t)rep * EMB)[c4];
+            if (reset && c4 == 0) map[lrow] = EMB_UNTOUCHED;
+        }
+        if (OPT == 2) {
+            reinterpret_cast<f32x4*>(a.m)[e4] = m + g;
             continue;
         }
-        if (a.opt.optimizer == 0) {
-            f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
-            f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
+        if (OPT == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float pk = p[k], mk = m[k], vk = v[k];
-                opt_step(a.opt, g[k], pk, mk, vk);
-                p[k] = pk; m[k] = mk; v[k] = vk;
+                m[k] = m[k] + (g[k] - m[k]) * a.opt.omb1;
+                v[k] = v[k] + (g[k] * g[k] - v[k]) * a.opt.omb2;
+                p[k] = p[k] - (m[k] * a.opt.alpha) / (sqrtf(v[k]) + a.opt.eps);
             }
             reinterpret_cast<f32x4*>(a.m)[e4] = m;
             reinterpret_cast<f32x4*>(a.v)[e4] = v;
@@ -92,49 +126,61 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
         }
         reinterpret_cast<f32x4*>(a.p)[e4] = p;
     }
-    if (a.lin_p == nullptr) return;
-    // DeepFM 1-d linear table of the same feature: one scalar per table row, same update rule
-    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (int64_t)gridDim.x * 256) {
-        float p = a.lin_p[row];
+}
+
+// DeepFM: 1-d linear tables of the two features (one scalar per table row) + the map reset
+__global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) {
+    const int64_t n0 = a.t[0].n_rows, n_all = n0 + a.t[1].n_rows;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n_all; row += (int64_t)gridDim.x * 256) {
+        const bool second = row >= n0;
+        int32_t* map = second ? a.t[1].map : a.t[0].map;
+        const float* glin = second ? a.t[1].glin : a.t[0].glin;
+        float* lin_p = second ? a.t[1].lin_p : a.t[0].lin_p;
+        float* lin_m = second ? a.t[1].lin_m : a.t[0].lin_m;
+        float* lin_v = second ? a.t[1].lin_v : a.t[0].lin_v;
+        const int64_t lrow = second ? row - n0 : row;
+        float p = lin_p[lrow];
         float g = a.two_l2_lin * p;
-        const int rep = a.map[row];
-        if (rep != EMB_UNTOUCHED) g += a.glin[rep];
+        const int rep = map[lrow];
+        if (rep != EMB_UNTOUCHED) {
+            g += glin[rep];
+            map[lrow] = EMB_UNTOUCHED;
+        }
         if (a.opt.optimizer == 2) {
-            a.lin_m[row] += g;
+            lin_m[lrow] += g;
             continue;
         }
         if (a.opt.optimizer == 0) {
-            float m = a.lin_m[row], v = a.lin_v[row];
+            float m = lin_m[lrow], v = lin_v[lrow];
             opt_step(a.opt, g, p, m, v);
-            a.lin_m[row] = m;
-            a.lin_v[row] = v;
+            lin_m[lrow] = m;
+            lin_v[lrow] = v;
         } else {
             p = p - g * a.opt.alpha;
         }
-        a.lin_p[row] = p;
+        lin_p[lrow] = p;
     }
 }
 
-__global__ __launch_bounds__(256) void k_emb_unmark(const EmbStepArgs a) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= a.rows) return;
-    const int r = a.brow[b];
-    if (r >= 0) a.map[r] = EMB_UNTOUCHED;
-}
-
-void launch_emb_scatter(const EmbStepArgs& a, hipStream_t s) {
-    const int pb = (a.rows + 255) / 256;
-    hipLaunchKernelGGL(k_emb_mark, dim3(pb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_emb_reduce, dim3(a.rows), dim3(EMB), (size_t)a.rows * sizeof(int32_t), s, a);
+void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_reduce, dim3(a.rows, 2), dim3(EMB), (size_t)a.rows * sizeof(int32_t), s, a);
 }
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s) {
-    const int64_t n4 = a.n_rows * (EMB / 4);
+    const int64_t n_all = a.t[0].n_rows + a.t[1].n_rows;
+    const int64_t n4 = n_all * (EMB / 4);
     int64_t blocks = (n4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;       // grid-stride beyond 16 workgroups per CU
-    hipLaunchKernelGGL(k_emb_sweep, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    // one float4 per thread: measured on Amazon-6 (79 M elements) 349 us uncapped vs 415 us with a
+    // 4096-workgroup grid-stride loop; the cap only guards the 32-bit grid dimension
+    if (blocks > 0x7fffffff) blocks = 0x7fffffff;
+    if (a.opt.optimizer == 0) hipLaunchKernelGGL(k_emb_sweep<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (a.opt.optimizer == 1) hipLaunchKernelGGL(k_emb_sweep<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_emb_sweep<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
-void launch_emb_unmark(const EmbStepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_unmark, dim3((a.rows + 255) / 256), dim3(256), 0, s, a);
+void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s) {
+    const int64_t n_all = a.t[0].n_rows + a.t[1].n_rows;
+    int64_t blocks = (n_all + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_lin_sweep, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

@@ -492,6 +492,8 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.dxe = c->dxe;
         ta.urow = c->urow;
         ta.irow = c->irow;
+        ta.map_u = c->map_u;
+        ta.map_i = c->map_i;
         ta.loss_part = c->loss_part;
         ta.fmq = c->fmq;
 #ifdef MAMDR_STAMPS
@@ -595,57 +597,48 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         if (c->cfg.emb_trainable) {
             EmbStepArgs ea;
             memset(&ea, 0, sizeof(ea));
+            float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
+            ea.p = c->params;
+            ea.m = slot_m;
+            ea.v = c->adam_v;
             ea.dxe = c->dxe;
+            ea.dlogit = c->dlogit;
             ea.rows = rows;
+            ea.two_l2_lin = 2.0f * c->cfg.l2_linear;
             ea.opt.optimizer = ua.optimizer;
             ea.opt.alpha = ua.alpha;
             ea.opt.omb1 = ua.omb1;
             ea.opt.omb2 = ua.omb2;
             ea.opt.eps = ua.eps;
             ea.opt.two_l2 = ua.two_l2;
-            float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
-            ea.dlogit = c->dlogit;
-            ea.two_l2_lin = 2.0f * c->cfg.l2_linear;
+            EmbTable& tu = ea.t[0];
+            EmbTable& ti = ea.t[1];
+            tu.n_rows = c->cfg.n_user;
+            tu.brow = c->urow;
+            tu.map = c->map_u;
+            tu.gbuf = c->gbuf_u;
+            tu.dx_off = 0;
+            ti.n_rows = c->cfg.n_item;
+            ti.brow = c->irow;
+            ti.map = c->map_i;
+            ti.gbuf = c->gbuf_i;
+            ti.dx_off = EMB;
             if (c->deepfm) {
-                ea.lin_p = c->params + c->lin_user_off;
-                ea.lin_m = slot_m + c->lin_user_off;
-                ea.lin_v = c->adam_v + c->lin_user_off;
-                ea.glin = c->glin_u;
+                tu.lin_p = c->params + c->lin_user_off;
+                tu.lin_m = slot_m + c->lin_user_off;
+                tu.lin_v = c->adam_v + c->lin_user_off;
+                tu.glin = c->glin_u;
+                ti.lin_p = c->params + c->lin_item_off;
+                ti.lin_m = slot_m + c->lin_item_off;
+                ti.lin_v = c->adam_v + c->lin_item_off;
+                ti.glin = c->glin_i;
             }
-            ea.p = c->params;
-            ea.m = slot_m;
-            ea.v = c->adam_v;
-            ea.n_rows = c->cfg.n_user;
-            ea.brow = c->urow;
-            ea.dx_off = 0;
-            ea.map = c->map_u;
-            ea.gbuf = c->gbuf_u;
-            launch_emb_scatter(ea, c->stream);
+            launch_emb_reduce(ea, c->stream);
             {
                 Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
                 launch_emb_sweep(ea, c->stream);
             }
-            launch_emb_unmark(ea, c->stream);
-            if (c->deepfm) {
-                ea.lin_p = c->params + c->lin_item_off;
-                ea.lin_m = slot_m + c->lin_item_off;
-                ea.lin_v = c->adam_v + c->lin_item_off;
-                ea.glin = c->glin_i;
-            }
-            ea.p = c->params + (size_t)c->cfg.n_user * EMB;
-            ea.m = slot_m + (size_t)c->cfg.n_user * EMB;
-            ea.v = c->adam_v + (size_t)c->cfg.n_user * EMB;
-            ea.n_rows = c->cfg.n_item;
-            ea.brow = c->irow;
-            ea.dx_off = EMB;
-            ea.map = c->map_i;
-            ea.gbuf = c->gbuf_i;
-            launch_emb_scatter(ea, c->stream);
-            {
-                Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
-                launch_emb_sweep(ea, c->stream);
-            }
-            launch_emb_unmark(ea, c->stream);
+            if (c->deepfm) launch_lin_sweep(ea, c->stream);
         }
         c->global_step += 1;
     }

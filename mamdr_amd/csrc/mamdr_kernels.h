@@ -49,6 +49,8 @@ struct TowerArgs {
     float* dxe;                // [rows_pad][256]  d loss / d [user | item] embedding row
     int32_t* urow;             // [rows_pad] user row of each batch position (-1 = padding)
     int32_t* irow;             // [rows_pad]
+    int32_t* map_u;            // [n_user] / [n_item]: atomicMin of the batch position touching the row
+    int32_t* map_i;
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
     // DeepFM: logit += FM second-order term + linear tables
     int deepfm;
@@ -151,29 +153,32 @@ void launch_sumsq(const float* x, int64_t n, float* partials /*>=1024 floats*/, 
 size_t tower_lds_bytes();
 
 // emb_kernels.hip: trainable embedding tables (TF1 dense Adam over every row)
-struct EmbStepArgs {
-    float* p;                  // table [n_rows][EMB] inside the flat vector
-    float* m;
-    float* v;
+struct EmbTable {
     int64_t n_rows;
     const int32_t* brow;       // [rows] table row of each batch position (-1 = padding)
-    const float* dxe;          // [rows][256]
-    int dx_off;                // 0 = user slice, EMB = item slice
-    int rows;                  // batch rows
-    int32_t* map;              // [n_rows] first batch position touching the row, EMB_UNTOUCHED otherwise
+    int32_t* map;              // [n_rows] first batch position touching the row, EMB_UNTOUCHED otherwise (set by k_tower)
     float* gbuf;               // [rows][EMB] summed row gradients, indexed by representative position
+    int dx_off;                // 0 = user slice of dxe, EMB = item slice
     // DeepFM 1-d linear table of the same feature (null otherwise): gradient = scatter-add of dlogit
     float* lin_p;
     float* lin_m;
     float* lin_v;
-    const float* dlogit;       // [rows]
     float* glin;               // [rows] summed dlogit, indexed by representative position
+};
+struct EmbStepArgs {
+    float* p;                  // [user table | item table], contiguous at the head of the flat vector
+    float* m;
+    float* v;
+    EmbTable t[2];             // user, item
+    const float* dxe;          // [rows][256]
+    const float* dlogit;       // [rows]
+    int rows;                  // batch rows
     float two_l2_lin;
     OptArgsLite opt;
 };
-void launch_emb_scatter(const EmbStepArgs& a, hipStream_t s);
+void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s);
-void launch_emb_unmark(const EmbStepArgs& a, hipStream_t s);
+void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s);
 
 // outer_kernels.hip (compiled with -ffp-contract=off)

@@ -503,6 +503,10 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
                 if (DX) {
                     a.urow[r0 + i] = valid ? rowi[i] : -1;
                     a.irow[r0 + i] = valid ? rowi[TILE_ROWS + i] : -1;
+                    if (valid) {    // representative of a table row = its smallest batch position (exact)
+                        atomicMin(a.map_u + rowi[i], r0 + i);
+                        atomicMin(a.map_i + rowi[TILE_ROWS + i], r0 + i);
+                    }
                 }
             }
             // gate = relu'(z) * dropout mask / keep = (h_post > 0) * scale
