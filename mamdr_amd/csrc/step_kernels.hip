@@ -811,7 +811,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
         return;
     }
     WSTAMP(0);
-    const int tile = blockIdx.x % g.n_tiles, grp = blockIdx.x / g.n_tiles;
+    // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
+    // 4 MB L2), so the row group is the fast index: every XCD then touches the activation / gradient
+    // rows of only n_groups/8 (or one of n_groups) groups and its tiles' re-reads of them hit its L2.
+    const int grp = blockIdx.x % g.n_groups, tile = blockIdx.x / g.n_groups;
     const TileDesc t = g.tiles[tile];
     WSTAMP(1);
     const int gb0 = grp * g.rows_per_group;
