@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 2
+#define MAMDR_ABI_VERSION 3
 
 enum {
     MAMDR_OK = 0,
@@ -58,7 +58,16 @@ enum {
        vector only when emb_trainable (they inherit the feature column's `trainable`), behind the
        embedding tables; the domain one follows the global bias */
     MAMDR_SEG_LIN_USER = 11, MAMDR_SEG_LIN_ITEM = 12, MAMDR_SEG_LIN_DOMAIN = 13,
-    MAMDR_SEG_COUNT = 14
+    /* Star tower (model_zoo/Star/star_fcn.py:61-103, partitioned_norm.py:56-100): shared kernels / biases
+       (meta parameters), then PartitionedNorm gamma / beta (shared [384], specific [D][384]), specific
+       kernels [D][in][out] and biases [D][out].  W0..B2 report count 0 for this tower. */
+    MAMDR_SEG_STAR_WS0 = 14, MAMDR_SEG_STAR_WS1 = 15, MAMDR_SEG_STAR_WS2 = 16,
+    MAMDR_SEG_STAR_BS0 = 17, MAMDR_SEG_STAR_BS1 = 18, MAMDR_SEG_STAR_BS2 = 19,
+    MAMDR_SEG_PN_GAMMA_SHARED = 20, MAMDR_SEG_PN_BETA_SHARED = 21,
+    MAMDR_SEG_PN_GAMMA_SPEC = 22, MAMDR_SEG_PN_BETA_SPEC = 23,
+    MAMDR_SEG_STAR_WD0 = 24, MAMDR_SEG_STAR_WD1 = 25, MAMDR_SEG_STAR_WD2 = 26,
+    MAMDR_SEG_STAR_BD0 = 27, MAMDR_SEG_STAR_BD1 = 28, MAMDR_SEG_STAR_BD2 = 29,
+    MAMDR_SEG_COUNT = 30
 };
 /* kernels whose device time can be profiled (mamdr_profile_*) */
 enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
@@ -99,6 +108,18 @@ int mamdr_destroy(mamdr_ctx* ctx);
  *     padding (padding elements stay 0).  Layout per segment via mamdr_param_segment;
  *     a segment absent from the vector (frozen tables) reports count 0. */
 int64_t mamdr_param_count(const mamdr_ctx* ctx);
+/* Length of the META prefix of the flat vector: the tensors `MAML._get_model_meta_parms` selects
+ * (model_zoo/maml.py:153-179).  Equals mamdr_param_count for the mlp / deepfm towers (meta_parms ["all"]);
+ * for the Star tower it covers the tables, shared kernels and shared biases
+ * (config/Taobao-10/star_taobao.json:37-41) -- theta / phi / merged vectors have this length and the
+ * outer updates and weight assignment act on this prefix only. */
+int64_t mamdr_meta_count(const mamdr_ctx* ctx);
+/* Non-trainable model state (Star: PartitionedNorm moving mean / variance per domain and the
+ * zero-debias slots of their moving averages, partitioned_norm.py:71-87,177-193): number of floats
+ * (0 for the other towers) and binding of a caller-owned device buffer, initialised by the caller
+ * (layout: mov_mean [D][384] = 0 | mov_var [D][384] = 1 | biased_mean = 0 | biased_var = 0 | steps [D] = 0). */
+int64_t mamdr_aux_count(const mamdr_ctx* ctx);
+int mamdr_bind_aux(mamdr_ctx* ctx, float* d_aux);
 int mamdr_param_segment(const mamdr_ctx* ctx, int seg, int64_t* offset, int64_t* count);
 
 /* Bind the live model state (caller-owned device memory, mamdr_param_count floats

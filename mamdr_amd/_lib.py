@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR = 0, 1, 2
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -18,7 +18,10 @@ MERGE_PLUS, MERGE_TIMES = 0, 1
 (SEG_USER_EMB, SEG_ITEM_EMB, SEG_DOMAIN_EMB, SEG_W0, SEG_W1, SEG_W2, SEG_B0, SEG_B1, SEG_B2, SEG_WO,
  SEG_GB, SEG_LIN_USER, SEG_LIN_ITEM, SEG_LIN_DOMAIN) = range(14)
 SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb",
-             "lin_user", "lin_item", "lin_domain")
+             "lin_user", "lin_item", "lin_domain",
+             # Star tower
+             "Ws0", "Ws1", "Ws2", "bs0", "bs1", "bs2", "pn_gamma_shared", "pn_beta_shared", "pn_gamma_spec",
+             "pn_beta_spec", "Wd0", "Wd1", "Wd2", "bd0", "bd1", "bd2")
 KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP = range(6)
 KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep")
 
@@ -52,6 +55,9 @@ SIGNATURES = {
     "mamdr_destroy": (C.c_int, [_VP]),
     "mamdr_param_count": (_I64, [_VP]),
     "mamdr_param_segment": (C.c_int, [_VP, C.c_int, C.POINTER(_I64), C.POINTER(_I64)]),
+    "mamdr_meta_count": (_I64, [_VP]),
+    "mamdr_aux_count": (_I64, [_VP]),
+    "mamdr_bind_aux": (C.c_int, [_VP, _VP]),
     "mamdr_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_optimizer_steps": (_I64, [_VP]),

@@ -17,6 +17,7 @@ SOURCES = [
     ("step_kernels.hip", []),
     ("emb_kernels.hip", []),
     ("tower4_kernels.hip", []),
+    ("star_kernels.hip", []),
     ("outer_kernels.hip", ["-ffp-contract=off"]),
     ("mamdr_api.hip", []),
 ]

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     int cnt = 0;
     for (int i = p0; i < p1; ++i) cnt += (T.brow[i] == r) ? 1 : 0;
     if (__syncthreads_count(cnt) == 0) {       // the common case: no other position shares the row
-        T.gbuf[(size_t)b * EMB + t] = a.dxe[(size_t)b * (2 * EMB) + T.dx_off + t];
+        T.gbuf[(size_t)b * EMB + t] = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
         if (T.lin_p && t == 0) T.glin[b] = a.dlogit[b];
         return;
     }
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     if (t == EMB - 1) n_list = off;            // the last thread's end offset is the total
     __syncthreads();
     const int n = n_list;
-    float acc = a.dxe[(size_t)b * (2 * EMB) + T.dx_off + t];
-    for (int k = 0; k < n; ++k) acc += a.dxe[(size_t)list[k] * (2 * EMB) + T.dx_off + t];
+    float acc = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
+    for (int k = 0; k < n; ++k) acc += a.dxe[(size_t)list[k] * a.dx_ld + T.dx_off + t];
     T.gbuf[(size_t)b * EMB + t] = acc;
     if (T.lin_p && t == 0) {                   // DeepFM: the 1-d linear table's row gradient = sum of dlogit
         float accl = a.dlogit[b];

@@ -58,6 +58,16 @@ struct mamdr_ctx {
     DenseLayout L;
     int64_t table_floats = 0;   // trainable user+item floats in front of the dense block
     bool deepfm = false;
+    bool star = false;
+    StarLayout SL;
+    StarAuxLayout AL;
+    int64_t n_meta = 0;
+    float* aux = nullptr;           // bound PartitionedNorm state (Star)
+    float* eff = nullptr;           // Star: effective dense block of the step's domain
+    float* pn = nullptr;            // Star: [PN_WS_FLOATS]
+    float* star_part = nullptr;     // Star: [chunks][2][384] partials (forward statistics, then backward sums)
+    float* star_sums = nullptr;     // Star: [2][384]
+    float* star_dmpart = nullptr;   // Star: [chunks][EMB]
     int64_t lin_user_off = 0;   // DeepFM + trainable tables: 1-d linear tables behind the embedding tables
     int64_t lin_item_off = 0;
     int64_t n_params = 0;       // floats of the flat vector (incl. padding)
@@ -202,12 +212,169 @@ void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
 
 int ready(const mamdr_ctx* c) {
     if (!c->params) return fail(MAMDR_ESTATE, "mamdr_bind_state has not been called");
+    if (c->star && !c->aux) return fail(MAMDR_ESTATE, "Star tower: mamdr_bind_aux has not been called");
     if (!c->cfg.emb_trainable && (!c->user_tab || !c->item_tab))
         return fail(MAMDR_ESTATE, "frozen user/item tables are not bound (mamdr_bind_table)");
     return MAMDR_OK;
 }
 
 }  // namespace
+
+
+// ---- Star tower: one training step on `rows` rows of domain `domain` (star.py:70-97; kernels in star_kernels.hip)
+static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const int32_t* d_perm, int64_t row_base, int rows,
+                           int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out) {
+    const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    const int chunks = (rows + STAR_CHUNK - 1) / STAR_CHUNK;
+    float* blk = c->params + c->table_floats;
+    TowerArgs ta;
+    fill_tower_common(c, d, ta);
+    ta.perm = d_perm;
+    ta.row_base = row_base;
+    ta.rows = rows;
+    ta.batch = rows;
+    // forward statistics read the raw rows (domain table straight from the flat vector: SL.dm == L.dm == 0)
+    launch_star_stats(ta, c->star_part, c->stream);
+    StarPrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.blk = blk;
+    pa.SL = c->SL;
+    pa.L = c->L;
+    pa.n_domain = c->cfg.n_domain;
+    pa.d = domain;
+    pa.eff = c->eff;
+    pa.pn = c->pn;
+    pa.part = c->star_part;
+    pa.n_chunks = chunks;
+    pa.rows = rows;
+    pa.aux = c->aux;
+    pa.AL = c->AL;
+    pa.train = 1;
+    launch_star_prep(pa, c->stream);
+
+    ta.dense = c->eff;
+    ta.pn_aff = c->pn;
+    ta.use_dropout = 0;
+    ta.keep_scale = 1.0f;
+    ta.acts = c->acts;
+    ta.dz = c->dz;
+    ta.dlogit = c->dlogit;
+    ta.domrow = c->domrow;
+    ta.dxe = c->dxe;
+    ta.dx_ld = XDIM;
+    ta.urow = c->urow;
+    ta.irow = c->irow;
+    ta.map_u = c->map_u;          // null with frozen tables
+    ta.map_i = c->map_i;
+    ta.loss_part = c->loss_part;
+    {
+        Prof p(c, MAMDR_KERNEL_FWD_BWD);
+        launch_tower_train(ta, c->stream);
+    }
+    WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.acts = c->acts;
+    wa.dz = c->dz;
+    wa.dlogit = c->dlogit;
+    wa.domrow = c->domrow;
+    wa.tiles = c->tiles;
+    wa.n_tiles = c->n_tiles;
+    wa.rows_pad = rows_pad;
+    int rpg = rows_pad <= 2048 ? 256 : 512;
+    int groups = (rows_pad + rpg - 1) / rpg;
+    if (groups > c->max_groups) {
+        rpg = ((rows_pad + c->max_groups - 1) / c->max_groups + 7) / 8 * 8;
+        groups = (rows_pad + rpg - 1) / rpg;
+    }
+    wa.n_groups = groups;
+    wa.rows_per_group = rpg;
+    wa.slabs = c->slabs;
+    wa.slab_ld = c->slab_ld;
+    wa.w0dom = c->eff + c->L.w0 + (size_t)(2 * EMB) * H1;
+    wa.w0dom_copy = c->w0dom_copy;
+    wa.loss_part = c->loss_part;
+    wa.n_loss_tiles = rows_pad / TILE_ROWS;
+    wa.rows = rows;
+    wa.dense = c->eff;
+    wa.dm_count = 0;              // no regularisers in this tower: loss = mean BCE
+    wa.l2_emb = 0.f;
+    wa.frozen_sumsq = c->frozen_sumsq;
+    wa.loss_out = loss_out;
+    {
+        Prof p(c, MAMDR_KERNEL_WGRAD);
+        launch_wgrad(wa, c->stream);
+    }
+    StarPnBwdArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.user_tab = ta.user_tab;
+    ba.item_tab = ta.item_tab;
+    ba.dm_row = blk + c->SL.dm + (size_t)domain * EMB;
+    ba.urow = c->urow;
+    ba.irow = c->irow;
+    ba.rows = rows;
+    ba.n_chunks = chunks;
+    ba.dxe = c->dxe;
+    ba.pn = c->pn;
+    ba.part = c->star_part;
+    ba.sums = c->star_sums;
+    ba.dmpart = c->star_dmpart;
+    launch_star_pn_bwd(ba, c->stream);
+
+    float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
+    StarUpdateArgs ua;
+    memset(&ua, 0, sizeof(ua));
+    ua.p = blk;
+    ua.m = slot_m + c->table_floats;
+    ua.v = c->adam_v + c->table_floats;
+    ua.SL = c->SL;
+    ua.L = c->L;
+    ua.n_domain = c->cfg.n_domain;
+    ua.d = domain;
+    ua.slabs = c->slabs;
+    ua.n_groups = groups;
+    ua.slab_ld = c->slab_ld;
+    ua.sums = c->star_sums;
+    ua.dmpart = c->star_dmpart;
+    ua.n_chunks = chunks;
+    ua.opt.optimizer = optimizer;
+    ua.opt.alpha = alpha;
+    ua.opt.omb1 = omb1;
+    ua.opt.omb2 = omb2;
+    ua.opt.eps = c->cfg.adam_eps;
+    ua.opt.two_l2 = 0.f;
+    {
+        Prof p(c, MAMDR_KERNEL_UPDATE);
+        launch_star_update(ua, c->stream);
+    }
+    if (c->cfg.emb_trainable) {
+        EmbStepArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.p = c->params;
+        ea.m = slot_m;
+        ea.v = c->adam_v;
+        ea.dxe = c->dxe;
+        ea.dx_ld = XDIM;
+        ea.dlogit = c->dlogit;
+        ea.rows = rows;
+        ea.opt = ua.opt;
+        ea.t[0].n_rows = c->cfg.n_user;
+        ea.t[0].brow = c->urow;
+        ea.t[0].map = c->map_u;
+        ea.t[0].gbuf = c->gbuf_u;
+        ea.t[0].dx_off = 0;
+        ea.t[1].n_rows = c->cfg.n_item;
+        ea.t[1].brow = c->irow;
+        ea.t[1].map = c->map_i;
+        ea.t[1].gbuf = c->gbuf_i;
+        ea.t[1].dx_off = EMB;
+        launch_emb_reduce(ea, c->stream);
+        {
+            Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
+            launch_emb_sweep(ea, c->stream);
+        }
+    }
+    return MAMDR_OK;
+}
 
 extern "C" {
 
@@ -219,8 +386,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     *out = nullptr;
     if (cfg->abi_version != MAMDR_ABI_VERSION)
         return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
-    if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM)
-        return fail(MAMDR_ENOTBUILT, "tower kind %d is not built yet (the mlp and deepfm towers are)", cfg->tower);
+    if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM && cfg->tower != MAMDR_TOWER_STAR)
+        return fail(MAMDR_EINVAL, "unknown tower kind %d", cfg->tower);
     if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
         return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
                     cfg->emb_dim, cfg->hidden[0], cfg->hidden[1], cfg->hidden[2]);
@@ -243,7 +410,11 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         c->lin_item_off = c->lin_user_off + (((int64_t)cfg->n_user + 3) & ~(int64_t)3);
         c->table_floats = c->lin_item_off + (((int64_t)cfg->n_item + 3) & ~(int64_t)3);
     }
-    c->n_params = c->table_floats + c->L.alloc;
+    c->star = cfg->tower == MAMDR_TOWER_STAR;
+    c->SL = StarLayout::make(cfg->n_domain);
+    c->AL = StarAuxLayout::make(cfg->n_domain);
+    c->n_params = c->table_floats + (c->star ? c->SL.alloc : c->L.alloc);
+    c->n_meta = c->star ? c->table_floats + c->SL.n_meta : c->n_params;
     c->data.resize((size_t)cfg->n_domain * 3);
     c->rows_pad_max = cfg->max_batch;
     if (const char* tt = getenv("MAMDR_TOWER_TILE")) c->tower_tile = atoi(tt);
@@ -273,10 +444,20 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->dz, rp * DZ_LD * sizeof(float));
     ALLOC(c->dlogit, rp * sizeof(float));
     ALLOC(c->w0dom_copy, (size_t)EMB * H1 * sizeof(float));
-    if (cfg->emb_trainable) {
-        ALLOC(c->dxe, rp * 2 * EMB * sizeof(float));
+    if (c->star) {
+        const size_t chunks = (rp + STAR_CHUNK - 1) / STAR_CHUNK;
+        ALLOC(c->eff, (size_t)c->L.alloc * sizeof(float));
+        ALLOC(c->pn, (size_t)PN_WS_FLOATS * sizeof(float));
+        ALLOC(c->star_part, chunks * 2 * XDIM * sizeof(float));
+        ALLOC(c->star_sums, 2 * XDIM * sizeof(float));
+        ALLOC(c->star_dmpart, chunks * EMB * sizeof(float));
+    }
+    if (cfg->emb_trainable || c->star) {
+        ALLOC(c->dxe, rp * (c->star ? XDIM : 2 * EMB) * sizeof(float));
         ALLOC(c->urow, rp * sizeof(int32_t));
         ALLOC(c->irow, rp * sizeof(int32_t));
+    }
+    if (cfg->emb_trainable) {
         ALLOC(c->map_u, (size_t)cfg->n_user * sizeof(int32_t));
         ALLOC(c->map_i, (size_t)cfg->n_item * sizeof(int32_t));
         ALLOC(c->gbuf_u, rp * EMB * sizeof(float));
@@ -320,7 +501,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->fmq, c->glin_u, c->glin_i, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -329,6 +510,16 @@ int mamdr_destroy(mamdr_ctx* c) {
 }
 
 int64_t mamdr_param_count(const mamdr_ctx* c) { return c ? c->n_params : 0; }
+int64_t mamdr_meta_count(const mamdr_ctx* c) { return c ? c->n_meta : 0; }
+int64_t mamdr_aux_count(const mamdr_ctx* c) { return (c && c->star) ? c->AL.count : 0; }
+
+int mamdr_bind_aux(mamdr_ctx* c, float* d_aux) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (!c->star) return fail(MAMDR_ESTATE, "this tower has no auxiliary state");
+    if (!d_aux || ((uintptr_t)d_aux & 15)) return fail(MAMDR_EINVAL, "aux pointer null or not 16-byte aligned");
+    c->aux = d_aux;
+    return MAMDR_OK;
+}
 
 int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* count) {
     if (check_ctx(c)) return MAMDR_EINVAL;
@@ -336,6 +527,43 @@ int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* c
     const DenseLayout& L = c->L;
     const int64_t base = c->table_floats;
     int64_t off = 0, cnt = 0;
+    if (c->star) {
+        const StarLayout& S = c->SL;
+        const int64_t D = c->cfg.n_domain;
+        const bool tr = c->cfg.emb_trainable != 0;
+        if (seg >= MAMDR_SEG_STAR_WS0 && seg <= MAMDR_SEG_STAR_WS2) {
+            off = base + S.ws[seg - MAMDR_SEG_STAR_WS0]; cnt = StarLayout::ksize(seg - MAMDR_SEG_STAR_WS0);
+        } else if (seg >= MAMDR_SEG_STAR_BS0 && seg <= MAMDR_SEG_STAR_BS2) {
+            off = base + S.bs[seg - MAMDR_SEG_STAR_BS0]; cnt = StarLayout::bsize(seg - MAMDR_SEG_STAR_BS0);
+        } else if (seg >= MAMDR_SEG_STAR_WD0 && seg <= MAMDR_SEG_STAR_WD2) {
+            off = base + S.wd[seg - MAMDR_SEG_STAR_WD0]; cnt = D * StarLayout::ksize(seg - MAMDR_SEG_STAR_WD0);
+        } else if (seg >= MAMDR_SEG_STAR_BD0 && seg <= MAMDR_SEG_STAR_BD2) {
+            off = base + S.bd[seg - MAMDR_SEG_STAR_BD0]; cnt = D * StarLayout::bsize(seg - MAMDR_SEG_STAR_BD0);
+        } else {
+            switch (seg) {
+                case MAMDR_SEG_USER_EMB: off = 0; cnt = tr ? (int64_t)c->cfg.n_user * EMB : 0; break;
+                case MAMDR_SEG_ITEM_EMB: off = tr ? (int64_t)c->cfg.n_user * EMB : 0; cnt = tr ? (int64_t)c->cfg.n_item * EMB : 0; break;
+                case MAMDR_SEG_DOMAIN_EMB: off = base + S.dm; cnt = D * EMB; break;
+                case MAMDR_SEG_PN_GAMMA_SHARED: off = base + S.pgs; cnt = XDIM; break;
+                case MAMDR_SEG_PN_BETA_SHARED: off = base + S.pbs; cnt = XDIM; break;
+                case MAMDR_SEG_PN_GAMMA_SPEC: off = base + S.pgd; cnt = D * XDIM; break;
+                case MAMDR_SEG_PN_BETA_SPEC: off = base + S.pbd; cnt = D * XDIM; break;
+                case MAMDR_SEG_WO: off = base + S.wo; cnt = H3; break;
+                case MAMDR_SEG_GB: off = base + S.gb; cnt = 1; break;
+                default:
+                    if (seg < 0 || seg >= MAMDR_SEG_COUNT) return fail(MAMDR_EINVAL, "unknown segment %d", seg);
+                    off = 0; cnt = 0;      // a segment of another tower
+            }
+        }
+        *offset = off;
+        *count = cnt;
+        return MAMDR_OK;
+    }
+    if (seg >= MAMDR_SEG_STAR_WS0 && seg < MAMDR_SEG_COUNT) {      // Star segments are absent from this tower
+        *offset = 0;
+        *count = 0;
+        return MAMDR_OK;
+    }
     switch (seg) {
         case MAMDR_SEG_USER_EMB: off = 0; cnt = c->cfg.emb_trainable ? (int64_t)c->cfg.n_user * EMB : 0; break;
         case MAMDR_SEG_ITEM_EMB:
@@ -465,13 +693,27 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
 
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
-    const bool may_use4 = !c->cfg.emb_trainable && !c->deepfm && c->tower_tile != 16;
+    const bool may_use4 = !c->cfg.emb_trainable && !c->deepfm && !c->star && c->tower_tile != 16;
     if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
 
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
         const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+        if (c->star) {
+            float alpha = lr;
+            if (optimizer == MAMDR_OPT_ADAM) {
+                c->adam_t += 1;
+                c->b1p = c->b1p * c->cfg.adam_beta1;
+                c->b2p = c->b2p * c->cfg.adam_beta2;
+                alpha = lr * sqrtf(1.0f - c->b2p) / (1.0f - c->b1p);
+            }
+            const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, alpha, omb1, omb2,
+                                           d_loss_out ? d_loss_out + s : nullptr);
+            if (rc) return rc;
+            c->global_step += 1;
+            continue;
+        }
 
         TowerArgs ta;
         fill_tower_common(c, *d, ta);
@@ -490,6 +732,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ta.dlogit = c->dlogit;
         ta.domrow = c->domrow;
         ta.dxe = c->dxe;
+        ta.dx_ld = 2 * EMB;
         ta.urow = c->urow;
         ta.irow = c->irow;
         ta.map_u = c->map_u;
@@ -602,6 +845,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             ea.m = slot_m;
             ea.v = c->adam_v;
             ea.dxe = c->dxe;
+            ea.dx_ld = 2 * EMB;
             ea.dlogit = c->dlogit;
             ea.rows = rows;
             ea.two_l2_lin = 2.0f * c->cfg.l2_linear;
@@ -665,6 +909,24 @@ int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float*
     ta.loss_part = c->eval_part;
     ta.hist = d_hist;
     ta.pred_out = d_pred_out;
+    if (c->star) {
+        // inference: domain `domain`'s moving statistics and merged kernels (partitioned_norm.py:143-165)
+        StarPrepArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.blk = c->params + c->table_floats;
+        pa.SL = c->SL;
+        pa.L = c->L;
+        pa.n_domain = c->cfg.n_domain;
+        pa.d = domain;
+        pa.eff = c->eff;
+        pa.pn = c->pn;
+        pa.aux = c->aux;
+        pa.AL = c->AL;
+        pa.train = 0;
+        launch_star_prep(pa, c->stream);
+        ta.dense = c->eff;
+        ta.pn_aff = c->pn;
+    }
     {
         Prof p(c, MAMDR_KERNEL_EVAL);
         launch_tower_eval(ta, c->stream);
@@ -683,8 +945,8 @@ int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float*
     fa.n_rows = d->n;
     fa.batch = batch;
     fa.dense = c->params + c->table_floats;
-    fa.dm_count = c->cfg.n_domain * EMB;
-    fa.l2_emb = c->cfg.l2_emb;
+    fa.dm_count = c->star ? 0 : c->cfg.n_domain * EMB;
+    fa.l2_emb = c->star ? 0.f : c->cfg.l2_emb;
     fa.frozen_sumsq = c->frozen_sumsq;
     fa.ld_off = c->L.ld;
     fa.ld_count = c->L.ld_count;

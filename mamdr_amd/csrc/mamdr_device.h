@@ -47,6 +47,56 @@ struct DenseLayout {
     }
 };
 
+// Star tower (model_zoo/Star): block of the flat trainable vector behind the (optional) tables.
+// The meta parameters of the reference's name filter ("emb", "kernel_shared", "bias_shared",
+// config/Taobao-10/star_taobao.json:37-41) come first, so theta / phi are a prefix of the vector.
+struct StarLayout {
+    int dm, ws[3], bs[3], n_meta;
+    int pgs, pbs, pgd, pbd;        // PartitionedNorm gamma / beta: shared [384], specific [D][384]
+    int wd[3], bd[3];              // specific kernels [D][in*out] and biases [D][out]
+    int wo, gb, count, alloc;
+    __host__ __device__ static int ksize(int l) { return l == 0 ? XDIM * H1 : (l == 1 ? H1 * H2 : H2 * H3); }
+    __host__ __device__ static int bsize(int l) { return l == 0 ? H1 : (l == 1 ? H2 : H3); }
+    __host__ __device__ static StarLayout make(int n_domain) {
+        StarLayout S;
+        int o = 0;
+        S.dm = o; o += n_domain * EMB;
+        for (int l = 0; l < 3; ++l) { S.ws[l] = o; o += ksize(l); }
+        for (int l = 0; l < 3; ++l) { S.bs[l] = o; o += bsize(l); }
+        S.n_meta = o;
+        S.pgs = o; o += XDIM;
+        S.pbs = o; o += XDIM;
+        S.pgd = o; o += n_domain * XDIM;
+        S.pbd = o; o += n_domain * XDIM;
+        for (int l = 0; l < 3; ++l) { S.wd[l] = o; o += n_domain * ksize(l); }
+        for (int l = 0; l < 3; ++l) { S.bd[l] = o; o += n_domain * bsize(l); }
+        S.wo = o; o += H3;
+        S.gb = o; o += 1;
+        S.count = o;
+        S.alloc = (o + 3) & ~3;
+        return S;
+    }
+};
+// non-trainable PartitionedNorm state per domain (partitioned_norm.py:71-87 + the zero-debias slots
+// of TF 1.12's assign_moving_average): [mov_mean | mov_var | biased_mean | biased_var] each [D][384], steps [D]
+struct StarAuxLayout {
+    int mov_mean, mov_var, biased_mean, biased_var, steps, count;
+    __host__ __device__ static StarAuxLayout make(int n_domain) {
+        StarAuxLayout A;
+        A.mov_mean = 0;
+        A.mov_var = n_domain * XDIM;
+        A.biased_mean = 2 * n_domain * XDIM;
+        A.biased_var = 3 * n_domain * XDIM;
+        A.steps = 4 * n_domain * XDIM;
+        A.count = (A.steps + n_domain + 3) & ~3;
+        return A;
+    }
+};
+constexpr float PN_EPS = 1e-3f;
+constexpr float PN_MOMENTUM = 0.99f;
+constexpr int STAR_CHUNK = 16;        // batch rows per partial of the column statistics
+constexpr int PN_WS_FLOATS = 5 * XDIM;   // scale | shift | mean | inv | coef = gamma_eff * inv
+
 // ---- counter-based dropout stream (restated in oracle/rng.py)
 __host__ __device__ inline uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;

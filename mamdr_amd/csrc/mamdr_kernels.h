@@ -46,10 +46,12 @@ struct TowerArgs {
     float* dlogit;             // [rows_pad]
     int32_t* domrow;           // [rows_pad]
     // trainable user / item tables only (null otherwise)
-    float* dxe;                // [rows_pad][256]  d loss / d [user | item] embedding row
+    float* dxe;                // [rows_pad][dx_ld]  d loss / d [user | item (| domain)] embedding row
+    int dx_ld;                 // 256, or 384 for the Star tower
+    const float* pn_aff;       // Star: [scale 384 | shift 384] of PartitionedNorm, null otherwise
     int32_t* urow;             // [rows_pad] user row of each batch position (-1 = padding)
     int32_t* irow;             // [rows_pad]
-    int32_t* map_u;            // [n_user] / [n_item]: atomicMin of the batch position touching the row
+    int32_t* map_u;            // [n_user] / [n_item]: atomicMin of the batch position touching the row (null: frozen tables)
     int32_t* map_i;
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
     // DeepFM: logit += FM second-order term + linear tables
@@ -170,7 +172,8 @@ struct EmbStepArgs {
     float* m;
     float* v;
     EmbTable t[2];             // user, item
-    const float* dxe;          // [rows][256]
+    const float* dxe;          // [rows][dx_ld]
+    int dx_ld;                 // 256, or 384 for the Star tower
     const float* dlogit;       // [rows]
     int rows;                  // batch rows
     float two_l2_lin;
@@ -180,6 +183,53 @@ void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s);
 void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s);
+
+// star_kernels.hip: Star tower = PartitionedNorm + StarFCN (model_zoo/Star).  The step reuses
+// k_tower / k_wgrad on an "effective" dense block (kernel_shared * kernel_specific[d], ...) built per step.
+struct StarPrepArgs {
+    const float* blk;          // Star block of the live weights
+    StarLayout SL;
+    DenseLayout L;             // layout of the effective block
+    int n_domain, d;
+    float* eff;                // effective dense block [L.alloc]
+    float* pn;                 // [PN_WS_FLOATS]
+    const float* part;         // training: [chunks][2][384] chunk mean / M2 of the raw input columns
+    int n_chunks, rows;
+    float* aux;                // moving statistics (read at eval, updated in training)
+    StarAuxLayout AL;
+    int train;
+};
+struct StarPnBwdArgs {
+    const float* user_tab;
+    const float* item_tab;
+    const float* dm_row;       // domain table row d
+    const int32_t* urow;       // [rows] (-1 = padding)
+    const int32_t* irow;
+    int rows, n_chunks;
+    float* dxe;                // in: d loss / d normalised input [rows][384]; out: d loss / d raw input
+    const float* pn;
+    float* part;               // [chunks][2][384]
+    float* sums;               // [2][384] s1 = sum dxn, s2 = sum dxn * xhat
+    float* dmpart;             // [chunks][EMB] column sums of dx[:, 256:384]
+};
+struct StarUpdateArgs {
+    float* p;                  // Star block of weights / Adam m / Adam v (or accumulator)
+    float* m;
+    float* v;
+    StarLayout SL;
+    DenseLayout L;
+    int n_domain, d;
+    const float* slabs;        // k_wgrad output on the effective layout
+    int n_groups, slab_ld;
+    const float* sums;         // PartitionedNorm [2][384]
+    const float* dmpart;
+    int n_chunks;
+    OptArgsLite opt;
+};
+void launch_star_stats(const TowerArgs& a, float* part, hipStream_t s);
+void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
+void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s);
+void launch_star_update(const StarUpdateArgs& a, hipStream_t s);
 
 // outer_kernels.hip (compiled with -ffp-contract=off)
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s);

@@ -1,0 +1,292 @@
+// Star tower: PartitionedNorm + StarFCN around the shared step kernels.
+//
+// Per training step on domain d (model_zoo/Star/star.py:70-97, partitioned_norm.py:102-203,
+// star_fcn.py:105-139):
+//   k_star_stats    per-chunk mean / M2 of the 384 raw input columns of the batch (gathered rows)
+//   k_star_prep     block 0: merges the chunks (Chan) -> batch mean / variance, updates domain d's
+//                   zero-debiased moving statistics, emits the PartitionedNorm affine
+//                   (scale = gamma_s * gamma_d[d] * rsqrt(var + eps), shift = beta_s + beta_d[d] - mean * scale);
+//                   other blocks: effective dense block  K_l = W_shared_l * W_specific_l[d],
+//                   b_l = b_shared_l + b_specific_l[d]  in the layout k_tower / k_wgrad read
+//   k_tower<train, DXW=384>, k_wgrad      (step_kernels.hip) on the effective block
+//   k_star_pnb_*    PartitionedNorm backward through the batch statistics: column sums
+//                   s1 = sum dxn, s2 = sum dxn * xhat, then dx = gamma * inv * (dxn - s1/B - xhat * s2/B)
+//   (k_emb_reduce / k_emb_sweep with trainable tables)
+//   k_star_update   chain rule onto shared / specific tensors + TF1 Adam over EVERY slice (the
+//                   specific tensors of the other domains get zero gradient but still decay and move,
+//                   as tf.train.AdamOptimizer's sparse rule does)
+// Every reduction runs in a fixed order (no float atomics).
+#include "mamdr_kernels.h"
+
+namespace mamdr {
+
+namespace {
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void opt_apply(const OptArgsLite& o, float g, float* p, float* m, float* v, size_t i) {
+    if (o.optimizer == 0) {
+        float mm = m[i], vv = v[i];
+        mm = mm + (g - mm) * o.omb1;
+        vv = vv + (g * g - vv) * o.omb2;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] = p[i] - (mm * o.alpha) / (sqrtf(vv) + o.eps);
+    } else if (o.optimizer == 1) {
+        p[i] = p[i] - g * o.alpha;
+    } else {
+        m[i] = m[i] + g;          // accumulate only: m is the meta-gradient accumulator
+    }
+}
+}  // namespace
+
+// ------------------------------------------------------------------ forward statistics
+// grid = chunks of STAR_CHUNK batch rows, block = 384 threads (one per input column; a row of the
+// batch is three coalesced 512-B table rows)
+__global__ __launch_bounds__(XDIM) void k_star_stats(const TowerArgs a, float* part) {
+    __shared__ int rowi[3 * STAR_CHUNK];
+    const int c = threadIdx.x, ch = blockIdx.x;
+    const int r0 = ch * STAR_CHUNK;
+    const int nb = min(STAR_CHUNK, a.rows - r0);
+    if (c < STAR_CHUNK) {
+        int64_t src = 0;
+        if (c < nb) {
+            const int64_t pos = a.row_base + r0 + c;
+            src = a.perm ? (int64_t)a.perm[pos] : pos;
+            if (src < 0) src = 0;
+            if (src >= a.n_rows_split) src = a.n_rows_split - 1;
+        }
+        rowi[c] = clampi(a.uid[src], 0, a.n_user - 1);
+        rowi[STAR_CHUNK + c] = clampi(a.pid[src], 0, a.n_item - 1);
+        rowi[2 * STAR_CHUNK + c] = clampi(a.dom[src], 0, a.n_domain - 1);
+    }
+    __syncthreads();
+    const int seg = c >> 7, k = c & (EMB - 1);
+    const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
+    float x[STAR_CHUNK];
+#pragma unroll
+    for (int r = 0; r < STAR_CHUNK; ++r) x[r] = base[(size_t)rowi[seg * STAR_CHUNK + r] * EMB + k];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < STAR_CHUNK; ++r) s += (r < nb) ? x[r] : 0.f;
+    const float mean = s / (float)nb;
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < STAR_CHUNK; ++r) {
+        const float dlt = x[r] - mean;
+        m2 += (r < nb) ? dlt * dlt : 0.f;
+    }
+    part[(size_t)ch * 2 * XDIM + c] = mean;
+    part[(size_t)ch * 2 * XDIM + XDIM + c] = m2;
+}
+void launch_star_stats(const TowerArgs& a, float* part, hipStream_t s) {
+    const int chunks = (a.rows + STAR_CHUNK - 1) / STAR_CHUNK;
+    hipLaunchKernelGGL(k_star_stats, dim3(chunks), dim3(XDIM), 0, s, a, part);
+}
+
+// ------------------------------------------------------------------ per-step preparation
+__global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ float step_old;
+        if (tid == 0) step_old = a.aux[a.AL.steps + a.d];
+        __syncthreads();
+        if (tid >= XDIM) return;
+        const int c = tid;
+        float mean, var;
+        if (a.train) {
+            // Chan et al. pairwise merge of the chunk (mean, M2) pairs, chunk order
+            float n = 0.f, M2 = 0.f;
+            mean = 0.f;
+            for (int ch = 0; ch < a.n_chunks; ++ch) {
+                const float nb = (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK);
+                const float mb = a.part[(size_t)ch * 2 * XDIM + c];
+                const float Mb = a.part[(size_t)ch * 2 * XDIM + XDIM + c];
+                const float delta = mb - mean;
+                const float nn = n + nb;
+                mean += delta * (nb / nn);
+                M2 += Mb + delta * delta * (n * nb / nn);
+                n = nn;
+            }
+            var = M2 / (float)a.rows;      // population variance (nn.moments)
+            // assign_moving_average(zero_debias=True): biased += (value - biased) * (1 - momentum);
+            // moving = biased / (1 - momentum^step)
+            const float t = step_old + 1.0f;
+            const float factor = 1.0f - powf(PN_MOMENTUM, t);
+            const float omm = 1.0f - PN_MOMENTUM;
+            const size_t o = (size_t)a.d * XDIM + c;
+            float bm = a.aux[a.AL.biased_mean + o], bv = a.aux[a.AL.biased_var + o];
+            bm += (mean - bm) * omm;
+            bv += (var - bv) * omm;
+            a.aux[a.AL.biased_mean + o] = bm;
+            a.aux[a.AL.biased_var + o] = bv;
+            a.aux[a.AL.mov_mean + o] = bm / factor;
+            a.aux[a.AL.mov_var + o] = bv / factor;
+            if (c == 0) a.aux[a.AL.steps + a.d] = t;
+        } else {
+            mean = a.aux[a.AL.mov_mean + (size_t)a.d * XDIM + c];
+            var = a.aux[a.AL.mov_var + (size_t)a.d * XDIM + c];
+        }
+        const float inv = 1.0f / sqrtf(var + PN_EPS);
+        const float gamma = a.blk[a.SL.pgs + c] * a.blk[a.SL.pgd + a.d * XDIM + c];
+        const float beta = a.blk[a.SL.pbs + c] + a.blk[a.SL.pbd + a.d * XDIM + c];
+        const float scale = __fmul_rn(inv, gamma);
+        a.pn[c] = scale;
+        a.pn[XDIM + c] = __fsub_rn(beta, __fmul_rn(mean, scale));
+        a.pn[2 * XDIM + c] = mean;
+        a.pn[3 * XDIM + c] = inv;
+        a.pn[4 * XDIM + c] = __fmul_rn(gamma, inv);
+        return;
+    }
+    // effective dense block, one element per thread
+    const int e = ((int)blockIdx.x - 1) * 512 + tid;
+    const DenseLayout& L = a.L;
+    if (e >= L.count) return;
+    float v;
+    if (e < L.w0) {
+        v = a.blk[a.SL.dm + e];
+    } else if (e < L.b0) {
+        const int l = e < L.w1 ? 0 : (e < L.w2 ? 1 : 2);
+        const int i = e - (l == 0 ? L.w0 : (l == 1 ? L.w1 : L.w2));
+        v = a.blk[a.SL.ws[l] + i] * a.blk[a.SL.wd[l] + (size_t)a.d * StarLayout::ksize(l) + i];
+    } else if (e < L.wo) {
+        const int l = e < L.b1 ? 0 : (e < L.b2 ? 1 : 2);
+        const int i = e - (l == 0 ? L.b0 : (l == 1 ? L.b1 : L.b2));
+        v = a.blk[a.SL.bs[l] + i] + a.blk[a.SL.bd[l] + a.d * StarLayout::bsize(l) + i];
+    } else if (e < L.gb) {
+        v = a.blk[a.SL.wo + (e - L.wo)];
+    } else {
+        v = a.blk[a.SL.gb];
+    }
+    a.eff[e] = v;
+}
+void launch_star_prep(const StarPrepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_star_prep, dim3(1 + (a.L.count + 511) / 512), dim3(512), 0, s, a);
+}
+
+// ------------------------------------------------------------------ PartitionedNorm backward
+__device__ __forceinline__ float star_xhat(const StarPnBwdArgs& a, int b, int c) {
+    const int seg = c >> 7, k = c & (EMB - 1);
+    const float* row = seg == 0 ? a.user_tab + (size_t)a.urow[b] * EMB
+                                : (seg == 1 ? a.item_tab + (size_t)a.irow[b] * EMB : a.dm_row);
+    return (row[k] - a.pn[2 * XDIM + c]) * a.pn[3 * XDIM + c];
+}
+
+__global__ __launch_bounds__(XDIM) void k_star_pnb_partial(const StarPnBwdArgs a) {
+    const int c = threadIdx.x, ch = blockIdx.x;
+    const int r0 = ch * STAR_CHUNK;
+    const int nb = min(STAR_CHUNK, a.rows - r0);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nb; ++r) {
+        const int b = r0 + r;
+        const float g = a.dxe[(size_t)b * XDIM + c];
+        s1 += g;
+        s2 += g * star_xhat(a, b, c);
+    }
+    a.part[(size_t)ch * 2 * XDIM + c] = s1;
+    a.part[(size_t)ch * 2 * XDIM + XDIM + c] = s2;
+}
+__global__ __launch_bounds__(XDIM) void k_star_pnb_final(const StarPnBwdArgs a) {
+    const int c = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = 0; ch < a.n_chunks; ++ch) {
+        s1 += a.part[(size_t)ch * 2 * XDIM + c];
+        s2 += a.part[(size_t)ch * 2 * XDIM + XDIM + c];
+    }
+    a.sums[c] = s1;
+    a.sums[XDIM + c] = s2;
+}
+__global__ __launch_bounds__(XDIM) void k_star_pnb_apply(const StarPnBwdArgs a) {
+    const int c = threadIdx.x, ch = blockIdx.x;
+    const int r0 = ch * STAR_CHUNK;
+    const int nb = min(STAR_CHUNK, a.rows - r0);
+    const float B = (float)a.rows;
+    const float m1 = a.sums[c] / B, m2 = a.sums[XDIM + c] / B;
+    const float coef = a.pn[4 * XDIM + c];
+    float colsum = 0.f;
+    for (int r = 0; r < nb; ++r) {
+        const int b = r0 + r;
+        const float g = a.dxe[(size_t)b * XDIM + c];
+        const float dx = coef * ((g - m1) - star_xhat(a, b, c) * m2);
+        a.dxe[(size_t)b * XDIM + c] = dx;
+        colsum += dx;
+    }
+    if (c >= 2 * EMB) a.dmpart[(size_t)ch * EMB + (c - 2 * EMB)] = colsum;
+}
+void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_star_pnb_partial, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
+    hipLaunchKernelGGL(k_star_pnb_final, dim3(1), dim3(XDIM), 0, s, a);
+    hipLaunchKernelGGL(k_star_pnb_apply, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
+}
+
+// ------------------------------------------------------------------ chain rule + optimiser
+// One thread per element index of a group; it owns the shared element and the D specific elements
+// at that index, so the products use the pre-update values of both factors.
+__device__ __forceinline__ float slab_sum(const StarUpdateArgs& u, int off) {
+    float g = u.slabs[off];
+    for (int s = 1; s < u.n_groups; ++s) g += u.slabs[(size_t)s * u.slab_ld + off];
+    return g;
+}
+
+__global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
+    const int K0 = XDIM * H1, K1 = H1 * H2, K2 = H2 * H3;
+    const int n_kernel = K0 + K1 + K2, n_bias = H1 + H2 + H3;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    const int D = u.n_domain, d = u.d;
+    if (e < n_kernel) {
+        const int l = e < K0 ? 0 : (e < K0 + K1 ? 1 : 2);
+        const int i = e - (l == 0 ? 0 : (l == 1 ? K0 : K0 + K1));
+        const int ks = StarLayout::ksize(l);
+        const float gK = slab_sum(u, (l == 0 ? u.L.w0 : (l == 1 ? u.L.w1 : u.L.w2)) + i);
+        const size_t si = (size_t)u.SL.ws[l] + i;
+        const float ws = u.p[si];
+        const float wd_live = u.p[(size_t)u.SL.wd[l] + (size_t)d * ks + i];
+        for (int dd = 0; dd < D; ++dd)
+            opt_apply(u.opt, dd == d ? gK * ws : 0.f, u.p, u.m, u.v, (size_t)u.SL.wd[l] + (size_t)dd * ks + i);
+        opt_apply(u.opt, gK * wd_live, u.p, u.m, u.v, si);
+        return;
+    }
+    e -= n_kernel;
+    if (e < n_bias) {
+        const int l = e < H1 ? 0 : (e < H1 + H2 ? 1 : 2);
+        const int i = e - (l == 0 ? 0 : (l == 1 ? H1 : H1 + H2));
+        const int bsz = StarLayout::bsize(l);
+        const float gb = slab_sum(u, (l == 0 ? u.L.b0 : (l == 1 ? u.L.b1 : u.L.b2)) + i);
+        for (int dd = 0; dd < D; ++dd)
+            opt_apply(u.opt, dd == d ? gb : 0.f, u.p, u.m, u.v, (size_t)u.SL.bd[l] + (size_t)dd * bsz + i);
+        opt_apply(u.opt, gb, u.p, u.m, u.v, (size_t)u.SL.bs[l] + i);
+        return;
+    }
+    e -= n_bias;
+    if (e < XDIM) {               // PartitionedNorm gamma / beta
+        const float s1 = u.sums[e], s2 = u.sums[XDIM + e];
+        const float gs = u.p[u.SL.pgs + e];
+        const float gd_live = u.p[u.SL.pgd + d * XDIM + e];
+        for (int dd = 0; dd < D; ++dd) {
+            opt_apply(u.opt, dd == d ? s2 * gs : 0.f, u.p, u.m, u.v, (size_t)u.SL.pgd + dd * XDIM + e);
+            opt_apply(u.opt, dd == d ? s1 : 0.f, u.p, u.m, u.v, (size_t)u.SL.pbd + dd * XDIM + e);
+        }
+        opt_apply(u.opt, s2 * gd_live, u.p, u.m, u.v, (size_t)u.SL.pgs + e);
+        opt_apply(u.opt, s1, u.p, u.m, u.v, (size_t)u.SL.pbs + e);
+        return;
+    }
+    e -= XDIM;
+    if (e < H3 + 1) {             // output unit
+        const float g = slab_sum(u, e < H3 ? u.L.wo + e : u.L.gb);
+        opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)(e < H3 ? u.SL.wo + e : u.SL.gb));
+        return;
+    }
+    e -= H3 + 1;
+    if (e < D * EMB) {            // domain table: only row d is touched (its gradient is PN's rounding residue)
+        const int dd = e / EMB, k = e - dd * EMB;
+        float g = 0.f;
+        if (dd == d)
+            for (int ch = 0; ch < u.n_chunks; ++ch) g += u.dmpart[(size_t)ch * EMB + k];
+        opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)u.SL.dm + e);
+    }
+}
+void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
+    const int n = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + a.n_domain * EMB;
+    hipLaunchKernelGGL(k_star_update, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace mamdr

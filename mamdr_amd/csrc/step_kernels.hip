@@ -353,10 +353,19 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
         const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
         v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * TILE_ROWS + row] * EMB + off);
     }
+    // Star: PartitionedNorm folded into the gather as a per-column affine, y = x * scale + shift with
+    // separately rounded multiply and add (nn.batch_normalization, partitioned_norm.py:172-174)
+    const float* aff = a.pn_aff;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int e = tid + TOWER_THREADS * u;
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
+        if (aff) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + c4 * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + XDIM + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = __fadd_rn(__fmul_rn(v[u][k], sc[k]), sh[k]);
+        }
         if (!rowi[3 * TILE_ROWS + row]) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v[u];
         if (gx) *reinterpret_cast<f32x4*>(gx + (size_t)row * gx_ld + c4 * 4) = v[u];
@@ -386,8 +395,12 @@ constexpr int PFB2 = 2, PFB1 = 2, PFB0 = 4;
 // DX: the user / item tables are trainable, so every row also needs d loss / d [user | item]
 // embedding = dz1 . W0[0:256, :]^T (the frozen-table path replaces that contraction by linearity).
 // FM: DeepFM tower: logit += sum_f w_f[id_f] + sum_k (u i + u d + i d)_k.
-template <bool TRAIN, bool DX, bool FM>
+// DXW: width of the input gradient written to a.dxe: 0 none, 256 = [user | item] (trainable tables),
+// 384 = all three fields (Star: PartitionedNorm's backward needs d loss / d normalised input).
+template <bool TRAIN, int DXW, bool FM>
 __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
+    constexpr bool DX = DXW > 0;
+    constexpr int DXN = DX ? DXW : 2 * EMB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     FwdW<H2, H3, PF2, 4> fw2;
     BwdW<H3, H2, H3, PFB2, 8> bw2;
     BwdW<H2, H1, H2, PFB1, 8> bw1;
-    BwdW<H1, 2 * EMB, H1, PFB0, 8> bw0;
+    BwdW<H1, DXN, H1, PFB0, 8> bw0;
     STAMP(0);
     fw0.prefetch(P + a.L.w0, P + a.L.b0);
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
                 if (DX) {
                     a.urow[r0 + i] = valid ? rowi[i] : -1;
                     a.irow[r0 + i] = valid ? rowi[TILE_ROWS + i] : -1;
-                    if (valid) {    // representative of a table row = its smallest batch position (exact)
+                    if (valid && a.map_u) {   // representative of a table row = its smallest batch position (exact)
                         atomicMin(a.map_u + rowi[i], r0 + i);
                         atomicMin(a.map_i + rowi[TILE_ROWS + i], r0 + i);
                     }
@@ -573,8 +586,8 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     STAMP(8);
     if (DX) {
         __syncthreads();
-        float* dxe_t = a.dxe + (size_t)r0 * (2 * EMB);
-        bwd_layer<H1, 2 * EMB, H1, H1_LD>(bw0, P + a.L.w0, smem + DZ1S_OFF, []() {}, [&](int row, int col, float v) {
+        float* dxe_t = a.dxe + (size_t)r0 * DXN;
+        bwd_layer<H1, DXN, H1, H1_LD>(bw0, P + a.L.w0, smem + DZ1S_OFF, []() {}, [&](int row, int col, float v) {
             if (FM) {
                 // d fm / d e_f = sum of the other two fields (x re-read from the activation workspace)
                 const float* xr = acts_t + (size_t)row * ACT_LD;
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
                 const float other = (col < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
                 v = fmaf(rowf[3 * TILE_ROWS + row], other, v);
             }
-            dxe_t[(size_t)row * (2 * EMB) + col] = v;
+            dxe_t[(size_t)row * DXN + col] = v;
         });
     }
     STAMP(9);
@@ -592,21 +605,23 @@ void launch_tower_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
     if (a.deepfm) {
         if (a.dxe)
-            hipLaunchKernelGGL((k_tower<true, true, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+            hipLaunchKernelGGL((k_tower<true, 256, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
         else
-            hipLaunchKernelGGL((k_tower<true, false, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+            hipLaunchKernelGGL((k_tower<true, 0, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+    } else if (a.dxe && a.dx_ld == XDIM) {
+        hipLaunchKernelGGL((k_tower<true, 384, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
     } else if (a.dxe) {
-        hipLaunchKernelGGL((k_tower<true, true, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        hipLaunchKernelGGL((k_tower<true, 256, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
     } else {
-        hipLaunchKernelGGL((k_tower<true, false, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        hipLaunchKernelGGL((k_tower<true, 0, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
     }
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
     if (a.deepfm)
-        hipLaunchKernelGGL((k_tower<false, false, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        hipLaunchKernelGGL((k_tower<false, 0, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
     else
-        hipLaunchKernelGGL((k_tower<false, false, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        hipLaunchKernelGGL((k_tower<false, 0, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
 }
 
 // ------------------------------------------------------------------ standalone gather

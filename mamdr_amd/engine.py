@@ -84,6 +84,8 @@ class TowerEngine(object):
         self.emb_trainable = bool(emb_trainable)
         self.tower = tower
         self.n_params = int(self.lib.mamdr_param_count(self.ctx))
+        # theta / phi vectors cover the META prefix only (all of it except for the Star tower)
+        self.n_meta = int(self.lib.mamdr_meta_count(self.ctx))
         self.segments = {}
         for seg, name in enumerate(L.SEG_NAMES):
             off, cnt = C.c_int64(), C.c_int64()
@@ -95,6 +97,14 @@ class TowerEngine(object):
         self.adam_m = self.new_vector()
         self.adam_v = self.new_vector()
         L.check(self.lib.mamdr_bind_state(self.ctx, _ptr(self.weights), _ptr(self.adam_m), _ptr(self.adam_v)))
+        # non-trainable model state (Star: PartitionedNorm moving statistics, initial mean 0 / variance 1)
+        self.aux = None
+        n_aux = int(self.lib.mamdr_aux_count(self.ctx))
+        if n_aux:
+            self.aux = torch.zeros(n_aux, dtype=torch.float32, device=self.device)
+            dx = self.n_domain * 3 * emb_dim
+            self.aux[dx:2 * dx] = 1.0
+            L.check(self.lib.mamdr_bind_aux(self.ctx, _ptr(self.aux)))
         self.tables = {}
         self.data = {}          # (domain, split) -> dict of device columns
         self._hist = torch.zeros(2 * 501, dtype=torch.int32, device=self.device)
@@ -113,10 +123,22 @@ class TowerEngine(object):
             pass
 
     # ------------------------------------------------------------ flat vectors
-    def new_vector(self, like=None):
+    def new_vector(self, like=None, meta=False):
         if like is not None:
             return like.clone()
-        return torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        return torch.zeros(self.n_meta if meta else self.n_params, dtype=torch.float32, device=self.device)
+
+    def aux_state(self):
+        """Star: {mov_mean, mov_var [D,384], steps [D]} as numpy (partitioned_norm.py:71-87)."""
+        if self.aux is None:
+            return {}
+        h = self.aux.cpu().numpy()
+        dx = self.n_domain * 384
+        return {"mov_mean": h[0:dx].reshape(self.n_domain, 384).copy(),
+                "mov_var": h[dx:2 * dx].reshape(self.n_domain, 384).copy(),
+                "biased_mean": h[2 * dx:3 * dx].reshape(self.n_domain, 384).copy(),
+                "biased_var": h[3 * dx:4 * dx].reshape(self.n_domain, 384).copy(),
+                "steps": h[4 * dx:4 * dx + self.n_domain].copy()}
 
     def pack(self, named):
         """numpy dict {segment name: array} -> flat device vector (padding zero)."""
@@ -133,8 +155,9 @@ class TowerEngine(object):
         return {name: host[off:off + cnt].copy() for name, (off, cnt) in self.segments.items()}
 
     def set_weights(self, vec):
-        """SetVarOp.__call__ (utils/tool.py:36-45): device copy into the live weights."""
-        L.check(self.lib.mamdr_copy(_ptr(self.weights), _ptr(vec), self.n_params, self._s()))
+        """SetVarOp.__call__ (utils/tool.py:36-45): device copy into the live weights.  A vector of
+        meta length assigns the meta prefix only (MAML._set_model_meta_parms, maml.py:181-187)."""
+        L.check(self.lib.mamdr_copy(_ptr(self.weights), _ptr(vec), vec.numel(), self._s()))
 
     def get_weights(self, out=None):
         """K.batch_get_value (maml.py:189-194): snapshot of the live weights."""

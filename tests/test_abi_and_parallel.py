@@ -29,8 +29,9 @@ def test_library_exports_every_declared_symbol():
     h = C.c_void_p()
     assert lib.mamdr_create(C.byref(cfg), None, C.byref(h)) == _lib.EINVAL
     assert b"emb_dim 128" in lib.mamdr_last_error()
-    cfg.emb_dim, cfg.tower = 128, _lib.TOWER_STAR
-    assert lib.mamdr_create(C.byref(cfg), None, C.byref(h)) == _lib.ENOTBUILT
+    cfg.emb_dim, cfg.tower = 128, 7
+    assert lib.mamdr_create(C.byref(cfg), None, C.byref(h)) == _lib.EINVAL
+    assert b"unknown tower kind" in lib.mamdr_last_error()
     with pytest.raises(NotImplementedError):
         _lib.check(_lib.ENOTBUILT)
 

@@ -522,3 +522,105 @@ def test_full_size_properties_taobao10(env):
         outs.append(e2.get_weights().cpu().numpy())
         e2.close()
     assert same_bits(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------ Star tower
+def make_star_problem(env, emb_trainable, scale=0.1, batch=256, seed=11):
+    from oracle import star as ostar
+    engine, synthetic = env
+    g = synthetic.generate("taobao10", batch_size=batch, seed=seed, scale=scale)
+    rs = np.random.RandomState(seed)
+    p = ostar.init_params(rs, g["n_user"], g["n_item"], g["n_domain"])
+    p["user_emb"] = g["tables"]["user_emb"].copy()
+    p["item_emb"] = g["tables"]["item_emb"].copy()
+    # off the special initial values, effective kernels of useful size
+    for n in ("pn_gamma_shared", "pn_gamma_spec"):
+        p[n] = (p[n] + rs.standard_normal(p[n].shape) * 0.2).astype(F32)
+    for n in ("pn_beta_shared", "pn_beta_spec", "bs0", "bs1", "bs2", "bd0", "bd1", "bd2", "gb"):
+        p[n] = (rs.standard_normal(p[n].shape) * 0.05).astype(F32)
+    for l in range(3):
+        p["Wd%d" % l] = (p["Wd%d" % l] * 8).astype(F32)
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=0.0,
+                             emb_trainable=emb_trainable, tower="star")
+    if not emb_trainable:
+        eng.bind_table("user_emb", p["user_emb"])
+        eng.bind_table("item_emb", p["item_emb"])
+    for split in ("train", "val", "test"):
+        for d in range(g["n_domain"]):
+            c = g["data"][split][d]
+            eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
+    eng.set_weights(eng.pack(p))
+    model = ostar.OracleStar({k: v.copy() for k, v in p.items()}, emb_trainable=emb_trainable, lr=1e-3)
+    return g, eng, model
+
+
+@pytest.mark.parametrize("emb_trainable", [True, False])
+def test_star_step_adam_eval(env, emb_trainable):
+    """PartitionedNorm (batch statistics, zero-debiased moving statistics, backward through the statistics)
+    + StarFCN (shared * specific kernels): gradients of every tensor incl. the zero-gradient slices of the
+    other domains, moving statistics, a few Adam steps, inference with the moving statistics."""
+    from oracle import star as ostar
+    g, eng, model = make_star_problem(env, emb_trainable)
+    meta_names, rest_names = ostar.param_names(emb_trainable)
+    assert [n for n in meta_names + rest_names if n not in eng.segments] == []
+    n_meta = sum(eng.segments[n][1] for n in meta_names)
+    assert eng.n_meta == n_meta and max(eng.segments[n][0] + eng.segments[n][1] for n in meta_names) == n_meta
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=4)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_steps = -(-n // 256)
+    for step in (0, n_steps - 1):          # a full batch and the final (partial) batch
+        idx = perm[step * 256:(step + 1) * 256]
+        loss, grads, _, c = ostar.loss_and_grads(model.params, model.state, cols["uid"][idx], cols["pid"][idx],
+                                                 cols["domain"][idx], cols["label"][idx], emb_trainable)
+        ostar.update_moving(model.state, c["d"], c["mean"], c["var"])
+        want = eng.pack(grads).cpu().numpy()
+        w0 = eng.get_weights()
+        loss_t = torch.zeros(1, device=eng.device)
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = (w0 - eng.get_weights()).cpu().numpy()
+        eng.set_weights(w0)
+        for name, (off, cnt) in eng.segments.items():
+            w = want[off:off + cnt]
+            if name == "domain_emb":
+                # constant over a single-domain batch: PartitionedNorm removes it; both sides hold rounding residue
+                assert np.abs(got[off:off + cnt]).max() < 1e-5 and np.abs(w).max() < 1e-5
+                continue
+            # p_old - p_new recovers g only to ~ulp(p): gamma ~ 1, tables / specific kernels up to ~0.8
+            floor = 2e-7 if name.startswith("pn_gamma") else (6e-8 if name in ("user_emb", "item_emb") or
+                                                              name.startswith("Wd") else 3e-8)
+            np.testing.assert_allclose(got[off:off + cnt], w, rtol=5e-4,
+                                       atol=max(4e-6 * max(np.abs(w).max(), 1e-3), floor), err_msg=name)
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+        aux = eng.aux_state()
+        np.testing.assert_allclose(aux["steps"], model.state["steps"])
+        np.testing.assert_allclose(aux["mov_mean"], model.state["mov_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(aux["mov_var"], model.state["mov_var"], rtol=1e-4, atol=1e-7)
+    # zero-gradient slices of the other domains did not move under SGD
+    # a few Adam steps incl. the partial last batch; the other domains' specific tensors stay put (m = v = 0)
+    first = max(0, n_steps - 3)
+    eng.train_steps(d, perm=perm_t, first_step=first, n_steps=n_steps - first, lr=1e-3)
+    for s_ in range(first, n_steps):
+        ii = perm[s_ * 256:(s_ + 1) * 256]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        if name == "domain_emb":
+            continue          # Adam normalises its rounding-residue gradient: not comparable
+        assert_adam_close(got[name], model.params[name], n_steps - first, 1e-3, name)
+    other = (d + 1) % 10
+    assert np.array_equal(got["Wd0"].reshape(10, 384, 256)[other], model.params["Wd0"][other])
+    # inference uses domain d's moving statistics
+    eng.set_weights(eng.pack(model.params))
+    loss_g, auc_g, hist, preds = eng.evaluate(d, "val", want_preds=True)
+    loss_o, preds_o = model.evaluate(g["data"]["val"][d], 256)
+    np.testing.assert_allclose(preds, preds_o, rtol=5e-4, atol=5e-5)
+    assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+    # a domain that never trained evaluates with the initial statistics (mean 0, variance 1)
+    o2 = (d + 2) % 10
+    loss_g2, _, _, preds2 = eng.evaluate(o2, "val", want_preds=True)
+    loss_o2, preds_o2 = model.evaluate(g["data"]["val"][o2], 256)
+    np.testing.assert_allclose(preds2, preds_o2, rtol=5e-4, atol=5e-5)
+    eng.close()
