@@ -22,11 +22,10 @@ def in_name_list(x, name_list):
 
 
 def build_model(config, dataset, engine_factory=None):
-    from .model_zoo import MAML, MAMDR, DeepCTR, DomainNegotiation, Reptile
+    from .model_zoo import MAML, MAMDR, DeepCTR, DomainNegotiation, Reptile, Star
     name = config["model"]["name"]
     if "star" in name:
-        raise NotImplementedError("Star tower (PartitionedNorm + StarFCN, model_zoo/Star) is on the hot-path "
-                                  "list (SURVEY.md section 8 a13) but not built in this round")
+        model = Star(dataset, config, engine_factory)
     elif in_name_list(name, DEEP_CTR_LIST):
         model = DeepCTR(dataset, config, engine_factory)
     elif in_name_list(name, MTL_DEEP_CTR_LIST):

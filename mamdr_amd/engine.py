@@ -128,6 +128,18 @@ class TowerEngine(object):
             return like.clone()
         return torch.zeros(self.n_meta if meta else self.n_params, dtype=torch.float32, device=self.device)
 
+    # Keras variable names of the segments, for the reference's substring filters (maml.py:153-179)
+    KERAS_NAMES = {"Ws0": "kernel_shared_0", "Ws1": "kernel_shared_1", "Ws2": "kernel_shared_2",
+                   "bs0": "bias_shared_0", "bs1": "bias_shared_1", "bs2": "bias_shared_2",
+                   "Wd0": "kernel_specific_0", "Wd1": "kernel_specific_1", "Wd2": "kernel_specific_2",
+                   "bd0": "bias_specific_0", "bd1": "bias_specific_1", "bd2": "bias_specific_2",
+                   "pn_gamma_shared": "gamma_shared", "pn_beta_shared": "beta_shared",
+                   "pn_gamma_spec": "gamma_specific", "pn_beta_spec": "beta_specific",
+                   "wo": "dense/kernel", "gb": "dense/bias"}
+
+    def keras_name(self, segment):
+        return self.KERAS_NAMES.get(segment, segment)
+
     def aux_state(self):
         """Star: {mov_mean, mov_var [D,384], steps [D]} as numpy (partitioned_norm.py:71-87)."""
         if self.aux is None:

@@ -5,3 +5,4 @@ from .maml import MAML  # noqa: F401
 from .reptile import Reptile  # noqa: F401
 from .domain_negotiation import DomainNegotiation  # noqa: F401
 from .mamdr import MAMDR  # noqa: F401
+from .star import Star  # noqa: F401

@@ -132,7 +132,9 @@ class BaseModel(object):
     def save_model(self, path):
         os.makedirs(osp.dirname(path) or ".", exist_ok=True)
         seg = self.model.segments
+        aux = getattr(self.model, "aux", None)      # Star: PartitionedNorm moving statistics
         np.savez(path, weights=self.model.get_weights().cpu().numpy(),
+                 aux=aux.cpu().numpy() if aux is not None else np.zeros(0, np.float32),
                  segment_names=np.array(list(seg.keys())),
                  segment_offsets=np.array([v[0] for v in seg.values()], np.int64),
                  segment_counts=np.array([v[1] for v in seg.values()], np.int64))
@@ -141,6 +143,9 @@ class BaseModel(object):
         import torch
         with np.load(path) as z:
             w = z["weights"]
+            aux = z["aux"] if "aux" in z.files else np.zeros(0, np.float32)
+        if aux.size and getattr(self.model, "aux", None) is not None:
+            self.model.aux.copy_(torch.from_numpy(aux).to(self.model.device))
         if w.shape[0] != self.model.n_params:
             raise ValueError("checkpoint has %d parameters, model has %d" % (w.shape[0], self.model.n_params))
         self.model.set_weights(torch.from_numpy(w).to(self.model.device))

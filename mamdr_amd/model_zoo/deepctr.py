@@ -53,7 +53,7 @@ class DeepCTR(BaseModel):
     def __init__(self, dataset, config, engine_factory=None):
         super(DeepCTR, self).__init__(dataset, config, engine_factory)
 
-    def build_model(self):
+    def tower_kind(self):
         name = self.model_config["name"]
         if "mlp" in name:
             tower = "mlp"
@@ -64,6 +64,10 @@ class DeepCTR(BaseModel):
             tower = "deepfm"
         else:
             raise ValueError("model: {} not found".format(name))
+        return tower
+
+    def build_model(self):
+        tower = self.tower_kind()
         mc, tc = self.model_config, self.train_config
         if not (mc["user_dim"] == mc["item_dim"] == mc["domain_dim"]):
             raise ValueError("user_dim, item_dim and domain_dim must be equal")

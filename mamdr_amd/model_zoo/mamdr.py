@@ -33,13 +33,14 @@ class MAMDR(SpecificBase):
         self.meta_weights = self._get_meta_weights()
         self.domain_weights = {}
         for domain_idx in range(self.n_domain):
-            self.domain_weights[domain_idx] = self.model.pack(self.base_model.draw_initial_tensors())
+            self.domain_weights[domain_idx] = \
+                self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
         self.model.optimizer_reset()
         planner = EpochPlanner(self.build_meta_sequence(), tc["sample_num"], tc["add_query_domain"],
                                tc["shuffle_sequence"], seed=self.dataset.seed)
         planner.rng = self.rng
         batch_variant = "batch" in self.model_config["name"]
-        scratch = self.model.new_vector()
+        scratch = self.model.new_vector(meta=True)
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)

@@ -33,20 +33,26 @@ class MAML(object):
         else:
             chosen = []
             for name in names:
-                hit = [s for s in self.model.segments if name in s]
+                hit = [s for s in self.model.segments if name in self.model.keras_name(s) and s not in chosen]
                 if not hit:
                     raise ValueError("meta parms: {} not found in the model".format(name))
                 chosen += hit
             self.model_meta_parms = chosen
-        if set(self.model_meta_parms) != set(self.model.segments.keys()):
-            raise NotImplementedError("meta_parms subsets (%s) are not built in this round: only ['all']"
-                                      % (self.train_config["meta_parms"],))
+        # The engine lays the flat vector out so that ONE meta set is a prefix of it: everything for the
+        # mlp / deepfm towers, the reference's Star filter (tables, kernel_shared, bias_shared;
+        # config/Taobao-10/star_taobao.json:37-41) for the Star tower.  Other subsets are not built.
+        n_meta = self.model.n_meta
+        prefix = set(s for s, (off, cnt) in self.model.segments.items() if off + cnt <= n_meta)
+        if set(self.model_meta_parms) != prefix:
+            raise NotImplementedError("meta_parms %s select %s; this tower's engine supports exactly %s"
+                                      % (self.train_config["meta_parms"], sorted(self.model_meta_parms),
+                                         sorted(prefix)))
 
     def _set_model_meta_parms(self, meta_weights):
         self.model.set_weights(meta_weights)
 
     def _get_meta_weights(self):
-        return self.model.get_weights()
+        return self.model.get_weights()[:self.model.n_meta].clone()
 
     # ------------------------------------------------------------------ validation
     def val(self):

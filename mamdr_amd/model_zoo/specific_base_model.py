@@ -34,7 +34,7 @@ class SpecificBase(MAML):
         if method not in ("plus", "times"):
             raise ValueError("merged_method must be 'plus' or 'times', not: {}".format(method))
         if out is None:
-            out = self.model.new_vector()
+            out = self.model.new_vector(meta=True)
         self.model.merge(out, shared_weights, specific_weights, method)
         return out
 
@@ -71,7 +71,7 @@ class SpecificBase(MAML):
         else:
             raise ValueError("Mode can be either val or test, not: {}".format(mode))
         domain_loss, domain_auc = {}, {}
-        merged = self.model.new_vector()
+        merged = self.model.new_vector(meta=True)
         for idx in store:
             self._set_model_meta_parms(self._merge_weights(shared, specific[idx], out=merged))
             p_loss, p_auc = self.evaluate_domain(idx, mode)
@@ -81,7 +81,7 @@ class SpecificBase(MAML):
     def separate_train_val_test(self, init_parms=True):
         if init_parms:
             return self.base_model.separate_train_val_test(init_parms=True)
-        merged = self.model.new_vector()
+        merged = self.model.new_vector(meta=True)
 
         def start(d):
             return self._merge_weights(self.best_shared_weights, self.best_domain_weights[d], out=merged)

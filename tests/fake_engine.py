@@ -33,11 +33,15 @@ class FakeEngine(object):
             self.segments[name] = (off, params[name].size)
             off += params[name].size
         self.n_params = off
+        self.n_meta = off
         self.data = {}
         self.calls = []
 
     # flat vectors
-    def new_vector(self, like=None):
+    def keras_name(self, segment):
+        return segment
+
+    def new_vector(self, like=None, meta=False):
         return like.clone() if like is not None else torch.zeros(self.n_params, dtype=torch.float32)
 
     def pack(self, named):

@@ -56,3 +56,37 @@ def test_run_amazon6_deepfm_config_trainable_tables(tmp_path):
     rdir = os.path.join(cfg["train"]["result_save_path"], cfg["model"]["name"], "Amazon", "split_by_category_6")
     z = np.load(os.path.join(rdir, os.listdir(rdir)[0], "model_parameters.npz"))
     assert np.isfinite(z["weights"]).all() and z["weights"].shape[0] > 128 * 1000
+
+
+@pytest.mark.parametrize("name,trainable", [("star", False), ("star_meta_mamdr_finetune", False),
+                                            ("star_meta_domain_negotiation", True)])
+def test_run_star_configs_on_gpu(tmp_path, name, trainable):
+    """Star tower (PartitionedNorm + StarFCN) through run.py's entry: plain alternate training, MAMDR over
+    the name-filtered meta parameters (theta / phi = tables, shared kernels, shared biases) + finetune,
+    and DN with trainable tables."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import cli
+    with open(os.path.join(ROOT, "config", "Taobao-10", "star_taobao.json")) as f:
+        cfg = json.load(f)
+    cfg["model"]["name"] = name
+    cfg["train"].update(epoch=3, patience=1, sample_num=2, meta_learning_rate=0.5, emb_trainable=trainable,
+                        load_pretrain_emb=not trainable,
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
+    avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg)
+    assert len(domain_auc) == 10 and np.isfinite(avg_loss)
+    if not trainable:
+        assert avg_auc > 0.6, (name, avg_auc)      # pretrained tables: the tower learns the planted signal
+    rdir = os.path.join(cfg["train"]["result_save_path"], name, "Taobao", "split_by_theme_10")
+    z = np.load(os.path.join(rdir, os.listdir(rdir)[0], "model_parameters.npz"))
+    assert np.isfinite(z["weights"]).all() and z["aux"].shape[0] == 4 * 10 * 384 + 12
+    assert (z["aux"][4 * 10 * 384:4 * 10 * 384 + 10] > 0).all()      # every domain's moving statistics were updated
+
+
+def test_amazon13_star_config_parses_and_selects_meta_prefix():
+    """BASELINE config 5 file: star_meta_mamdr, bs 8192, trainable tables, the reference's meta filter."""
+    with open(os.path.join(ROOT, "config", "Amazon_13", "star_DN+DR.json")) as f:
+        cfg = json.load(f)
+    assert cfg["model"]["name"] == "star_meta_mamdr" and cfg["dataset"]["batch_size"] == 8192
+    assert cfg["train"]["meta_parms"] == ["emb", "kernel_shared", "bias_shared"] and cfg["train"]["emb_trainable"]
