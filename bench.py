@@ -50,6 +50,10 @@ WORKLOADS = {
                     name="deepfm_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
                          "2% of the rows per epoch)"),
 }
+# (BASELINE.json configs[4]: Star tower under MAMDR, theta / phi over the tables + shared kernels / biases)
+WORKLOADS["amazon13"] = dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", row_scale=0.02,
+                             tower="star", name="star_meta_mamdr Amazon-13 bs=8192 (PartitionedNorm + StarFCN, "
+                                                "trainable tables, full-size tables, 2% of the rows per epoch)")
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
 
@@ -93,8 +97,12 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
     if params is None:
         params = init_params(g)
         params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
-    model = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
-                               lr=TRAIN["learning_rate"], tower=tower)
+    if tower == "star":
+        from oracle import star as ostar
+        model = ostar.OracleStar(params, emb_trainable=emb_trainable, lr=TRAIN["learning_rate"])
+    else:
+        model = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
+                                   lr=TRAIN["learning_rate"], tower=tower)
     d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     cols = g["data"]["train"][d]
     n = cols["uid"].shape[0]
@@ -161,6 +169,11 @@ def main():
     eng = setup_engine(g, batch, trainable, tower)
 
     def full_params(seed=1024):
+        if tower == "star":      # Keras defaults of the Star layers (mamdr_amd/model_zoo/star.py)
+            from mamdr_amd.model_zoo.star import initial_tensors
+            return initial_tensors(np.random.RandomState(seed), g["n_user"], g["n_item"], D, 128, (256, 128, 64),
+                                   None if trainable else g["tables"]["user_emb"],
+                                   None if trainable else g["tables"]["item_emb"])
         p = init_params(g, seed)
         if trainable:      # Amazon: no pretraining, N(0, 1e-4^2) tables (deepctr.py:115 SparseFeat default)
             rs_ = np.random.RandomState(seed + 7)
@@ -169,12 +182,16 @@ def main():
         return p
     sizes = [eng.n_rows(d, "train") for d in range(D)]
     steps_per_domain = [-(-n // batch) for n in sizes]
-    theta = eng.pack(full_params())
+    full0 = eng.pack(full_params())
+    eng.set_weights(full0)                 # tensors outside theta (Star: PN, specific kernels, output unit)
+    theta = full0[:eng.n_meta].clone()
+    del full0
     owner = parallel.lpt_partition(sizes, world)
     # phi_d starts as a second random init of the whole model (mamdr.py:31-33)
     wrapper = wl.get("wrapper", "mamdr")
-    phis = {d: eng.pack(full_params(seed=2000 + d)) for d in range(D) if owner[d] == rank} if wrapper == "mamdr" else {}
-    bufs = {"delta": eng.new_vector(), "zero": eng.new_vector(), "merged": eng.new_vector()}
+    phis = {d: eng.pack(full_params(seed=2000 + d))[:eng.n_meta].clone() for d in range(D) if owner[d] == rank} \
+        if wrapper == "mamdr" else {}
+    bufs = {"delta": eng.new_vector(meta=True), "zero": eng.new_vector(meta=True), "merged": eng.new_vector(meta=True)}
     planner = mplan.EpochPlanner(range(D), TRAIN["sample_num"], TRAIN["add_query_domain"], True, TRAIN["seed"])
     shuffler = mplan.PassShuffler(sizes, TRAIN["shuffle_buffer_size"], TRAIN["seed"] + rank)
 
@@ -249,8 +266,10 @@ def main():
         use4 = (not trainable) and batch <= 2048 and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
         fm = ", true>" if tower == "deepfm" else ", false>"
         use4 = use4 and tower == "mlp"
-        roofline = finish_roofline("k_tower4" if use4 else ("k_tower<true, true" if trainable else "k_tower<true, false") + fm,
-                                   roofline_ms, cnt, prof_rows)
+        kname = "k_tower4" if use4 else ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
+        if tower == "star":
+            kname = "k_tower<true, 384, false>"
+        roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows)
         # gather kernel on a pass-sized batch (largest domain, shuffled order)
         dbig = max(range(D), key=lambda k: sizes[k])
         perm = torch.from_numpy(shuffler(dbig)).to(eng.device)

@@ -4,7 +4,8 @@
 // gradients PLUS the dense regulariser term 2*l2*W on every row, and tf.train.AdamOptimizer
 // updates every element every step.  Per step, for both tables at once:
 //   (k_tower)     map[row] = min batch position touching the row          (integer atomicMin: exact)
-//   k_emb_reduce  the representative position gathers the positions of its row in ascending order
+//   k_emb_flag    positions that are not their row's representative flag the representative
+//   k_emb_reduce  a flagged representative gathers the positions of its row in ascending order
 //                 (parallel compare + prefix sum) and sums their gradients in that order
 //                 -> bitwise reproducible, no float atomics
 //   k_emb_sweep   HBM-bound pass over both tables: g = 2 l2 p (+ gbuf[map[row]]), Adam / SGD /
@@ -24,7 +25,18 @@ void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_fill, dim3(blocks), dim3(256), 0, s, map, n, EMB_UNTOUCHED);
 }
 
-// One 128-thread workgroup per (batch position, table); only representatives do work.
+__global__ __launch_bounds__(256) void k_emb_flag(const EmbStepArgs a) {
+    const EmbTable& T = a.t[blockIdx.y];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.rows) return;
+    const int r = T.brow[b];
+    if (r < 0) return;
+    const int rep = T.map[r];
+    if (rep != b) T.hasdup[rep] = 1;           // same value from every writer
+}
+
+// One 128-thread workgroup per (batch position, table); only representatives do work, and only those
+// whose row occurs more than once in the batch scan the batch (O(B/128) per such row).
 // Thread t checks the contiguous positions [t*per, (t+1)*per); an exclusive prefix sum of the match
 // counts (wave shuffles + one LDS hand-over between the two waves) places the matches in ascending
 // order in `list`, then thread c sums column c of the listed positions in that order.
@@ -35,15 +47,17 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int r = T.brow[b];
     if (r < 0 || T.map[r] != b) return;        // uniform over the workgroup
-    const int per = (a.rows + EMB - 1) / EMB;
-    const int p0 = max(t * per, b + 1), p1 = min((t + 1) * per, a.rows);   // b is the minimum position
-    int cnt = 0;
-    for (int i = p0; i < p1; ++i) cnt += (T.brow[i] == r) ? 1 : 0;
-    if (__syncthreads_count(cnt) == 0) {       // the common case: no other position shares the row
+    if (!T.hasdup[b]) {                        // the common case: no other position shares the row
         T.gbuf[(size_t)b * EMB + t] = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
         if (T.lin_p && t == 0) T.glin[b] = a.dlogit[b];
         return;
     }
+    const int per = (a.rows + EMB - 1) / EMB;
+    const int p0 = max(t * per, b + 1), p1 = min((t + 1) * per, a.rows);   // b is the minimum position
+    int cnt = 0;
+    for (int i = p0; i < p1; ++i) cnt += (T.brow[i] == r) ? 1 : 0;
+    __syncthreads();                           // every thread has read the flag
+    if (t == 0) T.hasdup[b] = 0;               // reset for the next step
     int incl = cnt;
     const int lane = t & 63;
 #pragma unroll
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) {
 }
 
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_flag, dim3((a.rows + 255) / 256, 2), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_emb_reduce, dim3(a.rows, 2), dim3(EMB), (size_t)a.rows * sizeof(int32_t), s, a);
 }
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s) {

@@ -66,7 +66,7 @@ struct mamdr_ctx {
     float* eff = nullptr;           // Star: effective dense block of the step's domain
     float* pn = nullptr;            // Star: [PN_WS_FLOATS]
     float* star_part = nullptr;     // Star: [chunks][2][384] partials (forward statistics, then backward sums)
-    float* star_sums = nullptr;     // Star: [2][384]
+    float* star_sums = nullptr;     // Star: [2][384] PN sums + [128] domain-row gradient
     float* star_dmpart = nullptr;   // Star: [chunks][EMB]
     int64_t lin_user_off = 0;   // DeepFM + trainable tables: 1-d linear tables behind the embedding tables
     int64_t lin_item_off = 0;
@@ -99,6 +99,8 @@ struct mamdr_ctx {
     int32_t* map_i = nullptr;
     float* gbuf_u = nullptr;
     float* gbuf_i = nullptr;
+    int32_t* hasdup_u = nullptr;
+    int32_t* hasdup_i = nullptr;
     float* fmq = nullptr;           // DeepFM: [rows_pad][EMB]
     float* glin_u = nullptr;        // DeepFM + trainable tables: [rows_pad]
     float* glin_i = nullptr;
@@ -234,7 +236,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ta.rows = rows;
     ta.batch = rows;
     // forward statistics read the raw rows (domain table straight from the flat vector: SL.dm == L.dm == 0)
-    launch_star_stats(ta, c->star_part, c->stream);
+    launch_star_stats(ta, c->star_part, c->aux + c->AL.steps + domain, c->stream);
     StarPrepArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.blk = blk;
@@ -318,6 +320,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ba.part = c->star_part;
     ba.sums = c->star_sums;
     ba.dmpart = c->star_dmpart;
+    ba.dmsum = c->star_sums + 2 * XDIM;
     launch_star_pn_bwd(ba, c->stream);
 
     float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
@@ -334,8 +337,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ua.n_groups = groups;
     ua.slab_ld = c->slab_ld;
     ua.sums = c->star_sums;
-    ua.dmpart = c->star_dmpart;
-    ua.n_chunks = chunks;
+    ua.dmsum = c->star_sums + 2 * XDIM;
     ua.opt.optimizer = optimizer;
     ua.opt.alpha = alpha;
     ua.opt.omb1 = omb1;
@@ -361,11 +363,13 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
         ea.t[0].brow = c->urow;
         ea.t[0].map = c->map_u;
         ea.t[0].gbuf = c->gbuf_u;
+        ea.t[0].hasdup = c->hasdup_u;
         ea.t[0].dx_off = 0;
         ea.t[1].n_rows = c->cfg.n_item;
         ea.t[1].brow = c->irow;
         ea.t[1].map = c->map_i;
         ea.t[1].gbuf = c->gbuf_i;
+        ea.t[1].hasdup = c->hasdup_i;
         ea.t[1].dx_off = EMB;
         launch_emb_reduce(ea, c->stream);
         {
@@ -449,7 +453,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->eff, (size_t)c->L.alloc * sizeof(float));
         ALLOC(c->pn, (size_t)PN_WS_FLOATS * sizeof(float));
         ALLOC(c->star_part, chunks * 2 * XDIM * sizeof(float));
-        ALLOC(c->star_sums, 2 * XDIM * sizeof(float));
+        ALLOC(c->star_sums, (2 * XDIM + EMB) * sizeof(float));
         ALLOC(c->star_dmpart, chunks * EMB * sizeof(float));
     }
     if (cfg->emb_trainable || c->star) {
@@ -462,6 +466,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->map_i, (size_t)cfg->n_item * sizeof(int32_t));
         ALLOC(c->gbuf_u, rp * EMB * sizeof(float));
         ALLOC(c->gbuf_i, rp * EMB * sizeof(float));
+        ALLOC(c->hasdup_u, rp * sizeof(int32_t));
+        ALLOC(c->hasdup_i, rp * sizeof(int32_t));
         if (c->deepfm) {
             ALLOC(c->glin_u, rp * sizeof(float));
             ALLOC(c->glin_i, rp * sizeof(float));
@@ -480,6 +486,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     hipError_t e = hipMemsetAsync(c->slabs, 0, (size_t)c->max_groups * c->slab_ld * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->frozen_sumsq, 0, 4 * sizeof(float), c->stream);
     if (cfg->emb_trainable) {
+        if (e == hipSuccess) e = hipMemsetAsync(c->hasdup_u, 0, rp * sizeof(int32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->hasdup_i, 0, rp * sizeof(int32_t), c->stream);
         launch_emb_map_init(c->map_u, cfg->n_user, c->stream);
         launch_emb_map_init(c->map_i, cfg->n_item, c->stream);
     }
@@ -501,7 +509,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -861,11 +869,13 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             tu.brow = c->urow;
             tu.map = c->map_u;
             tu.gbuf = c->gbuf_u;
+            tu.hasdup = c->hasdup_u;
             tu.dx_off = 0;
             ti.n_rows = c->cfg.n_item;
             ti.brow = c->irow;
             ti.map = c->map_i;
             ti.gbuf = c->gbuf_i;
+            ti.hasdup = c->hasdup_i;
             ti.dx_off = EMB;
             if (c->deepfm) {
                 tu.lin_p = c->params + c->lin_user_off;

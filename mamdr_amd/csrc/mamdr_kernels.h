@@ -160,6 +160,7 @@ struct EmbTable {
     const int32_t* brow;       // [rows] table row of each batch position (-1 = padding)
     int32_t* map;              // [n_rows] first batch position touching the row, EMB_UNTOUCHED otherwise (set by k_tower)
     float* gbuf;               // [rows][EMB] summed row gradients, indexed by representative position
+    int32_t* hasdup;           // [rows] 1 if the representative's row occurs again in the batch (self-resetting)
     int dx_off;                // 0 = user slice of dxe, EMB = item slice
     // DeepFM 1-d linear table of the same feature (null otherwise): gradient = scatter-add of dlogit
     float* lin_p;
@@ -211,6 +212,7 @@ struct StarPnBwdArgs {
     float* part;               // [chunks][2][384]
     float* sums;               // [2][384] s1 = sum dxn, s2 = sum dxn * xhat
     float* dmpart;             // [chunks][EMB] column sums of dx[:, 256:384]
+    float* dmsum;              // [EMB] their total
 };
 struct StarUpdateArgs {
     float* p;                  // Star block of weights / Adam m / Adam v (or accumulator)
@@ -222,11 +224,10 @@ struct StarUpdateArgs {
     const float* slabs;        // k_wgrad output on the effective layout
     int n_groups, slab_ld;
     const float* sums;         // PartitionedNorm [2][384]
-    const float* dmpart;
-    int n_chunks;
+    const float* dmsum;        // [EMB] gradient of the domain-table row d
     OptArgsLite opt;
 };
-void launch_star_stats(const TowerArgs& a, float* part, hipStream_t s);
+void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hipStream_t s);
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
 void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s);
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s);

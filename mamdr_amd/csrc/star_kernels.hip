@@ -3,7 +3,7 @@
 // Per training step on domain d (model_zoo/Star/star.py:70-97, partitioned_norm.py:102-203,
 // star_fcn.py:105-139):
 //   k_star_stats    per-chunk mean / M2 of the 384 raw input columns of the batch (gathered rows)
-//   k_star_prep     block 0: merges the chunks (Chan) -> batch mean / variance, updates domain d's
+//   k_star_prep     first 12 blocks: merge the chunks (Chan) -> batch mean / variance, update domain d's
 //                   zero-debiased moving statistics, emits the PartitionedNorm affine
 //                   (scale = gamma_s * gamma_d[d] * rsqrt(var + eps), shift = beta_s + beta_d[d] - mean * scale);
 //                   other blocks: effective dense block  K_l = W_shared_l * W_specific_l[d],
@@ -42,7 +42,7 @@ __device__ __forceinline__ void opt_apply(const OptArgsLite& o, float g, float* 
 // ------------------------------------------------------------------ forward statistics
 // grid = chunks of STAR_CHUNK batch rows, block = 384 threads (one per input column; a row of the
 // batch is three coalesced 512-B table rows)
-__global__ __launch_bounds__(XDIM) void k_star_stats(const TowerArgs a, float* part) {
+__global__ __launch_bounds__(XDIM) void k_star_stats(const TowerArgs a, float* part, float* step_counter) {
     __shared__ int rowi[3 * STAR_CHUNK];
     const int c = threadIdx.x, ch = blockIdx.x;
     const int r0 = ch * STAR_CHUNK;
@@ -77,27 +77,32 @@ __global__ __launch_bounds__(XDIM) void k_star_stats(const TowerArgs a, float* p
     }
     part[(size_t)ch * 2 * XDIM + c] = mean;
     part[(size_t)ch * 2 * XDIM + XDIM + c] = m2;
+    // local step of domain d's moving averages: bumped here so that every block of k_star_prep reads
+    // the same, final value
+    if (ch == 0 && c == 0) *step_counter += 1.0f;
 }
-void launch_star_stats(const TowerArgs& a, float* part, hipStream_t s) {
+void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hipStream_t s) {
     const int chunks = (a.rows + STAR_CHUNK - 1) / STAR_CHUNK;
-    hipLaunchKernelGGL(k_star_stats, dim3(chunks), dim3(XDIM), 0, s, a, part);
+    hipLaunchKernelGGL(k_star_stats, dim3(chunks), dim3(XDIM), 0, s, a, part, step_counter);
 }
 
 // ------------------------------------------------------------------ per-step preparation
+constexpr int PN_COLS = 32;                    // columns per finalize block
+constexpr int PN_LANES = 16;                   // chunk lanes per column (PN_COLS * PN_LANES = 512 threads)
+constexpr int PN_BLOCKS = XDIM / PN_COLS;      // 12
+
 __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0) {
-        __shared__ float step_old;
-        if (tid == 0) step_old = a.aux[a.AL.steps + a.d];
-        __syncthreads();
-        if (tid >= XDIM) return;
-        const int c = tid;
-        float mean, var;
+    if ((int)blockIdx.x < PN_BLOCKS) {
+        // thread (column cl, lane j) merges chunks j, j + 16, ... (Chan et al.), then the 16 lanes of a
+        // column are merged in lane order by lane 0 -- a fixed order for every batch size
+        __shared__ float sh_n[PN_LANES][PN_COLS], sh_mean[PN_LANES][PN_COLS], sh_m2[PN_LANES][PN_COLS];
+        const int cl = tid & (PN_COLS - 1), j = tid / PN_COLS;
+        const int c = blockIdx.x * PN_COLS + cl;
+        float mean = 0.f, var = 1.f;
         if (a.train) {
-            // Chan et al. pairwise merge of the chunk (mean, M2) pairs, chunk order
             float n = 0.f, M2 = 0.f;
-            mean = 0.f;
-            for (int ch = 0; ch < a.n_chunks; ++ch) {
+            for (int ch = j; ch < a.n_chunks; ch += PN_LANES) {
                 const float nb = (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK);
                 const float mb = a.part[(size_t)ch * 2 * XDIM + c];
                 const float Mb = a.part[(size_t)ch * 2 * XDIM + XDIM + c];
@@ -107,10 +112,28 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
                 M2 += Mb + delta * delta * (n * nb / nn);
                 n = nn;
             }
+            sh_n[j][cl] = n;
+            sh_mean[j][cl] = mean;
+            sh_m2[j][cl] = M2;
+        }
+        __syncthreads();
+        if (j != 0) return;
+        if (a.train) {
+            float n = sh_n[0][cl], M2 = sh_m2[0][cl];
+            mean = sh_mean[0][cl];
+            for (int q = 1; q < PN_LANES; ++q) {
+                const float nb = sh_n[q][cl];
+                if (nb == 0.f) continue;
+                const float delta = sh_mean[q][cl] - mean;
+                const float nn = n + nb;
+                mean += delta * (nb / nn);
+                M2 += sh_m2[q][cl] + delta * delta * (n * nb / nn);
+                n = nn;
+            }
             var = M2 / (float)a.rows;      // population variance (nn.moments)
             // assign_moving_average(zero_debias=True): biased += (value - biased) * (1 - momentum);
-            // moving = biased / (1 - momentum^step)
-            const float t = step_old + 1.0f;
+            // moving = biased / (1 - momentum^step); the step was bumped by k_star_stats
+            const float t = a.aux[a.AL.steps + a.d];
             const float factor = 1.0f - powf(PN_MOMENTUM, t);
             const float omm = 1.0f - PN_MOMENTUM;
             const size_t o = (size_t)a.d * XDIM + c;
@@ -121,7 +144,6 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
             a.aux[a.AL.biased_var + o] = bv;
             a.aux[a.AL.mov_mean + o] = bm / factor;
             a.aux[a.AL.mov_var + o] = bv / factor;
-            if (c == 0) a.aux[a.AL.steps + a.d] = t;
         } else {
             mean = a.aux[a.AL.mov_mean + (size_t)a.d * XDIM + c];
             var = a.aux[a.AL.mov_var + (size_t)a.d * XDIM + c];
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
         return;
     }
     // effective dense block, one element per thread
-    const int e = ((int)blockIdx.x - 1) * 512 + tid;
+    const int e = ((int)blockIdx.x - PN_BLOCKS) * 512 + tid;
     const DenseLayout& L = a.L;
     if (e >= L.count) return;
     float v;
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
     a.eff[e] = v;
 }
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_star_prep, dim3(1 + (a.L.count + 511) / 512), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(k_star_prep, dim3(PN_BLOCKS + (a.L.count + 511) / 512), dim3(512), 0, s, a);
 }
 
 // ------------------------------------------------------------------ PartitionedNorm backward
@@ -185,12 +207,22 @@ __global__ __launch_bounds__(XDIM) void k_star_pnb_partial(const StarPnBwdArgs a
     a.part[(size_t)ch * 2 * XDIM + c] = s1;
     a.part[(size_t)ch * 2 * XDIM + XDIM + c] = s2;
 }
-__global__ __launch_bounds__(XDIM) void k_star_pnb_final(const StarPnBwdArgs a) {
-    const int c = threadIdx.x;
+__global__ __launch_bounds__(512) void k_star_pnb_final(const StarPnBwdArgs a) {
+    __shared__ float sh1[PN_LANES][PN_COLS], sh2[PN_LANES][PN_COLS];
+    const int cl = threadIdx.x & (PN_COLS - 1), j = threadIdx.x / PN_COLS;
+    const int c = blockIdx.x * PN_COLS + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int ch = 0; ch < a.n_chunks; ++ch) {
+    for (int ch = j; ch < a.n_chunks; ch += PN_LANES) {
         s1 += a.part[(size_t)ch * 2 * XDIM + c];
         s2 += a.part[(size_t)ch * 2 * XDIM + XDIM + c];
+    }
+    sh1[j][cl] = s1;
+    sh2[j][cl] = s2;
+    __syncthreads();
+    if (j != 0) return;
+    for (int q = 1; q < PN_LANES; ++q) {
+        s1 += sh1[q][cl];
+        s2 += sh2[q][cl];
     }
     a.sums[c] = s1;
     a.sums[XDIM + c] = s2;
@@ -212,81 +244,102 @@ __global__ __launch_bounds__(XDIM) void k_star_pnb_apply(const StarPnBwdArgs a) 
     }
     if (c >= 2 * EMB) a.dmpart[(size_t)ch * EMB + (c - 2 * EMB)] = colsum;
 }
+// column sums of dx[:, 256:384] (the domain-table row gradient) from the per-chunk partials: same
+// column x lane blocking as the other finalizers; result in dmpart[0][:]
+__global__ __launch_bounds__(512) void k_star_dm_final(const StarPnBwdArgs a) {
+    __shared__ float sh[PN_LANES][PN_COLS];
+    const int cl = threadIdx.x & (PN_COLS - 1), j = threadIdx.x / PN_COLS;
+    const int k = blockIdx.x * PN_COLS + cl;
+    float g = 0.f;
+    for (int ch = j; ch < a.n_chunks; ch += PN_LANES) g += a.dmpart[(size_t)ch * EMB + k];
+    sh[j][cl] = g;
+    __syncthreads();            // (also orders the reads of dmpart[0] above before the write below)
+    if (j != 0) return;
+    for (int q = 1; q < PN_LANES; ++q) g += sh[q][cl];
+    a.dmsum[k] = g;
+}
 void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_star_pnb_partial, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
-    hipLaunchKernelGGL(k_star_pnb_final, dim3(1), dim3(XDIM), 0, s, a);
+    hipLaunchKernelGGL(k_star_pnb_final, dim3(PN_BLOCKS), dim3(512), 0, s, a);
     hipLaunchKernelGGL(k_star_pnb_apply, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
+    hipLaunchKernelGGL(k_star_dm_final, dim3(EMB / PN_COLS), dim3(512), 0, s, a);
 }
 
 // ------------------------------------------------------------------ chain rule + optimiser
-// One thread per element index of a group; it owns the shared element and the D specific elements
-// at that index, so the products use the pre-update values of both factors.
 __device__ __forceinline__ float slab_sum(const StarUpdateArgs& u, int off) {
     float g = u.slabs[off];
     for (int s = 1; s < u.n_groups; ++s) g += u.slabs[(size_t)s * u.slab_ld + off];
     return g;
 }
 
+// grid.y = domain slice dd.  The thread of the LIVE slice (dd == d) also owns the shared element, so the
+// products use the pre-update values of both factors; the other slices only decay (zero gradient).
 __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
     const int K0 = XDIM * H1, K1 = H1 * H2, K2 = H2 * H3;
     const int n_kernel = K0 + K1 + K2, n_bias = H1 + H2 + H3;
     int e = blockIdx.x * 256 + threadIdx.x;
-    const int D = u.n_domain, d = u.d;
+    const int d = u.d, dd = blockIdx.y;
+    const bool live = dd == d;
     if (e < n_kernel) {
         const int l = e < K0 ? 0 : (e < K0 + K1 ? 1 : 2);
         const int i = e - (l == 0 ? 0 : (l == 1 ? K0 : K0 + K1));
-        const int ks = StarLayout::ksize(l);
+        const size_t wi = (size_t)u.SL.wd[l] + (size_t)dd * StarLayout::ksize(l) + i;
+        if (!live) {
+            opt_apply(u.opt, 0.f, u.p, u.m, u.v, wi);
+            return;
+        }
         const float gK = slab_sum(u, (l == 0 ? u.L.w0 : (l == 1 ? u.L.w1 : u.L.w2)) + i);
         const size_t si = (size_t)u.SL.ws[l] + i;
-        const float ws = u.p[si];
-        const float wd_live = u.p[(size_t)u.SL.wd[l] + (size_t)d * ks + i];
-        for (int dd = 0; dd < D; ++dd)
-            opt_apply(u.opt, dd == d ? gK * ws : 0.f, u.p, u.m, u.v, (size_t)u.SL.wd[l] + (size_t)dd * ks + i);
-        opt_apply(u.opt, gK * wd_live, u.p, u.m, u.v, si);
+        const float ws = u.p[si], wd = u.p[wi];
+        opt_apply(u.opt, gK * ws, u.p, u.m, u.v, wi);
+        opt_apply(u.opt, gK * wd, u.p, u.m, u.v, si);
         return;
     }
     e -= n_kernel;
     if (e < n_bias) {
         const int l = e < H1 ? 0 : (e < H1 + H2 ? 1 : 2);
         const int i = e - (l == 0 ? 0 : (l == 1 ? H1 : H1 + H2));
-        const int bsz = StarLayout::bsize(l);
+        const size_t bi = (size_t)u.SL.bd[l] + (size_t)dd * StarLayout::bsize(l) + i;
+        if (!live) {
+            opt_apply(u.opt, 0.f, u.p, u.m, u.v, bi);
+            return;
+        }
         const float gb = slab_sum(u, (l == 0 ? u.L.b0 : (l == 1 ? u.L.b1 : u.L.b2)) + i);
-        for (int dd = 0; dd < D; ++dd)
-            opt_apply(u.opt, dd == d ? gb : 0.f, u.p, u.m, u.v, (size_t)u.SL.bd[l] + (size_t)dd * bsz + i);
+        opt_apply(u.opt, gb, u.p, u.m, u.v, bi);
         opt_apply(u.opt, gb, u.p, u.m, u.v, (size_t)u.SL.bs[l] + i);
         return;
     }
     e -= n_bias;
     if (e < XDIM) {               // PartitionedNorm gamma / beta
-        const float s1 = u.sums[e], s2 = u.sums[XDIM + e];
-        const float gs = u.p[u.SL.pgs + e];
-        const float gd_live = u.p[u.SL.pgd + d * XDIM + e];
-        for (int dd = 0; dd < D; ++dd) {
-            opt_apply(u.opt, dd == d ? s2 * gs : 0.f, u.p, u.m, u.v, (size_t)u.SL.pgd + dd * XDIM + e);
-            opt_apply(u.opt, dd == d ? s1 : 0.f, u.p, u.m, u.v, (size_t)u.SL.pbd + dd * XDIM + e);
+        const size_t gi = (size_t)u.SL.pgd + dd * XDIM + e, bi = (size_t)u.SL.pbd + dd * XDIM + e;
+        if (!live) {
+            opt_apply(u.opt, 0.f, u.p, u.m, u.v, gi);
+            opt_apply(u.opt, 0.f, u.p, u.m, u.v, bi);
+            return;
         }
-        opt_apply(u.opt, s2 * gd_live, u.p, u.m, u.v, (size_t)u.SL.pgs + e);
+        const float s1 = u.sums[e], s2 = u.sums[XDIM + e];
+        const float gs = u.p[u.SL.pgs + e], gd = u.p[gi];
+        opt_apply(u.opt, s2 * gs, u.p, u.m, u.v, gi);
+        opt_apply(u.opt, s1, u.p, u.m, u.v, bi);
+        opt_apply(u.opt, s2 * gd, u.p, u.m, u.v, (size_t)u.SL.pgs + e);
         opt_apply(u.opt, s1, u.p, u.m, u.v, (size_t)u.SL.pbs + e);
         return;
     }
     e -= XDIM;
-    if (e < H3 + 1) {             // output unit
+    if (e < H3 + 1) {             // output unit (owned by the live slice's threads)
+        if (!live) return;
         const float g = slab_sum(u, e < H3 ? u.L.wo + e : u.L.gb);
         opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)(e < H3 ? u.SL.wo + e : u.SL.gb));
         return;
     }
     e -= H3 + 1;
-    if (e < D * EMB) {            // domain table: only row d is touched (its gradient is PN's rounding residue)
-        const int dd = e / EMB, k = e - dd * EMB;
-        float g = 0.f;
-        if (dd == d)
-            for (int ch = 0; ch < u.n_chunks; ++ch) g += u.dmpart[(size_t)ch * EMB + k];
-        opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)u.SL.dm + e);
+    if (e < EMB) {                // domain table row dd: only row d is touched (PN's rounding residue)
+        opt_apply(u.opt, live ? u.dmsum[e] : 0.f, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
     }
 }
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
-    const int n = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + a.n_domain * EMB;
-    hipLaunchKernelGGL(k_star_update, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    const int n = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + EMB;
+    hipLaunchKernelGGL(k_star_update, dim3((n + 255) / 256, a.n_domain), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr
