@@ -132,6 +132,15 @@ int mamdr_optimizer_reset(mamdr_ctx* ctx);
  * target of MAMDR_OPT_ACCUMULATE steps.  Replaces `self.accum_grads` (model_zoo/maml.py:202). */
 int mamdr_bind_accumulator(mamdr_ctx* ctx, float* d_acc);
 int64_t mamdr_optimizer_steps(const mamdr_ctx* ctx);
+/* Trainable tables only (no-op otherwise).  tf.train.AdamOptimizer moves every table row every step
+ * (deepctr.py:54-60 with l2_reg_embedding: regulariser gradient + decaying moments).  The library replays
+ * those per-row steps lazily -- bit-identical to the per-step dense update -- so between two calls of
+ * mamdr_train_steps rows that no batch touched may lag.  Call this before READING the bound weights /
+ * Adam slots from outside the library or REPLACING them (K.batch_get_value / SetVarOp, maml.py:181-194;
+ * mamdr_copy / mamdr_interp / ... on the bound vectors).  mamdr_eval_domain, mamdr_gather_rows,
+ * mamdr_optimizer_reset, mamdr_bind_state and SGD / accumulate steps synchronise by themselves.
+ * MAMDR_DENSE_ADAM=1 in the environment keeps the per-step dense sweep instead. */
+int mamdr_sync_tables(mamdr_ctx* ctx);
 
 /* Bind the frozen user / item tables (row-major [rows, emb_dim] fp32).  Replaces
  * DeepCTR.build_emb with a Constant initializer, trainable=False

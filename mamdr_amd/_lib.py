@@ -61,6 +61,7 @@ SIGNATURES = {
     "mamdr_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_optimizer_steps": (_I64, [_VP]),
+    "mamdr_sync_tables": (C.c_int, [_VP]),
     "mamdr_bind_accumulator": (C.c_int, [_VP, _VP]),
     "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
     "mamdr_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),

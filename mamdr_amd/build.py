@@ -15,7 +15,9 @@ BUILD = os.path.join(HERE, "build")
 # (source, extra flags).  outer_kernels must not fuse multiply-adds (bit-exact vs numpy).
 SOURCES = [
     ("step_kernels.hip", []),
-    ("emb_kernels.hip", []),
+    # emb_kernels: the lazy and the dense table updates must round identically -> no implicit fma fusion
+    # (HIP's __fmul_rn / __fadd_rn are plain operators; explicit __fmaf_rn where an fma is wanted)
+    ("emb_kernels.hip", ["-ffp-contract=off"]),
     ("tower4_kernels.hip", []),
     ("star_kernels.hip", []),
     ("outer_kernels.hip", ["-ffp-contract=off"]),
@@ -48,11 +50,16 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+        cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+        # a change of flags rebuilds too: the command line is kept next to the object
+        stamp = o + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_cmd or _stale(o, [s] + headers):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(" ".join(cmd))
     if force or _stale(OUT, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
         if verbose:

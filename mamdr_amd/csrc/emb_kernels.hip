@@ -83,11 +83,18 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     }
 }
 
+// TF1 ApplyAdam on one element with an explicit rounding sequence: the dense sweep, the lazy catch-up,
+// the touched-row update and the flush all go through it, so a row that is advanced lazily ends up with
+// exactly the bits the per-step dense sweep would have produced.
+__device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v, float alpha, float omb1, float omb2,
+                                          float eps) {
+    m = __fmaf_rn(__fsub_rn(g, m), omb1, m);
+    v = __fmaf_rn(__fsub_rn(__fmul_rn(g, g), v), omb2, v);
+    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(m, alpha), __fadd_rn(__fsqrt_rn(v), eps)));
+}
 __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {
     if (o.optimizer == 0) {
-        m = m + (g - m) * o.omb1;
-        v = v + (g * g - v) * o.omb2;
-        p = p - (m * o.alpha) / (sqrtf(v) + o.eps);
+        adam_elem(g, p, m, v, o.alpha, o.omb1, o.omb2, o.eps);
     } else {
         p = p - g * o.alpha;
     }
@@ -112,6 +119,10 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
         const float* gbuf = second ? a.t[1].gbuf : a.t[0].gbuf;
         const int64_t lrow = second ? row - n0 : row;
         const int rep = map[lrow];
+        if (OPT == 0 && c4 == 0) {               // lazy bookkeeping: the row is current at this step
+            int32_t* last = second ? a.t[1].last : a.t[0].last;
+            if (last) last[lrow] = a.t_now;
+        }
         // streaming access: every element is touched exactly once per step, so the loads / stores are
         // marked non-temporal (measured 364 -> 346 us per Amazon-6 sweep)
 #define SW_LD(ptr) __builtin_nontemporal_load(ptr)
@@ -120,9 +131,13 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
         f32x4 m = (f32x4){0.f, 0.f, 0.f, 0.f}, v = m;
         if (OPT != 1) m = SW_LD(reinterpret_cast<const f32x4*>(a.m) + e4);
         if (OPT == 0) v = SW_LD(reinterpret_cast<const f32x4*>(a.v) + e4);
-        f32x4 g = a.opt.two_l2 * p;
+        f32x4 g;       // explicit roundings: the lazy path (k_emb_touch / k_emb_flush) must reproduce these bits
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = __fmul_rn(a.opt.two_l2, p[k]);
         if (rep != EMB_UNTOUCHED) {
-            g += reinterpret_cast<const f32x4*>(gbuf + (size_t)rep * EMB)[c4];
+            const f32x4 gb = reinterpret_cast<const f32x4*>(gbuf + (size_t)rep * EMB)[c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = __fadd_rn(g[k], gb[k]);
             if (reset && c4 == 0) map[lrow] = EMB_UNTOUCHED;
         }
         if (OPT == 2) {
@@ -132,9 +147,9 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
         if (OPT == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = m[k] + (g[k] - m[k]) * a.opt.omb1;
-                v[k] = v[k] + (g[k] * g[k] - v[k]) * a.opt.omb2;
-                p[k] = p[k] - (m[k] * a.opt.alpha) / (sqrtf(v[k]) + a.opt.eps);
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam_elem(g[k], pk, mk, vk, a.opt.alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
             }
             SW_ST(m, reinterpret_cast<f32x4*>(a.m) + e4);
             SW_ST(v, reinterpret_cast<f32x4*>(a.v) + e4);
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) {
         const int rep = map[lrow];
         if (rep != EMB_UNTOUCHED) {
             g += glin[rep];
-            map[lrow] = EMB_UNTOUCHED;
+            if (!a.lin_keep_map) map[lrow] = EMB_UNTOUCHED;
         }
         if (a.opt.optimizer == 2) {
             lin_m[lrow] += g;
@@ -178,6 +193,125 @@ __global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) {
         }
         lin_p[lrow] = p;
     }
+}
+
+// ------------------------------------------------------------------ lazy dense Adam
+// TF1's Adam moves EVERY table row every step (regulariser gradient 2 l2 p, decaying moments), which the
+// dense sweep above pays for with 24 B/element of HBM traffic per step.  The same per-element recurrence
+// can be run late: a row that the batch does not touch is left alone, and when it is needed (touched by a
+// batch, or the weights are read / replaced: mamdr_sync_tables) its missed steps last[row]+1 .. t are replayed
+// in registers with the logged per-step alpha.  Same arithmetic, same order per element -> same bits; the
+// HBM traffic of a step drops from the whole table to the rows of the batch.
+__global__ __launch_bounds__(256) void k_emb_rows(const EmbRowsArgs a) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b == 0) a.alpha_log[a.log_idx] = a.alpha;
+    if (b >= a.rows_pad) return;
+    if (b >= a.rows) {
+        a.urow[b] = -1;
+        a.irow[b] = -1;
+        return;
+    }
+    const int64_t pos = a.row_base + b;
+    int64_t src = a.perm ? (int64_t)a.perm[pos] : pos;
+    if (src < 0) src = 0;
+    if (src >= a.n_rows_split) src = a.n_rows_split - 1;
+    int u = a.uid[src], i = a.pid[src];
+    u = u < 0 ? 0 : (u > a.n_user - 1 ? a.n_user - 1 : u);
+    i = i < 0 ? 0 : (i > a.n_item - 1 ? a.n_item - 1 : i);
+    a.urow[b] = u;
+    a.irow[b] = i;
+    atomicMin(a.map_u + u, b);
+    atomicMin(a.map_i + i, b);
+}
+void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_rows, dim3((a.rows_pad + 255) / 256), dim3(256), 0, s, a);
+}
+
+// 8 batch positions per workgroup, 32 lanes x float4 per 512-B row; only representatives work.
+// FINAL = false: replay the missed steps up to t_now - 1 (before the gather reads the row);
+// FINAL = true: step t_now with the batch gradient, and the row map is released.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_emb_touch(const EmbStepArgs a) {
+    const int b = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
+    if (b >= a.rows) return;
+    const bool second = blockIdx.y != 0;
+    const EmbTable& T = a.t[blockIdx.y];
+    const int r = T.brow[b];
+    if (r < 0 || T.map[r] != b) return;
+    const size_t e4 = ((size_t)(second ? a.t[0].n_rows : 0) + r) * (EMB / 4) + c4;
+    const int last = T.last[r];
+    const int t_prev = a.t_now - 1;
+    if (!FINAL && last >= t_prev) return;
+    f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
+    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
+    f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
+    if (!FINAL) {
+        for (int t = last + 1; t <= t_prev; ++t) {
+            const float alpha = a.alpha_log[t & a.log_mask];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+            }
+        }
+    } else {
+        const f32x4 gb = reinterpret_cast<const f32x4*>(T.gbuf + (size_t)b * EMB)[c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = p[k], mk = m[k], vk = v[k];
+            adam_elem(__fadd_rn(__fmul_rn(a.opt.two_l2, pk), gb[k]), pk, mk, vk, a.opt.alpha, a.opt.omb1, a.opt.omb2,
+                      a.opt.eps);
+            p[k] = pk; m[k] = mk; v[k] = vk;
+        }
+    }
+    reinterpret_cast<f32x4*>(a.p)[e4] = p;
+    reinterpret_cast<f32x4*>(a.m)[e4] = m;
+    reinterpret_cast<f32x4*>(a.v)[e4] = v;
+    if (c4 == 0) {      // (the 32 lanes of the row read last[] / map[] in one instruction above)
+        T.last[r] = FINAL ? a.t_now : t_prev;
+        if (FINAL) T.map[r] = EMB_UNTOUCHED;
+    }
+}
+void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_touch<false>, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
+}
+void launch_emb_apply(const EmbStepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_touch<true>, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
+}
+
+// every row of both tables -> current at t_now (one float4 per thread; rows already current cost one
+// 4-byte read per half wave)
+__global__ __launch_bounds__(256) void k_emb_flush(const EmbStepArgs a) {
+    const int64_t n0 = a.t[0].n_rows;
+    const int64_t n4 = (n0 + a.t[1].n_rows) * (EMB / 4);
+    const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e4 >= n4) return;
+    const int64_t row = e4 >> 5;
+    const bool second = row >= n0;
+    int32_t* lastp = (second ? a.t[1].last : a.t[0].last) + (second ? row - n0 : row);
+    const int last = *lastp;
+    if (last >= a.t_now) return;
+    f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
+    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
+    f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
+    for (int t = last + 1; t <= a.t_now; ++t) {
+        const float alpha = a.alpha_log[t & a.log_mask];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = p[k], mk = m[k], vk = v[k];
+            adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+            p[k] = pk; m[k] = mk; v[k] = vk;
+        }
+    }
+    reinterpret_cast<f32x4*>(a.p)[e4] = p;
+    reinterpret_cast<f32x4*>(a.m)[e4] = m;
+    reinterpret_cast<f32x4*>(a.v)[e4] = v;
+    if ((e4 & 31) == 0) *lastp = a.t_now;
+}
+void launch_emb_flush(const EmbStepArgs& a, hipStream_t s) {
+    const int64_t n4 = (a.t[0].n_rows + a.t[1].n_rows) * (EMB / 4);
+    hipLaunchKernelGGL(k_emb_flush, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s) {

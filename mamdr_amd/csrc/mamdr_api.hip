@@ -101,6 +101,14 @@ struct mamdr_ctx {
     float* gbuf_i = nullptr;
     int32_t* hasdup_u = nullptr;
     int32_t* hasdup_i = nullptr;
+    // lazy dense Adam over the trainable tables (emb_kernels.hip); MAMDR_DENSE_ADAM=1 keeps the per-step sweep
+    bool lazy = false;
+    bool tables_dirty = false;      // some rows lag behind adam_t
+    int32_t* last_u = nullptr;      // [n_user] / [n_item] Adam step each row is current at
+    int32_t* last_i = nullptr;
+    float* alpha_log = nullptr;     // ring of the per-step alpha
+    int log_cap = 1 << 16;
+    int64_t flush_t = 0;            // adam_t of the last flush
     float* fmq = nullptr;           // DeepFM: [rows_pad][EMB]
     float* glin_u = nullptr;        // DeepFM + trainable tables: [rows_pad]
     float* glin_i = nullptr;
@@ -223,6 +231,124 @@ int ready(const mamdr_ctx* c) {
 }  // namespace
 
 
+// ---- trainable user / item tables: shared by the mlp / deepfm and the Star step
+static void fill_emb_args(const mamdr_ctx* c, int32_t optimizer, float alpha, float omb1, float omb2, float two_l2,
+                          int rows, int dx_ld, EmbStepArgs& ea) {
+    memset(&ea, 0, sizeof(ea));
+    float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
+    ea.p = c->params;
+    ea.m = slot_m;
+    ea.v = c->adam_v;
+    ea.dxe = c->dxe;
+    ea.dx_ld = dx_ld;
+    ea.dlogit = c->dlogit;
+    ea.rows = rows;
+    ea.two_l2_lin = 2.0f * c->cfg.l2_linear;
+    ea.opt.optimizer = optimizer;
+    ea.opt.alpha = alpha;
+    ea.opt.omb1 = omb1;
+    ea.opt.omb2 = omb2;
+    ea.opt.eps = c->cfg.adam_eps;
+    ea.opt.two_l2 = two_l2;
+    ea.alpha_log = c->alpha_log;
+    ea.log_mask = c->log_cap - 1;
+    ea.t_now = (int)c->adam_t;
+    EmbTable& tu = ea.t[0];
+    EmbTable& ti = ea.t[1];
+    tu.n_rows = c->cfg.n_user;
+    tu.brow = c->urow;
+    tu.map = c->map_u;
+    tu.gbuf = c->gbuf_u;
+    tu.hasdup = c->hasdup_u;
+    tu.last = c->last_u;
+    tu.dx_off = 0;
+    ti.n_rows = c->cfg.n_item;
+    ti.brow = c->irow;
+    ti.map = c->map_i;
+    ti.gbuf = c->gbuf_i;
+    ti.hasdup = c->hasdup_i;
+    ti.last = c->last_i;
+    ti.dx_off = EMB;
+    if (c->deepfm) {
+        tu.lin_p = c->params + c->lin_user_off;
+        tu.lin_m = slot_m + c->lin_user_off;
+        tu.lin_v = c->adam_v + c->lin_user_off;
+        tu.glin = c->glin_u;
+        ti.lin_p = c->params + c->lin_item_off;
+        ti.lin_m = slot_m + c->lin_item_off;
+        ti.lin_v = c->adam_v + c->lin_item_off;
+        ti.glin = c->glin_i;
+    }
+}
+
+static float table_two_l2(const mamdr_ctx* c) { return c->star ? 0.f : 2.0f * c->cfg.l2_emb; }
+
+// every table row -> current at adam_t (no-op when nothing lags)
+static void sync_tables(mamdr_ctx* c) {
+    if (!c->tables_dirty) return;
+    EmbStepArgs ea;
+    fill_emb_args(c, MAMDR_OPT_ADAM, 0.f, 1.0f - c->cfg.adam_beta1, 1.0f - c->cfg.adam_beta2, table_two_l2(c), 0,
+                  c->star ? XDIM : 2 * EMB, ea);
+    launch_emb_flush(ea, c->stream);
+    c->tables_dirty = false;
+    c->flush_t = c->adam_t;
+}
+
+// lazy mode, before the tower of Adam step adam_t (already incremented): row ids + representatives of the
+// batch, alpha of this step into the ring, rows of the batch brought up to adam_t - 1
+static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm, int64_t row_base, int rows,
+                         int rows_pad, float alpha, float omb1, float omb2) {
+    if (c->adam_t - c->flush_t >= c->log_cap - 2) {       // the ring would wrap over a lagging row's range
+        c->adam_t -= 1;
+        sync_tables(c);
+        c->adam_t += 1;
+    }
+    EmbRowsArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.uid = d.uid;
+    ra.pid = d.pid;
+    ra.perm = d_perm;
+    ra.row_base = row_base;
+    ra.n_rows_split = d.n;
+    ra.rows = rows;
+    ra.rows_pad = rows_pad;
+    ra.n_user = c->cfg.n_user;
+    ra.n_item = c->cfg.n_item;
+    ra.urow = c->urow;
+    ra.irow = c->irow;
+    ra.map_u = c->map_u;
+    ra.map_i = c->map_i;
+    ra.alpha_log = c->alpha_log;
+    ra.log_idx = (int)(c->adam_t & (c->log_cap - 1));
+    ra.alpha = alpha;
+    launch_emb_rows(ra, c->stream);
+    EmbStepArgs ea;
+    fill_emb_args(c, MAMDR_OPT_ADAM, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
+    launch_emb_catchup(ea, c->stream);
+    c->tables_dirty = true;
+}
+
+// after the tower / wgrad: scatter-add of the row gradients and the optimiser on the tables
+static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float omb1, float omb2, int rows) {
+    EmbStepArgs ea;
+    fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
+    launch_emb_reduce(ea, c->stream);
+    if (c->lazy && optimizer == MAMDR_OPT_ADAM) {
+        if (c->deepfm) {
+            ea.lin_keep_map = 1;
+            launch_lin_sweep(ea, c->stream);
+        }
+        Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
+        launch_emb_apply(ea, c->stream);
+        return;
+    }
+    {
+        Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
+        launch_emb_sweep(ea, c->stream);
+    }
+    if (c->deepfm) launch_lin_sweep(ea, c->stream);
+}
+
 // ---- Star tower: one training step on `rows` rows of domain `domain` (star.py:70-97; kernels in star_kernels.hip)
 static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const int32_t* d_perm, int64_t row_base, int rows,
                            int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out) {
@@ -235,6 +361,8 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ta.row_base = row_base;
     ta.rows = rows;
     ta.batch = rows;
+    if (c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM)
+        emb_pre_step(c, d, d_perm, row_base, rows, rows_pad, alpha, omb1, omb2);
     // forward statistics read the raw rows (domain table straight from the flat vector: SL.dm == L.dm == 0)
     launch_star_stats(ta, c->star_part, c->aux + c->AL.steps + domain, c->stream);
     StarPrepArgs pa;
@@ -348,35 +476,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
         Prof p(c, MAMDR_KERNEL_UPDATE);
         launch_star_update(ua, c->stream);
     }
-    if (c->cfg.emb_trainable) {
-        EmbStepArgs ea;
-        memset(&ea, 0, sizeof(ea));
-        ea.p = c->params;
-        ea.m = slot_m;
-        ea.v = c->adam_v;
-        ea.dxe = c->dxe;
-        ea.dx_ld = XDIM;
-        ea.dlogit = c->dlogit;
-        ea.rows = rows;
-        ea.opt = ua.opt;
-        ea.t[0].n_rows = c->cfg.n_user;
-        ea.t[0].brow = c->urow;
-        ea.t[0].map = c->map_u;
-        ea.t[0].gbuf = c->gbuf_u;
-        ea.t[0].hasdup = c->hasdup_u;
-        ea.t[0].dx_off = 0;
-        ea.t[1].n_rows = c->cfg.n_item;
-        ea.t[1].brow = c->irow;
-        ea.t[1].map = c->map_i;
-        ea.t[1].gbuf = c->gbuf_i;
-        ea.t[1].hasdup = c->hasdup_i;
-        ea.t[1].dx_off = EMB;
-        launch_emb_reduce(ea, c->stream);
-        {
-            Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
-            launch_emb_sweep(ea, c->stream);
-        }
-    }
+    if (c->cfg.emb_trainable) emb_post_step(c, optimizer, alpha, omb1, omb2, rows);
     return MAMDR_OK;
 }
 
@@ -468,6 +568,11 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->gbuf_i, rp * EMB * sizeof(float));
         ALLOC(c->hasdup_u, rp * sizeof(int32_t));
         ALLOC(c->hasdup_i, rp * sizeof(int32_t));
+        const char* dense_env = getenv("MAMDR_DENSE_ADAM");
+        c->lazy = !(dense_env && atoi(dense_env) != 0);
+        ALLOC(c->last_u, (size_t)cfg->n_user * sizeof(int32_t));
+        ALLOC(c->last_i, (size_t)cfg->n_item * sizeof(int32_t));
+        ALLOC(c->alpha_log, (size_t)c->log_cap * sizeof(float));
         if (c->deepfm) {
             ALLOC(c->glin_u, rp * sizeof(float));
             ALLOC(c->glin_i, rp * sizeof(float));
@@ -488,6 +593,9 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (cfg->emb_trainable) {
         if (e == hipSuccess) e = hipMemsetAsync(c->hasdup_u, 0, rp * sizeof(int32_t), c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(c->hasdup_i, 0, rp * sizeof(int32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->last_u, 0, (size_t)cfg->n_user * sizeof(int32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->last_i, 0, (size_t)cfg->n_item * sizeof(int32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->alpha_log, 0, (size_t)c->log_cap * sizeof(float), c->stream);
         launch_emb_map_init(c->map_u, cfg->n_user, c->stream);
         launch_emb_map_init(c->map_i, cfg->n_item, c->stream);
     }
@@ -509,7 +617,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             hipEventDestroy(p.a);
             hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -608,6 +716,7 @@ int mamdr_bind_state(mamdr_ctx* c, float* d_params, float* d_adam_m, float* d_ad
     if (!d_params || !d_adam_m || !d_adam_v) return fail(MAMDR_EINVAL, "null state pointer");
     if (((uintptr_t)d_params | (uintptr_t)d_adam_m | (uintptr_t)d_adam_v) & 15)
         return fail(MAMDR_EINVAL, "state pointers must be 16-byte aligned");
+    if (c->params) sync_tables(c);
     c->params = d_params;
     c->adam_m = d_adam_m;
     c->adam_v = d_adam_v;
@@ -617,6 +726,12 @@ int mamdr_bind_state(mamdr_ctx* c, float* d_params, float* d_adam_m, float* d_ad
 int mamdr_optimizer_reset(mamdr_ctx* c) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (!c->adam_m) return fail(MAMDR_ESTATE, "mamdr_bind_state has not been called");
+    sync_tables(c);             // pending moves of the lagging rows belong to the old optimiser state
+    if (c->last_u) {
+        HIP_TRY(hipMemsetAsync(c->last_u, 0, (size_t)c->cfg.n_user * sizeof(int32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->last_i, 0, (size_t)c->cfg.n_item * sizeof(int32_t), c->stream));
+    }
+    c->flush_t = 0;
     HIP_TRY(hipMemsetAsync(c->adam_m, 0, (size_t)c->n_params * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->adam_v, 0, (size_t)c->n_params * sizeof(float), c->stream));
     c->adam_t = 0;
@@ -626,6 +741,13 @@ int mamdr_optimizer_reset(mamdr_ctx* c) {
 }
 
 int64_t mamdr_optimizer_steps(const mamdr_ctx* c) { return c ? c->adam_t : 0; }
+
+int mamdr_sync_tables(mamdr_ctx* c) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    sync_tables(c);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
 
 int mamdr_bind_accumulator(mamdr_ctx* c, float* d_acc) {
     if (check_ctx(c)) return MAMDR_EINVAL;
@@ -698,6 +820,8 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
     const uint32_t drop_thresh = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(int64_t)thr;
     const float keep_scale = (float)(1.0 / (1.0 - (double)rate));
     const float omb1 = 1.0f - c->cfg.adam_beta1, omb2 = 1.0f - c->cfg.adam_beta2;
+    // SGD / accumulate steps update the tables densely: bring every lagging row up to date first
+    if (optimizer != MAMDR_OPT_ADAM) sync_tables(c);
 
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
@@ -708,21 +832,23 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
         const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+        float step_alpha = lr;
+        if (optimizer == MAMDR_OPT_ADAM) {
+            c->adam_t += 1;
+            c->b1p = c->b1p * c->cfg.adam_beta1;
+            c->b2p = c->b2p * c->cfg.adam_beta2;
+            step_alpha = lr * sqrtf(1.0f - c->b2p) / (1.0f - c->b1p);
+        }
         if (c->star) {
-            float alpha = lr;
-            if (optimizer == MAMDR_OPT_ADAM) {
-                c->adam_t += 1;
-                c->b1p = c->b1p * c->cfg.adam_beta1;
-                c->b2p = c->b2p * c->cfg.adam_beta2;
-                alpha = lr * sqrtf(1.0f - c->b2p) / (1.0f - c->b1p);
-            }
-            const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, alpha, omb1, omb2,
+            const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, step_alpha, omb1, omb2,
                                            d_loss_out ? d_loss_out + s : nullptr);
             if (rc) return rc;
             c->global_step += 1;
             continue;
         }
 
+        if (c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM)
+            emb_pre_step(c, *d, d_perm, row_base, rows, rows_pad, step_alpha, omb1, omb2);
         TowerArgs ta;
         fill_tower_common(c, *d, ta);
         ta.perm = d_perm;
@@ -827,14 +953,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         ua.ld_count = c->L.ld_count;
         ua.two_l2_lin = 2.0f * c->cfg.l2_linear;
         ua.optimizer = optimizer;
-        if (optimizer == MAMDR_OPT_ADAM) {
-            c->adam_t += 1;
-            c->b1p = c->b1p * c->cfg.adam_beta1;
-            c->b2p = c->b2p * c->cfg.adam_beta2;
-            ua.alpha = lr * sqrtf(1.0f - c->b2p) / (1.0f - c->b1p);
-        } else {
-            ua.alpha = lr;
-        }
+        ua.alpha = step_alpha;
         ua.omb1 = omb1;
         ua.omb2 = omb2;
         ua.eps = c->cfg.adam_eps;
@@ -845,55 +964,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
             Prof p(c, MAMDR_KERNEL_UPDATE);
             launch_update(ua, c->stream);
         }
-        if (c->cfg.emb_trainable) {
-            EmbStepArgs ea;
-            memset(&ea, 0, sizeof(ea));
-            float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
-            ea.p = c->params;
-            ea.m = slot_m;
-            ea.v = c->adam_v;
-            ea.dxe = c->dxe;
-            ea.dx_ld = 2 * EMB;
-            ea.dlogit = c->dlogit;
-            ea.rows = rows;
-            ea.two_l2_lin = 2.0f * c->cfg.l2_linear;
-            ea.opt.optimizer = ua.optimizer;
-            ea.opt.alpha = ua.alpha;
-            ea.opt.omb1 = ua.omb1;
-            ea.opt.omb2 = ua.omb2;
-            ea.opt.eps = ua.eps;
-            ea.opt.two_l2 = ua.two_l2;
-            EmbTable& tu = ea.t[0];
-            EmbTable& ti = ea.t[1];
-            tu.n_rows = c->cfg.n_user;
-            tu.brow = c->urow;
-            tu.map = c->map_u;
-            tu.gbuf = c->gbuf_u;
-            tu.hasdup = c->hasdup_u;
-            tu.dx_off = 0;
-            ti.n_rows = c->cfg.n_item;
-            ti.brow = c->irow;
-            ti.map = c->map_i;
-            ti.gbuf = c->gbuf_i;
-            ti.hasdup = c->hasdup_i;
-            ti.dx_off = EMB;
-            if (c->deepfm) {
-                tu.lin_p = c->params + c->lin_user_off;
-                tu.lin_m = slot_m + c->lin_user_off;
-                tu.lin_v = c->adam_v + c->lin_user_off;
-                tu.glin = c->glin_u;
-                ti.lin_p = c->params + c->lin_item_off;
-                ti.lin_m = slot_m + c->lin_item_off;
-                ti.lin_v = c->adam_v + c->lin_item_off;
-                ti.glin = c->glin_i;
-            }
-            launch_emb_reduce(ea, c->stream);
-            {
-                Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
-                launch_emb_sweep(ea, c->stream);
-            }
-            if (c->deepfm) launch_lin_sweep(ea, c->stream);
-        }
+        if (c->cfg.emb_trainable) emb_post_step(c, optimizer, ua.alpha, omb1, omb2, rows);
         c->global_step += 1;
     }
     HIP_TRY(hipGetLastError());
@@ -907,6 +978,7 @@ int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float*
     SplitData* d = split_of(c, domain, split);
     if (!d || !d->uid) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
     if (!d_loss_out || !d_hist) return fail(MAMDR_EINVAL, "null output pointer");
+    sync_tables(c);
     if (batch <= 0 || batch % TILE_ROWS != 0) return fail(MAMDR_EINVAL, "eval batch must be a positive multiple of %d", TILE_ROWS);
     if (d->n <= 0) return fail(MAMDR_EINVAL, "split %d of domain %d is empty", split, domain);
     HIP_TRY(hipMemsetAsync(d_hist, 0, 2 * 501 * sizeof(uint32_t), c->stream));
@@ -976,6 +1048,7 @@ int mamdr_gather_rows(mamdr_ctx* c, int domain, int split, const int32_t* d_perm
     if (!d_out) return fail(MAMDR_EINVAL, "null output pointer");
     if (first_row < 0 || n_rows < 0 || first_row + n_rows > d->n) return fail(MAMDR_EINVAL, "row range outside the split");
     if (n_rows == 0) return MAMDR_OK;
+    sync_tables(c);
     TowerArgs ta;
     fill_tower_common(c, *d, ta);
     ta.perm = d_perm;

@@ -161,6 +161,7 @@ struct EmbTable {
     int32_t* map;              // [n_rows] first batch position touching the row, EMB_UNTOUCHED otherwise (set by k_tower)
     float* gbuf;               // [rows][EMB] summed row gradients, indexed by representative position
     int32_t* hasdup;           // [rows] 1 if the representative's row occurs again in the batch (self-resetting)
+    int32_t* last;             // [n_rows] Adam step up to which the row's (p, m, v) are current (lazy mode), or null
     int dx_off;                // 0 = user slice of dxe, EMB = item slice
     // DeepFM 1-d linear table of the same feature (null otherwise): gradient = scatter-add of dlogit
     float* lin_p;
@@ -179,7 +180,30 @@ struct EmbStepArgs {
     int rows;                  // batch rows
     float two_l2_lin;
     OptArgsLite opt;
+    // lazy dense-Adam bookkeeping (emb_kernels.hip): alpha of every Adam step in a ring, current step
+    const float* alpha_log;
+    int log_mask;
+    int t_now;
+    int lin_keep_map;          // k_lin_sweep leaves the row maps alone (k_emb_apply resets them afterwards)
 };
+struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the batch BEFORE the tower runs
+    const int32_t* uid;
+    const int32_t* pid;
+    const int32_t* perm;
+    int64_t row_base, n_rows_split;
+    int rows, rows_pad, n_user, n_item;
+    int32_t* urow;
+    int32_t* irow;
+    int32_t* map_u;
+    int32_t* map_i;
+    float* alpha_log;
+    int log_idx;
+    float alpha;
+};
+void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s);
+void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s);     // rows of the batch -> current at t_now - 1
+void launch_emb_apply(const EmbStepArgs& a, hipStream_t s);       // step t_now on the rows of the batch
+void launch_emb_flush(const EmbStepArgs& a, hipStream_t s);       // every row -> current at t_now
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s);
 void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s);

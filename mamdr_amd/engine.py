@@ -93,10 +93,10 @@ class TowerEngine(object):
             if cnt.value:
                 self.segments[name] = (off.value, cnt.value)
         # live state: weights + Adam slots (one set for the whole run)
-        self.weights = self.new_vector()
-        self.adam_m = self.new_vector()
-        self.adam_v = self.new_vector()
-        L.check(self.lib.mamdr_bind_state(self.ctx, _ptr(self.weights), _ptr(self.adam_m), _ptr(self.adam_v)))
+        self._weights = self.new_vector()
+        self._adam_m = self.new_vector()
+        self._adam_v = self.new_vector()
+        L.check(self.lib.mamdr_bind_state(self.ctx, _ptr(self._weights), _ptr(self._adam_m), _ptr(self._adam_v)))
         # non-trainable model state (Star: PartitionedNorm moving statistics, initial mean 0 / variance 1)
         self.aux = None
         n_aux = int(self.lib.mamdr_aux_count(self.ctx))
@@ -109,6 +109,27 @@ class TowerEngine(object):
         self.data = {}          # (domain, split) -> dict of device columns
         self._hist = torch.zeros(2 * 501, dtype=torch.int32, device=self.device)
         self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # The live state is only handed out synchronised: with trainable tables the library advances rows that
+    # no batch touched lazily (mamdr_sync_tables in include/mamdr_hip.h); every read or replacement of the
+    # bound vectors from the host side goes through these properties.
+    def sync(self):
+        L.check(self.lib.mamdr_sync_tables(self.ctx))
+
+    @property
+    def weights(self):
+        self.sync()
+        return self._weights
+
+    @property
+    def adam_m(self):
+        self.sync()
+        return self._adam_m
+
+    @property
+    def adam_v(self):
+        self.sync()
+        return self._adam_v
 
     def close(self):
         if getattr(self, "ctx", None):

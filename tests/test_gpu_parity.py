@@ -624,3 +624,41 @@ def test_star_step_adam_eval(env, emb_trainable):
     loss_o2, preds_o2 = model.evaluate(g["data"]["val"][o2], 256)
     np.testing.assert_allclose(preds2, preds_o2, rtol=5e-4, atol=5e-5)
     eng.close()
+
+
+# ------------------------------------------------------------------ lazy dense Adam over trainable tables
+@pytest.mark.parametrize("tower", ["mlp", "deepfm", "star"])
+def test_lazy_table_adam_is_bit_identical_to_the_dense_sweep(env, tower):
+    """TF1's Adam moves every table row every step.  The default path replays the steps of rows no batch
+    touched lazily (catch-up before a row is gathered, flush before the weights are read); with
+    MAMDR_DENSE_ADAM=1 the library sweeps the whole table every step.  Same per-element arithmetic in the
+    same order -> the two must agree BITWISE in weights and both Adam slots, including rows with long gaps,
+    rows repeated inside a batch, an SGD step in between and a weight assignment in between."""
+    results = {}
+    for mode in ("lazy", "dense"):
+        os.environ["MAMDR_DENSE_ADAM"] = "1" if mode == "dense" else "0"
+        try:
+            if tower == "star":
+                g, eng, model = make_star_problem(env, True)
+            else:
+                g, eng, model = make_problem(env, scale=0.1, batch=256, dropout=0.5, emb_trainable=True, tower=tower)
+        finally:
+            os.environ.pop("MAMDR_DENSE_ADAM", None)
+        sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(10)]
+        order = sorted(range(10), key=lambda k: -sizes[k])[:3]
+        snap = None
+        for rep_ in range(2):
+            for d in order:
+                perm = torch.from_numpy(orng.shuffle_perm(sizes[d], 10000, seed=17 + d + rep_)).to(eng.device)
+                eng.train_steps(d, perm=perm, lr=1e-3)
+            if rep_ == 0:
+                snap = eng.get_weights()                                  # a read in between (forces a flush)
+                eng.train_steps(order[0], first_step=0, n_steps=1, lr=1e-3, optimizer="sgd")   # dense SGD step
+                eng.set_weights((snap + eng.get_weights()) * 0.5)        # weight assignment; slots persist
+        results[mode] = (eng.weights.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(),
+                         eng.adam_v.cpu().numpy().copy(), int(eng.lib.mamdr_optimizer_steps(eng.ctx)))
+        eng.close()
+    assert results["lazy"][3] == results["dense"][3] > 10
+    for a, b, name in zip(results["lazy"][:3], results["dense"][:3], ("weights", "adam_m", "adam_v")):
+        assert np.isfinite(a).all()
+        assert same_bits(a, b), (tower, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
