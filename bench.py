@@ -236,7 +236,7 @@ def main():
 
     # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
     #      the same workload; reported for the dominant kernel, k_tower<train>
-    roofline, gather_info, kernels, sweep_info = None, None, {}, None
+    roofline, gather_info, kernels, sweep_info, table_info = None, None, {}, None, None
     if not args.no_profile:
         eng.profile(True)
         eng.profile_reset()
@@ -245,7 +245,14 @@ def main():
             ms, cnt = eng.profile_read(k)
             if cnt:
                 kernels[L.KERNEL_NAMES[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
-        if trainable:
+        dense_adam = os.environ.get("MAMDR_DENSE_ADAM", "0") not in ("", "0")
+        if trainable and not dense_adam:
+            # default: lazy replay of TF1's dense table Adam (csrc/emb_kernels.hip) -- per step only the rows of
+            # the batch move through HBM; MAMDR_DENSE_ADAM=1 measures the per-step sweep instead
+            ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
+            table_info = {"mode": "lazy (bit-identical to the per-step dense sweep)", "kernel": "k_emb_touch<true>",
+                          "avg_us": ms / max(cnt, 1) * 1e3, "launches": cnt}
+        if trainable and dense_adam:
             # HBM-bound dense optimiser pass: 24 B per table element (read p, m, v; write p, m, v) + 4 B
             # of row map per 512-B row, one launch per step over both tables
             ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
@@ -306,7 +313,7 @@ def main():
                        if world > 1 else "single GPU"},
             "us_per_domain_step": dt / global_steps * 1e6 * world,
             "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0))
-            else roofline, "tower": roofline, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
+            else roofline, "tower": roofline, "table_update": table_info or sweep_info, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
         }
         if cpu:
             result["gpu_over_cpu"] = result["value"] / cpu["value"]

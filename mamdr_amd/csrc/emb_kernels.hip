@@ -90,7 +90,9 @@ __device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v,
                                           float eps) {
     m = __fmaf_rn(__fsub_rn(g, m), omb1, m);
     v = __fmaf_rn(__fsub_rn(__fmul_rn(g, g), v), omb2, v);
-    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(m, alpha), __fadd_rn(__fsqrt_rn(v), eps)));
+    // sqrt and reciprocal on the hardware units (v_sqrt_f32 / v_rcp_f32, 1 ulp): the replay of long gaps is
+    // bound by exactly this sequence, and both paths share it, so they still agree bit for bit
+    p = __fsub_rn(p, __fmul_rn(__fmul_rn(m, alpha), __builtin_amdgcn_rcpf(__fadd_rn(__builtin_amdgcn_sqrtf(v), eps))));
 }
 __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {
     if (o.optimizer == 0) {
