@@ -260,7 +260,7 @@ def main():
             sweep_bytes = (g["n_user"] + g["n_item"]) * (128 * 24 + 4) * cnt
             ach = sweep_bytes / (ms * 1e-3) / 1e9
             sweep_info = {"kernel": "k_emb_sweep", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
-                          "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("k_emb_sweep"),
+                          "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("k_emb_sweep<0>"),
                           "avg_us": ms / max(cnt, 1) * 1e3, "launches": cnt,
                           "bytes_per_step": (g["n_user"] + g["n_item"]) * (128 * 24 + 4)}
         roofline_ms, cnt = eng.profile_read(L.KERNEL_FWD_BWD)
