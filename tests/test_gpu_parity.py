@@ -662,3 +662,110 @@ def test_lazy_table_adam_is_bit_identical_to_the_dense_sweep(env, tower):
     for a, b, name in zip(results["lazy"][:3], results["dense"][:3], ("weights", "adam_m", "adam_v")):
         assert np.isfinite(a).all()
         assert same_bits(a, b), (tower, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+
+
+# ------------------------------------------------------------------ AUC parity of the other two BASELINE towers
+def _perm_fn_factory(sizes):
+    def make():
+        counter = [0]
+
+        def perm_fn(d):
+            counter[0] += 1
+            return orng.shuffle_perm(sizes[d], 10000, seed=2000 + counter[0])
+        return perm_fn
+    return make
+
+
+def test_deepfm_dn_auc_parity_trainable_tables(env):
+    """BASELINE config 3 in miniature: DeepFM under Domain Negotiation with TRAINABLE tables (lazy table Adam
+    on the HIP side, dense numpy Adam in the oracle), three epochs, per-domain val AUC within 1e-3."""
+    engine, synthetic = env
+    from mamdr_amd import meta
+    shape = dict(synthetic.SHAPES["taobao10"], n_domain=4)
+    g, eng, model = make_problem(env, scale=0.15, batch=256, dropout=0.5, shape=shape, emb_trainable=True,
+                                 tower="deepfm")
+    D = g["n_domain"]
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    make = _perm_fn_factory(sizes)
+    seqs = [[2, 0, 3, 1], [1, 3, 0, 2], [0, 2, 1, 3]]
+    theta_o = model.get_flat().copy()
+    pf = make()
+    trace_o = []
+    for seq in seqs:
+        trace_o += oloops.dn_epoch(model, theta_o, g["data"]["train"], seq, pf, 256, 0.5)
+    theta_g = eng.get_weights()
+    pf = make()
+    trace_g = []
+    for seq in seqs:
+        trace_g += meta.dn_epoch(eng, theta_g, seq, pf, 256, lr=1e-3, meta_lr=0.5)
+    assert trace_g == trace_o
+    eng.set_weights(theta_g)
+    model.set_flat(theta_o)
+    for d in range(D):
+        _, auc_g = eng.evaluate(d, "val")
+        _, preds = model.evaluate(g["data"]["val"][d], 256)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
+        print("deepfm domain %d: AUC hip %.5f oracle %.5f" % (d, auc_g, auc_o))
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+        assert auc_o > 0.6
+    eng.close()
+
+
+class _StarMeta(object):
+    """oracle Star model seen through its meta parameters (what the MAMDR loop reads and assigns)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def get_flat(self):
+        return self.m.get_flat(meta_only=True)
+
+    def set_flat(self, vec):
+        self.m.set_flat(vec, meta_only=True)
+
+    def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
+        assert accumulate_into is None
+        return self.m.train_pass(data, perm, batch_size, max_steps)
+
+
+def test_star_mamdr_auc_parity(env):
+    """BASELINE config 5 in miniature: Star tower under MAMDR, theta / phi over the reference's meta filter
+    (shared kernels / biases + domain table; pretrained tables frozen as in config/Taobao-10/star_taobao.json),
+    two DN+DR epochs, per-domain val AUC with theta + phi_d within 1e-3."""
+    from oracle import star as ostar
+    engine, synthetic = env
+    from mamdr_amd import meta
+    g, eng, model = make_star_problem(env, False, scale=0.15)
+    D = 4                                   # the first four domains take part
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(10)]
+    make = _perm_fn_factory(sizes)
+    plan = {"seq": [2, 0, 3, 1], "dr": [(2, [0, 3, 2]), (0, [1, 2, 0]), (3, [2, 1, 3]), (1, [3, 0, 1])]}
+    wrapped = _StarMeta(model)
+    theta0 = wrapped.get_flat().copy()
+    assert theta0.size == eng.n_meta
+    rs = np.random.RandomState(5)
+    phis0 = [(rs.standard_normal(theta0.size) * 0.001).astype(F32) for _ in range(D)]
+    theta_o, phis_o = theta0.copy(), [p.copy() for p in phis0]
+    pf = make()
+    trace_o = []
+    for _ in range(2):
+        trace_o += oloops.mamdr_epoch(wrapped, theta_o, phis_o, g["data"]["train"], plan, pf, 256, 0.5)
+    theta_g = torch.from_numpy(theta0).to(eng.device)
+    phis_g = [torch.from_numpy(p).to(eng.device) for p in phis0]
+    pf = make()
+    trace_g = []
+    for _ in range(2):
+        trace_g += meta.mamdr_epoch(eng, theta_g, phis_g, plan, pf, 256, lr=1e-3, meta_lr=0.5)
+    assert trace_g == trace_o
+    merged = eng.new_vector(meta=True)
+    for d in range(D):
+        eng.merge(merged, theta_g, phis_g[d], "plus")
+        eng.set_weights(merged)
+        _, auc_g = eng.evaluate(d, "val")
+        wrapped.set_flat(oouter.merge(theta_o, phis_o[d], "plus"))
+        _, preds = model.evaluate(g["data"]["val"][d], 256)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
+        print("star domain %d: AUC hip %.5f oracle %.5f" % (d, auc_g, auc_o))
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+        assert auc_o > 0.6
+    eng.close()
