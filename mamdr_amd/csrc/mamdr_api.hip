@@ -140,10 +140,11 @@ std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepf
     struct G { int a_off, M, b_off, N, dst; };
     // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
     const G gemms[3] = {{0, XDIM, 0, H1, L.w0}, {XDIM, H1, H1, H2, L.w1}, {XDIM + H1, H2, H1 + H2, H3, L.w2}};
+    // (64x64 tiles first: the kernel stages their operands through LDS)
     for (const G& g : gemms)
-        for (int m0 = 0; m0 < g.M; m0 += 32)
-            for (int n0 = 0; n0 < g.N; n0 += 32)
-                t.push_back(TileDesc{0, g.a_off + m0, 0, g.b_off + n0, g.dst + m0 * g.N + n0, g.N, 32, 32});
+        for (int m0 = 0; m0 < g.M; m0 += 64)
+            for (int n0 = 0; n0 < g.N; n0 += 64)
+                t.push_back(TileDesc{0, g.a_off + m0, 0, g.b_off + n0, g.dst + m0 * g.N + n0, g.N, 64, 64, 1});
     // biases = column sums of dz (A = ones in row 0)
     const int boff[3] = {L.b0, L.b1, L.b2}, bn[3] = {H1, H2, H3}, zoff[3] = {0, H1, H1 + H2};
     for (int l = 0; l < 3; ++l)
@@ -410,7 +411,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     wa.tiles = c->tiles;
     wa.n_tiles = c->n_tiles;
     wa.rows_pad = rows_pad;
-    int rpg = rows_pad <= 2048 ? 256 : 512;
+    int rpg = rows_pad <= 4096 ? 256 : 512;
     int groups = (rows_pad + rpg - 1) / rpg;
     if (groups > c->max_groups) {
         rpg = ((rows_pad + c->max_groups - 1) / c->max_groups + 7) / 8 * 8;
@@ -907,7 +908,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
         wa.tiles = c->tiles;
         wa.n_tiles = c->n_tiles;
         wa.rows_pad = rows_pad;
-        int rpg = rows_pad <= 2048 ? 256 : 512;
+        int rpg = rows_pad <= 4096 ? 256 : 512;
         int groups = (rows_pad + rpg - 1) / rpg;
         if (groups > c->max_groups) {
             rpg = ((rows_pad + c->max_groups - 1) / c->max_groups + 7) / 8 * 8;

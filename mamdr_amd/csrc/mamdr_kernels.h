@@ -75,6 +75,7 @@ struct TileDesc {
     int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0), 2: fmq column block
     int dst_off, dst_ld;       // destination in the dense-block gradient slab
     int m_valid, n_valid;      // valid rows / cols of the 32x32 tile
+    int big;                   // 1: full 64x64 tile of acts^T dz (LDS-staged path), 0: 32x32 tile with synthesised operands
 };
 
 struct WgradArgs {

@@ -804,8 +804,70 @@ constexpr int W0DOM_COPY_WGS = W0DOM_FLOAT4 / 256;        // 32
 #define WSTAMP(k) do { } while (0)
 #endif
 
+// ---- 64x64 tiles of acts^T dz: the four waves own the 2x2 32x32 quadrants of the tile and share the
+// operands through LDS.  Rows are staged in chunks of 32 (16-B global loads, 16 lanes per 256-B row slice,
+// a 4-deep register ring ahead of the MFMAs); LDS rows are 96 floats apart so that the two half-waves of
+// an operand read (rows 2i and 2i+1) hit disjoint banks.
+constexpr int WG_KC = 32;          // rows per staged chunk
+constexpr int WG_LD = 96;          // LDS row stride (floats)
+constexpr int WG_PF = 4;           // chunks in flight
+constexpr int WG_BUF = WG_KC * WG_LD;          // one operand buffer
+static_assert(4 * WG_BUF >= 4 * 1024, "the 32x32 path's reduction buffer aliases the staging buffers");
+
+__device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t, int gb0, int gb1, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int c = lane & 31, kk = lane >> 5;
+    const int lr = tid >> 4, lc4 = (tid & 15) * 4;          // staging: rows lr and lr + 16, columns lc4..+3
+    const int n_chunks = (gb1 - gb0 + WG_KC - 1) / WG_KC;
+    f32x4 ra[WG_PF][2], rb[WG_PF][2];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int slot, int ch) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = gb0 + ch * WG_KC + lr + 16 * h;
+            const bool ok = ch < n_chunks && b < gb1;
+            ra[slot][h] = ok ? *reinterpret_cast<const f32x4*>(g.acts + (size_t)b * ACT_LD + t.a_off + lc4) : zero4;
+            rb[slot][h] = ok ? *reinterpret_cast<const f32x4*>(g.dz + (size_t)b * DZ_LD + t.b_off + lc4) : zero4;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < WG_PF; ++s) issue(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ch0 = 0; ch0 < n_chunks; ch0 += WG_PF) {
+#pragma unroll
+        for (int u = 0; u < WG_PF; ++u) {
+            const int ch = ch0 + u;
+            if (ch >= n_chunks) break;                 // uniform
+            float* As = lds + (ch & 1) * 2 * WG_BUF;
+            float* Bs = As + WG_BUF;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<f32x4*>(As + (lr + 16 * h) * WG_LD + lc4) = ra[u][h];
+                *reinterpret_cast<f32x4*>(Bs + (lr + 16 * h) * WG_LD + lc4) = rb[u][h];
+            }
+            __syncthreads();
+            issue(u, ch + WG_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* ap = As + kk * WG_LD + wm * 32 + c;
+            const float* bp = Bs + kk * WG_LD + wn * 32 + c;
+#pragma unroll
+            for (int i = 0; i < WG_KC / 2; ++i) acc = MAMDR_MFMA32(ap[2 * i * WG_LD], bp[2 * i * WG_LD], acc);
+        }
+    }
+    // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* dst = g.slabs + (size_t)(blockIdx.x % g.n_groups) * g.slab_ld + t.dst_off +
+                 (size_t)(wm * 32) * t.dst_ld + wn * 32;
+    const int rb4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + rb4) * t.dst_ld + c] = acc[r];
+}
+
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 1024];
+    __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n_work = g.n_tiles * g.n_groups;
     if ((int)blockIdx.x > n_work) {
@@ -834,6 +896,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     WSTAMP(1);
     const int gb0 = grp * g.rows_per_group;
     const int gb1 = min(gb0 + g.rows_per_group, g.rows_pad);
+    if (t.big) {
+        wgrad_big(g, t, gb0, gb1, red);
+        return;
+    }
     // split the group's rows over the 4 waves in multiples of 2
     const int span = gb1 > gb0 ? gb1 - gb0 : 0;
     const int per = ((span + 7) / 8) * 2;
