@@ -250,7 +250,7 @@ def main():
             # default: lazy replay of TF1's dense table Adam (csrc/emb_kernels.hip) -- per step only the rows of
             # the batch move through HBM; MAMDR_DENSE_ADAM=1 measures the per-step sweep instead
             ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
-            table_info = {"mode": "lazy (bit-identical to the per-step dense sweep)", "kernel": "k_emb_touch<true>",
+            table_info = {"mode": "lazy (bit-identical to the per-step dense sweep)", "kernel": "k_emb_reduce (+ Adam step of the touched rows)",
                           "avg_us": ms / max(cnt, 1) * 1e3, "launches": cnt}
         if trainable and dense_adam:
             # HBM-bound dense optimiser pass: 24 B per table element (read p, m, v; write p, m, v) + 4 B

@@ -25,6 +25,33 @@ void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_fill, dim3(blocks), dim3(256), 0, s, map, n, EMB_UNTOUCHED);
 }
 
+// TF1 ApplyAdam on one element with an explicit rounding sequence: the dense sweep, the lazy catch-up,
+// the touched-row update and the flush all go through it, so a row that is advanced lazily ends up with
+// exactly the bits the per-step dense sweep would have produced.
+__device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v, float alpha, float omb1, float omb2,
+                                          float eps) {
+    m = __fmaf_rn(__fsub_rn(g, m), omb1, m);
+    v = __fmaf_rn(__fsub_rn(__fmul_rn(g, g), v), omb2, v);
+    // sqrt and reciprocal on the hardware units (v_sqrt_f32 / v_rcp_f32, 1 ulp): the replay of long gaps is
+    // bound by exactly this sequence, and both paths share it, so they still agree bit for bit
+    p = __fsub_rn(p, __fmul_rn(__fmul_rn(m, alpha), __builtin_amdgcn_rcpf(__fadd_rn(__builtin_amdgcn_sqrtf(v), eps))));
+}
+// lazy mode: the representative workgroup of k_emb_reduce applies Adam step t_now to its row right away
+// (element t of row r; the row was brought to t_now - 1 by k_emb_catchup before the gather)
+__device__ __forceinline__ void emb_apply_row(const EmbStepArgs& a, const EmbTable& T, bool second, int r, int t,
+                                              float gsum) {
+    const size_t e = ((size_t)(second ? a.t[0].n_rows : 0) + r) * EMB + t;
+    float p = a.p[e], m = a.m[e], v = a.v[e];
+    adam_elem(__fadd_rn(__fmul_rn(a.opt.two_l2, p), gsum), p, m, v, a.opt.alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+    a.p[e] = p;
+    a.m[e] = m;
+    a.v[e] = v;
+    if (t == 0) {
+        T.last[r] = a.t_now;
+        if (!T.lin_p) T.map[r] = EMB_UNTOUCHED;      // DeepFM: k_lin_sweep still needs the map and resets it
+    }
+}
+
 __global__ __launch_bounds__(256) void k_emb_flag(const EmbStepArgs a) {
     const EmbTable& T = a.t[blockIdx.y];
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -48,8 +75,10 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     const int r = T.brow[b];
     if (r < 0 || T.map[r] != b) return;        // uniform over the workgroup
     if (!T.hasdup[b]) {                        // the common case: no other position shares the row
-        T.gbuf[(size_t)b * EMB + t] = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
+        const float g1 = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
         if (T.lin_p && t == 0) T.glin[b] = a.dlogit[b];
+        if (a.apply_now) emb_apply_row(a, T, blockIdx.y != 0, r, t, g1);
+        else T.gbuf[(size_t)b * EMB + t] = g1;
         return;
     }
     const int per = (a.rows + EMB - 1) / EMB;
@@ -75,25 +104,15 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     const int n = n_list;
     float acc = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
     for (int k = 0; k < n; ++k) acc += a.dxe[(size_t)list[k] * a.dx_ld + T.dx_off + t];
-    T.gbuf[(size_t)b * EMB + t] = acc;
     if (T.lin_p && t == 0) {                   // DeepFM: the 1-d linear table's row gradient = sum of dlogit
         float accl = a.dlogit[b];
         for (int k = 0; k < n; ++k) accl += a.dlogit[list[k]];
         T.glin[b] = accl;
     }
+    if (a.apply_now) emb_apply_row(a, T, blockIdx.y != 0, r, t, acc);
+    else T.gbuf[(size_t)b * EMB + t] = acc;
 }
 
-// TF1 ApplyAdam on one element with an explicit rounding sequence: the dense sweep, the lazy catch-up,
-// the touched-row update and the flush all go through it, so a row that is advanced lazily ends up with
-// exactly the bits the per-step dense sweep would have produced.
-__device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v, float alpha, float omb1, float omb2,
-                                          float eps) {
-    m = __fmaf_rn(__fsub_rn(g, m), omb1, m);
-    v = __fmaf_rn(__fsub_rn(__fmul_rn(g, g), v), omb2, v);
-    // sqrt and reciprocal on the hardware units (v_sqrt_f32 / v_rcp_f32, 1 ulp): the replay of long gaps is
-    // bound by exactly this sequence, and both paths share it, so they still agree bit for bit
-    p = __fsub_rn(p, __fmul_rn(__fmul_rn(m, alpha), __builtin_amdgcn_rcpf(__fadd_rn(__builtin_amdgcn_sqrtf(v), eps))));
-}
 __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {
     if (o.optimizer == 0) {
         adam_elem(g, p, m, v, o.alpha, o.omb1, o.omb2, o.eps);
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
         f32x4 m = (f32x4){0.f, 0.f, 0.f, 0.f}, v = m;
         if (OPT != 1) m = SW_LD(reinterpret_cast<const f32x4*>(a.m) + e4);
         if (OPT == 0) v = SW_LD(reinterpret_cast<const f32x4*>(a.v) + e4);
-        f32x4 g;       // explicit roundings: the lazy path (k_emb_touch / k_emb_flush) must reproduce these bits
+        f32x4 g;       // explicit roundings: the lazy path (k_emb_catchup / emb_apply_row / k_emb_flush) must reproduce these bits
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = __fmul_rn(a.opt.two_l2, p[k]);
         if (rep != EMB_UNTOUCHED) {
@@ -229,57 +248,44 @@ void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_rows, dim3((a.rows_pad + 255) / 256), dim3(256), 0, s, a);
 }
 
-// 8 batch positions per workgroup, 32 lanes x float4 per 512-B row; only representatives work.
-// FINAL = false: replay the missed steps up to t_now - 1 (before the gather reads the row);
-// FINAL = true: step t_now with the batch gradient, and the row map is released.
-template <bool FINAL>
-__global__ __launch_bounds__(256) void k_emb_touch(const EmbStepArgs a) {
+// 8 batch positions per workgroup, 32 lanes x float4 per 512-B row.  A representative replays its row's
+// missed steps up to t_now - 1 (before the gather reads the row); every other position flags its
+// representative as "row occurs more than once" for k_emb_reduce.
+__global__ __launch_bounds__(256) void k_emb_catchup(const EmbStepArgs a) {
     const int b = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
     if (b >= a.rows) return;
     const bool second = blockIdx.y != 0;
     const EmbTable& T = a.t[blockIdx.y];
     const int r = T.brow[b];
-    if (r < 0 || T.map[r] != b) return;
-    const size_t e4 = ((size_t)(second ? a.t[0].n_rows : 0) + r) * (EMB / 4) + c4;
+    if (r < 0) return;
+    const int rep = T.map[r];
+    if (rep != b) {
+        if (c4 == 0) T.hasdup[rep] = 1;        // same value from every writer
+        return;
+    }
     const int last = T.last[r];
     const int t_prev = a.t_now - 1;
-    if (!FINAL && last >= t_prev) return;
+    if (last >= t_prev) return;
+    const size_t e4 = ((size_t)(second ? a.t[0].n_rows : 0) + r) * (EMB / 4) + c4;
     f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
     f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
     f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
-    if (!FINAL) {
-        for (int t = last + 1; t <= t_prev; ++t) {
-            const float alpha = a.alpha_log[t & a.log_mask];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float pk = p[k], mk = m[k], vk = v[k];
-                adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
-                p[k] = pk; m[k] = mk; v[k] = vk;
-            }
-        }
-    } else {
-        const f32x4 gb = reinterpret_cast<const f32x4*>(T.gbuf + (size_t)b * EMB)[c4];
+    for (int t = last + 1; t <= t_prev; ++t) {
+        const float alpha = a.alpha_log[t & a.log_mask];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float pk = p[k], mk = m[k], vk = v[k];
-            adam_elem(__fadd_rn(__fmul_rn(a.opt.two_l2, pk), gb[k]), pk, mk, vk, a.opt.alpha, a.opt.omb1, a.opt.omb2,
-                      a.opt.eps);
+            adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
             p[k] = pk; m[k] = mk; v[k] = vk;
         }
     }
     reinterpret_cast<f32x4*>(a.p)[e4] = p;
     reinterpret_cast<f32x4*>(a.m)[e4] = m;
     reinterpret_cast<f32x4*>(a.v)[e4] = v;
-    if (c4 == 0) {      // (the 32 lanes of the row read last[] / map[] in one instruction above)
-        T.last[r] = FINAL ? a.t_now : t_prev;
-        if (FINAL) T.map[r] = EMB_UNTOUCHED;
-    }
+    if (c4 == 0) T.last[r] = t_prev;           // (the 32 lanes of the row read last[] in one instruction above)
 }
 void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_touch<false>, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
-}
-void launch_emb_apply(const EmbStepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_touch<true>, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_emb_catchup, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
 }
 
 // every row of both tables -> current at t_now (one float4 per thread; rows already current cost one
@@ -317,7 +323,7 @@ void launch_emb_flush(const EmbStepArgs& a, hipStream_t s) {
 }
 
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_flag, dim3((a.rows + 255) / 256, 2), dim3(256), 0, s, a);
+    if (!a.flags_done) hipLaunchKernelGGL(k_emb_flag, dim3((a.rows + 255) / 256, 2), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_emb_reduce, dim3(a.rows, 2), dim3(EMB), (size_t)a.rows * sizeof(int32_t), s, a);
 }
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s) {

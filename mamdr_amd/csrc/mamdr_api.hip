@@ -333,16 +333,18 @@ static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm
 static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float omb1, float omb2, int rows) {
     EmbStepArgs ea;
     fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
-    launch_emb_reduce(ea, c->stream);
     if (c->lazy && optimizer == MAMDR_OPT_ADAM) {
-        if (c->deepfm) {
-            ea.lin_keep_map = 1;
-            launch_lin_sweep(ea, c->stream);
+        // duplicates were flagged by the catch-up kernel; the reducing workgroup applies the step itself
+        ea.flags_done = 1;
+        ea.apply_now = 1;
+        {
+            Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
+            launch_emb_reduce(ea, c->stream);
         }
-        Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
-        launch_emb_apply(ea, c->stream);
+        if (c->deepfm) launch_lin_sweep(ea, c->stream);     // reads the row maps, then releases them
         return;
     }
+    launch_emb_reduce(ea, c->stream);
     {
         Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
         launch_emb_sweep(ea, c->stream);

@@ -185,7 +185,9 @@ struct EmbStepArgs {
     const float* alpha_log;
     int log_mask;
     int t_now;
-    int lin_keep_map;          // k_lin_sweep leaves the row maps alone (k_emb_apply resets them afterwards)
+    int lin_keep_map;          // k_lin_sweep leaves the row maps alone
+    int flags_done;            // duplicate flags were set by k_emb_catchup (lazy mode): skip k_emb_flag
+    int apply_now;             // lazy mode: k_emb_reduce applies Adam step t_now to the rows it reduces
 };
 struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the batch BEFORE the tower runs
     const int32_t* uid;
@@ -203,7 +205,6 @@ struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the b
 };
 void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s);
 void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s);     // rows of the batch -> current at t_now - 1
-void launch_emb_apply(const EmbStepArgs& a, hipStream_t s);       // step t_now on the rows of the batch
 void launch_emb_flush(const EmbStepArgs& a, hipStream_t s);       // every row -> current at t_now
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s);
