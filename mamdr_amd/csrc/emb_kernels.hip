@@ -102,8 +102,19 @@ __global__ __launch_bounds__(EMB) void k_emb_reduce(const EmbStepArgs a) {
     if (t == EMB - 1) n_list = off;            // the last thread's end offset is the total
     __syncthreads();
     const int n = n_list;
+    // ascending-position sum; the loads of 8 listed rows are issued together, the adds stay in order
+    // (a popular item can occur hundreds of times in a batch of 8192: the chain of dependent loads was
+    // the critical path of the kernel)
     float acc = a.dxe[(size_t)b * a.dx_ld + T.dx_off + t];
-    for (int k = 0; k < n; ++k) acc += a.dxe[(size_t)list[k] * a.dx_ld + T.dx_off + t];
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = a.dxe[(size_t)list[k + u] * a.dx_ld + T.dx_off + t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v8[u];
+    }
+    for (; k < n; ++k) acc += a.dxe[(size_t)list[k] * a.dx_ld + T.dx_off + t];
     if (T.lin_p && t == 0) {                   // DeepFM: the 1-d linear table's row gradient = sum of dlogit
         float accl = a.dlogit[b];
         for (int k = 0; k < n; ++k) accl += a.dlogit[list[k]];

@@ -502,6 +502,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         return fail(MAMDR_EINVAL, "n_user/n_item/n_domain must be positive");
     if (cfg->max_batch <= 0 || cfg->max_batch % TILE_ROWS != 0)
         return fail(MAMDR_EINVAL, "max_batch must be a positive multiple of %d", TILE_ROWS);
+    if (cfg->max_batch > 16384) return fail(MAMDR_EINVAL, "max_batch %d exceeds 16384", cfg->max_batch);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
 
     mamdr_ctx* c = new (std::nothrow) mamdr_ctx();
@@ -573,6 +574,10 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->hasdup_i, rp * sizeof(int32_t));
         const char* dense_env = getenv("MAMDR_DENSE_ADAM");
         c->lazy = !(dense_env && atoi(dense_env) != 0);
+        if (const char* cap_env = getenv("MAMDR_LAZY_LOG_CAP")) {      // tests: force the alpha ring to wrap
+            const int cap = atoi(cap_env);
+            if (cap >= 4 && (cap & (cap - 1)) == 0) c->log_cap = cap;
+        }
         ALLOC(c->last_u, (size_t)cfg->n_user * sizeof(int32_t));
         ALLOC(c->last_i, (size_t)cfg->n_item * sizeof(int32_t));
         ALLOC(c->alpha_log, (size_t)c->log_cap * sizeof(float));

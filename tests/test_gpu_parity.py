@@ -628,7 +628,7 @@ def test_star_step_adam_eval(env, emb_trainable):
 
 
 # ------------------------------------------------------------------ lazy dense Adam over trainable tables
-@pytest.mark.parametrize("tower", ["mlp", "deepfm", "star"])
+@pytest.mark.parametrize("tower", ["mlp", "deepfm", "star", "mlp-ring8"])
 def test_lazy_table_adam_is_bit_identical_to_the_dense_sweep(env, tower):
     """TF1's Adam moves every table row every step.  The default path replays the steps of rows no batch
     touched lazily (catch-up before a row is gathered, flush before the weights are read); with
@@ -636,8 +636,12 @@ def test_lazy_table_adam_is_bit_identical_to_the_dense_sweep(env, tower):
     same order -> the two must agree BITWISE in weights and both Adam slots, including rows with long gaps,
     rows repeated inside a batch, an SGD step in between and a weight assignment in between."""
     results = {}
+    ring = tower.endswith("-ring8")        # an 8-entry alpha ring: the library must flush before it wraps
+    tower = tower.split("-")[0]
     for mode in ("lazy", "dense"):
         os.environ["MAMDR_DENSE_ADAM"] = "1" if mode == "dense" else "0"
+        if ring:
+            os.environ["MAMDR_LAZY_LOG_CAP"] = "8"
         try:
             if tower == "star":
                 g, eng, model = make_star_problem(env, True)
@@ -645,6 +649,7 @@ def test_lazy_table_adam_is_bit_identical_to_the_dense_sweep(env, tower):
                 g, eng, model = make_problem(env, scale=0.1, batch=256, dropout=0.5, emb_trainable=True, tower=tower)
         finally:
             os.environ.pop("MAMDR_DENSE_ADAM", None)
+            os.environ.pop("MAMDR_LAZY_LOG_CAP", None)
         sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(10)]
         order = sorted(range(10), key=lambda k: -sizes[k])[:3]
         snap = None
