@@ -172,6 +172,13 @@ int mamdr_bind_domain_data(mamdr_ctx* ctx, int domain, int split, const int32_t*
 int mamdr_train_steps(mamdr_ctx* ctx, int domain, const int32_t* d_perm, int64_t first_step,
                       int64_t n_steps, int32_t batch, uint32_t dropout_seed, int32_t optimizer,
                       float lr, float* d_loss_out);
+/* Same, over a pass of `pass_rows` positions only (d_perm then holds pass_rows row indices of the split;
+ * -1 = the whole split).  Replaces the take/skip sub-datasets of the meta-train / meta-val split
+ * (model_zoo/maml.py:300-330, mldg.py:309-325: `dataset.take(n_train)` / `dataset.skip(n_train)`), whose
+ * final partial batch ends at the sub-dataset's end. */
+int mamdr_train_steps_n(mamdr_ctx* ctx, int domain, const int32_t* d_perm, int64_t pass_rows, int64_t first_step,
+                        int64_t n_steps, int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr,
+                        float* d_loss_out);
 
 /* Evaluate one domain's split with the live weights, dropout off.  Replaces
  * model.evaluate(data, steps=n_step) (model_zoo/base_model.py:131,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
     "mamdr_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),
     "mamdr_train_steps": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
+    "mamdr_train_steps_n": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
     "mamdr_eval_domain": (C.c_int, [_VP, C.c_int, C.c_int, _I32, _VP, _VP, _VP]),
     "mamdr_gather_rows": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _I64, _I64, _VP]),
     "mamdr_interp": (C.c_int, [_VP, _VP, _VP, _F, _I64, _VP]),

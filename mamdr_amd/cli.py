@@ -22,7 +22,7 @@ def in_name_list(x, name_list):
 
 
 def build_model(config, dataset, engine_factory=None):
-    from .model_zoo import MAML, MAMDR, DeepCTR, DomainNegotiation, Reptile, Star
+    from .model_zoo import MAML, MAMDR, MLDG, DeepCTR, DomainNegotiation, Reptile, Star
     name = config["model"]["name"]
     if "star" in name:
         model = Star(dataset, config, engine_factory)
@@ -45,7 +45,7 @@ def build_model(config, dataset, engine_factory=None):
         elif "reptile" in name:
             model = Reptile(model)
         elif "mldg" in name:
-            raise NotImplementedError("MLDG is a comparison baseline outside the hot path")
+            model = MLDG(model)
         else:
             model = MAML(model)
     return model

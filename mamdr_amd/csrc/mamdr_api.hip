@@ -808,6 +808,12 @@ int mamdr_bind_domain_data(mamdr_ctx* c, int domain, int split, const int32_t* d
 
 int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t first_step, int64_t n_steps,
                       int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr, float* d_loss_out) {
+    return mamdr_train_steps_n(c, domain, d_perm, -1, first_step, n_steps, batch, dropout_seed, optimizer, lr, d_loss_out);
+}
+
+int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t pass_rows, int64_t first_step,
+                        int64_t n_steps, int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr,
+                        float* d_loss_out) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (ready(c)) return MAMDR_ESTATE;
     SplitData* d = split_of(c, domain, MAMDR_SPLIT_TRAIN);
@@ -818,7 +824,10 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
     if (optimizer == MAMDR_OPT_ACCUMULATE && !c->accum)
         return fail(MAMDR_ESTATE, "MAMDR_OPT_ACCUMULATE needs mamdr_bind_accumulator first");
     if (first_step < 0 || n_steps < 0) return fail(MAMDR_EINVAL, "negative step range");
-    const int64_t pass_steps = (d->n + batch - 1) / batch;
+    if (pass_rows < 0) pass_rows = d->n;                 // the whole split
+    if (pass_rows > d->n) return fail(MAMDR_EINVAL, "pass of %lld rows exceeds the %lld rows of domain %d",
+                                      (long long)pass_rows, (long long)d->n, domain);
+    const int64_t pass_steps = (pass_rows + batch - 1) / batch;
     if (first_step + n_steps > pass_steps)
         return fail(MAMDR_EINVAL, "steps [%lld,%lld) exceed the %lld batches of domain %d", (long long)first_step,
                     (long long)(first_step + n_steps), (long long)pass_steps, domain);
@@ -838,7 +847,7 @@ int mamdr_train_steps(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t f
 
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
-        const int rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
+        const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
         const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
         float step_alpha = lr;
         if (optimizer == MAMDR_OPT_ADAM) {

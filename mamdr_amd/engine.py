@@ -253,15 +253,18 @@ class TowerEngine(object):
 
     # ------------------------------------------------------------ the hot path
     def train_steps(self, domain, perm=None, first_step=0, n_steps=None, lr=1e-3, optimizer="adam",
-                    loss_out=None, batch_size=None):
-        """n_steps x train_on_batch on one domain, device-side. perm: int32 device tensor or None."""
+                    loss_out=None, batch_size=None, pass_rows=None):
+        """n_steps x train_on_batch on one domain, device-side. perm: int32 device tensor or None.
+        pass_rows: the pass covers only that many positions (perm then lists that many rows of the split) --
+        the take / skip sub-datasets of the meta-train / meta-val split."""
         bs = batch_size or self.batch_size
-        n = self.n_rows(domain, "train")
+        n = self.n_rows(domain, "train") if pass_rows is None else int(pass_rows)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
         opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD, "accumulate": L.OPT_ACCUMULATE}[optimizer]
-        L.check(self.lib.mamdr_train_steps(self.ctx, domain, _ptr(perm), first_step, n_steps, bs,
-                                           self.dropout_seed, opt, float(lr), _ptr(loss_out)))
+        L.check(self.lib.mamdr_train_steps_n(self.ctx, domain, _ptr(perm), -1 if pass_rows is None else n,
+                                             first_step, n_steps, bs, self.dropout_seed, opt, float(lr),
+                                             _ptr(loss_out)))
         return n_steps
 
     def evaluate(self, domain, split, want_preds=False):

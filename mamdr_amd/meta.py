@@ -27,15 +27,28 @@ def _upload_perm(eng, perm):
     return torch.from_numpy(perm).to(eng.device, non_blocking=True)
 
 
-def run_pass(eng, d, perm_fn, batch_size, lr, trace, phase, max_steps=0, optimizer="adam"):
-    """one pass over domain d's train split = re-initialised iterator + n_step x train_on_batch."""
-    perm = _upload_perm(eng, perm_fn(d) if perm_fn is not None else None)
-    n = eng.n_rows(d, "train")
+def run_pass(eng, d, perm_fn, batch_size, lr, trace, phase, max_steps=0, optimizer="adam", window=None):
+    """one pass over domain d's train split = re-initialised iterator + n_step x train_on_batch.
+    window = (begin, end): the pass covers that file-order slice only (meta-train / meta-val split)."""
+    if window is None:
+        perm = _upload_perm(eng, perm_fn(d) if perm_fn is not None else None)
+        n, pass_rows = eng.n_rows(d, "train"), None
+    else:
+        import numpy as np
+        perm = perm_fn(d, window) if perm_fn is not None else None
+        if perm is None:
+            perm = np.arange(window[0], window[1], dtype=np.int32)
+        perm = _upload_perm(eng, perm)
+        n = pass_rows = window[1] - window[0]
     n_steps = -(-n // batch_size)
     if max_steps and max_steps > 0:
         n_steps = min(n_steps, max_steps)
-    eng.train_steps(d, perm=perm, first_step=0, n_steps=n_steps, lr=lr, optimizer=optimizer,
-                    batch_size=batch_size)
+    if pass_rows is None:
+        eng.train_steps(d, perm=perm, first_step=0, n_steps=n_steps, lr=lr, optimizer=optimizer,
+                        batch_size=batch_size)
+    else:
+        eng.train_steps(d, perm=perm, first_step=0, n_steps=n_steps, lr=lr, optimizer=optimizer,
+                        batch_size=batch_size, pass_rows=pass_rows)
     trace.append((phase, d, n_steps))
     return n_steps
 
@@ -86,25 +99,58 @@ class OuterAdamState(object):
         self.b1p = np.float32(1.0)
         self.b2p = np.float32(1.0)
 
-    def apply(self, eng, theta, acc, lr, grad_scale=1.0):
+    def apply(self, eng, theta, acc, lr, grad_scale=1.0, clear=True):
         import numpy as np
         self.b1p = np.float32(self.b1p * np.float32(0.9))
         self.b2p = np.float32(self.b2p * np.float32(0.999))
         eng.adam_apply(theta, self.m, self.v, acc, lr, float(self.b1p), float(self.b2p), grad_scale)
-        acc.zero_()
+        if clear:
+            acc.zero_()
 
 
 def maml_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False,
-               meta_train_step=0, grad_scale=1.0):
-    """acc must be bound with eng.bind_accumulator(acc) and zero on entry."""
+               meta_train_step=0, grad_scale=1.0, windows=None):
+    """acc must be bound with eng.bind_accumulator(acc) and zero on entry.
+    windows: {domain: (train window, meta window)} for the meta-train / meta-val split, None = train-train."""
     trace = []
     for d in seq:
+        wt, wm = windows[d] if windows else (None, None)
         eng.set_weights(theta)
-        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_train", meta_train_step)
-        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_meta", meta_train_step, optimizer="accumulate")
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_train", meta_train_step, window=wt)
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_meta", meta_train_step, optimizer="accumulate",
+                 window=wm)
         if not batch_variant:
             outer.apply(eng, theta, acc, meta_lr, grad_scale)
     if batch_variant:
+        outer.apply(eng, theta, acc, meta_lr, grad_scale)
+    eng.set_weights(theta)
+    return trace
+
+
+def mldg_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False,
+               meta_train_step=0, grad_scale=1.0, windows=None):
+    """MLDG as the reference implements it (model_zoo/mldg.py:62-125): per domain the model is reset to
+    theta, the meta-train pass only ACCUMULATES d total_loss / d theta (no inner optimiser step), the outer
+    Adam moves the live model by that gradient (accumulator kept), the meta-val pass adds the gradients at
+    the moved weights, then the model is reset to theta and the outer Adam applies the sum -> new theta
+    (per domain, or once per epoch for "batch" names).  One outer Adam (meta_learning_rate) for both applies.
+    `lr` is unused by the passes (accumulate mode) and only kept for symmetry."""
+    trace = []
+    for d in seq:
+        wt, wm = windows[d] if windows else (None, None)
+        eng.set_weights(theta)
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "mldg_train", meta_train_step, optimizer="accumulate",
+                 window=wt)
+        live = eng.get_weights()[:theta.numel()].clone()
+        outer.apply(eng, live, acc, meta_lr, grad_scale, clear=False)
+        eng.set_weights(live)
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "mldg_meta", meta_train_step, optimizer="accumulate",
+                 window=wm)
+        if not batch_variant:
+            eng.set_weights(theta)
+            outer.apply(eng, theta, acc, meta_lr, grad_scale)
+    if batch_variant:
+        eng.set_weights(theta)
         outer.apply(eng, theta, acc, meta_lr, grad_scale)
     eng.set_weights(theta)
     return trace

@@ -6,3 +6,4 @@ from .reptile import Reptile  # noqa: F401
 from .domain_negotiation import DomainNegotiation  # noqa: F401
 from .mamdr import MAMDR  # noqa: F401
 from .star import Star  # noqa: F401
+from .mldg import MLDG  # noqa: F401

@@ -61,6 +61,26 @@ class MAML(object):
         print("Val Result: ")
         return self.val_and_test("val")
 
+    def build_meta_windows(self):
+        """maml.py:289-341 / mldg.py:296-341 `build_meta_data_split`: "meta-train/val" takes the first
+        int(n * meta_split_ratio) rows (file order) as the meta-train set and the rest as the meta-val set,
+        each shuffled on its own; any other value except the non-exclusive variant is the train-train split
+        (both iterators over the whole train set) -> None."""
+        tc = self.train_config
+        if tc["meta_split"] == "meta-train/val-no-exclusive":
+            raise NotImplementedError("meta_split 'meta-train/val-no-exclusive' (shuffle, then take / skip) is not built")
+        if tc["meta_split"] != "meta-train/val":
+            return None
+        windows = {}
+        for d, v in self.dataset.train_dataset.items():
+            n = v["n_data"]
+            n_train = int(n * tc["meta_split_ratio"])
+            if n_train <= 0 or n_train >= n:
+                raise ValueError("domain %s: meta_split_ratio %s leaves an empty meta-train or meta-val set"
+                                 % (d, tc["meta_split_ratio"]))
+            windows[d] = ((0, n_train), (n_train, n))
+        return windows
+
     def _val_metric(self, val_avg_auc, val_domain_auc):
         t = self.train_config["target_domain"]
         return val_domain_auc[t] if t >= 0 else val_avg_auc
@@ -74,9 +94,7 @@ class MAML(object):
         tc = self.train_config
         if tc["target_domain"] >= 0:
             raise NotImplementedError("target_domain >= 0 is not built in this round")
-        if tc["meta_split"] != "train-train":
-            raise NotImplementedError("meta_split '%s': only the 'train-train' split of the reference configs "
-                                      "(maml.py:325-330) is built" % tc["meta_split"])
+        windows = self.build_meta_windows()
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
             grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])          # maml.py:208-210
@@ -98,7 +116,7 @@ class MAML(object):
             self.rng.shuffle(train_sequence)
             self.trace += meta.maml_epoch(self.model, meta_weights, outer, acc, list(train_sequence), self.shuffler,
                                           self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                          batch_variant, tc["meta_train_step"], grad_scale)
+                                          batch_variant, tc["meta_train_step"], grad_scale, windows)
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

@@ -8,6 +8,8 @@ tf.data (utils/dataset.py:27-37).  Here the same decisions come from a seeded
 """
 import random
 
+import numpy as np
+
 from . import engine as _engine
 
 
@@ -62,11 +64,15 @@ class PassShuffler(object):
         self.shuffle = shuffle
         self.shuffle_fn = shuffle_fn or _engine.shuffle_perm
 
-    def __call__(self, d):
+    def __call__(self, d, window=None):
+        """window = (begin, end): a pass over that file-order slice only (dataset.take / dataset.skip of the
+        meta-train / meta-val split, maml.py:300-330): the slice is shuffled on its own."""
+        begin, end = window if window is not None else (0, self.sizes[d])
         if not self.shuffle:
-            return None
+            return None if window is None else np.arange(begin, end, dtype=np.int32)
         self.counter += 1
-        return self.shuffle_fn(self.sizes[d], self.buffer_size, _mix64(self.seed * 0x10001 + self.counter))
+        perm = self.shuffle_fn(end - begin, self.buffer_size, _mix64(self.seed * 0x10001 + self.counter))
+        return perm if begin == 0 else (perm + np.int32(begin)).astype(np.int32)
 
 
 def plan_steps(plan, steps_per_domain, domain_regulation_step=0):

@@ -16,8 +16,8 @@ from . import outer
 F32 = np.float32
 
 
-def _pass(model, data, perm_fn, d, batch_size, trace, phase, max_steps=0, accumulate_into=None):
-    perm = perm_fn(d)
+def _pass(model, data, perm_fn, d, batch_size, trace, phase, max_steps=0, accumulate_into=None, window=None):
+    perm = perm_fn(d) if window is None else perm_fn(d, window)
     losses = model.train_pass(data[d], perm, batch_size, max_steps, accumulate_into)
     trace.append((phase, d, len(losses)))
     return losses
@@ -61,8 +61,35 @@ def reptile_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, batch_v
     return trace
 
 
+def mldg_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
+               meta_train_step=0, grad_scale=1.0, windows=None):
+    """model_zoo/mldg.py:62-125: accumulate at theta over the meta-train split, outer-Adam step of the LIVE
+    model with the accumulator kept, accumulate at the moved weights over the meta-val split, reset to theta,
+    outer-Adam step -> new theta."""
+    trace = []
+
+    def outer_step():
+        outer.apply(theta, acc, meta_lr, grad_scale)
+        acc[...] = 0
+
+    for d in seq:
+        wt, wm = windows[d] if windows else (None, None)
+        model.set_flat(theta)
+        _pass(model, data, perm_fn, d, batch_size, trace, "mldg_train", meta_train_step, accumulate_into=acc, window=wt)
+        live = model.get_flat()
+        outer.apply(live, acc, meta_lr, grad_scale)
+        model.set_flat(live)
+        _pass(model, data, perm_fn, d, batch_size, trace, "mldg_meta", meta_train_step, accumulate_into=acc, window=wm)
+        if not batch_variant:
+            outer_step()
+    if batch_variant:
+        outer_step()
+    model.set_flat(theta)
+    return trace
+
+
 def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
-               meta_train_step=0, grad_scale=1.0):
+               meta_train_step=0, grad_scale=1.0, windows=None):
     """first-order MAML, model_zoo/maml.py:62-116 with meta_split "train-train": per domain reset
     to theta, inner Adam pass, meta pass that only accumulates gradients at the adapted weights,
     then (per domain, or once per epoch for "batch" names) the outer Adam step on theta."""
@@ -73,9 +100,10 @@ def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr
         acc[...] = 0
 
     for d in seq:
+        wt, wm = windows[d] if windows else (None, None)
         model.set_flat(theta)
-        _pass(model, data, perm_fn, d, batch_size, trace, "maml_train", meta_train_step)
-        _pass(model, data, perm_fn, d, batch_size, trace, "maml_meta", meta_train_step, accumulate_into=acc)
+        _pass(model, data, perm_fn, d, batch_size, trace, "maml_train", meta_train_step, window=wt)
+        _pass(model, data, perm_fn, d, batch_size, trace, "maml_meta", meta_train_step, accumulate_into=acc, window=wm)
         if not batch_variant:
             outer_step()
     if batch_variant:

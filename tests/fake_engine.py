@@ -99,10 +99,10 @@ class FakeEngine(object):
 
     # hot path
     def train_steps(self, domain, perm=None, first_step=0, n_steps=None, lr=1e-3, optimizer="adam", loss_out=None,
-                    batch_size=None):
+                    batch_size=None, pass_rows=None):
         bs = batch_size or self.batch_size
         cols = self.data[(domain, "train")]
-        n = cols["uid"].shape[0]
+        n = cols["uid"].shape[0] if pass_rows is None else pass_rows
         p = np.arange(n, dtype=np.int32) if perm is None else np.asarray(perm)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step

@@ -780,3 +780,29 @@ def test_star_mamdr_auc_parity(env):
         assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
         assert auc_o > 0.6
     eng.close()
+
+
+# ------------------------------------------------------------------ sub-range passes (meta-train / meta-val split)
+def test_pass_window_matches_oracle(env):
+    """mamdr_train_steps_n: a pass over a take / skip slice of the split (maml.py:300-330): the permutation
+    lists only the slice's rows and the final partial batch ends at the slice's end."""
+    g, eng, model = make_problem(env, batch=256, dropout=0.5)
+    d = 9
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    n_train = int(n * 0.8)
+    for (b, e), seed in (((0, n_train), 3), ((n_train, n), 4)):
+        perm = (orng.shuffle_perm(e - b, 10000, seed=seed) + b).astype(np.int32)
+        n_steps = -(-(e - b) // 256)
+        losses_t = torch.zeros(n_steps, device=eng.device)
+        got_steps = eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), lr=1e-3, loss_out=losses_t,
+                                    pass_rows=e - b)
+        assert got_steps == n_steps
+        want = model.train_pass(cols, perm, 256)
+        assert len(want) == n_steps and (e - b) % 256 != 0           # a partial final batch is exercised
+        np.testing.assert_allclose(losses_t.cpu().numpy(), np.array(want, F32), rtol=2e-5, atol=2e-6)
+    assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == model.opt.t
+    # a pass longer than the split is rejected
+    with pytest.raises(Exception):
+        eng.train_steps(d, pass_rows=n + 1)
+    eng.close()

@@ -51,18 +51,21 @@ def patch_emb_dim(monkeypatch):
 # ------------------------------------------------------------------ registry (run.py:37-85)
 def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
     patch_emb_dim(monkeypatch)
-    from mamdr_amd.model_zoo import MAML, MAMDR, DeepCTR, DomainNegotiation, Reptile
+    from mamdr_amd.model_zoo import MAML, MAMDR, MLDG, DeepCTR, DomainNegotiation, Reptile
     ds = mds.MultiDomainDataset(tiny_config(tmp_path)["dataset"])
     for name, cls in (("mlp", DeepCTR), ("mlp_meta_mamdr_finetune", MAMDR), ("mlp_meta_reptile", Reptile),
+                      ("mlp_meta_mldg", MLDG),
                       ("mlp_meta_domain_negotiation_finetune", DomainNegotiation), ("mlp_meta", MAML)):
         cfg = tiny_config(tmp_path, name)
         assert type(cli.build_model(cfg, ds, FakeEngine)) is cls
     # substring order: 'domain_negotiation' wins over 'mamdr' (run.py:55-58)
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_meta_domain_negotiation_mamdr"), ds, FakeEngine)) \
         is DomainNegotiation
-    for bad in ("star_meta_mamdr", "mmoe", "mlp_pcgrad", "mlp_uncertainty_weight", "mlp_meta_mldg", "wdl"):
+    for bad in ("mmoe", "mlp_pcgrad", "mlp_uncertainty_weight", "wdl"):
         with pytest.raises(NotImplementedError):
             cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
+    with pytest.raises(NotImplementedError):      # the CPU stand-in engine has no Star tower (the HIP engine does)
+        cli.build_model(tiny_config(tmp_path, "star_meta_mamdr"), ds, FakeEngine)
     with pytest.raises(ValueError):
         cli.build_model(tiny_config(tmp_path, "nonsense"), ds, FakeEngine)
 
@@ -116,6 +119,26 @@ def test_meta_epochs_follow_oracle_loops():
         assert tr_g == tr_o and [t[0] for t in tr_g[:2]] == ["maml_train", "maml_meta"]
         assert np.array_equal(th_g.numpy(), th_o) and not acc_g.numpy().any()
         assert np.abs(th_o - theta0).max() > 1e-3                # the outer Adam moved theta by ~meta_lr
+    # MLDG (mldg.py:62-125) and MAML over the exclusive meta-train / meta-val split (take / skip windows)
+    windows = {d: ((0, int(sizes[d] * 0.8)), (int(sizes[d] * 0.8), sizes[d])) for d in range(3)}
+    for fn_g, fn_o, first in ((meta.mldg_epoch, oloops.mldg_epoch, "mldg_train"),
+                              (meta.maml_epoch, oloops.maml_epoch, "maml_train")):
+        for bv in (False, True):
+            e1, e2 = fresh(), fresh()
+            th_o = theta0.copy()
+            acc_o = np.zeros_like(th_o)
+            tr_o = fn_o(e1.oracle, th_o, otower.OuterAdam(th_o.size), acc_o, g["data"]["train"], [1, 0, 2],
+                        perm_fn_factory(), 64, 0.1, batch_variant=bv, windows=windows)
+            th_g = torch.from_numpy(theta0.copy())
+            acc_g = torch.zeros(th_g.numel())
+            e2.bind_accumulator(acc_g)
+            tr_g = fn_g(e2, th_g, meta.OuterAdamState(e2), acc_g, [1, 0, 2], perm_fn_factory(), 64, 1e-3, 0.1,
+                        batch_variant=bv, windows=windows)
+            assert tr_g == tr_o and tr_g[0][0] == first
+            # the two passes of a domain cover the 80 % / 20 % slices, final partial batches kept
+            assert tr_g[0][2] == -(-windows[1][0][1] // 64) and tr_g[1][2] == -(-(sizes[1] - windows[1][0][1]) // 64)
+            assert np.array_equal(th_g.numpy(), th_o) and not acc_g.numpy().any()
+            assert np.abs(th_o - theta0).max() > 1e-3
     # DN and Reptile (both variants)
     for fn_g, fn_o, kw in ((meta.dn_epoch, oloops.dn_epoch, {}), (meta.reptile_epoch, oloops.reptile_epoch, {}),
                            (meta.reptile_epoch, oloops.reptile_epoch, {"batch_variant": True})):
