@@ -277,6 +277,7 @@ def main():
         if tower == "star":
             kname = "k_tower<true, 384, false>"
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows)
+        roofline["rocprofv3_avg_us"] = rocprof_avg_us(kname, wl["shape"])
         # gather kernel on a pass-sized batch (largest domain, shuffled order)
         dbig = max(range(D), key=lambda k: sizes[k])
         perm = torch.from_numpy(shuffler(dbig)).to(eng.device)
@@ -333,6 +334,25 @@ def pmc_traffic(kernel_key):
             return json.load(f)[kernel_key]["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+def rocprof_avg_us(kernel, shape):
+    """average duration of `kernel` in the newest committed rocprofv3 summary of this workload
+    (profiles/r*_kernel_stats_<shape>.csv), for comparison with the HIP-event average measured live
+    (events bracket single launches and add ~2 us of inter-command gap); None if no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_%s.csv" % shape)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if kernel in row["Name"]:
+                    return float(row["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
 
 
 def finish_roofline(kernel, total_ms, launches, rows):

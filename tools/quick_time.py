@@ -3,13 +3,12 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from mamdr_amd import engine, synthetic, _lib as L
-from oracle import tower as otower
+import bench
 
 shape = sys.argv[1] if len(sys.argv) > 1 else "taobao10"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 g = synthetic.generate(shape, batch_size=bs, seed=123)
-rs = np.random.RandomState(0)
-params = otower.init_params(rs, g["n_user"], g["n_item"], g["n_domain"])
+params = bench.init_params(g, 0)
 eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], bs, dropout=0.5)
 eng.bind_table("user_emb", g["tables"]["user_emb"]); eng.bind_table("item_emb", g["tables"]["item_emb"])
 for split in ("train", "val"):
