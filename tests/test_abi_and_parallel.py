@@ -37,16 +37,28 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_product_path_does_not_import_oracle():
-    """the oracle is test infrastructure: nothing under mamdr_amd/, run.py may import it."""
+    """the oracle is test infrastructure: nothing under mamdr_amd/ or tools/, nor run.py, may import it;
+    bench.py only inside its cpu_baseline leg, __graft_entry__ only inside smoke()."""
     bad = []
-    for base, _, files in os.walk(os.path.join(ROOT, "mamdr_amd")):
-        for f in files:
-            if f.endswith(".py"):
-                src = open(os.path.join(base, f)).read()
-                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
-                    bad.append(f)
+    for top in ("mamdr_amd", "tools"):
+        for base, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(base, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                        bad.append(os.path.join(top, f))
     assert not bad, bad
     assert "oracle" not in open(os.path.join(ROOT, "run.py")).read()
+    # bench.py / __graft_entry__.py: every oracle import sits inside cpu_baseline() / smoke()
+    for fname, func in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        src = open(os.path.join(ROOT, fname)).read()
+        assert not re.search(r"^(from|import)\s+oracle\b", src, flags=re.M), fname      # none at module level
+        body = src[src.index("def %s(" % func):]
+        nxt = re.search(r"^def \w+\(", body[4:], flags=re.M)
+        body = body[:nxt.start() + 4] if nxt else body
+        n_inside = len(re.findall(r"^\s+(from|import)\s+oracle\b", body, flags=re.M))
+        n_total = len(re.findall(r"^\s*(from|import)\s+oracle\b", src, flags=re.M))
+        assert n_inside == n_total > 0, (fname, n_inside, n_total)
 
 
 def test_lpt_and_plan_sharding():
