@@ -269,11 +269,11 @@ def main():
         # every launch is one batch; a pass of n_steps launches covers min(rows of the domain, n_steps*batch) rows
         prof_rows = sum(min(sizes[d], n * batch) for (_, d, n) in prof_trace)
         assert cnt == sum(n for (_, _, n) in prof_trace)
-        # frozen tables and batches <= 2048 rows launch the 4-row-tile kernel (mamdr_api.hip: use4)
-        use4 = (not trainable) and batch <= 2048 and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
+        # batches <= 2048 rows launch the 4-row-tile kernel (mamdr_api.hip: use4), template <DX, FM>
+        use4 = batch <= 2048 and tower != "star" and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
         fm = ", true>" if tower == "deepfm" else ", false>"
-        use4 = use4 and tower == "mlp"
-        kname = "k_tower4" if use4 else ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
+        kname = ("k_tower4<true" if trainable else "k_tower4<false") + fm if use4 else \
+            ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
         if tower == "star":
             kname = "k_tower<true, 384, false>"
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows)

@@ -842,7 +842,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
 
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
-    const bool may_use4 = !c->cfg.emb_trainable && !c->deepfm && !c->star && c->tower_tile != 16;
+    const bool may_use4 = !c->star && c->tower_tile != 16;
     if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
 
     for (int64_t s = 0; s < n_steps; ++s) {
@@ -977,6 +977,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.wT = (may_use4 && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
         ua.w1_off = c->L.w1;
         ua.w2_off = c->L.w2;
+        ua.w0_off = c->L.w0;
+        ua.w0t = c->cfg.emb_trainable ? 1 : 0;
         {
             Prof p(c, MAMDR_KERNEL_UPDATE);
             launch_update(ua, c->stream);

@@ -22,7 +22,8 @@ constexpr int TILE_ROWS = 16;                 // batch rows per workgroup in the
 // transposed copies of W1 / W2 for the 4-row tower's backward layers (workspace, kept by k_update)
 constexpr int W1T_OFF = 0;                    // [128][256]
 constexpr int W2T_OFF = H1 * H2;              // [64][128]
-constexpr int WT_FLOATS = H1 * H2 + H2 * H3;
+constexpr int W0T_OFF = H1 * H2 + H2 * H3;    // [256][256]: W0[0:256, :]^T (user | item rows), trainable tables only
+constexpr int WT_FLOATS = H1 * H2 + H2 * H3 + 2 * EMB * H1;
 
 // dense block of the flat trainable vector, relative to the domain table start
 // (DeepFM appends its 1-d linear table of the domain feature, `ld`, behind the global bias)

@@ -129,6 +129,7 @@ struct UpdateArgs {
     float omb1, omb2, eps;
     float* wT;                 // nullable: transposed W1 / W2 copies to keep current
     int w1_off, w2_off;        // offsets of W1 / W2 in the dense block
+    int w0_off, w0t;           // W0 offset; w0t: also keep W0T (trainable tables)
 };
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s);

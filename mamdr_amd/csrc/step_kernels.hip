@@ -995,6 +995,10 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
                 const int f = e0 - u.w2_off, r = f / H3, c = f - r * H3;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) u.wT[W2T_OFF + (c + k) * H2 + r] = p[k];
+            } else if (u.w0t && e0 >= u.w0_off && e0 < u.w0_off + 2 * EMB * H1) {
+                const int f = e0 - u.w0_off, r = f / H1, c = f - r * H1;      // W0[r][c], user | item rows
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u.wT[W0T_OFF + (c + k) * (2 * EMB) + r] = p[k];
             }
         }
         return;

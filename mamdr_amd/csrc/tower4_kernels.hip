@@ -30,7 +30,8 @@ constexpr int T4_H2 = T4_H1 + T4_ROWS * H1;            // [4][128]
 constexpr int T4_H3 = T4_H2 + T4_ROWS * H2;            // [4][64]
 constexpr int T4_DZ3 = T4_H3 + T4_ROWS * H3;           // [4][64]
 constexpr int T4_DZ2 = T4_DZ3 + T4_ROWS * H3;          // [4][128]
-constexpr int T4_RED = T4_DZ2 + T4_ROWS * H2;          // [8 waves][4][256] split-k partials
+constexpr int T4_DZ1 = T4_DZ2 + T4_ROWS * H2;          // [4][256] (trainable tables: input of the dx contraction)
+constexpr int T4_RED = T4_DZ1 + T4_ROWS * H1;          // [8 waves][4][256] split-k partials
 constexpr int T4_ROWI = T4_RED + T4_WAVES * T4_ROWS * H1;
 constexpr int T4_LDS_FLOATS = T4_ROWI + 64;
 
@@ -150,6 +151,10 @@ __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
 
 __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// DX: trainable user / item tables -> d loss / d [user | item] row = dz1 . W0[0:256,:]^T through the
+// transposed copy W0T (kept current by k_update), row ids + representatives for the table update.
+// FM: DeepFM tower (logit += linear tables + FM second-order term), as in k_tower.
+template <bool DX, bool FM>
 __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     T4W<H2, H3> w2;
     T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
     T4W<H2, H1> v1;      // backward: dz2 . W1^T through W1T [128][256]
+    T4W<H1, 2 * EMB> v0; // DX: dz1 . W0[0:256,:]^T through W0T [256][256]
     T4STAMP(0);
     w0.prefetch(P + a.L.w0);
     const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
@@ -203,6 +209,22 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = v;
     }
     __syncthreads();
+    if (FM) {
+        // thread (row, k): FM second-order term sum_k (u i + (u + i) d), reduced over the row's two waves
+        const int row = tid >> 7, k = tid & 127;
+        const float* xr = smem + T4_XS + row * XDIM;
+        const float u = xr[k], it = xr[EMB + k], dd = xr[2 * EMB + k];
+        float s = u * it + (u + it) * dd;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) rowf[16 + w] = s;                // wave w = 2 row + half
+        __syncthreads();
+        if (tid < T4_ROWS) {
+            float lin = P[a.L.ld + rowi[8 + tid]];
+            if (a.lin_user) lin = (a.lin_user[rowi[tid]] + a.lin_item[rowi[4 + tid]]) + lin;
+            rowf[8 + tid] = (rowf[16 + 2 * tid] + rowf[17 + 2 * tid]) + lin;
+        }
+        // (read in the output-unit phase, several barriers later)
+    }
 
     T4STAMP(1);
     const float scale = a.use_dropout ? a.keep_scale : 1.0f;
@@ -271,7 +293,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         acts_t[(size_t)row * ACT_LD + XDIM + H1 + H2 + col] = h;
         float s = h * wor;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float logit = s + gbr;
+        float logit = s + gbr;
+        if (FM) logit += rowf[8 + row];
         float p;
         if (logit >= 0.f) {
             p = 1.0f / (1.0f + __expf(-logit));
@@ -291,6 +314,15 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
             a.dlogit[r0 + row] = dl;
             a.domrow[r0 + row] = rowi[8 + row];
             rowf[4 + row] = valid ? loss : 0.f;
+            rowf[12 + row] = dl;
+            if (DX) {
+                a.urow[r0 + row] = valid ? rowi[row] : -1;
+                a.irow[r0 + row] = valid ? rowi[4 + row] : -1;
+                if (valid && a.map_u) {   // representative of a table row = its smallest batch position (exact)
+                    atomicMin(a.map_u + rowi[row], r0 + row);
+                    atomicMin(a.map_i + rowi[4 + row], r0 + row);
+                }
+            }
         }
         const float d = (h > 0.f) ? (dl * wor) * scale : 0.f;
         smem[T4_DZ3 + row * H3 + col] = d;
@@ -298,6 +330,11 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
     __syncthreads();
     if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
+    if (FM) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
+        const int row = tid >> 7, k = tid & 127;
+        const float* xr = smem + T4_XS + row * XDIM;
+        a.fmq[(size_t)(r0 + row) * EMB + k] = rowf[12 + row] * (xr[k] + xr[EMB + k]);
+    }
 
     T4STAMP(7);
     // ---- backward: dz2 = (dz3 . W2^T) * gate(h2)
@@ -313,20 +350,48 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     __syncthreads();
     T4STAMP(8);
     // ---- dz1 = (dz2 . W1^T) * gate(h1); the domain-table gradient follows from dz1 by linearity
-    t4_contract<H2, H1>(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, []() {});
+    t4_contract<H2, H1>(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = erow2 + 2 * rr;
         const float v = t4_sum<H1>(red, row, ecol);
-        dz_t[(size_t)row * DZ_LD + ecol] = (smem[T4_H1 + row * H1 + ecol] > 0.f) ? v * scale : 0.f;
+        const float d = (smem[T4_H1 + row * H1 + ecol] > 0.f) ? v * scale : 0.f;
+        dz_t[(size_t)row * DZ_LD + ecol] = d;
+        if (DX) smem[T4_DZ1 + row * H1 + ecol] = d;
     }
     T4STAMP(9);
+    if (DX) {
+        __syncthreads();           // dz1 complete, `red` free again
+        t4_contract<H1, 2 * EMB>(v0, a.wT + W0T_OFF, smem + T4_DZ1, H1, red, []() {});
+        __syncthreads();
+        float* dxe_t = a.dxe + (size_t)r0 * (2 * EMB);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = erow2 + 2 * rr;
+            float v = t4_sum<2 * EMB>(red, row, ecol);
+            if (FM) {              // d fm / d e_f = sum of the other two fields
+                const float* xr = smem + T4_XS + row * XDIM;
+                const int k = ecol & (EMB - 1);
+                const float other = (ecol < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
+                v = fmaf(rowf[12 + row], other, v);
+            }
+            dxe_t[(size_t)row * (2 * EMB) + ecol] = v;
+        }
+    }
 }
 
 void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
-    hipLaunchKernelGGL(k_tower4, dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+    const bool dx = a.dxe != nullptr;
+    if (a.deepfm) {
+        if (dx) hipLaunchKernelGGL((k_tower4<true, true>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+        else hipLaunchKernelGGL((k_tower4<false, true>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+    } else if (dx) {
+        hipLaunchKernelGGL((k_tower4<true, false>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+    } else {
+        hipLaunchKernelGGL((k_tower4<false, false>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+    }
 }
 
 // W1T / W2T from the live weights (start of every mamdr_train_steps call; k_update keeps them current)
@@ -339,10 +404,14 @@ __global__ __launch_bounds__(256) void k_transpose_w(const float* dense, DenseLa
         const int f = e - H1 * H2;
         const int r = f / H3, c = f - r * H3;               // W2[r][c], r < 128, c < 64
         wT[W2T_OFF + c * H2 + r] = dense[L.w2 + f];
+    } else if (e < WT_FLOATS) {
+        const int f = e - (H1 * H2 + H2 * H3);
+        const int r = f / H1, c = f - r * H1;               // W0[r][c], r < 256 (user | item rows), c < 256
+        wT[W0T_OFF + c * (2 * EMB) + r] = dense[L.w0 + f];
     }
 }
 void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_w, dim3((H1 * H2 + H2 * H3 + 255) / 256), dim3(256), 0, s, dense, L, wT);
+    hipLaunchKernelGGL(k_transpose_w, dim3((WT_FLOATS + 255) / 256), dim3(256), 0, s, dense, L, wT);
 }
 
 }  // namespace mamdr
