@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) {
         const int rep = map[lrow];
         if (rep != EMB_UNTOUCHED) {
             g += glin[rep];
-            if (!a.lin_keep_map) map[lrow] = EMB_UNTOUCHED;
+            map[lrow] = EMB_UNTOUCHED;
         }
         if (a.opt.optimizer == 2) {
             lin_m[lrow] += g;

@@ -186,7 +186,6 @@ struct EmbStepArgs {
     const float* alpha_log;
     int log_mask;
     int t_now;
-    int lin_keep_map;          // k_lin_sweep leaves the row maps alone
     int flags_done;            // duplicate flags were set by k_emb_catchup (lazy mode): skip k_emb_flag
     int apply_now;             // lazy mode: k_emb_reduce applies Adam step t_now to the rows it reduces
 };
