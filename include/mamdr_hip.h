@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 3
+#define MAMDR_ABI_VERSION 4
 
 enum {
     MAMDR_OK = 0,
@@ -67,7 +67,9 @@ enum {
     MAMDR_SEG_PN_GAMMA_SPEC = 22, MAMDR_SEG_PN_BETA_SPEC = 23,
     MAMDR_SEG_STAR_WD0 = 24, MAMDR_SEG_STAR_WD1 = 25, MAMDR_SEG_STAR_WD2 = 26,
     MAMDR_SEG_STAR_BD0 = 27, MAMDR_SEG_STAR_BD1 = 28, MAMDR_SEG_STAR_BD2 = 29,
-    MAMDR_SEG_COUNT = 30
+    /* uncertainty weighting: `log_var` [D] (model_zoo/uncertainty_weight/weighted_loss.py:23-28), last segment */
+    MAMDR_SEG_LOG_VAR = 30,
+    MAMDR_SEG_COUNT = 31
 };
 /* kernels whose device time can be profiled (mamdr_profile_*) */
 enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
@@ -92,6 +94,9 @@ typedef struct mamdr_config {
     float l2_emb;            /* deepctr.py:118 l2_reg_embedding = 1e-5 */
     float l2_linear;         /* DeepFM l2_reg_linear (deepctr default 1e-5); ignored by the mlp tower */
     float adam_beta1, adam_beta2, adam_eps; /* tf.train.AdamOptimizer defaults 0.9/0.999/1e-8 */
+    int32_t uncertainty_weight; /* 1: training loss = mean(BCE) / var_d^2 + log var_d + regularisers with one trainable
+                                   var per domain (model_zoo/uncertainty_weight/weighted_loss.py:30-43); evaluation is
+                                   unweighted, as the reference evaluates the base model.  mlp / deepfm towers only */
 } mamdr_config;
 
 const char* mamdr_last_error(void);

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR = 0, 1, 2
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -21,7 +21,8 @@ SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1",
              "lin_user", "lin_item", "lin_domain",
              # Star tower
              "Ws0", "Ws1", "Ws2", "bs0", "bs1", "bs2", "pn_gamma_shared", "pn_beta_shared", "pn_gamma_spec",
-             "pn_beta_spec", "Wd0", "Wd1", "Wd2", "bd0", "bd1", "bd2")
+             "pn_beta_spec", "Wd0", "Wd1", "Wd2", "bd0", "bd1", "bd2",
+             "log_var")
 KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP = range(6)
 KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep")
 
@@ -42,6 +43,7 @@ class Config(C.Structure):
         ("n_domain", C.c_int32), ("emb_dim", C.c_int32), ("hidden", C.c_int32 * 3), ("max_batch", C.c_int32),
         ("emb_trainable", C.c_int32), ("dropout", C.c_float), ("l2_emb", C.c_float), ("l2_linear", C.c_float),
         ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+        ("uncertainty_weight", C.c_int32),
     ]
 
 

@@ -22,7 +22,7 @@ def in_name_list(x, name_list):
 
 
 def build_model(config, dataset, engine_factory=None):
-    from .model_zoo import MAML, MAMDR, MLDG, DeepCTR, DomainNegotiation, Reptile, Star
+    from .model_zoo import MAML, MAMDR, MLDG, DeepCTR, DomainNegotiation, Reptile, Star, UncertaintyWeight
     name = config["model"]["name"]
     if "star" in name:
         model = Star(dataset, config, engine_factory)
@@ -34,7 +34,7 @@ def build_model(config, dataset, engine_factory=None):
     else:
         raise ValueError("model: {} not found".format(name))
     if "uncertainty_weight" in name:
-        raise NotImplementedError("UncertaintyWeight is a comparison baseline outside the hot path")
+        model = UncertaintyWeight(model)
     if "pcgrad" in name:
         raise NotImplementedError("PCGrad is a comparison baseline outside the hot path")
     if "meta" in name:

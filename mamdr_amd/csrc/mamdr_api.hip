@@ -215,6 +215,7 @@ void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
     a.n_rows_split = d.n;
     a.thresholds = c->thresholds;
     a.deepfm = c->deepfm ? 1 : 0;
+    a.uw_off = -1;
     if (c->deepfm && c->cfg.emb_trainable) {
         a.lin_user = c->params + c->lin_user_off;
         a.lin_item = c->params + c->lin_item_off;
@@ -504,13 +505,15 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         return fail(MAMDR_EINVAL, "max_batch must be a positive multiple of %d", TILE_ROWS);
     if (cfg->max_batch > 16384) return fail(MAMDR_EINVAL, "max_batch %d exceeds 16384", cfg->max_batch);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
+    if (cfg->uncertainty_weight && cfg->tower == MAMDR_TOWER_STAR)
+        return fail(MAMDR_ENOTBUILT, "uncertainty weighting is built for the mlp / deepfm towers only");
 
     mamdr_ctx* c = new (std::nothrow) mamdr_ctx();
     if (!c) return fail(MAMDR_EINVAL, "out of host memory");
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
     c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM;
-    c->L = DenseLayout::make(cfg->n_domain, c->deepfm);
+    c->L = DenseLayout::make(cfg->n_domain, c->deepfm, cfg->uncertainty_weight != 0);
     c->table_floats = cfg->emb_trainable ? ((int64_t)cfg->n_user + cfg->n_item) * EMB : 0;
     if (c->deepfm && cfg->emb_trainable) {
         // each 1-d table padded to 4 floats so that the dense block stays 16-B aligned
@@ -683,7 +686,7 @@ int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* c
         *count = cnt;
         return MAMDR_OK;
     }
-    if (seg >= MAMDR_SEG_STAR_WS0 && seg < MAMDR_SEG_COUNT) {      // Star segments are absent from this tower
+    if (seg >= MAMDR_SEG_STAR_WS0 && seg <= MAMDR_SEG_STAR_BD2) {  // Star segments are absent from this tower
         *offset = 0;
         *count = 0;
         return MAMDR_OK;
@@ -712,6 +715,7 @@ int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* c
             cnt = (c->deepfm && c->cfg.emb_trainable) ? c->cfg.n_item : 0;
             break;
         case MAMDR_SEG_LIN_DOMAIN: off = base + L.ld; cnt = L.ld_count; break;
+        case MAMDR_SEG_LOG_VAR: off = base + L.lv; cnt = L.lv_count; break;
         default: return fail(MAMDR_EINVAL, "unknown segment %d", seg);
     }
     *offset = off;
@@ -890,6 +894,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.map_i = c->map_i;
         ta.loss_part = c->loss_part;
         ta.fmq = c->fmq;
+        if (c->L.lv_count > 0) ta.uw_off = c->L.lv + domain;
 #ifdef MAMDR_STAMPS
         ta.stamps = c->stamps;
 #endif
@@ -921,6 +926,9 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         wa.ld_off = c->L.ld;
         wa.ld_count = c->L.ld_count;
         wa.l2_lin = c->cfg.l2_linear;
+        wa.lv_off = c->L.lv;
+        wa.lv_count = c->L.lv_count;
+        wa.uw_d = domain;
         wa.tiles = c->tiles;
         wa.n_tiles = c->n_tiles;
         wa.rows_pad = rows_pad;

@@ -27,9 +27,10 @@ constexpr int WT_FLOATS = H1 * H2 + H2 * H3 + 2 * EMB * H1;
 
 // dense block of the flat trainable vector, relative to the domain table start
 // (DeepFM appends its 1-d linear table of the domain feature, `ld`, behind the global bias)
+// (uncertainty weighting appends one trainable scalar per domain, `lv`, at the very end)
 struct DenseLayout {
-    int dm, w0, w1, w2, b0, b1, b2, wo, gb, ld, ld_count, count, alloc;
-    __host__ __device__ static DenseLayout make(int n_domain, bool deepfm = false) {
+    int dm, w0, w1, w2, b0, b1, b2, wo, gb, ld, ld_count, lv, lv_count, count, alloc;
+    __host__ __device__ static DenseLayout make(int n_domain, bool deepfm = false, bool uncertainty = false) {
         DenseLayout L;
         L.dm = 0;
         L.w0 = n_domain * EMB;
@@ -42,7 +43,9 @@ struct DenseLayout {
         L.gb = L.wo + H3;
         L.ld = L.gb + 1;
         L.ld_count = deepfm ? n_domain : 0;
-        L.count = L.ld + L.ld_count;
+        L.lv = L.ld + L.ld_count;
+        L.lv_count = uncertainty ? n_domain : 0;
+        L.count = L.lv + L.lv_count;
         L.alloc = (L.count + 3) & ~3;
         return L;
     }

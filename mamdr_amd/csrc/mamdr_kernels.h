@@ -59,6 +59,9 @@ struct TowerArgs {
     const float* lin_user;     // [n_user] / [n_item] 1-d tables; null = frozen at their zero initialisation
     const float* lin_item;
     float* fmq;                // train: [rows_pad][EMB] dlogit * (user + item embedding), for the domain-table gradient
+    // uncertainty weighting (model_zoo/uncertainty_weight/weighted_loss.py:30-43): the BCE term of the loss is
+    // divided by var^2, var = dense[uw_off] (the batch's domain); -1 = off
+    int uw_off;
     const float* wT;           // k_tower4 only: transposed W1 / W2 copies
     // eval outputs
     const float* thresholds;   // 500 fp32 AUC thresholds
@@ -101,6 +104,7 @@ struct WgradArgs {
     const float* frozen_sumsq; // [4] sums of squares: user, item table; DeepFM linear user, item table
     int ld_off, ld_count;      // DeepFM: linear domain table inside the dense block (regulariser l2_lin)
     float l2_lin;
+    int lv_off, lv_count, uw_d; // uncertainty weighting: per-domain scalars in the dense block, the batch's domain
     float* loss_out;           // nullable: 1 float
     const float* w0dom;        // W0[256:384, :] (live weights)
     float* w0dom_copy;         // its pre-update snapshot, read by k_update

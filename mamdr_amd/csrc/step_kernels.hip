@@ -509,7 +509,11 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
         if (!valid || part != 0) loss = 0.f;
         if (TRAIN) {
             const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
-            const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
+            float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
+            if (a.uw_off >= 0) {       // uncertainty weighting: d loss / d logit scales by 1 / var^2
+                const float var = P[a.uw_off];
+                dl *= 1.0f / (var * var);
+            }
             if (part == 0) {
                 a.dlogit[r0 + i] = dl;
                 a.domrow[r0 + i] = rowi[2 * TILE_ROWS + i];
@@ -878,13 +882,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     }
     if ((int)blockIdx.x == n_work) {
         // ---- one extra workgroup: loss of the step = mean BCE + regularisers
-        if (g.loss_out == nullptr) return;
+        if (g.loss_out == nullptr && g.lv_count == 0) return;
         float* r4 = red;
         const float reg = reg_terms(g.dense, g.dm_count, g.l2_emb, g.frozen_sumsq, g.ld_off, g.ld_count, g.l2_lin, r4);
         float ls = 0.f;
         for (int e = tid; e < g.n_loss_tiles; e += 256) ls += g.loss_part[e];
         ls = block_sum_256(ls, r4);
-        if (tid == 0) g.loss_out[0] = ls / (float)g.rows + reg;
+        const float mean_bce = ls / (float)g.rows;
+        if (g.lv_count > 0) {
+            // uncertainty weighting: loss = mean(BCE) / var^2 + log var + regularisers;
+            // d loss / d var = -2 mean(BCE) / var^3 + 1 / var for the batch's domain, 0 for the others
+            // (written for every domain: slab 0 is the only slab that carries this region)
+            const float var = g.dense[g.lv_off + g.uw_d];
+            if (tid < g.lv_count)
+                g.slabs[g.lv_off + tid] = tid == g.uw_d ? (-2.0f * mean_bce / (var * var * var) + 1.0f / var) : 0.f;
+            if (tid == 0 && g.loss_out) g.loss_out[0] = (1.0f / (var * var)) * mean_bce + __logf(var) + reg;
+            return;
+        }
+        if (tid == 0) g.loss_out[0] = mean_bce + reg;
         return;
     }
     WSTAMP(0);

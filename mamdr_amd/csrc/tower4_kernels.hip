@@ -309,7 +309,11 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         const float zc = __logf(pc / (1.0f - pc));
         const float loss = fmaxf(zc, 0.f) - zc * y + __logf(1.0f + __expf(-fabsf(zc)));
         const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
-        const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
+        float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.0f;
+        if (a.uw_off >= 0) {           // uncertainty weighting: d loss / d logit scales by 1 / var^2
+            const float var = P[a.uw_off];
+            dl *= 1.0f / (var * var);
+        }
         if (lane == 0) {
             a.dlogit[r0 + row] = dl;
             a.domrow[r0 + row] = rowi[8 + row];

@@ -62,7 +62,7 @@ def auc_from_histogram(hist):
 class TowerEngine(object):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False,
                  tower="mlp", emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None,
-                 dropout_seed=1024, l2_linear=1e-5):
+                 dropout_seed=1024, l2_linear=1e-5, uncertainty_weight=False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("TowerEngine needs a HIP device (no CPU fallback for the MAMDR hot path)")
@@ -76,7 +76,7 @@ class TowerEngine(object):
         max_batch = (self.batch_size + 15) // 16 * 16
         cfg = L.Config(L.ABI_VERSION, tower_id, self.n_user, self.n_item, self.n_domain, emb_dim,
                        (C.c_int32 * 3)(*hidden), max_batch, 1 if emb_trainable else 0, float(dropout),
-                       float(l2_emb), float(l2_linear), 0.9, 0.999, 1e-8)
+                       float(l2_emb), float(l2_linear), 0.9, 0.999, 1e-8, 1 if uncertainty_weight else 0)
         self.eval_batch = max_batch
         handle = C.c_void_p()
         L.check(self.lib.mamdr_create(C.byref(cfg), C.c_void_p(self.stream.cuda_stream), C.byref(handle)))

@@ -7,3 +7,4 @@ from .domain_negotiation import DomainNegotiation  # noqa: F401
 from .mamdr import MAMDR  # noqa: F401
 from .star import Star  # noqa: F401
 from .mldg import MLDG  # noqa: F401
+from .uncertainty_weight import UncertaintyWeight  # noqa: F401

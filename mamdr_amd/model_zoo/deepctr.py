@@ -46,6 +46,8 @@ def initial_tensors(rs, n_user, n_item, n_domain, emb_dim, hidden, user_emb=None
     t["lin_user"] = np.zeros(n_user, np.float32)
     t["lin_item"] = np.zeros(n_item, np.float32)
     t["lin_domain"] = np.zeros(n_domain, np.float32)
+    # uncertainty weighting: `log_var` [D], Constant(1.) (uncertainty_weight/weighted_loss.py:23-28)
+    t["log_var"] = np.ones(n_domain, np.float32)
     return t
 
 
@@ -75,9 +77,12 @@ class DeepCTR(BaseModel):
         if factory is None:
             from ..engine import TowerEngine
             factory = TowerEngine
+        kw = {}
+        if "uncertainty_weight" in mc["name"]:     # run.py:49-50: the weighted loss joins the compiled model
+            kw["uncertainty_weight"] = True
         eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
                       emb_trainable=bool(tc["emb_trainable"]), tower=tower, emb_dim=mc["user_dim"],
-                      hidden=tuple(mc["hidden_dim"]))
+                      hidden=tuple(mc["hidden_dim"]), **kw)
         self.init_rs = np.random.RandomState(self.dataset.seed)
         pre = bool(tc["load_pretrain_emb"])
         self.pretrained = (self.dataset.user_emb, self.dataset.item_emb) if pre else (None, None)

@@ -33,7 +33,7 @@ L2_LIN = F32(1e-5)          # deepctr DeepFM l2_reg_linear default
 DENSE_NAMES = ("W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
 
 
-def param_names(emb_trainable, deepfm=False):
+def param_names(emb_trainable, deepfm=False, uncertainty=False):
     """Flat meta-vector order = Keras `trainable_weights` order:
     trainable embeddings in feature order (deepctr.py:102), DNN kernels, DNN
     biases, final dense kernel, global bias.  DeepFM (A.8) adds the 1-d linear
@@ -44,6 +44,8 @@ def param_names(emb_trainable, deepfm=False):
     emb = ("user_emb", "item_emb") if emb_trainable else ()
     lin = ("lin_user", "lin_item") if (emb_trainable and deepfm) else ()
     tail = ("lin_domain",) if deepfm else ()
+    # uncertainty weighting (model_zoo/uncertainty_weight/weighted_loss.py:23-28): one trainable scalar per domain
+    tail = tail + (("log_var",) if uncertainty else ())
     return emb + lin + ("domain_emb",) + DENSE_NAMES + tail
 
 
@@ -69,6 +71,9 @@ def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64)
     p["lin_user"] = np.zeros(n_user, F32)
     p["lin_item"] = np.zeros(n_item, F32)
     p["lin_domain"] = np.zeros(n_domain, F32)
+    # uncertainty weighting: `log_var` [D, 1], Constant(1.) (weighted_loss.py:23-28; despite its name it is
+    # used as the standard deviation: weight 1 / var^2, penalty log(var))
+    p["log_var"] = np.ones(n_domain, F32)
     return p
 
 
@@ -161,16 +166,29 @@ def train_masks(seed, step, n_rows, hidden, rate):
     return [rng.dropout_mask(seed, step, l, n_rows, hidden[l], rate) for l in range(3)]
 
 
-def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, deepfm=False):
-    """one batch: total loss (BCE mean + regularisers) and dense gradients."""
+def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, deepfm=False,
+                   uncertainty=False):
+    """one batch: total loss (BCE mean + regularisers) and dense gradients.
+    uncertainty (weighted_loss.py:30-43): loss = mean(BCE / var^2 + log var) + regularisers with
+    var = log_var[domain of the batch's first row]."""
     B = uid.shape[0]
     keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
     p, hs = forward(params, uid, pid, dom, masks, keep_scale, deepfm)
     y = label.astype(F32)
-    loss = F32(np.mean(bce_per_row(p, y), dtype=np.float64)) + reg_loss(params, frozen_sumsq, deepfm)
+    mean_bce = F32(np.mean(bce_per_row(p, y), dtype=np.float64))
     inside = ((p >= EPS_CLIP) & (p <= F32(1) - EPS_CLIP)).astype(F32)
     dlogit = ((p - y) * inside / F32(B)).astype(F32)
     g = {}
+    if uncertainty:
+        d0 = int(dom[0])
+        var = params["log_var"][d0]
+        w = F32(F32(1) / F32(var * var))
+        loss = F32(w * mean_bce) + F32(np.log(var, dtype=F32)) + reg_loss(params, frozen_sumsq, deepfm)
+        dlogit = (dlogit * w).astype(F32)
+        g["log_var"] = np.zeros_like(params["log_var"])
+        g["log_var"][d0] = F32(F32(-2) * mean_bce / F32(var * var * var)) + F32(F32(1) / var)
+    else:
+        loss = mean_bce + reg_loss(params, frozen_sumsq, deepfm)
     g["wo"] = (hs[3].T @ dlogit[:, None]).astype(F32)
     g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
     dh = (dlogit[:, None] * params["wo"][:, 0][None, :]).astype(F32)
@@ -258,11 +276,12 @@ class OracleModel(object):
     """Stand-in for the compiled Keras model: train_on_batch / evaluate."""
 
     def __init__(self, params, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64),
-                 dropout_seed=1024, tower="mlp"):
+                 dropout_seed=1024, tower="mlp", uncertainty=False):
         self.params = params
         self.emb_trainable = emb_trainable
         self.deepfm = tower == "deepfm"
-        self.names = param_names(emb_trainable, self.deepfm)
+        self.uncertainty = bool(uncertainty)
+        self.names = param_names(emb_trainable, self.deepfm, self.uncertainty)
         self.opt = Optimizer(params, self.names)
         self.rate = float(dropout)
         self.lr = lr
@@ -284,7 +303,7 @@ class OracleModel(object):
         masks = train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else \
             [np.ones((B, h), F32) for h in self.hidden]
         loss, g, _ = loss_and_grads(self.params, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
-                                    self.frozen_sumsq(), self.deepfm)
+                                    self.frozen_sumsq(), self.deepfm, self.uncertainty)
         if self.use_sgd:
             self.opt.sgd(self.params, g, self.lr)
         else:
@@ -306,7 +325,7 @@ class OracleModel(object):
         d total_loss / d theta at the current weights to `acc` (a flat vector); no update,
         learning phase 0 = dropout off.  The dropout counter still advances (one per step)."""
         _, g, _ = loss_and_grads(self.params, uid, pid, dom, label, None, 0.0, self.emb_trainable,
-                                 self.frozen_sumsq(), self.deepfm)
+                                 self.frozen_sumsq(), self.deepfm, self.uncertainty)
         acc += flatten(g, self.names)
         self.step += 1
 

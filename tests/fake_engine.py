@@ -15,7 +15,8 @@ F32 = np.float32
 
 class FakeEngine(object):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False, tower="mlp",
-                 emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5):
+                 emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5,
+                 uncertainty_weight=False):
         if tower not in ("mlp", "deepfm"):
             raise NotImplementedError(tower)
         self.tower = tower
@@ -26,7 +27,7 @@ class FakeEngine(object):
         rs = np.random.RandomState(0)
         params = otower.init_params(rs, n_user, n_item, n_domain, emb_dim, hidden)
         self.oracle = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=dropout, hidden=hidden,
-                                         dropout_seed=dropout_seed, tower=tower)
+                                         dropout_seed=dropout_seed, tower=tower, uncertainty=uncertainty_weight)
         self.segments = {}
         off = 0
         for name in self.oracle.names:

@@ -32,7 +32,7 @@ def env():
 
 
 def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao10", emb_trainable=False,
-                 tower="mlp"):
+                 tower="mlp", uncertainty=False):
     engine, synthetic = env
     g = synthetic.generate(shape, batch_size=batch, seed=seed, scale=scale)
     rs = np.random.RandomState(seed)
@@ -47,8 +47,10 @@ def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao1
         if emb_trainable:
             params["lin_user"] = (rs.standard_normal(g["n_user"]) * 0.05).astype(F32)
             params["lin_item"] = (rs.standard_normal(g["n_item"]) * 0.05).astype(F32)
+    if uncertainty:            # distinct per-domain scales around the initial value 1
+        params["log_var"] = (1.0 + rs.uniform(-0.3, 0.3, g["n_domain"])).astype(F32)
     eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=dropout,
-                             emb_trainable=emb_trainable, tower=tower)
+                             emb_trainable=emb_trainable, tower=tower, uncertainty_weight=uncertainty)
     if not emb_trainable:
         eng.bind_table("user_emb", params["user_emb"])
         eng.bind_table("item_emb", params["item_emb"])
@@ -58,7 +60,7 @@ def make_problem(env, scale=0.05, batch=256, dropout=0.5, seed=7, shape="taobao1
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
     eng.set_weights(eng.pack(params))
     model = otower.OracleModel({k: v.copy() for k, v in params.items()}, emb_trainable=emb_trainable, dropout=dropout,
-                               lr=1e-3, dropout_seed=eng.dropout_seed, tower=tower)
+                               lr=1e-3, dropout_seed=eng.dropout_seed, tower=tower, uncertainty=uncertainty)
     return g, eng, model
 
 
@@ -805,4 +807,52 @@ def test_pass_window_matches_oracle(env):
     # a pass longer than the split is rejected
     with pytest.raises(Exception):
         eng.train_steps(d, pass_rows=n + 1)
+    eng.close()
+
+
+# ------------------------------------------------------------------ uncertainty weighting
+@pytest.mark.parametrize("batch", [256, 4096])
+def test_uncertainty_weighted_step_matches_oracle(env, batch):
+    """weighted_loss.py:30-43 on the step kernels (4-row tower at 256, 16-row tower at 4096): every gradient
+    scaled by 1 / var_d^2, d loss / d var_d, zero gradient for the other domains' scalars; a few Adam steps;
+    evaluation unweighted."""
+    g, eng, model = make_problem(env, batch=batch, dropout=0.5, uncertainty=True, scale=0.3 if batch > 256 else 0.05)
+    assert eng.segments["log_var"][1] == 10 and model.names[-1] == "log_var"
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=11)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_step = -(-n // batch)
+    for step in (0, n_step - 1):
+        idx = perm[step * batch:(step + 1) * batch]
+        masks = otower.train_masks(model.seed, model.step, len(idx), model.hidden, 0.5)
+        loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                               cols["label"][idx], masks, 0.5, False, None, False, True)
+        want = eng.pack({**{k: np.zeros_like(v) for k, v in model.params.items()}, **grads}).cpu().numpy()
+        loss_t = torch.zeros(1, device=eng.device)
+        w0 = eng.get_weights()
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = (w0 - eng.get_weights()).cpu().numpy()
+        eng.set_weights(w0)
+        model.step += 1
+        for name, (off, cnt) in eng.segments.items():
+            w = want[off:off + cnt]
+            np.testing.assert_allclose(got[off:off + cnt], w, rtol=2e-4, atol=max(2e-6 * max(np.abs(w).max(), 1e-3), 1e-7),
+                                       err_msg=name)
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+        lv = got[eng.segments["log_var"][0]:][:10]
+        assert lv[d] != 0 and not np.delete(lv, d).any()
+    k = min(3, n_step)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=k, lr=1e-3)
+    for s_ in range(k):
+        ii = perm[s_ * batch:(s_ + 1) * batch]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=1e-2)
+    # evaluation is the base model's: unweighted loss
+    loss_g, _ = eng.evaluate(d, "val")
+    loss_o, _ = model.evaluate(g["data"]["val"][d], eng.eval_batch)
+    assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
     eng.close()

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation", "mlp_meta_reptile", "mlp",
-                                  "mlp_meta_maml", "deepfm_meta_domain_negotiation_finetune", "mlp_meta_mldg"])
+                                  "mlp_meta_maml", "deepfm_meta_domain_negotiation_finetune", "mlp_meta_mldg",
+                                  "mlp_uncertainty_weight"])
 def test_run_config_on_gpu(tmp_path, name):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -37,7 +38,7 @@ def test_run_config_on_gpu(tmp_path, name):
     assert abs(res["avg_auc"] - avg_auc) < 1e-12
     z = np.load(os.path.join(rdir, run, "model_parameters.npz"))
     # dense block: 139777 tower weights + domain table (+ DeepFM's linear domain table), padded to 4 floats
-    n_dense = 139777 + 128 * 10 + (10 if "deepfm" in name else 0)
+    n_dense = 139777 + 128 * 10 + (10 if "deepfm" in name else 0) + (10 if "uncertainty_weight" in name else 0)
     assert z["weights"].shape[0] == (n_dense + 3) // 4 * 4 and np.isfinite(z["weights"]).all()
 
 

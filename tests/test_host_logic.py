@@ -61,7 +61,9 @@ def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
     # substring order: 'domain_negotiation' wins over 'mamdr' (run.py:55-58)
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_meta_domain_negotiation_mamdr"), ds, FakeEngine)) \
         is DomainNegotiation
-    for bad in ("mmoe", "mlp_pcgrad", "mlp_uncertainty_weight", "wdl"):
+    from mamdr_amd.model_zoo import UncertaintyWeight
+    assert type(cli.build_model(tiny_config(tmp_path, "mlp_uncertainty_weight"), ds, FakeEngine)) is UncertaintyWeight
+    for bad in ("mmoe", "mlp_pcgrad", "wdl"):
         with pytest.raises(NotImplementedError):
             cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
     with pytest.raises(NotImplementedError):      # the CPU stand-in engine has no Star tower (the HIP engine does)

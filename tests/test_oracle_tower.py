@@ -145,3 +145,33 @@ def test_shuffle_perm_semantics():
             # an element can be emitted at most `buf-1`... positions early: out[i] <= i + buf - 1
             assert np.all(perm <= np.arange(n) + buf - 1)
     assert not np.array_equal(rng.shuffle_perm(100, 100, 1), rng.shuffle_perm(100, 100, 2))
+
+
+def test_uncertainty_weighted_loss_gradients():
+    """weighted_loss.py:30-43: loss = mean(BCE) / var^2 + log var (+ regularisers), var = log_var[domain]:
+    every gradient scales by 1 / var^2 and d loss / d var = -2 mean(BCE) / var^3 + 1 / var (finite differences)."""
+    rs = np.random.RandomState(4)
+    p = tower.init_params(rs, 30, 20, 3, emb_dim=8, hidden=(16, 8, 4))
+    p["log_var"] = np.array([1.3, 0.7, 1.0], F32)
+    B = 12
+    uid = rs.randint(0, 30, B).astype(np.int32)
+    pid = rs.randint(0, 20, B).astype(np.int32)
+    dom = np.full(B, 1, np.int32)
+    y = (rs.uniform(size=B) < 0.4).astype(F32)
+    masks = [np.ones((B, h), F32) for h in (16, 8, 4)]
+    loss_u, g_u, _ = tower.loss_and_grads(p, uid, pid, dom, y, masks, 0.0, False, None, False, True)
+    loss_p, g_p, _ = tower.loss_and_grads(p, uid, pid, dom, y, masks, 0.0, False, None, False, False)
+    reg = tower.reg_loss(p)
+    var = 0.7
+    np.testing.assert_allclose(float(loss_u), (float(loss_p) - float(reg)) / var ** 2 + np.log(var) + float(reg), rtol=1e-5)
+    two_l2 = 2e-5
+    for n in ("W0", "W2", "b1", "wo", "gb"):
+        np.testing.assert_allclose(g_u[n], g_p[n] / var ** 2, rtol=1e-4, atol=1e-7)
+    # the domain table carries its regulariser unweighted
+    np.testing.assert_allclose(g_u["domain_emb"] - two_l2 * p["domain_emb"],
+                               (g_p["domain_emb"] - two_l2 * p["domain_emb"]) / var ** 2, rtol=1e-4, atol=1e-9)
+    mean_bce = float(loss_p) - float(reg)
+    want = np.zeros(3)
+    want[1] = -2 * mean_bce / var ** 3 + 1 / var
+    np.testing.assert_allclose(g_u["log_var"], want, rtol=1e-5, atol=1e-7)
+    assert tower.param_names(False, False, True)[-1] == "log_var"
