@@ -236,6 +236,12 @@ int mamdr_adam_apply(float* d_p, float* d_m, float* d_v, const float* d_g, float
 /* dst[i] = src[i]: SetVarOp.__call__ / K.batch_get_value without the host round
  * trip (utils/tool.py:36-45, maml.py:189-194) */
 int mamdr_copy(float* d_dst, const float* d_src, int64_t n, void* stream);
+/* PCGrad projection of one auxiliary gradient onto the running gradient, both flat device vectors, in place.
+ * Replaces `PCGrad.PCGrad(final_grads, current_grads, aux_grads)` with final_grads IS current_grads
+ * (model_zoo/pcgrad.py:107-124,152-160).  The n_seg tensors are given as HOST arrays: element offset, number of
+ * slices along the last axis (rows), slice length (cols <= 4096); at most 24 tensors.  Bit-identical to numpy. */
+int mamdr_pcgrad_project(float* d_final, float* d_aux, const int64_t* h_offsets, const int64_t* h_rows,
+                         const int32_t* h_cols, int32_t n_seg, void* stream);
 
 /* --- host-side helper: tf.data shuffle(buffer_size) order of range(n)
  *     (utils/dataset.py:27-37), splitmix64-driven; writes n int32 to HOST memory. */

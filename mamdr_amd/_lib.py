@@ -78,6 +78,7 @@ SIGNATURES = {
     "mamdr_apply_accumulated": (C.c_int, [_VP, _VP, _F, _F, _I64, _VP]),
     "mamdr_adam_apply": (C.c_int, [_VP, _VP, _VP, _VP, _F, _F, _F, _F, _F, _F, _F, _I64, _VP]),
     "mamdr_copy": (C.c_int, [_VP, _VP, _I64, _VP]),
+    "mamdr_pcgrad_project": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "mamdr_shuffle_perm": (C.c_int, [_I64, _I64, _U64, _VP]),
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
     "mamdr_profile_reset": (C.c_int, [_VP]),

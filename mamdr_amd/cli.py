@@ -22,7 +22,7 @@ def in_name_list(x, name_list):
 
 
 def build_model(config, dataset, engine_factory=None):
-    from .model_zoo import MAML, MAMDR, MLDG, DeepCTR, DomainNegotiation, Reptile, Star, UncertaintyWeight
+    from .model_zoo import MAML, MAMDR, MLDG, DeepCTR, DomainNegotiation, PCGrad, Reptile, Star, UncertaintyWeight
     name = config["model"]["name"]
     if "star" in name:
         model = Star(dataset, config, engine_factory)
@@ -36,7 +36,7 @@ def build_model(config, dataset, engine_factory=None):
     if "uncertainty_weight" in name:
         model = UncertaintyWeight(model)
     if "pcgrad" in name:
-        raise NotImplementedError("PCGrad is a comparison baseline outside the hot path")
+        model = PCGrad(model)
     if "meta" in name:
         if "domain_negotiation" in name:
             model = DomainNegotiation(model)

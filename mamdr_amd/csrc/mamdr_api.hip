@@ -1145,6 +1145,26 @@ int mamdr_adam_apply(float* d_p, float* d_m, float* d_v, const float* d_g, float
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }
+int mamdr_pcgrad_project(float* d_final, float* d_aux, const int64_t* h_offsets, const int64_t* h_rows,
+                         const int32_t* h_cols, int32_t n_seg, void* stream) {
+    if (!d_final || !d_aux || !h_offsets || !h_rows || !h_cols) return fail(MAMDR_EINVAL, "null pointer");
+    if (n_seg < 0 || n_seg > PCG_MAX_SEG) return fail(MAMDR_EINVAL, "n_seg %d outside [0, %d]", n_seg, PCG_MAX_SEG);
+    PcgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.fin = d_final;
+    a.aux = d_aux;
+    a.n_seg = n_seg;
+    for (int i = 0; i < n_seg; ++i) {
+        if (h_offsets[i] < 0 || h_rows[i] < 0 || h_cols[i] <= 0 || h_cols[i] > 4096)
+            return fail(MAMDR_EINVAL, "tensor %d: bad offset / rows / cols", i);
+        a.off[i] = h_offsets[i];
+        a.cols[i] = h_cols[i];
+        a.row_start[i + 1] = a.row_start[i] + h_rows[i];
+    }
+    launch_pcgrad(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
 int mamdr_copy(float* d_dst, const float* d_src, int64_t n, void* stream) {
     if (!d_dst || !d_src) return fail(MAMDR_EINVAL, "null pointer");
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");

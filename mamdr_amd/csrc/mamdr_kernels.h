@@ -271,5 +271,16 @@ void launch_accumulate(float* acc, const float* a, const float* b, const float* 
 void launch_apply_accumulated(float* dst, float* acc, float divisor, float scale, int64_t n, hipStream_t s);
 void launch_adam_apply(float* p, float* m, float* v, const float* g, float gscale, float alpha, float omb1, float omb2,
                        float eps, int64_t n, hipStream_t s);
+// PCGrad projection (model_zoo/pcgrad.py:152-160) over tensors described as (offset, rows, cols) slices
+constexpr int PCG_MAX_SEG = 24;
+struct PcgArgs {
+    float* fin;                // running gradient (= current gradient), updated in place
+    float* aux;                // auxiliary gradient, projected in place
+    int n_seg;
+    int64_t off[PCG_MAX_SEG];
+    int64_t row_start[PCG_MAX_SEG + 1];   // prefix sums of the row counts
+    int cols[PCG_MAX_SEG];
+};
+void launch_pcgrad(const PcgArgs& a, hipStream_t s);
 
 }  // namespace mamdr

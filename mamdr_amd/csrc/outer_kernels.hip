@@ -175,4 +175,62 @@ void launch_adam_apply(float* p, float* m, float* v, const float* g, float gscal
     run(n, AdamApply{p, m, v, g, gscale, alpha, omb1, omb2, eps}, s);
 }
 
+// ------------------------------------------------------------------ PCGrad projection
+// The reference does this in numpy on the host (model_zoo/pcgrad.py:152-160): per tensor and per slice along
+// the last axis, d = sum(cur * aux); where d > 0: aux -= (d / ||cur||) * cur; cur += aux.  numpy reduces with
+// its pairwise summation (8 running sums over blocks of <= 128 elements, halves above that); this kernel walks
+// one slice per thread in exactly that order, so the result matches numpy bit for bit (tested against vectors
+// produced by the reference's own method).  Slices are short (<= 256 elements) and few outside the tables.
+namespace {
+template <typename F>
+__device__ float np_pairwise_sum(const F& f, int i0, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, f(i0 + i));
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = f(i0 + j);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], f(i0 + i + j));
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, f(i0 + i));
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_pairwise_sum(f, i0, n2), np_pairwise_sum(f, i0 + n2, n - n2));
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_pcgrad(const PcgArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.row_start[a.n_seg]) return;
+    int sgm = 0;
+    while (row >= a.row_start[sgm + 1]) ++sgm;
+    const int n = a.cols[sgm];
+    const int64_t base = a.off[sgm] + (row - a.row_start[sgm]) * n;
+    float* cur = a.fin + base;
+    float* aux = a.aux + base;
+    const float dot = __fadd_rn(0.f, np_pairwise_sum([&](int i) { return __fmul_rn(cur[i], aux[i]); }, 0, n));
+    if (dot > 0.f) {
+        const float nrm2 = __fadd_rn(0.f, np_pairwise_sum([&](int i) { return __fmul_rn(cur[i], cur[i]); }, 0, n));
+        // sqrtf and '/' are the correctly rounded IEEE operations here (HIP's __fsqrt_rn is the native
+        // approximation unless OCML_BASIC_ROUNDED_OPERATIONS is defined)
+        const float q = dot / sqrtf(nrm2);
+        for (int i = 0; i < n; ++i) aux[i] = __fsub_rn(aux[i], __fmul_rn(q, cur[i]));
+    }
+    for (int i = 0; i < n; ++i) cur[i] = __fadd_rn(cur[i], aux[i]);
+}
+void launch_pcgrad(const PcgArgs& a, hipStream_t s) {
+    const int64_t rows = a.row_start[a.n_seg];
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_pcgrad, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a);
+}
+
 }  // namespace mamdr

@@ -221,6 +221,44 @@ class TowerEngine(object):
         L.check(self.lib.mamdr_apply_accumulated(_ptr(dst), _ptr(acc), float(divisor), float(scale),
                                                  dst.numel(), self._s()))
 
+    def segment_shapes(self):
+        """{segment: (slices along the last axis, slice length)} of the Keras variables behind the segments --
+        what numpy's axis=-1 reductions in the reference's PCGrad see (model_zoo/pcgrad.py:152-160)."""
+        D = self.n_domain
+        out = {}
+        for name, (off, cnt) in self.segments.items():
+            if name in ("user_emb", "item_emb", "domain_emb"):
+                out[name] = (cnt // 128, 128)
+            elif name in ("W0", "Ws0"):
+                out[name] = (384, 256)
+            elif name in ("W1", "Ws1"):
+                out[name] = (256, 128)
+            elif name in ("W2", "Ws2"):
+                out[name] = (128, 64)
+            elif name in ("Wd0", "Wd1", "Wd2"):
+                cols = {"Wd0": 256, "Wd1": 128, "Wd2": 64}[name]
+                out[name] = (cnt // cols, cols)
+            elif name in ("bd0", "bd1", "bd2", "pn_gamma_spec", "pn_beta_spec"):
+                out[name] = (D, cnt // D)
+            elif name in ("wo", "lin_user", "lin_item", "lin_domain", "log_var", "gb"):
+                out[name] = (cnt, 1)
+            else:                                  # 1-d biases and PartitionedNorm shared vectors
+                out[name] = (1, cnt)
+        return out
+
+    def pcgrad_project(self, final, aux, tensors=None):
+        """PCGrad.PCGrad with final_grads is current_grads (pcgrad.py:107-124,152-160) on flat device vectors.
+        tensors: [(offset, rows, cols)], default = every segment inside the vectors."""
+        if tensors is None:
+            shapes = self.segment_shapes()
+            tensors = [(off, shapes[n][0], shapes[n][1]) for n, (off, cnt) in self.segments.items()
+                       if off + cnt <= final.numel()]
+        n = len(tensors)
+        offs = (C.c_int64 * n)(*[t[0] for t in tensors])
+        rows = (C.c_int64 * n)(*[t[1] for t in tensors])
+        cols = (C.c_int32 * n)(*[t[2] for t in tensors])
+        L.check(self.lib.mamdr_pcgrad_project(_ptr(final), _ptr(aux), offs, rows, cols, n, self._s()))
+
     # ------------------------------------------------------------ binding
     def bind_table(self, name, rows):
         """frozen pretrained table (deepctr.py:104-116), numpy [n, 128] fp32."""

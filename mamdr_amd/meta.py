@@ -156,6 +156,32 @@ def mldg_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
     return trace
 
 
+def pcgrad_epoch(eng, outer, cur, aux, seq, aux_plan, perm_fn, batch_size, lr, meta_lr, meta_train_step=0,
+                 grad_scale=1.0, windows=None):
+    """PCGrad as the reference implements it (model_zoo/pcgrad.py:62-124): the model is NOT reset between
+    domains (theta is the live model).  Per domain: accumulate d total_loss / d theta over its (meta-)train
+    pass at the current weights; for every sampled auxiliary domain accumulate its gradient at the same weights
+    and project it onto the running gradient (mamdr_pcgrad_project: pcgrad.py:152-160 with final is current);
+    one outer-Adam step of the live model with the result.  cur / aux: two full-size flat vectors.
+    aux_plan = {domain: [auxiliary domains]}."""
+    trace = []
+    for d in seq:
+        eng.bind_accumulator(cur)
+        cur.zero_()
+        run_pass(eng, d, perm_fn, batch_size, lr, trace, "pcgrad_query", meta_train_step, optimizer="accumulate",
+                 window=windows[d][0] if windows else None)
+        for a in aux_plan[d]:
+            eng.bind_accumulator(aux)
+            aux.zero_()
+            run_pass(eng, a, perm_fn, batch_size, lr, trace, "pcgrad_aux", 0, optimizer="accumulate",
+                     window=windows[a][0] if windows else None)
+            eng.pcgrad_project(cur, aux)
+        live = eng.get_weights().clone()
+        outer.apply(eng, live, cur, meta_lr, grad_scale)
+        eng.set_weights(live)
+    return trace
+
+
 def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, trace, merged,
              merged_method="plus", domain_regulation_step=0, batch_variant=False, sample_num=None, acc=None):
     """DR for one query domain (mamdr.py:60-108): phi is updated in place.  Reads theta

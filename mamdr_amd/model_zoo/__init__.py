@@ -8,3 +8,4 @@ from .mamdr import MAMDR  # noqa: F401
 from .star import Star  # noqa: F401
 from .mldg import MLDG  # noqa: F401
 from .uncertainty_weight import UncertaintyWeight  # noqa: F401
+from .pcgrad import PCGrad  # noqa: F401

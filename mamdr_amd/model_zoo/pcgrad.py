@@ -1,0 +1,53 @@
+"""PCGrad wrapper -- mirror of model_zoo/pcgrad.py (a comparison baseline of the paper).
+
+Per epoch (pcgrad.py:62-124): shuffle the domains; for each query domain accumulate the gradient of its train
+pass at the CURRENT model weights (no reset to a stored theta), sample `sample_num` auxiliary domains, project
+each one's pass-gradient onto the running gradient (`mamdr_pcgrad_project`, bit-identical to the reference's
+numpy) and take one outer-Adam step (lr = meta_learning_rate) of the model with the result.  The passes run
+the step kernels in accumulate mode (dropout off, no update).
+"""
+from .. import meta
+from .maml import MAML
+
+
+class PCGrad(MAML):
+    def train(self):
+        print("Start PCGrad training on model: {}".format(self.model_config["name"]))
+        tc = self.train_config
+        if tc["target_domain"] >= 0:
+            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        avg = tc["average_meta_grad"]
+        if avg == "mean" and tc["meta_train_step"] > 0:
+            grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])
+        elif avg in ("moving_mean", "drop"):
+            raise NotImplementedError("average_meta_grad '%s' is not built" % avg)
+        else:
+            grad_scale = 1.0
+        windows = self.build_meta_windows()
+        self._get_model_meta_parms()
+        if self.model.n_meta != self.model.n_params:
+            raise NotImplementedError("PCGrad over a meta-parameter subset (Star) is not built")
+        self.model.optimizer_reset()
+        outer = meta.OuterAdamState(self.model)
+        cur, aux = self.model.new_vector(), self.model.new_vector()
+        train_sequence = list(range(self.n_domain))
+        self.trace = []
+        for epoch in range(tc["epoch"]):
+            print("Epoch: {}".format(epoch), "-" * 30)
+            self.rng.shuffle(train_sequence)
+            aux_plan = {}
+            for idx in train_sequence:             # pcgrad.py:112-115
+                cand = list(train_sequence)
+                cand.remove(idx)
+                aux_plan[idx] = self.rng.sample(cand, k=min(tc["sample_num"], len(cand)))
+            self.trace += meta.pcgrad_epoch(self.model, outer, cur, aux, list(train_sequence), aux_plan, self.shuffler,
+                                            self.batch_size, self.learning_rate, tc["meta_learning_rate"],
+                                            tc["meta_train_step"], grad_scale, windows)
+            if epoch % tc["val_every_step"] == 0:
+                _, val_avg_auc, _, val_domain_auc = self.val()
+                if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):
+                    break
+                print("Test Result: ")
+                weights = self.model.get_weights()
+                self.val_and_test("test")          # loads the best checkpoint
+                self.model.set_weights(weights)

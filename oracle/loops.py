@@ -88,6 +88,38 @@ def mldg_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr
     return trace
 
 
+def tensor_views(model, flat):
+    """per-tensor views of a flat vector in the shapes the Keras variables have (the 1-d linear tables and the
+    uncertainty scalars are [n, 1] there) -- what numpy's axis=-1 reductions see in the reference."""
+    views, o = [], 0
+    for name in model.names:
+        p = model.params[name]
+        shape = (-1, 1) if name in ("lin_user", "lin_item", "lin_domain", "log_var") else p.shape
+        views.append(flat[o:o + p.size].reshape(shape))
+        o += p.size
+    return views
+
+
+def pcgrad_epoch(model, outer_opt, data, seq, aux_plan, perm_fn, batch_size, meta_lr, meta_train_step=0,
+                 grad_scale=1.0, windows=None):
+    """model_zoo/pcgrad.py:62-124: no reset between domains; gradient of the query domain's pass, each sampled
+    auxiliary domain's pass-gradient projected onto it (outer.pcgrad_project), one outer-Adam step of the model."""
+    trace = []
+    for d in seq:
+        cur = np.zeros_like(model.get_flat())
+        _pass(model, data, perm_fn, d, batch_size, trace, "pcgrad_query", meta_train_step, accumulate_into=cur,
+              window=windows[d][0] if windows else None)
+        for a in aux_plan[d]:
+            aux = np.zeros_like(cur)
+            _pass(model, data, perm_fn, a, batch_size, trace, "pcgrad_aux", 0, accumulate_into=aux,
+                  window=windows[a][0] if windows else None)
+            outer.pcgrad_project(tensor_views(model, cur), tensor_views(model, aux))
+        live = model.get_flat()
+        outer_opt.apply(live, cur, meta_lr, grad_scale)
+        model.set_flat(live)
+    return trace
+
+
 def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
                meta_train_step=0, grad_scale=1.0, windows=None):
     """first-order MAML, model_zoo/maml.py:62-116 with meta_split "train-train": per domain reset

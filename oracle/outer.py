@@ -68,3 +68,23 @@ def mamdr_apply_grads(old, grads, sample_num, meta_lr):
     old += (grads / F32(sample_num) * F32(meta_lr)).astype(F32)
     grads[...] = 0
     return old
+
+
+def pcgrad_project(final, aux):
+    """model_zoo/pcgrad.py:152-160 with `final_grads is current_grads`, as its train loop calls it
+    (pcgrad.py:107-124).  Per tensor and per slice along the last axis (rows of a kernel / table, the whole
+    vector of a bias): d = <cur, aux>; where d > 0 the auxiliary gradient loses d / ||cur|| times cur (the
+    reference divides by the norm, not its square, and projects where the dot product is POSITIVE); the result
+    is added to the running gradient.  fp32 throughout; numpy's own reductions (pairwise summation) are part of
+    the pinned arithmetic.  Mutates both lists in place, returns `final`."""
+    for k in range(len(final)):
+        cur, a = final[k], aux[k]
+        flat_cur = cur.reshape(-1, cur.shape[-1])
+        flat_aux = a.reshape(-1, a.shape[-1])
+        dots = np.sum(flat_cur * flat_aux, axis=-1)
+        hit = dots > 0
+        if hit.any():
+            norms = np.sqrt(np.add.reduce(flat_cur[hit] * flat_cur[hit], axis=-1))
+            flat_aux[hit] -= (dots[hit] / norms)[:, None] * flat_cur[hit]
+        flat_cur += flat_aux
+    return final

@@ -87,6 +87,10 @@ class FakeEngine(object):
         else:
             oouter.reptile_apply(dst.numpy(), acc.numpy(), scale)
 
+    def pcgrad_project(self, final, aux, tensors=None):
+        from oracle import loops as oloops
+        oouter.pcgrad_project(oloops.tensor_views(self.oracle, final.numpy()), oloops.tensor_views(self.oracle, aux.numpy()))
+
     # binding
     def bind_table(self, name, rows):
         self.oracle.params[name] = np.ascontiguousarray(rows, F32)

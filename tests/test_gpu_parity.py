@@ -856,3 +856,59 @@ def test_uncertainty_weighted_step_matches_oracle(env, batch):
     loss_o, _ = model.evaluate(g["data"]["val"][d], eng.eval_batch)
     assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
     eng.close()
+
+
+# ------------------------------------------------------------------ PCGrad projection: bit-exact vs the reference's numpy
+def test_pcgrad_projection_bit_exact_vs_reference_goldens(env, golden_dir):
+    """mamdr_pcgrad_project against vectors produced by the reference's own PCGrad.PCGrad
+    (tests/golden/make_pcgrad_goldens.py): the kernel walks every slice in numpy's pairwise-summation order."""
+    g, eng, model = make_problem(env)
+    G = np.load(os.path.join(golden_dir, "pcgrad_goldens.npz"))
+    n = int(G["n_tensors"])
+    tensors, off = [], 0
+    for i in range(n):
+        a = G["current_%d" % i]
+        cols = a.shape[-1]
+        tensors.append((off, a.size // cols, cols))
+        off += (a.size + 3) // 4 * 4           # 16-B aligned starts, as in the engine's flat vectors
+
+    def flat(prefix):
+        v = np.zeros(off, F32)
+        for i, (o, r, c) in enumerate(tensors):
+            v[o:o + r * c] = G["%s_%d" % (prefix, i)].ravel()
+        return torch.from_numpy(v).to(eng.device)
+
+    fin = flat("current")
+    for tag, step in (("aux1", "after1"), ("aux2", "after2")):
+        aux = flat(tag)
+        eng.pcgrad_project(fin, aux, tensors)
+        fh, ah = fin.cpu().numpy(), aux.cpu().numpy()
+        for i, (o, r, c) in enumerate(tensors):
+            assert same_bits(fh[o:o + r * c], G["%s_final_%d" % (step, i)].ravel()), (step, "final", i)
+            assert same_bits(ah[o:o + r * c], G["%s_aux_%d" % (step, i)].ravel()), (step, "aux", i)
+    # the engine's own tensor table covers the whole flat vector exactly once
+    shapes = eng.segment_shapes()
+    assert sum(r * c for r, c in shapes.values()) == sum(cnt for _, cnt in eng.segments.values())
+    eng.close()
+
+
+def test_pcgrad_epoch_matches_oracle(env):
+    """one PCGrad epoch (pcgrad.py:62-124) on three domains: accumulate-mode passes, bit-exact projection of
+    the auxiliary gradients, outer Adam on the live model."""
+    from mamdr_amd import meta
+    shape = dict(env[1].SHAPES["taobao10"], n_domain=3)
+    g, eng, model = make_problem(env, scale=0.15, batch=256, dropout=0.5, shape=shape)
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(3)]
+    make = _perm_fn_factory(sizes)
+    aux_plan = {1: [0, 2], 0: [2, 1], 2: [1]}
+    tr_o = oloops.pcgrad_epoch(model, otower.OuterAdam(model.get_flat().size), g["data"]["train"], [1, 0, 2], aux_plan,
+                               make(), 256, 0.003)
+    cur, aux = eng.new_vector(), eng.new_vector()
+    tr_g = meta.pcgrad_epoch(eng, meta.OuterAdamState(eng), cur, aux, [1, 0, 2], aux_plan, make(), 256, lr=1e-3,
+                             meta_lr=0.003)
+    assert tr_g == tr_o
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], 3, 0.003, name, max_frac=1e-2)
+    assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == 0          # the inner optimiser never stepped
+    eng.close()

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation", "mlp_meta_reptile", "mlp",
                                   "mlp_meta_maml", "deepfm_meta_domain_negotiation_finetune", "mlp_meta_mldg",
-                                  "mlp_uncertainty_weight"])
+                                  "mlp_uncertainty_weight", "mlp_pcgrad"])
 def test_run_config_on_gpu(tmp_path, name):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -23,7 +23,7 @@ def test_run_config_on_gpu(tmp_path, name):
     cfg["model"]["name"] = name
     cfg["train"].update(epoch=3, patience=1, sample_num=2, meta_learning_rate=0.5,
                         result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
-    if "maml" in name or "mldg" in name:   # meta_learning_rate is the step of an outer ADAM, not an interpolation weight
+    if "maml" in name or "mldg" in name or "pcgrad" in name:   # meta_learning_rate is the step of an outer ADAM, not an interpolation weight
         cfg["train"]["meta_learning_rate"] = 0.003
     if "mldg" in name:      # the reference's MLDG config splits every domain 80 / 20 into meta-train / meta-val
         cfg["train"].update(meta_split="meta-train/val", meta_split_ratio=0.8)

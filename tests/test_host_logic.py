@@ -61,9 +61,10 @@ def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
     # substring order: 'domain_negotiation' wins over 'mamdr' (run.py:55-58)
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_meta_domain_negotiation_mamdr"), ds, FakeEngine)) \
         is DomainNegotiation
-    from mamdr_amd.model_zoo import UncertaintyWeight
+    from mamdr_amd.model_zoo import PCGrad, UncertaintyWeight
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_uncertainty_weight"), ds, FakeEngine)) is UncertaintyWeight
-    for bad in ("mmoe", "mlp_pcgrad", "wdl"):
+    assert type(cli.build_model(tiny_config(tmp_path, "mlp_pcgrad"), ds, FakeEngine)) is PCGrad
+    for bad in ("mmoe", "wdl"):
         with pytest.raises(NotImplementedError):
             cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
     with pytest.raises(NotImplementedError):      # the CPU stand-in engine has no Star tower (the HIP engine does)
@@ -141,6 +142,17 @@ def test_meta_epochs_follow_oracle_loops():
             assert tr_g[0][2] == -(-windows[1][0][1] // 64) and tr_g[1][2] == -(-(sizes[1] - windows[1][0][1]) // 64)
             assert np.array_equal(th_g.numpy(), th_o) and not acc_g.numpy().any()
             assert np.abs(th_o - theta0).max() > 1e-3
+    # PCGrad (pcgrad.py:62-124): query gradient + projected auxiliary gradients, outer Adam on the live model
+    e1, e2 = fresh(), fresh()
+    aux_plan = {1: [0, 2], 0: [2], 2: [1, 0]}
+    tr_o = oloops.pcgrad_epoch(e1.oracle, otower.OuterAdam(theta0.size), g["data"]["train"], [1, 0, 2], aux_plan,
+                               perm_fn_factory(), 64, 0.01)
+    cur_g, aux_g = torch.zeros(theta0.size), torch.zeros(theta0.size)
+    tr_g = meta.pcgrad_epoch(e2, meta.OuterAdamState(e2), cur_g, aux_g, [1, 0, 2], aux_plan, perm_fn_factory(), 64,
+                             1e-3, 0.01)
+    assert tr_g == tr_o and [t[0] for t in tr_g[:3]] == ["pcgrad_query", "pcgrad_aux", "pcgrad_aux"]
+    assert np.array_equal(e2.oracle.get_flat(), e1.oracle.get_flat())
+    assert np.abs(e1.oracle.get_flat() - theta0).max() > 1e-3
     # DN and Reptile (both variants)
     for fn_g, fn_o, kw in ((meta.dn_epoch, oloops.dn_epoch, {}), (meta.reptile_epoch, oloops.reptile_epoch, {}),
                            (meta.reptile_epoch, oloops.reptile_epoch, {"batch_variant": True})):

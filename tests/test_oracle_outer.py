@@ -84,3 +84,22 @@ def test_mamdr_batch_and_domain_weights(G, method):
             outer.mamdr_apply_grads(p, acc, 5, 0.1)
             assert same_bits(p, want)
             assert same_bits(outer.mamdr_domain_weights(n1, merged), wdw)
+
+
+def test_pcgrad_projection_matches_reference_goldens(golden_dir):
+    """oracle.outer.pcgrad_project against vectors produced by the reference's own PCGrad.PCGrad
+    (tests/golden/make_pcgrad_goldens.py): two successive projections, every tensor shape of the tower."""
+    import os
+    from oracle import outer as oouter
+    G = np.load(os.path.join(golden_dir, "pcgrad_goldens.npz"))
+    n = int(G["n_tensors"])
+    cur = [G["current_%d" % i].copy() for i in range(n)]
+    for tag, step in (("aux1", "after1"), ("aux2", "after2")):
+        aux = [G["%s_%d" % (tag, i)].copy() for i in range(n)]
+        oouter.pcgrad_project(cur, aux)
+        for i in range(n):
+            assert np.array_equal(cur[i].view(np.uint32), G["%s_final_%d" % (step, i)].view(np.uint32)), (step, i)
+            assert np.array_equal(aux[i].view(np.uint32), G["%s_aux_%d" % (step, i)].view(np.uint32)), (step, i)
+    # both branches were exercised
+    d0 = np.sum(G["current_1"] * G["aux1_1"], axis=-1)
+    assert (d0 > 0).any() and (d0 <= 0).any()
