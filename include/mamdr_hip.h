@@ -38,7 +38,9 @@ enum {
 };
 
 /* tower kinds: run.py:37-47 + model_zoo/DeepCTR/deepctr.py:24-50 name registry */
-enum { MAMDR_TOWER_MLP = 0, MAMDR_TOWER_DEEPFM = 1, MAMDR_TOWER_STAR = 2 };
+enum { MAMDR_TOWER_MLP = 0, MAMDR_TOWER_DEEPFM = 1, MAMDR_TOWER_STAR = 2,
+       /* deepctr WDL (deepctr.py:29-32): linear tables + DNN = DeepFM without the FM term; same segments */
+       MAMDR_TOWER_WDL = 3 };
 /* data splits: utils/dataset.py:79-92 */
 enum { MAMDR_SPLIT_TRAIN = 0, MAMDR_SPLIT_VAL = 1, MAMDR_SPLIT_TEST = 2 };
 /* optimisers: deepctr.py:55 (Adam) / specific_base_model.py:120, base_model.py:69 (SGD finetune) */

@@ -214,7 +214,7 @@ void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
     a.label = d.label;
     a.n_rows_split = d.n;
     a.thresholds = c->thresholds;
-    a.deepfm = c->deepfm ? 1 : 0;
+    a.deepfm = c->deepfm ? (c->cfg.tower == MAMDR_TOWER_WDL ? 2 : 1) : 0;
     a.uw_off = -1;
     if (c->deepfm && c->cfg.emb_trainable) {
         a.lin_user = c->params + c->lin_user_off;
@@ -494,7 +494,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     *out = nullptr;
     if (cfg->abi_version != MAMDR_ABI_VERSION)
         return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
-    if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM && cfg->tower != MAMDR_TOWER_STAR)
+    if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM && cfg->tower != MAMDR_TOWER_STAR &&
+        cfg->tower != MAMDR_TOWER_WDL)
         return fail(MAMDR_EINVAL, "unknown tower kind %d", cfg->tower);
     if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
         return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
@@ -512,7 +513,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (!c) return fail(MAMDR_EINVAL, "out of host memory");
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
-    c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM;
+    c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM || cfg->tower == MAMDR_TOWER_WDL;   // linear tables (+ FM term)
     c->L = DenseLayout::make(cfg->n_domain, c->deepfm, cfg->uncertainty_weight != 0);
     c->table_floats = cfg->emb_trainable ? ((int64_t)cfg->n_user + cfg->n_item) * EMB : 0;
     if (c->deepfm && cfg->emb_trainable) {

@@ -434,9 +434,10 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(xr);
         const f32x4 it = *reinterpret_cast<const f32x4*>(xr + EMB);
         const f32x4 d = *reinterpret_cast<const f32x4*>(xr + 2 * EMB);
-        fm_ui = u + it;
-        const f32x4 t = u * it + fm_ui * d;
-        float s = (t[0] + t[1]) + (t[2] + t[3]);
+        const float fmw = a.deepfm == 1 ? 1.0f : 0.0f;    // 2 = WDL: linear tables only, no FM term
+        fm_ui = fmw * (u + it);
+        const f32x4 t = u * it + (u + it) * d;
+        float s = fmw * ((t[0] + t[1]) + (t[2] + t[3]));
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
                 const float* xr = acts_t + (size_t)row * ACT_LD;
                 const int k = col & (EMB - 1);
                 const float other = (col < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
-                v = fmaf(rowf[3 * TILE_ROWS + row], other, v);
+                if (a.deepfm == 1) v = fmaf(rowf[3 * TILE_ROWS + row], other, v);
             }
             dxe_t[(size_t)row * DXN + col] = v;
         });

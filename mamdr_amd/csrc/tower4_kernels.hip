@@ -214,7 +214,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         const int row = tid >> 7, k = tid & 127;
         const float* xr = smem + T4_XS + row * XDIM;
         const float u = xr[k], it = xr[EMB + k], dd = xr[2 * EMB + k];
-        float s = u * it + (u + it) * dd;
+        float s = a.deepfm == 1 ? u * it + (u + it) * dd : 0.f;      // 2 = WDL: no FM term
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) rowf[16 + w] = s;                // wave w = 2 row + half
         __syncthreads();
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     if (FM) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
         const int row = tid >> 7, k = tid & 127;
         const float* xr = smem + T4_XS + row * XDIM;
-        a.fmq[(size_t)(r0 + row) * EMB + k] = rowf[12 + row] * (xr[k] + xr[EMB + k]);
+        a.fmq[(size_t)(r0 + row) * EMB + k] = a.deepfm == 1 ? rowf[12 + row] * (xr[k] + xr[EMB + k]) : 0.f;
     }
 
     T4STAMP(7);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                 const float* xr = smem + T4_XS + row * XDIM;
                 const int k = ecol & (EMB - 1);
                 const float other = (ecol < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
-                v = fmaf(rowf[12 + row], other, v);
+                if (a.deepfm == 1) v = fmaf(rowf[12 + row], other, v);
             }
             dxe_t[(size_t)row * (2 * EMB) + ecol] = v;
         }

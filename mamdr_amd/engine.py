@@ -72,7 +72,7 @@ class TowerEngine(object):
         self.n_user, self.n_item, self.n_domain = int(n_user), int(n_item), int(n_domain)
         self.batch_size = int(batch_size)
         self.dropout_seed = int(dropout_seed) & 0xFFFFFFFF
-        tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR}[tower]
+        tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR, "wdl": L.TOWER_WDL}[tower]
         max_batch = (self.batch_size + 15) // 16 * 16
         cfg = L.Config(L.ABI_VERSION, tower_id, self.n_user, self.n_item, self.n_domain, emb_dim,
                        (C.c_int32 * 3)(*hidden), max_batch, 1 if emb_trainable else 0, float(dropout),

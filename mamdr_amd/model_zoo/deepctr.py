@@ -4,7 +4,8 @@
 containing `mlp` build the 3 x 128-d embedding -> DNN(hidden_dim) -> Dense(1) -> sigmoid
 tower (deepctr.py:95-136) on the HIP engine; names containing `deepfm` add the linear
 tables and the FM second-order term to the logit (deepctr.py:36-38, SURVEY A.8);
-wdl / nfm / autoint / ccpm / pnn are out of scope and raise.  Initial tensors follow the reference's initialisers (glorot normal for the
+`wdl` is the same without the FM term (deepctr.py:29-32); nfm / autoint / ccpm / pnn are out of scope
+ and raise.  Initial tensors follow the reference's initialisers (glorot normal for the
 kernels, zeros for biases, N(0, 1e-4^2) for the domain table and for user/item tables
 without pretraining, constants from the pretrained tables otherwise) drawn from a numpy
 stream seeded with dataset.seed -- TF's own streams are not reproducible.
@@ -15,7 +16,7 @@ import numpy as np
 
 from .base_model import BaseModel
 
-OUT_OF_SCOPE = ("wdl", "nfm", "autoint", "ccpm", "pnn")
+OUT_OF_SCOPE = ("nfm", "autoint", "ccpm", "pnn")
 
 
 def glorot_normal(rs, fan_in, fan_out, shape):
@@ -59,6 +60,8 @@ class DeepCTR(BaseModel):
         name = self.model_config["name"]
         if "mlp" in name:
             tower = "mlp"
+        elif "wdl" in name:               # deepctr.py:29-32: linear tables + DNN (DeepFM without the FM term)
+            tower = "wdl"
         elif any(k in name for k in OUT_OF_SCOPE):
             raise NotImplementedError("tower '%s': deepctr WDL/NFM/AutoInt/CCPM/PNN are outside the hot path "
                                       "(SURVEY.md section 2.1) and are not built" % name)

@@ -133,13 +133,16 @@ def gather(params, uid, pid, dom):
                            params["domain_emb"][dom]], axis=1)
 
 
-def fm_and_linear(params, x, uid, pid, dom):
+def fm_and_linear(params, x, uid, pid, dom, with_fm=True):
     """DeepFM extras (A.8): sum_f w_f[id_f] + 1/2 sum_k [(sum_f e_fk)^2 - sum_f e_fk^2] over the three
-    128-d fields = sum_k (u i + u d + i d)_k."""
+    128-d fields = sum_k (u i + u d + i d)_k.  with_fm=False: the linear ("wide") part only = deepctr's WDL
+    (model_zoo/DeepCTR/deepctr.py:29-32: final_logit = linear_logit + dnn_logit)."""
     E = params["domain_emb"].shape[1]
     u, i, d = x[:, :E], x[:, E:2 * E], x[:, 2 * E:]
-    fm = np.sum((u * i + u * d + i * d).astype(np.float64), axis=1).astype(F32)
     lin = (params["lin_user"][uid] + params["lin_item"][pid] + params["lin_domain"][dom]).astype(F32)
+    if not with_fm:
+        return lin
+    fm = np.sum((u * i + u * d + i * d).astype(np.float64), axis=1).astype(F32)
     return (fm + lin).astype(F32)
 
 
@@ -156,8 +159,8 @@ def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1), deepfm=False):
         hs.append(a)
         h = a
     logit = (h @ params["wo"]).astype(F32)[:, 0] + params["gb"][0]
-    if deepfm:
-        logit = (logit + fm_and_linear(params, x, uid, pid, dom)).astype(F32)
+    if deepfm:                                   # 1 / True: DeepFM, 2: WDL (linear part only)
+        logit = (logit + fm_and_linear(params, x, uid, pid, dom, deepfm != 2)).astype(F32)
     p = sigmoid(logit)
     return p, hs
 
@@ -204,10 +207,11 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
         # d fm / d e_f = sum of the other two fields' embeddings; d linear / d w_f[id] = 1
         x = hs[0]
         u, it, d = x[:, :E], x[:, E:2 * E], x[:, 2 * E:]
-        dh = dh.copy()
-        dh[:, :E] += dlogit[:, None] * (it + d)
-        dh[:, E:2 * E] += dlogit[:, None] * (u + d)
-        dh[:, 2 * E:] += dlogit[:, None] * (u + it)
+        if deepfm != 2:                          # WDL has no FM term
+            dh = dh.copy()
+            dh[:, :E] += dlogit[:, None] * (it + d)
+            dh[:, E:2 * E] += dlogit[:, None] * (u + d)
+            dh[:, 2 * E:] += dlogit[:, None] * (u + it)
         two_l2_lin = F32(2) * L2_LIN
         nd = params["lin_domain"].shape[0]
         gl = np.bincount(dom, weights=dlogit.astype(np.float64), minlength=nd)
@@ -279,7 +283,7 @@ class OracleModel(object):
                  dropout_seed=1024, tower="mlp", uncertainty=False):
         self.params = params
         self.emb_trainable = emb_trainable
-        self.deepfm = tower == "deepfm"
+        self.deepfm = {"deepfm": 1, "wdl": 2}.get(tower, 0)      # tower with linear tables (+ FM term for 1)
         self.uncertainty = bool(uncertainty)
         self.names = param_names(emb_trainable, self.deepfm, self.uncertainty)
         self.opt = Optimizer(params, self.names)

@@ -17,7 +17,7 @@ class FakeEngine(object):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False, tower="mlp",
                  emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5,
                  uncertainty_weight=False):
-        if tower not in ("mlp", "deepfm"):
+        if tower not in ("mlp", "deepfm", "wdl"):
             raise NotImplementedError(tower)
         self.tower = tower
         self.n_user, self.n_item, self.n_domain = n_user, n_item, n_domain

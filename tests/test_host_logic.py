@@ -64,7 +64,8 @@ def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
     from mamdr_amd.model_zoo import PCGrad, UncertaintyWeight
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_uncertainty_weight"), ds, FakeEngine)) is UncertaintyWeight
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_pcgrad"), ds, FakeEngine)) is PCGrad
-    for bad in ("mmoe", "wdl"):
+    assert type(cli.build_model(tiny_config(tmp_path, "wdl"), ds, FakeEngine)) is DeepCTR
+    for bad in ("mmoe", "nfm"):
         with pytest.raises(NotImplementedError):
             cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
     with pytest.raises(NotImplementedError):      # the CPU stand-in engine has no Star tower (the HIP engine does)
