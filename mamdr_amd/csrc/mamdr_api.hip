@@ -186,14 +186,14 @@ struct Prof {
     EventPair e{nullptr, nullptr};
     Prof(mamdr_ctx* c_, int k_) : c(c_), k(k_) {
         if (c->profile && c->ev[k].size() < 200000) {
-            hipEventCreate(&e.a);
-            hipEventCreate(&e.b);
-            hipEventRecord(e.a, c->stream);
+            (void)hipEventCreate(&e.a);
+            (void)hipEventCreate(&e.b);
+            (void)hipEventRecord(e.a, c->stream);
         }
     }
     ~Prof() {
         if (e.a) {
-            hipEventRecord(e.b, c->stream);
+            (void)hipEventRecord(e.b, c->stream);
             c->ev[k].push_back(e);
         }
     }
@@ -626,13 +626,13 @@ int mamdr_destroy(mamdr_ctx* c) {
     if (!c) return MAMDR_OK;
     for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k)
         for (EventPair& p : c->ev[k]) {
-            hipEventDestroy(p.a);
-            hipEventDestroy(p.b);
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
         }
     void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     delete c;
     return MAMDR_OK;
 }
@@ -1222,8 +1222,8 @@ int mamdr_profile_reset(mamdr_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k) {
         for (EventPair& p : c->ev[k]) {
-            hipEventDestroy(p.a);
-            hipEventDestroy(p.b);
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
         }
         c->ev[k].clear();
     }
