@@ -146,6 +146,7 @@ int64_t mamdr_optimizer_steps(const mamdr_ctx* ctx);
  * Adam slots from outside the library or REPLACING them (K.batch_get_value / SetVarOp, maml.py:181-194;
  * mamdr_copy / mamdr_interp / ... on the bound vectors).  mamdr_eval_domain, mamdr_gather_rows,
  * mamdr_optimizer_reset, mamdr_bind_state and SGD / accumulate steps synchronise by themselves.
+ * A non-null d_loss_out makes every step synchronise first (its regulariser term sums over all rows).
  * MAMDR_DENSE_ADAM=1 in the environment keeps the per-step dense sweep instead. */
 int mamdr_sync_tables(mamdr_ctx* ctx);
 

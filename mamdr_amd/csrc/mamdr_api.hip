@@ -854,6 +854,9 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
         const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+        // the reported loss carries l2 * sum(table^2) over EVERY row: bring lagging rows up to date first
+        // (only callers that ask for the per-step loss pay this flush; the meta loops do not)
+        if (d_loss_out) sync_tables(c);
         float step_alpha = lr;
         if (optimizer == MAMDR_OPT_ADAM) {
             c->adam_t += 1;

@@ -914,3 +914,74 @@ def test_pcgrad_epoch_matches_oracle(env):
         assert_adam_close(got[name], model.params[name], 3, 0.003, name, max_frac=1e-2)
     assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == 0          # the inner optimiser never stepped
     eng.close()
+
+
+# ------------------------------------------------------------------ the other BASELINE configs at full table / batch size
+@pytest.mark.parametrize("workload", ["taobao30", "amazon6", "amazon13"])
+def test_full_size_properties_other_baseline_configs(env, workload):
+    """BASELINE configs 3-5 at their full table sizes and batch sizes (Taobao-30 bs 4096 frozen; Amazon-6
+    DeepFM bs 1024 and Amazon-13 Star bs 8192 with trainable 79 M / 92 M-parameter tables; a 0.3 % sample of
+    the rows), checked through size-independent properties: bit-exact gather, the lazy table Adam bitwise equal
+    to the per-step dense sweep (weights and both Adam slots), bitwise run-to-run determinism, finite and
+    non-increasing loss."""
+    import bench
+    engine, synthetic = env
+    wl = bench.WORKLOADS[workload]
+    batch, trainable, tower = wl["batch"], bool(wl.get("emb_trainable")), wl.get("tower", "mlp")
+    g = synthetic.generate(wl["shape"], batch_size=batch, seed=123, row_scale={"amazon6": 0.003, "amazon13": 0.02}.get(workload, 1.0))
+    D = g["n_domain"]
+    if tower == "star":
+        from mamdr_amd.model_zoo.star import initial_tensors
+        params = initial_tensors(np.random.RandomState(1), g["n_user"], g["n_item"], D, 128, (256, 128, 64))
+    else:
+        params = bench.init_params(g, 1)
+        rs = np.random.RandomState(2)
+        params["user_emb"] = g["tables"]["user_emb"] if not trainable else \
+            (rs.standard_normal((g["n_user"], 128)) * 0.01).astype(F32)
+        params["item_emb"] = g["tables"]["item_emb"] if not trainable else \
+            (rs.standard_normal((g["n_item"], 128)) * 0.01).astype(F32)
+    sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(D)]
+    order = sorted(range(D), key=lambda k: -sizes[k])[:2]
+    perms = {k: orng.shuffle_perm(sizes[k], 10000, seed=5 + k) for k in order}
+
+    def run(dense):
+        os.environ["MAMDR_DENSE_ADAM"] = "1" if dense else "0"
+        try:
+            eng = bench.setup_engine(g, batch, trainable, tower)
+        finally:
+            os.environ.pop("MAMDR_DENSE_ADAM", None)
+        eng.set_weights(eng.pack(params))
+        losses = []
+        for rep_ in range(2):
+            for k in order:
+                n_steps = -(-sizes[k] // batch)
+                lt = torch.zeros(n_steps, device=eng.device)
+                eng.train_steps(k, perm=torch.from_numpy(perms[k]).to(eng.device), lr=1e-3, loss_out=lt)
+                losses.append(lt.cpu().numpy())
+        return eng, losses
+
+    eng, losses = run(False)
+    # bit-exact gather of the largest domain in shuffled order (first 4096 positions)
+    k = order[0]
+    cols = g["data"]["train"][k]
+    m = min(4096, sizes[k])
+    out = eng.gather(k, "train", perm=torch.from_numpy(perms[k]).to(eng.device), n_rows=m).cpu().numpy()
+    w = eng.unpack(eng.weights)
+    U = w["user_emb"].reshape(-1, 128) if trainable else params["user_emb"]
+    I = w["item_emb"].reshape(-1, 128) if trainable else params["item_emb"]
+    idx = perms[k][:m]
+    want = np.concatenate([U[cols["uid"][idx]], I[cols["pid"][idx]], w["domain_emb"].reshape(D, 128)[cols["domain"][idx]]],
+                          axis=1)
+    assert same_bits(out, want)
+    state = (eng.weights.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy())
+    eng.close()
+    assert all(np.isfinite(l).all() for l in losses) and np.isfinite(state[0]).all()
+    first, last = losses[0], losses[-2]               # the largest domain's first and second pass
+    assert last.mean() <= first.mean() + 1e-3, (float(first.mean()), float(last.mean()))
+    # the same run again (dense table sweep for the trainable configs): same bits
+    eng2, losses2 = run(trainable)
+    for a, b, name in zip(state, (eng2.weights, eng2.adam_m, eng2.adam_v), ("weights", "adam_m", "adam_v")):
+        assert same_bits(a, b.cpu().numpy()), (workload, name)
+    for a, b in zip(losses, losses2):
+        assert same_bits(a, b)
+    eng2.close()
