@@ -417,7 +417,9 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     FwdW<H2, H3, PF2, 4> fw2;
     BwdW<H3, H2, H3, PFB2, 8> bw2;
     BwdW<H2, H1, H2, PFB1, 8> bw1;
-    BwdW<H1, DXN, H1, PFB0, 8> bw0;
+    // (the 384-wide variant keeps a 2-deep ring: 120 instead of 168 VGPRs, so that two workgroups share a CU)
+    constexpr int PFB0V = DXN > 2 * EMB ? 2 : PFB0;
+    BwdW<H1, DXN, H1, PFB0V, 8> bw0;
     STAMP(0);
     fw0.prefetch(P + a.L.w0, P + a.L.b0);
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
