@@ -798,6 +798,7 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& g, const TileDesc& t
 constexpr int W0DOM_FLOAT4 = EMB * H1 / 4;               // rows 256..383 of W0
 constexpr int W0DOM_COPY_WGS = W0DOM_FLOAT4 / 256;        // 32
 
+
 #ifdef MAMDR_STAMPS
 #define WSTAMP(k)                                                                             \
     do {                                                                                      \
@@ -865,12 +866,15 @@ __device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t,
             for (int i = 0; i < WG_KC / 2; ++i) acc = MAMDR_MFMA32(ap[2 * i * WG_LD], bp[2 * i * WG_LD], acc);
         }
     }
+    WSTAMP(2);
     // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* dst = g.slabs + (size_t)(blockIdx.x % g.n_groups) * g.slab_ld + t.dst_off +
                  (size_t)(wm * 32) * t.dst_ld + wn * 32;
     const int rb4 = 4 * (lane >> 5);
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + rb4) * t.dst_ld + c] = acc[r];
+    WSTAMP(3);
+    WSTAMP(4);
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
