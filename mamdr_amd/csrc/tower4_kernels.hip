@@ -21,7 +21,11 @@ namespace mamdr {
 constexpr int T4_ROWS = 4;
 constexpr int T4_THREADS = 512;
 constexpr int T4_WAVES = 8;
-constexpr int T4_PF = 8;                 // k rows in flight per wave
+constexpr int T4_PF = 8;                 // k rows in flight per wave (first layer, input-gradient layer)
+#ifndef MAMDR_T4_DEEP
+#define MAMDR_T4_DEEP 8
+#endif
+constexpr int T4_DEEP = MAMDR_T4_DEEP;   // ring depth of the short layers (diagnostic builds may override it)
 
 // LDS map (floats)
 constexpr int T4_XS = 0;                               // [4][384]
@@ -56,12 +60,16 @@ __device__ __forceinline__ void t4_load(float (&b)[V], const float* __restrict__
     }
 }
 
-// weight ring of one layer: W is [K][N] row-major, this wave owns k in [w*K/8, (w+1)*K/8)
-template <int K, int N>
+// weight ring of one layer: W is [K][N] row-major, this wave owns k in [w*K/8, (w+1)*K/8).
+// DEPTH k rows are in flight per wave.  Stamps (tools/stamp_tower.py): the first layer streams its 393 KB per
+// CU at ~60 B/clk, the L1 fill peak; holding the later layers' whole per-wave share in flight (DEPTH 32) cuts
+// the L1 / bwd1 contractions from 4.6 K / 2.7 K to 2.1 K / 2.1 K cycles but lengthens the phases the loads
+// now overlap by as much -- the 0.72 MB per workgroup is a bandwidth, not a latency, cost -- so 8 stays.
+template <int K, int N, int DEPTH = T4_PF>
 struct T4W {
     static constexpr int V = N / 64;
     static constexpr int KW = K / T4_WAVES;
-    static constexpr int PF = KW < T4_PF ? KW : T4_PF;
+    static constexpr int PF = KW < DEPTH ? KW : DEPTH;
     float b[PF][V];
     static __device__ __forceinline__ const float* wptr(const float* __restrict__ W) {
         return W + (size_t)((threadIdx.x >> 6) * KW) * N + V * (threadIdx.x & 63);
@@ -75,13 +83,13 @@ struct T4W {
 };
 
 // partial[w][4][N] = A[4][k-range of wave w] . W[k-range][N]   (into LDS `red`)
-template <int K, int N, typename Mid>
-__device__ __forceinline__ void t4_contract(T4W<K, N>& tw, const float* __restrict__ W, const float* As, int lda,
+template <int K, int N, int DEPTH, typename Mid>
+__device__ __forceinline__ void t4_contract(T4W<K, N, DEPTH>& tw, const float* __restrict__ W, const float* As, int lda,
                                             float* red, Mid mid) {
-    constexpr int V = T4W<K, N>::V, KW = T4W<K, N>::KW, PF = T4W<K, N>::PF;
+    constexpr int V = T4W<K, N, DEPTH>::V, KW = T4W<K, N, DEPTH>::KW, PF = T4W<K, N, DEPTH>::PF;
     static_assert(KW % 4 == 0 && KW % PF == 0, "k range of a wave must be a multiple of 4 and of the ring depth");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float* wp = T4W<K, N>::wptr(W);
+    const float* wp = T4W<K, N, DEPTH>::wptr(W);
     const float* ap = As + (lane & 3) * lda + w * KW;
     f32x4 acc[V];
 #pragma unroll
@@ -169,10 +177,10 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
     // weights and small parameters first: they do not depend on the gather
     T4W<XDIM, H1> w0;
-    T4W<H1, H2> w1;
-    T4W<H2, H3> w2;
+    T4W<H1, H2, T4_DEEP> w1;
+    T4W<H2, H3, T4_DEEP> w2;
     T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
-    T4W<H2, H1> v1;      // backward: dz2 . W1^T through W1T [128][256]
+    T4W<H2, H1, T4_DEEP> v1;      // backward: dz2 . W1^T through W1T [128][256]
     T4W<H1, 2 * EMB> v0; // DX: dz1 . W0[0:256,:]^T through W0T [256][256]
     T4STAMP(0);
     w0.prefetch(P + a.L.w0);
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const bool drop = a.use_dropout != 0;
 
     // ---- layer 0: 384 -> 256
-    t4_contract<XDIM, H1>(w0, P + a.L.w0, smem + T4_XS, XDIM, red, [&]() { w1.prefetch(P + a.L.w1); });
+    t4_contract(w0, P + a.L.w0, smem + T4_XS, XDIM, red, [&]() { w1.prefetch(P + a.L.w1); });
     T4STAMP(2);
     if (tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream
         const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
     T4STAMP(3);
     // ---- layer 1: 256 -> 128
-    t4_contract<H1, H2>(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
+    t4_contract(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
     __syncthreads();
     T4STAMP(4);
     {
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
     T4STAMP(5);
     // ---- layer 2: 128 -> 64 (the backward weights are requested behind its K loop)
-    t4_contract<H2, H3>(w2, P + a.L.w2, smem + T4_H2, H2, red, [&]() {
+    t4_contract(w2, P + a.L.w2, smem + T4_H2, H2, red, [&]() {
         v2.prefetch(a.wT + W2T_OFF);
         v1.prefetch(a.wT + W1T_OFF);
     });
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
     T4STAMP(7);
     // ---- backward: dz2 = (dz3 . W2^T) * gate(h2)
-    t4_contract<H3, H2>(v2, a.wT + W2T_OFF, smem + T4_DZ3, H3, red, []() {});
+    t4_contract(v2, a.wT + W2T_OFF, smem + T4_DZ3, H3, red, []() {});
     __syncthreads();
     {
         const int row = tid >> 7, col = tid & 127;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     __syncthreads();
     T4STAMP(8);
     // ---- dz1 = (dz2 . W1^T) * gate(h1); the domain-table gradient follows from dz1 by linearity
-    t4_contract<H2, H1>(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
+    t4_contract(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     T4STAMP(9);
     if (DX) {
         __syncthreads();           // dz1 complete, `red` free again
-        t4_contract<H1, 2 * EMB>(v0, a.wT + W0T_OFF, smem + T4_DZ1, H1, red, []() {});
+        t4_contract(v0, a.wT + W0T_OFF, smem + T4_DZ1, H1, red, []() {});
         __syncthreads();
         float* dxe_t = a.dxe + (size_t)r0 * (2 * EMB);
 #pragma unroll
