@@ -51,11 +51,38 @@ def build_model(config, dataset, engine_factory=None):
     return model
 
 
+def init_distributed():
+    """one process per GPU when launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment): RCCL process group; MAMDR_SHARE_GPU=1 (testing on a 1-GPU box) keeps every rank on device 0
+    over gloo.  Returns (rank, world_size)."""
+    import os
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("MAMDR_SHARE_GPU") == "1":
+            if torch.cuda.is_available():
+                torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl")
+    return dist.get_rank(), dist.get_world_size()
+
+
 def main(config, engine_factory=None):
     from .utils import MultiDomainDataset
+    rank, world = init_distributed()
+    name = config["model"]["name"]
+    if world > 1 and not ("meta" in name and "mamdr" in name and "domain_negotiation" not in name):
+        raise NotImplementedError("multi-process runs shard the MAMDR wrapper (DN + DR) only; got '%s'" % name)
     dataset = MultiDomainDataset(config["dataset"])
     model = build_model(config, dataset, engine_factory)
-    name = config["model"]["name"]
     if "separate" in name:
         avg_loss, avg_auc, domain_loss, domain_auc = model.separate_train_val_test()
     else:
@@ -63,10 +90,12 @@ def main(config, engine_factory=None):
         print("Test Result: ")
         avg_loss, avg_auc, domain_loss, domain_auc = model.val_and_test("test")
     if "finetune" in name:
-        model.load_model(model.checkpoint_path)
+        if rank == 0:           # (the sharded wrapper finetunes from its in-memory best theta / phi; only rank 0 wrote a file)
+            model.load_model(model.checkpoint_path)
         print("Finetune: ")
         avg_loss, avg_auc, domain_loss, domain_auc = model.separate_train_val_test(init_parms=False)
-    model.save_result(avg_loss, avg_auc, domain_loss, domain_auc)
+    if rank == 0:
+        model.save_result(avg_loss, avg_auc, domain_loss, domain_auc)
     return avg_loss, avg_auc, domain_loss, domain_auc
 
 

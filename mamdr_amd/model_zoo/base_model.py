@@ -70,11 +70,11 @@ class BaseModel(object):
             self.model.optimizer_reset()
         return self._finetune_domains(lambda d: weights, "adam" if init_parms else "sgd", self.learning_rate)
 
-    def _finetune_domains(self, start_weights, optimizer, lr):
+    def _finetune_domains(self, start_weights, optimizer, lr, domains=None, summarise=True):
         domain_loss, domain_auc = {}, {}
         keep = self.model.get_weights()
         best = self.model.new_vector()
-        for d in self.dataset.train_dataset:
+        for d in (self.dataset.train_dataset if domains is None else domains):
             self.model.set_weights(start_weights(d))
             print("Train on domain: {}".format(d))
             # Keras EarlyStopping(monitor=val_AUC, mode=max, min_delta=1e-4) + ModelCheckpoint(best only)
@@ -95,6 +95,8 @@ class BaseModel(object):
             p_loss, p_auc = self.evaluate_domain(d, "test")
             domain_loss[d], domain_auc[d] = float(p_loss), float(p_auc)
         self.model.set_weights(keep)
+        if not summarise:
+            return None, None, domain_loss, domain_auc
         return self._summarise("test", domain_loss, domain_auc)
 
     def val_and_test(self, mode):

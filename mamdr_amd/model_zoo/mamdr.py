@@ -13,7 +13,7 @@ phi_d starts as a fresh random initialisation of the whole model (mamdr.py:31-33
 the model's own initial weights (mamdr.py:29).  The reference draws order and samples from
 the unseeded global `random`; here they come from a `random.Random(dataset.seed)`.
 """
-from .. import meta
+from .. import meta, parallel
 from ..plan import EpochPlanner
 from .specific_base_model import SpecificBase
 
@@ -31,25 +31,41 @@ class MAMDR(SpecificBase):
             raise NotImplementedError("finetune_every_epoch (mamdr.py:110-143) is not built in this round")
         self._get_model_meta_parms()
         self.meta_weights = self._get_meta_weights()
+        # one process per GPU: query domains have a fixed owner (LPT over their train rows) that
+        # holds phi_i, runs its DR and evaluates it; every rank draws all D initialisations so that the
+        # streams stay aligned with the single-process run
+        rank, world = parallel.world()
+        sizes = [self.dataset.train_dataset[d]["n_data"] for d in range(self.n_domain)]
+        self.owner = parallel.lpt_partition(sizes, world)
         self.domain_weights = {}
         for domain_idx in range(self.n_domain):
-            self.domain_weights[domain_idx] = \
-                self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
+            w = self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
+            if self.owner[domain_idx] == rank:
+                self.domain_weights[domain_idx] = w
         self.model.optimizer_reset()
         planner = EpochPlanner(self.build_meta_sequence(), tc["sample_num"], tc["add_query_domain"],
                                tc["shuffle_sequence"], seed=self.dataset.seed)
         planner.rng = self.rng
         batch_variant = "batch" in self.model_config["name"]
         scratch = self.model.new_vector(meta=True)
+        bufs = {"delta": self.model.new_vector(meta=True), "zero": self.model.new_vector(meta=True), "merged": scratch}
+        if world > 1 and (batch_variant or tc["merged_method"] not in ("plus", "times")):
+            raise NotImplementedError("multi-process MAMDR: the per-support update variant only")
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             plan = planner.next_epoch()
-            self.trace += meta.mamdr_epoch(self.model, self.meta_weights, self.domain_weights, plan,
-                                           self.shuffler, self.batch_size, self.learning_rate,
-                                           tc["meta_learning_rate"], tc["merged_method"],
-                                           tc["domain_regulation_step"], batch_variant, tc["sample_num"],
-                                           scratch)
+            if world > 1:
+                self.trace += parallel.mamdr_epoch_sharded(self.model, meta, self.meta_weights, self.domain_weights,
+                                                           plan, self.owner, self.shuffler, self.batch_size,
+                                                           self.learning_rate, tc["meta_learning_rate"], bufs,
+                                                           tc["merged_method"], tc["domain_regulation_step"])
+            else:
+                self.trace += meta.mamdr_epoch(self.model, self.meta_weights, self.domain_weights, plan,
+                                               self.shuffler, self.batch_size, self.learning_rate,
+                                               tc["meta_learning_rate"], tc["merged_method"],
+                                               tc["domain_regulation_step"], batch_variant, tc["sample_num"],
+                                               scratch)
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

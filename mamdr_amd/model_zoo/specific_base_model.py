@@ -6,6 +6,7 @@ host deep copies (specific_base_model.py:44-62); the finetune stage restarts eve
 its best merged weights with plain SGD, lr 0.001 hard-coded (specific_base_model.py:99-162,
 :120 -- the reference's comment says Adam, the code says GradientDescent).
 """
+from .. import parallel
 from .maml import MAML
 
 FINETUNE_SGD_LR = 0.001     # specific_base_model.py:120
@@ -42,6 +43,10 @@ class SpecificBase(MAML):
         self.best_shared_weights = self.meta_weights.clone()
         self.best_domain_weights = {d: w.clone() for d, w in self.domain_weights.items()}
 
+    def save_model(self, path):
+        if parallel.world()[0] == 0:                   # one checkpoint file per run
+            self.base_model.save_model(path)
+
     def early_stop_step(self, metric):
         base = self.base_model
         if base.best_metric is None:
@@ -72,10 +77,16 @@ class SpecificBase(MAML):
             raise ValueError("Mode can be either val or test, not: {}".format(mode))
         domain_loss, domain_auc = {}, {}
         merged = self.model.new_vector(meta=True)
+        rank, world = parallel.world()
         for idx in store:
+            if world > 1 and idx not in specific:      # another rank owns this domain's phi
+                continue
             self._set_model_meta_parms(self._merge_weights(shared, specific[idx], out=merged))
             p_loss, p_auc = self.evaluate_domain(idx, mode)
             domain_loss[idx], domain_auc[idx] = float(p_loss), float(p_auc)
+        if world > 1:                                  # owners evaluated; every rank gets every scalar
+            local = {d: (domain_loss[d], domain_auc[d]) for d in domain_loss}
+            domain_loss, domain_auc = parallel.gather_domain_scalars(local, self.n_domain, self.model.device)
         return self.base_model._summarise(mode, domain_loss, domain_auc)
 
     def separate_train_val_test(self, init_parms=True):
@@ -85,4 +96,10 @@ class SpecificBase(MAML):
 
         def start(d):
             return self._merge_weights(self.best_shared_weights, self.best_domain_weights[d], out=merged)
+        rank, world = parallel.world()
+        if world > 1:                                  # every owner finetunes its own domains
+            mine = [d for d in self.dataset.train_dataset if d in self.best_domain_weights]
+            _, _, dl, da = self.base_model._finetune_domains(start, "sgd", FINETUNE_SGD_LR, domains=mine, summarise=False)
+            dl, da = parallel.gather_domain_scalars({d: (dl[d], da[d]) for d in dl}, self.n_domain, self.model.device)
+            return self.base_model._summarise("test", dl, da)
         return self.base_model._finetune_domains(start, "sgd", FINETUNE_SGD_LR)

@@ -151,3 +151,51 @@ def test_sharded_mamdr_epoch_gloo_world2(tmp_path):
         outs.append(out.decode())
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in out, out[-3000:]
+
+
+RUN_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import numpy as np
+from fake_engine import FakeEngine
+from mamdr_amd import cli, synthetic
+real = synthetic.generate
+synthetic.generate = lambda *a, **k: real(*a, **dict(k, emb_dim=8))          # tiny tables for CPU speed
+cfg = json.load(open({cfg!r}))
+res = cli.main(cfg, FakeEngine)                  # run.py's entry; init_distributed() reads RANK / WORLD_SIZE
+rank = int(os.environ.get("RANK", "0"))
+json.dump({{"avg_loss": res[0], "avg_auc": res[1], "domain_auc": {{str(k): v for k, v in res[3].items()}}}},
+          open({out!r} % rank, "w"))
+print("rank", rank, "ok")
+'''
+
+
+def test_run_entry_sharded_mamdr_gloo_world2(tmp_path):
+    """run.py's entry under 2 processes (gloo): query domains sharded by owner, DN all-reduce, owners evaluate
+    and finetune, every rank ends with the same per-domain results; they stay close to the 1-process run."""
+    import json
+    sys.path.insert(0, HERE)
+    from test_host_logic import tiny_config
+    cfg = tiny_config(tmp_path, "mlp_meta_mamdr_finetune", epochs=2)
+    cfg_path = tmp_path / "cfg.json"
+    cfg_path.write_text(json.dumps(cfg))
+    script = tmp_path / "run_worker.py"
+    script.write_text(RUN_WORKER.format(root=ROOT, here=HERE, cfg=str(cfg_path), out=str(tmp_path / "res_%d.json")))
+    results = {}
+    for world in (1, 2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE=str(world), MAMDR_SHARE_GPU="1",
+                   OMP_NUM_THREADS="2")
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        for r, p in enumerate(procs):
+            try:
+                out, _ = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
+        results[world] = [json.load(open(str(tmp_path / ("res_%d.json" % r)))) for r in range(world)]
+    a, b = results[2]
+    assert a == b and sorted(a["domain_auc"]) == ["0", "1", "2"]          # every rank holds every domain's result
+    assert np.isfinite(a["avg_loss"]) and abs(a["avg_auc"] - results[1][0]["avg_auc"]) < 0.1
