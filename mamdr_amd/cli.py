@@ -79,8 +79,9 @@ def main(config, engine_factory=None):
     from .utils import MultiDomainDataset
     rank, world = init_distributed()
     name = config["model"]["name"]
-    if world > 1 and not ("meta" in name and "mamdr" in name and "domain_negotiation" not in name):
-        raise NotImplementedError("multi-process runs shard the MAMDR wrapper (DN + DR) only; got '%s'" % name)
+    if world > 1 and not ("meta" in name and ("mamdr" in name or "domain_negotiation" in name)):
+        raise NotImplementedError("multi-process runs shard the MAMDR (DN + DR) and Domain Negotiation wrappers "
+                                  "only; got '%s'" % name)
     dataset = MultiDomainDataset(config["dataset"])
     model = build_model(config, dataset, engine_factory)
     if "separate" in name:
@@ -90,8 +91,7 @@ def main(config, engine_factory=None):
         print("Test Result: ")
         avg_loss, avg_auc, domain_loss, domain_auc = model.val_and_test("test")
     if "finetune" in name:
-        if rank == 0:           # (the sharded wrapper finetunes from its in-memory best theta / phi; only rank 0 wrote a file)
-            model.load_model(model.checkpoint_path)
+        model.load_model(model.checkpoint_path)      # the best checkpoint (kept on the device as well)
         print("Finetune: ")
         avg_loss, avg_auc, domain_loss, domain_auc = model.separate_train_val_test(init_parms=False)
     if rank == 0:

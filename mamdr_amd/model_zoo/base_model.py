@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-from .. import meta
+from .. import meta, parallel
 from .. import plan as mplan
 
 
@@ -64,10 +64,18 @@ class BaseModel(object):
     # ------------------------------------------------------------------ finetune / separate training
     def separate_train_val_test(self, init_parms=True):
         """base_model.py:41-109.  init_parms=False is the finetune stage: plain SGD with
-        `learning_rate` (base_model.py:69), restarted from the same weights for every domain."""
+        `learning_rate` (base_model.py:69), restarted from the same weights for every domain.
+        Under several processes (every rank holds the same weights) the domains are dealt round-robin."""
         weights = self.model.get_weights()
         if init_parms:
             self.model.optimizer_reset()
+        rank, world = parallel.world()
+        if world > 1:
+            mine = [d for i, d in enumerate(self.dataset.train_dataset) if i % world == rank]
+            _, _, dl, da = self._finetune_domains(lambda d: weights, "adam" if init_parms else "sgd", self.learning_rate,
+                                                  domains=mine, summarise=False)
+            dl, da = parallel.gather_domain_scalars({d: (dl[d], da[d]) for d in dl}, self.n_domain, self.model.device)
+            return self._summarise("test", dl, da)
         return self._finetune_domains(lambda d: weights, "adam" if init_parms else "sgd", self.learning_rate)
 
     def _finetune_domains(self, start_weights, optimizer, lr, domains=None, summarise=True):
@@ -105,9 +113,15 @@ class BaseModel(object):
         if mode == "test":
             self.load_model(self.checkpoint_path)      # best weights so far (base_model.py:121)
         domain_loss, domain_auc = {}, {}
-        for idx in (self.dataset.val_dataset if mode == "val" else self.dataset.test_dataset):
+        rank, world = parallel.world()
+        for i, idx in enumerate(self.dataset.val_dataset if mode == "val" else self.dataset.test_dataset):
+            if world > 1 and i % world != rank:        # every rank holds the same weights: deal the domains out
+                continue
             p_loss, p_auc = self.evaluate_domain(idx, mode)
             domain_loss[idx], domain_auc[idx] = float(p_loss), float(p_auc)
+        if world > 1:
+            local = {d: (domain_loss[d], domain_auc[d]) for d in domain_loss}
+            domain_loss, domain_auc = parallel.gather_domain_scalars(local, self.n_domain, self.model.device)
         return self._summarise(mode, domain_loss, domain_auc)
 
     def _summarise(self, mode, domain_loss, domain_auc):
@@ -132,9 +146,13 @@ class BaseModel(object):
 
     # ------------------------------------------------------------------ persistence
     def save_model(self, path):
+        aux = getattr(self.model, "aux", None)      # Star: PartitionedNorm moving statistics
+        if path == self.checkpoint_path:            # the best-so-far checkpoint is also kept on the device
+            self._best_in_memory = (self.model.get_weights().clone(), aux.clone() if aux is not None else None)
+        if parallel.world()[0] != 0:                # one set of files per run
+            return
         os.makedirs(osp.dirname(path) or ".", exist_ok=True)
         seg = self.model.segments
-        aux = getattr(self.model, "aux", None)      # Star: PartitionedNorm moving statistics
         np.savez(path, weights=self.model.get_weights().cpu().numpy(),
                  aux=aux.cpu().numpy() if aux is not None else np.zeros(0, np.float32),
                  segment_names=np.array(list(seg.keys())),
@@ -143,6 +161,12 @@ class BaseModel(object):
 
     def load_model(self, path):
         import torch
+        best = getattr(self, "_best_in_memory", None)
+        if path == self.checkpoint_path and best is not None:
+            self.model.set_weights(best[0])
+            if best[1] is not None:
+                self.model.aux.copy_(best[1])
+            return
         with np.load(path) as z:
             w = z["weights"]
             aux = z["aux"] if "aux" in z.files else np.zeros(0, np.float32)

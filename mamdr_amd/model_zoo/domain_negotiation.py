@@ -4,7 +4,7 @@ Per epoch (domain_negotiation.py:37-116): shuffle the meta sequence, set the mod
 theta once, run one pass per domain WITHOUT resetting the weights in between, then
 theta += beta * (theta~ - theta) as one elementwise kernel, validate, early-stop, test.
 """
-from .. import meta
+from .. import meta, parallel
 from .maml import MAML
 
 
@@ -33,14 +33,28 @@ class DomainNegotiation(MAML):
         meta_weights = self._get_meta_weights()
         self.model.optimizer_reset()
         meta_sequence = self.build_meta_sequence()
+        # one process per GPU: every rank runs its own sub-sequence from the same theta, one
+        # all-reduce of the displacements per epoch (parallel.dn_phase_sharded)
+        rank, world = parallel.world()
+        sizes = [self.dataset.train_dataset[d]["n_data"] for d in range(self.n_domain)]
+        owner = parallel.lpt_partition(sizes, world)
+        delta, zero = (self.model.new_vector(meta=True), self.model.new_vector(meta=True)) if world > 1 else (None, None)
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             if tc["shuffle_sequence"]:
                 self.rng.shuffle(meta_sequence)
-            self.trace += meta.dn_epoch(self.model, meta_weights, list(meta_sequence), self.shuffler,
-                                        self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                        tc["meta_train_step"])
+            if world > 1:
+                if tc["meta_train_step"] > 0:
+                    raise NotImplementedError("multi-process DN with meta_train_step > 0 is not built")
+                parallel.dn_phase_sharded(self.model, meta, meta_weights, [d for d in meta_sequence if owner[d] == rank],
+                                          self.shuffler, self.batch_size, self.learning_rate, tc["meta_learning_rate"],
+                                          self.trace, delta, zero)
+                self.model.set_weights(meta_weights)
+            else:
+                self.trace += meta.dn_epoch(self.model, meta_weights, list(meta_sequence), self.shuffler,
+                                            self.batch_size, self.learning_rate, tc["meta_learning_rate"],
+                                            tc["meta_train_step"])
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

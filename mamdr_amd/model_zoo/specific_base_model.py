@@ -43,10 +43,6 @@ class SpecificBase(MAML):
         self.best_shared_weights = self.meta_weights.clone()
         self.best_domain_weights = {d: w.clone() for d, w in self.domain_weights.items()}
 
-    def save_model(self, path):
-        if parallel.world()[0] == 0:                   # one checkpoint file per run
-            self.base_model.save_model(path)
-
     def early_stop_step(self, metric):
         base = self.base_model
         if base.best_metric is None:

@@ -173,10 +173,20 @@ print("rank", rank, "ok")
 def test_run_entry_sharded_mamdr_gloo_world2(tmp_path):
     """run.py's entry under 2 processes (gloo): query domains sharded by owner, DN all-reduce, owners evaluate
     and finetune, every rank ends with the same per-domain results; they stay close to the 1-process run."""
+    _run_entry_worlds(tmp_path, "mlp_meta_mamdr_finetune")
+
+
+def test_run_entry_sharded_domain_negotiation_gloo_world2(tmp_path):
+    """the same for the Domain Negotiation wrapper (BASELINE config 3's wrapper): sub-sequences + one all-reduce,
+    evaluation and finetune dealt round-robin over ranks that hold identical weights."""
+    _run_entry_worlds(tmp_path, "mlp_meta_domain_negotiation_finetune")
+
+
+def _run_entry_worlds(tmp_path, name):
     import json
     sys.path.insert(0, HERE)
     from test_host_logic import tiny_config
-    cfg = tiny_config(tmp_path, "mlp_meta_mamdr_finetune", epochs=2)
+    cfg = tiny_config(tmp_path, name, epochs=2)
     cfg_path = tmp_path / "cfg.json"
     cfg_path.write_text(json.dumps(cfg))
     script = tmp_path / "run_worker.py"
