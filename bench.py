@@ -46,14 +46,14 @@ WORKLOADS = {
     "taobao30": dict(shape="taobao30", batch=4096, name="mlp_meta_mamdr Taobao-30 bs=4096 (frozen pretrained tables)"),
     # trainable 128-d tables (79 M parameters): every step ends with TF1's dense Adam over all rows
     # (BASELINE.json configs[2]: DeepFM tower under Domain Negotiation)
-    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.02, tower="deepfm",
+    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.1, tower="deepfm",
                     name="deepfm_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
-                         "2% of the rows per epoch)"),
+                         "10% of the rows per epoch)"),
 }
 # (BASELINE.json configs[4]: Star tower under MAMDR, theta / phi over the tables + shared kernels / biases)
-WORKLOADS["amazon13"] = dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", row_scale=0.02,
+WORKLOADS["amazon13"] = dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", row_scale=0.1,
                              tower="star", name="star_meta_mamdr Amazon-13 bs=8192 (PartitionedNorm + StarFCN, "
-                                                "trainable tables, full-size tables, 2% of the rows per epoch)")
+                                                "trainable tables, full-size tables, 10% of the rows per epoch)")
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
 

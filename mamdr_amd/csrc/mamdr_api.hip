@@ -108,6 +108,11 @@ struct mamdr_ctx {
     int32_t* last_i = nullptr;
     float* alpha_log = nullptr;     // ring of the per-step alpha
     int log_cap = 1 << 16;
+    // Adam steps between forced flushes.  Every missed step is replayed exactly once either way; the flush
+    // replays at full occupancy, the per-row catch-up before a gather is a serial chain per row, so short gaps
+    // win until the flush's own table traffic shows (Amazon-6, 10 % rows: 7.7 K domain-steps/s without a period,
+    // 11.6 K at 16, 12.1 K at 32, 12.0 K at 64, 10.9 K at 256).  MAMDR_LAZY_FLUSH_EVERY overrides.
+    int flush_every = 32;
     int64_t flush_t = 0;            // adam_t of the last flush
     float* fmq = nullptr;           // DeepFM: [rows_pad][EMB]
     float* glin_u = nullptr;        // DeepFM + trainable tables: [rows_pad]
@@ -300,7 +305,9 @@ static void sync_tables(mamdr_ctx* c) {
 // batch, alpha of this step into the ring, rows of the batch brought up to adam_t - 1
 static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm, int64_t row_base, int rows,
                          int rows_pad, float alpha, float omb1, float omb2) {
-    if (c->adam_t - c->flush_t >= c->log_cap - 2) {       // the ring would wrap over a lagging row's range
+    // the ring must not wrap over a lagging row's range; and a bounded gap keeps the per-row serial replay of
+    // k_emb_catchup short (the flush replays the same steps at full occupancy)
+    if (c->adam_t - c->flush_t >= c->log_cap - 2 || c->adam_t - c->flush_t > c->flush_every) {
         c->adam_t -= 1;
         sync_tables(c);
         c->adam_t += 1;
@@ -578,6 +585,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->hasdup_i, rp * sizeof(int32_t));
         const char* dense_env = getenv("MAMDR_DENSE_ADAM");
         c->lazy = !(dense_env && atoi(dense_env) != 0);
+        if (const char* fe = getenv("MAMDR_LAZY_FLUSH_EVERY")) c->flush_every = atoi(fe) > 0 ? atoi(fe) : c->flush_every;
         if (const char* cap_env = getenv("MAMDR_LAZY_LOG_CAP")) {      // tests: force the alpha ring to wrap
             const int cap = atoi(cap_env);
             if (cap >= 4 && (cap & (cap - 1)) == 0) c->log_cap = cap;
