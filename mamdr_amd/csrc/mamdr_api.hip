@@ -185,20 +185,23 @@ SplitData* split_of(mamdr_ctx* c, int domain, int split) {
     return &c->data[(size_t)domain * 3 + split];
 }
 
+// attached = true: the events are not recorded around the launch but handed to it as its own start / stop
+// events (launch_tower*_train), which times the kernel itself like rocprofv3 does
 struct Prof {
     mamdr_ctx* c;
     int k;
+    bool attached;
     EventPair e{nullptr, nullptr};
-    Prof(mamdr_ctx* c_, int k_) : c(c_), k(k_) {
+    Prof(mamdr_ctx* c_, int k_, bool attached_ = false) : c(c_), k(k_), attached(attached_) {
         if (c->profile && c->ev[k].size() < 200000) {
             (void)hipEventCreate(&e.a);
             (void)hipEventCreate(&e.b);
-            (void)hipEventRecord(e.a, c->stream);
+            if (!attached) (void)hipEventRecord(e.a, c->stream);
         }
     }
     ~Prof() {
         if (e.a) {
-            (void)hipEventRecord(e.b, c->stream);
+            if (!attached) (void)hipEventRecord(e.b, c->stream);
             c->ev[k].push_back(e);
         }
     }
@@ -409,8 +412,8 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ta.map_i = c->map_i;
     ta.loss_part = c->loss_part;
     {
-        Prof p(c, MAMDR_KERNEL_FWD_BWD);
-        launch_tower_train(ta, c->stream);
+        Prof p(c, MAMDR_KERNEL_FWD_BWD, true);
+        launch_tower_train(ta, c->stream, p.e.a, p.e.b);
     }
     WgradArgs wa;
     memset(&wa, 0, sizeof(wa));
@@ -913,9 +916,9 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
         ta.wT = c->wT;
         {
-            Prof p(c, MAMDR_KERNEL_FWD_BWD);
-            if (use4) launch_tower4_train(ta, c->stream);
-            else launch_tower_train(ta, c->stream);
+            Prof p(c, MAMDR_KERNEL_FWD_BWD, true);
+            if (use4) launch_tower4_train(ta, c->stream, p.e.a, p.e.b);
+            else launch_tower_train(ta, c->stream, p.e.a, p.e.b);
         }
 
         if (c->cfg.emb_trainable && d_loss_out) {

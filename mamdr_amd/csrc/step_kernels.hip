@@ -12,6 +12,8 @@
 //
 // Replaces `model.train_on_batch` / `model.evaluate` of the compiled Keras model
 // (model_zoo/DeepCTR/deepctr.py:54-60,118-136; call sites model_zoo/mamdr.py:54,86,97).
+#include <hip/hip_ext.h>
+
 #include "mamdr_kernels.h"
 
 namespace mamdr {
@@ -608,19 +610,25 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     STAMP(9);
 }
 
-void launch_tower_train(const TowerArgs& a, hipStream_t s) {
+#define MAMDR_TIMED_LAUNCH(kernel, grid, block, lds, stream, e0, e1, arg)                          \
+    do {                                                                                          \
+        if (e0) hipExtLaunchKernelGGL((kernel), (grid), (block), (lds), (stream), (e0), (e1), 0, (arg)); \
+        else hipLaunchKernelGGL((kernel), (grid), (block), (lds), (stream), (arg));               \
+    } while (0)
+
+void launch_tower_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
+    const dim3 grid(tiles), block(TOWER_THREADS);
+    const size_t lds = tower_lds_bytes();
     if (a.deepfm) {
-        if (a.dxe)
-            hipLaunchKernelGGL((k_tower<true, 256, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
-        else
-            hipLaunchKernelGGL((k_tower<true, 0, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        if (a.dxe) MAMDR_TIMED_LAUNCH((k_tower<true, 256, true>), grid, block, lds, s, e0, e1, a);
+        else MAMDR_TIMED_LAUNCH((k_tower<true, 0, true>), grid, block, lds, s, e0, e1, a);
     } else if (a.dxe && a.dx_ld == XDIM) {
-        hipLaunchKernelGGL((k_tower<true, 384, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        MAMDR_TIMED_LAUNCH((k_tower<true, 384, false>), grid, block, lds, s, e0, e1, a);
     } else if (a.dxe) {
-        hipLaunchKernelGGL((k_tower<true, 256, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        MAMDR_TIMED_LAUNCH((k_tower<true, 256, false>), grid, block, lds, s, e0, e1, a);
     } else {
-        hipLaunchKernelGGL((k_tower<true, 0, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        MAMDR_TIMED_LAUNCH((k_tower<true, 0, false>), grid, block, lds, s, e0, e1, a);
     }
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {

@@ -14,6 +14,8 @@
 // current by k_update, so they stream rows exactly like the forward layers.  The dropout
 // stream, loss, and workspace layout are identical to k_tower; results differ only by fp32
 // summation order.  Replaces the same reference call sites (model_zoo/mamdr.py:54,86,97).
+#include <hip/hip_ext.h>
+
 #include "mamdr_kernels.h"
 
 namespace mamdr {
@@ -393,16 +395,24 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
 }
 
-void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
+#define MAMDR_TIMED_LAUNCH4(kernel)                                                               \
+    do {                                                                                          \
+        if (e0) hipExtLaunchKernelGGL((kernel), grid, block, lds, s, e0, e1, 0, a);               \
+        else hipLaunchKernelGGL((kernel), grid, block, lds, s, a);                                \
+    } while (0)
+
+void launch_tower4_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
+    const dim3 grid(tiles), block(T4_THREADS);
+    const size_t lds = tower4_lds_bytes();
     const bool dx = a.dxe != nullptr;
     if (a.deepfm) {
-        if (dx) hipLaunchKernelGGL((k_tower4<true, true>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
-        else hipLaunchKernelGGL((k_tower4<false, true>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+        if (dx) MAMDR_TIMED_LAUNCH4((k_tower4<true, true>));
+        else MAMDR_TIMED_LAUNCH4((k_tower4<false, true>));
     } else if (dx) {
-        hipLaunchKernelGGL((k_tower4<true, false>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+        MAMDR_TIMED_LAUNCH4((k_tower4<true, false>));
     } else {
-        hipLaunchKernelGGL((k_tower4<false, false>), dim3(tiles), dim3(T4_THREADS), tower4_lds_bytes(), s, a);
+        MAMDR_TIMED_LAUNCH4((k_tower4<false, false>));
     }
 }
 
