@@ -292,6 +292,57 @@ def test_trainable_tables_gradients_and_adam(env):
     eng.close()
 
 
+@pytest.mark.parametrize("tower", ["mlp", "deepfm"])
+def test_trainable_tables_heavy_duplicates(env, tower):
+    """A batch of 4096 in which one user occupies 3000 positions and five items share all of them: the row
+    gradient of a repeated row is the sum over its positions in position order (np.add.at in the oracle) --
+    lists long enough that the scanning wave has to drain its position list several times; with DeepFM the
+    1-d linear tables sum dlogit over the same lists.  One SGD step at lr 1 exposes the gradients; then the
+    lazy Adam path on the same batches against the oracle."""
+    g, eng, model = make_problem(env, scale=0.3, batch=4096, dropout=0.5, emb_trainable=True, tower=tower)
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = {k: v.copy() for k, v in g["data"]["train"][d].items()}
+    n = cols["uid"].shape[0]
+    assert n >= 2 * 4096
+    rs = np.random.RandomState(5)
+    hot = rs.choice(n, 3000 + 900, replace=False)
+    cols["uid"][hot[:3000]] = cols["uid"][hot[0]]                      # 3000 positions, one user
+    cols["uid"][hot[3000:]] = cols["uid"][hot[3000:3000 + 3]][rs.randint(0, 3, 900)]   # three users, ~300 each
+    items = cols["pid"][rs.choice(n, 5, replace=False)]
+    cols["pid"][:] = items[rs.randint(0, 5, n)]                        # five items share every position
+    eng.bind_domain_data(d, "train", cols["uid"], cols["pid"], cols["domain"], cols["label"])
+    perm = np.concatenate([hot[:3000], np.setdiff1d(np.arange(n), hot[:3000])]).astype(np.int32)   # hot user first
+    perm[:4096] = perm[:4096][rs.permutation(4096)]
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    idx = perm[:4096]
+    assert (cols["uid"][idx] == cols["uid"][hot[0]]).sum() >= 3000
+    masks = otower.train_masks(model.seed, model.step, 4096, model.hidden, 0.5)
+    loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                           cols["label"][idx], masks, 0.5, True, None, model.deepfm)
+    want = eng.pack({**{k: np.zeros_like(v) for k, v in model.params.items()}, **grads}).cpu().numpy()
+    w0 = eng.get_weights()
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=1, lr=1.0, optimizer="sgd")
+    got = (w0 - eng.get_weights()).cpu().numpy()
+    eng.set_weights(w0)
+    for name, (off, cnt) in eng.segments.items():
+        w = want[off:off + cnt]
+        floor = 6e-8 if name in ("user_emb", "item_emb") else 1e-8
+        np.testing.assert_allclose(got[off:off + cnt], w, rtol=2e-4,
+                                   atol=max(2e-6 * max(np.abs(w).max(), 1e-3), floor), err_msg=name)
+    u_off = eng.segments["user_emb"][0] + int(cols["uid"][hot[0]]) * 128
+    assert np.abs(want[u_off:u_off + 128]).max() > 0
+    # lazy Adam over the same two batches (the hot rows are stepped by the reducing wave itself)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=2, lr=1e-3)
+    model.step = 1                                     # the SGD step above consumed dropout step 0
+    for s_ in range(2):
+        ii = perm[s_ * 4096:(s_ + 1) * 4096]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], 2, 1e-3, name, max_frac=1e-2)
+    eng.close()
+
+
 # ------------------------------------------------------------------ DeepFM tower (SURVEY A.8, BASELINE config 3)
 @pytest.mark.parametrize("tower", ["deepfm", "wdl"])
 @pytest.mark.parametrize("emb_trainable", [False, True])
