@@ -329,7 +329,14 @@ void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------ chain rule + optimiser
 __device__ __forceinline__ float slab_sum(const StarUpdateArgs& u, int off) {
     float g = u.slabs[off];
-    for (int s = 1; s < u.n_groups; ++s) g += u.slabs[(size_t)s * u.slab_ld + off];
+    for (int s0 = 1; s0 < u.n_groups; s0 += 8) {           // eight slabs in flight, summed in slab order
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = u.slabs[(size_t)min(s0 + k, u.n_groups - 1) * u.slab_ld + off];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < u.n_groups) g += t[k];
+    }
     return g;
 }
 

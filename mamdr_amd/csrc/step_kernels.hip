@@ -391,8 +391,21 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
 #endif
 
 // ring depths: forward in 16-deep chunks, backward in 32-deep chunks
-constexpr int PF0 = 4, PF1 = 4, PF2 = 4;
-constexpr int PFB2 = 2, PFB1 = 2, PFB0 = 4;
+// ring depths in chunks (diagnostic builds may override them)
+#ifndef MAMDR_PF0
+#define MAMDR_PF0 4
+#endif
+#ifndef MAMDR_PF1
+#define MAMDR_PF1 4
+#endif
+#ifndef MAMDR_PF2
+#define MAMDR_PF2 4
+#endif
+#ifndef MAMDR_PFB1
+#define MAMDR_PFB1 2
+#endif
+constexpr int PF0 = MAMDR_PF0, PF1 = MAMDR_PF1, PF2 = MAMDR_PF2;
+constexpr int PFB2 = 2, PFB1 = MAMDR_PFB1, PFB0 = 4;
 
 // DX: the user / item tables are trainable, so every row also needs d loss / d [user | item]
 // embedding = dz1 . W0[0:256, :]^T (the frozen-table path replaces that contraction by linearity).
@@ -968,6 +981,34 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS), dim3(256), 0, s, a);
 }
 
+// sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
+// loop paid one dependent round trip per slab: 4 at 1024 rows, 16 at 4096)
+__device__ __forceinline__ f32x4 slab_sum4(const float* slabs, int n_groups, int slab_ld, size_t e) {
+    f32x4 g = *reinterpret_cast<const f32x4*>(slabs + e);
+    for (int s0 = 1; s0 < n_groups; s0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            t[k] = *reinterpret_cast<const f32x4*>(slabs + (size_t)min(s0 + k, n_groups - 1) * slab_ld + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < n_groups) g += t[k];
+    }
+    return g;
+}
+__device__ __forceinline__ float slab_sum1(const float* slabs, int n_groups, int slab_ld, size_t e) {
+    float g = slabs[e];
+    for (int s0 = 1; s0 < n_groups; s0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = slabs[(size_t)min(s0 + k, n_groups - 1) * slab_ld + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < n_groups) g += t[k];
+    }
+    return g;
+}
+
 // ------------------------------------------------------------------ slab reduce + optimiser
 // TF1 ApplyAdam: m += (g - m)(1-b1); v += (g^2 - v)(1-b2);
 // p -= (m * alpha) / (sqrt(v) + eps), alpha = lr sqrt(1-b2^t)/(1-b1^t) from the host.
@@ -991,8 +1032,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
         const int e4 = u.dm_count / 4 + blockIdx.x * 256 + threadIdx.x;
         if (e4 >= u.count4) return;
         const size_t e = (size_t)e4 * 4;
-        f32x4 gsum = *reinterpret_cast<const f32x4*>(u.slabs + e);
-        for (int s = 1; s < u.n_groups; ++s) gsum += *reinterpret_cast<const f32x4*>(u.slabs + (size_t)s * u.slab_ld + e);
+        f32x4 gsum = slab_sum4(u.slabs, u.n_groups, u.slab_ld, e);
         f32x4 p = *reinterpret_cast<const f32x4*>(u.p + e);
         f32x4 m = *reinterpret_cast<const f32x4*>(u.m + e);
         f32x4 v = *reinterpret_cast<const f32x4*>(u.v + e);
@@ -1040,17 +1080,14 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
     if (el >= u.dm_count) return;
     const int d = el / EMB, c = el - d * EMB;
     const size_t so = (size_t)u.s_off + (size_t)d * H1 + 4 * lane;
-    f32x4 sv = *reinterpret_cast<const f32x4*>(u.slabs + so);
-    for (int s = 1; s < u.n_groups; ++s) sv += *reinterpret_cast<const f32x4*>(u.slabs + (size_t)s * u.slab_ld + so);
+    const f32x4 sv = slab_sum4(u.slabs, u.n_groups, u.slab_ld, so);
     const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
     float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
     for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
     if (lane == 0) {
         float p = u.p[el], m = u.m[el], v = u.v[el];
         if (u.s2_off) {
-            float g2 = u.slabs[(size_t)u.s2_off + el];
-            for (int s = 1; s < u.n_groups; ++s) g2 += u.slabs[(size_t)s * u.slab_ld + u.s2_off + el];
-            g += g2;
+            g += slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el);
         }
         g += u.two_l2 * p;
         optimizer_step(u, g, p, m, v);
