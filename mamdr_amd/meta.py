@@ -60,24 +60,37 @@ def alternate_epoch(eng, seq, perm_fn, batch_size, lr):
     return trace
 
 
-def dn_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, meta_train_step=0):
+def dn_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, meta_train_step=0, target=-1):
+    """target >= 0 (domain_negotiation.py:44-45,67,89-93): the target domain closes the inner sequence with an
+    uncapped pass, and after the outer update the model (not theta) takes one more full pass over it."""
     trace = []
     eng.set_weights(theta)
     for d in seq:
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
+    if target >= 0:
+        run_pass(eng, target, perm_fn, batch_size, lr, trace, "dn")
     eng.interp(theta, eng.weights, theta, meta_lr)     # theta += (theta~ - theta) * beta
     eng.set_weights(theta)
+    if target >= 0:
+        run_pass(eng, target, perm_fn, batch_size, lr, trace, "target")
     return trace
 
 
 def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False, meta_train_step=0,
-                  acc=None):
+                  acc=None, target=-1):
+    """target >= 0 (reptile.py:47-48,82-85,98-102): the target domain is skipped in the sequence; every
+    domain's pass is followed by ONE step on the target domain's freshly shuffled iterator before the outer
+    update, and the epoch ends with a full pass of the model (not theta) over the target domain."""
     trace = []
     if batch_variant and acc is None:
         acc = torch.zeros_like(theta)
     for d in seq:
+        if target >= 0 and d == target:
+            continue
         eng.set_weights(theta)
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
+        if target >= 0:
+            run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
         if batch_variant:
             eng.accumulate(acc, eng.weights, theta)
         else:
@@ -85,6 +98,8 @@ def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_varia
     if batch_variant:
         eng.apply_accumulated(theta, acc, 0.0, meta_lr)
     eng.set_weights(theta)
+    if target >= 0:
+        run_pass(eng, target, perm_fn, batch_size, lr, trace, "target")
     return trace
 
 
@@ -109,15 +124,20 @@ class OuterAdamState(object):
 
 
 def maml_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False,
-               meta_train_step=0, grad_scale=1.0, windows=None):
+               meta_train_step=0, grad_scale=1.0, windows=None, meta_domain=-1):
     """acc must be bound with eng.bind_accumulator(acc) and zero on entry.
-    windows: {domain: (train window, meta window)} for the meta-train / meta-val split, None = train-train."""
+    windows: {domain: (train window, meta window)} for the meta-train / meta-val split, None = train-train.
+    meta_domain >= 0 (train.target_domain, maml.py:336-338): every meta pass runs over that domain's whole
+    train split instead of the domain's own meta set."""
     trace = []
     for d in seq:
         wt, wm = windows[d] if windows else (None, None)
+        dm = d
+        if meta_domain >= 0:
+            dm, wm = meta_domain, None
         eng.set_weights(theta)
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_train", meta_train_step, window=wt)
-        run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_meta", meta_train_step, optimizer="accumulate",
+        run_pass(eng, dm, perm_fn, batch_size, lr, trace, "maml_meta", meta_train_step, optimizer="accumulate",
                  window=wm)
         if not batch_variant:
             outer.apply(eng, theta, acc, meta_lr, grad_scale)
@@ -128,7 +148,7 @@ def maml_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
 
 
 def mldg_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, batch_variant=False,
-               meta_train_step=0, grad_scale=1.0, windows=None):
+               meta_train_step=0, grad_scale=1.0, windows=None, meta_domain=-1):
     """MLDG as the reference implements it (model_zoo/mldg.py:62-125): per domain the model is reset to
     theta, the meta-train pass only ACCUMULATES d total_loss / d theta (no inner optimiser step), the outer
     Adam moves the live model by that gradient (accumulator kept), the meta-val pass adds the gradients at
@@ -144,7 +164,10 @@ def mldg_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
         live = eng.get_weights()[:theta.numel()].clone()
         outer.apply(eng, live, acc, meta_lr, grad_scale, clear=False)
         eng.set_weights(live)
-        run_pass(eng, d, perm_fn, batch_size, lr, trace, "mldg_meta", meta_train_step, optimizer="accumulate",
+        dm = d
+        if meta_domain >= 0:            # train.target_domain (mldg.py:339-341): the meta pass runs over the target domain
+            dm, wm = meta_domain, None
+        run_pass(eng, dm, perm_fn, batch_size, lr, trace, "mldg_meta", meta_train_step, optimizer="accumulate",
                  window=wm)
         if not batch_variant:
             eng.set_weights(theta)
@@ -203,8 +226,18 @@ def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, 
         eng.apply_accumulated(phi, acc, float(sample_num), meta_lr)
 
 
+def finetune_query(eng, theta, phi, query, perm_fn, batch_size, lr, trace, merged, merged_method="plus"):
+    """train.finetune_every_epoch (mamdr.py:110-143): after a query domain's DR the merged model takes one
+    full pass over that domain and phi := theta~ - merged (`_update_domain_weights`, mamdr.py:168-171)."""
+    eng.merge(merged, theta, phi, merged_method)
+    eng.set_weights(merged)
+    run_pass(eng, query, perm_fn, batch_size, lr, trace, "dr_finetune")
+    eng.sub(phi, eng.weights, merged)
+
+
 def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
-                domain_regulation_step=0, batch_variant=False, sample_num=None, scratch=None):
+                domain_regulation_step=0, batch_variant=False, sample_num=None, scratch=None,
+                finetune_every_epoch=False):
     """plan = {"seq": [...], "dr": [(query, [support...]), ...]}."""
     trace = []
     # DN phase (mamdr.py:48-57)
@@ -218,4 +251,6 @@ def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged
     for query, support in plan["dr"]:
         dr_query(eng, theta, phis[query], query, support, perm_fn, batch_size, lr, meta_lr, trace, merged,
                  merged_method, domain_regulation_step, batch_variant, sample_num, acc)
+        if finetune_every_epoch:
+            finetune_query(eng, theta, phis[query], query, perm_fn, batch_size, lr, trace, merged, merged_method)
     return trace

@@ -27,8 +27,7 @@ class DomainNegotiation(MAML):
     def train(self):
         print("Start Domain Negotiation on model: {}".format(self.model_config["name"]))
         tc = self.train_config
-        if tc["target_domain"] >= 0:
-            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        target = tc["target_domain"]
         self._get_model_meta_parms()
         meta_weights = self._get_meta_weights()
         self.model.optimizer_reset()
@@ -45,8 +44,8 @@ class DomainNegotiation(MAML):
             if tc["shuffle_sequence"]:
                 self.rng.shuffle(meta_sequence)
             if world > 1:
-                if tc["meta_train_step"] > 0:
-                    raise NotImplementedError("multi-process DN with meta_train_step > 0 is not built")
+                if tc["meta_train_step"] > 0 or target >= 0:
+                    raise NotImplementedError("multi-process DN with meta_train_step > 0 or a target domain is not built")
                 parallel.dn_phase_sharded(self.model, meta, meta_weights, [d for d in meta_sequence if owner[d] == rank],
                                           self.shuffler, self.batch_size, self.learning_rate, tc["meta_learning_rate"],
                                           self.trace, delta, zero)
@@ -54,7 +53,7 @@ class DomainNegotiation(MAML):
             else:
                 self.trace += meta.dn_epoch(self.model, meta_weights, list(meta_sequence), self.shuffler,
                                             self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                            tc["meta_train_step"])
+                                            tc["meta_train_step"], target)
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

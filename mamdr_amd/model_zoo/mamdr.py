@@ -25,10 +25,7 @@ class MAMDR(SpecificBase):
     def train(self):
         print("Start MAMDR on model: {}".format(self.model_config["name"]))
         tc = self.train_config
-        if tc["target_domain"] >= 0:
-            raise NotImplementedError("target_domain >= 0 is not built in this round")
-        if tc["finetune_every_epoch"]:
-            raise NotImplementedError("finetune_every_epoch (mamdr.py:110-143) is not built in this round")
+        # (train.target_domain only selects the early-stopping metric here: mamdr.py:153-154)
         self._get_model_meta_parms()
         self.meta_weights = self._get_meta_weights()
         # one process per GPU: query domains have a fixed owner (LPT over their train rows) that
@@ -49,8 +46,9 @@ class MAMDR(SpecificBase):
         batch_variant = "batch" in self.model_config["name"]
         scratch = self.model.new_vector(meta=True)
         bufs = {"delta": self.model.new_vector(meta=True), "zero": self.model.new_vector(meta=True), "merged": scratch}
-        if world > 1 and (batch_variant or tc["merged_method"] not in ("plus", "times")):
-            raise NotImplementedError("multi-process MAMDR: the per-support update variant only")
+        if world > 1 and (batch_variant or tc["merged_method"] not in ("plus", "times") or tc["finetune_every_epoch"]):
+            raise NotImplementedError("multi-process MAMDR: the per-support update variant without "
+                                      "finetune_every_epoch only")
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
@@ -65,7 +63,7 @@ class MAMDR(SpecificBase):
                                                self.shuffler, self.batch_size, self.learning_rate,
                                                tc["meta_learning_rate"], tc["merged_method"],
                                                tc["domain_regulation_step"], batch_variant, tc["sample_num"],
-                                               scratch)
+                                               scratch, bool(tc["finetune_every_epoch"]))
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

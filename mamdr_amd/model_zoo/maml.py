@@ -56,21 +56,45 @@ class MAML(object):
 
     # ------------------------------------------------------------------ validation
     def val(self):
-        if self.train_config["meta_finetune_step"] > 0:
-            raise NotImplementedError("meta_finetune_step > 0 (maml.py:245-287) is not built in this round")
         print("Val Result: ")
+        if self.train_config["meta_finetune_step"] > 0:
+            return self.meta_finetune_val()
         return self.val_and_test("val")
+
+    def meta_finetune_val(self):
+        """maml.py:245-287: every domain is evaluated after `meta_finetune_step` full passes over its own train
+        split, each starting from the current model weights (the optimiser slots are NOT restored between
+        domains: Keras' set_weights leaves them alone); the model is put back afterwards."""
+        from .. import meta, parallel
+        if parallel.world()[1] > 1:
+            raise NotImplementedError("meta_finetune_step > 0 in a multi-process run is not built")
+        weights = self.model.get_weights().clone()
+        aux = getattr(self.model, "aux", None)      # Star: PartitionedNorm moving statistics move while training
+        aux = aux.clone() if aux is not None else None
+        domain_loss, domain_auc = {}, {}
+        for idx in self.dataset.train_dataset:
+            self.model.set_weights(weights)
+            print("Finetune on domain: {}".format(idx))
+            for _ in range(self.train_config["meta_finetune_step"]):
+                meta.run_pass(self.model, idx, self.shuffler, self.batch_size, self.learning_rate, self.trace, "meta_finetune")
+            p_loss, p_auc = self.evaluate_domain(idx, "val")
+            domain_loss[idx], domain_auc[idx] = float(p_loss), float(p_auc)
+        self.model.set_weights(weights)
+        if aux is not None:
+            self.model.aux.copy_(aux)
+        return self._summarise("val", domain_loss, domain_auc)
 
     def build_meta_windows(self):
         """maml.py:289-341 / mldg.py:296-341 `build_meta_data_split`: "meta-train/val" takes the first
         int(n * meta_split_ratio) rows (file order) as the meta-train set and the rest as the meta-val set,
-        each shuffled on its own; any other value except the non-exclusive variant is the train-train split
-        (both iterators over the whole train set) -> None."""
+        each shuffled on its own; "meta-train/val-no-exclusive" shuffles first and takes / skips afterwards; any
+        other value is the train-train split (both iterators over the whole train set) -> None."""
         tc = self.train_config
-        if tc["meta_split"] == "meta-train/val-no-exclusive":
-            raise NotImplementedError("meta_split 'meta-train/val-no-exclusive' (shuffle, then take / skip) is not built")
-        if tc["meta_split"] != "meta-train/val":
+        if tc["meta_split"] not in ("meta-train/val", "meta-train/val-no-exclusive"):
             return None
+        # the non-exclusive variant shuffles the whole split first and then takes / skips (maml.py:316-323):
+        # window tag "stream" (plan.PassShuffler)
+        tag = ("stream",) if tc["meta_split"] == "meta-train/val-no-exclusive" else ()
         windows = {}
         for d, v in self.dataset.train_dataset.items():
             n = v["n_data"]
@@ -78,7 +102,7 @@ class MAML(object):
             if n_train <= 0 or n_train >= n:
                 raise ValueError("domain %s: meta_split_ratio %s leaves an empty meta-train or meta-val set"
                                  % (d, tc["meta_split_ratio"]))
-            windows[d] = ((0, n_train), (n_train, n))
+            windows[d] = ((0, n_train) + tag, (n_train, n) + tag)
         return windows
 
     def _val_metric(self, val_avg_auc, val_domain_auc):
@@ -92,8 +116,7 @@ class MAML(object):
         from .. import meta
         print("Start MAML training on model: {}".format(self.model_config["name"]))
         tc = self.train_config
-        if tc["target_domain"] >= 0:
-            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        target = tc["target_domain"]
         windows = self.build_meta_windows()
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
@@ -114,9 +137,13 @@ class MAML(object):
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             self.rng.shuffle(train_sequence)
-            self.trace += meta.maml_epoch(self.model, meta_weights, outer, acc, list(train_sequence), self.shuffler,
+            # (the shuffle covers every domain, the target is skipped inside the loop: maml.py:65-68)
+            seq = [d for d in train_sequence if d != target]
+            self.trace += meta.maml_epoch(self.model, meta_weights, outer, acc, seq, self.shuffler,
                                           self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                          batch_variant, tc["meta_train_step"], grad_scale, windows)
+                                          batch_variant, tc["meta_train_step"], grad_scale, windows, target)
+            if target >= 0:         # maml.py:124-128: the model (left at theta) takes a full pass over the target domain
+                meta.run_pass(self.model, target, self.shuffler, self.batch_size, self.learning_rate, self.trace, "target")
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

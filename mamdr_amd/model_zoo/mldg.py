@@ -14,8 +14,7 @@ class MLDG(MAML):
     def train(self):
         print("Start MLDG training on model: {}".format(self.model_config["name"]))
         tc = self.train_config
-        if tc["target_domain"] >= 0:
-            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        target = tc["target_domain"]
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
             grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])          # mldg.py:211-213
@@ -36,9 +35,13 @@ class MLDG(MAML):
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             self.rng.shuffle(train_sequence)
-            self.trace += meta.mldg_epoch(self.model, meta_weights, outer, acc, list(train_sequence), self.shuffler,
+            # (the shuffle covers every domain, the target is skipped inside the loop: mldg.py:65-68)
+            seq = [d for d in train_sequence if d != target]
+            self.trace += meta.mldg_epoch(self.model, meta_weights, outer, acc, seq, self.shuffler,
                                           self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                          batch_variant, tc["meta_train_step"], grad_scale, windows)
+                                          batch_variant, tc["meta_train_step"], grad_scale, windows, target)
+            if target >= 0:         # mldg.py:127-131: the model (left at theta) takes a full pass over the target domain
+                meta.run_pass(self.model, target, self.shuffler, self.batch_size, self.learning_rate, self.trace, "target")
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

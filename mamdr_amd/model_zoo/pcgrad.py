@@ -14,8 +14,7 @@ class PCGrad(MAML):
     def train(self):
         print("Start PCGrad training on model: {}".format(self.model_config["name"]))
         tc = self.train_config
-        if tc["target_domain"] >= 0:
-            raise NotImplementedError("target_domain >= 0 is not built in this round")
+        target = tc["target_domain"]      # skipped as a query domain (pcgrad.py:67-68), still a candidate auxiliary
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
             grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])
@@ -37,10 +36,13 @@ class PCGrad(MAML):
             self.rng.shuffle(train_sequence)
             aux_plan = {}
             for idx in train_sequence:             # pcgrad.py:112-115
+                if idx == target:
+                    continue
                 cand = list(train_sequence)
                 cand.remove(idx)
                 aux_plan[idx] = self.rng.sample(cand, k=min(tc["sample_num"], len(cand)))
-            self.trace += meta.pcgrad_epoch(self.model, outer, cur, aux, list(train_sequence), aux_plan, self.shuffler,
+            self.trace += meta.pcgrad_epoch(self.model, outer, cur, aux, [d for d in train_sequence if d != target], aux_plan,
+                                            self.shuffler,
                                             self.batch_size, self.learning_rate, tc["meta_learning_rate"],
                                             tc["meta_train_step"], grad_scale, windows)
             if epoch % tc["val_every_step"] == 0:

@@ -15,8 +15,6 @@ class Reptile(MAML):
     def train(self):
         print("Start reptile on model: {}".format(self.model_config["name"]))
         tc = self.train_config
-        if tc["target_domain"] >= 0:
-            raise NotImplementedError("target_domain >= 0 is not built in this round")
         self._get_model_meta_parms()
         meta_weights = self._get_meta_weights()
         self.model.optimizer_reset()
@@ -28,7 +26,7 @@ class Reptile(MAML):
             self.rng.shuffle(train_sequence)
             self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
                                              self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                             batch_variant, tc["meta_train_step"])
+                                             batch_variant, tc["meta_train_step"], target=tc["target_domain"])
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

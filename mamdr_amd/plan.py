@@ -67,11 +67,16 @@ class PassShuffler(object):
     def __call__(self, d, window=None):
         """window = (begin, end): a pass over that file-order slice only (dataset.take / dataset.skip of the
         meta-train / meta-val split, maml.py:300-330): the slice is shuffled on its own."""
-        begin, end = window if window is not None else (0, self.sizes[d])
+        begin, end = (window[0], window[1]) if window is not None else (0, self.sizes[d])
         if not self.shuffle:
             return None if window is None else np.arange(begin, end, dtype=np.int32)
         self.counter += 1
-        perm = self.shuffle_fn(end - begin, self.buffer_size, _mix64(self.seed * 0x10001 + self.counter))
+        seed = _mix64(self.seed * 0x10001 + self.counter)
+        if window is not None and len(window) > 2 and window[2] == "stream":
+            # (begin, end, "stream"): positions [begin, end) of a fresh shuffle of the WHOLE split -- dataset.shuffle
+            # then take / skip, the non-exclusive meta split (maml.py:316-323): two passes may share rows
+            return np.ascontiguousarray(self.shuffle_fn(self.sizes[d], self.buffer_size, seed)[begin:end])
+        perm = self.shuffle_fn(end - begin, self.buffer_size, seed)
         return perm if begin == 0 else (perm + np.int32(begin)).astype(np.int32)
 
 

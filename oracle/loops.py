@@ -31,26 +31,36 @@ def alternate_epoch(model, data, seq, perm_fn, batch_size):
     return trace
 
 
-def dn_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, meta_train_step=0):
-    """domain_negotiation.py:49-88: theta set once, sequential passes without
-    reset, then theta += beta (theta~ - theta) and model := theta."""
+def dn_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, meta_train_step=0, target=-1):
+    """domain_negotiation.py:49-93: theta set once, sequential passes without reset (the target domain, if any,
+    last and uncapped: :44-45,67), then theta += beta (theta~ - theta), model := theta, and with a target
+    domain one more full pass of the model over it (:89-93)."""
     trace = []
     model.set_flat(theta)
     for d in seq:
         _pass(model, data, perm_fn, d, batch_size, trace, "dn", meta_train_step)
+    if target >= 0:
+        _pass(model, data, perm_fn, target, batch_size, trace, "dn")
     outer.dn_update(theta, model.get_flat(), meta_lr)
     model.set_flat(theta)
+    if target >= 0:
+        _pass(model, data, perm_fn, target, batch_size, trace, "target")
     return trace
 
 
 def reptile_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
-                  meta_train_step=0):
-    """reptile.py:45-99."""
+                  meta_train_step=0, target=-1):
+    """reptile.py:45-102 (target domain: skipped in the sequence :47-48, one step on it after every
+    domain's pass :82-85, a full pass at the end of the epoch :98-102)."""
     trace = []
     acc = np.zeros_like(theta)
     for d in seq:
+        if target >= 0 and d == target:
+            continue
         model.set_flat(theta)
         _pass(model, data, perm_fn, d, batch_size, trace, "reptile", meta_train_step)
+        if target >= 0:
+            _pass(model, data, perm_fn, target, batch_size, trace, "target_step", 1)
         if batch_variant:
             outer.reptile_accumulate(acc, model.get_flat(), theta)
         else:
@@ -58,11 +68,13 @@ def reptile_epoch(model, theta, data, seq, perm_fn, batch_size, meta_lr, batch_v
     if batch_variant:
         outer.reptile_apply(theta, acc, meta_lr)
     model.set_flat(theta)
+    if target >= 0:
+        _pass(model, data, perm_fn, target, batch_size, trace, "target")
     return trace
 
 
 def mldg_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
-               meta_train_step=0, grad_scale=1.0, windows=None):
+               meta_train_step=0, grad_scale=1.0, windows=None, meta_domain=-1):
     """model_zoo/mldg.py:62-125: accumulate at theta over the meta-train split, outer-Adam step of the LIVE
     model with the accumulator kept, accumulate at the moved weights over the meta-val split, reset to theta,
     outer-Adam step -> new theta."""
@@ -79,7 +91,10 @@ def mldg_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr
         live = model.get_flat()
         outer.apply(live, acc, meta_lr, grad_scale)
         model.set_flat(live)
-        _pass(model, data, perm_fn, d, batch_size, trace, "mldg_meta", meta_train_step, accumulate_into=acc, window=wm)
+        dm = d
+        if meta_domain >= 0:       # train.target_domain (mldg.py:339-341)
+            dm, wm = meta_domain, None
+        _pass(model, data, perm_fn, dm, batch_size, trace, "mldg_meta", meta_train_step, accumulate_into=acc, window=wm)
         if not batch_variant:
             outer_step()
     if batch_variant:
@@ -121,7 +136,7 @@ def pcgrad_epoch(model, outer_opt, data, seq, aux_plan, perm_fn, batch_size, met
 
 
 def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr, batch_variant=False,
-               meta_train_step=0, grad_scale=1.0, windows=None):
+               meta_train_step=0, grad_scale=1.0, windows=None, meta_domain=-1):
     """first-order MAML, model_zoo/maml.py:62-116 with meta_split "train-train": per domain reset
     to theta, inner Adam pass, meta pass that only accumulates gradients at the adapted weights,
     then (per domain, or once per epoch for "batch" names) the outer Adam step on theta."""
@@ -135,7 +150,10 @@ def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr
         wt, wm = windows[d] if windows else (None, None)
         model.set_flat(theta)
         _pass(model, data, perm_fn, d, batch_size, trace, "maml_train", meta_train_step, window=wt)
-        _pass(model, data, perm_fn, d, batch_size, trace, "maml_meta", meta_train_step, accumulate_into=acc, window=wm)
+        dm = d
+        if meta_domain >= 0:       # train.target_domain (maml.py:336-338): the meta pass runs over the target domain
+            dm, wm = meta_domain, None
+        _pass(model, data, perm_fn, dm, batch_size, trace, "maml_meta", meta_train_step, accumulate_into=acc, window=wm)
         if not batch_variant:
             outer_step()
     if batch_variant:
@@ -145,7 +163,7 @@ def maml_epoch(model, theta, outer, acc, data, seq, perm_fn, batch_size, meta_lr
 
 
 def mamdr_epoch(model, theta, phis, data, plan, perm_fn, batch_size, meta_lr, merged_method="plus",
-                domain_regulation_step=0, batch_variant=False, sample_num=None):
+                domain_regulation_step=0, batch_variant=False, sample_num=None, finetune_every_epoch=False):
     """mamdr.py:44-108.  plan = {"seq": [...], "dr": [(query, [support...]), ...]}
     (support list already contains the query domain when add_query_domain)."""
     trace = []
@@ -169,6 +187,11 @@ def mamdr_epoch(model, theta, phis, data, plan, perm_fn, batch_size, meta_lr, me
                 merged = outer.merge(theta, phis[query], merged_method)
         if batch_variant:
             outer.mamdr_apply_grads(phis[query], acc, sample_num, meta_lr)
+        if finetune_every_epoch:          # mamdr.py:110-143: full pass of the merged model, phi := theta~ - merged
+            merged = outer.merge(theta, phis[query], merged_method)
+            model.set_flat(merged)
+            _pass(model, data, perm_fn, query, batch_size, trace, "dr_finetune")
+            phis[query][...] = outer.mamdr_domain_weights(model.get_flat(), merged)
     return trace
 
 
