@@ -4,7 +4,7 @@ Per epoch (reptile.py:40-125): shuffle all domains; for each, reset the model to
 run one pass, then either theta += beta * (theta~ - theta) immediately, or (names
 containing "batch") accumulate theta~ - theta and apply the sum once per epoch.
 """
-from .. import meta
+from .. import meta, parallel
 from .maml import MAML
 
 
@@ -20,13 +20,27 @@ class Reptile(MAML):
         self.model.optimizer_reset()
         train_sequence = list(range(self.n_domain))
         batch_variant = "batch" in self.model_config["name"]
+        rank, world = parallel.world()
+        if world > 1:
+            if not batch_variant or tc["target_domain"] >= 0:
+                raise NotImplementedError("multi-process Reptile: the batch variant without a target domain only "
+                                          "(its epoch update is a plain sum of per-domain displacements)")
+            sizes = [self.dataset.train_dataset[d]["n_data"] for d in range(self.n_domain)]
+            owner = parallel.lpt_partition(sizes, world)
+            acc = self.model.new_vector(meta=True)
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             self.rng.shuffle(train_sequence)
-            self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
-                                             self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                             batch_variant, tc["meta_train_step"], target=tc["target_domain"])
+            if world > 1:
+                # one process per GPU: the batch variant's sum of displacements is a sum over ranks
+                self.trace += parallel.reptile_batch_epoch_sharded(
+                    self.model, meta, meta_weights, [d for d in train_sequence if owner[d] == rank], self.shuffler,
+                    self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, tc["meta_train_step"])
+            else:
+                self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
+                                                 self.batch_size, self.learning_rate, tc["meta_learning_rate"],
+                                                 batch_variant, tc["meta_train_step"], target=tc["target_domain"])
             if epoch % tc["val_every_step"] == 0:
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):

@@ -68,6 +68,25 @@ def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_
         eng.interp(theta, delta_buf, zero_buf, meta_lr)
 
 
+def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, acc, meta_train_step=0):
+    """Reptile, batch variant (reptile.py:87-96,134-142): every domain starts from theta and adds its
+    displacement theta~ - theta to `acc`; the epoch applies theta += beta * sum.  The sum over domains is a sum
+    over ranks of per-rank sums: ONE all-reduce of `acc` per epoch, no other change to the algorithm.
+    Only the optimiser slots differ from the single-process run: each rank's Adam moments see its own domains."""
+    trace = []
+    acc.zero_()
+    for d in seq_local:
+        eng.set_weights(theta)
+        meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
+        eng.accumulate(acc, eng.weights, theta)
+    rank, ws = world()
+    if ws > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    eng.apply_accumulated(theta, acc, 0.0, meta_lr)
+    eng.set_weights(theta)
+    return trace
+
+
 def mamdr_epoch_sharded(eng, meta, theta, phis, plan, owner, perm_fn, batch_size, lr, meta_lr, bufs,
                         merged_method="plus", domain_regulation_step=0):
     """one DN+DR epoch; `phis` holds only the vectors this rank owns (dict domain -> vector)."""

@@ -182,6 +182,12 @@ def test_run_entry_sharded_domain_negotiation_gloo_world2(tmp_path):
     _run_entry_worlds(tmp_path, "mlp_meta_domain_negotiation_finetune")
 
 
+def test_run_entry_sharded_reptile_batch_gloo_world2(tmp_path):
+    """batch Reptile: the epoch's sum of per-domain displacements is a sum over ranks -- domains
+    dealt by owner, ONE all-reduce of the accumulator per epoch, identical theta on every rank."""
+    _run_entry_worlds(tmp_path, "mlp_meta_reptile_batch")
+
+
 def _run_entry_worlds(tmp_path, name):
     import json
     sys.path.insert(0, HERE)
