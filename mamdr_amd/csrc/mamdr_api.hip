@@ -425,7 +425,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     wa.tiles = c->tiles;
     wa.n_tiles = c->n_tiles;
     wa.rows_pad = rows_pad;
-    int rpg = rows_pad <= 1024 ? 128 : (rows_pad <= 4096 ? 256 : 512);
+    int rpg = rows_pad <= 512 ? 256 : (rows_pad <= 1024 ? 128 : (rows_pad <= 4096 ? 256 : 512));
     int groups = (rows_pad + rpg - 1) / rpg;
     if (groups > c->max_groups) {
         rpg = ((rows_pad + c->max_groups - 1) / c->max_groups + 7) / 8 * 8;
@@ -949,8 +949,9 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         wa.tiles = c->tiles;
         wa.n_tiles = c->n_tiles;
         wa.rows_pad = rows_pad;
-        // rows per K-split group (measured: 1024 rows, 8 groups of 128: 31.0 us/step vs 32.0 with 4 of 256)
-        int rpg = rows_pad <= 1024 ? 128 : (rows_pad <= 4096 ? 256 : 512);
+        // rows per K-split group (measured: 1024 rows, 8 groups of 128: 31.0 us/step vs 32.0 with 4 of 256;
+        // batches of <= 512 rows keep 256-row groups: one or two slabs)
+        int rpg = rows_pad <= 512 ? 256 : (rows_pad <= 1024 ? 128 : (rows_pad <= 4096 ? 256 : 512));
         if (c->rpg_override > 0) rpg = c->rpg_override;        // MAMDR_RPG (diagnostic)
         int groups = (rows_pad + rpg - 1) / rpg;
         if (groups > c->max_groups) {
