@@ -426,6 +426,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     wa.n_tiles = c->n_tiles;
     wa.rows_pad = rows_pad;
     int rpg = rows_pad <= 512 ? 256 : (rows_pad <= 1024 ? 128 : (rows_pad <= 4096 ? 256 : 512));
+    if (c->rpg_override > 0) rpg = c->rpg_override;        // MAMDR_RPG (diagnostic)
     int groups = (rows_pad + rpg - 1) / rpg;
     if (groups > c->max_groups) {
         rpg = ((rows_pad + c->max_groups - 1) / c->max_groups + 7) / 8 * 8;
@@ -606,6 +607,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->domrow, rp * sizeof(int32_t));
     ALLOC(c->loss_part, (rp / 4) * sizeof(float));
     ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
+    if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
+    if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
