@@ -39,6 +39,12 @@ PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 #   forward 384*256 + 256*128 + 128*64 + 64 MACs, backward chain dz3->dz2->dz1: 64*128 + 128*256 MACs
 #   (the per-row contraction with W0[256:384] is gone: the domain-table gradient uses linearity)
 TOWER_TRAIN_FLOPS_PER_ROW = 2 * ((384 * 256 + 256 * 128 + 128 * 64 + 64) + (64 * 128 + 128 * 256))
+
+
+def tower_flops_per_row(dx_width):
+    """+ the input-gradient contraction dz1 . W0[0:dx_width, :]^T of the towers whose tables train: 256 columns
+    ([user | item] rows, deepctr towers) or all 384 (Star: PartitionedNorm's backward needs d loss / d x)."""
+    return TOWER_TRAIN_FLOPS_PER_ROW + 2 * 256 * dx_width
 GATHER_BYTES_PER_ROW = 3 * 128 * 4 * 2 + 16   # read 3 rows + write 384 floats + 4 index/label words
 
 WORKLOADS = {
@@ -161,7 +167,7 @@ def main():
     from mamdr_amd import meta, parallel, plan as mplan, synthetic
 
     wl = WORKLOADS[args.workload]
-    batch = wl["batch"]
+    batch = int(os.environ.get("MAMDR_BENCH_BATCH", wl["batch"]))      # (exploration only: the named config fixes it)
     trainable = bool(wl.get("emb_trainable"))
     g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=wl.get("row_scale", 1.0))
     D = g["n_domain"]
@@ -276,7 +282,8 @@ def main():
             ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
         if tower == "star":
             kname = "k_tower<true, 384, false>"
-        roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows)
+        roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows,
+                                   tower_flops_per_row(384 if tower == "star" else (256 if trainable else 0)))
         roofline["rocprofv3_avg_us"] = rocprof_avg_us(kname, wl["shape"])
         # gather kernel on a pass-sized batch (largest domain, shuffled order)
         dbig = max(range(D), key=lambda k: sizes[k])
@@ -355,17 +362,17 @@ def rocprof_avg_us(kernel, shape):
     return None
 
 
-def finish_roofline(kernel, total_ms, launches, rows):
+def finish_roofline(kernel, total_ms, launches, rows, flops_per_row=TOWER_TRAIN_FLOPS_PER_ROW):
     """achieved = algorithmic flops of all profiled launches / their summed device time
     (= flops per average launch / average launch duration)."""
-    flops = rows * TOWER_TRAIN_FLOPS_PER_ROW
+    flops = rows * flops_per_row
     ach = flops / (total_ms * 1e-3) / 1e12
     return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(kernel),
             "traffic_unit": "HBM bytes per launch (profiles/pmc_hbm_latest.json: separate rocprofv3 --pmc passes)",
             "launches": launches,
             "avg_us": total_ms / max(launches, 1) * 1e3, "rows_per_launch": rows / max(launches, 1),
-            "flops_per_row": TOWER_TRAIN_FLOPS_PER_ROW}
+            "flops_per_row": flops_per_row}
 
 
 if __name__ == "__main__":

@@ -412,6 +412,9 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ta.map_u = c->map_u;          // null with frozen tables
     ta.map_i = c->map_i;
     ta.loss_part = c->loss_part;
+#ifdef MAMDR_STAMPS
+    ta.stamps = c->stamps;
+#endif
     {
         Prof p(c, MAMDR_KERNEL_FWD_BWD, true);
         launch_tower_train(ta, c->stream, p.e.a, p.e.b);
