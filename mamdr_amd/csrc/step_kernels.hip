@@ -46,7 +46,6 @@ template <> struct VecT<2> { typedef f32x2 type; };
 template <> struct VecT<1> { typedef float type; };
 
 constexpr int TOWER_THREADS = 512;   // 8 waves = 2 per SIMD: one wave's epilogue / waits overlap the other's MFMAs
-constexpr int TOWER_WAVES = TOWER_THREADS / 64;
 
 template <int TPW>
 __device__ __forceinline__ void load_b_rows(float (&b)[4][TPW], const float* __restrict__ p, int ld) {
