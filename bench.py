@@ -225,20 +225,22 @@ def main():
         epoch()
     barrier()
     t0 = time.perf_counter()
-    local_steps, global_steps = 0, 0
+    local_steps, global_steps, local_passes = 0, 0, 0
     for _ in range(args.steps):
         tr, b = epoch()
         local_steps += sum(t[2] for t in tr)
+        local_passes += len(tr)
         global_steps += b
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt, float(local_steps)], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([dt, float(local_steps), float(local_passes)], dtype=torch.float64, device=eng.device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         assert int(round(float(t[1]))) == global_steps, (float(t[1]), global_steps)
+        local_passes = int(round(float(t[2])))
 
     # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
     #      the same workload; reported for the dominant kernel, k_tower<train>
@@ -320,6 +322,9 @@ def main():
                        "parallelism": "domain-sharded x%d, 1 all-reduce of the DN displacement per epoch" % world
                        if world > 1 else "single GPU"},
             "us_per_domain_step": dt / global_steps * 1e6 * world,
+            # also domain-passes/sec (one pass = one domain's re-initialised iterator run to its end or
+            # cap) and the epoch time (= ms_per_step: a bench step is one meta-epoch)
+            "domain_passes_per_sec": local_passes / dt, "epoch_time_ms": dt / args.steps * 1e3,
             "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0))
             else roofline, "tower": roofline, "table_update": table_info or sweep_info, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
         }
