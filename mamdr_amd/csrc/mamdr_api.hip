@@ -89,6 +89,8 @@ struct mamdr_ctx {
     float* dz = nullptr;
     float* dlogit = nullptr;
     float* w0dom_copy = nullptr;
+    float* dm_copy = nullptr;       // pre-update snapshot of the domain table (dW0[256:384] by linearity)
+    bool lin_w0dom = false;         // k_wgrad carries no tiles for W0[256:384]: k_update rebuilds that gradient from S
     float* wT = nullptr;            // transposed W1 / W2 (k_tower4)
     int tower_tile = 0;             // 0 auto, 4 / 16 forced (env MAMDR_TOWER_TILE)
     // trainable user / item tables
@@ -141,14 +143,15 @@ struct mamdr_ctx {
 
 namespace {
 
-std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off) {
+std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off, bool lin_w0dom) {
     std::vector<TileDesc> t;
     struct G { int a_off, M, b_off, N, dst; };
     // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
     const G gemms[3] = {{0, XDIM, 0, H1, L.w0}, {XDIM, H1, H1, H2, L.w1}, {XDIM + H1, H2, H1 + H2, H3, L.w2}};
     // (64x64 tiles first: the kernel stages their operands through LDS)
+    // (lin_w0dom: rows 256..383 of x are per-domain constants, their part of dW0 follows from S in k_update)
     for (const G& g : gemms)
-        for (int m0 = 0; m0 < g.M; m0 += 64)
+        for (int m0 = 0; m0 < ((lin_w0dom && g.dst == L.w0) ? 2 * EMB : g.M); m0 += 64)
             for (int n0 = 0; n0 < g.N; n0 += 64)
                 t.push_back(TileDesc{0, g.a_off + m0, 0, g.b_off + n0, g.dst + m0 * g.N + n0, g.N, 64, 64, 1});
     // biases = column sums of dz (A = ones in row 0)
@@ -552,7 +555,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     }
 
     const size_t rp = (size_t)c->rows_pad_max;
-    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off);
+    c->lin_w0dom = !c->star && cfg->n_domain <= 64 && !getenv("MAMDR_NO_W0LIN");
+    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom);
     c->n_tiles = (int)tiles.size();
     float thr[500];
     thr[0] = (float)(0.0 - 1e-7);
@@ -571,6 +575,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->dz, rp * DZ_LD * sizeof(float));
     ALLOC(c->dlogit, rp * sizeof(float));
     ALLOC(c->w0dom_copy, (size_t)EMB * H1 * sizeof(float));
+    ALLOC(c->dm_copy, (size_t)cfg->n_domain * EMB * sizeof(float));
     if (c->star) {
         const size_t chunks = (rp + STAR_CHUNK - 1) / STAR_CHUNK;
         ALLOC(c->eff, (size_t)c->L.alloc * sizeof(float));
@@ -648,7 +653,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -970,6 +975,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         wa.slab_ld = c->slab_ld;
         wa.w0dom = c->params + c->table_floats + c->L.w0 + (size_t)(2 * EMB) * H1;
         wa.w0dom_copy = c->w0dom_copy;
+        wa.dm_copy = c->lin_w0dom ? c->dm_copy : nullptr;
         wa.loss_part = c->loss_part;
         wa.n_loss_tiles = use4 ? rows_pad / 4 : rows_pad / TILE_ROWS;
         wa.rows = rows;
@@ -996,6 +1002,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.slab_ld = c->slab_ld;
         ua.s_off = c->L.alloc;
         ua.w0dom_copy = c->w0dom_copy;
+        ua.dm_copy = c->lin_w0dom ? c->dm_copy : nullptr;
+        ua.n_domain = c->cfg.n_domain;
         ua.count4 = c->L.alloc / 4;
         ua.dm_count = c->cfg.n_domain * EMB;
         ua.two_l2 = 2.0f * c->cfg.l2_emb;

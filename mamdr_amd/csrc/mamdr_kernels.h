@@ -108,6 +108,7 @@ struct WgradArgs {
     float* loss_out;           // nullable: 1 float
     const float* w0dom;        // W0[256:384, :] (live weights)
     float* w0dom_copy;         // its pre-update snapshot, read by k_update
+    float* dm_copy;            // pre-update snapshot of the domain table (k_update: dW0[256:384] by linearity), nullable
 #ifdef MAMDR_STAMPS
     unsigned long long* stamps; // diagnostic build only
 #endif
@@ -124,6 +125,8 @@ struct UpdateArgs {
     int dm_count;              // elements [0, dm_count): domain table, gradient = S . W0dom^T + 2*l2*p
     int s_off;                 // offset of S = onehot(domain)^T dz1 ([n_domain][256]) inside a slab
     const float* w0dom_copy;
+    const float* dm_copy;      // not null: dW0[256:384, :] = Dm^T . S (the slabs carry no tiles for those rows)
+    int n_domain;
     int s2_off;                // DeepFM: offset of S2 = onehot(domain)^T fmq ([n_domain][EMB]) inside a slab, 0 = none
     int ld_off, ld_count;      // DeepFM: linear domain table (gradient += 2 l2_lin p)
     float two_l2_lin;

@@ -902,9 +902,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n_work = g.n_tiles * g.n_groups;
     if ((int)blockIdx.x > n_work) {
-        // ---- snapshot of W0[256:384, :] (pre-update) for the domain-table gradient in k_update
+        // ---- snapshots (pre-update) for k_update: W0[256:384, :] for the domain-table gradient and the
+        // domain table for dW0[256:384, :]
         const int e = ((int)blockIdx.x - n_work - 1) * 256 + tid;
-        reinterpret_cast<f32x4*>(g.w0dom_copy)[e] = reinterpret_cast<const f32x4*>(g.w0dom)[e];
+        if (e < W0DOM_FLOAT4) {
+            reinterpret_cast<f32x4*>(g.w0dom_copy)[e] = reinterpret_cast<const f32x4*>(g.w0dom)[e];
+        } else if (g.dm_copy && e - W0DOM_FLOAT4 < g.dm_count / 4) {
+            reinterpret_cast<f32x4*>(g.dm_copy)[e - W0DOM_FLOAT4] = reinterpret_cast<const f32x4*>(g.dense)[e - W0DOM_FLOAT4];
+        }
         return;
     }
     if ((int)blockIdx.x == n_work) {
@@ -977,7 +982,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     WSTAMP(4);
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS), dim3(256), 0, s, a);
+    const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs), dim3(256), 0, s, a);
 }
 
 // sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
@@ -1024,58 +1030,118 @@ __device__ __forceinline__ void optimizer_step(const UpdateArgs& u, float g, flo
     }
 }
 
-__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
-    const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
-    if ((int)blockIdx.x < n_vec_wgs) {
-        // dense weights behind the domain table: float4 per thread
-        const int e4 = u.dm_count / 4 + blockIdx.x * 256 + threadIdx.x;
-        if (e4 >= u.count4) return;
-        const size_t e = (size_t)e4 * 4;
-        f32x4 gsum = slab_sum4(u.slabs, u.n_groups, u.slab_ld, e);
-        f32x4 p = *reinterpret_cast<const f32x4*>(u.p + e);
-        f32x4 m = *reinterpret_cast<const f32x4*>(u.m + e);
-        f32x4 v = *reinterpret_cast<const f32x4*>(u.v + e);
+// four consecutive elements e..e+3 of the dense block (e a multiple of 4) with gradient sum gsum: the linear
+// domain table's regulariser, the optimiser, and the transposed copies k_tower4's backward layers read
+__device__ __forceinline__ void apply_vec4(const UpdateArgs& u, size_t e, f32x4 gsum, f32x4 p, f32x4 m, f32x4 v) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float pc = p[c], mc = m[c], vc = v[c];
-            const int ec = (int)e + c;
-            if (ec >= u.ld_off && ec < u.ld_off + u.ld_count) gsum[c] += u.two_l2_lin * pc;
-            optimizer_step(u, gsum[c], pc, mc, vc);
-            p[c] = pc;
-            m[c] = mc;
-            v[c] = vc;
+    for (int c = 0; c < 4; ++c) {
+        float pc = p[c], mc = m[c], vc = v[c];
+        const int ec = (int)e + c;
+        if (ec >= u.ld_off && ec < u.ld_off + u.ld_count) gsum[c] += u.two_l2_lin * pc;
+        optimizer_step(u, gsum[c], pc, mc, vc);
+        p[c] = pc;
+        m[c] = mc;
+        v[c] = vc;
+    }
+    if (u.optimizer == 2) {
+        *reinterpret_cast<f32x4*>(u.m + e) = m;
+        return;
+    }
+    if (u.optimizer == 0) {
+        *reinterpret_cast<f32x4*>(u.m + e) = m;
+        *reinterpret_cast<f32x4*>(u.v + e) = v;
+    }
+    *reinterpret_cast<f32x4*>(u.p + e) = p;
+    if (u.wT) {     // keep the transposed copies used by k_tower4's backward layers current
+        const int e0 = (int)e;
+        if (e0 >= u.w1_off && e0 < u.w1_off + H1 * H2) {
+            const int f = e0 - u.w1_off, r = f / H2, c = f - r * H2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u.wT[W1T_OFF + (c + k) * H1 + r] = p[k];
+        } else if (e0 >= u.w2_off && e0 < u.w2_off + H2 * H3) {
+            const int f = e0 - u.w2_off, r = f / H3, c = f - r * H3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u.wT[W2T_OFF + (c + k) * H2 + r] = p[k];
+        } else if (u.w0t && e0 >= u.w0_off && e0 < u.w0_off + 2 * EMB * H1) {
+            const int f = e0 - u.w0_off, r = f / H1, c = f - r * H1;      // W0[r][c], user | item rows
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u.wT[W0T_OFF + (c + k) * (2 * EMB) + r] = p[k];
         }
-        if (u.optimizer == 2) {
-            *reinterpret_cast<f32x4*>(u.m + e) = m;
-            return;
-        }
-        if (u.optimizer == 0) {
-            *reinterpret_cast<f32x4*>(u.m + e) = m;
-            *reinterpret_cast<f32x4*>(u.v + e) = v;
-        }
-        *reinterpret_cast<f32x4*>(u.p + e) = p;
-        if (u.wT) {     // keep the transposed copies used by k_tower4's backward layers current
-            const int e0 = (int)e;
-            if (e0 >= u.w1_off && e0 < u.w1_off + H1 * H2) {
-                const int f = e0 - u.w1_off, r = f / H2, c = f - r * H2;
+    }
+}
+
+__device__ __forceinline__ void apply_vec4(const UpdateArgs& u, size_t e, f32x4 gsum) {
+    apply_vec4(u, e, gsum, *reinterpret_cast<const f32x4*>(u.p + e), *reinterpret_cast<const f32x4*>(u.m + e),
+               *reinterpret_cast<const f32x4*>(u.v + e));
+}
+
+// dW0[256:384, :] by linearity.  Those rows of x are the domain-embedding row of the sample's domain, the same
+// vector for every sample of a domain, so  sum_b x[b][256 + r] dz1[b][c] = sum_d Dm[d][r] S[d][c]  with
+// S = onehot(domain)^T dz1 -- which k_wgrad computes anyway for the domain-table gradient.  8 of the 34 64x64
+// tiles of k_wgrad (24 % of its MFMA work) become D fmas per element here.  One workgroup per 8 columns:
+// S[:, 8 columns] is summed over the slabs into LDS once, thread (r, half) then owns W0[256 + r][c0 + 4 half .. +3].
+constexpr int W0LIN_COLS = 8;
+constexpr int W0LIN_WGS = H1 / W0LIN_COLS;      // 32
+__device__ __forceinline__ void update_w0dom_linear(const UpdateArgs& u, int wg, float* s_l) {
+    const int tid = threadIdx.x, c0 = wg * W0LIN_COLS;
+    const int r = tid >> 1, half = tid & 1;
+    // this thread's parameters and slots, and the first eight domains' embedding values of row r, are requested
+    // before the S block is reduced
+    const size_t e = (size_t)u.w0_off + (size_t)(2 * EMB + r) * H1 + c0 + 4 * half;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(u.p + e);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(u.m + e);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(u.v + e);
+    float x[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) u.wT[W1T_OFF + (c + k) * H1 + r] = p[k];
-            } else if (e0 >= u.w2_off && e0 < u.w2_off + H2 * H3) {
-                const int f = e0 - u.w2_off, r = f / H3, c = f - r * H3;
+    for (int k = 0; k < 8; ++k) x[k] = u.dm_copy[min(k, u.n_domain - 1) * EMB + r];
+    for (int idx = tid; idx < u.n_domain * W0LIN_COLS; idx += 256) {
+        const int d = idx / W0LIN_COLS, cc = idx - d * W0LIN_COLS;
+        s_l[idx] = slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + c0 + cc);
+    }
+    __syncthreads();
+    f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < u.n_domain; d0 += 8) {
+        float xn[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) u.wT[W2T_OFF + (c + k) * H2 + r] = p[k];
-            } else if (u.w0t && e0 >= u.w0_off && e0 < u.w0_off + 2 * EMB * H1) {
-                const int f = e0 - u.w0_off, r = f / H1, c = f - r * H1;      // W0[r][c], user | item rows
+        for (int k = 0; k < 8; ++k) xn[k] = u.dm_copy[min(d0 + 8 + k, u.n_domain - 1) * EMB + r];   // next eight
 #pragma unroll
-                for (int k = 0; k < 4; ++k) u.wT[W0T_OFF + (c + k) * (2 * EMB) + r] = p[k];
+        for (int k = 0; k < 8; ++k) {
+            if (d0 + k < u.n_domain) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + (d0 + k) * W0LIN_COLS + 4 * half);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = fmaf(x[k], sv[q], g[q]);
             }
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = xn[k];
+    }
+    apply_vec4(u, e, g, p0, m0, v0);
+}
+
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
+    __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];     // n_domain <= 64
+    const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
+    // the workgroups with the longest dependent chain come first in the grid
+    const int n_lin_wgs = u.dm_copy ? W0LIN_WGS : 0;
+    if ((int)blockIdx.x < n_lin_wgs) {
+        update_w0dom_linear(u, (int)blockIdx.x, s_l);
+        return;
+    }
+    const int bid = (int)blockIdx.x - n_lin_wgs;
+    if (bid < n_vec_wgs) {
+        // dense weights behind the domain table: float4 per thread
+        const int e4 = u.dm_count / 4 + bid * 256 + threadIdx.x;
+        if (e4 >= u.count4) return;
+        const size_t e = (size_t)e4 * 4;
+        // (rows 256..383 of W0 have no tiles when their gradient comes from S: update_w0dom_linear)
+        if (u.dm_copy && (int)e >= u.w0_off + 2 * EMB * H1 && (int)e < u.w0_off + XDIM * H1) return;
+        apply_vec4(u, e, slab_sum4(u.slabs, u.n_groups, u.slab_ld, e));
         return;
     }
     // domain table: one wave per element (d, c):
     //   g = sum_k S[d][k] * W0[256 + c][k] + 2 l2 p,   S = onehot(domain)^T dz1 summed over the slabs
     const int lane = threadIdx.x & 63;
-    const int el = ((int)blockIdx.x - n_vec_wgs) * 4 + (threadIdx.x >> 6);
+    const int el = (bid - n_vec_wgs) * 4 + (threadIdx.x >> 6);
     if (el >= u.dm_count) return;
     const int d = el / EMB, c = el - d * EMB;
     const size_t so = (size_t)u.s_off + (size_t)d * H1 + 4 * lane;
@@ -1103,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
 }
 void launch_update(const UpdateArgs& a, hipStream_t s) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
-    hipLaunchKernelGGL(k_update, dim3(n_vec_wgs + (a.dm_count + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_update, dim3(n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0)), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr
