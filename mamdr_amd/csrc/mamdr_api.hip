@@ -143,7 +143,7 @@ struct mamdr_ctx {
 
 namespace {
 
-std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off, bool lin_w0dom) {
+std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off, bool lin_w0dom, bool star) {
     std::vector<TileDesc> t;
     struct G { int a_off, M, b_off, N, dst; };
     // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
@@ -163,7 +163,8 @@ std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepf
     t.push_back(TileDesc{1, 0, 1, 0, L.gb, 0, 1, 1});
     // domain table, by linearity: S = onehot(domain)^T dz1 ([n_domain][256], behind the dense block in
     // the slab); k_update turns it into dDm = S . W0[256:384,:]^T
-    for (int m0 = 0; m0 < n_domain; m0 += 32)
+    // (not for the Star tower: its domain-row gradient comes through PartitionedNorm's backward)
+    for (int m0 = 0; m0 < (star ? 0 : n_domain); m0 += 32)
         for (int n0 = 0; n0 < H1; n0 += 32) {
             const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
             t.push_back(TileDesc{2, m0, 0, n0, L.alloc + m0 * H1 + n0, H1, mv, 32});
@@ -488,6 +489,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ua.slab_ld = c->slab_ld;
     ua.sums = c->star_sums;
     ua.dmsum = c->star_sums + 2 * XDIM;
+    ua.xdom = c->lin_w0dom ? c->pn + PN_XDOM_OFF : nullptr;
     ua.opt.optimizer = optimizer;
     ua.opt.alpha = alpha;
     ua.opt.omb1 = omb1;
@@ -555,8 +557,10 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     }
 
     const size_t rp = (size_t)c->rows_pad_max;
-    c->lin_w0dom = !c->star && cfg->n_domain <= 64 && !getenv("MAMDR_NO_W0LIN");
-    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom);
+    // dW0[256:384] without tiles: Dm^T . S in k_update, or (Star: one normalised domain row per batch) the
+    // rank-1 form in k_star_update
+    c->lin_w0dom = (c->star || cfg->n_domain <= 64) && !getenv("MAMDR_NO_W0LIN");
+    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom, c->star);
     c->n_tiles = (int)tiles.size();
     float thr[500];
     thr[0] = (float)(0.0 - 1e-7);

@@ -99,7 +99,8 @@ struct StarAuxLayout {
 constexpr float PN_EPS = 1e-3f;
 constexpr float PN_MOMENTUM = 0.99f;
 constexpr int STAR_CHUNK = 16;        // batch rows per partial of the column statistics
-constexpr int PN_WS_FLOATS = 5 * XDIM;   // scale | shift | mean | inv | coef = gamma_eff * inv
+constexpr int PN_XDOM_OFF = 5 * XDIM;    // the batch's normalised domain-embedding row (what every sample's x[256:384] is)
+constexpr int PN_WS_FLOATS = 5 * XDIM + EMB;   // scale | shift | mean | inv | coef = gamma_eff * inv | xdom
 
 // ---- counter-based dropout stream (restated in oracle/rng.py)
 __host__ __device__ inline uint32_t fmix32(uint32_t h) {

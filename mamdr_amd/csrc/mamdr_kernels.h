@@ -260,6 +260,7 @@ struct StarUpdateArgs {
     int n_groups, slab_ld;
     const float* sums;         // PartitionedNorm [2][384]
     const float* dmsum;        // [EMB] gradient of the domain-table row d
+    const float* xdom;         // [EMB] the batch's normalised domain row (k_star_prep)
     OptArgsLite opt;
 };
 void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hipStream_t s);

@@ -169,6 +169,12 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
         a.pn[2 * XDIM + c] = mean;
         a.pn[3 * XDIM + c] = inv;
         a.pn[4 * XDIM + c] = __fmul_rn(gamma, inv);
+        // the normalised domain row, rounded exactly as the tower's gather rounds it: every sample of the batch
+        // carries it in x[256:384], so dW0[256:384, :] = xdom (x) column sums of dz1 (k_star_update)
+        if (c >= 2 * EMB) {
+            const float raw = a.blk[a.SL.dm + (size_t)a.d * EMB + (c - 2 * EMB)];
+            a.pn[PN_XDOM_OFF + (c - 2 * EMB)] = __fadd_rn(__fmul_rn(raw, scale), __fsub_rn(beta, __fmul_rn(mean, scale)));
+        }
         return;
     }
     // effective dense block, one element per thread
@@ -356,7 +362,15 @@ __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
             opt_apply(u.opt, 0.f, u.p, u.m, u.v, wi);
             return;
         }
-        const float gK = slab_sum(u, (l == 0 ? u.L.w0 : (l == 1 ? u.L.w1 : u.L.w2)) + i);
+        float gK;
+        if (u.xdom && l == 0 && i >= 2 * EMB * H1) {
+            // rows 256..383 of x are the same normalised domain row for every sample of the batch: the tile-free
+            // rank-1 form  dK0[256 + r][c] = xdom[r] * sum_b dz1[b][c]  (the bias gradient of column c)
+            const int r = i / H1 - 2 * EMB, c = i - (i / H1) * H1;
+            gK = u.xdom[r] * slab_sum(u, u.L.b0 + c);
+        } else {
+            gK = slab_sum(u, (l == 0 ? u.L.w0 : (l == 1 ? u.L.w1 : u.L.w2)) + i);
+        }
         const size_t si = (size_t)u.SL.ws[l] + i;
         const float ws = u.p[si], wd = u.p[wi];
         opt_apply(u.opt, gK * ws, u.p, u.m, u.v, wi);
