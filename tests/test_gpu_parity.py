@@ -292,6 +292,44 @@ def test_trainable_tables_gradients_and_adam(env):
     eng.close()
 
 
+@pytest.mark.parametrize("batch", [256, 1024, 4096])
+def test_mixed_domain_ids_in_one_batch(env, batch):
+    """The domain-table gradient and dW0[256:384] are rebuilt from S = onehot(domain)^T dz1 by linearity (k_wgrad
+    carries no tiles for those rows of W0): exact for ANY mix of domain ids inside a batch, not only for the
+    one-domain batches a pass normally produces.  A split whose domain column cycles through several ids,
+    one SGD step at lr 1: every gradient against the oracle, at one and at several row groups per tile, with
+    the 4-row and the 16-row tower."""
+    g, eng, model = make_problem(env, scale=0.3 if batch > 1024 else 0.1, batch=batch, dropout=0.5)
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = {k: v.copy() for k, v in g["data"]["train"][d].items()}
+    n = cols["uid"].shape[0]
+    assert n >= batch
+    rs = np.random.RandomState(3)
+    cols["domain"][:] = rs.choice([1, 4, 7, 9], size=n).astype(cols["domain"].dtype)
+    eng.bind_domain_data(d, "train", cols["uid"], cols["pid"], cols["domain"], cols["label"])
+    perm = orng.shuffle_perm(n, 10000, seed=8)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    idx = perm[:batch]
+    assert len(np.unique(cols["domain"][idx])) == 4
+    masks = otower.train_masks(model.seed, model.step, batch, model.hidden, 0.5)
+    loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                           cols["label"][idx], masks, 0.5, False)
+    want = eng.pack(grads).cpu().numpy()
+    w0 = eng.get_weights()
+    loss_t = torch.zeros(1, device=eng.device)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+    got = (w0 - eng.get_weights()).cpu().numpy()
+    for name, (off, cnt) in eng.segments.items():
+        w = want[off:off + cnt]
+        np.testing.assert_allclose(got[off:off + cnt], w, rtol=2e-4, atol=max(2e-6 * max(np.abs(w).max(), 1e-3), 1e-8),
+                                   err_msg=name)
+    assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    off = eng.segments["domain_emb"][0]
+    mag = np.abs(want[off:off + 1280].reshape(10, 128)).max(axis=1)
+    assert mag[[1, 4, 7, 9]].min() > 100 * mag[[0, 2, 3, 5, 6, 8]].max()   # the other rows see the regulariser only
+    eng.close()
+
+
 @pytest.mark.parametrize("tower", ["mlp", "deepfm"])
 def test_trainable_tables_heavy_duplicates(env, tower):
     """A batch of 4096 in which one user occupies 3000 positions and five items share all of them: the row
