@@ -1135,7 +1135,11 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
         const size_t e = (size_t)e4 * 4;
         // (rows 256..383 of W0 have no tiles when their gradient comes from S: update_w0dom_linear)
         if (u.dm_copy && (int)e >= u.w0_off + 2 * EMB * H1 && (int)e < u.w0_off + XDIM * H1) return;
-        apply_vec4(u, e, slab_sum4(u.slabs, u.n_groups, u.slab_ld, e));
+        // (parameters and slots are requested before the slab sum is waited for: one round of misses, not two)
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(u.p + e);
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(u.m + e);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(u.v + e);
+        apply_vec4(u, e, slab_sum4(u.slabs, u.n_groups, u.slab_ld, e), p0, m0, v0);
         return;
     }
     // domain table: one wave per element (d, c):
@@ -1145,15 +1149,15 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
     if (el >= u.dm_count) return;
     const int d = el / EMB, c = el - d * EMB;
     const size_t so = (size_t)u.s_off + (size_t)d * H1 + 4 * lane;
-    const f32x4 sv = slab_sum4(u.slabs, u.n_groups, u.slab_ld, so);
+    // (every load of the element is requested up front; all lanes read p / m / v / S2 of the element: one address)
+    float p = u.p[el], m = u.m[el], v = u.v[el];
     const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
+    const float g2 = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
+    const f32x4 sv = slab_sum4(u.slabs, u.n_groups, u.slab_ld, so);
     float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
     for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
     if (lane == 0) {
-        float p = u.p[el], m = u.m[el], v = u.v[el];
-        if (u.s2_off) {
-            g += slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el);
-        }
+        if (u.s2_off) g += g2;
         g += u.two_l2 * p;
         optimizer_step(u, g, p, m, v);
         if (u.optimizer == 2) {
