@@ -1,0 +1,21 @@
+"""A handful of training steps on one domain, for hardware-counter passes (rocprofv3 --pmc ... -- python3 tools/pmc_steps.py).
+usage: python tools/pmc_steps.py [shape] [batch] [steps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mamdr_amd import engine, synthetic
+shape = sys.argv[1] if len(sys.argv) > 1 else "taobao30"
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+g = synthetic.generate(shape, batch_size=bs, seed=123)
+eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], bs, dropout=0.5)
+eng.bind_table("user_emb", g["tables"]["user_emb"]); eng.bind_table("item_emb", g["tables"]["item_emb"])
+d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+c = g["data"]["train"][d]; eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+rs = np.random.RandomState(0)
+eng.set_weights(torch.from_numpy((rs.standard_normal(eng.n_params) * 0.05).astype(np.float32)).to(eng.device))
+n = eng.n_rows(d, "train")
+perm = torch.from_numpy(engine.shuffle_perm(n, 10000, 1)).to(eng.device)
+eng.train_steps(d, perm=perm, first_step=0, n_steps=min(steps, -(-n // bs)))
+torch.cuda.synchronize()
+print("done", shape, bs, min(steps, -(-n // bs)))
