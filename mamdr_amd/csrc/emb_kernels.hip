@@ -11,7 +11,7 @@
 //   k_emb_sweep   HBM-bound pass over both tables: g = 2 l2 p (+ gbuf[map[row]]), Adam / SGD /
 //                 accumulate; resets map[row] on the way
 //   k_lin_sweep   DeepFM only: the 1-d linear tables of the same two features, same rule
-#include "mamdr_kernels.h"
+#include "emb_bodies.h"
 
 namespace mamdr {
 
@@ -25,66 +25,6 @@ void launch_emb_map_init(int32_t* map, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_fill, dim3(blocks), dim3(256), 0, s, map, n, EMB_UNTOUCHED);
 }
 
-// TF1 ApplyAdam on one element with an explicit rounding sequence: the dense sweep, the lazy catch-up,
-// the touched-row update and the flush all go through it, so a row that is advanced lazily ends up with
-// exactly the bits the per-step dense sweep would have produced.
-__device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v, float alpha, float omb1, float omb2,
-                                          float eps) {
-    m = __fmaf_rn(__fsub_rn(g, m), omb1, m);
-    v = __fmaf_rn(__fsub_rn(__fmul_rn(g, g), v), omb2, v);
-    // sqrt and reciprocal on the hardware units (v_sqrt_f32 / v_rcp_f32, 1 ulp): the replay of long gaps is
-    // bound by exactly this sequence, and both paths share it, so they still agree bit for bit
-    p = __fsub_rn(p, __fmul_rn(__fmul_rn(m, alpha), __builtin_amdgcn_rcpf(__fadd_rn(__builtin_amdgcn_sqrtf(v), eps))));
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// lazy mode: the representative wave of k_emb_reduce applies Adam step t_now to its row right away
-// (columns 2*lane, 2*lane+1 of row r; the row was brought to t_now - 1 by k_emb_catchup before the gather)
-__device__ __forceinline__ void emb_apply_row(const EmbStepArgs& a, const EmbTable& T, bool second, int r, int lane,
-                                              f32x2 gsum) {
-    const size_t e = ((size_t)(second ? a.t[0].n_rows : 0) + r) * EMB + 2 * lane;
-    f32x2 p = *reinterpret_cast<const f32x2*>(a.p + e);
-    f32x2 m = *reinterpret_cast<const f32x2*>(a.m + e);
-    f32x2 v = *reinterpret_cast<const f32x2*>(a.v + e);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        float pk = p[k], mk = m[k], vk = v[k];
-        adam_elem(__fadd_rn(__fmul_rn(a.opt.two_l2, pk), gsum[k]), pk, mk, vk, a.opt.alpha, a.opt.omb1, a.opt.omb2,
-                  a.opt.eps);
-        p[k] = pk; m[k] = mk; v[k] = vk;
-    }
-    *reinterpret_cast<f32x2*>(a.p + e) = p;
-    *reinterpret_cast<f32x2*>(a.m + e) = m;
-    *reinterpret_cast<f32x2*>(a.v + e) = v;
-    if (lane == 0) {
-        T.last[r] = a.t_now;
-        if (!T.lin_p) T.map[r] = EMB_UNTOUCHED;      // DeepFM: k_lin_sweep still needs the map and resets it
-    }
-}
-
-// the same step on columns 4*c4 .. 4*c4+3 (the no-duplicate path: half a wave per row)
-__device__ __forceinline__ void emb_apply_row4(const EmbStepArgs& a, const EmbTable& T, bool second, int r, int c4,
-                                               f32x4 gsum) {
-    const size_t e = ((size_t)(second ? a.t[0].n_rows : 0) + r) * EMB + 4 * c4;
-    f32x4 p = *reinterpret_cast<const f32x4*>(a.p + e);
-    f32x4 m = *reinterpret_cast<const f32x4*>(a.m + e);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.v + e);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float pk = p[k], mk = m[k], vk = v[k];
-        adam_elem(__fadd_rn(__fmul_rn(a.opt.two_l2, pk), gsum[k]), pk, mk, vk, a.opt.alpha, a.opt.omb1, a.opt.omb2,
-                  a.opt.eps);
-        p[k] = pk; m[k] = mk; v[k] = vk;
-    }
-    *reinterpret_cast<f32x4*>(a.p + e) = p;
-    *reinterpret_cast<f32x4*>(a.m + e) = m;
-    *reinterpret_cast<f32x4*>(a.v + e) = v;
-    if (c4 == 0) {
-        T.last[r] = a.t_now;
-        if (!T.lin_p) T.map[r] = EMB_UNTOUCHED;
-    }
-}
-
 __global__ __launch_bounds__(256) void k_emb_flag(const EmbStepArgs a) {
     const EmbTable& T = a.t[blockIdx.y];
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -95,136 +35,9 @@ __global__ __launch_bounds__(256) void k_emb_flag(const EmbStepArgs a) {
     if (rep != b) T.hasdup[rep] = 1;           // same value from every writer
 }
 
-// 8 batch positions per 256-thread workgroup (one grid row per table); only representatives (the minimum
-// position of their row) do work.
-// Phase A, the common case -- no other position shares the row: half a wave per position, 32 lanes x float4 =
-// the 512-B row, gradient row + p / m / v in one round of loads, Adam, store (the layout of k_emb_catchup).
-// Phase B -- rows that occur more than once (flagged by k_emb_catchup / k_emb_flag; Amazon-13, 8192 rows:
-// ~900 of 16 K positions, lists of 1-3): the representative's wave looks at the whole batch, 512 positions per
-// step (two 16-B loads of brow per lane, four steps in flight; brow is 32 KB and cache-resident).  Steps
-// without a match -- all but a few -- cost a compare and one ballot.  In a step with matches the matching
-// lanes append their positions to the wave's LDS list at (count + matches in lower lanes + own earlier
-// matches): ascending positions without a prefix sum.  The listed positions' gradient rows are then added IN
-// THAT ORDER (bitwise reproducible, no float atomics), 8 row loads in flight, lane l owning columns 2l, 2l+1;
-// the list is drained whenever the next step might overflow it.
-// (History: one 128-thread workgroup per position with a worst-case 32 KB list: 48 us of a 300 us Amazon-13
-// step, occupancy-bound on the trivial workgroups; 16-bit lists and two scanning waves: 30 us; one wave per
-// two positions scanning 64 positions per step, from global memory or from an LDS copy: 48-56 us -- the
-// serial chain of 128 dependent steps per flagged row was the whole kernel.)
-constexpr int RED_STEP = 512;                  // positions per scan step (8 per lane)
-constexpr int RED_CAP = 2 * RED_STEP;          // list entries per wave
 __global__ __launch_bounds__(256) void k_emb_reduce(const EmbStepArgs a) {
-    __shared__ uint16_t list_all[4][RED_CAP];  // positions fit 16 bits (max_batch <= 16384)
-    const EmbTable& T = a.t[blockIdx.y];
-    const bool second = blockIdx.y != 0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int h = lane >> 5, c4 = lane & 31;
-    const int b = blockIdx.x * 8 + w * 2 + h;  // this half-wave's position
-    int r = -1;
-    bool dupf = false;
-    if (b < a.rows) {
-        const int rb = T.brow[b];
-        if (rb >= 0 && T.map[rb] == b) {
-            r = rb;
-            dupf = T.hasdup[b] != 0;
-        }
-    }
-    // ---- phase A
-    if (r >= 0 && !dupf) {
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.dxe + (size_t)b * a.dx_ld + T.dx_off + 4 * c4);
-        if (T.lin_p && c4 == 0) T.glin[b] = a.dlogit[b];
-        if (a.apply_now) emb_apply_row4(a, T, second, r, c4, g4);
-        else *reinterpret_cast<f32x4*>(T.gbuf + (size_t)b * EMB + 4 * c4) = g4;
-    }
-    const unsigned long long dmask = __ballot(dupf);       // bits 0..31: position h = 0, bits 32..63: h = 1
-    if (dmask == 0ull) return;                              // wave-uniform
-    // ---- phase B
-    uint16_t* L = list_all[w];
-    const int n_steps = (a.rows + RED_STEP - 1) / RED_STEP;
-    const int rows8 = (a.rows + 7) / 8;                     // brow is allocated (and -1 padded) to a multiple of 16
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll 1
-    for (int s = 0; s < 2; ++s) {
-        if (((dmask >> (32 * s)) & 1ull) == 0ull) continue;            // wave-uniform
-        const int bs = blockIdx.x * 8 + w * 2 + s;
-        const int rs = __shfl(r, 32 * s);
-        const float* gcol = a.dxe + T.dx_off + 2 * lane;
-        f32x2 acc = *reinterpret_cast<const f32x2*>(gcol + (size_t)bs * a.dx_ld);
-        float accl = T.lin_p ? a.dlogit[bs] : 0.f;         // DeepFM: the 1-d linear table's row gradient
-        int cnt = 0;                           // wave-uniform
-        auto drain = [&]() {
-            __builtin_amdgcn_wave_barrier();
-            int k = 0;
-            for (; k + 8 <= cnt; k += 8) {
-                f32x2 v8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v8[u] = *reinterpret_cast<const f32x2*>(gcol + (size_t)L[k + u] * a.dx_ld);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v8[u];
-            }
-            for (; k < cnt; ++k) acc += *reinterpret_cast<const f32x2*>(gcol + (size_t)L[k] * a.dx_ld);
-            if (T.lin_p)
-                for (int q = 0; q < cnt; ++q) accl += a.dlogit[L[q]];
-            __builtin_amdgcn_wave_barrier();
-            cnt = 0;
-        };
-        // lane's eight positions of step `st` (brow is -1 beyond the batch: never a match)
-        auto load8 = [&](int st, int4& lo, int4& hi) {
-            const int g8 = min(st * 64 + lane, rows8 - 1);  // (clamped lanes re-read the last group: masked in step)
-            lo = reinterpret_cast<const int4*>(T.brow)[2 * g8];
-            hi = reinterpret_cast<const int4*>(T.brow)[2 * g8 + 1];
-        };
-        auto step = [&](int st, const int4 lo, const int4 hi) {
-            const int base = st * RED_STEP + lane * 8;
-            unsigned m8 = (lo.x == rs ? 1u : 0u) | (lo.y == rs ? 2u : 0u) | (lo.z == rs ? 4u : 0u) | (lo.w == rs ? 8u : 0u) |
-                          (hi.x == rs ? 16u : 0u) | (hi.y == rs ? 32u : 0u) | (hi.z == rs ? 64u : 0u) | (hi.w == rs ? 128u : 0u);
-            // positions <= bs (only bs itself can carry the id) and the -1 padding are not matches
-            if (base <= bs) m8 &= base + 7 <= bs ? 0u : ~((2u << (bs - base)) - 1u);
-            if (st * 64 + lane >= rows8) m8 = 0u;
-            if (__ballot(m8 != 0) == 0ull) return;          // the usual case
-            if (cnt + RED_STEP > RED_CAP) drain();
-            int lower = 0, total = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned long long mj = __ballot((m8 >> j) & 1u);
-                lower += __popcll(mj & below);
-                total += __popcll(mj);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if ((m8 >> j) & 1u) L[cnt + lower + __popc(m8 & ((1u << j) - 1u))] = (uint16_t)(base + j);
-            cnt += total;
-        };
-        // bs is the row's minimum position: steps before its step hold no match
-        int st = bs / RED_STEP;
-        for (; st + 4 <= n_steps; st += 4) {
-            int4 lo[4], hi[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) load8(st + u, lo[u], hi[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) step(st + u, lo[u], hi[u]);
-        }
-        for (; st < n_steps; ++st) {
-            int4 lo, hi;
-            load8(st, lo, hi);
-            step(st, lo, hi);
-        }
-        drain();
-        if (lane == 0) {
-            T.hasdup[bs] = 0;                  // reset for the next step (read above by every lane that needs it)
-            if (T.lin_p) T.glin[bs] = accl;
-        }
-        if (a.apply_now) emb_apply_row(a, T, second, rs, lane, acc);
-        else *reinterpret_cast<f32x2*>(T.gbuf + (size_t)bs * EMB + 2 * lane) = acc;
-    }
-}
-
-__device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {
-    if (o.optimizer == 0) {
-        adam_elem(g, p, m, v, o.alpha, o.omb1, o.omb2, o.eps);
-    } else {
-        p = p - g * o.alpha;
-    }
+    __shared__ uint16_t list_all[4][RED_CAP];
+    emb_reduce_body(a, (int)blockIdx.x, (int)blockIdx.y, list_all);
 }
 
 // 16 B per lane over [user table | item table] (contiguous in the flat vector); a wave covers two
@@ -289,38 +102,7 @@ __global__ __launch_bounds__(256) void k_emb_sweep(const EmbStepArgs a) {
 }
 
 // DeepFM: 1-d linear tables of the two features (one scalar per table row) + the map reset
-__global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) {
-    const int64_t n0 = a.t[0].n_rows, n_all = n0 + a.t[1].n_rows;
-    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n_all; row += (int64_t)gridDim.x * 256) {
-        const bool second = row >= n0;
-        int32_t* map = second ? a.t[1].map : a.t[0].map;
-        const float* glin = second ? a.t[1].glin : a.t[0].glin;
-        float* lin_p = second ? a.t[1].lin_p : a.t[0].lin_p;
-        float* lin_m = second ? a.t[1].lin_m : a.t[0].lin_m;
-        float* lin_v = second ? a.t[1].lin_v : a.t[0].lin_v;
-        const int64_t lrow = second ? row - n0 : row;
-        float p = lin_p[lrow];
-        float g = a.two_l2_lin * p;
-        const int rep = map[lrow];
-        if (rep != EMB_UNTOUCHED) {
-            g += glin[rep];
-            map[lrow] = EMB_UNTOUCHED;
-        }
-        if (a.opt.optimizer == 2) {
-            lin_m[lrow] += g;
-            continue;
-        }
-        if (a.opt.optimizer == 0) {
-            float m = lin_m[lrow], v = lin_v[lrow];
-            opt_step(a.opt, g, p, m, v);
-            lin_m[lrow] = m;
-            lin_v[lrow] = v;
-        } else {
-            p = p - g * a.opt.alpha;
-        }
-        lin_p[lrow] = p;
-    }
-}
+__global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) { lin_sweep_body(a, (int)blockIdx.x, (int)gridDim.x); }
 
 // ------------------------------------------------------------------ lazy dense Adam
 // TF1's Adam moves EVERY table row every step (regulariser gradient 2 l2 p, decaying moments), which the

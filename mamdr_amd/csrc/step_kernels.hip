@@ -14,7 +14,7 @@
 // (model_zoo/DeepCTR/deepctr.py:54-60,118-136; call sites model_zoo/mamdr.py:54,86,97).
 #include <hip/hip_ext.h>
 
-#include "mamdr_kernels.h"
+#include "emb_bodies.h"
 
 namespace mamdr {
 
@@ -842,7 +842,7 @@ constexpr int WG_PF = 4;           // chunks in flight
 constexpr int WG_BUF = WG_KC * WG_LD;          // one operand buffer
 static_assert(4 * WG_BUF >= 4 * 1024, "the 32x32 path's reduction buffer aliases the staging buffers");
 
-__device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t, int gb0, int gb1, float* lds) {
+__device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t, int gb0, int gb1, float* lds, int grp) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int c = lane & 31, kk = lane >> 5;
@@ -888,7 +888,7 @@ __device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t,
     }
     WSTAMP(2);
     // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* dst = g.slabs + (size_t)(blockIdx.x % g.n_groups) * g.slab_ld + t.dst_off +
+    float* dst = g.slabs + (size_t)grp * g.slab_ld + t.dst_off +
                  (size_t)(wm * 32) * t.dst_ld + wn * 32;
     const int rb4 = 4 * (lane >> 5);
 #pragma unroll
@@ -897,14 +897,14 @@ __device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t,
     WSTAMP(4);
 }
 
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
-    __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
+// (a body: the kernel also hosts k_emb_reduce's workgroups in k_wgrad_reduce; bid = workgroup index, red = 4 WG_BUF floats of LDS)
+__device__ __forceinline__ void wgrad_body(const WgradArgs& g, const int bid, float* red) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n_work = g.n_tiles * g.n_groups;
-    if ((int)blockIdx.x > n_work) {
+    if (bid > n_work) {
         // ---- snapshots (pre-update) for k_update: W0[256:384, :] for the domain-table gradient and the
         // domain table for dW0[256:384, :]
-        const int e = ((int)blockIdx.x - n_work - 1) * 256 + tid;
+        const int e = (bid - n_work - 1) * 256 + tid;
         if (e < W0DOM_FLOAT4) {
             reinterpret_cast<f32x4*>(g.w0dom_copy)[e] = reinterpret_cast<const f32x4*>(g.w0dom)[e];
         } else if (g.dm_copy && e - W0DOM_FLOAT4 < g.dm_count / 4) {
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
         }
         return;
     }
-    if ((int)blockIdx.x == n_work) {
+    if (bid == n_work) {
         // ---- one extra workgroup: loss of the step = mean BCE + regularisers
         if (g.loss_out == nullptr && g.lv_count == 0) return;
         float* r4 = red;
@@ -938,13 +938,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
     // 4 MB L2), so the row group is the fast index: every XCD then touches the activation / gradient
     // rows of only n_groups/8 (or one of n_groups) groups and its tiles' re-reads of them hit its L2.
-    const int grp = blockIdx.x % g.n_groups, tile = blockIdx.x / g.n_groups;
+    const int grp = bid % g.n_groups, tile = bid / g.n_groups;
     const TileDesc t = g.tiles[tile];
     WSTAMP(1);
     const int gb0 = grp * g.rows_per_group;
     const int gb1 = min(gb0 + g.rows_per_group, g.rows_pad);
     if (t.big) {
-        wgrad_big(g, t, gb0, gb1, red);
+        wgrad_big(g, t, gb0, gb1, red, grp);
         return;
     }
     // split the group's rows over the 4 waves in multiples of 2
@@ -981,9 +981,32 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
     }
     WSTAMP(4);
 }
-void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
+    wgrad_body(g, (int)blockIdx.x, red);
+}
+// k_wgrad and k_emb_reduce only need the tower's outputs and write disjoint state: one launch, the table
+// workgroups behind the weight-gradient ones (they share CUs instead of queueing behind each other)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradArgs g, const EmbStepArgs e, const int n_wgrad) {
+    __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
+    const int bid = (int)blockIdx.x;
+    if (bid < n_wgrad) {
+        wgrad_body(g, bid, red);
+        return;
+    }
+    const int nb = (e.rows + 7) / 8, idx = bid - n_wgrad;
+    emb_reduce_body(e, idx % nb, idx / nb, reinterpret_cast<uint16_t(*)[RED_CAP]>(red));
+}
+static int wgrad_blocks(const WgradArgs& a) {
     const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
-    hipLaunchKernelGGL(k_wgrad, dim3(a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs), dim3(256), 0, s, a);
+    return a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs;
+}
+void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, hipStream_t s) {
+    const int n_wgrad = wgrad_blocks(a);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_wgrad + 2 * ((e.rows + 7) / 8)), dim3(256), 0, s, a, e, n_wgrad);
+}
+void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, a);
 }
 
 // sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
@@ -1118,16 +1141,15 @@ __device__ __forceinline__ void update_w0dom_linear(const UpdateArgs& u, int wg,
     apply_vec4(u, e, g, p0, m0, v0);
 }
 
-__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
-    __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];     // n_domain <= 64
+__device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, float* s_l) {
     const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
     // the workgroups with the longest dependent chain come first in the grid
     const int n_lin_wgs = u.dm_copy ? W0LIN_WGS : 0;
-    if ((int)blockIdx.x < n_lin_wgs) {
-        update_w0dom_linear(u, (int)blockIdx.x, s_l);
+    if (bx < n_lin_wgs) {
+        update_w0dom_linear(u, bx, s_l);
         return;
     }
-    const int bid = (int)blockIdx.x - n_lin_wgs;
+    const int bid = bx - n_lin_wgs;
     if (bid < n_vec_wgs) {
         // dense weights behind the domain table: float4 per thread
         const int e4 = u.dm_count / 4 + bid * 256 + threadIdx.x;
@@ -1171,9 +1193,30 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
         u.p[el] = p;
     }
 }
-void launch_update(const UpdateArgs& a, hipStream_t s) {
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
+    __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];     // n_domain <= 64
+    update_body(u, (int)blockIdx.x, s_l);
+}
+// k_update and DeepFM's k_lin_sweep touch disjoint state: one launch
+__global__ __launch_bounds__(256) void k_update_lin(const UpdateArgs u, const EmbStepArgs e, const int n_update, const int n_lin) {
+    __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
+    const int bid = (int)blockIdx.x;
+    if (bid < n_update) update_body(u, bid, s_l);
+    else lin_sweep_body(e, bid - n_update, n_lin);
+}
+static int update_blocks(const UpdateArgs& a) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
-    hipLaunchKernelGGL(k_update, dim3(n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0)), dim3(256), 0, s, a);
+    return n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0);
+}
+void launch_update(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_update, dim3(update_blocks(a)), dim3(256), 0, s, a);
+}
+void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, hipStream_t s) {
+    const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
+    int64_t n_lin = (n_all + 255) / 256;
+    if (n_lin > 256 * 8) n_lin = 256 * 8;
+    const int n_update = update_blocks(a);
+    hipLaunchKernelGGL(k_update_lin, dim3(n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin);
 }
 
 }  // namespace mamdr
