@@ -497,11 +497,21 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ua.opt.omb2 = omb2;
     ua.opt.eps = c->cfg.adam_eps;
     ua.opt.two_l2 = 0.f;
+    // lazy table Adam: k_emb_reduce rides in k_star_update's launch (disjoint state, both last in the step)
+    const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile;
     {
         Prof p(c, MAMDR_KERNEL_UPDATE);
-        launch_star_update(ua, c->stream);
+        if (tail) {
+            EmbStepArgs tea;
+            fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
+            tea.flags_done = 1;
+            tea.apply_now = 1;
+            launch_star_update_reduce(ua, tea, c->stream);
+        } else {
+            launch_star_update(ua, c->stream);
+        }
     }
-    if (c->cfg.emb_trainable) emb_post_step(c, optimizer, alpha, omb1, omb2, rows);
+    if (c->cfg.emb_trainable && !tail) emb_post_step(c, optimizer, alpha, omb1, omb2, rows);
     return MAMDR_OK;
 }
 

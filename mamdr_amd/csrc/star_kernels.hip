@@ -16,7 +16,7 @@
 //                   specific tensors of the other domains get zero gradient but still decay and move,
 //                   as tf.train.AdamOptimizer's sparse rule does)
 // Every reduction runs in a fixed order (no float atomics).
-#include "mamdr_kernels.h"
+#include "emb_bodies.h"
 
 namespace mamdr {
 
@@ -348,11 +348,12 @@ __device__ __forceinline__ float slab_sum(const StarUpdateArgs& u, int off) {
 
 // grid.y = domain slice dd.  The thread of the LIVE slice (dd == d) also owns the shared element, so the
 // products use the pre-update values of both factors; the other slices only decay (zero gradient).
-__global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
+// (a body: the kernel also hosts k_emb_reduce's workgroups in k_star_update_reduce; (bx, dd) = workgroup coordinates)
+__device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const int bx, const int dd) {
     const int K0 = XDIM * H1, K1 = H1 * H2, K2 = H2 * H3;
     const int n_kernel = K0 + K1 + K2, n_bias = H1 + H2 + H3;
-    int e = blockIdx.x * 256 + threadIdx.x;
-    const int d = u.d, dd = blockIdx.y;
+    int e = bx * 256 + threadIdx.x;
+    const int d = u.d;
     const bool live = dd == d;
     if (e < n_kernel) {
         const int l = e < K0 ? 0 : (e < K0 + K1 ? 1 : 2);
@@ -419,9 +420,30 @@ __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
         opt_apply(u.opt, live ? u.dmsum[e] : 0.f, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
     }
 }
+constexpr int STAR_UPDATE_N = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + EMB;
+constexpr int STAR_UPDATE_BX = (STAR_UPDATE_N + 255) / 256;
+__global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
+    star_update_body(u, (int)blockIdx.x, (int)blockIdx.y);
+}
+// the chain rule + optimiser on the Star block and the table update touch disjoint state and both come last in
+// the step: one launch, the table workgroups first (their chains are the longer ones)
+__global__ __launch_bounds__(256) void k_star_update_reduce(const StarUpdateArgs u, const EmbStepArgs e, const int n_reduce) {
+    __shared__ uint16_t list_all[4][RED_CAP];
+    const int bid = (int)blockIdx.x;
+    if (bid < n_reduce) {
+        const int nb = (e.rows + 7) / 8;
+        emb_reduce_body(e, bid % nb, bid / nb, list_all);
+        return;
+    }
+    const int idx = bid - n_reduce;
+    star_update_body(u, idx % STAR_UPDATE_BX, idx / STAR_UPDATE_BX);
+}
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
-    const int n = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + EMB;
-    hipLaunchKernelGGL(k_star_update, dim3((n + 255) / 256, a.n_domain), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_star_update, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
+}
+void launch_star_update_reduce(const StarUpdateArgs& a, const EmbStepArgs& e, hipStream_t s) {
+    const int n_reduce = 2 * ((e.rows + 7) / 8);
+    hipLaunchKernelGGL(k_star_update_reduce, dim3(n_reduce + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, e, n_reduce);
 }
 
 }  // namespace mamdr
