@@ -258,4 +258,28 @@ __device__ __forceinline__ void lin_sweep_body(const EmbStepArgs& a, int bx, int
 }
 
 
+// Row ids + representatives of a batch (see k_emb_rows in emb_kernels.hip).  A body: the NEXT step's rows can be
+// resolved in the current step's last launch (k_update_lin), into the other half of a double buffer.
+__device__ __forceinline__ void emb_rows_body(const EmbRowsArgs& a, int bx) {
+    const int b = bx * 256 + threadIdx.x;
+    if (b == 0) a.alpha_log[a.log_idx] = a.alpha;
+    if (b >= a.rows_pad) return;
+    if (b >= a.rows) {
+        a.urow[b] = -1;
+        a.irow[b] = -1;
+        return;
+    }
+    const int64_t pos = a.row_base + b;
+    int64_t src = a.perm ? (int64_t)a.perm[pos] : pos;
+    if (src < 0) src = 0;
+    if (src >= a.n_rows_split) src = a.n_rows_split - 1;
+    int u = a.uid[src], i = a.pid[src];
+    u = u < 0 ? 0 : (u > a.n_user - 1 ? a.n_user - 1 : u);
+    i = i < 0 ? 0 : (i > a.n_item - 1 ? a.n_item - 1 : i);
+    a.urow[b] = u;
+    a.irow[b] = i;
+    atomicMin(a.map_u + u, b);
+    atomicMin(a.map_i + i, b);
+}
+
 }  // namespace mamdr

@@ -111,27 +111,7 @@ __global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) { lin_sw
 // batch, or the weights are read / replaced: mamdr_sync_tables) its missed steps last[row]+1 .. t are replayed
 // in registers with the logged per-step alpha.  Same arithmetic, same order per element -> same bits; the
 // HBM traffic of a step drops from the whole table to the rows of the batch.
-__global__ __launch_bounds__(256) void k_emb_rows(const EmbRowsArgs a) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b == 0) a.alpha_log[a.log_idx] = a.alpha;
-    if (b >= a.rows_pad) return;
-    if (b >= a.rows) {
-        a.urow[b] = -1;
-        a.irow[b] = -1;
-        return;
-    }
-    const int64_t pos = a.row_base + b;
-    int64_t src = a.perm ? (int64_t)a.perm[pos] : pos;
-    if (src < 0) src = 0;
-    if (src >= a.n_rows_split) src = a.n_rows_split - 1;
-    int u = a.uid[src], i = a.pid[src];
-    u = u < 0 ? 0 : (u > a.n_user - 1 ? a.n_user - 1 : u);
-    i = i < 0 ? 0 : (i > a.n_item - 1 ? a.n_item - 1 : i);
-    a.urow[b] = u;
-    a.irow[b] = i;
-    atomicMin(a.map_u + u, b);
-    atomicMin(a.map_i + i, b);
-}
+__global__ __launch_bounds__(256) void k_emb_rows(const EmbRowsArgs a) { emb_rows_body(a, (int)blockIdx.x); }
 void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_rows, dim3((a.rows_pad + 255) / 256), dim3(256), 0, s, a);
 }

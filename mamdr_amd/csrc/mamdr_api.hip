@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/mamdr_hip.h"
@@ -127,6 +128,12 @@ struct mamdr_ctx {
     int max_groups = 16;
     int rpg_override = 0;       // MAMDR_RPG: rows per K-split group of k_wgrad (diagnostic)
     bool tail_fuse = true;      // MAMDR_NO_TAILFUSE=1: k_emb_reduce / k_lin_sweep as launches of their own
+    // the other half of the row / map double buffer: the NEXT step's k_emb_rows rides in this step's last launch
+    int32_t* urow_alt = nullptr;
+    int32_t* irow_alt = nullptr;
+    int32_t* map_u_alt = nullptr;
+    int32_t* map_i_alt = nullptr;
+    bool rows_ready = false;    // the current buffers already hold the rows of the step about to run
     int slab_ld = 0;            // dense block + S region ([n_domain][256]) (+ DeepFM S2 region [n_domain][128])
     int s2_off = 0;
     TileDesc* tiles = nullptr;
@@ -310,6 +317,28 @@ static void sync_tables(mamdr_ctx* c) {
     c->flush_t = c->adam_t;
 }
 
+// k_emb_rows arguments of the batch at row_base for Adam step `t` (alt: into the other half of the double buffer)
+static void fill_rows_args(const mamdr_ctx* c, const SplitData& d, const int32_t* d_perm, int64_t row_base, int rows,
+                           int rows_pad, float alpha, int64_t t, bool alt, EmbRowsArgs& ra) {
+    memset(&ra, 0, sizeof(ra));
+    ra.uid = d.uid;
+    ra.pid = d.pid;
+    ra.perm = d_perm;
+    ra.row_base = row_base;
+    ra.n_rows_split = d.n;
+    ra.rows = rows;
+    ra.rows_pad = rows_pad;
+    ra.n_user = c->cfg.n_user;
+    ra.n_item = c->cfg.n_item;
+    ra.urow = alt ? c->urow_alt : c->urow;
+    ra.irow = alt ? c->irow_alt : c->irow;
+    ra.map_u = alt ? c->map_u_alt : c->map_u;
+    ra.map_i = alt ? c->map_i_alt : c->map_i;
+    ra.alpha_log = c->alpha_log;
+    ra.log_idx = (int)(t & (c->log_cap - 1));
+    ra.alpha = alpha;
+}
+
 // lazy mode, before the tower of Adam step adam_t (already incremented): row ids + representatives of the
 // batch, alpha of this step into the ring, rows of the batch brought up to adam_t - 1
 static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm, int64_t row_base, int rows,
@@ -321,25 +350,12 @@ static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm
         sync_tables(c);
         c->adam_t += 1;
     }
-    EmbRowsArgs ra;
-    memset(&ra, 0, sizeof(ra));
-    ra.uid = d.uid;
-    ra.pid = d.pid;
-    ra.perm = d_perm;
-    ra.row_base = row_base;
-    ra.n_rows_split = d.n;
-    ra.rows = rows;
-    ra.rows_pad = rows_pad;
-    ra.n_user = c->cfg.n_user;
-    ra.n_item = c->cfg.n_item;
-    ra.urow = c->urow;
-    ra.irow = c->irow;
-    ra.map_u = c->map_u;
-    ra.map_i = c->map_i;
-    ra.alpha_log = c->alpha_log;
-    ra.log_idx = (int)(c->adam_t & (c->log_cap - 1));
-    ra.alpha = alpha;
-    launch_emb_rows(ra, c->stream);
+    if (!c->rows_ready) {
+        EmbRowsArgs ra;
+        fill_rows_args(c, d, d_perm, row_base, rows, rows_pad, alpha, c->adam_t, false, ra);
+        launch_emb_rows(ra, c->stream);
+    }
+    c->rows_ready = false;
     EmbStepArgs ea;
     fill_emb_args(c, MAMDR_OPT_ADAM, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
     launch_emb_catchup(ea, c->stream);
@@ -607,6 +623,10 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (cfg->emb_trainable) {
         ALLOC(c->map_u, (size_t)cfg->n_user * sizeof(int32_t));
         ALLOC(c->map_i, (size_t)cfg->n_item * sizeof(int32_t));
+        ALLOC(c->urow_alt, rp * sizeof(int32_t));
+        ALLOC(c->irow_alt, rp * sizeof(int32_t));
+        ALLOC(c->map_u_alt, (size_t)cfg->n_user * sizeof(int32_t));
+        ALLOC(c->map_i_alt, (size_t)cfg->n_item * sizeof(int32_t));
         ALLOC(c->gbuf_u, rp * EMB * sizeof(float));
         ALLOC(c->gbuf_i, rp * EMB * sizeof(float));
         ALLOC(c->hasdup_u, rp * sizeof(int32_t));
@@ -650,6 +670,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         if (e == hipSuccess) e = hipMemsetAsync(c->alpha_log, 0, (size_t)c->log_cap * sizeof(float), c->stream);
         launch_emb_map_init(c->map_u, cfg->n_user, c->stream);
         launch_emb_map_init(c->map_i, cfg->n_item, c->stream);
+        launch_emb_map_init(c->map_u_alt, cfg->n_user, c->stream);
+        launch_emb_map_init(c->map_i_alt, cfg->n_item, c->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(c->tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->thresholds, thr, sizeof(thr), hipMemcpyHostToDevice, c->stream);
@@ -669,7 +691,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
         }
-    void* ptrs[] = {c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -890,6 +912,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     const bool may_use4 = !c->star && c->tower_tile != 16;
     if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
 
+    c->rows_ready = false;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
@@ -1051,8 +1074,28 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.w0t = c->cfg.emb_trainable ? 1 : 0;
         {
             Prof p(c, MAMDR_KERNEL_UPDATE);
-            if (tail && c->deepfm) launch_update_lin(ua, tea, c->stream);
-            else launch_update(ua, c->stream);
+            if (tail) {
+                // the next step of this call is known: resolve its rows in this launch, into the alternate buffers
+                EmbRowsArgs nr;
+                const bool pre = s + 1 < n_steps;
+                if (pre) {
+                    const int64_t nb = (first_step + s + 1) * batch;
+                    const int nrows = (int)((pass_rows - nb) < batch ? (pass_rows - nb) : batch);
+                    const float b1n = c->b1p * c->cfg.adam_beta1, b2n = c->b2p * c->cfg.adam_beta2;
+                    fill_rows_args(c, *d, d_perm, nb, nrows, (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS,
+                                   lr * sqrtf(1.0f - b2n) / (1.0f - b1n), c->adam_t + 1, true, nr);
+                }
+                launch_update_lin(ua, tea, c->deepfm, pre ? &nr : nullptr, c->stream);
+                if (pre) {
+                    std::swap(c->urow, c->urow_alt);
+                    std::swap(c->irow, c->irow_alt);
+                    std::swap(c->map_u, c->map_u_alt);
+                    std::swap(c->map_i, c->map_i_alt);
+                    c->rows_ready = true;
+                }
+            } else {
+                launch_update(ua, c->stream);
+            }
         }
         if (c->cfg.emb_trainable && !tail) emb_post_step(c, optimizer, ua.alpha, omb1, omb2, rows);
         c->global_step += 1;

@@ -14,6 +14,8 @@
 // (model_zoo/DeepCTR/deepctr.py:54-60,118-136; call sites model_zoo/mamdr.py:54,86,97).
 #include <hip/hip_ext.h>
 
+#include <cstring>
+
 #include "emb_bodies.h"
 
 namespace mamdr {
@@ -1198,11 +1200,15 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
     update_body(u, (int)blockIdx.x, s_l);
 }
 // k_update and DeepFM's k_lin_sweep touch disjoint state: one launch
-__global__ __launch_bounds__(256) void k_update_lin(const UpdateArgs u, const EmbStepArgs e, const int n_update, const int n_lin) {
+// ... and so does the NEXT step's k_emb_rows (n_rows workgroups; it writes the other half of the row / map double
+// buffer, so the current step's k_lin_sweep still sees its own maps)
+__global__ __launch_bounds__(256) void k_update_lin(const UpdateArgs u, const EmbStepArgs e, const int n_update, const int n_lin,
+                                                    const EmbRowsArgs nr, const int n_rows) {
     __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
     const int bid = (int)blockIdx.x;
-    if (bid < n_update) update_body(u, bid, s_l);
-    else lin_sweep_body(e, bid - n_update, n_lin);
+    if (bid < n_rows) emb_rows_body(nr, bid);
+    else if (bid < n_rows + n_update) update_body(u, bid - n_rows, s_l);
+    else lin_sweep_body(e, bid - n_rows - n_update, n_lin);
 }
 static int update_blocks(const UpdateArgs& a) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
@@ -1211,12 +1217,17 @@ static int update_blocks(const UpdateArgs& a) {
 void launch_update(const UpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_update, dim3(update_blocks(a)), dim3(256), 0, s, a);
 }
-void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, hipStream_t s) {
+void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbRowsArgs* next_rows, hipStream_t s) {
     const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
-    int64_t n_lin = (n_all + 255) / 256;
+    int64_t n_lin = lin ? (n_all + 255) / 256 : 0;
     if (n_lin > 256 * 8) n_lin = 256 * 8;
     const int n_update = update_blocks(a);
-    hipLaunchKernelGGL(k_update_lin, dim3(n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin);
+    EmbRowsArgs nr;
+    memset(&nr, 0, sizeof(nr));
+    if (next_rows) nr = *next_rows;
+    const int n_rows = next_rows ? (nr.rows_pad + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_update_lin, dim3(n_rows + n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin, nr,
+                       n_rows);
 }
 
 }  // namespace mamdr
