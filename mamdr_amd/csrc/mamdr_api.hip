@@ -386,8 +386,10 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
 }
 
 // ---- Star tower: one training step on `rows` rows of domain `domain` (star.py:70-97; kernels in star_kernels.hip)
+// next_rows (nullable): the NEXT step's k_emb_rows arguments (alternate buffers), riding in this step's last launch
 static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const int32_t* d_perm, int64_t row_base, int rows,
-                           int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out) {
+                           int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out,
+                           const EmbRowsArgs* next_rows) {
     const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
     const int chunks = (rows + STAR_CHUNK - 1) / STAR_CHUNK;
     float* blk = c->params + c->table_floats;
@@ -522,7 +524,14 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
             fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
             tea.flags_done = 1;
             tea.apply_now = 1;
-            launch_star_update_reduce(ua, tea, c->stream);
+            launch_star_update_reduce(ua, tea, next_rows, c->stream);
+            if (next_rows) {
+                std::swap(c->urow, c->urow_alt);
+                std::swap(c->irow, c->irow_alt);
+                std::swap(c->map_u, c->map_u_alt);
+                std::swap(c->map_i, c->map_i_alt);
+                c->rows_ready = true;
+            }
         } else {
             launch_star_update(ua, c->stream);
         }
@@ -928,8 +937,19 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             step_alpha = lr * sqrtf(1.0f - c->b2p) / (1.0f - c->b1p);
         }
         if (c->star) {
+            // the next step of this call (lazy Adam, launches fused): its rows are resolved in this step's last launch
+            EmbRowsArgs nr;
+            const bool pre = s + 1 < n_steps && c->tail_fuse && c->cfg.emb_trainable && c->lazy &&
+                             optimizer == MAMDR_OPT_ADAM && !c->profile;
+            if (pre) {
+                const int64_t nb = (first_step + s + 1) * batch;
+                const int nrows = (int)((pass_rows - nb) < batch ? (pass_rows - nb) : batch);
+                const float b1n = c->b1p * c->cfg.adam_beta1, b2n = c->b2p * c->cfg.adam_beta2;
+                fill_rows_args(c, *d, d_perm, nb, nrows, (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS,
+                               lr * sqrtf(1.0f - b2n) / (1.0f - b1n), c->adam_t + 1, true, nr);
+            }
             const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, step_alpha, omb1, omb2,
-                                           d_loss_out ? d_loss_out + s : nullptr);
+                                           d_loss_out ? d_loss_out + s : nullptr, pre ? &nr : nullptr);
             if (rc) return rc;
             c->global_step += 1;
             continue;

@@ -16,6 +16,8 @@
 //                   specific tensors of the other domains get zero gradient but still decay and move,
 //                   as tf.train.AdamOptimizer's sparse rule does)
 // Every reduction runs in a fixed order (no float atomics).
+#include <cstring>
+
 #include "emb_bodies.h"
 
 namespace mamdr {
@@ -427,9 +429,16 @@ __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
 }
 // the chain rule + optimiser on the Star block and the table update touch disjoint state and both come last in
 // the step: one launch, the table workgroups first (their chains are the longer ones)
-__global__ __launch_bounds__(256) void k_star_update_reduce(const StarUpdateArgs u, const EmbStepArgs e, const int n_reduce) {
+// (and the NEXT step's k_emb_rows, n_rows workgroups writing the other half of the row / map double buffer)
+__global__ __launch_bounds__(256) void k_star_update_reduce(const StarUpdateArgs u, const EmbStepArgs e, const int n_reduce,
+                                                            const EmbRowsArgs nr, const int n_rows) {
     __shared__ uint16_t list_all[4][RED_CAP];
-    const int bid = (int)blockIdx.x;
+    int bid = (int)blockIdx.x;
+    if (bid < n_rows) {
+        emb_rows_body(nr, bid);
+        return;
+    }
+    bid -= n_rows;
     if (bid < n_reduce) {
         const int nb = (e.rows + 7) / 8;
         emb_reduce_body(e, bid % nb, bid / nb, list_all);
@@ -441,9 +450,14 @@ __global__ __launch_bounds__(256) void k_star_update_reduce(const StarUpdateArgs
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_star_update, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
 }
-void launch_star_update_reduce(const StarUpdateArgs& a, const EmbStepArgs& e, hipStream_t s) {
+void launch_star_update_reduce(const StarUpdateArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s) {
     const int n_reduce = 2 * ((e.rows + 7) / 8);
-    hipLaunchKernelGGL(k_star_update_reduce, dim3(n_reduce + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, e, n_reduce);
+    EmbRowsArgs nr;
+    memset(&nr, 0, sizeof(nr));
+    if (next_rows) nr = *next_rows;
+    const int n_rows = next_rows ? (nr.rows_pad + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_star_update_reduce, dim3(n_rows + n_reduce + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, e,
+                       n_reduce, nr, n_rows);
 }
 
 }  // namespace mamdr
