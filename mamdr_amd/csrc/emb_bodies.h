@@ -282,4 +282,41 @@ __device__ __forceinline__ void emb_rows_body(const EmbRowsArgs& a, int bx) {
     atomicMin(a.map_i + i, b);
 }
 
+// 8 batch positions per workgroup, 32 lanes x float4 per 512-B row (see k_emb_catchup in emb_kernels.hip)
+// (a body: the NEXT step's catch-up can ride in the current step's k_update launch)
+__device__ __forceinline__ void emb_catchup_body(const EmbStepArgs& a, int bx, int table) {
+#pragma clang fp contract(off)
+    const int b = bx * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
+    if (b >= a.rows) return;
+    const bool second = table != 0;
+    const EmbTable& T = a.t[table];
+    const int r = T.brow[b];
+    if (r < 0) return;
+    const int rep = T.map[r];
+    if (rep != b) {
+        if (c4 == 0) T.hasdup[rep] = 1;        // same value from every writer
+        return;
+    }
+    const int last = T.last[r];
+    const int t_prev = a.t_now - 1;
+    if (last >= t_prev) return;
+    const size_t e4 = ((size_t)(second ? a.t[0].n_rows : 0) + r) * (EMB / 4) + c4;
+    f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
+    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
+    f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
+    for (int t = last + 1; t <= t_prev; ++t) {
+        const float alpha = a.alpha_log[t & a.log_mask];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = p[k], mk = m[k], vk = v[k];
+            adam_elem(nc_mul(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+            p[k] = pk; m[k] = mk; v[k] = vk;
+        }
+    }
+    reinterpret_cast<f32x4*>(a.p)[e4] = p;
+    reinterpret_cast<f32x4*>(a.m)[e4] = m;
+    reinterpret_cast<f32x4*>(a.v)[e4] = v;
+    if (c4 == 0) T.last[r] = t_prev;           // (the 32 lanes of the row read last[] in one instruction above)
+}
+
 }  // namespace mamdr

@@ -119,39 +119,7 @@ void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s) {
 // 8 batch positions per workgroup, 32 lanes x float4 per 512-B row.  A representative replays its row's
 // missed steps up to t_now - 1 (before the gather reads the row); every other position flags its
 // representative as "row occurs more than once" for k_emb_reduce.
-__global__ __launch_bounds__(256) void k_emb_catchup(const EmbStepArgs a) {
-    const int b = blockIdx.x * 8 + (threadIdx.x >> 5), c4 = threadIdx.x & 31;
-    if (b >= a.rows) return;
-    const bool second = blockIdx.y != 0;
-    const EmbTable& T = a.t[blockIdx.y];
-    const int r = T.brow[b];
-    if (r < 0) return;
-    const int rep = T.map[r];
-    if (rep != b) {
-        if (c4 == 0) T.hasdup[rep] = 1;        // same value from every writer
-        return;
-    }
-    const int last = T.last[r];
-    const int t_prev = a.t_now - 1;
-    if (last >= t_prev) return;
-    const size_t e4 = ((size_t)(second ? a.t[0].n_rows : 0) + r) * (EMB / 4) + c4;
-    f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
-    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
-    f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
-    for (int t = last + 1; t <= t_prev; ++t) {
-        const float alpha = a.alpha_log[t & a.log_mask];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float pk = p[k], mk = m[k], vk = v[k];
-            adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
-            p[k] = pk; m[k] = mk; v[k] = vk;
-        }
-    }
-    reinterpret_cast<f32x4*>(a.p)[e4] = p;
-    reinterpret_cast<f32x4*>(a.m)[e4] = m;
-    reinterpret_cast<f32x4*>(a.v)[e4] = v;
-    if (c4 == 0) T.last[r] = t_prev;           // (the 32 lanes of the row read last[] in one instruction above)
-}
+__global__ __launch_bounds__(256) void k_emb_catchup(const EmbStepArgs a) { emb_catchup_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_emb_catchup, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
 }

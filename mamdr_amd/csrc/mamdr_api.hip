@@ -134,6 +134,7 @@ struct mamdr_ctx {
     int32_t* map_u_alt = nullptr;
     int32_t* map_i_alt = nullptr;
     bool rows_ready = false;    // the current buffers already hold the rows of the step about to run
+    bool catchup_ready = false; // ... and those rows were already brought up to the previous step
     int slab_ld = 0;            // dense block + S region ([n_domain][256]) (+ DeepFM S2 region [n_domain][128])
     int s2_off = 0;
     TileDesc* tiles = nullptr;
@@ -356,9 +357,12 @@ static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm
         launch_emb_rows(ra, c->stream);
     }
     c->rows_ready = false;
-    EmbStepArgs ea;
-    fill_emb_args(c, MAMDR_OPT_ADAM, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
-    launch_emb_catchup(ea, c->stream);
+    if (!c->catchup_ready) {
+        EmbStepArgs ea;
+        fill_emb_args(c, MAMDR_OPT_ADAM, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
+        launch_emb_catchup(ea, c->stream);
+    }
+    c->catchup_ready = false;
     c->tables_dirty = true;
 }
 
@@ -922,6 +926,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
 
     c->rows_ready = false;
+    c->catchup_ready = false;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
@@ -1051,15 +1056,33 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         // for per-kernel times; a reported loss reads the tables between the two and keeps them apart too)
         const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !d_loss_out &&
                           !c->profile;
-        EmbStepArgs tea;
+        EmbStepArgs tea, nea;
+        EmbRowsArgs nr;
+        // the next step of this call is known: its row ids / maps are resolved in this step's k_wgrad launch (into
+        // the alternate buffers) and its catch-up runs in this step's k_update launch
+        const bool pre = tail && s + 1 < n_steps;
         if (tail) {
             fill_emb_args(c, optimizer, step_alpha, omb1, omb2, table_two_l2(c), rows, 2 * EMB, tea);
             tea.flags_done = 1;
             tea.apply_now = 1;
         }
+        if (pre) {
+            const int64_t nb = (first_step + s + 1) * batch;
+            const int nrows = (int)((pass_rows - nb) < batch ? (pass_rows - nb) : batch);
+            const float b1n = c->b1p * c->cfg.adam_beta1, b2n = c->b2p * c->cfg.adam_beta2;
+            const float alpha_n = lr * sqrtf(1.0f - b2n) / (1.0f - b1n);
+            fill_rows_args(c, *d, d_perm, nb, nrows, (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS, alpha_n, c->adam_t + 1,
+                           true, nr);
+            fill_emb_args(c, MAMDR_OPT_ADAM, alpha_n, omb1, omb2, table_two_l2(c), nrows, 2 * EMB, nea);
+            nea.t_now = (int)c->adam_t + 1;
+            nea.t[0].brow = c->urow_alt;
+            nea.t[0].map = c->map_u_alt;
+            nea.t[1].brow = c->irow_alt;
+            nea.t[1].map = c->map_i_alt;
+        }
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
-            if (tail) launch_wgrad_reduce(wa, tea, c->stream);
+            if (tail) launch_wgrad_reduce(wa, tea, pre ? &nr : nullptr, c->stream);
             else launch_wgrad(wa, c->stream);
         }
 
@@ -1095,23 +1118,15 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         {
             Prof p(c, MAMDR_KERNEL_UPDATE);
             if (tail) {
-                // the next step of this call is known: resolve its rows in this launch, into the alternate buffers
-                EmbRowsArgs nr;
-                const bool pre = s + 1 < n_steps;
-                if (pre) {
-                    const int64_t nb = (first_step + s + 1) * batch;
-                    const int nrows = (int)((pass_rows - nb) < batch ? (pass_rows - nb) : batch);
-                    const float b1n = c->b1p * c->cfg.adam_beta1, b2n = c->b2p * c->cfg.adam_beta2;
-                    fill_rows_args(c, *d, d_perm, nb, nrows, (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS,
-                                   lr * sqrtf(1.0f - b2n) / (1.0f - b1n), c->adam_t + 1, true, nr);
-                }
-                launch_update_lin(ua, tea, c->deepfm, pre ? &nr : nullptr, c->stream);
+                launch_update_lin(ua, tea, c->deepfm, pre ? &nea : nullptr, c->stream);
                 if (pre) {
                     std::swap(c->urow, c->urow_alt);
                     std::swap(c->irow, c->irow_alt);
                     std::swap(c->map_u, c->map_u_alt);
                     std::swap(c->map_i, c->map_i_alt);
                     c->rows_ready = true;
+                    c->catchup_ready = true;
+                    c->tables_dirty = true;
                 }
             } else {
                 launch_update(ua, c->stream);

@@ -213,12 +213,12 @@ struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the b
     float alpha;
 };
 void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s);
-// k_update (+ DeepFM's k_lin_sweep) (+ the NEXT step's k_emb_rows, into the alternate row / map buffers) in one launch
-void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbRowsArgs* next_rows, hipStream_t s);
+// k_wgrad + k_emb_reduce (+ the NEXT step's k_emb_rows, into the alternate row / map buffers) in one launch;
+// k_update (+ DeepFM's k_lin_sweep) (+ the NEXT step's k_emb_catchup) in one launch
+void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s);
+void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s);
 void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s);     // rows of the batch -> current at t_now - 1
 void launch_emb_flush(const EmbStepArgs& a, hipStream_t s);       // every row -> current at t_now
-// horizontal fusion (step_kernels.hip): k_wgrad + k_emb_reduce in one launch
-void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, hipStream_t s);
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s);
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s);
 void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s);

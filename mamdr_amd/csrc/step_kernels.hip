@@ -989,7 +989,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
 }
 // k_wgrad and k_emb_reduce only need the tower's outputs and write disjoint state: one launch, the table
 // workgroups behind the weight-gradient ones (they share CUs instead of queueing behind each other)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradArgs g, const EmbStepArgs e, const int n_wgrad) {
+// ... and the NEXT step's k_emb_rows (n_rows workgroups): it writes the other half of the row-id / map double
+// buffer, so this step's reduction still sees its own maps
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradArgs g, const EmbStepArgs e, const int n_wgrad,
+                                                      const EmbRowsArgs nr, const int n_rows) {
     __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
     const int bid = (int)blockIdx.x;
     if (bid < n_wgrad) {
@@ -997,15 +1000,21 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradArgs g, const E
         return;
     }
     const int nb = (e.rows + 7) / 8, idx = bid - n_wgrad;
-    emb_reduce_body(e, idx % nb, idx / nb, reinterpret_cast<uint16_t(*)[RED_CAP]>(red));
+    if (idx < 2 * nb) emb_reduce_body(e, idx % nb, idx / nb, reinterpret_cast<uint16_t(*)[RED_CAP]>(red));
+    else emb_rows_body(nr, idx - 2 * nb);
 }
 static int wgrad_blocks(const WgradArgs& a) {
     const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
     return a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs;
 }
-void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, hipStream_t s) {
+void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s) {
     const int n_wgrad = wgrad_blocks(a);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_wgrad + 2 * ((e.rows + 7) / 8)), dim3(256), 0, s, a, e, n_wgrad);
+    EmbRowsArgs nr;
+    memset(&nr, 0, sizeof(nr));
+    if (next_rows) nr = *next_rows;
+    const int n_rows = next_rows ? (nr.rows_pad + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, a, e, n_wgrad, nr,
+                       n_rows);
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, a);
@@ -1200,15 +1209,15 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
     update_body(u, (int)blockIdx.x, s_l);
 }
 // k_update and DeepFM's k_lin_sweep touch disjoint state: one launch
-// ... and so does the NEXT step's k_emb_rows (n_rows workgroups; it writes the other half of the row / map double
-// buffer, so the current step's k_lin_sweep still sees its own maps)
+// ... and so does the NEXT step's k_emb_catchup (n_cu workgroups per table; its rows were resolved in the previous
+// launch, k_wgrad_reduce): the rows of the next batch are brought up to this step while the dense block steps
 __global__ __launch_bounds__(256) void k_update_lin(const UpdateArgs u, const EmbStepArgs e, const int n_update, const int n_lin,
-                                                    const EmbRowsArgs nr, const int n_rows) {
+                                                    const EmbStepArgs nc, const int n_cu) {
     __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
     const int bid = (int)blockIdx.x;
-    if (bid < n_rows) emb_rows_body(nr, bid);
-    else if (bid < n_rows + n_update) update_body(u, bid - n_rows, s_l);
-    else lin_sweep_body(e, bid - n_rows - n_update, n_lin);
+    if (bid < 2 * n_cu) emb_catchup_body(nc, bid % n_cu, bid / n_cu);
+    else if (bid < 2 * n_cu + n_update) update_body(u, bid - 2 * n_cu, s_l);
+    else lin_sweep_body(e, bid - 2 * n_cu - n_update, n_lin);
 }
 static int update_blocks(const UpdateArgs& a) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
@@ -1217,17 +1226,15 @@ static int update_blocks(const UpdateArgs& a) {
 void launch_update(const UpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_update, dim3(update_blocks(a)), dim3(256), 0, s, a);
 }
-void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbRowsArgs* next_rows, hipStream_t s) {
+void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s) {
     const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
     int64_t n_lin = lin ? (n_all + 255) / 256 : 0;
     if (n_lin > 256 * 8) n_lin = 256 * 8;
     const int n_update = update_blocks(a);
-    EmbRowsArgs nr;
-    memset(&nr, 0, sizeof(nr));
-    if (next_rows) nr = *next_rows;
-    const int n_rows = next_rows ? (nr.rows_pad + 255) / 256 : 0;
-    hipLaunchKernelGGL(k_update_lin, dim3(n_rows + n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin, nr,
-                       n_rows);
+    const EmbStepArgs& nc = next_catchup ? *next_catchup : e;
+    const int n_cu = next_catchup ? (nc.rows + 7) / 8 : 0;
+    hipLaunchKernelGGL(k_update_lin, dim3(2 * n_cu + n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin, nc,
+                       n_cu);
 }
 
 }  // namespace mamdr
