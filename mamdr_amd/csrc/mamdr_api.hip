@@ -393,7 +393,7 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
 // next_rows (nullable): the NEXT step's k_emb_rows arguments (alternate buffers), riding in this step's last launch
 static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const int32_t* d_perm, int64_t row_base, int rows,
                            int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out,
-                           const EmbRowsArgs* next_rows) {
+                           const EmbRowsArgs* next_rows, const EmbStepArgs* next_catchup) {
     const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
     const int chunks = (rows + STAR_CHUNK - 1) / STAR_CHUNK;
     float* blk = c->params + c->table_floats;
@@ -476,10 +476,6 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     wa.l2_emb = 0.f;
     wa.frozen_sumsq = c->frozen_sumsq;
     wa.loss_out = loss_out;
-    {
-        Prof p(c, MAMDR_KERNEL_WGRAD);
-        launch_wgrad(wa, c->stream);
-    }
     StarPnBwdArgs ba;
     memset(&ba, 0, sizeof(ba));
     ba.user_tab = ta.user_tab;
@@ -495,7 +491,25 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ba.sums = c->star_sums;
     ba.dmpart = c->star_dmpart;
     ba.dmsum = c->star_sums + 2 * XDIM;
-    launch_star_pn_bwd(ba, c->stream);
+    // lazy table Adam with fused tails: PartitionedNorm's backward first (it only needs the tower's outputs), then
+    // [k_wgrad + k_emb_reduce(t) + k_emb_rows(t+1)], then [k_star_update + k_emb_catchup(t+1)]
+    const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile &&
+                      !loss_out;
+    if (tail) {
+        launch_star_pn_bwd(ba, c->stream);
+        EmbStepArgs tea;
+        fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
+        tea.flags_done = 1;
+        tea.apply_now = 1;
+        Prof p(c, MAMDR_KERNEL_WGRAD);
+        launch_wgrad_reduce(wa, tea, next_rows, c->stream);
+    } else {
+        {
+            Prof p(c, MAMDR_KERNEL_WGRAD);
+            launch_wgrad(wa, c->stream);
+        }
+        launch_star_pn_bwd(ba, c->stream);
+    }
 
     float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
     StarUpdateArgs ua;
@@ -519,26 +533,19 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ua.opt.omb2 = omb2;
     ua.opt.eps = c->cfg.adam_eps;
     ua.opt.two_l2 = 0.f;
-    // lazy table Adam: k_emb_reduce rides in k_star_update's launch (disjoint state, both last in the step)
-    const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile;
     {
         Prof p(c, MAMDR_KERNEL_UPDATE);
-        if (tail) {
-            EmbStepArgs tea;
-            fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
-            tea.flags_done = 1;
-            tea.apply_now = 1;
-            launch_star_update_reduce(ua, tea, next_rows, c->stream);
-            if (next_rows) {
-                std::swap(c->urow, c->urow_alt);
-                std::swap(c->irow, c->irow_alt);
-                std::swap(c->map_u, c->map_u_alt);
-                std::swap(c->map_i, c->map_i_alt);
-                c->rows_ready = true;
-            }
-        } else {
-            launch_star_update(ua, c->stream);
-        }
+        if (tail && next_catchup) launch_star_update_catchup(ua, *next_catchup, c->stream);
+        else launch_star_update(ua, c->stream);
+    }
+    if (tail && next_rows) {
+        std::swap(c->urow, c->urow_alt);
+        std::swap(c->irow, c->irow_alt);
+        std::swap(c->map_u, c->map_u_alt);
+        std::swap(c->map_i, c->map_i_alt);
+        c->rows_ready = true;
+        c->catchup_ready = next_catchup != nullptr;
+        c->tables_dirty = true;
     }
     if (c->cfg.emb_trainable && !tail) emb_post_step(c, optimizer, alpha, omb1, omb2, rows);
     return MAMDR_OK;
@@ -945,7 +952,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             // the next step of this call (lazy Adam, launches fused): its rows are resolved in this step's last launch
             EmbRowsArgs nr;
             const bool pre = s + 1 < n_steps && c->tail_fuse && c->cfg.emb_trainable && c->lazy &&
-                             optimizer == MAMDR_OPT_ADAM && !c->profile;
+                             optimizer == MAMDR_OPT_ADAM && !c->profile && !d_loss_out;
             if (pre) {
                 const int64_t nb = (first_step + s + 1) * batch;
                 const int nrows = (int)((pass_rows - nb) < batch ? (pass_rows - nb) : batch);
@@ -953,8 +960,17 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
                 fill_rows_args(c, *d, d_perm, nb, nrows, (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS,
                                lr * sqrtf(1.0f - b2n) / (1.0f - b1n), c->adam_t + 1, true, nr);
             }
+            EmbStepArgs nea;
+            if (pre) {
+                fill_emb_args(c, MAMDR_OPT_ADAM, nr.alpha, omb1, omb2, table_two_l2(c), nr.rows, XDIM, nea);
+                nea.t_now = (int)c->adam_t + 1;
+                nea.t[0].brow = c->urow_alt;
+                nea.t[0].map = c->map_u_alt;
+                nea.t[1].brow = c->irow_alt;
+                nea.t[1].map = c->map_i_alt;
+            }
             const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, step_alpha, omb1, omb2,
-                                           d_loss_out ? d_loss_out + s : nullptr, pre ? &nr : nullptr);
+                                           d_loss_out ? d_loss_out + s : nullptr, pre ? &nr : nullptr, pre ? &nea : nullptr);
             if (rc) return rc;
             c->global_step += 1;
             continue;

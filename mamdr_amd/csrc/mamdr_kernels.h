@@ -271,8 +271,8 @@ void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hip
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
 void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s);
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s);
-// k_star_update + k_emb_reduce in one launch (lazy table Adam)
-void launch_star_update_reduce(const StarUpdateArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s);
+// k_star_update + the NEXT step's k_emb_catchup in one launch (lazy table Adam)
+void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& next_catchup, hipStream_t s);
 
 // outer_kernels.hip (compiled with -ffp-contract=off)
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s);

@@ -427,37 +427,24 @@ constexpr int STAR_UPDATE_BX = (STAR_UPDATE_N + 255) / 256;
 __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
     star_update_body(u, (int)blockIdx.x, (int)blockIdx.y);
 }
-// the chain rule + optimiser on the Star block and the table update touch disjoint state and both come last in
-// the step: one launch, the table workgroups first (their chains are the longer ones)
-// (and the NEXT step's k_emb_rows, n_rows workgroups writing the other half of the row / map double buffer)
-__global__ __launch_bounds__(256) void k_star_update_reduce(const StarUpdateArgs u, const EmbStepArgs e, const int n_reduce,
-                                                            const EmbRowsArgs nr, const int n_rows) {
-    __shared__ uint16_t list_all[4][RED_CAP];
-    int bid = (int)blockIdx.x;
-    if (bid < n_rows) {
-        emb_rows_body(nr, bid);
+// the chain rule + optimiser on the Star block and the NEXT step's k_emb_catchup touch disjoint state: one launch,
+// the catch-up workgroups first (their chains are the longer ones).  (This step's k_emb_reduce and the next step's
+// k_emb_rows ride in the k_wgrad launch before it, k_wgrad_reduce.)
+__global__ __launch_bounds__(256) void k_star_update_catchup(const StarUpdateArgs u, const EmbStepArgs nc, const int n_cu) {
+    const int bid = (int)blockIdx.x;
+    if (bid < 2 * n_cu) {
+        emb_catchup_body(nc, bid % n_cu, bid / n_cu);
         return;
     }
-    bid -= n_rows;
-    if (bid < n_reduce) {
-        const int nb = (e.rows + 7) / 8;
-        emb_reduce_body(e, bid % nb, bid / nb, list_all);
-        return;
-    }
-    const int idx = bid - n_reduce;
+    const int idx = bid - 2 * n_cu;
     star_update_body(u, idx % STAR_UPDATE_BX, idx / STAR_UPDATE_BX);
 }
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_star_update, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
 }
-void launch_star_update_reduce(const StarUpdateArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s) {
-    const int n_reduce = 2 * ((e.rows + 7) / 8);
-    EmbRowsArgs nr;
-    memset(&nr, 0, sizeof(nr));
-    if (next_rows) nr = *next_rows;
-    const int n_rows = next_rows ? (nr.rows_pad + 255) / 256 : 0;
-    hipLaunchKernelGGL(k_star_update_reduce, dim3(n_rows + n_reduce + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, e,
-                       n_reduce, nr, n_rows);
+void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& nc, hipStream_t s) {
+    const int n_cu = (nc.rows + 7) / 8;
+    hipLaunchKernelGGL(k_star_update_catchup, dim3(2 * n_cu + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, nc, n_cu);
 }
 
 }  // namespace mamdr
