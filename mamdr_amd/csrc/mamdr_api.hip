@@ -496,19 +496,19 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile &&
                       !loss_out;
     if (tail) {
-        launch_star_pn_bwd(ba, c->stream);
+        launch_star_pn_bwd(ba, false, c->stream);       // (its last kernel, the domain-row column sums, rides below)
         EmbStepArgs tea;
         fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
         tea.flags_done = 1;
         tea.apply_now = 1;
         Prof p(c, MAMDR_KERNEL_WGRAD);
-        launch_wgrad_reduce(wa, tea, next_rows, c->stream);
+        launch_wgrad_reduce(wa, tea, next_rows, &ba, c->stream);
     } else {
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
             launch_wgrad(wa, c->stream);
         }
-        launch_star_pn_bwd(ba, c->stream);
+        launch_star_pn_bwd(ba, true, c->stream);
     }
 
     float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
@@ -1098,7 +1098,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         }
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
-            if (tail) launch_wgrad_reduce(wa, tea, pre ? &nr : nullptr, c->stream);
+            if (tail) launch_wgrad_reduce(wa, tea, pre ? &nr : nullptr, nullptr, c->stream);
             else launch_wgrad(wa, c->stream);
         }
 

@@ -215,7 +215,9 @@ struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the b
 void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s);
 // k_wgrad + k_emb_reduce (+ the NEXT step's k_emb_rows, into the alternate row / map buffers) in one launch;
 // k_update (+ DeepFM's k_lin_sweep) (+ the NEXT step's k_emb_catchup) in one launch
-void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s);
+struct StarPnBwdArgs;
+void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, const StarPnBwdArgs* star_dm,
+                         hipStream_t s);     // star_dm: also the Star tower's domain-row column sums (k_star_dm_final)
 void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s);
 void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s);     // rows of the batch -> current at t_now - 1
 void launch_emb_flush(const EmbStepArgs& a, hipStream_t s);       // every row -> current at t_now
@@ -269,7 +271,7 @@ struct StarUpdateArgs {
 };
 void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hipStream_t s);
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
-void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s);
+void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s);
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s);
 // k_star_update + the NEXT step's k_emb_catchup in one launch (lazy table Adam)
 void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& next_catchup, hipStream_t s);

@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "emb_bodies.h"
+#include "star_bodies.h"
 
 namespace mamdr {
 
@@ -306,32 +307,17 @@ __global__ __launch_bounds__(XDIM) void k_star_pnb_apply(const StarPnBwdArgs a) 
     }
     if (c >= 2 * EMB) a.dmpart[(size_t)ch * EMB + (c - 2 * EMB)] = colsum;
 }
-// column sums of dx[:, 256:384] (the domain-table row gradient) from the per-chunk partials: same
-// column x lane blocking as the other finalizers; result in dmpart[0][:]
+// column sums of dx[:, 256:384]: star_bodies.h (the body also rides in k_wgrad_reduce)
 __global__ __launch_bounds__(512) void k_star_dm_final(const StarPnBwdArgs a) {
-    __shared__ float sh[PN_LANES][PN_COLS];
-    const int cl = threadIdx.x & (PN_COLS - 1), j = threadIdx.x / PN_COLS;
-    const int k = blockIdx.x * PN_COLS + cl;
-    float g = 0.f;
-    for (int ch0 = j; ch0 < a.n_chunks; ch0 += 8 * PN_LANES) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = a.dmpart[(size_t)min(ch0 + u * PN_LANES, a.n_chunks - 1) * EMB + k];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (ch0 + u * PN_LANES < a.n_chunks) g += t[u];
-    }
-    sh[j][cl] = g;
-    __syncthreads();            // (also orders the reads of dmpart[0] above before the write below)
-    if (j != 0) return;
-    for (int q = 1; q < PN_LANES; ++q) g += sh[q][cl];
-    a.dmsum[k] = g;
+    __shared__ float sh[STAR_DM_LANES * PN_COLS];
+    star_dm_final_body<PN_COLS>(a, (int)blockIdx.x, sh);
 }
-void launch_star_pn_bwd(const StarPnBwdArgs& a, hipStream_t s) {
+// dm_final = false: the caller lets the domain-row column sums ride in its next launch (k_wgrad_reduce)
+void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s) {
     hipLaunchKernelGGL(k_star_pnb_partial, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
     hipLaunchKernelGGL(k_star_pnb_final, dim3(PN_BLOCKS), dim3(512), 0, s, a);
     hipLaunchKernelGGL(k_star_pnb_apply, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
-    hipLaunchKernelGGL(k_star_dm_final, dim3(EMB / PN_COLS), dim3(512), 0, s, a);
+    if (dm_final) hipLaunchKernelGGL(k_star_dm_final, dim3(EMB / PN_COLS), dim3(512), 0, s, a);
 }
 
 // ------------------------------------------------------------------ chain rule + optimiser

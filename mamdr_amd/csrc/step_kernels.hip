@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "emb_bodies.h"
+#include "star_bodies.h"
 
 namespace mamdr {
 
@@ -991,10 +992,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
 // workgroups behind the weight-gradient ones (they share CUs instead of queueing behind each other)
 // ... and the NEXT step's k_emb_rows (n_rows workgroups): it writes the other half of the row-id / map double
 // buffer, so this step's reduction still sees its own maps
+// ... and (Star tower) the domain-row column sums of PartitionedNorm's backward, n_dm workgroups of 16 columns
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradArgs g, const EmbStepArgs e, const int n_wgrad,
-                                                      const EmbRowsArgs nr, const int n_rows) {
+                                                      const EmbRowsArgs nr, const int n_rows, const StarPnBwdArgs sd,
+                                                      const int n_dm) {
     __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
-    const int bid = (int)blockIdx.x;
+    int bid = (int)blockIdx.x;
+    if (bid < n_dm) {
+        star_dm_final_body<16>(sd, bid, red);
+        return;
+    }
+    bid -= n_dm;
     if (bid < n_wgrad) {
         wgrad_body(g, bid, red);
         return;
@@ -1007,14 +1015,19 @@ static int wgrad_blocks(const WgradArgs& a) {
     const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
     return a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs;
 }
-void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, hipStream_t s) {
+void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRowsArgs* next_rows, const StarPnBwdArgs* star_dm,
+                         hipStream_t s) {
     const int n_wgrad = wgrad_blocks(a);
     EmbRowsArgs nr;
     memset(&nr, 0, sizeof(nr));
     if (next_rows) nr = *next_rows;
     const int n_rows = next_rows ? (nr.rows_pad + 255) / 256 : 0;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, a, e, n_wgrad, nr,
-                       n_rows);
+    StarPnBwdArgs sd;
+    memset(&sd, 0, sizeof(sd));
+    if (star_dm) sd = *star_dm;
+    const int n_dm = star_dm ? EMB / 16 : 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, a, e, n_wgrad,
+                       nr, n_rows, sd, n_dm);
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, a);
