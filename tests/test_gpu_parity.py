@@ -763,6 +763,43 @@ def test_lazy_table_adam_is_bit_identical_to_the_dense_sweep(env, tower):
         assert same_bits(a, b), (tower, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
 
 
+@pytest.mark.parametrize("tower", ["mlp", "deepfm", "star"])
+def test_fused_tail_launches_are_bit_identical_to_separate_kernels(env, tower):
+    """With lazy table Adam a training step's table kernels ride in the dense kernels' launches (k_wgrad_reduce:
+    k_emb_reduce(t) + the NEXT step's k_emb_rows; k_update_lin / k_star_update_catchup: k_lin_sweep(t) + the next
+    step's k_emb_catchup; row ids and representative maps double-buffered).  MAMDR_NO_TAILFUSE=1 launches every
+    kernel on its own.  Same bodies, same order per element -> weights and both Adam slots must agree BITWISE,
+    across pass boundaries, an SGD step, a read (flush) and a weight assignment in between."""
+    results = {}
+    for mode in ("fused", "separate"):
+        os.environ["MAMDR_NO_TAILFUSE"] = "1" if mode == "separate" else "0"
+        try:
+            if tower == "star":
+                g, eng, model = make_star_problem(env, True)
+            else:
+                g, eng, model = make_problem(env, scale=0.1, batch=256, dropout=0.5, emb_trainable=True, tower=tower)
+        finally:
+            os.environ.pop("MAMDR_NO_TAILFUSE", None)
+        sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(10)]
+        order = sorted(range(10), key=lambda k: -sizes[k])[:3]
+        for rep_ in range(2):
+            for d in order:
+                perm = torch.from_numpy(orng.shuffle_perm(sizes[d], 10000, seed=31 + d + rep_)).to(eng.device)
+                eng.train_steps(d, perm=perm, lr=1e-3)
+                eng.train_steps(d, perm=perm, first_step=1, n_steps=1, lr=1e-3)      # a one-step call: nothing to pre-launch
+            if rep_ == 0:
+                snap = eng.get_weights()
+                eng.train_steps(order[0], first_step=0, n_steps=1, lr=1e-3, optimizer="sgd")
+                eng.set_weights((snap + eng.get_weights()) * 0.5)
+        results[mode] = (eng.get_weights().cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(),
+                         eng.adam_v.cpu().numpy().copy(), int(eng.lib.mamdr_optimizer_steps(eng.ctx)))
+        eng.close()
+    assert results["fused"][3] == results["separate"][3] > 40
+    for a, b, name in zip(results["fused"][:3], results["separate"][:3], ("weights", "adam_m", "adam_v")):
+        assert np.isfinite(a).all()
+        assert same_bits(a, b), (tower, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+
+
 # ------------------------------------------------------------------ AUC parity of the other two BASELINE towers
 def _perm_fn_factory(sizes):
     def make():
