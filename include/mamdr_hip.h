@@ -218,6 +218,12 @@ int mamdr_interp(float* d_dst, const float* d_a, const float* d_b, float scale, 
 /* dst[i] = theta[i] + phi[i]  or  theta[i] * phi[i]  (specific_base_model.py:164-172) */
 int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t mode, int64_t n,
                 void* stream);
+/* One Domain-Regularisation support step on flat vectors in a single pass (mamdr.py:103-105, then the next
+ * support's assignment of the merged weights to the model, mamdr.py:74):
+ *   phi[i] += (w[i] - merged[i]) * gamma;  merged[i] = theta[i] (+|*) phi[i];  if (assign_model) w[i] = merged[i]
+ * bit-identical to mamdr_interp(phi, w, merged, gamma) + mamdr_merge(merged, theta, phi, mode) + mamdr_copy(w, merged). */
+int mamdr_dr_advance(float* d_phi, float* d_w, float* d_merged, const float* d_theta, float gamma, int32_t mode,
+                     int32_t assign_model, int64_t n, void* stream);
 /* dst[i] = a[i] - b[i]   (mamdr.py:168-171) */
 int mamdr_sub(float* d_dst, const float* d_a, const float* d_b, int64_t n, void* stream);
 /* acc[i] += (a[i] - b[i]) [* shared[i]] / divisor   (reptile.py:134-137 with shared NULL,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mamdr_gather_rows": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _I64, _I64, _VP]),
     "mamdr_interp": (C.c_int, [_VP, _VP, _VP, _F, _I64, _VP]),
     "mamdr_merge": (C.c_int, [_VP, _VP, _VP, _I32, _I64, _VP]),
+    "mamdr_dr_advance": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I32, _I32, _I64, _VP]),
     "mamdr_sub": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
     "mamdr_accumulate": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I64, _VP]),
     "mamdr_apply_accumulated": (C.c_int, [_VP, _VP, _F, _F, _I64, _VP]),

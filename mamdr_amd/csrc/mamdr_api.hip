@@ -1269,6 +1269,16 @@ int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t 
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }
+int mamdr_dr_advance(float* d_phi, float* d_w, float* d_merged, const float* d_theta, float gamma, int32_t mode,
+                     int32_t assign_model, int64_t n, void* stream) {
+    CHECK_VEC(d_phi); CHECK_VEC(d_w); CHECK_VEC(d_merged); CHECK_VEC(d_theta);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (mode != MAMDR_MERGE_PLUS && mode != MAMDR_MERGE_TIMES) return fail(MAMDR_EINVAL, "unknown merge mode %d", mode);
+    launch_dr_advance(d_phi, d_w, d_merged, d_theta, gamma, mode == MAMDR_MERGE_PLUS ? 0 : 1, assign_model != 0, n,
+                      (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
 int mamdr_sub(float* d_dst, const float* d_a, const float* d_b, int64_t n, void* stream) {
     CHECK_VEC(d_dst); CHECK_VEC(d_a); CHECK_VEC(d_b);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");

@@ -75,6 +75,41 @@ struct Sub {      // dst = a - b
     __device__ __forceinline__ void one(int64_t i) const { dst[i] = __fsub_rn(a[i], b[i]); }
 };
 
+// One DR support step in a single pass (mamdr.py:103-105 followed by the next support's :74 assignment):
+//   phi += (w - merged) * gamma;  merged = theta (+|*) phi;  [w = merged]
+// -- the same roundings, in the same order, as mamdr_interp + mamdr_merge + mamdr_copy one after the other.
+template <int MODE, bool ASSIGN>
+struct DrAdvance {
+    float* phi; float* w; float* merged; const float* theta; float gamma;
+    __device__ __forceinline__ void elem(float& ph, float& wv, float& mg, float th) const {
+        ph = __fadd_rn(ph, __fmul_rn(__fsub_rn(wv, mg), gamma));
+        mg = MODE == 0 ? __fadd_rn(th, ph) : __fmul_rn(th, ph);
+        if (ASSIGN) wv = mg;
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        f32x4 ph = reinterpret_cast<f32x4*>(phi)[i];
+        f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+        f32x4 mg = reinterpret_cast<f32x4*>(merged)[i];
+        const f32x4 th = reinterpret_cast<const f32x4*>(theta)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = ph[c], b = wv[c], m = mg[c];
+            elem(a, b, m, th[c]);
+            ph[c] = a; wv[c] = b; mg[c] = m;
+        }
+        reinterpret_cast<f32x4*>(phi)[i] = ph;
+        reinterpret_cast<f32x4*>(merged)[i] = mg;
+        if (ASSIGN) reinterpret_cast<f32x4*>(w)[i] = wv;
+    }
+    __device__ __forceinline__ void one(int64_t i) const {
+        float a = phi[i], b = w[i], m = merged[i];
+        elem(a, b, m, theta[i]);
+        phi[i] = a;
+        merged[i] = m;
+        if (ASSIGN) w[i] = b;
+    }
+};
+
 template <bool SHARED>
 struct Accumulate {   // acc += (a - b) [* shared] / divisor
     float* acc; const float* a; const float* b; const float* shared; float divisor;
@@ -152,6 +187,14 @@ void run(int64_t n, const F& f, hipStream_t s) {
 
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s) {
     run(n, Interp{dst, a, b, scale}, s);
+}
+void launch_dr_advance(float* phi, float* w, float* merged, const float* theta, float gamma, int mode, int assign, int64_t n,
+                       hipStream_t s) {
+    const dim3 grid(grid_for(n >> 2)), block(BLOCK);
+    if (mode == 0 && assign) hipLaunchKernelGGL((k_elementwise<DrAdvance<0, true>>), grid, block, 0, s, n, (DrAdvance<0, true>{phi, w, merged, theta, gamma}));
+    else if (mode == 0) hipLaunchKernelGGL((k_elementwise<DrAdvance<0, false>>), grid, block, 0, s, n, (DrAdvance<0, false>{phi, w, merged, theta, gamma}));
+    else if (assign) hipLaunchKernelGGL((k_elementwise<DrAdvance<1, true>>), grid, block, 0, s, n, (DrAdvance<1, true>{phi, w, merged, theta, gamma}));
+    else hipLaunchKernelGGL((k_elementwise<DrAdvance<1, false>>), grid, block, 0, s, n, (DrAdvance<1, false>{phi, w, merged, theta, gamma}));
 }
 void launch_merge(float* dst, const float* t, const float* p, int mode, int64_t n, hipStream_t s) {
     if (mode == 0) run(n, Merge<0>{dst, t, p}, s);

@@ -210,6 +210,13 @@ class TowerEngine(object):
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
         L.check(self.lib.mamdr_merge(_ptr(dst), _ptr(theta), _ptr(phi), mode, dst.numel(), self._s()))
 
+    def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
+        """one DR support step in a single pass: phi += (live - merged) * gamma; merged = theta (+|*) phi; and, for
+        the next support, model := merged (mamdr.py:103-105,74) -- bit-identical to interp + merge + set_weights."""
+        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self._weights), _ptr(merged), _ptr(theta), float(gamma), mode,
+                                          1 if assign_model else 0, phi.numel(), self._s()))
+
     def sub(self, dst, a, b):
         L.check(self.lib.mamdr_sub(_ptr(dst), _ptr(a), _ptr(b), dst.numel(), self._s()))
 

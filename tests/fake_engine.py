@@ -73,6 +73,12 @@ class FakeEngine(object):
     def merge(self, dst, theta, phi, method="plus"):
         dst.copy_(torch.from_numpy(oouter.merge(theta.numpy(), phi.numpy(), method)))
 
+    def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
+        self.interp(phi, self.weights[:phi.numel()], merged, gamma)
+        self.merge(merged, theta, phi, method)
+        if assign_model:
+            self.set_weights(merged)
+
     def sub(self, dst, a, b):
         dst.copy_(torch.from_numpy(oouter.mamdr_domain_weights(a.numpy(), b.numpy())))
 

@@ -163,6 +163,35 @@ def test_outer_updates_bit_exact_vs_reference_goldens(env, golden_dir):
     eng.close()
 
 
+@pytest.mark.parametrize("method", ["plus", "times"])
+def test_dr_advance_is_bit_identical_to_interp_merge_assign(env, method):
+    """mamdr_dr_advance = one DR support step in a single pass (phi += (live - merged) gamma; merged = theta (+|*) phi;
+    model := merged): the same bits as mamdr_interp + mamdr_merge + mamdr_copy, on the meta prefix of the live
+    vector (the Star tower's theta is a prefix), with and without the model assignment."""
+    g, eng, model = make_problem(env, scale=0.05, batch=256)
+    n = eng.n_meta - 3                                  # not a multiple of 4: the scalar tail runs too
+    rs = np.random.RandomState(9)
+    vec = lambda: torch.from_numpy((rs.standard_normal(n) * 0.1).astype(F32)).to(eng.device)
+    live0 = (rs.standard_normal(eng.n_params) * 0.1).astype(F32)
+    for assign in (True, False):
+        theta, phi0, merged0 = vec(), vec(), vec()
+        eng.set_weights(torch.from_numpy(live0).to(eng.device))
+        phi_a, merged_a = phi0.clone(), merged0.clone()
+        eng.interp(phi_a, eng.weights[:n], merged_a, 0.37)
+        eng.merge(merged_a, theta, phi_a, method)
+        want_live = live0.copy()
+        if assign:
+            want_live[:n] = merged_a.cpu().numpy()
+        phi_b, merged_b = phi0.clone(), merged0.clone()
+        eng.set_weights(torch.from_numpy(live0).to(eng.device))
+        eng.dr_advance(phi_b, merged_b, theta, 0.37, method, assign_model=assign)
+        assert same_bits(phi_b.cpu().numpy(), phi_a.cpu().numpy())
+        assert same_bits(merged_b.cpu().numpy(), merged_a.cpu().numpy())
+        assert same_bits(eng.get_weights().cpu().numpy(), want_live)
+        assert float((phi_b - phi0).abs().max()) > 0
+    eng.close()
+
+
 def test_outer_updates_random_vs_oracle_large(env):
     """full flat-vector size, random data, vs oracle/outer.py (itself pinned to the goldens)."""
     g, eng, _ = make_problem(env, scale=0.02)
