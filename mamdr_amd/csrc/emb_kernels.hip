@@ -160,7 +160,7 @@ void launch_emb_flush(const EmbStepArgs& a, hipStream_t s) {
 
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s) {
     if (!a.flags_done) hipLaunchKernelGGL(k_emb_flag, dim3((a.rows + 255) / 256, 2), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_emb_reduce, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_emb_reduce, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
 }
 void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s) {
     const int64_t n_all = a.t[0].n_rows + a.t[1].n_rows;
@@ -169,9 +169,9 @@ void launch_emb_sweep(const EmbStepArgs& a, hipStream_t s) {
     // one float4 per thread: measured on Amazon-6 (79 M elements) 349 us uncapped vs 415 us with a
     // 4096-workgroup grid-stride loop; the cap only guards the 32-bit grid dimension
     if (blocks > 0x7fffffff) blocks = 0x7fffffff;
-    if (a.opt.optimizer == 0) hipLaunchKernelGGL(k_emb_sweep<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else if (a.opt.optimizer == 1) hipLaunchKernelGGL(k_emb_sweep<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_emb_sweep<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.opt.optimizer == 0) MAMDR_LAUNCH(k_emb_sweep<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (a.opt.optimizer == 1) MAMDR_LAUNCH(k_emb_sweep<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else MAMDR_LAUNCH(k_emb_sweep<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s) {
     const int64_t n_all = a.t[0].n_rows + a.t[1].n_rows;

@@ -21,6 +21,10 @@
 
 using namespace mamdr;
 
+namespace mamdr {
+thread_local hipEvent_t g_prof_stop = nullptr;
+}
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -49,6 +53,7 @@ struct SplitData {
 
 struct EventPair {
     hipEvent_t a, b;
+    bool own_a = true;         // false: `a` is the previous kernel's stop event (owned by that pair)
 };
 
 }  // namespace
@@ -147,6 +152,13 @@ struct mamdr_ctx {
 #endif
     // profiling
     bool profile = false;
+    std::vector<hipEvent_t> ev_pool;    // recycled profiling events
+    void ev_pool_push(hipEvent_t e) { ev_pool.push_back(e); }
+    // a kernel's time = its stop event minus the stop event of the kernel launched right before it on the stream
+    // (start markers of their own, attached or recorded, run ahead of the previous kernel's completion when the
+    // host is ahead, or add a packet between the kernels); chain_ok: prev_b is that immediately preceding event
+    hipEvent_t prev_b = nullptr;
+    bool chain_ok = false;
     std::vector<EventPair> ev[MAMDR_KERNEL_COUNT];
 };
 
@@ -199,27 +211,46 @@ SplitData* split_of(mamdr_ctx* c, int domain, int split) {
     return &c->data[(size_t)domain * 3 + split];
 }
 
-// attached = true: the events are not recorded around the launch but handed to it as its own start / stop
-// events (launch_tower*_train), which times the kernel itself like rocprofv3 does
+// per-kernel device time from stop events chained along the stream (see mamdr_ctx::prev_b)
 struct Prof {
     mamdr_ctx* c;
     int k;
-    bool attached;
-    EventPair e{nullptr, nullptr};
-    Prof(mamdr_ctx* c_, int k_, bool attached_ = false) : c(c_), k(k_), attached(attached_) {
-        if (c->profile && c->ev[k].size() < 200000) {
-            (void)hipEventCreate(&e.a);
-            (void)hipEventCreate(&e.b);
-            if (!attached) (void)hipEventRecord(e.a, c->stream);
+    EventPair e{nullptr, nullptr, true};
+    Prof(mamdr_ctx* c_, int k_, bool = false) : c(c_), k(k_) {
+        if (!c->profile || c->ev[k].size() >= 200000) return;
+        auto take = [&]() {
+            hipEvent_t ev = nullptr;
+            if (!c->ev_pool.empty()) {          // (pool refilled by mamdr_profile_reset: no event creation per launch)
+                ev = c->ev_pool.back();
+                c->ev_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&ev);
+            }
+            return ev;
+        };
+        e.b = take();
+        if (c->chain_ok && c->prev_b) {
+            e.a = c->prev_b;
+            e.own_a = false;
+        } else {                                // nothing timed right before: an explicit start marker
+            e.a = take();
+            (void)hipEventRecord(e.a, c->stream);
         }
+        g_prof_stop = e.b;                      // the launch issued inside this scope carries it (MAMDR_LAUNCH)
     }
     ~Prof() {
-        if (e.a) {
-            if (!attached) (void)hipEventRecord(e.b, c->stream);
-            c->ev[k].push_back(e);
+        if (!e.b) return;
+        if (g_prof_stop) {                      // no launch took it (should not happen): record it the plain way
+            g_prof_stop = nullptr;
+            (void)hipEventRecord(e.b, c->stream);
         }
+        c->ev[k].push_back(e);
+        c->prev_b = e.b;
+        c->chain_ok = true;
     }
 };
+// a launch that is not timed went out: the next timed kernel needs a start marker of its own
+static inline void prof_break(mamdr_ctx* c) { c->chain_ok = false; }
 
 void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
     memset(&a, 0, sizeof(a));
@@ -314,6 +345,7 @@ static void sync_tables(mamdr_ctx* c) {
     fill_emb_args(c, MAMDR_OPT_ADAM, 0.f, 1.0f - c->cfg.adam_beta1, 1.0f - c->cfg.adam_beta2, table_two_l2(c), 0,
                   c->star ? XDIM : 2 * EMB, ea);
     launch_emb_flush(ea, c->stream);
+    prof_break(c);
     c->tables_dirty = false;
     c->flush_t = c->adam_t;
 }
@@ -355,12 +387,14 @@ static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm
         EmbRowsArgs ra;
         fill_rows_args(c, d, d_perm, row_base, rows, rows_pad, alpha, c->adam_t, false, ra);
         launch_emb_rows(ra, c->stream);
+        prof_break(c);
     }
     c->rows_ready = false;
     if (!c->catchup_ready) {
         EmbStepArgs ea;
         fill_emb_args(c, MAMDR_OPT_ADAM, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
         launch_emb_catchup(ea, c->stream);
+        prof_break(c);
     }
     c->catchup_ready = false;
     c->tables_dirty = true;
@@ -378,15 +412,22 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
             Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
             launch_emb_reduce(ea, c->stream);
         }
-        if (c->deepfm) launch_lin_sweep(ea, c->stream);     // reads the row maps, then releases them
+        if (c->deepfm) {
+            launch_lin_sweep(ea, c->stream);     // reads the row maps, then releases them
+            prof_break(c);
+        }
         return;
     }
     launch_emb_reduce(ea, c->stream);
+    prof_break(c);
     {
         Prof p(c, MAMDR_KERNEL_EMB_SWEEP);
         launch_emb_sweep(ea, c->stream);
     }
-    if (c->deepfm) launch_lin_sweep(ea, c->stream);
+    if (c->deepfm) {
+        launch_lin_sweep(ea, c->stream);
+        prof_break(c);
+    }
 }
 
 // ---- Star tower: one training step on `rows` rows of domain `domain` (star.py:70-97; kernels in star_kernels.hip)
@@ -423,6 +464,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     pa.AL = c->AL;
     pa.train = 1;
     launch_star_prep(pa, c->stream);
+    prof_break(c);
 
     ta.dense = c->eff;
     ta.pn_aff = c->pn;
@@ -443,8 +485,8 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ta.stamps = c->stamps;
 #endif
     {
-        Prof p(c, MAMDR_KERNEL_FWD_BWD, true);
-        launch_tower_train(ta, c->stream, p.e.a, p.e.b);
+        Prof p(c, MAMDR_KERNEL_FWD_BWD);
+        launch_tower_train(ta, c->stream);
     }
     WgradArgs wa;
     memset(&wa, 0, sizeof(wa));
@@ -497,6 +539,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
                       !loss_out;
     if (tail) {
         launch_star_pn_bwd(ba, false, c->stream);       // (its last kernel, the domain-row column sums, rides below)
+        prof_break(c);
         EmbStepArgs tea;
         fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
         tea.flags_done = 1;
@@ -509,6 +552,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
             launch_wgrad(wa, c->stream);
         }
         launch_star_pn_bwd(ba, true, c->stream);
+        prof_break(c);
     }
 
     float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
@@ -708,9 +752,10 @@ int mamdr_destroy(mamdr_ctx* c) {
     if (!c) return MAMDR_OK;
     for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k)
         for (EventPair& p : c->ev[k]) {
-            (void)hipEventDestroy(p.a);
+            if (p.own_a) (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
         }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
@@ -934,6 +979,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
 
     c->rows_ready = false;
     c->catchup_ready = false;
+    prof_break(c);
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
@@ -1009,12 +1055,13 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
         ta.wT = c->wT;
         {
-            Prof p(c, MAMDR_KERNEL_FWD_BWD, true);
-            if (use4) launch_tower4_train(ta, c->stream, p.e.a, p.e.b);
-            else launch_tower_train(ta, c->stream, p.e.a, p.e.b);
+            Prof p(c, MAMDR_KERNEL_FWD_BWD);
+            if (use4) launch_tower4_train(ta, c->stream);
+            else launch_tower_train(ta, c->stream);
         }
 
         if (c->cfg.emb_trainable && d_loss_out) {
+            prof_break(c);
             // the regulariser of the reported loss needs the current tables' sums of squares
             launch_sumsq(c->params, (int64_t)c->cfg.n_user * EMB, c->sumsq_partials, c->frozen_sumsq + 0, c->stream);
             launch_sumsq(c->params + (size_t)c->cfg.n_user * EMB, (int64_t)c->cfg.n_item * EMB, c->sumsq_partials,
@@ -1387,12 +1434,14 @@ int mamdr_profile_reset(mamdr_ctx* c) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k) {
-        for (EventPair& p : c->ev[k]) {
-            (void)hipEventDestroy(p.a);
-            (void)hipEventDestroy(p.b);
+        for (EventPair& p : c->ev[k]) {        // kept for the next profiled run
+            if (p.own_a) c->ev_pool_push(p.a);
+            c->ev_pool_push(p.b);
         }
         c->ev[k].clear();
     }
+    c->prev_b = nullptr;
+    c->chain_ok = false;
     return MAMDR_OK;
 }
 int mamdr_profile_read(mamdr_ctx* c, int32_t kernel, double* total_ms, int64_t* launches) {

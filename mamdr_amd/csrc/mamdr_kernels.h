@@ -2,6 +2,7 @@
 // translation units.  Not part of the public boundary (include/mamdr_hip.h is).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "mamdr_device.h"
@@ -16,6 +17,20 @@ struct OptArgsLite {
     float two_l2;
 };
 constexpr int32_t EMB_UNTOUCHED = 0x7fffffff;
+
+// Profiling (mamdr_api.hip: Prof): while a timed launch is being issued, g_prof_stop is the event the launch
+// carries as its OWN stop event (hipExtLaunchKernelGGL: recorded by the kernel's completion, no marker packet
+// between the kernels).  A kernel's time is then its stop event minus the stop event of the kernel before it.
+extern thread_local hipEvent_t g_prof_stop;
+#define MAMDR_LAUNCH(kernel, grid, block, lds, stream, ...)                                               \
+    do {                                                                                                  \
+        if (::mamdr::g_prof_stop) {                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ::mamdr::g_prof_stop, 0, __VA_ARGS__); \
+            ::mamdr::g_prof_stop = nullptr;                                                               \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                            \
+        }                                                                                                 \
+    } while (0)
 
 // One launch of the fused tower kernel: gather -> MLP forward -> BCE -> (train:
 // backward activation chain) over a contiguous range of positions of one split.

@@ -426,11 +426,11 @@ __global__ __launch_bounds__(256) void k_star_update_catchup(const StarUpdateArg
     star_update_body(u, idx % STAR_UPDATE_BX, idx / STAR_UPDATE_BX);
 }
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_star_update, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_star_update, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
 }
 void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& nc, hipStream_t s) {
     const int n_cu = (nc.rows + 7) / 8;
-    hipLaunchKernelGGL(k_star_update_catchup, dim3(2 * n_cu + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, nc, n_cu);
+    MAMDR_LAUNCH(k_star_update_catchup, dim3(2 * n_cu + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, nc, n_cu);
 }
 
 }  // namespace mamdr

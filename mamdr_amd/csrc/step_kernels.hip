@@ -627,8 +627,9 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
 
 #define MAMDR_TIMED_LAUNCH(kernel, grid, block, lds, stream, e0, e1, arg)                          \
     do {                                                                                          \
-        if (e0) hipExtLaunchKernelGGL((kernel), (grid), (block), (lds), (stream), (e0), (e1), 0, (arg)); \
-        else hipLaunchKernelGGL((kernel), (grid), (block), (lds), (stream), (arg));               \
+        (void)(e0);                                                                               \
+        (void)(e1);                                                                               \
+        MAMDR_LAUNCH(kernel, (grid), (block), (lds), (stream), (arg));                            \
     } while (0)
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_gather(const TowerArgs a, flo
 }
 void launch_gather(const TowerArgs& a, float* out, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
-    hipLaunchKernelGGL(k_gather, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a, out);
+    MAMDR_LAUNCH(k_gather, dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a, out);
 }
 
 // ------------------------------------------------------------------ eval loss epilogue
@@ -1026,11 +1027,11 @@ void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRows
     memset(&sd, 0, sizeof(sd));
     if (star_dm) sd = *star_dm;
     const int n_dm = star_dm ? EMB / 16 : 0;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, a, e, n_wgrad,
+    MAMDR_LAUNCH(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, a, e, n_wgrad,
                        nr, n_rows, sd, n_dm);
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, a);
 }
 
 // sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
@@ -1237,7 +1238,7 @@ static int update_blocks(const UpdateArgs& a) {
     return n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0);
 }
 void launch_update(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_update, dim3(update_blocks(a)), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_update, dim3(update_blocks(a)), dim3(256), 0, s, a);
 }
 void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s) {
     const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
@@ -1246,7 +1247,7 @@ void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, cons
     const int n_update = update_blocks(a);
     const EmbStepArgs& nc = next_catchup ? *next_catchup : e;
     const int n_cu = next_catchup ? (nc.rows + 7) / 8 : 0;
-    hipLaunchKernelGGL(k_update_lin, dim3(2 * n_cu + n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin, nc,
+    MAMDR_LAUNCH(k_update_lin, dim3(2 * n_cu + n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin, nc,
                        n_cu);
 }
 

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 #define MAMDR_TIMED_LAUNCH4(kernel)                                                               \
     do {                                                                                          \
         if (e0) hipExtLaunchKernelGGL((kernel), grid, block, lds, s, e0, e1, 0, a);               \
-        else hipLaunchKernelGGL((kernel), grid, block, lds, s, a);                                \
+        else MAMDR_LAUNCH(kernel, grid, block, lds, s, a);                                        \
     } while (0)
 
 void launch_tower4_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
