@@ -154,11 +154,9 @@ struct UpdateArgs {
     int w0_off, w0t;           // W0 offset; w0t: also keep W0T (trainable tables)
 };
 
-// e0 / e1 (both or neither): the launch carries them as its start / stop events (hipExtLaunchKernelGGL), so
-// that hipEventElapsedTime(e0, e1) is the kernel's own duration, as rocprofv3 reports it
-void launch_tower_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void launch_tower_train(const TowerArgs& a, hipStream_t s);
 void launch_tower_eval(const TowerArgs& a, hipStream_t s);
-void launch_tower4_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void launch_tower4_train(const TowerArgs& a, hipStream_t s);
 void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s);
 struct EvalFinishArgs {
     const float* loss_part;

@@ -625,26 +625,19 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     STAMP(9);
 }
 
-#define MAMDR_TIMED_LAUNCH(kernel, grid, block, lds, stream, e0, e1, arg)                          \
-    do {                                                                                          \
-        (void)(e0);                                                                               \
-        (void)(e1);                                                                               \
-        MAMDR_LAUNCH(kernel, (grid), (block), (lds), (stream), (arg));                            \
-    } while (0)
-
-void launch_tower_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void launch_tower_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
     const dim3 grid(tiles), block(TOWER_THREADS);
     const size_t lds = tower_lds_bytes();
     if (a.deepfm) {
-        if (a.dxe) MAMDR_TIMED_LAUNCH((k_tower<true, 256, true>), grid, block, lds, s, e0, e1, a);
-        else MAMDR_TIMED_LAUNCH((k_tower<true, 0, true>), grid, block, lds, s, e0, e1, a);
+        if (a.dxe) MAMDR_LAUNCH((k_tower<true, 256, true>), grid, block, lds, s, a);
+        else MAMDR_LAUNCH((k_tower<true, 0, true>), grid, block, lds, s, a);
     } else if (a.dxe && a.dx_ld == XDIM) {
-        MAMDR_TIMED_LAUNCH((k_tower<true, 384, false>), grid, block, lds, s, e0, e1, a);
+        MAMDR_LAUNCH((k_tower<true, 384, false>), grid, block, lds, s, a);
     } else if (a.dxe) {
-        MAMDR_TIMED_LAUNCH((k_tower<true, 256, false>), grid, block, lds, s, e0, e1, a);
+        MAMDR_LAUNCH((k_tower<true, 256, false>), grid, block, lds, s, a);
     } else {
-        MAMDR_TIMED_LAUNCH((k_tower<true, 0, false>), grid, block, lds, s, e0, e1, a);
+        MAMDR_LAUNCH((k_tower<true, 0, false>), grid, block, lds, s, a);
     }
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {

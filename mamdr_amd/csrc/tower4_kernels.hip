@@ -395,24 +395,18 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
 }
 
-#define MAMDR_TIMED_LAUNCH4(kernel)                                                               \
-    do {                                                                                          \
-        if (e0) hipExtLaunchKernelGGL((kernel), grid, block, lds, s, e0, e1, 0, a);               \
-        else MAMDR_LAUNCH(kernel, grid, block, lds, s, a);                                        \
-    } while (0)
-
-void launch_tower4_train(const TowerArgs& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
     const dim3 grid(tiles), block(T4_THREADS);
     const size_t lds = tower4_lds_bytes();
     const bool dx = a.dxe != nullptr;
     if (a.deepfm) {
-        if (dx) MAMDR_TIMED_LAUNCH4((k_tower4<true, true>));
-        else MAMDR_TIMED_LAUNCH4((k_tower4<false, true>));
+        if (dx) MAMDR_LAUNCH((k_tower4<true, true>), grid, block, lds, s, a);
+        else MAMDR_LAUNCH((k_tower4<false, true>), grid, block, lds, s, a);
     } else if (dx) {
-        MAMDR_TIMED_LAUNCH4((k_tower4<true, false>));
+        MAMDR_LAUNCH((k_tower4<true, false>), grid, block, lds, s, a);
     } else {
-        MAMDR_TIMED_LAUNCH4((k_tower4<false, false>));
+        MAMDR_LAUNCH((k_tower4<false, false>), grid, block, lds, s, a);
     }
 }
 
