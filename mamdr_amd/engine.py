@@ -214,7 +214,9 @@ class TowerEngine(object):
         """one DR support step in a single pass: phi += (live - merged) * gamma; merged = theta (+|*) phi; and, for
         the next support, model := merged (mamdr.py:103-105,74) -- bit-identical to interp + merge + set_weights."""
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
-        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self._weights), _ptr(merged), _ptr(theta), float(gamma), mode,
+        # self.weights (not _weights): the live table rows must be brought up to the current Adam step before they
+        # are read into phi / replaced by merged (include/mamdr_hip.h: sync before reading or replacing the state)
+        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self.weights), _ptr(merged), _ptr(theta), float(gamma), mode,
                                           1 if assign_model else 0, phi.numel(), self._s()))
 
     def sub(self, dst, a, b):

@@ -67,6 +67,10 @@ class SpecificBase(MAML):
             shared, specific = self.meta_weights, self.domain_weights
             store = self.dataset.val_dataset
         elif mode == "test":
+            # specific_base_model.py:71: the best checkpoint comes back first -- for the Star tower that restores
+            # the tensors outside theta / phi (PartitionedNorm gamma / beta and moving statistics, the specific
+            # kernels, the output unit), and training goes on from them afterwards, as in the reference
+            self.load_model(self.checkpoint_path)
             shared, specific = self.best_shared_weights, self.best_domain_weights
             store = self.dataset.test_dataset
         else:

@@ -24,6 +24,7 @@ import json
 import math
 import os
 import os.path as osp
+import zipfile
 
 import numpy as np
 
@@ -120,7 +121,7 @@ class MultiDomainDataset(object):
         if not osp.isdir(base):
             raise FileNotFoundError("%s not found; set dataset.synthetic (e.g. \"taobao10\") to generate "
                                     "Taobao-/Amazon-shaped logs instead" % base)
-        cache = osp.join(base, "mamdr_amd_cache_bs%d.npz" % self.batch_size)
+        cache = osp.join(base, "mamdr_amd_cache.npz")          # (the columns do not depend on the batch size)
         with open(osp.join(base, "processed_data/uid2id.json"), "r") as f:
             self.n_uid = json.load(f)["id"]                                   # utils/dataset.py:50-52
         with open(osp.join(base, "processed_data/pid2id.json"), "r") as f:
@@ -128,8 +129,22 @@ class MultiDomainDataset(object):
         domains = glob.glob(osp.join(base, "domain_*"))
         domains.sort(key=lambda x: int(x.split("_")[-1]))                    # utils/dataset.py:63-64
         self.n_domain = len(domains)
-        cached = np.load(cache) if osp.exists(cache) else None
-        store = {}
+        # the cache is valid only for the files it was built from: (name, size, mtime) of every source file
+        sources = [osp.join(base, "processed_data", n) for n in ("uid2id.json", "pid2id.json", "item_emb.json",
+                                                                  "user_emb.json")]
+        for d_path in domains:
+            sources += [osp.join(d_path, n) for n in ("train.csv", "val.csv", "test.csv", "domain_property.json")]
+        stamp = json.dumps([[osp.relpath(f, base), os.stat(f).st_size, int(os.stat(f).st_mtime_ns)]
+                            for f in sources if osp.exists(f)])
+        cached = None
+        if osp.exists(cache):
+            try:
+                z = np.load(cache)
+                if "source_stamp" in z.files and str(z["source_stamp"]) == stamp:
+                    cached = z
+            except (OSError, ValueError, zipfile.BadZipFile):
+                cached = None
+        store = {"source_stamp": np.array(stamp)}
         if self.conf["name"] == "Taobao":                                     # utils/dataset.py:57-61
             if cached is not None:
                 self.user_emb, self.item_emb = cached["user_emb"], cached["item_emb"]
@@ -155,11 +170,17 @@ class MultiDomainDataset(object):
                 self._add(target, idx, cols)
             with open(osp.join(d_path, "domain_property.json")) as f:
                 self.ctr_ratio[idx] = json.load(f)["ctr_ratio"]
-        if cached is None:
+        # one writer (rank 0), written beside the target and renamed into place: readers never see a torn file
+        if cached is None and int(os.environ.get("RANK", "0")) == 0:
+            tmp = "%s.tmp.%d.npz" % (cache, os.getpid())
             try:
-                np.savez(cache, **store)
+                np.savez(tmp, **store)
+                os.replace(tmp, cache)
             except OSError:
-                pass
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
 
     # ------------------------------------------------------------------ reference API
     def get_train_dataset(self, domain_idx):

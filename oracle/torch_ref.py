@@ -1,0 +1,186 @@
+"""torch-CPU restatement of the reference's inner step with AUTOGRAD gradients (test infrastructure).
+
+Two uses, both outside the product path (only tests/ and bench.py's cpu_baseline leg import this file):
+
+* an independent cross-check of oracle/tower.py and oracle/star.py: those derive every gradient by hand in
+  numpy fp32; here only the FORWARD is written down (the same published
+  tensorflow-gpu==1.12.0 / deepctr==0.9.0 algorithms, requirements.txt:1,6) and torch.autograd differentiates
+  it in float64 (tests/test_oracle_crosscheck.py).  PARITY UNPINNED all the same: neither side is TF.
+* the CPU baseline of bench.py ("torch-CPU fp32, same step list, torch.set_num_threads(all cores)"):
+  `TorchCpuModel.train_on_batch` = gather -> tower forward -> Keras BCE + regularisers -> autograd backward ->
+  TF1 dense Adam over every trainable tensor, what `model.train_on_batch` of the compiled Keras model executes
+  per step (model_zoo/mamdr.py:54,86,97; model_zoo/DeepCTR/deepctr.py:54-60,118-136).
+
+Formulas cited next to each function; names of the tensors = oracle/tower.py / oracle/star.py.
+"""
+import numpy as np
+import torch
+
+EPS_CLIP = 1e-7      # K.epsilon(): Keras binary_crossentropy clips the probability to [eps, 1 - eps]   (A.4)
+L2_EMB = 1e-5        # deepctr l2_reg_embedding, deepctr.py:119,125-126                                  (A.3)
+L2_LIN = 1e-5        # deepctr DeepFM / WDL l2_reg_linear default                                        (A.8)
+PN_EPS = 1e-3        # partitioned_norm.py:60 epsilon
+BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8     # tf.train.AdamOptimizer defaults, deepctr.py:55            (A.5)
+
+
+def keras_bce(p, y):
+    """Keras binary_crossentropy on probabilities (A.4): clip, back to logits, sigmoid_cross_entropy_with_logits
+    (max(z, 0) - z y + log1p(exp(-|z|))).  The clip's zero gradient outside [eps, 1 - eps] comes from autograd."""
+    pc = torch.clamp(p, EPS_CLIP, 1.0 - EPS_CLIP)
+    z = torch.log(pc / (1.0 - pc))
+    return torch.clamp(z, min=0.0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))
+
+
+def deepctr_forward(P, uid, pid, dom, masks, keep_scale, tower):
+    """deepctr.py:118-136 (A.1): concat(user, item, domain rows) -> DNN(256, 128, 64; relu; dropout) ->
+    Dense(1, no bias) + global_bias -> sigmoid; DeepFM (A.8) adds the three 1-d linear tables and the FM
+    second-order term over the three 128-d fields, WDL the linear tables only (deepctr.py:29-32)."""
+    u, i, d = P["user_emb"][uid], P["item_emb"][pid], P["domain_emb"][dom]
+    h = torch.cat([u, i, d], dim=1)
+    for l in range(3):
+        h = torch.relu(h @ P["W%d" % l] + P["b%d" % l])
+        if masks is not None:
+            h = h * keep_scale * masks[l]
+    logit = (h @ P["wo"])[:, 0] + P["gb"][0]
+    if tower in ("deepfm", "wdl"):
+        logit = logit + P["lin_user"][uid] + P["lin_item"][pid] + P["lin_domain"][dom]
+    if tower == "deepfm":
+        s = u + i + d
+        logit = logit + 0.5 * torch.sum(s * s - (u * u + i * i + d * d), dim=1)
+    return torch.sigmoid(logit)
+
+
+def deepctr_loss(P, uid, pid, dom, y, masks, keep_scale, tower, uncertainty=False):
+    """mean BCE + l2 * sum(W^2) over every embedding table, frozen or not (A.3) (+ the linear tables for DeepFM /
+    WDL); uncertainty weighting (weighted_loss.py:30-43): mean(BCE) / var^2 + log var, var = log_var[dom[0]]."""
+    p = deepctr_forward(P, uid, pid, dom, masks, keep_scale, tower)
+    bce = keras_bce(p, y).mean()
+    reg = L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum())
+    if tower in ("deepfm", "wdl"):
+        reg = reg + L2_LIN * (P["lin_user"].pow(2).sum() + P["lin_item"].pow(2).sum() + P["lin_domain"].pow(2).sum())
+    if uncertainty:
+        var = P["log_var"][int(dom[0])]
+        return bce / (var * var) + torch.log(var) + reg, p
+    return bce + reg, p
+
+
+def star_forward(P, state, uid, pid, dom, training):
+    """Star tower (A.7): d = domain of the first row (partitioned_norm.py:136, star_fcn.py:112);
+    PartitionedNorm with batch statistics (population variance) in training, domain d's moving statistics in
+    inference, gamma = gamma_shared * gamma_specific[d], beta = beta_shared + beta_specific[d], eps 1e-3
+    (partitioned_norm.py:102-110,143-174); StarFCN kernel = shared * specific[d], bias = shared + specific[d]
+    (star_fcn.py:105-139); Dense(1, sigmoid) with bias (star.py:95); no dropout, no regularisers."""
+    d = int(dom[0])
+    x = torch.cat([P["user_emb"][uid], P["item_emb"][pid], P["domain_emb"][dom]], dim=1)
+    if training:
+        mean = x.mean(dim=0)
+        var = ((x - mean) ** 2).mean(dim=0)
+    else:
+        mean, var = state["mov_mean"][d], state["mov_var"][d]
+    gamma = P["pn_gamma_shared"] * P["pn_gamma_spec"][d]
+    beta = P["pn_beta_shared"] + P["pn_beta_spec"][d]
+    h = (x - mean) * torch.rsqrt(var + PN_EPS) * gamma + beta
+    for l in range(3):
+        h = torch.relu(h @ (P["Ws%d" % l] * P["Wd%d" % l][d]) + P["bs%d" % l] + P["bd%d" % l][d])
+    logit = (h @ P["wo"])[:, 0] + P["gb"][0]
+    return torch.sigmoid(logit), mean.detach(), var.detach()
+
+
+def _as_tensors(params, names, dtype, trainable):
+    out = {}
+    for n, a in params.items():
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+        if n in trainable:
+            t.requires_grad_(True)
+        out[n] = t
+    return out
+
+
+def loss_and_grads(params, names, uid, pid, dom, label, masks=None, rate=0.0, tower="mlp", uncertainty=False,
+                   state=None, dtype=torch.float64):
+    """loss and d loss / d (every tensor in `names`) by autograd in `dtype`; numpy in, numpy out.
+    tower "star": `state` carries the moving statistics (unused in training mode); masks / rate ignored."""
+    P = _as_tensors(params, names, dtype, set(names))
+    ui, pi, di = (torch.from_numpy(np.asarray(a, np.int64)) for a in (uid, pid, dom))
+    y = torch.from_numpy(np.asarray(label, np.float32)).to(dtype)
+    if tower == "star":
+        p, mean, var = star_forward(P, None, ui, pi, di, True)
+        loss = keras_bce(p, y).mean()
+        extra = {"mean": mean.numpy(), "var": var.numpy()}
+    else:
+        m = [torch.from_numpy(np.asarray(k, np.float32)).to(dtype) for k in masks] if masks is not None else None
+        keep = 1.0 / (1.0 - rate) if masks is not None else 1.0
+        loss, p = deepctr_loss(P, ui, pi, di, y, m, keep, tower, uncertainty)
+        extra = {}
+    grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
+    g = {n: (gr.numpy() if gr is not None else np.zeros(params[n].shape)) for n, gr in zip(names, grads)}
+    return float(loss.detach()), g, p.detach().numpy(), extra
+
+
+def adam_step(params, grads, names, lr, t=1, m=None, v=None):
+    """ONE tf.train.AdamOptimizer step in float64 (A.5; ApplyAdam: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t);
+    m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p -= lr_t m / (sqrt(v) + eps), eps OUTSIDE the bias
+    correction).  Returns the new parameters (float64 numpy)."""
+    lr_t = lr * np.sqrt(1.0 - BETA2 ** t) / (1.0 - BETA1 ** t)
+    out = {}
+    for n in names:
+        g = np.asarray(grads[n], np.float64)
+        m0 = np.zeros_like(g) if m is None else np.asarray(m[n], np.float64)
+        v0 = np.zeros_like(g) if v is None else np.asarray(v[n], np.float64)
+        m1 = m0 + (g - m0) * (1.0 - BETA1)
+        v1 = v0 + (g * g - v0) * (1.0 - BETA2)
+        out[n] = np.asarray(params[n], np.float64) - lr_t * m1 / (np.sqrt(v1) + ADAM_EPS)
+    return out
+
+
+class TorchCpuModel(object):
+    """fp32 stand-in for the compiled Keras model on the host cores: what one `train_on_batch` costs a CPU.
+    Dense TF1 Adam over every trainable tensor each step (with trainable tables that is the whole table: the
+    l2 regulariser makes their gradient dense; Star's tables go through Adam's sparse apply, which still decays
+    and moves every row -- A.5).  Dropout uses torch's own generator (the mask stream is not what is timed)."""
+
+    def __init__(self, params, names, tower="mlp", dropout=0.5, lr=1e-3, n_domain=None):
+        self.names = list(names)
+        self.tower = tower
+        self.rate = float(dropout)
+        self.lr = float(lr)
+        self.P = _as_tensors(params, self.names, torch.float32, set(self.names))
+        self.m = {n: torch.zeros_like(self.P[n]) for n in self.names}
+        self.v = {n: torch.zeros_like(self.P[n]) for n in self.names}
+        self.t = 0
+        if tower == "star":
+            D, X = self.P["pn_gamma_spec"].shape
+            self.state = {"mov_mean": torch.zeros(D, X), "mov_var": torch.ones(D, X),
+                          "biased_mean": torch.zeros(D, X), "biased_var": torch.zeros(D, X), "steps": torch.zeros(D)}
+
+    def train_on_batch(self, uid, pid, dom, label):
+        ui, pi, di = (torch.from_numpy(np.asarray(a, np.int64)) for a in (uid, pid, dom))
+        y = torch.from_numpy(np.asarray(label, np.float32))
+        if self.tower == "star":
+            p, mean, var = star_forward(self.P, self.state, ui, pi, di, True)
+            loss = keras_bce(p, y).mean()
+            d = int(di[0])
+            st = self.state                       # assign_moving_average(zero_debias=True), momentum 0.99
+            st["steps"][d] += 1.0
+            factor = 1.0 - 0.99 ** float(st["steps"][d])
+            for key, value in (("mean", mean), ("var", var)):
+                st["biased_" + key][d] += (value - st["biased_" + key][d]) * 0.01
+                st["mov_" + key][d] = st["biased_" + key][d] / factor
+        else:
+            masks, keep = None, 1.0
+            if self.rate > 0:
+                keep = 1.0 / (1.0 - self.rate)
+                masks = [(torch.rand(ui.shape[0], h) >= self.rate).float() for h in (256, 128, 64)]
+            loss, _ = deepctr_loss(self.P, ui, pi, di, y, masks, keep, self.tower)
+        grads = torch.autograd.grad(loss, [self.P[n] for n in self.names], allow_unused=True)
+        self.t += 1
+        lr_t = self.lr * np.sqrt(1.0 - BETA2 ** self.t) / (1.0 - BETA1 ** self.t)
+        with torch.no_grad():
+            for n, g in zip(self.names, grads):
+                p, m, v = self.P[n], self.m[n], self.v[n]
+                if g is None:
+                    g = torch.zeros_like(p)
+                m.add_(g - m, alpha=1.0 - BETA1)
+                v.add_(g * g - v, alpha=1.0 - BETA2)
+                p.sub_(lr_t * m / (v.sqrt() + ADAM_EPS))
+        return float(loss.detach())

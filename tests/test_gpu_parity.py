@@ -829,6 +829,42 @@ def test_fused_tail_launches_are_bit_identical_to_separate_kernels(env, tower):
         assert same_bits(a, b), (tower, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
 
 
+@pytest.mark.parametrize("tower", ["mlp", "star"])
+def test_meta_epoch_lazy_equals_dense_with_trainable_tables(env, tower):
+    """One DN + DR epoch (meta.mamdr_epoch: DN passes, the outer interpolation, per query domain the fused DR
+    support step mamdr_dr_advance that reads the live rows into phi and replaces them by the merged weights) with
+    trainable tables inside theta / phi.  Every host-side read or replacement of the live state must see the
+    table rows at the current Adam step: lazy replay and MAMDR_DENSE_ADAM=1 agree BITWISE in theta, every phi,
+    the live weights and both Adam slots."""
+    from mamdr_amd import meta
+    results = {}
+    for mode in ("lazy", "dense"):
+        os.environ["MAMDR_DENSE_ADAM"] = "1" if mode == "dense" else "0"
+        try:
+            if tower == "star":
+                g, eng, model = make_star_problem(env, True, scale=0.05)
+            else:
+                g, eng, model = make_problem(env, scale=0.05, batch=256, dropout=0.5, emb_trainable=True, tower=tower)
+        finally:
+            os.environ.pop("MAMDR_DENSE_ADAM", None)
+        sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(10)]
+        theta = eng.get_weights()[:eng.n_meta].clone()
+        rs = np.random.RandomState(5)
+        phis = {d: (theta * 0 + torch.from_numpy((rs.standard_normal(eng.n_meta) * 1e-3).astype(F32)).to(eng.device))
+                for d in (1, 4)}
+        plan = {"seq": [3, 1, 4], "dr": [(1, [4, 3, 1]), (4, [1, 4])]}
+        make_perm = _perm_fn_factory(sizes)
+        for ep in range(2):
+            meta.mamdr_epoch(eng, theta, phis, plan, make_perm(), 256, lr=1e-3, meta_lr=0.1)
+        results[mode] = [theta.cpu().numpy().copy(), phis[1].cpu().numpy().copy(), phis[4].cpu().numpy().copy(),
+                         eng.weights.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(),
+                         eng.adam_v.cpu().numpy().copy()]
+        eng.close()
+    for a, b, name in zip(results["lazy"], results["dense"], ("theta", "phi1", "phi4", "weights", "adam_m", "adam_v")):
+        assert np.isfinite(a).all()
+        assert same_bits(a, b), (tower, name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+
+
 # ------------------------------------------------------------------ AUC parity of the other two BASELINE towers
 def _perm_fn_factory(sizes):
     def make():

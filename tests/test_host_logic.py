@@ -382,6 +382,32 @@ def test_reference_layout_round_trip(tmp_path):
     assert info["n_user"] == g["n_user"] and info["total_val"] == sum(info[d]["n_val"] for d in range(3))
 
 
+def test_dataset_cache_is_invalidated_by_source_changes(tmp_path):
+    """the .npz cache carries (size, mtime) of every source file: an edited CSV is re-read, a torn cache file is
+    ignored, and the cache name does not depend on the batch size."""
+    g = small_gen()
+    root = str(tmp_path / "dataset" / "Taobao")
+    mds.write_reference_layout(g, root, "split_by_theme_3")
+    conf = {"name": "Taobao", "dataset_path": root, "domain_split_path": "split_by_theme_3", "batch_size": 64,
+            "shuffle_buffer_size": 10000, "num_parallel_reads": 8, "seed": 5}
+    mds.MultiDomainDataset(conf)
+    base = os.path.join(root, "split_by_theme_3")
+    caches = [f for f in os.listdir(base) if f.endswith(".npz")]
+    assert caches == ["mamdr_amd_cache.npz"]
+    csv = os.path.join(base, "domain_1", "val.csv")
+    with open(csv) as f:
+        lines = f.read().splitlines()
+    with open(csv, "w") as f:
+        f.write("\n".join(lines[:-3]) + "\n")                    # three rows fewer
+    ds = mds.MultiDomainDataset(dict(conf, batch_size=32))
+    assert ds.val_dataset[1]["n_data"] == g["data"]["val"][1]["uid"].shape[0] - 3
+    with open(os.path.join(base, caches[0]), "wb") as f:           # a torn cache file
+        f.write(b"PK\x03\x04 not a zip")
+    ds = mds.MultiDomainDataset(conf)
+    assert ds.val_dataset[1]["n_data"] == g["data"]["val"][1]["uid"].shape[0] - 3
+    assert np.array_equal(ds.train_dataset[0]["data"]["uid"], g["data"]["train"][0]["uid"])
+
+
 def test_missing_dataset_is_a_clear_error(tmp_path):
     with pytest.raises(FileNotFoundError):
         mds.MultiDomainDataset({"name": "Taobao", "dataset_path": str(tmp_path), "domain_split_path": "nope",

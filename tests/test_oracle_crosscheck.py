@@ -1,0 +1,161 @@
+"""Independent cross-check of the CPU oracle's hand-derived backward passes (CPU only, no HIP).
+
+oracle/tower.py and oracle/star.py compute every gradient by hand in numpy fp32.  oracle/torch_ref.py writes
+down only the FORWARD of the same towers and lets torch.autograd differentiate it in
+float64.  Agreement here removes the single-derivation risk of the oracle; it does not pin it to TF
+(tensorflow-gpu==1.12.0 / deepctr==0.9.0 are not installable: parity of the inner step stays unpinned).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import rng as orng            # noqa: E402
+from oracle import star as ostar          # noqa: E402
+from oracle import torch_ref as tref      # noqa: E402
+from oracle import tower as otower        # noqa: E402
+
+F32 = np.float32
+
+
+def _batch(rs, n_user, n_item, n_domain, B, single_domain=None):
+    uid = rs.randint(0, n_user, B).astype(np.int32)
+    pid = rs.randint(0, n_item, B).astype(np.int32)
+    uid[: B // 8] = uid[0]                  # repeated rows: the scatter-add paths must sum them
+    pid[B // 2:B // 2 + 5] = pid[1]
+    dom = (np.full(B, single_domain) if single_domain is not None else rs.randint(0, n_domain, B)).astype(np.int32)
+    label = (rs.uniform(size=B) < 0.3).astype(F32)
+    return uid, pid, dom, label
+
+
+def _params(rs, n_user, n_item, n_domain, tower, uncertainty):
+    p = otower.init_params(rs, n_user, n_item, n_domain)
+    p["domain_emb"] = (rs.standard_normal(p["domain_emb"].shape) * 0.05).astype(F32)
+    for l in range(3):
+        p["b%d" % l] = (rs.standard_normal(p["b%d" % l].shape) * 0.05).astype(F32)
+    p["gb"] = np.array([0.1], F32)
+    if tower in ("deepfm", "wdl"):
+        for n in ("lin_user", "lin_item", "lin_domain"):
+            p[n] = (rs.standard_normal(p[n].shape) * 0.05).astype(F32)
+    if uncertainty:
+        p["log_var"] = (1.0 + rs.uniform(-0.3, 0.3, n_domain)).astype(F32)
+    return p
+
+
+def _check_grads(got32, want64, names, rtol=3e-4):
+    for n in names:
+        g, w = np.asarray(got32[n], np.float64), np.asarray(want64[n], np.float64)
+        assert g.shape == w.shape, n
+        scale = max(np.abs(w).max(), 1e-12)
+        # fp32 contractions over <= 384 terms and <= 256 rows against float64: a few 1e-6 of the tensor's scale
+        np.testing.assert_allclose(g, w, rtol=rtol, atol=3e-6 * scale, err_msg=n)
+        rel = np.linalg.norm(g - w) / max(np.linalg.norm(w), 1e-30)
+        assert rel < 2e-6, (n, rel)
+
+
+@pytest.mark.parametrize("tower,emb_trainable,rate,uncertainty", [
+    ("mlp", False, 0.5, False), ("mlp", True, 0.5, False), ("mlp", False, 0.0, False), ("mlp", False, 0.5, True),
+    ("deepfm", True, 0.5, False), ("deepfm", False, 0.0, False), ("wdl", True, 0.5, False)])
+def test_deepctr_towers_gradients_vs_float64_autograd(tower, emb_trainable, rate, uncertainty):
+    rs = np.random.RandomState(11)
+    n_user, n_item, n_domain, B = 300, 200, 5, 192
+    p = _params(rs, n_user, n_item, n_domain, tower, uncertainty)
+    uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B, single_domain=2 if uncertainty else None)
+    deepfm = {"deepfm": 1, "wdl": 2}.get(tower, 0)
+    names = otower.param_names(emb_trainable, deepfm, uncertainty)
+    masks = otower.train_masks(1024, 3, B, (256, 128, 64), rate) if rate > 0 else None
+    loss32, g32, p32 = otower.loss_and_grads(p, uid, pid, dom, label, masks, rate, emb_trainable, None, deepfm,
+                                             uncertainty)
+    loss64, g64, p64, _ = tref.loss_and_grads(p, names, uid, pid, dom, label, masks, rate, tower, uncertainty)
+    assert abs(float(loss32) - loss64) < 2e-6 * max(1.0, abs(loss64))
+    np.testing.assert_allclose(p32, p64, rtol=2e-5, atol=2e-7)
+    _check_grads(g32, g64, names)
+
+
+@pytest.mark.parametrize("emb_trainable", [True, False])
+def test_star_tower_gradients_vs_float64_autograd(emb_trainable):
+    rs = np.random.RandomState(12)
+    n_user, n_item, n_domain, B = 300, 200, 4, 192
+    p = ostar.init_params(rs, n_user, n_item, n_domain)
+    for n in ("pn_gamma_shared", "pn_gamma_spec"):
+        p[n] = (p[n] + rs.standard_normal(p[n].shape) * 0.2).astype(F32)
+    for n in ("pn_beta_shared", "pn_beta_spec", "bs0", "bs1", "bs2", "bd0", "bd1", "bd2", "gb"):
+        p[n] = (rs.standard_normal(p[n].shape) * 0.05).astype(F32)
+    for l in range(3):
+        p["Wd%d" % l] = (p["Wd%d" % l] * 8).astype(F32)
+    uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B, single_domain=1)
+    meta, rest = ostar.param_names(emb_trainable)
+    names = meta + rest
+    state = ostar.init_state(n_domain)
+    loss32, g32, p32, c = ostar.loss_and_grads(p, state, uid, pid, dom, label, emb_trainable)
+    loss64, g64, p64, extra = tref.loss_and_grads(p, names, uid, pid, dom, label, tower="star")
+    assert abs(float(loss32) - loss64) < 2e-6 * max(1.0, abs(loss64))
+    np.testing.assert_allclose(p32, p64, rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(c["mean"], extra["mean"], rtol=1e-5, atol=1e-7)       # batch statistics
+    np.testing.assert_allclose(c["var"], extra["var"], rtol=1e-5, atol=1e-9)
+    # the domain row is constant over a single-domain batch: PartitionedNorm maps it to beta, its gradient is
+    # rounding residue in fp32 and exactly ~0 in float64
+    assert np.abs(g32["domain_emb"]).max() < 1e-5 and np.abs(g64["domain_emb"]).max() < 1e-12
+    _check_grads(g32, g64, [n for n in names if n != "domain_emb"], rtol=1e-3)
+    # the slices of the other domains carry exactly zero gradient on both sides
+    for n in ("Wd0", "bd1", "pn_gamma_spec"):
+        assert not np.any(g32[n][0]) and not np.any(g64[n][0])
+
+
+def test_tf1_adam_step_formula_vs_float64():
+    """oracle/tower.Optimizer.adam (fp32, ApplyAdam operation order) against the float64 textbook form of the same
+    update from the SAME gradients: first step from zero slots and a later step from non-zero slots."""
+    rs = np.random.RandomState(13)
+    names = ("a", "b")
+    p = {"a": rs.standard_normal((40, 30)).astype(F32), "b": rs.standard_normal(17).astype(F32)}
+    opt = otower.Optimizer(p, names)
+    for t in range(1, 4):
+        g = {n: (rs.standard_normal(p[n].shape) * 10.0 ** rs.randint(-6, 1)).astype(F32) for n in names}
+        m0 = {n: opt.m[n].copy() for n in names}
+        v0 = {n: opt.v[n].copy() for n in names}
+        want = tref.adam_step(p, g, names, 1e-3, t=t, m=m0, v=v0)
+        before = {n: p[n].copy() for n in names}
+        opt.adam(p, g, 1e-3)
+        for n in names:
+            step = np.abs(want[n] - before[n]).max()
+            np.testing.assert_allclose(p[n], want[n], rtol=0, atol=2e-7 * np.abs(before[n]).max() + 1e-4 * step)
+
+
+def test_oracle_step_equals_autograd_then_adam_end_to_end():
+    """one whole train_on_batch of the oracle (gradients by hand, fp32 Adam) against float64 autograd gradients
+    pushed through the float64 Adam step: all but a sliver of the elements within 2 % of lr (Adam's first step
+    moves every element by ~lr * sign(g); elements whose gradient is rounding noise may differ by up to 2 lr)."""
+    rs = np.random.RandomState(14)
+    n_user, n_item, n_domain, B = 300, 200, 5, 192
+    p = _params(rs, n_user, n_item, n_domain, "deepfm", False)
+    uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B)
+    names = otower.param_names(True, 1, False)
+    model = otower.OracleModel({k: v.copy() for k, v in p.items()}, emb_trainable=True, dropout=0.5, lr=1e-3,
+                               tower="deepfm")
+    masks = otower.train_masks(model.seed, 0, B, (256, 128, 64), 0.5)
+    _, g64, _, _ = tref.loss_and_grads(p, names, uid, pid, dom, label, masks, 0.5, "deepfm")
+    want = tref.adam_step(p, g64, names, 1e-3, t=1)
+    model.train_on_batch(uid, pid, dom, label)
+    for n in names:
+        diff = np.abs(model.params[n].astype(np.float64) - want[n])
+        assert diff.max() <= 2.02e-3, n
+        assert np.mean(diff > 2e-5) < 2e-3, (n, float(np.mean(diff > 2e-5)))
+
+
+def test_torch_cpu_model_follows_the_oracle():
+    """bench.py's CPU baseline model (fp32 torch, autograd, dense TF1 Adam) takes the same steps as the oracle
+    when dropout is off (its dropout masks come from torch's generator): three steps, weights within Adam noise."""
+    rs = np.random.RandomState(15)
+    n_user, n_item, n_domain, B = 300, 200, 5, 128
+    p = _params(rs, n_user, n_item, n_domain, "mlp", False)
+    names = otower.param_names(False)
+    cpu = tref.TorchCpuModel(p, names, tower="mlp", dropout=0.0, lr=1e-3)
+    model = otower.OracleModel({k: v.copy() for k, v in p.items()}, emb_trainable=False, dropout=0.0, lr=1e-3)
+    for s in range(3):
+        uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B)
+        l_cpu = cpu.train_on_batch(uid, pid, dom, label)
+        l_ora = model.train_on_batch(uid, pid, dom, label)
+        assert abs(l_cpu - float(l_ora)) < 1e-5
+    for n in names:
+        diff = np.abs(cpu.P[n].detach().numpy() - model.params[n])
+        assert np.mean(diff > 1.5e-4) < 2e-3 and diff.max() <= 6.1e-3, n
