@@ -1,37 +1,38 @@
 """bench.py -- domain-steps/sec of the MAMDR hot path on N MI355X GPUs of one node.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
-launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL); started
+WITHOUT a rendezvous (`python bench.py --gpus N`, no WORLD_SIZE) it starts that launcher itself as a child
+process -- before anything touches the GPU -- and relays the child's one JSON line and exit code.
+Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): mlp_meta_mamdr, Taobao-10 shaped synthetic
-click logs, batch 1024, pretrained 128-d tables frozen, Adam lr 1e-3, dropout 0.5,
-meta lr 0.1, 5 sampled support domains + the query domain (config/Taobao-10/
-deepctr_DN+DR.json).  ONE bench "step" = one full MAMDR meta-epoch (DN phase over all
-domains, then the DR phase: for every query domain and every support domain, a pass
-over the support domain and a pass over the query domain, with all outer updates),
-i.e. `domain_steps_per_epoch` inner optimisation steps (gather + MLP fwd/bwd + BCE +
-Adam).  value = inner domain-steps executed by all ranks / wall time of the K epochs
-(max over ranks), inputs resident in HBM, per-pass shuffles generated and uploaded
-inside the timed region, no eval inside it.
+Workload (BASELINE.json configs[1]): mlp_meta_mamdr, Taobao-10 shaped synthetic click logs, batch 1024,
+pretrained 128-d tables frozen, Adam lr 1e-3, dropout 0.5, meta lr 0.1, 5 sampled support domains + the query
+domain (config/Taobao-10/deepctr_DN+DR.json).  ONE bench "step" = one full MAMDR meta-epoch (DN phase over all
+domains, then the DR phase: for every query domain and every support domain, a pass over the support domain
+and a pass over the query domain, with all outer updates), i.e. `domain_steps_per_epoch` inner optimisation
+steps (gather + MLP fwd/bwd + BCE + Adam).  value = inner domain-steps executed by all ranks / wall time of
+the K epochs (max over ranks), inputs resident in HBM, the epoch's shuffles generated on the host and uploaded
+(one copy per epoch) inside the timed region, no eval inside it.
 
-N > 1: query domains (DR) and the DN sub-sequences are sharded over the ranks with a
-single all-reduce of the DN displacement per epoch (mamdr_amd/parallel.py); total
-work is fixed -> "scaling": "strong".
+N > 1: every epoch's DR query domains and DN passes are dealt to the ranks by longest-processing-time on the
+cost THAT epoch's sampled plan will execute (mamdr_amd/parallel.py: BalancedMAMDR), with ONE all-reduce per
+epoch (DN displacement + the phi hand-over); total work is fixed -> "scaling": "strong".
+
+Besides the headline line the JSON carries `targets.taobao30` (BASELINE.json configs[3] / north_star: Taobao-30
+bs 4096, same run), `gather` (the embedding gather on Amazon-6-sized tables, 316 MB > the 256 MiB infinity
+cache) and `cpu_baseline` (torch-CPU fp32 restatement of the TF1.12 step on this box's host cores).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector peak)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
@@ -45,6 +46,8 @@ def tower_flops_per_row(dx_width):
     """+ the input-gradient contraction dz1 . W0[0:dx_width, :]^T of the towers whose tables train: 256 columns
     ([user | item] rows, deepctr towers) or all 384 (Star: PartitionedNorm's backward needs d loss / d x)."""
     return TOWER_TRAIN_FLOPS_PER_ROW + 2 * 256 * dx_width
+
+
 GATHER_BYTES_PER_ROW = 3 * 128 * 4 * 2 + 16   # read 3 rows + write 384 floats + 4 index/label words
 
 WORKLOADS = {
@@ -54,18 +57,19 @@ WORKLOADS = {
     # (BASELINE.json configs[2]: DeepFM tower under Domain Negotiation)
     "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.1, tower="deepfm",
                     name="deepfm_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
-                         "10% of the rows per epoch)"),
+                         "{rows} of the rows per epoch)"),
+    # (BASELINE.json configs[4]: Star tower under MAMDR, theta / phi over the tables + shared kernels / biases)
+    "amazon13": dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", row_scale=0.1, tower="star",
+                     name="star_meta_mamdr Amazon-13 bs=8192 (PartitionedNorm + StarFCN, trainable tables, "
+                          "full-size tables, {rows} of the rows per epoch)"),
 }
-# (BASELINE.json configs[4]: Star tower under MAMDR, theta / phi over the tables + shared kernels / biases)
-WORKLOADS["amazon13"] = dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", row_scale=0.1,
-                             tower="star", name="star_meta_mamdr Amazon-13 bs=8192 (PartitionedNorm + StarFCN, "
-                                                "trainable tables, full-size tables, 10% of the rows per epoch)")
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
 
 
 def init_params(g, seed=1024):
     """random-init weights of the reference architecture (deepctr.py:118-136 initialisers)."""
+    import numpy as np
     rs = np.random.RandomState(seed)
     p = {"domain_emb": (rs.standard_normal((g["n_domain"], 128)) * 1e-4).astype(np.float32)}
     dims = (384, 256, 128, 64)
@@ -95,81 +99,202 @@ def setup_engine(g, batch, emb_trainable=False, tower="mlp"):
     return eng
 
 
-def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, tower="mlp"):
-    """the oracle (numpy restatement of the TF1.12 path) timed on this box's host cores on
-    the first domain-steps of the same workload; TF itself is not installable."""
-    from oracle import rng as orng
-    from oracle import tower as otower
-    if params is None:
-        params = init_params(g)
-        params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
-    if tower == "star":
-        from oracle import star as ostar
-        model = ostar.OracleStar(params, emb_trainable=emb_trainable, lr=TRAIN["learning_rate"])
-    else:
-        model = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
-                                   lr=TRAIN["learning_rate"], tower=tower)
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_sample(g, batch, shuffle_perm):
+    """the inner steps the CPU legs run: passes over the largest domain of the same synthetic workload."""
+    import numpy as np
     d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     cols = g["data"]["train"][d]
     n = cols["uid"].shape[0]
-    perm = orng.shuffle_perm(n, TRAIN["shuffle_buffer_size"], 1)
+    perm = np.asarray(shuffle_perm(n, TRAIN["shuffle_buffer_size"], 1))
+    return d, cols, n, perm
+
+
+def _time_steps(step_fn, cols, n, perm, batch, budget_s):
     steps, t0 = 0, time.time()
     while time.time() - t0 < budget_s:
         for s in range(-(-n // batch)):
             idx = perm[s * batch:(s + 1) * batch]
-            model.train_on_batch(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
+            step_fn(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
             steps += 1
             if time.time() - t0 >= budget_s:
                 break
-    dt = time.time() - t0
+    return steps, time.time() - t0
+
+
+def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, tower="mlp"):
+    """The reference's CPU path (TF1.12, not installable here) is represented by restatements of the same step
+    (oracle/, test infrastructure), timed on this box's host cores on a bounded sample of the same workload:
+      * "value": torch-CPU fp32, autograd + dense TF1 Adam, at the fastest thread count of a sweep --
+        the reported baseline;
+      * "numpy_oracle": the numpy fp32 parity oracle on the same steps (a checker, not tuned for speed)."""
+    import torch
+    from oracle import rng as orng
+    from oracle import torch_ref as tref
+    from oracle import tower as otower
+    if params is None:
+        params = init_params(g)
+        params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
+    d, cols, n, perm = _cpu_sample(g, batch, orng.shuffle_perm)
+    cores = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        cores = len(os.sched_getaffinity(0))
     except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": steps / dt, "unit": "domain-steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d inner steps (bs=%d, domain %d of the same synthetic workload) of the numpy fp32 oracle "
-                      "in %.1f s; restatement of the TF1.12 CPU path, not TF" % (steps, batch, d, dt)}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed MAMDR meta-epochs")
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="taobao10", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # MAMDR_BENCH_SHARE_GPU=1 (testing on a 1-GPU box only): all ranks use device 0 and gloo
-        share = os.environ.get("MAMDR_BENCH_SHARE_GPU") == "1"
-        torch.cuda.set_device(0 if share else local_rank)
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            except TypeError:
-                dist.init_process_group("nccl")
+        pass
+    if tower == "star":
+        from oracle import star as ostar
+        names = sum(ostar.param_names(emb_trainable), ())
     else:
-        torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        names = otower.param_names(emb_trainable, {"deepfm": 1, "wdl": 2}.get(tower, 0), False)
+    model = tref.TorchCpuModel({k: v for k, v in params.items()}, names, tower=tower, dropout=TRAIN["dropout"],
+                               lr=TRAIN["learning_rate"])
 
+    def one(s):
+        idx = perm[(s % (n // batch or 1)) * batch:(s % (n // batch or 1) + 1) * batch]
+        t = time.time()
+        model.train_on_batch(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
+        return time.time() - t
+    # the thread count is the baseline's own tuning knob: at these sizes (0.4 - 3.4 GFLOP per step) all hardware
+    # threads of a big host are far slower than a fraction of them (fork / join per small op; with every SMT
+    # sibling busy a step took SECONDS on the 256-thread GPU host).  Doubling sweep from 8 threads up to half the
+    # visible hardware threads, each trial 1 warm + 4 timed steps, stopped once a trial is clearly slower than
+    # the best so far; the timed sample then runs at the best count (reported as `cores`).
+    cap = cores // 2 if cores >= 16 else cores
+    trials, best_nt, best_t, nt = [], None, None, min(8, cap)
+    while True:
+        torch.set_num_threads(nt)
+        one(0)
+        t = sum(one(k) for k in range(1, 5)) / 4.0
+        trials.append((nt, t))
+        if best_t is None or t < best_t:
+            best_nt, best_t = nt, t
+        if nt >= cap or t > 1.25 * best_t:
+            break
+        nt = min(2 * nt, cap)
+    torch.set_num_threads(best_nt)
+    steps, dt = _time_steps(model.train_on_batch, cols, n, perm, batch, budget_s * 0.6)
+    out = {"value": steps / dt, "unit": "domain-steps/s", "cores": int(best_nt), "kind": "port",
+           "host_cores_visible": int(cores),
+           "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 2) for k, v in trials},
+           "sample": "%d inner steps (bs=%d, domain %d of the same synthetic workload) in %.1f s: torch-CPU fp32 "
+                     "restatement of the TF1.12 step (gather, tower forward, Keras BCE, autograd backward, dense "
+                     "TF1 Adam, dropout masks from a pre-drawn pool; oracle/torch_ref.py) on %d threads (the fastest of a doubling sweep up to "
+                     "half of the %d visible hardware threads); a restatement, not TF" % (steps, batch, d, dt, best_nt, cores)}
+    del model
+    # second leg: the numpy parity oracle
+    if tower == "star":
+        from oracle import star as ostar
+        omodel = ostar.OracleStar(params, emb_trainable=emb_trainable, lr=TRAIN["learning_rate"])
+    else:
+        omodel = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
+                                    lr=TRAIN["learning_rate"], tower=tower)
+    osteps, odt = _time_steps(omodel.train_on_batch, cols, n, perm, batch, budget_s * 0.3)
+    out["numpy_oracle"] = {"value": osteps / odt, "unit": "domain-steps/s",
+                           "sample": "%d steps of the numpy fp32 oracle in %.1f s" % (osteps, odt)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- committed profiles
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/rocpd_summary.py pmc, gfx950 corrections applied); None if no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel_key]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def rocprof_avg_us(kernel, shape):
+    """average duration of `kernel` in the newest committed rocprofv3 summary of this workload
+    (profiles/r*_kernel_stats_<shape>.csv), for comparison with the HIP-event average measured live;
+    None if no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_%s.csv" % shape)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if kernel in row["Name"]:
+                    return float(row["AverageNs"]) / 1e3
+    except Exception:
+        pass
+    return None
+
+
+def finish_roofline(kernel, total_ms, launches, rows, flops_per_row=TOWER_TRAIN_FLOPS_PER_ROW):
+    """achieved = algorithmic flops of all profiled launches / their summed device time
+    (= flops per average launch / average launch duration)."""
+    flops = rows * flops_per_row
+    ach = flops / (total_ms * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(kernel),
+            "traffic_unit": "HBM bytes per launch (profiles/pmc_hbm_latest.json: separate rocprofv3 --pmc passes)",
+            "launches": launches,
+            "avg_us": total_ms / max(launches, 1) * 1e3, "rows_per_launch": rows / max(launches, 1),
+            "flops_per_row": flops_per_row}
+
+
+# ---------------------------------------------------------------------------------------------- gather evidence
+def gather_hbm_record(device, n_rows=1 << 19, reps=12):
+    """the embedding gather (k_gather = the tile code the step kernels use) on Amazon-6-sized tables: 445,789 +
+    172,653 rows x 128 fp32 = 316 MB, beyond the 256 MiB infinity cache, uniformly random rows, 2^19 positions
+    per launch (0.81 GB of output).  HIP-event timed on the launch stream; `traffic` = HBM bytes per launch from
+    the committed PMC passes of tools/gather_hbm.py (same sizes)."""
+    import numpy as np
+    import torch
+    from mamdr_amd import _lib as L
+    from mamdr_amd import engine, synthetic
+    spec = synthetic.SHAPES["amazon6"]
+    n_user, n_item, D = spec["n_user"], spec["n_item"], spec["n_domain"]
+    eng = engine.TowerEngine(n_user, n_item, D, 1024, dropout=0.0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(5)
+    for name, n in (("user_emb", n_user), ("item_emb", n_item)):
+        t = torch.randn((n, 128), generator=gen, device=device, dtype=torch.float32) * 0.1
+        eng.tables[name] = t
+        seg = {"user_emb": L.SEG_USER_EMB, "item_emb": L.SEG_ITEM_EMB}[name]
+        L.check(eng.lib.mamdr_bind_table(eng.ctx, seg, engine._ptr(t), n))
+    rs = np.random.RandomState(9)
+    eng.bind_domain_data(0, "train", rs.randint(0, n_user, n_rows), rs.randint(0, n_item, n_rows),
+                         rs.randint(0, D, n_rows), rs.randint(0, 2, n_rows).astype(np.float32))
+    out = torch.empty((n_rows, 384), dtype=torch.float32, device=device)
+    for _ in range(3):
+        eng.gather(0, "train", out=out)
+    eng.profile(True)
+    eng.profile_reset()
+    for _ in range(reps):
+        eng.gather(0, "train", out=out)
+    ms, cnt = eng.profile_read(L.KERNEL_GATHER)
+    eng.profile(False)
+    eng.close()
+    nbytes = n_rows * GATHER_BYTES_PER_ROW
+    ach = nbytes / (ms / cnt * 1e-3) / 1e9
+    return {"kernel": "k_gather", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": pmc_traffic("k_gather@amazon6"),
+            "traffic_unit": "HBM bytes per launch (profiles/pmc_hbm_latest.json, tools/gather_hbm.py)",
+            "avg_us": ms / cnt * 1e3, "launches": cnt, "rows_per_launch": n_rows, "bytes_per_row": GATHER_BYTES_PER_ROW,
+            "algorithmic_bytes_per_launch": nbytes, "table_bytes": (n_user + n_item) * 512,
+            "note": "Amazon-6-sized tables (316 MB, beyond the 256 MiB infinity cache), uniformly random rows; "
+                    "3 x 512-B rows read + 384 floats written per position"}
+
+
+# ---------------------------------------------------------------------------------------------- one workload
+def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0.0):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from mamdr_amd import _lib as L
     from mamdr_amd import meta, parallel, plan as mplan, synthetic
 
-    wl = WORKLOADS[args.workload]
+    wl = WORKLOADS[wl_name]
     batch = int(os.environ.get("MAMDR_BENCH_BATCH", wl["batch"]))      # (exploration only: the named config fixes it)
+    row_scale = float(os.environ.get("MAMDR_BENCH_ROW_SCALE", wl.get("row_scale", 1.0)))
     trainable = bool(wl.get("emb_trainable"))
-    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=wl.get("row_scale", 1.0))
+    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=row_scale)
     D = g["n_domain"]
     tower = wl.get("tower", "mlp")
     eng = setup_engine(g, batch, trainable, tower)
@@ -192,28 +317,35 @@ def main():
     eng.set_weights(full0)                 # tensors outside theta (Star: PN, specific kernels, output unit)
     theta = full0[:eng.n_meta].clone()
     del full0
-    owner = parallel.lpt_partition(sizes, world)
-    # phi_d starts as a second random init of the whole model (mamdr.py:31-33)
     wrapper = wl.get("wrapper", "mamdr")
-    phis = {d: eng.pack(full_params(seed=2000 + d))[:eng.n_meta].clone() for d in range(D) if owner[d] == rank} \
-        if wrapper == "mamdr" else {}
-    bufs = {"delta": eng.new_vector(meta=True), "zero": eng.new_vector(meta=True), "merged": eng.new_vector(meta=True)}
+    # phi_d starts as a second random init of the whole model (mamdr.py:31-33); every rank draws all of them
+    balanced = None
+    if wrapper == "mamdr":
+        phis = {d: eng.pack(full_params(seed=2000 + d))[:eng.n_meta] for d in range(D)}
+        balanced = parallel.BalancedMAMDR(eng, meta, theta, phis, steps_per_domain)
+        del phis
+    delta, zero = eng.new_vector(meta=True), eng.new_vector(meta=True)
     planner = mplan.EpochPlanner(range(D), TRAIN["sample_num"], TRAIN["add_query_domain"], True, TRAIN["seed"])
-    shuffler = mplan.PassShuffler(sizes, TRAIN["shuffle_buffer_size"], TRAIN["seed"] + rank)
+    shuffles = mplan.EpochShuffles(mplan.PassShuffler(sizes, TRAIN["shuffle_buffer_size"], TRAIN["seed"] + rank),
+                                   eng.device)
+    loads = []
 
     def epoch():
         if wrapper == "dn":               # Domain Negotiation only (domain_negotiation.py:37-88)
             p = planner.next_epoch(with_dr=False)
+            owner = parallel.lpt_partition(steps_per_domain, world)
+            local = [d for d in p["seq"] if owner[d] == rank]
+            shuffles.prepare([(d, 0) for d in local])
             tr = []
-            parallel.dn_phase_sharded(eng, meta, theta, parallel.shard_plan(p, owner, rank)["seq"], shuffler, batch,
-                                      TRAIN["learning_rate"], TRAIN["meta_learning_rate"], tr, bufs["delta"],
-                                      bufs["zero"])
+            parallel.dn_phase_sharded(eng, meta, theta, local, shuffles, batch, TRAIN["learning_rate"],
+                                      TRAIN["meta_learning_rate"], tr, delta, zero)
             eng.set_weights(theta)
             return tr, mplan.plan_steps(p, steps_per_domain)
         p = planner.next_epoch()          # same seed on every rank -> same global plan
-        tr = parallel.mamdr_epoch_sharded(eng, meta, theta, phis, p, owner, shuffler, batch,
-                                          TRAIN["learning_rate"], TRAIN["meta_learning_rate"], bufs,
-                                          TRAIN["merged_method"])
+        tr = balanced.epoch(p, shuffles.prepare, shuffles, batch, TRAIN["learning_rate"], TRAIN["meta_learning_rate"],
+                            TRAIN["merged_method"])
+        if balanced.last_load is not None:
+            loads.append(balanced.last_load)
         return tr, mplan.plan_steps(p, steps_per_domain)
 
     def barrier():
@@ -221,12 +353,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         epoch()
     barrier()
+    del loads[:]
     t0 = time.perf_counter()
     local_steps, global_steps, local_passes = 0, 0, 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         tr, b = epoch()
         local_steps += sum(t[2] for t in tr)
         local_passes += len(tr)
@@ -244,8 +377,8 @@ def main():
 
     # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
     #      the same workload; reported for the dominant kernel, k_tower<train>
-    roofline, gather_info, kernels, sweep_info, table_info = None, None, {}, None, None
-    if not args.no_profile:
+    roofline, kernels, sweep_info, table_info, l2_gather = None, {}, None, None, None
+    if profile:
         eng.profile(True)
         eng.profile_reset()
         epoch()                       # fills the library's event pool: the measured epoch below creates no events
@@ -260,7 +393,8 @@ def main():
             # default: lazy replay of TF1's dense table Adam (csrc/emb_kernels.hip) -- per step only the rows of
             # the batch move through HBM; MAMDR_DENSE_ADAM=1 measures the per-step sweep instead
             ms, cnt = eng.profile_read(L.KERNEL_EMB_SWEEP)
-            table_info = {"mode": "lazy (bit-identical to the per-step dense sweep)", "kernel": "k_emb_reduce (+ Adam step of the touched rows)",
+            table_info = {"mode": "lazy (bit-identical to the per-step dense sweep)",
+                          "kernel": "k_emb_reduce (+ Adam step of the touched rows)",
                           "avg_us": ms / max(cnt, 1) * 1e3, "launches": cnt}
         if trainable and dense_adam:
             # HBM-bound dense optimiser pass: 24 B per table element (read p, m, v; write p, m, v) + 4 B
@@ -289,97 +423,157 @@ def main():
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows,
                                    tower_flops_per_row(384 if tower == "star" else (256 if trainable else 0)))
         roofline["rocprofv3_avg_us"] = rocprof_avg_us(kname, wl["shape"])
-        # gather kernel on a pass-sized batch (largest domain, shuffled order)
-        dbig = max(range(D), key=lambda k: sizes[k])
-        perm = torch.from_numpy(shuffler(dbig)).to(eng.device)
-        out = torch.empty((sizes[dbig], 384), dtype=torch.float32, device=eng.device)
-        for _ in range(3):
-            eng.gather(dbig, "train", perm=perm, out=out)
-        eng.profile(True)
-        eng.profile_reset()
-        for _ in range(20):
-            eng.gather(dbig, "train", perm=perm, out=out)
-        gms, gcnt = eng.profile_read(L.KERNEL_GATHER)
-        eng.profile(False)
-        eng.profile_reset()
-        gbytes = sizes[dbig] * GATHER_BYTES_PER_ROW
-        gach = gbytes / (gms / gcnt * 1e-3) / 1e9
-        gather_info = {"kernel": "k_gather", "bound": "hbm", "achieved": gach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": gach / PEAK_HBM_GBS, "traffic": None, "rows_per_launch": sizes[dbig],
-                       "bytes_per_row": GATHER_BYTES_PER_ROW,
-                       "note": "standalone pass-sized gather of the same tile code the step kernel uses; "
-                               "Taobao tables (15.7 MB) are cache-resident, the 48 MB output is not"}
-    result = None
+        if not trainable:
+            # the workload's own gather: pass-sized, the frozen Taobao tables live in L2 / infinity cache
+            dbig = max(range(D), key=lambda k: sizes[k])
+            perm = torch.from_numpy(shuffles.sh(dbig)).to(eng.device)
+            out = torch.empty((sizes[dbig], 384), dtype=torch.float32, device=eng.device)
+            for _ in range(3):
+                eng.gather(dbig, "train", perm=perm, out=out)
+            eng.profile(True)
+            eng.profile_reset()
+            for _ in range(20):
+                eng.gather(dbig, "train", perm=perm, out=out)
+            gms, gcnt = eng.profile_read(L.KERNEL_GATHER)
+            eng.profile(False)
+            eng.profile_reset()
+            gach = sizes[dbig] * GATHER_BYTES_PER_ROW / (gms / gcnt * 1e-3) / 1e9
+            l2_gather = {"kernel": "k_gather", "served_from": "L2 / infinity cache (tables of %.1f MB)" %
+                         ((g["n_user"] + g["n_item"]) * 512 / 1e6), "achieved": gach, "unit": "GB/s",
+                         "rows_per_launch": sizes[dbig], "bytes_per_row": GATHER_BYTES_PER_ROW,
+                         "note": "cache-resident tables: NOT an HBM figure (the HBM-bound gather is `gather`)"}
+    cpu = None
+    if rank == 0 and world == 1 and cpu_budget > 0:
+        cpu = cpu_baseline(g, batch, cpu_budget, full_params() if trainable else None, trainable, tower)
+    rec = {
+        "value": global_steps / dt, "unit": "domain-steps/s", "ms_per_step": dt / steps * 1e3,
+        "workload": wl["name"].format(rows="%g %%" % (row_scale * 100)), "global_batch": batch, "domains": D,
+        "domain_steps_per_epoch": global_steps / steps, "epochs_timed": steps,
+        "us_per_domain_step": dt / global_steps * 1e6 * world,
+        "domain_passes_per_sec": local_passes / dt,
+        "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0)) else roofline,
+        "tower": roofline, "table_update": table_info or sweep_info, "gather_l2": l2_gather,
+        "kernels_avg_us": kernels, "cpu_baseline": cpu,
+    }
+    if loads:
+        # what the per-epoch partition allows: sum of the ranks' planned steps / the largest rank's
+        rec["partition_speedup_bound"] = float(np.mean([sum(l) / max(l) for l in loads]))
+    if cpu:
+        rec["gpu_over_cpu"] = rec["value"] / cpu["value"]
+    eng.close()
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------- launcher
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a rendezvous: start N ranks through torch.distributed.run as a CHILD
+    process (this process has not touched the GPU and never will), relay its JSON line and exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.stdout.flush()
+    return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed MAMDR meta-epochs")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="taobao10", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-targets", action="store_true", help="skip the Taobao-30 record and the Amazon-6-sized gather")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # MAMDR_BENCH_SHARE_GPU=1 (testing on a 1-GPU box only): all ranks use device 0 and gloo
+        share = os.environ.get("MAMDR_BENCH_SHARE_GPU") == "1"
+        torch.cuda.set_device(0 if share else local_rank)
+        backend = "gloo" if share else "nccl"
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:
+                dist.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    main_rec = run_workload(args.workload, args.steps, args.warmup, rank, world, not args.no_profile,
+                            args.cpu_budget * (0.6 if not args.no_targets and args.workload == "taobao10" else 1.0))
+    targets, gather = {}, None
+    if not args.no_targets and args.workload == "taobao10":
+        # north_star's target configuration in the same run: Taobao-30 bs 4096
+        t30 = run_workload("taobao30", max(3, args.steps // 4), min(args.warmup, 2), rank, world, not args.no_profile,
+                           args.cpu_budget * 0.4)
+        targets["taobao30"] = {k: t30[k] for k in ("workload", "value", "unit", "us_per_domain_step", "ms_per_step",
+                                                    "epochs_timed", "domain_steps_per_epoch", "tower", "kernels_avg_us",
+                                                    "cpu_baseline", "gpu_over_cpu", "partition_speedup_bound")
+                               if k in t30}
+    if not args.no_targets and rank == 0 and world == 1 and not args.no_profile:
+        gather = gather_hbm_record(torch.device("cuda", torch.cuda.current_device()))
     if rank == 0:
-        cpu = cpu_baseline(g, batch, args.cpu_budget, full_params() if trainable else None, trainable, tower) \
-            if args.cpu_budget > 0 else None
+        r = main_rec
         result = {
-            "metric": "domain-steps/sec", "value": global_steps / dt, "unit": "domain-steps/s",
+            "metric": "domain-steps/sec", "value": r["value"], "unit": "domain-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "global_batch": batch, "domains": D,
-                       "domain_steps_per_epoch": global_steps / args.steps,
+            "config": {"workload": r["workload"], "global_batch": r["global_batch"], "domains": r["domains"],
+                       "domain_steps_per_epoch": r["domain_steps_per_epoch"],
                        "step_definition": "one MAMDR meta-epoch (DN + DR phases, all outer updates)",
-                       "parallelism": "domain-sharded x%d, 1 all-reduce of the DN displacement per epoch" % world
-                       if world > 1 else "single GPU"},
-            "us_per_domain_step": dt / global_steps * 1e6 * world,
+                       "parallelism": ("per-epoch LPT of DR query domains + DN passes over %d ranks, 1 all-reduce per "
+                                       "epoch (DN displacement + phi hand-over)" % world) if world > 1 else "single GPU"},
+            "us_per_domain_step": r["us_per_domain_step"],
             # SURVEY 8d: also domain-passes/sec (one pass = one domain's re-initialised iterator run to its end or
             # cap) and the epoch time (= ms_per_step: a bench step is one meta-epoch)
-            "domain_passes_per_sec": local_passes / dt, "epoch_time_ms": dt / args.steps * 1e3,
-            "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0))
-            else roofline, "tower": roofline, "table_update": table_info or sweep_info, "gather": gather_info, "kernels_avg_us": kernels, "cpu_baseline": cpu,
+            "domain_passes_per_sec": r["domain_passes_per_sec"], "epoch_time_ms": r["ms_per_step"],
+            "roofline": r["roofline"], "tower": r["tower"], "table_update": r["table_update"],
+            "gather": gather, "gather_l2": r["gather_l2"], "kernels_avg_us": r["kernels_avg_us"],
+            "cpu_baseline": r["cpu_baseline"], "targets": targets,
         }
-        if cpu:
-            result["gpu_over_cpu"] = result["value"] / cpu["value"]
+        if world > 1:
+            result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
+            result["backend"] = backend
+            if "partition_speedup_bound" in r:
+                # (Taobao-10 has 10 query domains: the partition itself bounds the speed-up, ~5x on 8 ranks)
+                result["partition_speedup_bound"] = r["partition_speedup_bound"]
+        if r.get("gpu_over_cpu") is not None:
+            result["gpu_over_cpu"] = r["gpu_over_cpu"]
         print(json.dumps(result))
-    eng.close()
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
-    return result
-
-
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (tools/summarize_pmc.py, gfx950 corrections applied); None if no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[kernel_key]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
-
-
-def rocprof_avg_us(kernel, shape):
-    """average duration of `kernel` in the newest committed rocprofv3 summary of this workload
-    (profiles/r*_kernel_stats_<shape>.csv), for comparison with the HIP-event average measured live
-    (events bracket single launches and add ~2 us of inter-command gap); None if no summary is committed."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_%s.csv" % shape)))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            for row in csv.DictReader(f):
-                if kernel in row["Name"]:
-                    return float(row["AverageNs"]) / 1e3
-    except Exception:
-        pass
-    return None
-
-
-def finish_roofline(kernel, total_ms, launches, rows, flops_per_row=TOWER_TRAIN_FLOPS_PER_ROW):
-    """achieved = algorithmic flops of all profiled launches / their summed device time
-    (= flops per average launch / average launch duration)."""
-    flops = rows * flops_per_row
-    ach = flops / (total_ms * 1e-3) / 1e12
-    return {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(kernel),
-            "traffic_unit": "HBM bytes per launch (profiles/pmc_hbm_latest.json: separate rocprofv3 --pmc passes)",
-            "launches": launches,
-            "avg_us": total_ms / max(launches, 1) * 1e3, "rows_per_launch": rows / max(launches, 1),
-            "flops_per_row": flops_per_row}
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 4
+#define MAMDR_ABI_VERSION 5
 
 enum {
     MAMDR_OK = 0,
@@ -255,6 +255,11 @@ int mamdr_pcgrad_project(float* d_final, float* d_aux, const int64_t* h_offsets,
 /* --- host-side helper: tf.data shuffle(buffer_size) order of range(n)
  *     (utils/dataset.py:27-37), splitmix64-driven; writes n int32 to HOST memory. */
 int mamdr_shuffle_perm(int64_t n, int64_t buffer_size, uint64_t seed, int32_t* h_out);
+/* the same for every pass of an epoch in one call: pass k is a shuffle of range(h_n[k]) with seed h_seeds[k],
+ * written at h_out + sum(h_n[0..k)) (one pinned staging buffer, one upload per epoch instead of one per
+ * re-initialised iterator: mamdr.py:52-53,81-82,92-93). */
+int mamdr_shuffle_perms(int32_t n_passes, const int64_t* h_n, int64_t buffer_size, const uint64_t* h_seeds,
+                        int32_t* h_out);
 
 /* --- profiling: per-kernel device time from HIP events on the context's stream.
  *     enable != 0 brackets every launch of the listed kernels with events.

@@ -1416,6 +1416,18 @@ int mamdr_shuffle_perm(int64_t n, int64_t buffer_size, uint64_t seed, int32_t* h
     return MAMDR_OK;
 }
 
+int mamdr_shuffle_perms(int32_t n_passes, const int64_t* h_n, int64_t buffer_size, const uint64_t* h_seeds,
+                        int32_t* h_out) {
+    if (n_passes < 0 || (n_passes > 0 && (!h_n || !h_seeds))) return fail(MAMDR_EINVAL, "bad pass list");
+    int64_t off = 0;
+    for (int32_t k = 0; k < n_passes; ++k) {
+        const int rc = mamdr_shuffle_perm(h_n[k], buffer_size, h_seeds[k], h_out ? h_out + off : nullptr);
+        if (rc) return rc;
+        off += h_n[k];
+    }
+    return MAMDR_OK;
+}
+
 #ifdef MAMDR_STAMPS
 // diagnostic build only (tools/stamp_tower.py)
 int mamdr_debug_set_stamps(mamdr_ctx* c, unsigned long long* d_stamps) {

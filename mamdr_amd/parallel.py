@@ -101,6 +101,115 @@ def mamdr_epoch_sharded(eng, meta, theta, phis, plan, owner, perm_fn, batch_size
     return trace
 
 
+def epoch_assignment(plan, steps_per_domain, n_parts, domain_regulation_step=0):
+    """per-epoch balance of one DN + DR epoch over the ranks (hard part 6): the cost of query domain
+    i is what its DR will execute with THIS epoch's sampled supports, sum_j (steps_j + query steps_i)
+    (mamdr.py:72-108); queries go to ranks by longest-processing-time, then the DN passes (cost steps_d) fill up
+    the least-loaded ranks.  Every rank computes the same assignment from the same plan.
+    -> (dr_owner {query: rank}, dn_owner {domain: rank}, load per rank)"""
+    def qsteps(i):
+        s = steps_per_domain[i]
+        return min(s, domain_regulation_step) if domain_regulation_step and domain_regulation_step > 0 else s
+    cost = {q: sum(steps_per_domain[j] + qsteps(q) for j in support) for q, support in plan["dr"]}
+    load = [0.0] * n_parts
+    dr_owner, dn_owner = {}, {}
+    for q in sorted(cost, key=lambda i: (-cost[i], i)):
+        r = min(range(n_parts), key=lambda k: (load[k], k))
+        dr_owner[q] = r
+        load[r] += cost[q]
+    for d in sorted(plan["seq"], key=lambda i: (-steps_per_domain[i], i)):
+        r = min(range(n_parts), key=lambda k: (load[k], k))
+        dn_owner[d] = r
+        load[r] += steps_per_domain[d]
+    return dr_owner, dn_owner, load
+
+
+class BalancedMAMDR(object):
+    """DN + DR epochs sharded over the ranks with a per-epoch assignment and ONE collective per epoch.
+
+    Every rank keeps theta and ALL phi_d in one packed buffer [delta | phi_0 | ... | phi_{D-1}].  An epoch:
+      1. the plan (same seed everywhere) -> epoch_assignment -> this rank's DN sub-sequence and DR queries;
+      2. DN passes from theta; delta = theta~ - theta;
+      3. the phi slots this rank did NOT update in the previous epoch are zeroed and the whole buffer is
+         all-reduced (sum): delta becomes sum_g delta_g and every phi slot its last owner's value -- the phi
+         hand-over to this epoch's owners rides in the DN collective, so an epoch still has exactly one;
+      4. theta += beta * sum_g delta_g;  5. DR of the owned queries (meta.dr_query), phi slots updated in place.
+    With one rank no collective runs and the epoch is meta.mamdr_epoch's (the reference's loop).
+    `sync_phis()` makes every slot current everywhere (before validation / checkpoints)."""
+
+    def __init__(self, eng, meta, theta, phis, steps_per_domain):
+        """phis: {domain: vector}, the SAME initial values on every rank (every rank draws all D initialisations)."""
+        self.eng, self.meta, self.theta = eng, meta, theta
+        self.steps = list(steps_per_domain)
+        self.domains = sorted(phis)
+        P = theta.numel()
+        self.P = P
+        self.pack = torch.zeros((1 + len(self.domains)) * P, dtype=torch.float32, device=theta.device)
+        self.delta = self.pack[:P]
+        self.phis = {}
+        for k, d in enumerate(self.domains):
+            v = self.pack[(1 + k) * P:(2 + k) * P]
+            v.copy_(phis[d])
+            self.phis[d] = v
+        self.zero = torch.zeros_like(theta)
+        self.merged = torch.empty_like(theta)
+        self.mine = None            # queries whose phi this rank updated last (None: every slot is current)
+        self.last_queries = set()   # queries ANY rank updated in that epoch (the plan is global)
+        self.last_load = None
+
+    def _keep_only_current(self):
+        """zero every phi slot another rank holds the current value of; a slot nobody updated is identical
+        everywhere and stays on rank 0 only, so that the sum over ranks returns it unchanged."""
+        rank, _ = world()
+        for d in self.domains:
+            if d in self.mine or (d not in self.last_queries and rank == 0):
+                continue
+            self.phis[d].zero_()
+
+    def sync_phis(self):
+        rank, ws = world()
+        if ws > 1 and self.mine is not None:
+            self._keep_only_current()
+            dist.all_reduce(self.pack[self.P:], op=dist.ReduceOp.SUM)
+        self.mine = None
+
+    def epoch(self, plan, perm_prepare, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
+              domain_regulation_step=0):
+        """perm_prepare(passes) (optional) is told this rank's passes in execution order before they run
+        (plan.EpochShuffles.prepare).  Returns the trace of (phase, domain, n_steps)."""
+        from . import plan as mplan
+        rank, ws = world()
+        eng, meta, theta = self.eng, self.meta, self.theta
+        if ws == 1:
+            if perm_prepare is not None:
+                perm_prepare(mplan.epoch_passes(plan, domain_regulation_step))
+            return meta.mamdr_epoch(eng, theta, self.phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method,
+                                    domain_regulation_step, scratch=self.merged)
+        dr_owner, dn_owner, load = epoch_assignment(plan, self.steps, ws, domain_regulation_step)
+        self.last_load = load
+        local = {"seq": [d for d in plan["seq"] if dn_owner[d] == rank],
+                 "dr": [(q, s) for (q, s) in plan["dr"] if dr_owner[q] == rank]}
+        if perm_prepare is not None:
+            perm_prepare(mplan.epoch_passes(local, domain_regulation_step))
+        trace = []
+        eng.set_weights(theta)
+        for d in local["seq"]:
+            meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
+        eng.sub(self.delta, eng.weights, theta)
+        if self.mine is None:                       # every slot is current everywhere: only delta travels
+            dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+        else:
+            self._keep_only_current()
+            dist.all_reduce(self.pack, op=dist.ReduceOp.SUM)
+        eng.interp(theta, self.delta, self.zero, meta_lr)
+        for query, support in local["dr"]:
+            meta.dr_query(eng, theta, self.phis[query], query, support, perm_fn, batch_size, lr, meta_lr, trace,
+                          self.merged, merged_method, domain_regulation_step)
+        self.mine = set(q for q, _ in local["dr"])
+        self.last_queries = set(q for q, _ in plan["dr"])
+        return trace
+
+
 def gather_domain_scalars(local, n_domain, device):
     """local: dict domain -> (loss, auc) for owned domains; returns full dicts on every rank."""
     rank, ws = world()

@@ -80,6 +80,82 @@ class PassShuffler(object):
         return perm if begin == 0 else (perm + np.int32(begin)).astype(np.int32)
 
 
+def epoch_passes(plan, domain_regulation_step=0):
+    """the passes of one MAMDR epoch in execution order (mamdr.py:48-108): DN over the sequence, then for every
+    query domain and every support domain a support pass and a query pass.  -> [(domain, max_steps)],
+    max_steps 0 = the whole split."""
+    out = [(d, 0) for d in plan["seq"]]
+    for q, support in plan["dr"]:
+        for j in support:
+            out.append((j, 0))
+            out.append((q, int(domain_regulation_step) if domain_regulation_step and domain_regulation_step > 0 else 0))
+    return out
+
+
+class EpochShuffles(object):
+    """perm_fn for the meta loops that draws EVERY permutation of an epoch up front -- the same PassShuffler
+    stream in the same order, so the passes see the same shuffles as with one upload per pass -- into one pinned
+    staging buffer (one C call: mamdr_shuffle_perms) and uploads them in ONE copy; the passes then take device
+    slices.  Two staging / device buffers alternate so that the host may prepare epoch e + 1 while the stream
+    still runs epoch e."""
+
+    def __init__(self, shuffler, device):
+        import torch
+        self.sh = shuffler
+        self.device = device
+        self.torch = torch
+        self.host = [None, None]
+        self.dev = [None, None]
+        self.done = [None, None]
+        self.k = 0
+        self.queue = []
+
+    def prepare(self, passes):
+        """passes: [(domain, max_steps)] in execution order (epoch_passes) for THIS rank."""
+        import ctypes as C
+        torch = self.torch
+        sh = self.sh
+        self.pos = 0
+        if not sh.shuffle:
+            self.queue = [(d, None) for d, _ in passes]
+            return
+        n = np.array([sh.sizes[d] for d, _ in passes], np.int64)
+        seeds = np.empty(len(passes), np.uint64)
+        for i in range(len(passes)):
+            sh.counter += 1
+            seeds[i] = _mix64(sh.seed * 0x10001 + sh.counter)
+        total = int(n.sum())
+        k = self.k = self.k ^ 1
+        if self.host[k] is None or self.host[k].numel() < total:
+            cap = max(total, 1) * 5 // 4
+            self.host[k] = torch.empty(cap, dtype=torch.int32).pin_memory()
+            self.dev[k] = torch.empty(cap, dtype=torch.int32, device=self.device)
+            self.done[k] = None
+        if self.done[k] is not None:
+            self.done[k].synchronize()          # the previous upload from this staging buffer has been read
+        lib = _engine.L.load()
+        _engine.L.check(lib.mamdr_shuffle_perms(len(passes), n.ctypes.data_as(C.c_void_p), sh.buffer_size,
+                                                seeds.ctypes.data_as(C.c_void_p),
+                                                C.c_void_p(self.host[k].data_ptr())))
+        self.dev[k][:total].copy_(self.host[k][:total], non_blocking=True)
+        self.done[k] = torch.cuda.Event()
+        self.done[k].record(torch.cuda.current_stream(self.device))
+        off, q = 0, []
+        for (d, _), cnt in zip(passes, n):
+            q.append((d, self.dev[k][off:off + int(cnt)]))
+            off += int(cnt)
+        self.queue = q
+
+    def __call__(self, d, window=None):
+        if window is not None:
+            raise ValueError("EpochShuffles serves whole-split passes only")
+        dd, perm = self.queue[self.pos]
+        if dd != d:
+            raise RuntimeError("pass %d of the epoch is over domain %d, not %d" % (self.pos, dd, d))
+        self.pos += 1
+        return perm
+
+
 def plan_steps(plan, steps_per_domain, domain_regulation_step=0):
     """number of domain-steps a plan executes (metric accounting)."""
     n = sum(steps_per_domain[d] for d in plan["seq"])

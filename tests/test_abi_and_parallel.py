@@ -61,6 +61,36 @@ def test_product_path_does_not_import_oracle():
         assert n_inside == n_total > 0, (fname, n_inside, n_total)
 
 
+def test_bench_spawns_ranks_as_a_child_process(monkeypatch, capsys):
+    """`python bench.py --gpus N` without WORLD_SIZE: the parent starts `python -m torch.distributed.run
+    --nproc-per-node N ... bench.py <same arguments>` as a child (never exec), relays the one JSON line and the
+    exit code, and does not import torch.cuda-touching code itself."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    seen = {}
+
+    class Done(object):
+        returncode = 0
+        stdout = "noise\n" + '{"metric": "domain-steps/sec", "n_gpus": 4}' + "\n"
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw.get("env")
+        return Done()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    rc = bench.spawn_ranks(argparse.Namespace(gpus=4))
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "domain-steps/sec", "n_gpus": 4}' and "noise" in out.err
+    Done.returncode, Done.stdout = 3, ""
+    assert bench.spawn_ranks(argparse.Namespace(gpus=4)) == 3
+
+
 def test_lpt_and_plan_sharding():
     from mamdr_amd import parallel
     sizes = [4493, 3495, 7864, 5242, 6291, 31462, 3145, 10485, 3932, 15728]
@@ -151,6 +181,134 @@ def test_sharded_mamdr_epoch_gloo_world2(tmp_path):
         outs.append(out.decode())
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in out, out[-3000:]
+
+
+BAL_SETUP = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import numpy as np, torch
+from fake_engine import FakeEngine
+from mamdr_amd import meta, parallel, plan as mplan, synthetic
+from oracle import rng as orng
+D = 5
+def make_engine():
+    g = synthetic.generate({{"name": "Taobao", "split": "s", "n_domain": D, "n_user": 300, "n_item": 200, "n_train": 1900,
+                            "n_val": 400, "n_test": 400, "pretrained": True}}, batch_size=64, seed=5, emb_dim=8)
+    eng = FakeEngine(g["n_user"], g["n_item"], D, 64, emb_dim=8, hidden=(16, 8, 4))
+    eng.bind_table("user_emb", g["tables"]["user_emb"]); eng.bind_table("item_emb", g["tables"]["item_emb"])
+    for d in range(D):
+        c = g["data"]["train"][d]; eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+    return eng
+def initial(eng):
+    theta = torch.from_numpy(eng.oracle.get_flat().copy())
+    rs = np.random.RandomState(3)
+    phis = {{d: torch.from_numpy((rs.standard_normal(eng.n_params) * 0.01).astype(np.float32)) for d in range(D)}}
+    return theta, phis
+"""
+
+BAL_WORKER = BAL_SETUP + r"""
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+eng = make_engine()
+sizes = [eng.n_rows(d, "train") for d in range(D)]
+spd = [-(-n // 64) for n in sizes]
+theta, phis = initial(eng)
+bal = parallel.BalancedMAMDR(eng, meta, theta, phis, spd)
+planner = mplan.EpochPlanner(range(D), 2, True, True, 11)
+shuf = mplan.PassShuffler(sizes, 10000, 77 + rank, shuffle_fn=orng.shuffle_perm)
+total, owners = 0, []
+for ep in range(3):
+    p = planner.next_epoch()
+    tr = bal.epoch(p, None, shuf, 64, 1e-3, 0.1)
+    total += sum(t[2] for t in tr)
+    owners.append(sorted(bal.mine))
+    want = mplan.plan_steps(p, spd)
+    st = torch.tensor([float(sum(t[2] for t in tr))]); dist.all_reduce(st)
+    assert int(st.item()) == want, (st.item(), want)
+bal.sync_phis()
+np.savez({out!r} % rank, theta=theta.numpy(), owners=np.array([str(o) for o in owners]),
+         **{{"phi%d" % d: bal.phis[d].numpy() for d in range(D)}})
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_balanced_mamdr_epochs_gloo_world2(tmp_path):
+    """BalancedMAMDR: per-epoch LPT of queries / DN passes, phi hand-over inside the ONE all-reduce per epoch.
+    Two gloo ranks against an in-process emulation of the same two ranks (two engines, sums in numpy):
+    theta and every phi identical on both ranks after sync_phis() and bit-equal to the emulation; ownership
+    really moves between epochs."""
+    script = tmp_path / "bal_worker.py"
+    script.write_text(BAL_WORKER.format(root=ROOT, here=HERE, out=str(tmp_path / "bal_%d.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
+    res = [np.load(str(tmp_path / ("bal_%d.npz" % r))) for r in range(2)]
+    for k in res[0].files:
+        if k != "owners":
+            assert np.array_equal(res[0][k], res[1][k]), k
+    assert len(set(res[0]["owners"])) > 1 or len(set(res[1]["owners"])) > 1      # the assignment moved
+    # ---- emulation of the two ranks in this process
+    ns = {}
+    exec(BAL_SETUP.format(root=ROOT, here=HERE), ns)
+    import torch
+    from mamdr_amd import meta, parallel, plan as mplan
+    from oracle import rng as orng
+    D = ns["D"]
+    engs = [ns["make_engine"](), ns["make_engine"]()]
+    sizes = [engs[0].n_rows(d, "train") for d in range(D)]
+    spd = [-(-n // 64) for n in sizes]
+    theta, phi0 = ns["initial"](engs[0])
+    theta = theta.clone()
+    phis = {d: v.clone() for d, v in phi0.items()}
+    planner = mplan.EpochPlanner(range(D), 2, True, True, 11)
+    shufs = [mplan.PassShuffler(sizes, 10000, 77 + r, shuffle_fn=orng.shuffle_perm) for r in range(2)]
+    for ep in range(3):
+        p = planner.next_epoch()
+        dr_owner, dn_owner, _ = parallel.epoch_assignment(p, spd, 2)
+        deltas = []
+        for r in range(2):
+            engs[r].set_weights(theta)
+            for d in p["seq"]:
+                if dn_owner[d] == r:
+                    meta.run_pass(engs[r], d, shufs[r], 64, 1e-3, [], "dn")
+            deltas.append((engs[r].weights.numpy() - theta.numpy()).astype(np.float32))
+        tot = (deltas[0] + deltas[1]).astype(np.float32)
+        engs[0].interp(theta, torch.from_numpy(tot), torch.zeros_like(theta), 0.1)
+        for r in range(2):
+            merged = torch.empty_like(theta)
+            for q, sup in p["dr"]:
+                if dr_owner[q] == r:
+                    meta.dr_query(engs[r], theta, phis[q], q, sup, shufs[r], 64, 1e-3, 0.1, [], merged)
+    assert np.array_equal(theta.numpy(), res[0]["theta"])
+    for d in range(D):
+        assert np.array_equal(phis[d].numpy(), res[0]["phi%d" % d]), d
+
+
+def test_epoch_assignment_balances_the_sampled_plan():
+    from mamdr_amd import parallel, plan as mplan
+    spd = [5, 4, 8, 6, 7, 31, 4, 11, 4, 16, 3, 9, 2, 14, 6, 5, 7, 3, 20, 4, 6, 8, 5, 3, 9, 4, 12, 5, 3, 6]
+    planner = mplan.EpochPlanner(range(30), 5, True, True, 123)
+    for _ in range(5):
+        p = planner.next_epoch()
+        for n in (1, 2, 4, 8):
+            dr_owner, dn_owner, load = parallel.epoch_assignment(p, spd, n)
+            assert sorted(dr_owner) == list(range(30)) and sorted(dn_owner) == list(range(30))
+            assert abs(sum(load) - mplan.plan_steps(p, spd)) < 1e-6          # the cost model IS the step count
+            assert max(load) <= sum(load) / n * 1.12 + 1                     # 30 long-tailed domains: within 12 %
+    # with a cap on the query pass (domain_regulation_step) the cost follows it
+    p = planner.next_epoch()
+    _, _, load = parallel.epoch_assignment(p, spd, 4, domain_regulation_step=2)
+    assert abs(sum(load) - mplan.plan_steps(p, spd, 2)) < 1e-6
 
 
 RUN_WORKER = r'''

@@ -93,3 +93,47 @@ def test_amazon13_star_config_parses_and_selects_meta_prefix():
         cfg = json.load(f)
     assert cfg["model"]["name"] == "star_meta_mamdr" and cfg["dataset"]["batch_size"] == 8192
     assert cfg["train"]["meta_parms"] == ["emb", "kernel_shared", "bias_shared"] and cfg["train"]["emb_trainable"]
+
+
+def test_bench_gpus2_starts_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a rendezvous starts two ranks itself (child torch.distributed.run, before
+    touching the GPU) and relays ONE JSON line with n_gpus 2.  On this 1-GPU box both ranks share device 0 over
+    gloo (MAMDR_BENCH_SHARE_GPU=1); with one GPU per rank the same code path runs RCCL."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    env = dict(os.environ, MAMDR_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--cpu-budget", "0", "--no-profile", "--no-targets"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["backend"] == "gloo" and rec["value"] > 0
+    assert rec["config"]["domain_steps_per_epoch"] > 1000 and 1.0 < rec["partition_speedup_bound"] <= 2.0
+
+
+def test_epoch_shuffles_equal_per_pass_shuffles():
+    """plan.EpochShuffles (every permutation of an epoch from one C call, one upload) hands out exactly the
+    permutations PassShuffler would have produced pass by pass."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import plan as mplan
+    sizes = [700, 12000, 31, 2500]
+    plan = {"seq": [2, 0, 3, 1], "dr": [(2, [0, 2]), (0, [1, 0]), (3, [2, 3]), (1, [3, 1])]}
+    passes = mplan.epoch_passes(plan)
+    assert [d for d, _ in passes][:4] == [2, 0, 3, 1] and len(passes) == 4 + 2 * 8
+    a = mplan.PassShuffler(sizes, 10000, 91)
+    es = mplan.EpochShuffles(mplan.PassShuffler(sizes, 10000, 91), torch.device("cuda", 0))
+    for ep in range(3):                          # both staging buffers and a reuse
+        es.prepare(passes)
+        for d, _ in passes:
+            got = es(d).cpu().numpy()
+            assert np.array_equal(got, a(d)) and sorted(got.tolist()) == list(range(sizes[d]))
+    with pytest.raises(RuntimeError):
+        es.prepare(passes)
+        es(0)                                    # the epoch's first pass is over domain 2

@@ -6,6 +6,8 @@
   python tools/rocpd_summary.py pmc <fetch.db> <write.db> <out.json>
         per-kernel HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes with the
         gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests at 64 B)
+  python tools/rocpd_summary.py pmc1 <fetch.db> <write.db> <kernel substring> <key> <out.json>
+        the same for ONE kernel, merged into an existing summary under <key>
 """
 import collections, csv, json, sqlite3, sys
 
@@ -39,6 +41,21 @@ def main():
                 w.writerow(list(r))
         return
     fetch, write = counter_avg(sys.argv[2], "FETCH_SIZE"), counter_avg(sys.argv[3], "WRITE_SIZE")
+    if sys.argv[1] == "pmc1":
+        sub, key, path = sys.argv[4], sys.argv[5], sys.argv[6]
+        try:
+            out = json.load(open(path))
+        except Exception:
+            out = {}
+        for k in sorted(set(fetch) | set(write)):
+            if sub in k:
+                fkb, n = fetch.get(k, (0.0, 0))
+                wkb, _ = write.get(k, (0.0, 0))
+                out[key] = {"launches": n, "FETCH_SIZE_KB_raw": fkb, "WRITE_SIZE_KB": wkb,
+                            "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0,
+                            "note": "read side = 2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B)"}
+        json.dump(out, open(path, "w"), indent=1)
+        return
     out = {}
     for k in sorted(set(fetch) | set(write)):
         if "mamdr" not in k:
