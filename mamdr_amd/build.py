@@ -19,6 +19,7 @@ SOURCES = [
     # (HIP's __fmul_rn / __fadd_rn are plain operators; explicit __fmaf_rn where an fma is wanted)
     ("emb_kernels.hip", ["-ffp-contract=off"]),
     ("tower4_kernels.hip", []),
+    ("fused_kernels.hip", []),
     ("star_kernels.hip", []),
     ("outer_kernels.hip", ["-ffp-contract=off"]),
     ("mamdr_api.hip", []),

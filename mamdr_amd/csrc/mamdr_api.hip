@@ -98,6 +98,16 @@ struct mamdr_ctx {
     float* dm_copy = nullptr;       // pre-update snapshot of the domain table (dW0[256:384] by linearity)
     bool lin_w0dom = false;         // k_wgrad carries no tiles for W0[256:384]: k_update rebuilds that gradient from S
     float* wT = nullptr;            // transposed W1 / W2 (k_tower4)
+    // mlp tower with frozen tables: weight gradients + optimiser step in one launch (k_wgrad_adam) + k_dm_finish
+    // instead of k_wgrad -> slabs -> k_update (MAMDR_FUSED=0 keeps the slab path)
+    bool fused = false;
+    int fused_max_batch = 2048;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size)
+    float* pdm = nullptr;           // [32][n_domain][EMB] partial domain-table gradients
+    // the domain table's step stays pending until the next tower kernel applies it (DmStep, mamdr_kernels.h):
+    // two snapshots [3][n_domain][EMB] of (p, m, v) alternate between steps
+    float* dmsnap[2] = {nullptr, nullptr};
+    int dm_cur = 0;
+    bool dm_finish_each = false;    // MAMDR_DM_EACH=1: materialise after every step (k_dm_finish per step; A/B measurements)
     int tower_tile = 0;             // 0 auto, 4 / 16 forced (env MAMDR_TOWER_TILE)
     // trainable user / item tables
     float* dxe = nullptr;
@@ -714,6 +724,18 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->domrow, rp * sizeof(int32_t));
     ALLOC(c->loss_part, (rp / 4) * sizeof(float));
     ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
+    {
+        const char* fe = getenv("MAMDR_FUSED");
+        c->fused = cfg->tower == MAMDR_TOWER_MLP && !cfg->emb_trainable && !cfg->uncertainty_weight && c->lin_w0dom &&
+                   cfg->n_domain <= 64 && !(fe && atoi(fe) == 0);
+        if (c->fused && fe && atoi(fe) == 2) c->fused_max_batch = 1 << 30;
+        if (c->fused) {
+            ALLOC(c->pdm, (size_t)DM_PARTS * cfg->n_domain * EMB * sizeof(float));
+            ALLOC(c->dmsnap[0], (size_t)3 * cfg->n_domain * EMB * sizeof(float));
+            ALLOC(c->dmsnap[1], (size_t)3 * cfg->n_domain * EMB * sizeof(float));
+            if (const char* de = getenv("MAMDR_DM_EACH")) c->dm_finish_each = atoi(de) != 0;
+        }
+    }
     if (const char* ev = getenv("MAMDR_NO_TAILFUSE")) c->tail_fuse = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
@@ -756,7 +778,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             (void)hipEventDestroy(p.b);
         }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->pdm, c->dmsnap[0], c->dmsnap[1], c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -980,6 +1002,11 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     c->rows_ready = false;
     c->catchup_ready = false;
     prof_break(c);
+    DmStep dm_pending;                  // k_wgrad_adam path: the domain table's step of the previous step of THIS call
+    memset(&dm_pending, 0, sizeof(dm_pending));
+    // one path per call (the pending domain-table step lives across the steps of a call): k_wgrad_adam for batches up
+    // to fused_max_batch rows (measured: 27.3 vs 29.5 us / step at 1,024 rows, a tie at 4,096)
+    const bool fused = c->fused && (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
@@ -1050,14 +1077,84 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.fmq = c->fmq;
         if (c->L.lv_count > 0) ta.uw_off = c->L.lv + domain;
 #ifdef MAMDR_STAMPS
-        ta.stamps = c->stamps;
+        ta.stamps = c->stamps ? c->stamps + (c->global_step & 1) * 16384 : nullptr;      // two steps side by side
 #endif
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
         ta.wT = c->wT;
+        float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
+        if (fused) {
+            ta.w0dom_snap = c->w0dom_copy;
+            c->dm_cur ^= 1;
+            ta.dms = dm_pending;                       // the previous step of this call (snap == null: none)
+            ta.dm_hint = domain;
+            ta.dm_live_p = c->params + c->table_floats + c->L.dm;
+            ta.dm_live_m = dense_m + c->L.dm;
+            ta.dm_live_v = c->adam_v + c->table_floats + c->L.dm;
+            ta.dm_snap_out = c->dmsnap[c->dm_cur];
+        }
         {
             Prof p(c, MAMDR_KERNEL_FWD_BWD);
             if (use4) launch_tower4_train(ta, c->stream);
             else launch_tower_train(ta, c->stream);
+        }
+        if (fused) {
+            FusedArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.acts = c->acts;
+            fa.dz = c->dz;
+            fa.dlogit = c->dlogit;
+            fa.domrow = c->domrow;
+            fa.xa = c->acts;
+            fa.xa_ld = ACT_LD;
+            fa.rows_pad = rows_pad;
+            fa.rows = rows;
+            fa.p = c->params + c->table_floats;
+            fa.m = dense_m;
+            fa.v = c->adam_v + c->table_floats;
+            fa.L = c->L;
+            fa.n_domain = c->cfg.n_domain;
+            fa.w0dom_snap = c->w0dom_copy;
+            fa.dm_snap = c->dmsnap[c->dm_cur];         // p plane: the domain table as this step's forward pass saw it
+            fa.pdm = c->pdm;
+            fa.wT = (may_use4 && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
+            fa.optimizer = optimizer;
+            fa.alpha = step_alpha;
+            fa.omb1 = omb1;
+            fa.omb2 = omb2;
+            fa.eps = c->cfg.adam_eps;
+            fa.two_l2 = 2.0f * c->cfg.l2_emb;
+            fa.loss_part = c->loss_part;
+            fa.n_loss_tiles = use4 ? rows_pad / 4 : rows_pad / TILE_ROWS;
+            fa.frozen_sumsq = c->frozen_sumsq;
+            fa.l2_emb = c->cfg.l2_emb;
+            fa.loss_out = d_loss_out ? d_loss_out + s : nullptr;
+#ifdef MAMDR_STAMPS
+            fa.stamps = c->stamps ? c->stamps + 65536 + (c->global_step & 1) * 4096 : nullptr;
+#endif
+            {
+                Prof p(c, MAMDR_KERNEL_WGRAD);
+                launch_wgrad_adam(fa, c->stream);
+            }
+            // the domain table's step stays pending: the next step's tower kernel applies it, the last one of the
+            // call is materialised below
+            dm_pending.snap = c->dmsnap[c->dm_cur];
+            dm_pending.pdm = c->pdm;
+            dm_pending.n_part = DM_PARTS;
+            dm_pending.n_domain = c->cfg.n_domain;
+            dm_pending.optimizer = optimizer;
+            dm_pending.alpha = step_alpha;
+            dm_pending.omb1 = omb1;
+            dm_pending.omb2 = omb2;
+            dm_pending.eps = c->cfg.adam_eps;
+            dm_pending.two_l2 = 2.0f * c->cfg.l2_emb;
+            if (c->dm_finish_each || s + 1 == n_steps) {
+                Prof p(c, MAMDR_KERNEL_UPDATE);
+                launch_dm_finish(dm_pending, c->params + c->table_floats + c->L.dm, dense_m + c->L.dm,
+                                 c->adam_v + c->table_floats + c->L.dm, c->stream);
+                dm_pending.snap = nullptr;
+            }
+            c->global_step += 1;
+            continue;
         }
 
         if (c->cfg.emb_trainable && d_loss_out) {

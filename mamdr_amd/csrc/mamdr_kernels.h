@@ -32,6 +32,69 @@ extern thread_local hipEvent_t g_prof_stop;
         }                                                                                                 \
     } while (0)
 
+// ---- domain table under k_wgrad_adam.  Its gradient is a sum over the S workgroups' partials, i.e. a device-wide
+// dependency inside the step.  Instead of a kernel of its own per step (4 us of launch + drain for 1,280 elements)
+// the step stays PENDING: the next step's tower kernel applies it on the fly -- every workgroup recomputes the
+// row(s) its samples use from (p, m, v before the step, the partials), workgroup d < n_domain also writes row d
+// back -- and k_dm_finish materialises the last step of a mamdr_train_steps call.  All three sites run dm_step4:
+// explicit roundings, the same bits wherever it is instantiated.
+constexpr int DM_PARTS = 32;       // partial gradients per step = S workgroups of k_wgrad_adam
+constexpr int DM_PAIRS = DM_PARTS / 2;
+struct DmStep {
+    const float* snap;         // [3][n_domain][EMB]: p, m, v of the domain table BEFORE the pending step; null = none pending
+    const float* pdm;          // [n_part][n_domain][EMB] partial gradients of the pending step
+    int n_part, n_domain;
+    int optimizer;             // of the pending step: 0 adam, 1 sgd, 2 accumulate
+    float alpha, omb1, omb2, eps, two_l2;
+};
+// Canonical arithmetic (every site, bit for bit): pair sums s_j = pdm[2 j] + pdm[2 j + 1], g = s_0 + s_1 + ... in
+// order, g += 2 l2 p, optimiser step with separately rounded operations.
+__device__ __forceinline__ f32x4 dm_pair(const DmStep& q, int d, int c4, int j) {
+#pragma clang fp contract(off)
+    const size_t row = (size_t)d * EMB + 4 * c4, plane = (size_t)q.n_domain * EMB;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(q.pdm + (size_t)(2 * j) * plane + row);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(q.pdm + (size_t)(2 * j + 1) * plane + row);
+    return a + b;
+}
+// (p, m, v of the row BEFORE the step: separate, so that a caller can request them ahead of a barrier)
+__device__ __forceinline__ void dm_load4(const DmStep& q, int d, int c4, f32x4& p, f32x4& m, f32x4& v) {
+    const size_t row = (size_t)d * EMB + 4 * c4, plane = (size_t)q.n_domain * EMB;
+    p = *reinterpret_cast<const f32x4*>(q.snap + row);
+    m = *reinterpret_cast<const f32x4*>(q.snap + plane + row);
+    v = *reinterpret_cast<const f32x4*>(q.snap + 2 * plane + row);
+}
+__device__ __forceinline__ void dm_apply4(const DmStep& q, f32x4 g, f32x4& p, f32x4& m, f32x4& v) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float gk = g[k] + q.two_l2 * p[k];
+        if (q.optimizer == 0) {
+            m[k] = m[k] + (gk - m[k]) * q.omb1;
+            v[k] = v[k] + (gk * gk - v[k]) * q.omb2;
+            p[k] = p[k] - (m[k] * q.alpha) / (sqrtf(v[k]) + q.eps);
+        } else if (q.optimizer == 1) {
+            p[k] = p[k] - gk * q.alpha;
+        } else {
+            m[k] = m[k] + gk;
+        }
+    }
+}
+// one lane does it all (the writer workgroups and k_dm_finish: off the critical path): four batches of loads
+__device__ __forceinline__ void dm_step4(const DmStep& q, int d, int c4, f32x4& p, f32x4& m, f32x4& v) {
+#pragma clang fp contract(off)
+    dm_load4(q, d, c4, p, m, v);
+    f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j0 = 0; j0 < DM_PAIRS; j0 += 4) {
+        f32x4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = dm_pair(q, d, c4, j0 + k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g = (j0 + k == 0) ? t[k] : g + t[k];
+    }
+    dm_apply4(q, g, p, m, v);
+}
+
 // One launch of the fused tower kernel: gather -> MLP forward -> BCE -> (train:
 // backward activation chain) over a contiguous range of positions of one split.
 struct TowerArgs {
@@ -78,6 +141,17 @@ struct TowerArgs {
     // divided by var^2, var = dense[uw_off] (the batch's domain); -1 = off
     int uw_off;
     const float* wT;           // k_tower4 only: transposed W1 / W2 copies
+    // k_wgrad_adam path: the tower also snapshots W0[256:384, :] and the domain table (it only READS the weights;
+    // the fused kernel steps them while other workgroups still need the pre-update values); null otherwise
+    float* w0dom_snap;
+    // domain table (see DmStep): the pending step to apply on the fly, the live rows workgroup d < n_domain writes
+    // back, and the snapshot [3][n_domain][EMB] of (p, m, v) as this step's forward pass saw them
+    DmStep dms;
+    int dm_hint;               // the domain the caller expects every row of the batch to carry (the pass's domain)
+    float* dm_live_p;
+    float* dm_live_m;
+    float* dm_live_v;
+    float* dm_snap_out;
     // eval outputs
     const float* thresholds;   // 500 fp32 AUC thresholds
     uint32_t* hist;            // [2][501]
@@ -153,6 +227,187 @@ struct UpdateArgs {
     int w1_off, w2_off;        // offsets of W1 / W2 in the dense block
     int w0_off, w0t;           // W0 offset; w0t: also keep W0T (trainable tables)
 };
+
+// pre-update snapshot of W0[256:384, :] for k_wgrad_adam, by the LAST wave of every tower workgroup (it is not on
+// the row bookkeeping's critical path): float4 i for i in this workgroup's share
+__device__ __forceinline__ void tower_snapshots(const TowerArgs& a, int n_threads, int n_tiles) {
+    if (a.w0dom_snap == nullptr) return;
+    const int st = (int)threadIdx.x - (n_threads - 64);
+    if (st < 0) return;
+    const int total = EMB * H1 / 4;
+    const int per = (total + n_tiles - 1) / n_tiles;
+    const int i0 = (int)blockIdx.x * per, i1 = min(i0 + per, total);
+    const f32x4* w0dom = reinterpret_cast<const f32x4*>(a.dense + a.L.w0 + 2 * EMB * H1);
+    for (int i = i0 + st; i < i1; i += 64) reinterpret_cast<f32x4*>(a.w0dom_snap)[i] = w0dom[i];
+}
+// ---- the tile workgroups' domain-table duty (DmStep).  Everything is requested at kernel start, beside the weight
+// prefetch, from the domain the caller expects (dm_hint: per-domain datasets carry one domain per batch), so the
+// round trip to the partials hides behind the row bookkeeping's own dependent loads:
+//   reader  all 512 lanes fetch one pair sum each of row dm_hint (16 pairs x 32 float4) -> LDS -> behind a barrier
+//           32 lanes add them in order and step the row: the tile's x[256:384] (if the batch's rows do carry
+//           dm_hint; otherwise every lane of a domain segment runs dm_step4 alone)
+//   writer  workgroup d < n_domain does the same for row d with lanes 32..63 and writes it back: live p / m / v and
+//           the snapshot [3][n_domain][EMB] this step's k_wgrad_adam and the next step's towers read
+// one element: the 16 staged pair sums of column c in order, then the step (the scalar form of dm_step4: same bits)
+__device__ __forceinline__ void dm_elem_finish(const DmStep& q, int c, const float* parts, float& p, float& m, float& v) {
+#pragma clang fp contract(off)
+    float t[DM_PAIRS];
+#pragma unroll
+    for (int j = 0; j < DM_PAIRS; ++j) t[j] = parts[j * EMB + c];
+    float g = t[0];
+#pragma unroll
+    for (int j = 1; j < DM_PAIRS; ++j) g = g + t[j];
+    const float gk = g + q.two_l2 * p;
+    if (q.optimizer == 0) {
+        m = m + (gk - m) * q.omb1;
+        v = v + (gk * gk - v) * q.omb2;
+        p = p - (m * q.alpha) / (sqrtf(v) + q.eps);
+    } else if (q.optimizer == 1) {
+        p = p - gk * q.alpha;
+    } else {
+        m = m + gk;
+    }
+}
+// per-lane state of the tile workgroups' duty.  Only waves 4..7 take part: wave 0 runs the row bookkeeping's chain of
+// dependent loads, and loads retire in order -- anything requested ahead of that chain is waited for with it.
+//   waves 4..7 (256 lanes)  two pair sums each of the hinted row (and of the row to write back): lane L' = lane - 256
+//                            owns float4 c4 = L' & 31 of pairs g and g + 8, g = L' >> 5
+//   waves 4, 5 (reader)     lane L' < 128: (p, m, v) of column L' of the hinted row
+//   waves 6, 7 (writer)     lane L' - 128: the same for the row this workgroup writes back
+struct DmTile {
+    f32x4 pr[2], pw[2];
+    float p, m, v;
+};
+__device__ __forceinline__ void dm_tile_begin(const TowerArgs& a, int tile, int d_read, DmTile& t) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // scalar branches below: no divergence
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    t.pr[0] = t.pr[1] = t.pw[0] = t.pw[1] = zero;
+    t.p = t.m = t.v = 0.f;
+    if (wv < 4) return;
+    const bool pend = a.dms.snap != nullptr, wr = tile < a.n_domain;      // both uniform
+    const int dw = min(tile, a.n_domain - 1);
+    const int lp = (int)threadIdx.x - 256, grp = lp >> 5, c4 = lp & 31;
+    if (pend) {
+        t.pr[0] = dm_pair(a.dms, d_read, c4, grp);
+        t.pr[1] = dm_pair(a.dms, d_read, c4, grp + 8);
+        if (wr) {
+            t.pw[0] = dm_pair(a.dms, dw, c4, grp);
+            t.pw[1] = dm_pair(a.dms, dw, c4, grp + 8);
+        }
+    }
+    const size_t plane = (size_t)a.n_domain * EMB;
+    const int c = lp & (EMB - 1);
+    if (wv < 6) {
+        if (pend) {
+            const size_t e = (size_t)d_read * EMB + c;
+            t.p = a.dms.snap[e];
+            t.m = a.dms.snap[plane + e];
+            t.v = a.dms.snap[2 * plane + e];
+        }
+    } else if (wr) {
+        const size_t e = (size_t)dw * EMB + c;
+        if (pend) {
+            t.p = a.dms.snap[e];
+            t.m = a.dms.snap[plane + e];
+            t.v = a.dms.snap[2 * plane + e];
+        } else {
+            t.p = a.dm_live_p[e];
+            t.m = a.dm_live_m[e];
+            t.v = a.dm_live_v[e];
+        }
+    }
+}
+// pair sums -> LDS parts[2][16][128] floats (16 KB)
+__device__ __forceinline__ void dm_tile_stage(const TowerArgs& a, int tile, const DmTile& t, float* parts) {
+    if (!a.dms.snap || threadIdx.x < 256) return;
+    const int lp = (int)threadIdx.x - 256;
+    *reinterpret_cast<f32x4*>(parts + lp * 4) = t.pr[0];
+    *reinterpret_cast<f32x4*>(parts + 1024 + lp * 4) = t.pr[1];
+    if (tile < a.n_domain) {
+        *reinterpret_cast<f32x4*>(parts + 2048 + lp * 4) = t.pw[0];
+        *reinterpret_cast<f32x4*>(parts + 3072 + lp * 4) = t.pw[1];
+    }
+}
+// behind the barrier that follows dm_tile_stage: the hinted row's element c after the pending step
+__device__ __forceinline__ float dm_tile_reader(const TowerArgs& a, int c, const float* parts, const DmTile& t) {
+    float p = t.p, m = t.m, v = t.v;
+    dm_elem_finish(a.dms, c, parts, p, m, v);
+    return p;
+}
+__device__ __forceinline__ void dm_store_elem(const TowerArgs& a, size_t e, bool stepped, float p, float m, float v) {
+    const size_t plane = (size_t)a.n_domain * EMB;
+    if (stepped) {
+        if (a.dms.optimizer != 2) a.dm_live_p[e] = p;
+        if (a.dms.optimizer != 1) a.dm_live_m[e] = m;
+        if (a.dms.optimizer == 0) a.dm_live_v[e] = v;
+    }
+    a.dm_snap_out[e] = p;
+    a.dm_snap_out[plane + e] = m;
+    a.dm_snap_out[2 * plane + e] = v;
+}
+// writer lanes (waves 6, 7: c = lane - 384), behind the same barrier
+__device__ __forceinline__ void dm_tile_writer(const TowerArgs& a, int tile, int n_tiles, int c, const float* parts,
+                                               const DmTile& t) {
+    const bool pend = a.dms.snap != nullptr;
+    if (tile < a.n_domain) {
+        float p = t.p, m = t.m, v = t.v;
+        if (pend) dm_elem_finish(a.dms, c, parts + 2048, p, m, v);
+        dm_store_elem(a, (size_t)tile * EMB + c, pend, p, m, v);
+    }
+    // grids smaller than the domain count (tiny batches): the remaining rows, one lane chain per float4
+    if (c < EMB / 4) {
+        for (int d = tile + n_tiles; d < a.n_domain; d += n_tiles) {
+            f32x4 p, m, v;
+            const size_t row = (size_t)d * EMB + 4 * c, plane = (size_t)a.n_domain * EMB;
+            if (pend) {
+                dm_step4(a.dms, d, c, p, m, v);
+                if (a.dms.optimizer != 2) *reinterpret_cast<f32x4*>(a.dm_live_p + row) = p;
+                if (a.dms.optimizer != 1) *reinterpret_cast<f32x4*>(a.dm_live_m + row) = m;
+                if (a.dms.optimizer == 0) *reinterpret_cast<f32x4*>(a.dm_live_v + row) = v;
+            } else {
+                p = *reinterpret_cast<const f32x4*>(a.dm_live_p + row);
+                m = *reinterpret_cast<const f32x4*>(a.dm_live_m + row);
+                v = *reinterpret_cast<const f32x4*>(a.dm_live_v + row);
+            }
+            *reinterpret_cast<f32x4*>(a.dm_snap_out + row) = p;
+            *reinterpret_cast<f32x4*>(a.dm_snap_out + plane + row) = m;
+            *reinterpret_cast<f32x4*>(a.dm_snap_out + 2 * plane + row) = v;
+        }
+    }
+}
+
+// k_wgrad_adam (fused_kernels.hip): weight gradients + optimiser step of the dense block in one launch
+struct FusedArgs {
+    const float* acts;         // [rows_pad][ACT_LD]
+    const float* dz;           // [rows_pad][DZ_LD]
+    const float* dlogit;       // [rows_pad]
+    const int32_t* domrow;     // [rows_pad]
+    const float* xa;           // A operand of dW0[0:256, :]: rows of [user | item] embeddings, leading dimension xa_ld
+    int xa_ld;
+    int rows_pad, rows;
+    float* p;                  // dense block of params / slots (m = accumulator for optimizer 2)
+    float* m;
+    float* v;
+    DenseLayout L;
+    int n_domain;
+    const float* w0dom_snap;   // pre-update W0[256:384, :] and domain table (tower_snapshots)
+    const float* dm_snap;
+    float* pdm;                // [8][n_domain][EMB] partial domain-table gradients
+    float* wT;                 // nullable: k_tower4's transposed W1 / W2 copies
+    int optimizer;             // 0 adam, 1 sgd, 2 accumulate
+    float alpha, omb1, omb2, eps, two_l2;
+    const float* loss_part;    // loss of the step (optional)
+    int n_loss_tiles;
+    const float* frozen_sumsq;
+    float l2_emb;
+    float* loss_out;
+#ifdef MAMDR_STAMPS
+    unsigned long long* stamps; // diagnostic build only: [workgroups][8] s_memtime stamps of wave 0
+#endif
+};
+void launch_wgrad_adam(const FusedArgs& a, hipStream_t s);
+// materialise a pending domain-table step (end of a mamdr_train_steps call): live p / m / v := dm_step4
+void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live_v, hipStream_t s);
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s);
 void launch_tower_eval(const TowerArgs& a, hipStream_t s);

@@ -323,7 +323,14 @@ __device__ __forceinline__ void bwd_layer(BwdW<K, N, LDW, PF, NW>& bw, const flo
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // row bookkeeping + embedding gather of one 16-row tile into LDS (and optionally global)
-__device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int r0, float* gx, int gx_ld) {
+// perm[position of row tid & 15], requested by every lane before anything else (see k_tower: loads retire in order)
+__device__ __forceinline__ int early_perm(const TowerArgs& a, int r0) {
+    if (!a.perm) return 0;
+    const int64_t pc = a.row_base + min(r0 + (int)(threadIdx.x & (TILE_ROWS - 1)), max(a.rows - 1, 0));
+    return a.perm[pc];
+}
+__device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int r0, float* gx, int gx_ld,
+                                            const bool dmw = false, const int* perm_src = nullptr) {
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
     float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;
     const int tid = threadIdx.x;
@@ -332,7 +339,7 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
         int64_t pos = a.row_base + r0 + tid;
         int64_t src = 0;
         if (valid) {
-            src = a.perm ? (int64_t)a.perm[pos] : pos;
+            src = a.perm ? (perm_src ? (int64_t)*perm_src : (int64_t)a.perm[pos]) : pos;
             if (src < 0) src = 0;
             if (src >= a.n_rows_split) src = a.n_rows_split - 1;
         }
@@ -348,12 +355,34 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
     // padding rows are harmless and are zeroed afterwards).
     float* xs = smem + XS_OFF;
     constexpr int PER = TILE_ROWS * (XDIM / 4) / TOWER_THREADS;   // 3
+    // domain-table step still pending (DmStep, mamdr_kernels.h): the domain rows as that step leaves them, requested
+    // beside the table rows (waves 4..7).  One domain per batch is the rule; if the tile's rows carry several, every
+    // lane of a domain segment works alone.  (LDS scratch: the h1 region, unused until layer 0's epilogue.)
+    const bool pend = dmw && a.dms.snap != nullptr;
+    const int d0 = rowi[2 * TILE_ROWS];
+    bool same = pend;
+    if (pend) {
+#pragma unroll
+        for (int r = 1; r < TILE_ROWS; ++r) same = same && rowi[2 * TILE_ROWS + r] == d0;
+    }
+    float* parts = smem + H1S_OFF;
+    DmTile dmt_;
+    const DmTile* dmt = &dmt_;
+    if (dmw) dm_tile_begin(a, (int)blockIdx.x, d0, dmt_);
     f32x4 v[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int e = tid + TOWER_THREADS * u;
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
         const int seg = c4 >> 5, off = (c4 & 31) * 4;
+        if (pend && seg == 2) {
+            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!same) {
+                f32x4 mn, vn;
+                dm_step4(a.dms, rowi[2 * TILE_ROWS + row], c4 & 31, v[u], mn, vn);
+            }
+            continue;
+        }
         const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
         v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * TILE_ROWS + row] * EMB + off);
     }
@@ -370,9 +399,28 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[u][k] = __fadd_rn(__fmul_rn(v[u][k], sc[k]), sh[k]);
         }
+        if (same && (c4 >> 5) == 2) continue;        // filled behind the barrier below
         if (!rowi[3 * TILE_ROWS + row]) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v[u];
         if (gx) *reinterpret_cast<f32x4*>(gx + (size_t)row * gx_ld + c4 * 4) = v[u];
+    }
+    if (dmw) {
+        dm_tile_stage(a, (int)blockIdx.x, *dmt, parts);
+        if (pend) __syncthreads();
+        if (tid >= 256 && tid < 256 + EMB) {          // waves 4, 5: one column of the batch's domain row each
+            if (same) {
+                const int c = tid - 256;
+                const float pn = dm_tile_reader(a, c, parts, *dmt);
+#pragma unroll
+                for (int rr = 0; rr < TILE_ROWS; ++rr) {
+                    const float val = rowi[3 * TILE_ROWS + rr] ? pn : 0.f;
+                    xs[rr * XS_LD + 2 * EMB + c] = val;
+                    if (gx) gx[(size_t)rr * gx_ld + 2 * EMB + c] = val;
+                }
+            }
+        } else if (tid >= 256 + EMB) {                // waves 6, 7: the row this workgroup writes back
+            dm_tile_writer(a, (int)blockIdx.x, (int)gridDim.x, tid - 256 - EMB, parts, *dmt);
+        }
     }
     __syncthreads();
 }
@@ -421,6 +469,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
+    const int n_tiles = (int)gridDim.x;
     const int r0 = tile * TILE_ROWS;
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
     // [0,16) label, [16,32) DeepFM fm + linear term, [32,40) per-wave loss, [48,64) DeepFM dlogit
@@ -438,11 +487,15 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     constexpr int PFB0V = DXN > 2 * EMB ? 2 : PFB0;
     BwdW<H1, DXN, H1, PFB0V, 8> bw0;
     STAMP(0);
+    const int perm_src = early_perm(a, r0);
+    __builtin_amdgcn_sched_barrier(0);
     fw0.prefetch(P + a.L.w0, P + a.L.b0);
+    if (TRAIN) tower_snapshots(a, TOWER_THREADS, n_tiles);
+    const bool dmw = TRAIN && a.dm_snap_out != nullptr;      // k_wgrad_adam path: domain-table duty (DmStep)
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
     const float gb_reg = P[a.L.gb];
 
-    gather_tile(a, smem, r0, acts_t, ACT_LD);
+    gather_tile(a, smem, r0, acts_t, ACT_LD, dmw, &perm_src);
     STAMP(1);
     // DeepFM: thread (i, part) owns columns 4 part .. +3 of row i's three fields.  u + i stays in
     // registers for the domain-table gradient (the x tile is overwritten by the backward chain).

@@ -155,8 +155,18 @@ __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (k)] = t_;               \
     } while (0)
+// wall-clock stamp (s_memrealtime: one 100 MHz counter for the whole device, comparable across XCDs and kernels)
+#define T4REAL(k)                                                                             \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (k)] = t_;               \
+    } while (0)
 #else
 #define T4STAMP(k) do { } while (0)
+#define T4REAL(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
+    const int n_tiles = (int)gridDim.x;
     const int r0 = tile * T4_ROWS;
     int* rowi = reinterpret_cast<int*>(smem + T4_ROWI);          // [0,4) uid [4,8) pid [8,12) dom [12,16) valid
     float* rowf = smem + T4_ROWI + 16;                           // [0,4) label, [4,8) loss of the row
@@ -184,8 +195,20 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
     T4W<H2, H1, T4_DEEP> v1;      // backward: dz2 . W1^T through W1T [128][256]
     T4W<H1, 2 * EMB> v0; // DX: dz1 . W0[0:256,:]^T through W0T [256][256]
+    T4REAL(10);
     T4STAMP(0);
+    // the row bookkeeping's first dependent load (perm) goes out before everything else: loads retire in order, so
+    // whatever is requested ahead of it (weights, domain-table partials) would be waited for together with it.
+    // Every lane loads (a clamped position): a divergent branch around a load drains all loads at its end.
+    int perm_src = 0;
+    if (a.perm) {       // uniform
+        const int64_t pc = a.row_base + min(r0 + (tid & (T4_ROWS - 1)), max(a.rows - 1, 0));
+        perm_src = a.perm[pc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     w0.prefetch(P + a.L.w0);
+    tower_snapshots(a, T4_THREADS, n_tiles);
+    const bool dmw = a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
     const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
     const float b0r = P[a.L.b0 + ecol];
     const float b1r = P[a.L.b1 + (tid & 127)];
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         int64_t pos = a.row_base + r0 + tid;
         int64_t src = 0;
         if (valid) {
-            src = a.perm ? (int64_t)a.perm[pos] : pos;
+            src = a.perm ? (int64_t)perm_src : pos;
             if (src < 0) src = 0;
             if (src >= a.n_rows_split) src = a.n_rows_split - 1;
         }
@@ -210,13 +233,50 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         rowf[tid] = a.label[src];
     }
     __syncthreads();
+    // domain-table step still pending (DmStep): the domain rows as that step leaves them.  The row of the expected
+    // domain was requested at kernel start; if the batch's rows carry another domain every lane works alone.
+    // (LDS scratch: `red`, unused until layer 0 ends.)
+    T4STAMP(12);
+    // (requested only now, beside the table rows: at kernel start these loads -- misses all the way to HBM, the
+    // partials were written by the previous kernel -- sat in the CU's miss queue ahead of the bookkeeping's
+    // second dependent load and delayed the whole gather)
+    const bool pend = a.dms.snap != nullptr;
+    const bool same = pend && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
+    DmTile dmt;
+    if (dmw) dm_tile_begin(a, tile, rowi[8], dmt);
     if (tid < T4_ROWS * (XDIM / 4)) {
         const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
         const int seg = c4 >> 5, off = (c4 & 31) * 4;
-        const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
-        f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * 4 + row] * EMB + off);
-        if (!rowi[12 + row]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = v;
+        if (seg == 2 && pend) {
+            if (!same) {
+                f32x4 pn, mn, vn;
+                dm_step4(a.dms, rowi[8 + row], c4 & 31, pn, mn, vn);
+                if (!rowi[12 + row]) pn = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = pn;
+            }
+        } else {
+            const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
+            f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * 4 + row] * EMB + off);
+            if (!rowi[12 + row]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = v;
+        }
+    }
+    if (dmw) {
+        dm_tile_stage(a, tile, dmt, red);
+        T4STAMP(13);
+        if (pend) __syncthreads();
+        T4STAMP(14);
+        if (tid >= 256 && tid < 256 + EMB) {          // waves 4, 5: one column of the batch's domain row each
+            if (same) {
+                const int c = tid - 256;
+                const float pn = dm_tile_reader(a, c, red, dmt);
+#pragma unroll
+                for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * XDIM + 2 * EMB + c] = rowi[12 + rr] ? pn : 0.f;
+            }
+        } else if (tid >= 256 + EMB) {                // waves 6, 7: the row this workgroup writes back
+            dm_tile_writer(a, tile, n_tiles, tid - 256 - EMB, red, dmt);
+        }
+        T4STAMP(15);
     }
     __syncthreads();
     if (FM) {
@@ -375,6 +435,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         if (DX) smem[T4_DZ1 + row * H1 + ecol] = d;
     }
     T4STAMP(9);
+    T4REAL(11);
     if (DX) {
         __syncthreads();           // dz1 complete, `red` free again
         t4_contract(v0, a.wT + W0T_OFF, smem + T4_DZ1, H1, red, []() {});

@@ -359,6 +359,89 @@ def test_mixed_domain_ids_in_one_batch(env, batch):
     eng.close()
 
 
+def _mlp_state(eng):
+    return (eng.weights.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy())
+
+
+def _fused_workout(env, batch, mixed):
+    """a call pattern that exercises the pending domain-table step of the k_wgrad_adam path: whole passes (the final
+    batch partial), single-step calls, a call starting in the middle of a pass, SGD and accumulate steps, a weight
+    assignment in between -- on one-domain batches, or on a split whose domain column mixes four ids."""
+    g, eng, model = make_problem(env, scale=0.3 if batch > 1024 else 0.1, batch=batch, dropout=0.5)
+    sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(10)]
+    order = sorted(range(10), key=lambda k: -sizes[k])[:3]
+    if mixed:
+        d = order[0]
+        cols = {k: v.copy() for k, v in g["data"]["train"][d].items()}
+        cols["domain"][:] = np.random.RandomState(3).choice([1, 4, 7, 9], size=sizes[d]).astype(cols["domain"].dtype)
+        eng.bind_domain_data(d, "train", cols["uid"], cols["pid"], cols["domain"], cols["label"])
+    acc = eng.new_vector()
+    eng.bind_accumulator(acc)
+    for rep_ in range(2):
+        for d in order:
+            perm = torch.from_numpy(orng.shuffle_perm(sizes[d], 10000, seed=41 + d + rep_)).to(eng.device)
+            nb = -(-sizes[d] // batch)
+            eng.train_steps(d, perm=perm, lr=1e-3)
+            eng.train_steps(d, perm=perm, first_step=nb - 1, n_steps=1, lr=1e-3)
+            if nb > 2:
+                eng.train_steps(d, perm=perm, first_step=1, n_steps=2, lr=1e-3, optimizer="sgd")
+            eng.train_steps(d, perm=perm, first_step=0, n_steps=min(2, -(-sizes[d] // batch)), lr=1e-3, optimizer="accumulate")
+        if rep_ == 0:
+            snap = eng.get_weights()
+            eng.set_weights((snap + eng.get_weights()) * 0.5 + 1e-3)
+    out = _mlp_state(eng) + (acc.cpu().numpy().copy(),)
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("batch,mixed", [(256, False), (1024, False), (1024, True), (4096, False)])
+def test_pending_domain_table_step_is_bitwise(env, batch, mixed):
+    """k_wgrad_adam path: the domain table's optimiser step is applied by the NEXT step's tower kernel (every
+    workgroup recomputes the row its batch uses; waves 6, 7 of workgroup d write row d back) and by k_dm_finish for
+    the last step of a call.  MAMDR_DM_EACH=1 materialises it after every step instead.  Same arithmetic at
+    every site (dm_pair / dm_elem_finish / dm_step4) -> weights, both Adam slots and a MAML accumulator agree
+    BITWISE, on one-domain batches (the fast path) and on mixed-domain batches (every lane on its own)."""
+    res = {}
+    for mode in ("pending", "each"):
+        os.environ["MAMDR_FUSED"] = "2"
+        os.environ["MAMDR_DM_EACH"] = "1" if mode == "each" else "0"
+        try:
+            res[mode] = _fused_workout(env, batch, mixed)
+        finally:
+            os.environ.pop("MAMDR_FUSED", None)
+            os.environ.pop("MAMDR_DM_EACH", None)
+    for a, b, name in zip(res["pending"], res["each"], ("weights", "adam_m", "adam_v", "accumulator")):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert same_bits(a, b), (name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+
+
+@pytest.mark.parametrize("batch", [256, 1024, 4096])
+def test_fused_wgrad_adam_matches_the_slab_path(env, batch):
+    """k_wgrad_adam (output-stationary tiles, optimiser step in the same launch, S workgroups for the domain-row
+    terms) against k_wgrad -> slabs -> k_update on the same steps: one SGD step at lr 1 (= the gradient of every
+    dense tensor) within fp32 summation-order noise, and the workout above within the multi-step Adam bar."""
+    grads, runs = {}, {}
+    for mode in ("fused", "slabs"):
+        os.environ["MAMDR_FUSED"] = "2" if mode == "fused" else "0"
+        try:
+            g, eng, model = make_problem(env, scale=0.3 if batch > 1024 else 0.1, batch=batch, dropout=0.5)
+            d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+            n = g["data"]["train"][d]["uid"].shape[0]
+            perm_t = torch.from_numpy(orng.shuffle_perm(n, 10000, seed=8)).to(eng.device)
+            w0 = eng.get_weights()
+            eng.train_steps(d, perm=perm_t, first_step=0, n_steps=1, lr=1.0, optimizer="sgd")
+            grads[mode] = (w0 - eng.get_weights()).cpu().numpy()
+            eng.close()
+            runs[mode] = _fused_workout(env, batch, False)
+        finally:
+            os.environ.pop("MAMDR_FUSED", None)
+    ga, gb = grads["fused"], grads["slabs"]
+    np.testing.assert_allclose(ga, gb, rtol=2e-4, atol=2e-6 * max(np.abs(gb).max(), 1e-3))
+    n_adam = 2 * 3 * 12
+    for a, b, name in zip(runs["fused"][:1], runs["slabs"][:1], ("weights",)):
+        assert_adam_close(a, b, n_adam, 1e-3, name, max_frac=1e-2)
+
+
 @pytest.mark.parametrize("tower", ["mlp", "deepfm"])
 def test_trainable_tables_heavy_duplicates(env, tower):
     """A batch of 4096 in which one user occupies 3000 positions and five items share all of them: the row

@@ -42,6 +42,12 @@ if os.environ.get('MAMDR_TOWER_TILE') != '16':
               "L2 contract", "barrier+L2 epi+out/loss/dz3", "bwd2 contract+epilogue", "bwd1 contract+epilogue"]
 names = ["w0 prefetch+gather", "L0 fwd", "L1 fwd (incl. barrier)", "L2 fwd", "barrier+out/loss", "bw2 prefetch+barrier+dz3",
          "bwd2 (dz2)", "bwd1 (dz1)", "bwd0 (dxe)"]
+full = allst[:tiles * 16].reshape(tiles, 16).astype(np.float64)
+if full[:, 12].min() > 0:
+    g0 = full[:, 0]
+    print("  gather detail (cycles after kernel start, median): bookkeeping barrier passed %.0f | pair sums staged %.0f | "
+          "pending barrier passed %.0f | domain rows finished %.0f | gather done %.0f" % tuple(
+              np.median(full[:, k] - g0) for k in (12, 13, 14, 15, 1)))
 dif = np.diff(st, axis=1)
 tot = st[:, 9] - st[:, 0]
 print("tiles %d; total cycles median %.0f (min %.0f max %.0f); s_memtime ticks = shader cycles" % (tiles, np.median(tot), tot.min(), tot.max()))
