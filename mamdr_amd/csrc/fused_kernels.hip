@@ -73,16 +73,21 @@ __device__ __forceinline__ void fz_opt(const FusedArgs& a, float g, float& p, fl
     }
 }
 
+#ifdef FZ_SC1_STORES          // diagnostic builds: write-through parameter stores
+#define FZ_ST(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define FZ_ST(ptr, val) (*(ptr) = (val))
+#endif
 __device__ __forceinline__ void fz_store(const FusedArgs& a, int e, float p, float m, float v) {
     if (a.optimizer == 2) {
-        a.m[e] = m;
+        FZ_ST(&a.m[e], m);
         return;
     }
     if (a.optimizer == 0) {
-        a.m[e] = m;
-        a.v[e] = v;
+        FZ_ST(&a.m[e], m);
+        FZ_ST(&a.v[e], v);
     }
-    a.p[e] = p;
+    FZ_ST(&a.p[e], p);
 }
 
 // this wave's share of the 4-row slots [0, n_slots): contiguous, in wave order
@@ -299,10 +304,10 @@ __device__ __forceinline__ void fz_tile_body(const FusedArgs& a, int t, float* l
     if (a.wT && a.optimizer != 2) {          // k_tower4's transposed copies of W1 / W2
         if (gemm == 2) {
             const int row = (e - a.L.w2) / H3, col = (e - a.L.w2) - row * H3;
-            a.wT[W2T_OFF + col * H2 + row] = p;
+            FZ_ST(&a.wT[W2T_OFF + col * H2 + row], p);
         } else if (gemm == 1) {
             const int row = (e - a.L.w1) / H2, col = (e - a.L.w1) - row * H2;
-            a.wT[W1T_OFF + col * H1 + row] = p;
+            FZ_ST(&a.wT[W1T_OFF + col * H1 + row], p);
         }
     }
     if (bias_tile && tid < 32) {
@@ -589,6 +594,39 @@ __global__ __launch_bounds__(256) void k_dm_finish(const DmStep q, float* live_p
 
 void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live_v, hipStream_t s) {
     MAMDR_LAUNCH(k_dm_finish, dim3((q.n_domain * (EMB / 4) + 255) / 256), dim3(256), 0, s, q, live_p, live_m, live_v);
+}
+
+// ---- k_pass_prep: the rows of a whole call resolved and gathered ONCE (frozen tables: the rows do not depend on
+// the weights).  One wave per position: every lane resolves the position (the same addresses: broadcast loads),
+// lane l copies float4 l of the 1-KB [user | item] row.  Replaces, per step, the tower kernel's chain of three
+// dependent loads (perm -> uid / pid -> table rows) and its copy of x into the activation workspace.
+__global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= a.n) {
+        // rows up to the next multiple of 16: k_wgrad_adam contracts whole 16-row tiles (against zero gradients for
+        // the padding rows, but 0 x garbage must stay 0)
+        if (i < (a.n + 15) / 16 * 16)
+            *reinterpret_cast<f32x4*>(a.xpre + (size_t)i * (2 * EMB) + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    int64_t src = a.perm ? (int64_t)a.perm[a.pos0 + i] : a.pos0 + i;
+    src = src < 0 ? 0 : (src >= a.n_rows_split ? a.n_rows_split - 1 : src);
+    int u = a.uid[src], it = a.pid[src];
+    u = u < 0 ? 0 : (u >= a.n_user ? a.n_user - 1 : u);
+    it = it < 0 ? 0 : (it >= a.n_item ? a.n_item - 1 : it);
+    const float* row = lane < 32 ? a.user_tab + (size_t)u * EMB + 4 * lane : a.item_tab + (size_t)it * EMB + 4 * (lane - 32);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row);
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.xpre + (size_t)i * (2 * EMB) + 4 * lane));
+    if (lane == 0) {
+        int d = a.dom[src];
+        a.pdom[i] = d < 0 ? 0 : (d >= a.n_domain ? a.n_domain - 1 : d);
+        a.plabel[i] = a.label[src];
+    }
+}
+void launch_pass_prep(const PassPrepArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(k_pass_prep, dim3((unsigned)(((a.n + 15) / 16 * 16 + 3) / 4)), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

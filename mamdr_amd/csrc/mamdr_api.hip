@@ -105,6 +105,12 @@ struct mamdr_ctx {
     float* pdm = nullptr;           // [32][n_domain][EMB] partial domain-table gradients
     // the domain table's step stays pending until the next tower kernel applies it (DmStep, mamdr_kernels.h):
     // two snapshots [3][n_domain][EMB] of (p, m, v) alternate between steps
+    // the rows of a call pre-gathered once (k_pass_prep): [cap][2 EMB] + domain / label per position, grown on demand
+    float* xpre = nullptr;
+    int32_t* pdom = nullptr;
+    float* plabel = nullptr;
+    int64_t pre_cap = 0;
+    bool use_pre = true;            // MAMDR_NO_PREGATHER=1: the towers gather through perm / uid / pid every step
     float* dmsnap[2] = {nullptr, nullptr};
     int dm_cur = 0;
     bool dm_finish_each = false;    // MAMDR_DM_EACH=1: materialise after every step (k_dm_finish per step; A/B measurements)
@@ -734,6 +740,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
             ALLOC(c->dmsnap[0], (size_t)3 * cfg->n_domain * EMB * sizeof(float));
             ALLOC(c->dmsnap[1], (size_t)3 * cfg->n_domain * EMB * sizeof(float));
             if (const char* de = getenv("MAMDR_DM_EACH")) c->dm_finish_each = atoi(de) != 0;
+            if (const char* pe = getenv("MAMDR_NO_PREGATHER")) c->use_pre = atoi(pe) == 0;
         }
     }
     if (const char* ev = getenv("MAMDR_NO_TAILFUSE")) c->tail_fuse = atoi(ev) == 0;
@@ -778,7 +785,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             (void)hipEventDestroy(p.b);
         }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->pdm, c->dmsnap[0], c->dmsnap[1], c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->pdm, c->dmsnap[0], c->dmsnap[1], c->xpre, c->pdom, c->plabel, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1007,6 +1014,41 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     // one path per call (the pending domain-table step lives across the steps of a call): k_wgrad_adam for batches up
     // to fused_max_batch rows (measured: 27.3 vs 29.5 us / step at 1,024 rows, a tie at 4,096)
     const bool fused = c->fused && (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch;
+    // ... and on that path the rows of the whole call are resolved and gathered once (frozen tables; 4-row tower)
+    const int64_t pre_pos0 = first_step * batch;
+    const int64_t pre_n = std::min<int64_t>((first_step + n_steps) * (int64_t)batch, pass_rows) - pre_pos0;
+    const bool pre = fused && c->use_pre && may_use4 && n_steps > 0 && pre_n > 0 &&
+                     (c->tower_tile == 4 || (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= 2048);
+    if (pre) {
+        if (pre_n > c->pre_cap) {
+            const int64_t cap = pre_n + pre_n / 4 + 1024;
+            if (c->xpre) { (void)hipFree(c->xpre); (void)hipFree(c->pdom); (void)hipFree(c->plabel); }
+            c->xpre = nullptr; c->pdom = nullptr; c->plabel = nullptr; c->pre_cap = 0;
+            HIP_TRY(hipMalloc((void**)&c->xpre, (size_t)cap * 2 * EMB * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&c->pdom, (size_t)cap * sizeof(int32_t)));
+            HIP_TRY(hipMalloc((void**)&c->plabel, (size_t)cap * sizeof(float)));
+            c->pre_cap = cap;
+        }
+        PassPrepArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.user_tab = c->user_tab;
+        pa.item_tab = c->item_tab;
+        pa.uid = d->uid;
+        pa.pid = d->pid;
+        pa.dom = d->dom;
+        pa.label = d->label;
+        pa.perm = d_perm;
+        pa.pos0 = pre_pos0;
+        pa.n = pre_n;
+        pa.n_rows_split = d->n;
+        pa.n_user = c->cfg.n_user;
+        pa.n_item = c->cfg.n_item;
+        pa.n_domain = c->cfg.n_domain;
+        pa.xpre = c->xpre;
+        pa.pdom = c->pdom;
+        pa.plabel = c->plabel;
+        launch_pass_prep(pa, c->stream);
+    }
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
@@ -1079,14 +1121,20 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
 #ifdef MAMDR_STAMPS
         ta.stamps = c->stamps ? c->stamps + (c->global_step & 1) * 16384 : nullptr;      // two steps side by side
 #endif
-        const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
         ta.wT = c->wT;
         float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
+        const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
+        const bool use4_now = use4;
         if (fused) {
             ta.w0dom_snap = c->w0dom_copy;
             c->dm_cur ^= 1;
             ta.dms = dm_pending;                       // the previous step of this call (snap == null: none)
             ta.dm_hint = domain;
+            if (pre && use4_now) {
+                ta.xpre = c->xpre + (size_t)(row_base - pre_pos0) * 2 * EMB;
+                ta.pdom = c->pdom + (row_base - pre_pos0);
+                ta.plabel = c->plabel + (row_base - pre_pos0);
+            }
             ta.dm_live_p = c->params + c->table_floats + c->L.dm;
             ta.dm_live_m = dense_m + c->L.dm;
             ta.dm_live_v = c->adam_v + c->table_floats + c->L.dm;
@@ -1104,8 +1152,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             fa.dz = c->dz;
             fa.dlogit = c->dlogit;
             fa.domrow = c->domrow;
-            fa.xa = c->acts;
-            fa.xa_ld = ACT_LD;
+            fa.xa = ta.xpre ? ta.xpre : c->acts;
+            fa.xa_ld = ta.xpre ? 2 * EMB : ACT_LD;
             fa.rows_pad = rows_pad;
             fa.rows = rows;
             fa.p = c->params + c->table_floats;

@@ -146,6 +146,11 @@ struct TowerArgs {
     float* w0dom_snap;
     // domain table (see DmStep): the pending step to apply on the fly, the live rows workgroup d < n_domain writes
     // back, and the snapshot [3][n_domain][EMB] of (p, m, v) as this step's forward pass saw them
+    // pre-gathered pass (k_pass_prep; frozen tables on the k_wgrad_adam path): row i of this launch reads its
+    // [user | item] embedding rows, domain and label at xpre[i], pdom[i], plabel[i] -- no chain of dependent loads
+    const float* xpre;         // [rows][2 EMB], null = gather through perm / uid / pid
+    const int32_t* pdom;
+    const float* plabel;
     DmStep dms;
     int dm_hint;               // the domain the caller expects every row of the batch to carry (the pass's domain)
     float* dm_live_p;
@@ -275,24 +280,35 @@ __device__ __forceinline__ void dm_elem_finish(const DmStep& q, int c, const flo
 //   waves 4, 5 (reader)     lane L' < 128: (p, m, v) of column L' of the hinted row
 //   waves 6, 7 (writer)     lane L' - 128: the same for the row this workgroup writes back
 struct DmTile {
-    f32x4 pr[2], pw[2];
+    f32x4 pr[2][2], pw[2][2];  // the two partials of each pair, as loaded: added only when staged (an add right behind
+                               // the loads would make the wave wait out their round trip before its next barrier)
     float p, m, v;
 };
+__device__ __forceinline__ void dm_pair_load(const DmStep& q, int d, int c4, int j, f32x4 (&t)[2]) {
+    const size_t row = (size_t)d * EMB + 4 * c4, plane = (size_t)q.n_domain * EMB;
+    t[0] = *reinterpret_cast<const f32x4*>(q.pdm + (size_t)(2 * j) * plane + row);
+    t[1] = *reinterpret_cast<const f32x4*>(q.pdm + (size_t)(2 * j + 1) * plane + row);
+}
+__device__ __forceinline__ f32x4 dm_pair_add(const f32x4 (&t)[2]) {
+#pragma clang fp contract(off)
+    return t[0] + t[1];
+}
 __device__ __forceinline__ void dm_tile_begin(const TowerArgs& a, int tile, int d_read, DmTile& t) {
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // scalar branches below: no divergence
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    t.pr[0] = t.pr[1] = t.pw[0] = t.pw[1] = zero;
+    t.pr[0][0] = t.pr[0][1] = t.pr[1][0] = t.pr[1][1] = zero;
+    t.pw[0][0] = t.pw[0][1] = t.pw[1][0] = t.pw[1][1] = zero;
     t.p = t.m = t.v = 0.f;
     if (wv < 4) return;
     const bool pend = a.dms.snap != nullptr, wr = tile < a.n_domain;      // both uniform
     const int dw = min(tile, a.n_domain - 1);
     const int lp = (int)threadIdx.x - 256, grp = lp >> 5, c4 = lp & 31;
     if (pend) {
-        t.pr[0] = dm_pair(a.dms, d_read, c4, grp);
-        t.pr[1] = dm_pair(a.dms, d_read, c4, grp + 8);
+        dm_pair_load(a.dms, d_read, c4, grp, t.pr[0]);
+        dm_pair_load(a.dms, d_read, c4, grp + 8, t.pr[1]);
         if (wr) {
-            t.pw[0] = dm_pair(a.dms, dw, c4, grp);
-            t.pw[1] = dm_pair(a.dms, dw, c4, grp + 8);
+            dm_pair_load(a.dms, dw, c4, grp, t.pw[0]);
+            dm_pair_load(a.dms, dw, c4, grp + 8, t.pw[1]);
         }
     }
     const size_t plane = (size_t)a.n_domain * EMB;
@@ -321,11 +337,11 @@ __device__ __forceinline__ void dm_tile_begin(const TowerArgs& a, int tile, int 
 __device__ __forceinline__ void dm_tile_stage(const TowerArgs& a, int tile, const DmTile& t, float* parts) {
     if (!a.dms.snap || threadIdx.x < 256) return;
     const int lp = (int)threadIdx.x - 256;
-    *reinterpret_cast<f32x4*>(parts + lp * 4) = t.pr[0];
-    *reinterpret_cast<f32x4*>(parts + 1024 + lp * 4) = t.pr[1];
+    *reinterpret_cast<f32x4*>(parts + lp * 4) = dm_pair_add(t.pr[0]);
+    *reinterpret_cast<f32x4*>(parts + 1024 + lp * 4) = dm_pair_add(t.pr[1]);
     if (tile < a.n_domain) {
-        *reinterpret_cast<f32x4*>(parts + 2048 + lp * 4) = t.pw[0];
-        *reinterpret_cast<f32x4*>(parts + 3072 + lp * 4) = t.pw[1];
+        *reinterpret_cast<f32x4*>(parts + 2048 + lp * 4) = dm_pair_add(t.pw[0]);
+        *reinterpret_cast<f32x4*>(parts + 3072 + lp * 4) = dm_pair_add(t.pw[1]);
     }
 }
 // behind the barrier that follows dm_tile_stage: the hinted row's element c after the pending step
@@ -406,6 +422,23 @@ struct FusedArgs {
 #endif
 };
 void launch_wgrad_adam(const FusedArgs& a, hipStream_t s);
+// positions [pos0, pos0 + n) of a pass resolved once per mamdr_train_steps call: src = perm[pos] (or pos), clamped;
+// xpre[i] = [user row | item row] of src, pdom[i] / plabel[i] its domain (clamped) and label
+struct PassPrepArgs {
+    const float* user_tab;
+    const float* item_tab;
+    const int32_t* uid;
+    const int32_t* pid;
+    const int32_t* dom;
+    const float* label;
+    const int32_t* perm;       // nullable
+    int64_t pos0, n, n_rows_split;
+    int n_user, n_item, n_domain;
+    float* xpre;
+    int32_t* pdom;
+    float* plabel;
+};
+void launch_pass_prep(const PassPrepArgs& a, hipStream_t s);
 // materialise a pending domain-table step (end of a mamdr_train_steps call): live p / m / v := dm_step4
 void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live_v, hipStream_t s);
 

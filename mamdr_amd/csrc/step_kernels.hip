@@ -48,6 +48,24 @@ template <> struct VecT<4> { typedef f32x4 type; };
 template <> struct VecT<2> { typedef f32x2 type; };
 template <> struct VecT<1> { typedef float type; };
 
+// Workspace stores (activations, gradients, gradient slabs): write-through (agent-scope relaxed atomic store =
+// global_store ... sc1) under -DMAMDR_WS_SC1 -- see tower4_kernels.hip: dirty lines left in the L2s are written back
+// BETWEEN the kernels.  4-byte pieces only (wider vectors are stored piecewise).
+#ifdef MAMDR_WS_PLAIN
+#define WS_STORE1(ptr, val) (*(ptr) = (val))
+#else
+#define WS_STORE1(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+template <typename V>
+__device__ __forceinline__ void ws_store(float* p, const V& v) {
+    if constexpr (sizeof(V) == 4) {
+        WS_STORE1(p, v);
+    } else {
+#pragma unroll
+        for (int t = 0; t < (int)(sizeof(V) / 4); ++t) WS_STORE1(p + t, v[t]);
+    }
+}
+
 constexpr int TOWER_THREADS = 512;   // 8 waves = 2 per SIMD: one wave's epilogue / waits overlap the other's MFMAs
 
 template <int TPW>
@@ -199,7 +217,7 @@ __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF, NW>& fw, const float* _
         }
         *reinterpret_cast<V*>(Os + row * LDO + ncol) = v;
 #ifndef MAMDR_ABLATE_STORES
-        if (TRAIN) *reinterpret_cast<V*>(gout + (size_t)row * ACT_LD + ncol) = v;
+        if (TRAIN) ws_store<V>(gout + (size_t)row * ACT_LD + ncol, v);
 #endif
     }
 }
@@ -604,7 +622,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) d[c] = (h[c] > 0.f) ? (dl * wo[c]) * scale : 0.f;
             *reinterpret_cast<f32x2*>(smem + DZ3S_OFF + i * H3_LD + n2) = d;
-            *reinterpret_cast<f32x2*>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n2) = d;
+            ws_store<f32x2>(dz_t + (size_t)i * DZ_LD + H1 + H2 + n2, d);
             if (FM) {
                 // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
                 *reinterpret_cast<f32x4*>(a.fmq + (size_t)(r0 + i) * EMB + 4 * part) = dl * fm_ui;
@@ -640,7 +658,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
             const float d = (hs[row * H2_LD + col] > 0.f) ? v * scale : 0.f;
             dzs[row * H2_LD + col] = d;
 #ifndef MAMDR_ABLATE_STORES
-            dz_t[(size_t)row * DZ_LD + H1 + col] = d;
+            WS_STORE1(&dz_t[(size_t)row * DZ_LD + H1 + col], d);
 #endif
         });
     }
@@ -656,7 +674,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
             const float d = (hs[row * H1_LD + col] > 0.f) ? v * scale : 0.f;
             if (DX) dzs[row * H1_LD + col] = d;
 #ifndef MAMDR_ABLATE_STORES
-            dz_t[(size_t)row * DZ_LD + col] = d;
+            WS_STORE1(&dz_t[(size_t)row * DZ_LD + col], d);
 #endif
         });
     }
@@ -942,7 +960,7 @@ __device__ __forceinline__ void wgrad_big(const WgradArgs& g, const TileDesc& t,
                  (size_t)(wm * 32) * t.dst_ld + wn * 32;
     const int rb4 = 4 * (lane >> 5);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2) + rb4) * t.dst_ld + c] = acc[r];
+    for (int r = 0; r < 16; ++r) WS_STORE1(&dst[(size_t)((r & 3) + 8 * (r >> 2) + rb4) * t.dst_ld + c], acc[r]);
     WSTAMP(3);
     WSTAMP(4);
 }
@@ -1026,7 +1044,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& g, const int bid, fl
         const int row = e >> 5, col = e & 31;
         if (row < t.m_valid && col < t.n_valid) {
             const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
-            slab[t.dst_off + row * t.dst_ld + col] = v;
+            WS_STORE1(&slab[t.dst_off + row * t.dst_ld + col], v);
         }
     }
     WSTAMP(4);

@@ -43,6 +43,20 @@ constexpr int T4_LDS_FLOATS = T4_ROWI + 64;
 
 size_t tower4_lds_bytes() { return T4_LDS_FLOATS * sizeof(float); }
 
+// Workspace stores of the activations / gradients: WRITE-THROUGH (agent-scope relaxed atomic store = global_store
+// ... sc1).  With plain stores the 3.7 MB a step writes sit dirty in the eight L2s until the kernel ends and are
+// written back between this kernel and k_wgrad_adam: 3.6 us from the tower's last workgroup to the next kernel's
+// first one, 1.5 us with no stores at all, 2.2 us with write-through stores (tools/stamp_wall.py; -DT4_NT_STORES,
+// nontemporal: 2.6 us).  The next kernel reads these rows from other XCDs anyway.
+#ifdef T4_ABLATE_STORES        // diagnostic builds
+#define T4_WS_STORE(ptr, val) do { } while (0)
+#elif defined(T4_NT_STORES)
+#define T4_WS_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#elif defined(T4_PLAIN_STORES)
+#define T4_WS_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define T4_WS_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 #define MAMDR_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, 0, 0)
 
 template <int V> struct Vec4T;
@@ -137,6 +151,66 @@ __device__ __forceinline__ void t4_contract(T4W<K, N, DEPTH>& tw, const float* _
     }
 }
 
+// ---- layer 0 (384 -> 256) with the reduction index split in TWO segments per wave: the [user | item] part first
+// (k in [32 w, 32 w + 32)), then the domain part (k in [256 + 16 w, 256 + 16 w + 16)).  `midseg` runs between them:
+// with a domain-table step still pending (DmStep) the domain columns of x only become known there -- the round trip
+// to the step's partials and the step itself overlap the first segment's weight stream instead of standing in front
+// of the whole layer.  Same 8-deep register ring; the second segment's first rows are requested behind the last
+// chunk of the first, so they are in flight across `midseg`.
+struct T4L0 {
+    float b[T4_PF][4];
+    static __device__ __forceinline__ const float* wptr1(const float* __restrict__ W) {
+        return W + (size_t)((threadIdx.x >> 6) * 32) * H1 + 4 * (threadIdx.x & 63);
+    }
+    static __device__ __forceinline__ const float* wptr2(const float* __restrict__ W) {
+        return W + (size_t)(2 * EMB + (threadIdx.x >> 6) * 16) * H1 + 4 * (threadIdx.x & 63);
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
+        const float* wp = wptr1(W);
+#pragma unroll
+        for (int u = 0; u < T4_PF; ++u) t4_load<4>(b[u], wp + (size_t)u * H1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+template <typename MidSeg, typename Mid>
+__device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict__ W, const float* xs, float* red,
+                                               MidSeg midseg, Mid mid) {
+    static_assert(T4_PF == 8, "two segments of 32 and 16 rows, 8-deep ring");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* wp1 = T4L0::wptr1(W);
+    const float* wp2 = T4L0::wptr2(W);
+    const float* ap1 = xs + (lane & 3) * XDIM + 32 * w;
+    const float* ap2 = xs + (lane & 3) * XDIM + 2 * EMB + 16 * w;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto chunk = [&](const float* ap, const float* next, bool reload) {
+#pragma unroll
+        for (int q = 0; q < T4_PF; q += 4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = MAMDR_MFMA4(a4[u], tw.b[q + u][t], acc[t]);
+                if (reload) t4_load<4>(tw.b[q + u], next + (size_t)(q + u) * H1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll 1
+    for (int k0 = 0; k0 < 24; k0 += 8) chunk(ap1 + k0, wp1 + (size_t)(k0 + 8) * H1, true);
+    chunk(ap1 + 24, wp2, true);                    // ... and the domain segment's first 8 rows
+    midseg();
+    chunk(ap2, wp2 + (size_t)8 * H1, true);
+    chunk(ap2 + 8, wp2, false);
+    mid();
+    // D register r of lane l = row r, columns 4 l .. 4 l + 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(red + (w * T4_ROWS + r) * H1 + 4 * lane) = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+}
+
 // sum of the 8 wave partials of output (row, col), wave order
 template <int N>
 __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
@@ -155,6 +229,15 @@ __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (k)] = t_;               \
     } while (0)
+// the same stamp by the first lane of wave 4 (rows 256.. of the stamp buffer)
+#define T4STAMP_W4(k)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (a.stamps && threadIdx.x == 256) a.stamps[(blockIdx.x + 256) * 16 + (k)] = t_;     \
+    } while (0)
 // wall-clock stamp (s_memrealtime: one 100 MHz counter for the whole device, comparable across XCDs and kernels)
 #define T4REAL(k)                                                                             \
     do {                                                                                      \
@@ -166,6 +249,7 @@ __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
     } while (0)
 #else
 #define T4STAMP(k) do { } while (0)
+#define T4STAMP_W4(k) do { } while (0)
 #define T4REAL(k) do { } while (0)
 #endif
 
@@ -189,7 +273,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     float* dz_t = a.dz + (size_t)r0 * DZ_LD;
 
     // weights and small parameters first: they do not depend on the gather
-    T4W<XDIM, H1> w0;
+    T4L0 w0;
     T4W<H1, H2, T4_DEEP> w1;
     T4W<H2, H3, T4_DEEP> w2;
     T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
@@ -201,7 +285,19 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // whatever is requested ahead of it (weights, domain-table partials) would be waited for together with it.
     // Every lane loads (a clamped position): a divergent branch around a load drains all loads at its end.
     int perm_src = 0;
-    if (a.perm) {       // uniform
+    // pre-gathered pass (k_pass_prep): the tile's four [user | item] rows, domains and labels sit at known addresses;
+    // every lane loads (clamped rows; lanes 256.. repeat rows 0..3), no dependent chain
+    const bool pre = a.xpre != nullptr;
+    f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int pre_dom = 0;
+    float pre_lab = 0.f;
+    if (pre) {
+        const int rr = min(r0 + ((tid >> 6) & 3), max(a.rows - 1, 0));
+        xv = *reinterpret_cast<const f32x4*>(a.xpre + (size_t)rr * (2 * EMB) + 4 * (tid & 63));
+        const int rb = min(r0 + (tid & 3), max(a.rows - 1, 0));
+        pre_dom = a.pdom[rb];
+        pre_lab = a.plabel[rb];
+    } else if (a.perm) {       // uniform
         const int64_t pc = a.row_base + min(r0 + (tid & (T4_ROWS - 1)), max(a.rows - 1, 0));
         perm_src = a.perm[pc];
     }
@@ -209,6 +305,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     w0.prefetch(P + a.L.w0);
     tower_snapshots(a, T4_THREADS, n_tiles);
     const bool dmw = a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
+    // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
+    // the caller's expected domain, its loads -- misses to HBM -- delayed the x rows by 1.5 K cycles; measured)
+    DmTile dmt;
     const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
     const float b0r = P[a.L.b0 + ecol];
     const float b1r = P[a.L.b1 + (tid & 127)];
@@ -217,7 +316,21 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const float gbr = P[a.L.gb];
 
     // ---- row bookkeeping + embedding gather (4 rows x 96 float4)
-    if (tid < T4_ROWS) {
+    if (pre) {
+        if (tid < T4_ROWS) {
+            const bool valid = (r0 + tid) < a.rows;
+            rowi[tid] = 0;
+            rowi[4 + tid] = 0;
+            rowi[8 + tid] = pre_dom;
+            rowi[12 + tid] = valid ? 1 : 0;
+            rowf[tid] = pre_lab;
+        }
+        if (tid < 256) {
+            const int row = tid >> 6;
+            if (r0 + row >= a.rows) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + 4 * (tid & 63)) = xv;
+        }
+    } else if (tid < T4_ROWS) {
         const bool valid = (r0 + tid) < a.rows;
         int64_t pos = a.row_base + r0 + tid;
         int64_t src = 0;
@@ -237,14 +350,17 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // domain was requested at kernel start; if the batch's rows carry another domain every lane works alone.
     // (LDS scratch: `red`, unused until layer 0 ends.)
     T4STAMP(12);
+    T4STAMP_W4(0);
     // (requested only now, beside the table rows: at kernel start these loads -- misses all the way to HBM, the
     // partials were written by the previous kernel -- sat in the CU's miss queue ahead of the bookkeeping's
     // second dependent load and delayed the whole gather)
     const bool pend = a.dms.snap != nullptr;
     const bool same = pend && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
-    DmTile dmt;
     if (dmw) dm_tile_begin(a, tile, rowi[8], dmt);
-    if (tid < T4_ROWS * (XDIM / 4)) {
+    T4STAMP_W4(1);
+    // (a scalar branch around the whole block: the loads inside sit in divergent branches, at whose end the compiler
+    // drains EVERY outstanding load -- including the partials just requested, a full round trip to HBM)
+    if (!(pre && same) && tid < T4_ROWS * (XDIM / 4)) {
         const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
         const int seg = c4 >> 5, off = (c4 & 31) * 4;
         if (seg == 2 && pend) {
@@ -254,30 +370,22 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                 if (!rowi[12 + row]) pn = (f32x4){0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = pn;
             }
-        } else {
+        } else if (!(pre && seg < 2)) {         // (pre-gathered pass: the user / item part is in LDS already)
             const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
             f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * 4 + row] * EMB + off);
             if (!rowi[12 + row]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = v;
         }
     }
-    if (dmw) {
-        dm_tile_stage(a, tile, dmt, red);
-        T4STAMP(13);
-        if (pend) __syncthreads();
-        T4STAMP(14);
-        if (tid >= 256 && tid < 256 + EMB) {          // waves 4, 5: one column of the batch's domain row each
-            if (same) {
-                const int c = tid - 256;
-                const float pn = dm_tile_reader(a, c, red, dmt);
-#pragma unroll
-                for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * XDIM + 2 * EMB + c] = rowi[12 + rr] ? pn : 0.f;
-            }
-        } else if (tid >= 256 + EMB) {                // waves 6, 7: the row this workgroup writes back
-            dm_tile_writer(a, tile, n_tiles, tid - 256 - EMB, red, dmt);
-        }
-        T4STAMP(15);
+    // (pending + one-domain tile: the domain columns of x are filled between layer 0's two segments, see midseg)
+    float rdp = 0.f, rdm = 0.f, rdv = 0.f;           // lanes 0..15 of wave w: (p, m, v) of column 16 w + lane before the step
+    if (same) {
+        const size_t e = (size_t)rowi[8] * EMB + 16 * w + (lane & 15), plane = (size_t)a.n_domain * EMB;
+        rdp = a.dms.snap[e];
+        rdm = a.dms.snap[plane + e];
+        rdv = a.dms.snap[2 * plane + e];
     }
+    T4STAMP_W4(2);
     __syncthreads();
     if (FM) {
         // thread (row, k): FM second-order term sum_k (u i + (u + i) d), reduced over the row's two waves
@@ -301,9 +409,31 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const bool drop = a.use_dropout != 0;
 
     // ---- layer 0: 384 -> 256
-    t4_contract(w0, P + a.L.w0, smem + T4_XS, XDIM, red, [&]() { w1.prefetch(P + a.L.w1); });
+    t4_contract_l0(w0, P + a.L.w0, smem + T4_XS, red,
+                   [&]() {
+                       if (!dmw) return;
+                       // the pair sums of the pending step (requested behind the bookkeeping) -> LDS, then every wave
+                       // finishes the 16 domain columns ITS second segment contracts (lanes 0..15; written to all
+                       // four rows of the tile, read back by the same wave only) and waves 6, 7 of workgroup
+                       // d < n_domain write row d back.  (`red` is free until the end of this layer.)
+                       dm_tile_stage(a, tile, dmt, red);
+                       T4STAMP(13);
+                       if (pend) __syncthreads();
+                       T4STAMP(14);
+                       if (same && lane < 16) {
+                           float p = rdp, m = rdm, v = rdv;
+                           const int c = 16 * w + lane;
+                           dm_elem_finish(a.dms, c, red, p, m, v);
+#pragma unroll
+                           for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * XDIM + 2 * EMB + c] = rowi[12 + rr] ? p : 0.f;
+                       }
+                       if (tid >= 256 + EMB) dm_tile_writer(a, tile, n_tiles, tid - 256 - EMB, red, dmt);
+                       T4STAMP(15);
+                   },
+                   [&]() { w1.prefetch(P + a.L.w1); });
     T4STAMP(2);
-    if (tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream
+    if (!pre && tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream (k_wgrad_adam reads
+                                                  // a pre-gathered pass in place)
         const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
         *reinterpret_cast<f32x4*>(acts_t + (size_t)row * ACT_LD + c4 * 4) =
             *reinterpret_cast<const f32x4*>(smem + T4_XS + row * XDIM + c4 * 4);
@@ -320,7 +450,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                 h = (u >= a.drop_thresh) ? h * scale : 0.f;
             }
             smem[T4_H1 + row * H1 + ecol] = h;
-            acts_t[(size_t)row * ACT_LD + XDIM + ecol] = h;
+            T4_WS_STORE(&acts_t[(size_t)row * ACT_LD + XDIM + ecol], h);
         }
     }
     __syncthreads();
@@ -339,7 +469,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
             h = (u >= a.drop_thresh) ? h * scale : 0.f;
         }
         smem[T4_H2 + row * H2 + col] = h;
-        acts_t[(size_t)row * ACT_LD + XDIM + H1 + col] = h;
+        T4_WS_STORE(&acts_t[(size_t)row * ACT_LD + XDIM + H1 + col], h);
     }
     __syncthreads();
 
@@ -360,7 +490,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
             const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H3 + (uint32_t)col);
             h = (u >= a.drop_thresh) ? h * scale : 0.f;
         }
-        acts_t[(size_t)row * ACT_LD + XDIM + H1 + H2 + col] = h;
+        T4_WS_STORE(&acts_t[(size_t)row * ACT_LD + XDIM + H1 + H2 + col], h);
         float s = h * wor;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         float logit = s + gbr;
@@ -400,7 +530,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         }
         const float d = (h > 0.f) ? (dl * wor) * scale : 0.f;
         smem[T4_DZ3 + row * H3 + col] = d;
-        dz_t[(size_t)row * DZ_LD + H1 + H2 + col] = d;
+        T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + H1 + H2 + col], d);
     }
     __syncthreads();
     if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
@@ -419,7 +549,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         const float v = t4_sum<H2>(red, row, col);
         const float d = (smem[T4_H2 + row * H2 + col] > 0.f) ? v * scale : 0.f;
         smem[T4_DZ2 + row * H2 + col] = d;
-        dz_t[(size_t)row * DZ_LD + H1 + col] = d;
+        T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + H1 + col], d);
     }
     __syncthreads();
     T4STAMP(8);
@@ -431,7 +561,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         const int row = erow2 + 2 * rr;
         const float v = t4_sum<H1>(red, row, ecol);
         const float d = (smem[T4_H1 + row * H1 + ecol] > 0.f) ? v * scale : 0.f;
-        dz_t[(size_t)row * DZ_LD + ecol] = d;
+        T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + ecol], d);
         if (DX) smem[T4_DZ1 + row * H1 + ecol] = d;
     }
     T4STAMP(9);

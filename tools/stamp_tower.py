@@ -48,6 +48,10 @@ if full[:, 12].min() > 0:
     print("  gather detail (cycles after kernel start, median): bookkeeping barrier passed %.0f | pair sums staged %.0f | "
           "pending barrier passed %.0f | domain rows finished %.0f | gather done %.0f" % tuple(
               np.median(full[:, k] - g0) for k in (12, 13, 14, 15, 1)))
+w4 = allst[256 * 16:(256 + tiles) * 16].reshape(tiles, 16).astype(np.float64)
+if w4[:, 0].min() > 0:
+    print("  wave 4 (cycles after kernel start, median): after the bookkeeping barrier %.0f | partials requested %.0f | "
+          "at the gather-end barrier %.0f" % tuple(np.median(w4[:, k] - full[:, 0]) for k in (0, 1, 2)))
 dif = np.diff(st, axis=1)
 tot = st[:, 9] - st[:, 0]
 print("tiles %d; total cycles median %.0f (min %.0f max %.0f); s_memtime ticks = shader cycles" % (tiles, np.median(tot), tot.min(), tot.max()))
