@@ -384,10 +384,11 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         epoch()                       # fills the library's event pool: the measured epoch below creates no events
         eng.profile_reset()
         prof_trace, _ = epoch()
+        names = dict({k: L.KERNEL_NAMES[k] for k in (L.KERNEL_EMB_SWEEP,)}, **eng.step_kernel_names(batch))
         for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE, L.KERNEL_EMB_SWEEP):
             ms, cnt = eng.profile_read(k)
             if cnt:
-                kernels[L.KERNEL_NAMES[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
+                kernels[names[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
         dense_adam = os.environ.get("MAMDR_DENSE_ADAM", "0") not in ("", "0")
         if trainable and not dense_adam:
             # default: lazy replay of TF1's dense table Adam (csrc/emb_kernels.hip) -- per step only the rows of

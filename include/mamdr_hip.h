@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 5
+#define MAMDR_ABI_VERSION 6
 
 enum {
     MAMDR_OK = 0,
@@ -266,6 +266,12 @@ int mamdr_shuffle_perms(int32_t n_passes, const int64_t* h_n, int64_t buffer_siz
  *     mamdr_profile_read synchronises the stream, returns the summed milliseconds
  *     and launch count since the last reset. */
 int mamdr_profile_enable(mamdr_ctx* ctx, int32_t enable);
+/* which kernels a training step of `batch` rows launches (for reports; no reference counterpart):
+ *   0  tower -> k_wgrad (split-K slabs) -> k_update
+ *   1  [k_pass_prep once per call] tower -> k_wgrad_adam (weight gradients + optimiser step in one launch;
+ *      MAMDR_KERNEL_WGRAD times it), the domain table's step applied by the next tower, k_dm_finish once per call
+ *      (MAMDR_KERNEL_UPDATE times it) */
+int mamdr_step_path(const mamdr_ctx* ctx, int32_t batch);
 int mamdr_profile_reset(mamdr_ctx* ctx);
 int mamdr_profile_read(mamdr_ctx* ctx, int32_t kernel, double* total_ms, int64_t* launches);
 

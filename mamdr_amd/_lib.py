@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -82,6 +82,7 @@ SIGNATURES = {
     "mamdr_pcgrad_project": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "mamdr_shuffle_perm": (C.c_int, [_I64, _I64, _U64, _VP]),
     "mamdr_shuffle_perms": (C.c_int, [_I32, _VP, _I64, _VP, _VP]),
+    "mamdr_step_path": (C.c_int, [_VP, _I32]),
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
     "mamdr_profile_reset": (C.c_int, [_VP]),
     "mamdr_profile_read": (C.c_int, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64)]),

@@ -1582,6 +1582,11 @@ int mamdr_debug_set_stamps(mamdr_ctx* c, unsigned long long* d_stamps) {
 #endif
 
 // ---- profiling
+int mamdr_step_path(const mamdr_ctx* c, int32_t batch) {
+    if (!c || !c->fused) return 0;
+    return (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch ? 1 : 0;
+}
+
 int mamdr_profile_enable(mamdr_ctx* c, int32_t enable) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     c->profile = enable != 0;

@@ -550,6 +550,99 @@ def test_deepfm_gradients_adam_eval(env, emb_trainable, tower):
     eng.close()
 
 
+# ------------------------------------------------------------------ value-level parity at the largest BASELINE batches
+def _assert_grads(eng, got, want, floors=None):
+    for name, (off, cnt) in eng.segments.items():
+        w = want[off:off + cnt]
+        floor = (floors or {}).get(name, 1e-8)
+        np.testing.assert_allclose(got[off:off + cnt], w, rtol=2e-4, atol=max(2e-6 * max(np.abs(w).max(), 1e-3), floor),
+                                   err_msg=name)
+
+
+@pytest.mark.parametrize("tower,emb_trainable,batch", [("mlp", False, 8192), ("mlp", True, 8192),
+                                                      ("deepfm", False, 4096), ("deepfm", False, 8192)])
+def test_large_batch_gradients_match_oracle(env, tower, emb_trainable, batch):
+    """BASELINE config 5's batch size (8192) and config 3's tower with frozen tables above 2,048 rows: one SGD step
+    at lr 1 = every gradient against the oracle, a full batch and the pass's final partial batch.  These sizes take
+    code no small test reaches: 16-row tower tiles for all rows (k_tower<true, 0 | 256, FM>), k_wgrad with 512-row
+    groups and 16 slabs, 512 loss partials."""
+    g, eng, model = make_problem(env, scale=1.0, batch=batch, dropout=0.5, emb_trainable=emb_trainable, tower=tower)
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    assert n > batch
+    perm = orng.shuffle_perm(n, 10000, seed=12)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_step = -(-n // batch)
+    floors = {"user_emb": 6e-8, "item_emb": 6e-8}
+    for step in (0, n_step - 1):
+        idx = perm[step * batch:(step + 1) * batch]
+        masks = otower.train_masks(model.seed, model.step, len(idx), model.hidden, 0.5)
+        loss, grads, _ = otower.loss_and_grads(model.params, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                               cols["label"][idx], masks, 0.5, emb_trainable, None, model.deepfm)
+        want = eng.pack({**{k: np.zeros_like(v) for k, v in model.params.items()}, **grads}).cpu().numpy()
+        w0 = eng.get_weights()
+        loss_t = torch.zeros(1, device=eng.device)
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = (w0 - eng.get_weights()).cpu().numpy()
+        eng.set_weights(w0)
+        model.step += 1
+        _assert_grads(eng, got, want, floors)
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    # a few Adam steps at this size too (the multi-step bar)
+    k = min(3, n_step)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=k, lr=1e-3)
+    for s_ in range(k):
+        ii = perm[s_ * batch:(s_ + 1) * batch]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=1e-2)
+    eng.close()
+
+
+@pytest.mark.parametrize("emb_trainable", [True, False])
+def test_star_step_at_8192_rows(env, emb_trainable):
+    """BASELINE config 5's batch: the Star step's gradients of EVERY shared and specific tensor, the loss and
+    PartitionedNorm's moving statistics against oracle/star.py at 8192 rows (512 tower tiles, 512 statistics
+    chunks, k_wgrad with 512-row groups and 16 slabs), full batch and the final partial batch."""
+    from oracle import star as ostar
+    g, eng, model = make_star_problem(env, emb_trainable, scale=1.0, batch=8192)
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    assert n > 8192
+    perm = orng.shuffle_perm(n, 10000, seed=4)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_steps = -(-n // 8192)
+    for step in (0, n_steps - 1):
+        idx = perm[step * 8192:(step + 1) * 8192]
+        loss, grads, _, c = ostar.loss_and_grads(model.params, model.state, cols["uid"][idx], cols["pid"][idx],
+                                                 cols["domain"][idx], cols["label"][idx], emb_trainable)
+        ostar.update_moving(model.state, c["d"], c["mean"], c["var"])
+        want = eng.pack(grads).cpu().numpy()
+        w0 = eng.get_weights()
+        loss_t = torch.zeros(1, device=eng.device)
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = (w0 - eng.get_weights()).cpu().numpy()
+        eng.set_weights(w0)
+        for name, (off, cnt) in eng.segments.items():
+            w = want[off:off + cnt]
+            if name == "domain_emb":       # constant over a single-domain batch: rounding residue on both sides
+                assert np.abs(got[off:off + cnt]).max() < 1e-5 and np.abs(w).max() < 1e-5
+                continue
+            floor = 2e-7 if name.startswith("pn_gamma") else (6e-8 if name in ("user_emb", "item_emb") or
+                                                              name.startswith("Wd") else 3e-8)
+            np.testing.assert_allclose(got[off:off + cnt], w, rtol=5e-4,
+                                       atol=max(4e-6 * max(np.abs(w).max(), 1e-3), floor), err_msg=name)
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+        aux = eng.aux_state()
+        np.testing.assert_allclose(aux["steps"], model.state["steps"])
+        np.testing.assert_allclose(aux["mov_mean"], model.state["mov_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(aux["mov_var"], model.state["mov_var"], rtol=1e-4, atol=1e-7)
+    eng.close()
+
+
 # ------------------------------------------------------------------ eval: loss, AUC bins
 def test_eval_matches_oracle_and_auc_bins_exact(env):
     g, eng, model = make_problem(env, batch=256, dropout=0.5)
@@ -1021,7 +1114,8 @@ def test_star_mamdr_auc_parity(env):
     means something where the ORACLE ITSELF is stable to rounding.  The test therefore runs the oracle twice --
     once from theta, once from theta moved by ONE ulp -- and takes the per-domain AUC shift between the two runs
     as the width of the oracle's own answer (measured on this problem: 1e-5 .. 1e-3 depending on the domain).
-    Bar: within 1e-3 of the nominal oracle run, widened by twice that self-divergence."""
+    Bar: within 1e-3 of the nominal oracle run (north_star); the self-divergence is printed next to every domain so
+    that a failure can be read against the oracle's own conditioning, it is not used as slack."""
     STAR_META_LR = 0.2
     from oracle import star as ostar
     engine, synthetic = env
@@ -1075,7 +1169,7 @@ def test_star_mamdr_auc_parity(env):
         _, auc_g = eng.evaluate(d, "val")
         auc_o = aucs_o[d]
         print("star domain %d: AUC hip %.5f oracle %.5f (oracle self-divergence %.1e)" % (d, auc_g, auc_o, self_div[d]))
-        assert abs(auc_g - auc_o) <= 1e-3 + 2 * self_div[d], (d, auc_g, auc_o, self_div[d])
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o, self_div[d])       # north_star: per-domain AUC within 1e-3
         assert auc_o > 0.6
     eng.close()
 
