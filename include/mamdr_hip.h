@@ -272,6 +272,9 @@ int mamdr_profile_enable(mamdr_ctx* ctx, int32_t enable);
  *      MAMDR_KERNEL_WGRAD times it), the domain table's step applied by the next tower, k_dm_finish once per call
  *      (MAMDR_KERNEL_UPDATE times it) */
 int mamdr_step_path(const mamdr_ctx* ctx, int32_t batch);
+/* training steps taken so far (any optimiser): the position of the counter-based dropout stream, which the mask of
+ * step s is keyed on (dropout_seed, s).  A caller that replays the run elsewhere continues the stream from here. */
+int64_t mamdr_dropout_steps(const mamdr_ctx* ctx);
 int mamdr_profile_reset(mamdr_ctx* ctx);
 int mamdr_profile_read(mamdr_ctx* ctx, int32_t kernel, double* total_ms, int64_t* launches);
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mamdr_shuffle_perm": (C.c_int, [_I64, _I64, _U64, _VP]),
     "mamdr_shuffle_perms": (C.c_int, [_I32, _VP, _I64, _VP, _VP]),
     "mamdr_step_path": (C.c_int, [_VP, _I32]),
+    "mamdr_dropout_steps": (_I64, [_VP]),
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
     "mamdr_profile_reset": (C.c_int, [_VP]),
     "mamdr_profile_read": (C.c_int, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64)]),

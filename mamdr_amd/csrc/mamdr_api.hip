@@ -1582,6 +1582,8 @@ int mamdr_debug_set_stamps(mamdr_ctx* c, unsigned long long* d_stamps) {
 #endif
 
 // ---- profiling
+int64_t mamdr_dropout_steps(const mamdr_ctx* c) { return c ? (int64_t)c->global_step : 0; }
+
 int mamdr_step_path(const mamdr_ctx* c, int32_t batch) {
     if (!c || !c->fused) return 0;
     return (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch ? 1 : 0;

@@ -82,16 +82,21 @@ class BaseModel(object):
         domain_loss, domain_auc = {}, {}
         keep = self.model.get_weights()
         best = self.model.new_vector()
+        self.finetune_log = {}        # {domain: epochs run, epoch of the kept checkpoint, val AUC per epoch}
         for d in (self.dataset.train_dataset if domains is None else domains):
             self.model.set_weights(start_weights(d))
             print("Train on domain: {}".format(d))
             # Keras EarlyStopping(monitor=val_AUC, mode=max, min_delta=1e-4) + ModelCheckpoint(best only)
             es_best, wait, ck_best = -np.inf, 0, -np.inf
+            log = self.finetune_log[d] = {"epochs": 0, "best_epoch": -1, "val_auc": []}
             for epoch in range(self.train_config["epoch"]):
                 self.fit_domain(d, optimizer=optimizer, lr=lr, phase="finetune")
                 _, val_auc = self.evaluate_domain(d, "val")
+                log["epochs"] = epoch + 1
+                log["val_auc"].append(float(val_auc))
                 if val_auc > ck_best:
                     ck_best = val_auc
+                    log["best_epoch"] = epoch
                     self.model.get_weights(out=best)
                 if val_auc - 1e-4 > es_best:
                     es_best, wait = val_auc, 0

@@ -195,6 +195,50 @@ def mamdr_epoch(model, theta, phis, data, plan, perm_fn, batch_size, meta_lr, me
     return trace
 
 
+def finetune_domains(model, data, start_weights, perm_fn, batch_size, epochs, patience, lr, auc_fn, domains=None,
+                     set_start=None):
+    """The finetune stage (`*_finetune` model names): model_zoo/base_model.py:41-109 (every domain restarts from the
+    SAME saved weights, plain SGD with `learning_rate`: base_model.py:66-71) and, for MAMDR,
+    model_zoo/specific_base_model.py:99-162 (restart from best theta (+|*) best phi_d, SGD lr 0.001: :118-125).
+    Per domain: `model.fit(train.repeat(), steps_per_epoch=n_step, epochs=E, validation_data=val)` = per epoch one
+    shuffled pass over the train split (final partial batch kept) + one evaluation of the val split, under
+      callbacks.EarlyStopping(monitor='val_AUC', patience, mode='max', min_delta=1e-4)
+          -> improvement iff val_AUC - 1e-4 > best (best starts at -inf); else wait += 1, stop when wait >= patience
+      callbacks.ModelCheckpoint(save_best_only=True, mode='max')
+          -> weights saved iff val_AUC > best saved val_AUC (no min_delta)
+    then `load_weights(chk_path)` and `evaluate(test)` (base_model.py:85-96).
+    data = {"train": {d: cols}, "val": ..., "test": ...}; start_weights(d) -> flat vector; set_start (optional)
+    assigns it (default model.set_flat).  Returns {d: dict(epochs, best_epoch, val_auc list, test_loss, test_auc)}
+    and the trace of (phase, domain, n_steps)."""
+    out, trace = {}, []
+    model.use_sgd = True
+    model.lr = lr
+    for d in (sorted(data["train"]) if domains is None else domains):
+        (set_start or model.set_flat)(start_weights(d))
+        es_best, wait, ck_best, best_w, best_epoch, vals = -np.inf, 0, -np.inf, None, -1, []
+        n_epochs = 0
+        for epoch in range(epochs):
+            _pass(model, data["train"], perm_fn, d, batch_size, trace, "finetune")
+            _, preds = model.evaluate(data["val"][d], batch_size)
+            val_auc = float(auc_fn(data["val"][d]["label"], preds, batch_size))
+            vals.append(val_auc)
+            n_epochs = epoch + 1
+            if val_auc > ck_best:
+                ck_best, best_w, best_epoch = val_auc, model.get_flat().copy(), epoch
+            if val_auc - 1e-4 > es_best:
+                es_best, wait = val_auc, 0
+            else:
+                wait += 1
+                if wait >= patience:
+                    break
+        model.set_flat(best_w)
+        t_loss, t_preds = model.evaluate(data["test"][d], batch_size)
+        out[d] = {"epochs": n_epochs, "best_epoch": best_epoch, "val_auc": vals, "test_loss": float(t_loss),
+                  "test_auc": float(auc_fn(data["test"][d]["label"], t_preds, batch_size))}
+    model.use_sgd = False
+    return out, trace
+
+
 def evaluate_domains(model, data_split, batch_size, weights_for_domain, auc_fn):
     """base_model.py:111-144 / specific_base_model.py:64-97: per-domain
     (loss, AUC); averages are plain means over domains (base_model.py:138-139)."""

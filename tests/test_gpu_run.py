@@ -137,3 +137,91 @@ def test_epoch_shuffles_equal_per_pass_shuffles():
     with pytest.raises(RuntimeError):
         es.prepare(passes)
         es(0)                                    # the epoch's first pass is over domain 2
+
+
+@pytest.mark.parametrize("name", ["mlp_meta_domain_negotiation_finetune", "mlp_meta_mamdr_finetune"])
+def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
+    """the finetune stage on the HIP engine against oracle/loops.finetune_domains (a restatement of
+    base_model.py:41-109 / specific_base_model.py:99-162: per-domain SGD restart, Keras EarlyStopping with
+    min_delta 1e-4, best-only checkpoint, test from the kept weights).  Both sides start from the SAME weights (the
+    HIP run's best checkpoint, copied into the oracle), the same shuffles and dropout masks.  Bars: the val AUC of
+    every epoch both sides ran and the test AUC within 1e-3; the same number of epochs and the same kept checkpoint
+    wherever the oracle's own decision is not within 2e-4 of a tie (an early-stopping comparison closer than that is
+    decided by rounding on either side)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import cli, plan as mplan
+    from mamdr_amd.utils import dataset as mds
+    from oracle import auc as oauc
+    from oracle import loops as oloops
+    from oracle import outer as oouter
+    from oracle import rng as orng
+    from oracle import tower as otower
+    with open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
+        cfg = copy.deepcopy(json.load(f))
+    cfg["model"]["name"] = name
+    cfg["train"].update(epoch=4, patience=2, sample_num=2, meta_learning_rate=0.5, learning_rate=0.02,
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.08)
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    model = cli.build_model(cfg, ds)
+    model.train()
+    model.load_model(model.checkpoint_path)
+    eng = model.model
+    # the oracle twin: same tensors, same dropout stream position
+    named = eng.unpack(eng.get_weights())
+    named["user_emb"], named["item_emb"] = ds.user_emb, ds.item_emb
+    for k in ("lin_user", "lin_item", "lin_domain", "log_var"):
+        named.setdefault(k, np.zeros(1, np.float32))
+    twin = otower.OracleModel({k: np.array(v, np.float32).reshape(otower_shape(k, v, ds)) for k, v in named.items()},
+                              emb_trainable=False, dropout=cfg["model"]["dropout"], lr=0.02,
+                              dropout_seed=eng.dropout_seed)
+    twin.step = int(eng.lib.mamdr_dropout_steps(eng.ctx))
+    counter0 = model.shuffler.counter
+    _, _, d_loss, d_auc = model.separate_train_val_test(init_parms=False)
+    log = model.base_model.finetune_log if hasattr(model, "base_model") else model.finetune_log
+    sizes = {d: v["n_data"] for d, v in ds.train_dataset.items()}
+    shuf = mplan.PassShuffler(sizes, ds.shuffle_buffer_size, ds.seed, shuffle_fn=orng.shuffle_perm)
+    shuf.counter = counter0
+    data = {sp: {d: st[d]["data"] for d in st} for sp, st in (("train", ds.train_dataset), ("val", ds.val_dataset),
+                                                              ("test", ds.test_dataset))}
+    if "mamdr" in name:
+        bs_, bd_ = model.best_shared_weights.cpu().numpy(), {d: w.cpu().numpy() for d, w in model.best_domain_weights.items()}
+        n_flat = twin.get_flat().size                   # (the engine's vectors carry up to 3 floats of padding)
+        start = lambda d: oouter.merge(bs_, bd_[d], "plus")[:n_flat]
+        lr = 0.001
+    else:
+        w0 = twin.get_flat().copy()
+        start = lambda d: w0
+        lr = 0.02
+    want, _ = oloops.finetune_domains(twin, data, start, shuf, 256, 4, 2, lr, oauc.auc500)
+    decided = 0
+    for d in sorted(want):
+        o, h = want[d], log[d]
+        k = min(o["epochs"], h["epochs"])
+        assert np.abs(np.array(o["val_auc"][:k]) - np.array(h["val_auc"][:k])).max() <= 1e-3, (d, o, h)
+        # how close the oracle's own stop / keep decisions came to a tie
+        v = o["val_auc"]
+        margins = []
+        best = -np.inf
+        for a in v:
+            margins.append(abs(a - 1e-4 - best))
+            if a - 1e-4 > best:
+                best = a
+        ck_margin = min([abs(a - b) for i, a in enumerate(v) for b in v[:i]] or [1.0])
+        if min(margins) > 2e-4 and ck_margin > 2e-4:
+            decided += 1
+            assert (h["epochs"], h["best_epoch"]) == (o["epochs"], o["best_epoch"]), (d, o, h)
+        # the test AUC comes from the kept checkpoint: within 1e-3 also where a near-tie kept another epoch's weights
+        # (a near-tie means the candidates' val AUCs agree to 2e-4; the bar still holds the test AUC to 1e-3)
+        assert abs(d_auc[d] - o["test_auc"]) <= 1e-3, (d, d_auc[d], o["test_auc"], o, h)
+    print("finetune parity: %d of %d domains with a clear-cut early-stopping history" % (decided, len(want)))
+    if "mamdr" not in name:       # (SGD at the hard-coded 0.001 of the MAMDR finetune moves the val AUC by < 2e-4 per epoch)
+        assert decided >= len(want) // 2
+
+
+def otower_shape(name, v, ds):
+    """shape of a named tensor of the mlp tower (flat segment -> oracle array)."""
+    D = ds.n_domain
+    return {"user_emb": (ds.n_uid, 128), "item_emb": (ds.n_pid, 128), "domain_emb": (D, 128), "W0": (384, 256),
+            "W1": (256, 128), "W2": (128, 64), "wo": (64, 1)}.get(name, (np.asarray(v).size,))

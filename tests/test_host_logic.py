@@ -346,6 +346,50 @@ def test_mamdr_wrapper_quirks(tmp_path, monkeypatch):
     assert phases[n_dom:] == ["dr_support", "dr_query"] * ((len(phases) - n_dom) // 2)
 
 
+@pytest.mark.parametrize("name", ["mlp_meta_domain_negotiation_finetune", "mlp_meta_mamdr_finetune"])
+def test_finetune_stage_follows_the_oracle(tmp_path, monkeypatch, name):
+    """separate_train_val_test(init_parms=False) (base_model.py:41-109; MAMDR: specific_base_model.py:99-162) against
+    oracle/loops.finetune_domains on the oracle-backed engine: per domain the same epochs run, the same kept
+    checkpoint, the same val AUC sequence and test AUC (exact: same arithmetic on both sides), SGD with
+    `learning_rate` / 0.001, every domain restarted from the same weights / from best theta + best phi_d."""
+    import copy as _copy
+    from oracle import auc as oauc
+    from oracle import outer as oouter
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, name, epochs=4)
+    cfg["train"].update(patience=2, learning_rate=0.05)
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    model = cli.build_model(cfg, ds, FakeEngine)
+    model.train()
+    model.load_model(model.checkpoint_path)
+    eng = model.model
+    twin = _copy.deepcopy(eng.oracle)                    # the oracle model in the state the finetune stage starts from
+    counter0 = model.shuffler.counter
+    model.model.calls.clear()
+    _, _, d_loss, d_auc = model.separate_train_val_test(init_parms=False)
+    log = model.base_model.finetune_log if hasattr(model, "base_model") else model.finetune_log
+    sizes = {d: v["n_data"] for d, v in ds.train_dataset.items()}
+    shuf = mplan.PassShuffler(sizes, ds.shuffle_buffer_size, ds.seed, shuffle_fn=orng.shuffle_perm)
+    shuf.counter = counter0
+    data = {sp: {d: st[d]["data"] for d in st} for sp, st in (("train", ds.train_dataset), ("val", ds.val_dataset),
+                                                              ("test", ds.test_dataset))}
+    if "mamdr" in name:
+        start = lambda d: oouter.merge(model.best_shared_weights.numpy(), model.best_domain_weights[d].numpy(), "plus")
+        lr = 0.001
+    else:
+        w0 = twin.get_flat().copy()
+        start = lambda d: w0
+        lr = 0.05
+    want, trace = oloops.finetune_domains(twin, data, start, shuf, 64, 4, 2, lr, oauc.auc500)
+    assert sorted(want) == sorted(log) == [0, 1, 2]
+    for d in want:
+        assert log[d]["epochs"] == want[d]["epochs"] and log[d]["best_epoch"] == want[d]["best_epoch"], (d, log[d], want[d])
+        assert log[d]["val_auc"] == want[d]["val_auc"]
+        assert d_auc[d] == want[d]["test_auc"] and abs(d_loss[d] - want[d]["test_loss"]) < 1e-6
+    assert all(c[2] == "sgd" and c[3] == lr for c in eng.calls)
+    assert [t[2] for t in trace] == [c[1] for c in eng.calls]
+
+
 def test_early_stop_counts_ties(tmp_path, monkeypatch):
     patch_emb_dim(monkeypatch)
     cfg = tiny_config(tmp_path, "mlp")
