@@ -79,10 +79,9 @@ def main(config, engine_factory=None):
     from .utils import MultiDomainDataset
     rank, world = init_distributed()
     name = config["model"]["name"]
-    if world > 1 and not ("meta" in name and ("mamdr" in name or "domain_negotiation" in name or
-                                               ("reptile" in name and "batch" in name))):
-        raise NotImplementedError("multi-process runs shard the MAMDR (DN + DR), Domain Negotiation and batch "
-                                  "Reptile wrappers only; got '%s'" % name)
+    if world > 1 and not ("meta" in name and ("mamdr" in name or "domain_negotiation" in name or "reptile" in name)):
+        raise NotImplementedError("multi-process runs shard the MAMDR (DN + DR), Domain Negotiation and Reptile "
+                                  "wrappers only; got '%s'" % name)
     dataset = MultiDomainDataset(config["dataset"])
     model = build_model(config, dataset, engine_factory)
     if "separate" in name:

@@ -44,12 +44,13 @@ class DomainNegotiation(MAML):
             if tc["shuffle_sequence"]:
                 self.rng.shuffle(meta_sequence)
             if world > 1:
-                if tc["meta_train_step"] > 0 or target >= 0:
-                    raise NotImplementedError("multi-process DN with meta_train_step > 0 or a target domain is not built")
                 parallel.dn_phase_sharded(self.model, meta, meta_weights, [d for d in meta_sequence if owner[d] == rank],
                                           self.shuffler, self.batch_size, self.learning_rate, tc["meta_learning_rate"],
-                                          self.trace, delta, zero)
+                                          self.trace, delta, zero, tc["meta_train_step"], target)
                 self.model.set_weights(meta_weights)
+                if target >= 0:        # domain_negotiation.py:89-93: the model (not theta) takes one more pass over the target
+                    meta.run_pass(self.model, target, self.shuffler, self.batch_size, self.learning_rate, self.trace,
+                                  "target")
             else:
                 self.trace += meta.dn_epoch(self.model, meta_weights, list(meta_sequence), self.shuffler,
                                             self.batch_size, self.learning_rate, tc["meta_learning_rate"],

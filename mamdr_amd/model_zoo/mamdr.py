@@ -28,45 +28,38 @@ class MAMDR(SpecificBase):
         # (train.target_domain only selects the early-stopping metric here: mamdr.py:153-154)
         self._get_model_meta_parms()
         self.meta_weights = self._get_meta_weights()
-        # one process per GPU: query domains have a fixed owner (LPT over their train rows) that
-        # holds phi_i, runs its DR and evaluates it; every rank draws all D initialisations so that the
-        # streams stay aligned with the single-process run
+        # one process per GPU: every rank draws all D initialisations (the streams stay aligned with the
+        # single-process run) and keeps every phi; the DR queries and DN passes of an epoch are dealt by
+        # longest-processing-time on the cost THAT epoch's sampled plan will execute, one all-reduce per epoch carries
+        # the DN displacement and hands the phis over (parallel.BalancedMAMDR); before validation every phi is made
+        # current everywhere and the domains are dealt round-robin
         rank, world = parallel.world()
-        sizes = [self.dataset.train_dataset[d]["n_data"] for d in range(self.n_domain)]
-        self.owner = parallel.lpt_partition(sizes, world)
-        self.domain_weights = {}
+        steps = [self.dataset.train_dataset[d]["n_step"] for d in range(self.n_domain)]
+        phis = {}
         for domain_idx in range(self.n_domain):
-            w = self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
-            if self.owner[domain_idx] == rank:
-                self.domain_weights[domain_idx] = w
+            phis[domain_idx] = self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
+        self.balanced = parallel.BalancedMAMDR(self.model, meta, self.meta_weights, phis, steps)
+        self.domain_weights = self.balanced.phis
         self.model.optimizer_reset()
         planner = EpochPlanner(self.build_meta_sequence(), tc["sample_num"], tc["add_query_domain"],
                                tc["shuffle_sequence"], seed=self.dataset.seed)
         planner.rng = self.rng
         batch_variant = "batch" in self.model_config["name"]
-        scratch = self.model.new_vector(meta=True)
-        bufs = {"delta": self.model.new_vector(meta=True), "zero": self.model.new_vector(meta=True), "merged": scratch}
-        if world > 1 and (batch_variant or tc["merged_method"] not in ("plus", "times") or tc["finetune_every_epoch"]):
-            raise NotImplementedError("multi-process MAMDR: the per-support update variant without "
-                                      "finetune_every_epoch only")
+        if tc["merged_method"] not in ("plus", "times"):
+            raise ValueError("merged_method must be 'plus' or 'times', not: {}".format(tc["merged_method"]))
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             plan = planner.next_epoch()
-            if world > 1:
-                self.trace += parallel.mamdr_epoch_sharded(self.model, meta, self.meta_weights, self.domain_weights,
-                                                           plan, self.owner, self.shuffler, self.batch_size,
-                                                           self.learning_rate, tc["meta_learning_rate"], bufs,
-                                                           tc["merged_method"], tc["domain_regulation_step"])
-            else:
-                self.trace += meta.mamdr_epoch(self.model, self.meta_weights, self.domain_weights, plan,
-                                               self.shuffler, self.batch_size, self.learning_rate,
-                                               tc["meta_learning_rate"], tc["merged_method"],
-                                               tc["domain_regulation_step"], batch_variant, tc["sample_num"],
-                                               scratch, bool(tc["finetune_every_epoch"]))
+            self.trace += self.balanced.epoch(plan, None, self.shuffler, self.batch_size, self.learning_rate,
+                                              tc["meta_learning_rate"], tc["merged_method"],
+                                              tc["domain_regulation_step"], batch_variant, tc["sample_num"],
+                                              bool(tc["finetune_every_epoch"]))
             if epoch % tc["val_every_step"] == 0:
+                self.balanced.sync_phis()
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):
                     break
                 print("Test Result: ")
                 self.val_and_test("test")
+        self.balanced.sync_phis()

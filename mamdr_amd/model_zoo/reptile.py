@@ -22,21 +22,27 @@ class Reptile(MAML):
         batch_variant = "batch" in self.model_config["name"]
         rank, world = parallel.world()
         if world > 1:
-            if not batch_variant or tc["target_domain"] >= 0:
-                raise NotImplementedError("multi-process Reptile: the batch variant without a target domain only "
-                                          "(its epoch update is a plain sum of per-domain displacements)")
+            if tc["target_domain"] >= 0:
+                raise NotImplementedError("multi-process Reptile with a target domain is not built (the target step "
+                                          "after every domain ties the domains' passes together)")
             sizes = [self.dataset.train_dataset[d]["n_data"] for d in range(self.n_domain)]
             owner = parallel.lpt_partition(sizes, world)
             acc = self.model.new_vector(meta=True)
+            zero = self.model.new_vector(meta=True)
         self.trace = []
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
             self.rng.shuffle(train_sequence)
-            if world > 1:
+            if world > 1 and batch_variant:
                 # one process per GPU: the batch variant's sum of displacements is a sum over ranks
                 self.trace += parallel.reptile_batch_epoch_sharded(
                     self.model, meta, meta_weights, [d for d in train_sequence if owner[d] == rank], self.shuffler,
                     self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, tc["meta_train_step"])
+            elif world > 1:
+                # per-domain variant: every rank runs the recurrence over its domains, displacements summed
+                self.trace += parallel.reptile_epoch_sharded(
+                    self.model, meta, meta_weights, [d for d in train_sequence if owner[d] == rank], self.shuffler,
+                    self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, zero, tc["meta_train_step"])
             else:
                 self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
                                                  self.batch_size, self.learning_rate, tc["meta_learning_rate"],

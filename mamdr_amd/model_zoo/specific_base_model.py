@@ -78,8 +78,8 @@ class SpecificBase(MAML):
         domain_loss, domain_auc = {}, {}
         merged = self.model.new_vector(meta=True)
         rank, world = parallel.world()
-        for idx in store:
-            if world > 1 and idx not in specific:      # another rank owns this domain's phi
+        for i, idx in enumerate(store):
+            if world > 1 and i % world != rank:        # every rank holds every phi: the domains are dealt out
                 continue
             self._set_model_meta_parms(self._merge_weights(shared, specific[idx], out=merged))
             p_loss, p_auc = self.evaluate_domain(idx, mode)
@@ -97,8 +97,8 @@ class SpecificBase(MAML):
         def start(d):
             return self._merge_weights(self.best_shared_weights, self.best_domain_weights[d], out=merged)
         rank, world = parallel.world()
-        if world > 1:                                  # every owner finetunes its own domains
-            mine = [d for d in self.dataset.train_dataset if d in self.best_domain_weights]
+        if world > 1:                                  # every rank holds every best phi: the domains are dealt out
+            mine = [d for i, d in enumerate(self.dataset.train_dataset) if i % world == rank]
             _, _, dl, da = self.base_model._finetune_domains(start, "sgd", FINETUNE_SGD_LR, domains=mine, summarise=False)
             dl, da = parallel.gather_domain_scalars({d: (dl[d], da[d]) for d in dl}, self.n_domain, self.model.device)
             return self.base_model._summarise("test", dl, da)

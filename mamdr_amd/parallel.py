@@ -54,18 +54,47 @@ def allreduce_delta(eng, theta, delta_buf):
     return delta_buf
 
 
-def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, trace, delta_buf, zero_buf):
+def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, trace, delta_buf, zero_buf,
+                     meta_train_step=0, target=-1):
     """DN phase of one epoch on this rank's sub-sequence + the all-reduce outer update.
-    theta += (sum_g delta_g) * beta, evaluated as interp(theta, delta, 0, beta)."""
+    theta += (sum_g delta_g) * beta, evaluated as interp(theta, delta, 0, beta).
+    meta_train_step caps every pass (domain_negotiation.py:67); a target domain (:44-45,89-93) closes EVERY rank's
+    sub-sequence with an uncapped pass -- each displacement then ends adapted to the target, as the single
+    sequence's does -- and the caller runs the closing target pass on the updated model (identical on every rank)."""
     eng.set_weights(theta)
     for d in seq_local:
-        meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
+        meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
+    if target >= 0:
+        meta.run_pass(eng, target, perm_fn, batch_size, lr, trace, "dn")
     rank, ws = world()
     if ws == 1:
         eng.interp(theta, eng.weights, theta, meta_lr)
     else:
         allreduce_delta(eng, theta, delta_buf)
         eng.interp(theta, delta_buf, zero_buf, meta_lr)
+
+
+def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, delta_buf, zero_buf,
+                          meta_train_step=0):
+    """Reptile, per-domain variant (reptile.py:45-99): the reference interpolates theta after EVERY domain, a
+    sequential recurrence.  Sharded: every rank runs that recurrence over its own domains on a private copy
+    starting from the epoch's theta, then the ranks' total displacements are summed (ONE all-reduce) and applied:
+    theta += sum_g (theta_g - theta).  One rank: exactly the reference's epoch."""
+    trace = []
+    local = theta.clone()
+    for d in seq_local:
+        eng.set_weights(local)
+        meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
+        eng.interp(local, eng.weights, local, meta_lr)
+    rank, ws = world()
+    if ws == 1:
+        theta.copy_(local)
+    else:
+        eng.sub(delta_buf, local, theta)
+        dist.all_reduce(delta_buf, op=dist.ReduceOp.SUM)
+        eng.interp(theta, delta_buf, zero_buf, 1.0)
+    eng.set_weights(theta)
+    return trace
 
 
 def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, acc, meta_train_step=0):
@@ -174,7 +203,7 @@ class BalancedMAMDR(object):
         self.mine = None
 
     def epoch(self, plan, perm_prepare, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
-              domain_regulation_step=0):
+              domain_regulation_step=0, batch_variant=False, sample_num=None, finetune_every_epoch=False):
         """perm_prepare(passes) (optional) is told this rank's passes in execution order before they run
         (plan.EpochShuffles.prepare).  Returns the trace of (phase, domain, n_steps)."""
         from . import plan as mplan
@@ -184,14 +213,18 @@ class BalancedMAMDR(object):
             if perm_prepare is not None:
                 perm_prepare(mplan.epoch_passes(plan, domain_regulation_step))
             return meta.mamdr_epoch(eng, theta, self.phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method,
-                                    domain_regulation_step, scratch=self.merged)
+                                    domain_regulation_step, batch_variant, sample_num, scratch=self.merged,
+                                    finetune_every_epoch=finetune_every_epoch)
         dr_owner, dn_owner, load = epoch_assignment(plan, self.steps, ws, domain_regulation_step)
         self.last_load = load
         local = {"seq": [d for d in plan["seq"] if dn_owner[d] == rank],
                  "dr": [(q, s) for (q, s) in plan["dr"] if dr_owner[q] == rank]}
         if perm_prepare is not None:
+            if finetune_every_epoch:
+                raise ValueError("pre-drawn epoch shuffles do not cover the per-query finetune passes")
             perm_prepare(mplan.epoch_passes(local, domain_regulation_step))
         trace = []
+        acc = torch.zeros_like(theta) if batch_variant else None
         eng.set_weights(theta)
         for d in local["seq"]:
             meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
@@ -204,7 +237,10 @@ class BalancedMAMDR(object):
         eng.interp(theta, self.delta, self.zero, meta_lr)
         for query, support in local["dr"]:
             meta.dr_query(eng, theta, self.phis[query], query, support, perm_fn, batch_size, lr, meta_lr, trace,
-                          self.merged, merged_method, domain_regulation_step)
+                          self.merged, merged_method, domain_regulation_step, batch_variant, sample_num, acc)
+            if finetune_every_epoch:
+                meta.finetune_query(eng, theta, self.phis[query], query, perm_fn, batch_size, lr, trace, self.merged,
+                                    merged_method)
         self.mine = set(q for q, _ in local["dr"])
         self.last_queries = set(q for q, _ in plan["dr"])
         return trace

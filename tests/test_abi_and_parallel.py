@@ -346,11 +346,24 @@ def test_run_entry_sharded_reptile_batch_gloo_world2(tmp_path):
     _run_entry_worlds(tmp_path, "mlp_meta_reptile_batch")
 
 
-def _run_entry_worlds(tmp_path, name):
+@pytest.mark.parametrize("name,extra", [
+    ("mlp_meta_mamdr_batch", {}),                                   # mamdr.py:100-108 batch names: accumulated DR update
+    ("mlp_meta_mamdr", {"finetune_every_epoch": True}),             # mamdr.py:110-143
+    ("mlp_meta_domain_negotiation", {"meta_train_step": 2, "target_domain": 1}),   # domain_negotiation.py:44-45,67,89-93
+    ("mlp_meta_reptile", {}),                                       # reptile.py:45-99, per-domain interpolation
+])
+def test_run_entry_sharded_variants_gloo_world2(tmp_path, name, extra):
+    """the remaining multi-process variants through run.py's entry, 2 gloo ranks: identical results on every rank,
+    every domain reported, close to the 1-process run."""
+    _run_entry_worlds(tmp_path, name, extra)
+
+
+def _run_entry_worlds(tmp_path, name, extra=None):
     import json
     sys.path.insert(0, HERE)
     from test_host_logic import tiny_config
     cfg = tiny_config(tmp_path, name, epochs=2)
+    cfg["train"].update(extra or {})
     cfg_path = tmp_path / "cfg.json"
     cfg_path.write_text(json.dumps(cfg))
     script = tmp_path / "run_worker.py"
