@@ -384,7 +384,8 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         epoch()                       # fills the library's event pool: the measured epoch below creates no events
         eng.profile_reset()
         prof_trace, _ = epoch()
-        names = dict({k: L.KERNEL_NAMES[k] for k in (L.KERNEL_EMB_SWEEP,)}, **eng.step_kernel_names(batch))
+        names = {L.KERNEL_EMB_SWEEP: L.KERNEL_NAMES[L.KERNEL_EMB_SWEEP]}
+        names.update(eng.step_kernel_names(batch))
         for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE, L.KERNEL_EMB_SWEEP):
             ms, cnt = eng.profile_read(k)
             if cnt:
