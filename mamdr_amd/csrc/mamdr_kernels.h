@@ -47,8 +47,9 @@ struct DmStep {
     int optimizer;             // of the pending step: 0 adam, 1 sgd, 2 accumulate
     float alpha, omb1, omb2, eps, two_l2;
 };
-// Canonical arithmetic (every site, bit for bit): pair sums s_j = pdm[2 j] + pdm[2 j + 1], g = s_0 + s_1 + ... in
-// order, g += 2 l2 p, optimiser step with separately rounded operations.
+// Canonical arithmetic (every site, bit for bit): pair sums s_j = pdm[2 j] + pdm[2 j + 1] (j < 16), group sums
+// G_q = ((s_4q + s_4q+1) + s_4q+2) + s_4q+3 (q < 4), g = ((G_0 + G_1) + G_2) + G_3, g += 2 l2 p, optimiser step with
+// separately rounded operations.  (A tree, so that four lanes can each sum a quarter of the partials.)
 __device__ __forceinline__ f32x4 dm_pair(const DmStep& q, int d, int c4, int j) {
 #pragma clang fp contract(off)
     const size_t row = (size_t)d * EMB + 4 * c4, plane = (size_t)q.n_domain * EMB;
@@ -82,16 +83,17 @@ __device__ __forceinline__ void dm_apply4(const DmStep& q, f32x4 g, f32x4& p, f3
 // one lane does it all (the writer workgroups and k_dm_finish: off the critical path): four batches of loads
 __device__ __forceinline__ void dm_step4(const DmStep& q, int d, int c4, f32x4& p, f32x4& m, f32x4& v) {
 #pragma clang fp contract(off)
+    static_assert(DM_PAIRS == 16, "four groups of four pair sums");
     dm_load4(q, d, c4, p, m, v);
-    f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 G[4];
 #pragma unroll
-    for (int j0 = 0; j0 < DM_PAIRS; j0 += 4) {
+    for (int gq = 0; gq < 4; ++gq) {
         f32x4 t[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = dm_pair(q, d, c4, j0 + k);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g = (j0 + k == 0) ? t[k] : g + t[k];
+        for (int k = 0; k < 4; ++k) t[k] = dm_pair(q, d, c4, 4 * gq + k);
+        G[gq] = ((t[0] + t[1]) + t[2]) + t[3];
     }
+    const f32x4 g = ((G[0] + G[1]) + G[2]) + G[3];
     dm_apply4(q, g, p, m, v);
 }
 
@@ -253,15 +255,8 @@ __device__ __forceinline__ void tower_snapshots(const TowerArgs& a, int n_thread
 //           dm_hint; otherwise every lane of a domain segment runs dm_step4 alone)
 //   writer  workgroup d < n_domain does the same for row d with lanes 32..63 and writes it back: live p / m / v and
 //           the snapshot [3][n_domain][EMB] this step's k_wgrad_adam and the next step's towers read
-// one element: the 16 staged pair sums of column c in order, then the step (the scalar form of dm_step4: same bits)
-__device__ __forceinline__ void dm_elem_finish(const DmStep& q, int c, const float* parts, float& p, float& m, float& v) {
+__device__ __forceinline__ void dm_apply1(const DmStep& q, float g, float& p, float& m, float& v) {
 #pragma clang fp contract(off)
-    float t[DM_PAIRS];
-#pragma unroll
-    for (int j = 0; j < DM_PAIRS; ++j) t[j] = parts[j * EMB + c];
-    float g = t[0];
-#pragma unroll
-    for (int j = 1; j < DM_PAIRS; ++j) g = g + t[j];
     const float gk = g + q.two_l2 * p;
     if (q.optimizer == 0) {
         m = m + (gk - m) * q.omb1;
@@ -272,6 +267,62 @@ __device__ __forceinline__ void dm_elem_finish(const DmStep& q, int c, const flo
     } else {
         m = m + gk;
     }
+}
+// ---- the 4-row tower's form, without LDS and without a barrier: wave w owns the 16 domain columns its second
+// layer-0 segment contracts; lane (l = lane & 15, q = lane >> 4) loads partials 8 q .. 8 q + 7 of column 16 w + l,
+// sums its group G_q, and four cross-lane reads complete the tree.  Requested behind the row bookkeeping, consumed
+// between layer 0's segments.
+struct DmWave {
+    float r[8], w[8];          // partials of the batch's domain row / of the row this workgroup writes back
+    float rp, rm, rv, wp, wm, wv;
+};
+__device__ __forceinline__ void dm_wave_begin(const TowerArgs& a, int tile, int d_read, bool do_read, DmWave& t) {
+    const int lane = (int)threadIdx.x & 63, l = lane & 15, gq = lane >> 4, c = 16 * ((int)threadIdx.x >> 6) + l;
+    const bool pend = a.dms.snap != nullptr, wr = tile < a.n_domain;      // uniform
+    const size_t plane = (size_t)a.n_domain * EMB;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t.r[k] = t.w[k] = 0.f;
+    t.rp = t.rm = t.rv = t.wp = t.wm = t.wv = 0.f;
+    if (pend && do_read) {
+        const size_t e = (size_t)d_read * EMB + c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t.r[k] = a.dms.pdm[(size_t)(8 * gq + k) * plane + e];
+        t.rp = a.dms.snap[e];
+        t.rm = a.dms.snap[plane + e];
+        t.rv = a.dms.snap[2 * plane + e];
+    }
+    if (wr) {
+        const size_t e = (size_t)tile * EMB + c;
+        if (pend) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t.w[k] = a.dms.pdm[(size_t)(8 * gq + k) * plane + e];
+            t.wp = a.dms.snap[e];
+            t.wm = a.dms.snap[plane + e];
+            t.wv = a.dms.snap[2 * plane + e];
+        } else {
+            t.wp = a.dm_live_p[e];
+            t.wm = a.dm_live_m[e];
+            t.wv = a.dm_live_v[e];
+        }
+    }
+}
+__device__ __forceinline__ float dm_wave_sum(const float (&x)[8]) {
+#pragma clang fp contract(off)
+    const int l = (int)threadIdx.x & 15;
+    const float G = (((x[0] + x[1]) + (x[2] + x[3])) + (x[4] + x[5])) + (x[6] + x[7]);
+    const float G0 = __shfl(G, l), G1 = __shfl(G, l + 16), G2 = __shfl(G, l + 32), G3 = __shfl(G, l + 48);
+    return ((G0 + G1) + G2) + G3;
+}
+// one element: the 16 staged pair sums of column c in order, then the step (the scalar form of dm_step4: same bits)
+__device__ __forceinline__ void dm_elem_finish(const DmStep& q, int c, const float* parts, float& p, float& m, float& v) {
+#pragma clang fp contract(off)
+    float t[DM_PAIRS];
+#pragma unroll
+    for (int j = 0; j < DM_PAIRS; ++j) t[j] = parts[j * EMB + c];
+    float G[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) G[gq] = ((t[4 * gq] + t[4 * gq + 1]) + t[4 * gq + 2]) + t[4 * gq + 3];
+    dm_apply1(q, ((G[0] + G[1]) + G[2]) + G[3], p, m, v);
 }
 // per-lane state of the tile workgroups' duty.  Only waves 4..7 take part: wave 0 runs the row bookkeeping's chain of
 // dependent loads, and loads retire in order -- anything requested ahead of that chain is waited for with it.

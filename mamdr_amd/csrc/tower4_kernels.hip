@@ -307,7 +307,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const bool dmw = a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
     // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
     // the caller's expected domain, its loads -- misses to HBM -- delayed the x rows by 1.5 K cycles; measured)
-    DmTile dmt;
+    DmWave dmt;
     const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
     const float b0r = P[a.L.b0 + ecol];
     const float b1r = P[a.L.b1 + (tid & 127)];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // second dependent load and delayed the whole gather)
     const bool pend = a.dms.snap != nullptr;
     const bool same = pend && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
-    if (dmw) dm_tile_begin(a, tile, rowi[8], dmt);
+    if (dmw) dm_wave_begin(a, tile, rowi[8], same, dmt);
     T4STAMP_W4(1);
     // (a scalar branch around the whole block: the loads inside sit in divergent branches, at whose end the compiler
     // drains EVERY outstanding load -- including the partials just requested, a full round trip to HBM)
@@ -378,13 +378,6 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         }
     }
     // (pending + one-domain tile: the domain columns of x are filled between layer 0's two segments, see midseg)
-    float rdp = 0.f, rdm = 0.f, rdv = 0.f;           // lanes 0..15 of wave w: (p, m, v) of column 16 w + lane before the step
-    if (same) {
-        const size_t e = (size_t)rowi[8] * EMB + 16 * w + (lane & 15), plane = (size_t)a.n_domain * EMB;
-        rdp = a.dms.snap[e];
-        rdm = a.dms.snap[plane + e];
-        rdv = a.dms.snap[2 * plane + e];
-    }
     T4STAMP_W4(2);
     __syncthreads();
     if (FM) {
@@ -412,22 +405,46 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     t4_contract_l0(w0, P + a.L.w0, smem + T4_XS, red,
                    [&]() {
                        if (!dmw) return;
-                       // the pair sums of the pending step (requested behind the bookkeeping) -> LDS, then every wave
-                       // finishes the 16 domain columns ITS second segment contracts (lanes 0..15; written to all
-                       // four rows of the tile, read back by the same wave only) and waves 6, 7 of workgroup
-                       // d < n_domain write row d back.  (`red` is free until the end of this layer.)
-                       dm_tile_stage(a, tile, dmt, red);
+                       // every wave finishes the 16 domain columns ITS second segment contracts (partials requested
+                       // behind the bookkeeping: long since arrived; no LDS staging, no barrier) and writes them to all
+                       // four rows of the tile -- read back by the same wave only; workgroup d < n_domain does the same
+                       // for row d and writes it back (live p / m / v + the snapshot for k_wgrad_adam and the next tower)
                        T4STAMP(13);
-                       if (pend) __syncthreads();
-                       T4STAMP(14);
-                       if (same && lane < 16) {
-                           float p = rdp, m = rdm, v = rdv;
-                           const int c = 16 * w + lane;
-                           dm_elem_finish(a.dms, c, red, p, m, v);
+                       const int c = 16 * w + (lane & 15);
+                       if (same) {
+                           float p = dmt.rp, m = dmt.rm, v = dmt.rv;
+                           dm_apply1(a.dms, dm_wave_sum(dmt.r), p, m, v);
+                           if (lane < 16) {
 #pragma unroll
-                           for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * XDIM + 2 * EMB + c] = rowi[12 + rr] ? p : 0.f;
+                               for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * XDIM + 2 * EMB + c] = rowi[12 + rr] ? p : 0.f;
+                           }
                        }
-                       if (tid >= 256 + EMB) dm_tile_writer(a, tile, n_tiles, tid - 256 - EMB, red, dmt);
+                       T4STAMP(14);
+                       if (tile < a.n_domain) {
+                           float p = dmt.wp, m = dmt.wm, v = dmt.wv;
+                           if (pend) dm_apply1(a.dms, dm_wave_sum(dmt.w), p, m, v);
+                           if (lane < 16) dm_store_elem(a, (size_t)tile * EMB + c, pend, p, m, v);
+                       }
+                       // grids smaller than the domain count (tiny batches): the remaining rows, one lane chain per float4
+                       if (tile + n_tiles < a.n_domain && tid < EMB / 4) {
+                           for (int d = tile + n_tiles; d < a.n_domain; d += n_tiles) {
+                               f32x4 p4, m4, v4;
+                               const size_t row = (size_t)d * EMB + 4 * tid, plane = (size_t)a.n_domain * EMB;
+                               if (pend) {
+                                   dm_step4(a.dms, d, tid, p4, m4, v4);
+                                   if (a.dms.optimizer != 2) *reinterpret_cast<f32x4*>(a.dm_live_p + row) = p4;
+                                   if (a.dms.optimizer != 1) *reinterpret_cast<f32x4*>(a.dm_live_m + row) = m4;
+                                   if (a.dms.optimizer == 0) *reinterpret_cast<f32x4*>(a.dm_live_v + row) = v4;
+                               } else {
+                                   p4 = *reinterpret_cast<const f32x4*>(a.dm_live_p + row);
+                                   m4 = *reinterpret_cast<const f32x4*>(a.dm_live_m + row);
+                                   v4 = *reinterpret_cast<const f32x4*>(a.dm_live_v + row);
+                               }
+                               *reinterpret_cast<f32x4*>(a.dm_snap_out + row) = p4;
+                               *reinterpret_cast<f32x4*>(a.dm_snap_out + plane + row) = m4;
+                               *reinterpret_cast<f32x4*>(a.dm_snap_out + 2 * plane + row) = v4;
+                           }
+                       }
                        T4STAMP(15);
                    },
                    [&]() { w1.prefetch(P + a.L.w1); });
