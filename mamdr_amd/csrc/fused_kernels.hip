@@ -357,8 +357,15 @@ __device__ __forceinline__ void fz_s_body(const FusedArgs& a, int blk, float* ld
     // Dm[d][r] (pre-update) of every (padded) domain: requested before the contraction too
     float xd[64];
 #pragma unroll
-    for (int d = 0; d < 64; ++d)
-        if (d < 16 * MT) xd[d] = a.dm_snap[min(d, D - 1) * EMB + r];       // uniform condition
+    for (int c16 = 0; c16 < 4; ++c16) {
+        if (c16 < MT) {                                     // uniform: one batch of 16 loads per 16 domains
+#pragma unroll
+            for (int d = 0; d < 16; ++d) xd[16 * c16 + d] = a.dm_snap[min(16 * c16 + d, D - 1) * EMB + r];
+        } else {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) xd[16 * c16 + d] = 0.f;
+        }
+    }
     // b0[c0 + tid]  (every lane loads: a divergent branch around loads makes the compiler drain ALL loads at its end)
     const int be0 = a.L.b0 + c0 + (tid & (FZ_SC - 1));
     const float bp0 = a.p[be0];

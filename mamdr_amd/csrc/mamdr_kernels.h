@@ -276,33 +276,48 @@ struct DmWave {
     float r[8], w[8];          // partials of the batch's domain row / of the row this workgroup writes back
     float rp, rm, rv, wp, wm, wv;
 };
-__device__ __forceinline__ void dm_wave_begin(const TowerArgs& a, int tile, int d_read, bool do_read, DmWave& t) {
+// addresses first (pure arithmetic, from the domain the caller expects: done while the row bookkeeping's loads are in
+// flight), loads second (behind the bookkeeping barrier: a dozen instructions)
+struct DmWaveAddr {
+    const float* rb;           // partial 8 q of column c of row dm_hint; + k * plane for the others
+    const float* wb;           // ... of row `tile`
+    const float* rs;           // snapshot p of (dm_hint, c); + plane: m, + 2 plane: v
+    const float* ws;           // snapshot (or live) p of (tile, c)
+};
+__device__ __forceinline__ void dm_wave_addr(const TowerArgs& a, int tile, DmWaveAddr& q) {
     const int lane = (int)threadIdx.x & 63, l = lane & 15, gq = lane >> 4, c = 16 * ((int)threadIdx.x >> 6) + l;
+    const size_t plane = (size_t)a.n_domain * EMB;
+    const size_t er = (size_t)a.dm_hint * EMB + c, ew = (size_t)min(tile, a.n_domain - 1) * EMB + c;
+    q.rb = a.dms.pdm + (size_t)(8 * gq) * plane + er;
+    q.wb = a.dms.pdm + (size_t)(8 * gq) * plane + ew;
+    q.rs = a.dms.snap + er;
+    q.ws = (a.dms.snap ? a.dms.snap : a.dm_live_p) + ew;
+}
+__device__ __forceinline__ void dm_wave_begin(const TowerArgs& a, int tile, bool do_read, const DmWaveAddr& q, DmWave& t) {
     const bool pend = a.dms.snap != nullptr, wr = tile < a.n_domain;      // uniform
     const size_t plane = (size_t)a.n_domain * EMB;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t.r[k] = t.w[k] = 0.f;
     t.rp = t.rm = t.rv = t.wp = t.wm = t.wv = 0.f;
     if (pend && do_read) {
-        const size_t e = (size_t)d_read * EMB + c;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t.r[k] = a.dms.pdm[(size_t)(8 * gq + k) * plane + e];
-        t.rp = a.dms.snap[e];
-        t.rm = a.dms.snap[plane + e];
-        t.rv = a.dms.snap[2 * plane + e];
+        for (int k = 0; k < 8; ++k) t.r[k] = q.rb[(size_t)k * plane];
+        t.rp = q.rs[0];
+        t.rm = q.rs[plane];
+        t.rv = q.rs[2 * plane];
     }
     if (wr) {
-        const size_t e = (size_t)tile * EMB + c;
         if (pend) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t.w[k] = a.dms.pdm[(size_t)(8 * gq + k) * plane + e];
-            t.wp = a.dms.snap[e];
-            t.wm = a.dms.snap[plane + e];
-            t.wv = a.dms.snap[2 * plane + e];
+            for (int k = 0; k < 8; ++k) t.w[k] = q.wb[(size_t)k * plane];
+            t.wp = q.ws[0];
+            t.wm = q.ws[plane];
+            t.wv = q.ws[2 * plane];
         } else {
-            t.wp = a.dm_live_p[e];
-            t.wm = a.dm_live_m[e];
-            t.wv = a.dm_live_v[e];
+            const size_t off = (size_t)(q.ws - a.dm_live_p);
+            t.wp = q.ws[0];
+            t.wm = a.dm_live_m[off];
+            t.wv = a.dm_live_v[off];
         }
     }
 }

@@ -308,6 +308,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
     // the caller's expected domain, its loads -- misses to HBM -- delayed the x rows by 1.5 K cycles; measured)
     DmWave dmt;
+    DmWaveAddr dma;
+    if (dmw) dm_wave_addr(a, tile, dma);
     const int ecol = tid & 255, erow2 = tid >> 8;                // epilogue ownership for N = 256: rows erow2, erow2 + 2
     const float b0r = P[a.L.b0 + ecol];
     const float b1r = P[a.L.b1 + (tid & 127)];
@@ -355,8 +357,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // partials were written by the previous kernel -- sat in the CU's miss queue ahead of the bookkeeping's
     // second dependent load and delayed the whole gather)
     const bool pend = a.dms.snap != nullptr;
-    const bool same = pend && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
-    if (dmw) dm_wave_begin(a, tile, rowi[8], same, dmt);
+    // (one domain per tile AND the one the caller announced: the addresses were formed from it)
+    const bool same = pend && rowi[8] == a.dm_hint && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
+    if (dmw) dm_wave_begin(a, tile, same, dma, dmt);
     T4STAMP_W4(1);
     // (a scalar branch around the whole block: the loads inside sit in divergent branches, at whose end the compiler
     // drains EVERY outstanding load -- including the partials just requested, a full round trip to HBM)
