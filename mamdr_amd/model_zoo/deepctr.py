@@ -83,8 +83,11 @@ class DeepCTR(BaseModel):
         kw = {}
         if "uncertainty_weight" in mc["name"]:     # run.py:49-50: the weighted loss joins the compiled model
             kw["uncertainty_weight"] = True
+        # deepctr.py:104-116: `trainable=emb_trainable` reaches SparseFeat only on the pretrained branch; without
+        # pretrained tables the column is built with deepctr's default (trainable) WHATEVER emb_trainable says
+        self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
         eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
-                      emb_trainable=bool(tc["emb_trainable"]), tower=tower, emb_dim=mc["user_dim"],
+                      emb_trainable=self.tables_trainable, tower=tower, emb_dim=mc["user_dim"],
                       hidden=tuple(mc["hidden_dim"]), **kw)
         self.init_rs = np.random.RandomState(self.dataset.seed)
         pre = bool(tc["load_pretrain_emb"])
@@ -92,7 +95,7 @@ class DeepCTR(BaseModel):
         if pre and self.pretrained[0] is None:
             raise ValueError("load_pretrain_emb is set but the dataset has no pretrained tables")
         tensors = self.draw_initial_tensors()
-        if not tc["emb_trainable"]:
+        if not self.tables_trainable:
             eng.bind_table("user_emb", tensors["user_emb"])
             eng.bind_table("item_emb", tensors["item_emb"])
         for split, store in (("train", self.dataset.train_dataset), ("val", self.dataset.val_dataset),

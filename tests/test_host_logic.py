@@ -390,6 +390,19 @@ def test_finetune_stage_follows_the_oracle(tmp_path, monkeypatch, name):
     assert [t[2] for t in trace] == [c[1] for c in eng.calls]
 
 
+def test_tables_without_pretraining_always_train(tmp_path, monkeypatch):
+    """deepctr.py:104-116: `trainable=emb_trainable` is passed to SparseFeat only on the pretrained branch; with
+    load_pretrain_emb false the tables take deepctr's default and train even when emb_trainable is false."""
+    patch_emb_dim(monkeypatch)
+    for pre, flag, want in ((True, False, False), (True, True, True), (False, False, True), (False, True, True)):
+        cfg = tiny_config(tmp_path, "mlp")
+        cfg["train"].update(load_pretrain_emb=pre, emb_trainable=flag)
+        ds = mds.MultiDomainDataset(cfg["dataset"])
+        m = cli.build_model(cfg, ds, FakeEngine)
+        assert m.model.oracle.emb_trainable is want, (pre, flag)
+        assert ("user_emb" in m.model.segments) is want
+
+
 def test_early_stop_counts_ties(tmp_path, monkeypatch):
     patch_emb_dim(monkeypatch)
     cfg = tiny_config(tmp_path, "mlp")

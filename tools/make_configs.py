@@ -1,0 +1,70 @@
+"""Derive the dataset variants of the run configurations from this repo's Taobao-10 templates.
+
+The reference ships one directory of JSON files per dataset split (config/{Taobao-10,Taobao_20,Taobao_30,Amazon_6,
+Amazon_13}): the files of a split differ from the Taobao-10 ones only in the dataset section (name, paths), in
+`train.sample_num`, and -- for Amazon, which has no pretrained embeddings -- in `load_pretrain_emb: false,
+emb_trainable: true`.  This script writes those variants for the towers built here (mlp, star; the plain,
+Domain Negotiation and MAMDR entries), keeping every other value of the templates.  mmoe / ple / shared_bottom
+configurations are not written: those towers are not built (mamdr_amd/cli.py raises for them).
+
+usage: python tools/make_configs.py    (idempotent; writes under config/)"""
+import copy
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "config")
+
+
+def load(name):
+    with open(os.path.join(CFG, "Taobao-10", name)) as f:
+        return json.load(f)
+
+
+SPLITS = {
+    # directory: dataset overrides, train overrides, MAMDR sample_num, star file name
+    "Taobao_20": (dict(domain_split_path="split_by_theme_20", synthetic="taobao20"), {}, 19, "star_taobao.json"),
+    "Taobao_30": (dict(domain_split_path="split_by_theme_30", synthetic="taobao30", batch_size=4096), {}, 5,
+                  "star_taobao.json"),
+    "Amazon_6": (dict(name="Amazon", dataset_path="dataset/Amazon", domain_split_path="split_by_category_6",
+                      synthetic="amazon6"), dict(load_pretrain_emb=False, emb_trainable=True), 3, "star.json"),
+    "Amazon_13": (dict(name="Amazon", dataset_path="dataset/Amazon", domain_split_path="split_by_category_13",
+                       synthetic="amazon13"), dict(load_pretrain_emb=False, emb_trainable=True), 5, "star.json"),
+}
+# output file -> (template in config/Taobao-10, per-file train overrides)
+FILES = {
+    "deepctr.json": ("deepctr_taobao_10.json", {}),
+    "deepctr_DN.json": ("deepctr_DN_taobao_10.json", {}),
+    "deepctr_DN+DR.json": ("deepctr_DN+DR.json", "sample_num"),
+    "STAR": ("star_taobao.json", "star"),
+}
+
+
+def main():
+    written = []
+    for split, (ds_over, tr_over, sample_num, star_name) in SPLITS.items():
+        os.makedirs(os.path.join(CFG, split), exist_ok=True)
+        for out, (template, extra) in FILES.items():
+            cfg = copy.deepcopy(load(template))
+            cfg["dataset"].update(ds_over)
+            cfg["train"].update(tr_over)
+            if extra == "sample_num":
+                cfg["train"]["sample_num"] = sample_num
+            name = out
+            if extra == "star":
+                name = star_name
+                cfg["model"]["name"] = "star"              # the reference's per-split star files train the plain tower
+                for k in ("meta_parms",):
+                    cfg["train"].pop(k, None)
+            path = os.path.join(CFG, split, name)
+            if os.path.exists(path):                       # hand-written entries (the BASELINE configs) stay
+                continue
+            with open(path, "w") as f:
+                json.dump(cfg, f, indent=2)
+                f.write("\n")
+            written.append(os.path.relpath(path, ROOT))
+    print("\n".join(written) if written else "nothing to write")
+
+
+if __name__ == "__main__":
+    main()
