@@ -418,8 +418,13 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         # batches <= 2048 rows launch the 4-row-tile kernel (mamdr_api.hip: use4), template <DX, FM>
         use4 = batch <= 2048 and tower != "star" and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
         fm = ", true>" if tower == "deepfm" else ", false>"
-        kname = ("k_tower4<true" if trainable else "k_tower4<false") + fm if use4 else \
-            ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
+        if use4:
+            # template <DX, FM, W1L>; W1L (the W1 image in LDS) at one 4-row tile per CU or less (tower4_kernels.hip)
+            tiles4 = -(-batch // 16) * 4
+            w1l = tiles4 <= torch.cuda.get_device_properties(eng.device).multi_processor_count
+            kname = ("k_tower4<true" if trainable else "k_tower4<false") + fm[:-1] + (", true>" if w1l else ", false>")
+        else:
+            kname = ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
         if tower == "star":
             kname = "k_tower<true, 384, false>"
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows,

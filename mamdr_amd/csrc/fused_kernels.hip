@@ -613,8 +613,14 @@ __global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
     if (i >= a.n) {
         // rows up to the next multiple of 16: k_wgrad_adam contracts whole 16-row tiles (against zero gradients for
         // the padding rows, but 0 x garbage must stay 0)
-        if (i < (a.n + 15) / 16 * 16)
+        // (and carry the pass's domain: a tower tile compares all of its rows' domains with the caller's)
+        if (i < (a.n + 15) / 16 * 16) {
             *reinterpret_cast<f32x4*>(a.xpre + (size_t)i * (2 * EMB) + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (lane == 0) {
+                a.pdom[i] = a.pad_dom;
+                a.plabel[i] = 0.f;
+            }
+        }
         return;
     }
     int64_t src = a.perm ? (int64_t)a.perm[a.pos0 + i] : a.pos0 + i;

@@ -1017,8 +1017,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     // ... and on that path the rows of the whole call are resolved and gathered once (frozen tables; 4-row tower)
     const int64_t pre_pos0 = first_step * batch;
     const int64_t pre_n = std::min<int64_t>((first_step + n_steps) * (int64_t)batch, pass_rows) - pre_pos0;
-    const bool pre = fused && c->use_pre && may_use4 && n_steps > 0 && pre_n > 0 &&
-                     (c->tower_tile == 4 || (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= 2048);
+    const bool pre = fused && c->use_pre && n_steps > 0 && pre_n > 0;
     if (pre) {
         if (pre_n > c->pre_cap) {
             const int64_t cap = pre_n + pre_n / 4 + 1024;
@@ -1044,6 +1043,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         pa.n_user = c->cfg.n_user;
         pa.n_item = c->cfg.n_item;
         pa.n_domain = c->cfg.n_domain;
+        pa.pad_dom = domain;
         pa.xpre = c->xpre;
         pa.pdom = c->pdom;
         pa.plabel = c->plabel;
@@ -1124,13 +1124,12 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.wT = c->wT;
         float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
-        const bool use4_now = use4;
         if (fused) {
             ta.w0dom_snap = c->w0dom_copy;
             c->dm_cur ^= 1;
             ta.dms = dm_pending;                       // the previous step of this call (snap == null: none)
             ta.dm_hint = domain;
-            if (pre && use4_now) {
+            if (pre) {
                 ta.xpre = c->xpre + (size_t)(row_base - pre_pos0) * 2 * EMB;
                 ta.pdom = c->pdom + (row_base - pre_pos0);
                 ta.plabel = c->plabel + (row_base - pre_pos0);

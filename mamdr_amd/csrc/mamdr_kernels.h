@@ -500,6 +500,7 @@ struct PassPrepArgs {
     const int32_t* perm;       // nullable
     int64_t pos0, n, n_rows_split;
     int n_user, n_item, n_domain;
+    int pad_dom;               // domain written for the padding rows (the pass's domain)
     float* xpre;
     int32_t* pdom;
     float* plabel;

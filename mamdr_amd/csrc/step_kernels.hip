@@ -347,12 +347,48 @@ __device__ __forceinline__ int early_perm(const TowerArgs& a, int r0) {
     const int64_t pc = a.row_base + min(r0 + (int)(threadIdx.x & (TILE_ROWS - 1)), max(a.rows - 1, 0));
     return a.perm[pc];
 }
+// pre-gathered pass (k_pass_prep): the tile's sixteen [user | item] rows (2 float4 per lane), domains and labels sit
+// at known addresses -- requested before anything else, no dependent chain
+struct PreTile {
+    f32x4 x[2];
+    int dom;
+    float lab;
+};
+__device__ __forceinline__ void early_pre(const TowerArgs& a, int r0, PreTile& t) {
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + TOWER_THREADS * u;                 // 16 rows x 64 float4
+        const int rr = min(r0 + (e >> 6), max(a.rows - 1, 0));
+        t.x[u] = *reinterpret_cast<const f32x4*>(a.xpre + (size_t)rr * (2 * EMB) + 4 * (e & 63));
+    }
+    const int rb = min(r0 + (tid & (TILE_ROWS - 1)), max(a.rows - 1, 0));
+    t.dom = a.pdom[rb];
+    t.lab = a.plabel[rb];
+}
 __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int r0, float* gx, int gx_ld,
-                                            const bool dmw = false, const int* perm_src = nullptr) {
+                                            const bool dmw = false, const int* perm_src = nullptr,
+                                            const PreTile* pt = nullptr) {
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
     float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;
     const int tid = threadIdx.x;
-    if (tid < TILE_ROWS) {
+    const bool pre = pt != nullptr;
+    if (pre) {
+        if (tid < TILE_ROWS) {
+            rowi[tid] = 0;
+            rowi[TILE_ROWS + tid] = 0;
+            rowi[2 * TILE_ROWS + tid] = pt->dom;
+            rowi[3 * TILE_ROWS + tid] = (r0 + tid) < a.rows ? 1 : 0;
+            rowf[tid] = pt->lab;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + TOWER_THREADS * u, row = e >> 6;
+            f32x4 v = pt->x[u];
+            if (r0 + row >= a.rows) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(smem + XS_OFF + row * XS_LD + 4 * (e & 63)) = v;
+        }
+    } else if (tid < TILE_ROWS) {
         const bool valid = (r0 + tid) < a.rows;
         int64_t pos = a.row_base + r0 + tid;
         int64_t src = 0;
@@ -401,6 +437,10 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
             }
             continue;
         }
+        if (pre && seg < 2) {          // already in LDS
+            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
         v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * TILE_ROWS + row] * EMB + off);
     }
@@ -418,6 +458,7 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
             for (int k = 0; k < 4; ++k) v[u][k] = __fadd_rn(__fmul_rn(v[u][k], sc[k]), sh[k]);
         }
         if (same && (c4 >> 5) == 2) continue;        // filled behind the barrier below
+        if (pre && (c4 >> 5) < 2) continue;          // pre-gathered pass: in LDS already, not copied to the workspace
         if (!rowi[3 * TILE_ROWS + row]) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(xs + row * XS_LD + c4 * 4) = v[u];
         if (gx) *reinterpret_cast<f32x4*>(gx + (size_t)row * gx_ld + c4 * 4) = v[u];
@@ -505,7 +546,10 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     constexpr int PFB0V = DXN > 2 * EMB ? 2 : PFB0;
     BwdW<H1, DXN, H1, PFB0V, 8> bw0;
     STAMP(0);
-    const int perm_src = early_perm(a, r0);
+    const bool pre = TRAIN && a.xpre != nullptr;
+    PreTile pt;
+    if (pre) early_pre(a, r0, pt);
+    const int perm_src = pre ? 0 : early_perm(a, r0);
     __builtin_amdgcn_sched_barrier(0);
     fw0.prefetch(P + a.L.w0, P + a.L.b0);
     if (TRAIN) tower_snapshots(a, TOWER_THREADS, n_tiles);
@@ -513,7 +557,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
     const float gb_reg = P[a.L.gb];
 
-    gather_tile(a, smem, r0, acts_t, ACT_LD, dmw, &perm_src);
+    gather_tile(a, smem, r0, acts_t, ACT_LD, dmw, &perm_src, pre ? &pt : nullptr);
     STAMP(1);
     // DeepFM: thread (i, part) owns columns 4 part .. +3 of row i's three fields.  u + i stays in
     // registers for the domain-table gradient (the x tile is overwritten by the backward chain).

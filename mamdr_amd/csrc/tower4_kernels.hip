@@ -11,10 +11,16 @@
 // A wave covers ALL columns of a layer with one 16/8/4-byte load per k (col = V * lane + t), so
 // the 8 waves split the reduction index k instead and are summed through LDS in wave order
 // (fixed order, no atomics).  The backward layers use transposed copies of W1 / W2 kept
-// current by k_update, so they stream rows exactly like the forward layers.  The dropout
+// current by k_update, so they stream rows exactly like the forward layers.  With one workgroup per CU
+// (grids of up to 256 tiles, W1L) W1 is brought into LDS ONCE by LDS-DMA while the gather's misses are
+// outstanding and feeds both layer 1 and its backward contraction (see t4_w1_request).  The dropout
 // stream, loss, and workspace layout are identical to k_tower; results differ only by fp32
 // summation order.  Replaces the same reference call sites (model_zoo/mamdr.py:54,86,97).
 #include <hip/hip_ext.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 
 #include "mamdr_kernels.h"
 
@@ -29,19 +35,25 @@ constexpr int T4_PF = 8;                 // k rows in flight per wave (first lay
 #endif
 constexpr int T4_DEEP = MAMDR_T4_DEEP;   // ring depth of the short layers (diagnostic builds may override it)
 
-// LDS map (floats)
+// LDS map (floats).  dz_l overwrites h_l in place (the gate is read by the thread that writes the gradient); the
+// split-k partials of the 256-column contractions share a slot between waves w and w + 4 (t4_put), so that everything
+// but the W1 image is 30 KB and the image (128 KB) fits beside it in the CU's 160 KB.
 constexpr int T4_XS = 0;                               // [4][384]
-constexpr int T4_H1 = T4_XS + T4_ROWS * XDIM;          // [4][256]
-constexpr int T4_H2 = T4_H1 + T4_ROWS * H1;            // [4][128]
-constexpr int T4_H3 = T4_H2 + T4_ROWS * H2;            // [4][64]
-constexpr int T4_DZ3 = T4_H3 + T4_ROWS * H3;           // [4][64]
-constexpr int T4_DZ2 = T4_DZ3 + T4_ROWS * H3;          // [4][128]
-constexpr int T4_DZ1 = T4_DZ2 + T4_ROWS * H2;          // [4][256] (trainable tables: input of the dx contraction)
-constexpr int T4_RED = T4_DZ1 + T4_ROWS * H1;          // [8 waves][4][256] split-k partials
-constexpr int T4_ROWI = T4_RED + T4_WAVES * T4_ROWS * H1;
-constexpr int T4_LDS_FLOATS = T4_ROWI + 64;
+constexpr int T4_H1 = T4_XS + T4_ROWS * XDIM;          // [4][256]  h1, then dz1 (trainable tables: input of the dx contraction)
+constexpr int T4_H2 = T4_H1 + T4_ROWS * H1;            // [4][128]  h2, then dz2
+constexpr int T4_DZ3 = T4_H2 + T4_ROWS * H2;           // [4][64]
+constexpr int T4_DZ2 = T4_H2;
+constexpr int T4_DZ1 = T4_H1;
+constexpr int T4_RED = T4_DZ3 + T4_ROWS * H3;          // split-k partials: [8 waves][4][N <= 128] or [4 wave pairs][4][256]
+constexpr int T4_RED_FLOATS = 4 * T4_ROWS * H1;
+constexpr int T4_ROWI = T4_RED + T4_RED_FLOATS;
+constexpr int T4_W1S = T4_ROWI + 64;                   // W1L: [256][128] image of W1, 16-B chunks XOR-swizzled per row
+constexpr int T4_LDS_FLOATS = T4_W1S;
+constexpr int T4_LDS_FLOATS_W1L = T4_W1S + H1 * H2;
+static_assert(T4_LDS_FLOATS_W1L * sizeof(float) <= 160 * 1024, "LDS of a gfx950 CU");
+static_assert(T4_WAVES * T4_ROWS * H2 <= T4_RED_FLOATS, "one slot per wave up to 128 columns");
 
-size_t tower4_lds_bytes() { return T4_LDS_FLOATS * sizeof(float); }
+size_t tower4_lds_bytes(bool w1l) { return (w1l ? T4_LDS_FLOATS_W1L : T4_LDS_FLOATS) * sizeof(float); }
 
 // Workspace stores of the activations / gradients: WRITE-THROUGH (agent-scope relaxed atomic store = global_store
 // ... sc1).  With plain stores the 3.7 MB a step writes sit dirty in the eight L2s until the kernel ends and are
@@ -67,6 +79,7 @@ template <> struct Vec4T<1> { typedef float type; };
 template <int V>
 __device__ __forceinline__ void t4_load(float (&b)[V], const float* __restrict__ p) {
     typedef typename Vec4T<V>::type T;
+
     const T v = *reinterpret_cast<const T*>(p);
     if constexpr (V == 1) {
         b[0] = v;
@@ -86,6 +99,11 @@ struct T4W {
     static constexpr int V = N / 64;
     static constexpr int KW = K / T4_WAVES;
     static constexpr int PF = KW < DEPTH ? KW : DEPTH;
+#ifdef T4_ABLATE_W1          // diagnostic build: layer 1 / its backward without their weight streams
+    static constexpr bool LOADS = !((K == H1 && N == H2) || (K == H2 && N == H1));
+#else
+    static constexpr bool LOADS = true;
+#endif
     float b[PF][V];
     static __device__ __forceinline__ const float* wptr(const float* __restrict__ W) {
         return W + (size_t)((threadIdx.x >> 6) * KW) * N + V * (threadIdx.x & 63);
@@ -93,10 +111,58 @@ struct T4W {
     __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
         const float* wp = wptr(W);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) t4_load<V>(b[u], wp + (size_t)u * N);
+        for (int u = 0; u < PF; ++u) {
+            if constexpr (LOADS) t4_load<V>(b[u], wp + (size_t)u * N);
+            else for (int t = 0; t < V; ++t) b[u][t] = 1.0f;
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 };
+
+// Split-k partials of a wave -> LDS `red` as [slot][row][column].  D register r of lane l is row r; its column is
+// V*l + t (lane-major, one vector store per row) or l + 64 t (STRIDED: the LDS-fed backward contraction).
+// N <= 128: slot = wave.  N = 256: waves w and w + 4 share slot w -- waves 4..7 store, barrier, waves 0..3 add their
+// own partial (p_w + p_{w+4}) -- and t4_sum adds the four slots in order.
+template <int N, int V, bool STRIDED>
+__device__ __forceinline__ void t4_put(const f32x4 (&acc)[V], float* red) {
+    typedef typename Vec4T<V>::type T;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr bool PAIRED = N > H2;
+    float* slot = red + ((PAIRED ? (w & 3) : w) * T4_ROWS) * N;
+    if (!PAIRED || w >= 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (STRIDED) {
+#pragma unroll
+                for (int t = 0; t < V; ++t) slot[r * N + lane + 64 * t] = acc[t][r];
+            } else if constexpr (V == 1) {
+                slot[r * N + lane] = acc[0][r];
+            } else {
+                T v;
+#pragma unroll
+                for (int t = 0; t < V; ++t) v[t] = acc[t][r];
+                *reinterpret_cast<T*>(slot + r * N + V * lane) = v;
+            }
+        }
+    }
+    if constexpr (PAIRED) {
+        __syncthreads();
+        if (w < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (STRIDED) {
+#pragma unroll
+                    for (int t = 0; t < V; ++t) slot[r * N + lane + 64 * t] = acc[t][r] + slot[r * N + lane + 64 * t];
+                } else {
+                    T v = *reinterpret_cast<const T*>(slot + r * N + V * lane);
+#pragma unroll
+                    for (int t = 0; t < V; ++t) v[t] = acc[t][r] + v[t];
+                    *reinterpret_cast<T*>(slot + r * N + V * lane) = v;
+                }
+            }
+        }
+    }
+}
 
 // partial[w][4][N] = A[4][k-range of wave w] . W[k-range][N]   (into LDS `red`)
 template <int K, int N, int DEPTH, typename Mid>
@@ -120,7 +186,7 @@ __device__ __forceinline__ void t4_contract(T4W<K, N, DEPTH>& tw, const float* _
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int t = 0; t < V; ++t) acc[t] = MAMDR_MFMA4(a4[u], tw.b[q + u][t], acc[t]);
-                t4_load<V>(tw.b[q + u], wp + (size_t)(k0 + q + u + PF) * N);
+                if constexpr (T4W<K, N, DEPTH>::LOADS) t4_load<V>(tw.b[q + u], wp + (size_t)(k0 + q + u + PF) * N);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -136,19 +202,7 @@ __device__ __forceinline__ void t4_contract(T4W<K, N, DEPTH>& tw, const float* _
         __builtin_amdgcn_sched_barrier(0);
     }
     mid();
-    // D register r of lane l = row r, column V*l + t
-    typedef typename Vec4T<V>::type T;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        T v;
-        if constexpr (V == 1) {
-            v = acc[0][r];
-        } else {
-#pragma unroll
-            for (int t = 0; t < V; ++t) v[t] = acc[t][r];
-        }
-        *reinterpret_cast<T*>(red + (w * T4_ROWS + r) * N + V * lane) = v;
-    }
+    t4_put<N, V, false>(acc, red);
 }
 
 // ---- layer 0 (384 -> 256) with the reduction index split in TWO segments per wave: the [user | item] part first
@@ -172,18 +226,16 @@ struct T4L0 {
         __builtin_amdgcn_sched_barrier(0);
     }
 };
+// (`acc`: zeroed by the caller -- see k_tower4, where the registers are claimed before the gather)
 template <typename MidSeg, typename Mid>
 __device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict__ W, const float* xs, float* red,
-                                               MidSeg midseg, Mid mid) {
+                                               f32x4 (&acc)[4], MidSeg midseg, Mid mid) {
     static_assert(T4_PF == 8, "two segments of 32 and 16 rows, 8-deep ring");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* wp1 = T4L0::wptr1(W);
     const float* wp2 = T4L0::wptr2(W);
     const float* ap1 = xs + (lane & 3) * XDIM + 32 * w;
     const float* ap2 = xs + (lane & 3) * XDIM + 2 * EMB + 16 * w;
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto chunk = [&](const float* ap, const float* next, bool reload) {
 #pragma unroll
         for (int q = 0; q < T4_PF; q += 4) {
@@ -205,18 +257,115 @@ __device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict
     chunk(ap2, wp2 + (size_t)8 * H1, true);
     chunk(ap2 + 8, wp2, false);
     mid();
-    // D register r of lane l = row r, columns 4 l .. 4 l + 3
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(red + (w * T4_ROWS + r) * H1 + 4 * lane) = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    t4_put<H1, 4, false>(acc, red);
 }
 
-// sum of the 8 wave partials of output (row, col), wave order
+// ---- W1L: W1 [256][128] in LDS.  LDS-DMA (global_load_lds_dwordx4: 16 B per lane, two rows per wave instruction, 16
+// instructions per wave, no registers) writes a lane-linear image, so the swizzle sits on the SOURCE address: the 16-B
+// chunk q of row r lives at chunk position q ^ (r & 31).  Requested at kernel start, the 128 KB arrive while the
+// gather's misses are outstanding (probe, tools/probes/glds_probe.hip: 2.6 K cycles with all 256 workgroups
+// streaming, reads of either pattern conflict-free).  Forward (layer 1): row k of the image is read as 64 x 8 B
+// (lane l: columns 2 l, 2 l + 1).  Backward (dz2 . W1^T): lane l reads the chunk of rows l + 64 t holding columns
+// 4 q .. 4 q + 3 -- four consecutive k of the transposed contraction -- 8 lanes hit 8 different chunk positions.
+// W1 is streamed once per workgroup instead of twice (W1 and its transposed copy), and neither contraction waits on L2.
+// The requests are inline asm, i.e. NOT in the compiler's vmcnt bookkeeping: a counted LDS-DMA makes hipcc wait
+// vmcnt(0) at the next use of any load, which put the whole (cold: the weights were just rewritten by another
+// kernel) stream in front of the gather (stamps: +2.3 K cycles).  Uncounted, they only make the compiler's counted
+// waits conservative (vmcnt retires in order); issued behind every other load of the prologue they are waited for by
+// nobody until t4_w1_landed() at the end of layer 0.
+template <int ROWS>
+__device__ __forceinline__ void t4_w1_request(const float* __restrict__ W1, float* w1s, const int row0) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(w1s + row0 * H2));
+#pragma unroll
+    for (int kk = 0; kk < ROWS; kk += 2) {
+        const int k = row0 + kk + (lane >> 5);
+        const float* src = W1 + k * H2 + 4 * ((lane & 31) ^ (k & 31));
+        const uint32_t dst = base + kk * H2 * 4;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+// every request of this wave has landed (a workgroup barrier must follow before another wave reads the image)
+__device__ __forceinline__ void t4_w1_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// forward: the wave's 32 rows in chunks of 8, the next chunk's reads issued before the current chunk's MFMAs
+template <typename Mid>
+__device__ __forceinline__ void t4_contract_w1f(const float* w1s, const float* As, float* red, Mid mid) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* ap = As + (lane & 3) * H1 + 32 * w;
+    const float* wp = w1s + (32 * w) * H2 + 2 * (lane & 1);
+    const int half = lane >> 1;
+    f32x4 acc[2];
+    acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x2 b[2][8];
+    f32x4 a4[2][2];
+    auto request = [&](int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 8 * c + u;                              // = row & 31 (the wave's first row is a multiple of 32)
+            b[buf][u] = *reinterpret_cast<const f32x2*>(wp + k * H2 + 4 * (half ^ k));
+        }
+        a4[buf][0] = *reinterpret_cast<const f32x4*>(ap + 8 * c);
+        a4[buf][1] = *reinterpret_cast<const f32x4*>(ap + 8 * c + 4);
+    };
+    request(0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cur = c & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < 4) request(c + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[0] = MAMDR_MFMA4(a4[cur][u >> 2][u & 3], b[cur][u][0], acc[0]);
+            acc[1] = MAMDR_MFMA4(a4[cur][u >> 2][u & 3], b[cur][u][1], acc[1]);
+        }
+    }
+    mid();
+    t4_put<H2, 2, false>(acc, red);
+}
+// backward: the wave's 4 chunk columns (16 k of the transposed contraction), reads one chunk column ahead
+template <typename Mid>
+__device__ __forceinline__ void t4_contract_w1b(const float* w1s, const float* As, float* red, Mid mid) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* ap = As + (lane & 3) * H2 + 16 * w;
+    const float* rp = w1s + lane * H2;
+    const int sw = lane & 31;                                     // (l + 64 t) & 31
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 b[2][4], a4[2];
+    auto request = [&](int c, int buf) {
+        const int pos = 4 * ((4 * w + c) ^ sw);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[buf][t] = *reinterpret_cast<const f32x4*>(rp + t * 64 * H2 + pos);
+        a4[buf] = *reinterpret_cast<const f32x4*>(ap + 4 * c);
+    };
+    request(0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cur = c & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < 4) request(c + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MAMDR_MFMA4(a4[cur][j], b[cur][t][j], acc[t]);
+    }
+    mid();
+    t4_put<H1, 4, true>(acc, red);
+}
+
+// sum of the partials of output (row, col), slot order (8 wave slots, or 4 wave-pair slots at 256 columns: t4_put)
 template <int N>
 __device__ __forceinline__ float t4_sum(const float* red, int row, int col) {
+    constexpr int SLOTS = N > H2 ? 4 : T4_WAVES;
     float s = red[row * N + col];
 #pragma unroll
-    for (int w = 1; w < T4_WAVES; ++w) s += red[(w * T4_ROWS + row) * N + col];
+    for (int w = 1; w < SLOTS; ++w) s += red[(w * T4_ROWS + row) * N + col];
     return s;
 }
 
@@ -258,7 +407,7 @@ __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ?
 // DX: trainable user / item tables -> d loss / d [user | item] row = dz1 . W0[0:256,:]^T through the
 // transposed copy W0T (kept current by k_update), row ids + representatives for the table update.
 // FM: DeepFM tower (logit += linear tables + FM second-order term), as in k_tower.
-template <bool DX, bool FM>
+template <bool DX, bool FM, bool W1L>
 __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -274,11 +423,19 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
     // weights and small parameters first: they do not depend on the gather
     T4L0 w0;
-    T4W<H1, H2, T4_DEEP> w1;
-    T4W<H2, H3, T4_DEEP> w2;
+    T4W<H1, H2, T4_DEEP> w1;      // (W1L: unused, W1 is in LDS)
+    T4W<H2, H3, W1L ? 16 : T4_DEEP> w2;      // W1L: the wave's whole share in flight, requested across the LDS-fed layer 1
     T4W<H3, H2> v2;      // backward: dz3 . W2^T through the transposed copy W2T [64][128]
-    T4W<H2, H1, T4_DEEP> v1;      // backward: dz2 . W1^T through W1T [128][256]
+    T4W<H2, H1, T4_DEEP> v1;      // backward: dz2 . W1^T through W1T [128][256] (W1L: unused)
+    float* w1s = smem + T4_W1S;
     T4W<H1, 2 * EMB> v0; // DX: dz1 . W0[0:256,:]^T through W0T [256][256]
+    // layer 0's accumulators are zeroed HERE: initialised in front of the contraction, they took the registers of the
+    // gather's (divergent-branch) table loads and the compiler drained every outstanding load -- the pending
+    // domain-table partials, HBM misses needed only between layer 0's segments -- before the gather-end barrier
+    f32x4 acc0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc0[2]), "+v"(acc0[3]));
     T4REAL(10);
     T4STAMP(0);
     // the row bookkeeping's first dependent load (perm) goes out before everything else: loads retire in order, so
@@ -316,6 +473,15 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const float b2r = P[a.L.b2 + (tid & 63)];
     const float wor = P[a.L.wo + (tid & 63)];
     const float gbr = P[a.L.gb];
+    __builtin_amdgcn_sched_barrier(0);
+    // W1 image: behind every other load of the prologue (uncounted requests make the counted waits ahead of them
+    // conservative by their number: the wait for the x rows then also covers layer 0's first ring rows and ONE request).
+    // Variants measured (k_tower4 at 1,024 rows, us): requests by every wave here 14.0-14.2; by waves 4..7 only (which
+    // consume nothing before layer 0) 14.3-14.6 -- they sit in the issue queue until most of the image has landed and
+    // hold the bookkeeping barrier; the same without that barrier (domains by scalar loads) 14.9; counted requests
+    // (__builtin_amdgcn_global_load_lds: vmcnt(0) at the first use of any load) 14.6; no image 15.1-15.3.
+    if (W1L && pre) t4_w1_request<32>(P + a.L.w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- row bookkeeping + embedding gather (4 rows x 96 float4)
     if (pre) {
@@ -348,17 +514,15 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         rowf[tid] = a.label[src];
     }
     __syncthreads();
-    // domain-table step still pending (DmStep): the domain rows as that step leaves them.  The row of the expected
-    // domain was requested at kernel start; if the batch's rows carry another domain every lane works alone.
-    // (LDS scratch: `red`, unused until layer 0 ends.)
+    // domain-table step still pending (DmStep): the domain rows as that step leaves them.  `same`: one domain per tile
+    // AND the one the caller announced (the addresses were formed from it); otherwise every lane works alone.
+    const bool pend = a.dms.snap != nullptr;
+    const bool same = pend && rowi[8] == a.dm_hint && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
     T4STAMP(12);
     T4STAMP_W4(0);
     // (requested only now, beside the table rows: at kernel start these loads -- misses all the way to HBM, the
     // partials were written by the previous kernel -- sat in the CU's miss queue ahead of the bookkeeping's
     // second dependent load and delayed the whole gather)
-    const bool pend = a.dms.snap != nullptr;
-    // (one domain per tile AND the one the caller announced: the addresses were formed from it)
-    const bool same = pend && rowi[8] == a.dm_hint && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
     if (dmw) dm_wave_begin(a, tile, same, dma, dmt);
     T4STAMP_W4(1);
     // (a scalar branch around the whole block: the loads inside sit in divergent branches, at whose end the compiler
@@ -381,6 +545,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         }
     }
     // (pending + one-domain tile: the domain columns of x are filled between layer 0's two segments, see midseg)
+    // (no pre-gathered pass: the gather's dependent loads are younger than anything requested above and would wait
+    // for the image as well -- it is requested only now)
+    if (W1L && !pre) t4_w1_request<32>(P + a.L.w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
     T4STAMP_W4(2);
     __syncthreads();
     if (FM) {
@@ -405,7 +572,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const bool drop = a.use_dropout != 0;
 
     // ---- layer 0: 384 -> 256
-    t4_contract_l0(w0, P + a.L.w0, smem + T4_XS, red,
+    t4_contract_l0(w0, P + a.L.w0, smem + T4_XS, red, acc0,
                    [&]() {
                        if (!dmw) return;
                        // every wave finishes the 16 domain columns ITS second segment contracts (partials requested
@@ -450,7 +617,14 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                        }
                        T4STAMP(15);
                    },
-                   [&]() { w1.prefetch(P + a.L.w1); });
+                   [&]() {
+                       if (W1L) {
+                           t4_w1_landed();           // (layer 0's ring is empty: nothing else is outstanding)
+                           w2.prefetch(P + a.L.w2);
+                       } else {
+                           w1.prefetch(P + a.L.w1);
+                       }
+                   });
     T4STAMP(2);
     if (!pre && tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream (k_wgrad_adam reads
                                                   // a pre-gathered pass in place)
@@ -477,7 +651,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
     T4STAMP(3);
     // ---- layer 1: 256 -> 128
-    t4_contract(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
+    if (W1L) t4_contract_w1f(w1s, smem + T4_H1, red, [&]() { v2.prefetch(a.wT + W2T_OFF); });
+    else t4_contract(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
     __syncthreads();
     T4STAMP(4);
     {
@@ -496,8 +671,12 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     T4STAMP(5);
     // ---- layer 2: 128 -> 64 (the backward weights are requested behind its K loop)
     t4_contract(w2, P + a.L.w2, smem + T4_H2, H2, red, [&]() {
-        v2.prefetch(a.wT + W2T_OFF);
-        v1.prefetch(a.wT + W1T_OFF);
+        if (!W1L) {
+            v2.prefetch(a.wT + W2T_OFF);
+            v1.prefetch(a.wT + W1T_OFF);
+        } else if (DX) {
+            v0.prefetch(a.wT + W0T_OFF);
+        }
     });
     __syncthreads();
     T4STAMP(6);
@@ -574,7 +753,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     __syncthreads();
     T4STAMP(8);
     // ---- dz1 = (dz2 . W1^T) * gate(h1); the domain-table gradient follows from dz1 by linearity
-    t4_contract(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
+    if (W1L) t4_contract_w1b(w1s, smem + T4_DZ2, red, []() {});
+    else t4_contract(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -606,18 +786,42 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
 }
 
+// W1L needs the whole LDS of a CU: one workgroup per CU, i.e. grids of up to one tile per CU; larger grids keep the
+// streaming variant (30 KB of LDS, several workgroups per CU overlap each other's phases).
+template <bool DX, bool FM>
+static void launch_tower4_inst(const TowerArgs& a, dim3 grid, bool w1l, hipStream_t s) {
+    static int raised = 0;         // 1: the LDS limit of the W1L instance is raised, -1: refused (streaming variant only)
+    if (w1l && raised == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true));
+        raised = e == hipSuccess ? 1 : -1;
+        if (e != hipSuccess) fprintf(stderr, "mamdr: k_tower4 keeps streaming W1 (%s)\n", hipGetErrorString(e));
+    }
+    if (w1l && raised == 1) MAMDR_LAUNCH((k_tower4<DX, FM, true>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a);
+    else MAMDR_LAUNCH((k_tower4<DX, FM, false>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a);
+}
+static int t4_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
+        if (n <= 0) n = 1;
+        if (const char* e = getenv("MAMDR_T4_NO_W1L")) if (atoi(e)) n = -1;        // diagnostic: streaming variant only
+    }
+    return n;
+}
 void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
-    const dim3 grid(tiles), block(T4_THREADS);
-    const size_t lds = tower4_lds_bytes();
+    const dim3 grid(tiles);
     const bool dx = a.dxe != nullptr;
+    const bool w1l = tiles <= t4_cu_count();
     if (a.deepfm) {
-        if (dx) MAMDR_LAUNCH((k_tower4<true, true>), grid, block, lds, s, a);
-        else MAMDR_LAUNCH((k_tower4<false, true>), grid, block, lds, s, a);
+        if (dx) launch_tower4_inst<true, true>(a, grid, w1l, s);
+        else launch_tower4_inst<false, true>(a, grid, w1l, s);
     } else if (dx) {
-        MAMDR_LAUNCH((k_tower4<true, false>), grid, block, lds, s, a);
+        launch_tower4_inst<true, false>(a, grid, w1l, s);
     } else {
-        MAMDR_LAUNCH((k_tower4<false, false>), grid, block, lds, s, a);
+        launch_tower4_inst<false, false>(a, grid, w1l, s);
     }
 }
 
