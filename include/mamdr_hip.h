@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 6
+#define MAMDR_ABI_VERSION 7
 
 enum {
     MAMDR_OK = 0,
@@ -215,6 +215,13 @@ int mamdr_gather_rows(mamdr_ctx* ctx, int domain, int split, const int32_t* d_pe
  *   MAMDR:        model_zoo/mamdr.py:173-180 (b = merged or dst itself) */
 int mamdr_interp(float* d_dst, const float* d_a, const float* d_b, float scale, int64_t n,
                  void* stream);
+/* average_meta_grad == "moving_mean": `K.moving_average_update(ag, g, 0.999)` (model_zoo/maml.py:219-220,
+ * mldg.py:222-223, pcgrad.py:229-230) = TF 1.12's zero-debiased moving average of the accumulator variable:
+ *   biased[i] -= (biased[i] - value[i]) * decay;   unbiased[i] -= unbiased[i] - biased[i] / denom
+ * decay = float(1 - momentum); denom = 1 - (1 - decay)^local_step, formed by the caller (float32, local_step =
+ * number of updates since the accumulator was created, this one included).  One rounding per operation. */
+int mamdr_moving_average(float* d_unbiased, float* d_biased, const float* d_value, float decay, float denom,
+                         int64_t n, void* stream);
 /* dst[i] = theta[i] + phi[i]  or  theta[i] * phi[i]  (specific_base_model.py:164-172) */
 int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t mode, int64_t n,
                 void* stream);

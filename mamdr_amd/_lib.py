@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -72,6 +72,7 @@ SIGNATURES = {
     "mamdr_eval_domain": (C.c_int, [_VP, C.c_int, C.c_int, _I32, _VP, _VP, _VP]),
     "mamdr_gather_rows": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _I64, _I64, _VP]),
     "mamdr_interp": (C.c_int, [_VP, _VP, _VP, _F, _I64, _VP]),
+    "mamdr_moving_average": (C.c_int, [_VP, _VP, _VP, _F, _F, _I64, _VP]),
     "mamdr_merge": (C.c_int, [_VP, _VP, _VP, _I32, _I64, _VP]),
     "mamdr_dr_advance": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I32, _I32, _I64, _VP]),
     "mamdr_sub": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),

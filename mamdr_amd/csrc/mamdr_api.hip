@@ -1452,6 +1452,15 @@ int mamdr_interp(float* d_dst, const float* d_a, const float* d_b, float scale, 
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }
+int mamdr_moving_average(float* d_unbiased, float* d_biased, const float* d_value, float decay, float denom, int64_t n,
+                         void* stream) {
+    CHECK_VEC(d_unbiased); CHECK_VEC(d_biased); CHECK_VEC(d_value);
+    if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (!(denom > 0.f)) return fail(MAMDR_EINVAL, "moving average: debias denominator %g (local step < 1?)", (double)denom);
+    launch_moving_average(d_unbiased, d_biased, d_value, decay, denom, n, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
 int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t mode, int64_t n, void* stream) {
     CHECK_VEC(d_dst); CHECK_VEC(d_theta); CHECK_VEC(d_phi);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");

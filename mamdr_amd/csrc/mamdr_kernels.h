@@ -646,6 +646,8 @@ void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& next
 
 // outer_kernels.hip (compiled with -ffp-contract=off)
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s);
+void launch_moving_average(float* unbiased, float* biased, const float* value, float decay, float denom, int64_t n,
+                           hipStream_t s);
 void launch_merge(float* dst, const float* t, const float* p, int mode, int64_t n, hipStream_t s);
 void launch_dr_advance(float* phi, float* w, float* merged, const float* theta, float gamma, int mode, int assign, int64_t n,
                        hipStream_t s);

@@ -75,6 +75,34 @@ struct Sub {      // dst = a - b
     __device__ __forceinline__ void one(int64_t i) const { dst[i] = __fsub_rn(a[i], b[i]); }
 };
 
+// K.moving_average_update(ag, g, momentum) with TF 1.12's zero-debiased moving average (maml.py:219-220):
+//   biased -= (biased - value) * decay;  unbiased -= unbiased - biased / denom      (denom = 1 - (1 - decay)^step, host)
+struct MovingAverage {
+    float* unbiased; float* biased; const float* value; float decay, denom;
+    __device__ __forceinline__ void op(float& u, float& b, float g) const {
+        b = __fsub_rn(b, __fmul_rn(__fsub_rn(b, g), decay));
+        u = __fsub_rn(u, __fsub_rn(u, __fdiv_rn(b, denom)));
+    }
+    __device__ __forceinline__ void vec(int64_t i) const {
+        f32x4 u = reinterpret_cast<f32x4*>(unbiased)[i];
+        f32x4 b = reinterpret_cast<f32x4*>(biased)[i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(value)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float uc = u[c], bc = b[c];
+            op(uc, bc, g[c]);
+            u[c] = uc; b[c] = bc;
+        }
+        reinterpret_cast<f32x4*>(unbiased)[i] = u;
+        reinterpret_cast<f32x4*>(biased)[i] = b;
+    }
+    __device__ __forceinline__ void one(int64_t i) const {
+        float u = unbiased[i], b = biased[i];
+        op(u, b, value[i]);
+        unbiased[i] = u; biased[i] = b;
+    }
+};
+
 // One DR support step in a single pass (mamdr.py:103-105 followed by the next support's :74 assignment):
 //   phi += (w - merged) * gamma;  merged = theta (+|*) phi;  [w = merged]
 // -- the same roundings, in the same order, as mamdr_interp + mamdr_merge + mamdr_copy one after the other.
@@ -187,6 +215,10 @@ void run(int64_t n, const F& f, hipStream_t s) {
 
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s) {
     run(n, Interp{dst, a, b, scale}, s);
+}
+void launch_moving_average(float* unbiased, float* biased, const float* value, float decay, float denom, int64_t n,
+                           hipStream_t s) {
+    run(n, MovingAverage{unbiased, biased, value, decay, denom}, s);
 }
 void launch_dr_advance(float* phi, float* w, float* merged, const float* theta, float gamma, int mode, int assign, int64_t n,
                        hipStream_t s) {

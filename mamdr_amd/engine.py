@@ -72,6 +72,8 @@ class TowerEngine(object):
         self.n_user, self.n_item, self.n_domain = int(n_user), int(n_item), int(n_domain)
         self.batch_size = int(batch_size)
         self.dropout_seed = int(dropout_seed) & 0xFFFFFFFF
+        self._acc = None
+        self._ema = None            # set_moving_average
         tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR, "wdl": L.TOWER_WDL}[tower]
         max_batch = (self.batch_size + 15) // 16 * 16
         cfg = L.Config(L.ABI_VERSION, tower_id, self.n_user, self.n_item, self.n_domain, emb_dim,
@@ -309,6 +311,20 @@ class TowerEngine(object):
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
         opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD, "accumulate": L.OPT_ACCUMULATE}[optimizer]
+        if optimizer == "accumulate" and self._ema is not None:
+            # average_meta_grad == "moving_mean": every meta batch updates the accumulator's moving average
+            # (maml.py:219-220) -- one step at a time into a scratch gradient, then mamdr_moving_average
+            ema = self._ema
+            for s in range(first_step, first_step + n_steps):
+                ema["scratch"].zero_()
+                L.check(self.lib.mamdr_train_steps_n(self.ctx, domain, _ptr(perm), -1 if pass_rows is None else n,
+                                                     s, 1, bs, self.dropout_seed, opt, float(lr), _ptr(None)))
+                ema["step"] += 1
+                decay = np.float32(1.0 - ema["momentum"])
+                denom = np.float32(1.0) - np.power(np.float32(1.0) - decay, np.float32(ema["step"]), dtype=np.float32)
+                L.check(self.lib.mamdr_moving_average(_ptr(self._acc), _ptr(ema["biased"]), _ptr(ema["scratch"]),
+                                                      float(decay), float(denom), self._acc.numel(), self._s()))
+            return n_steps
         L.check(self.lib.mamdr_train_steps_n(self.ctx, domain, _ptr(perm), -1 if pass_rows is None else n,
                                              first_step, n_steps, bs, self.dropout_seed, opt, float(lr),
                                              _ptr(loss_out)))
@@ -337,9 +353,18 @@ class TowerEngine(object):
         return out
 
     def bind_accumulator(self, acc):
-        """meta-gradient accumulator of the MAML meta pass (maml.py:202); optimizer="accumulate" adds to it."""
+        """meta-gradient accumulator of the MAML meta pass (maml.py:202); optimizer="accumulate" adds to it
+        (or, after set_moving_average, moves it towards every batch's gradient)."""
         self._acc = acc
-        L.check(self.lib.mamdr_bind_accumulator(self.ctx, _ptr(acc)))
+        L.check(self.lib.mamdr_bind_accumulator(self.ctx, _ptr(acc if self._ema is None else self._ema["scratch"])))
+
+    def set_moving_average(self, momentum):
+        """average_meta_grad == "moving_mean" (maml.py:219-220): accumulate passes keep TF 1.12's zero-debiased
+        moving average of the batch gradients in the bound accumulator.  Its hidden state (`biased`, `local_step`)
+        lives as long as the engine, like the hidden variables of the reference's accumulator."""
+        self._ema = {"momentum": float(momentum), "step": 0, "biased": self.new_vector(), "scratch": self.new_vector()}
+        if self._acc is not None:
+            self.bind_accumulator(self._acc)
 
     def adam_apply(self, p, m, v, g, lr, beta1_power, beta2_power, grad_scale=1.0):
         """outer TF1 Adam on flat vectors (maml.py:236-243)."""

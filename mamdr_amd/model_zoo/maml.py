@@ -121,9 +121,12 @@ class MAML(object):
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
             grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])          # maml.py:208-210
-        elif avg in ("moving_mean", "drop"):
-            raise NotImplementedError("average_meta_grad '%s' (maml.py:218-229) is not built" % avg)
         else:
+            if avg == "moving_mean":      # maml.py:219-220: K.moving_average_update(ag, g, 0.999) per meta batch
+                self.model.set_moving_average(0.999)
+            # "drop" (maml.py:220-226) passes the rank-1 gradients through layers.Dropout(0.2) inside a K.function
+            # whose inputs do not include the learning phase (maml.py:231-234): the phase keeps its default, False,
+            # and the layer is the identity -- the accumulation is the plain sum, exactly as for "none"
             grad_scale = 1.0
         self._get_model_meta_parms()
         meta_weights = self._get_meta_weights()

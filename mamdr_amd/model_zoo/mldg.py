@@ -18,9 +18,11 @@ class MLDG(MAML):
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
             grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])          # mldg.py:211-213
-        elif avg in ("moving_mean", "drop"):
-            raise NotImplementedError("average_meta_grad '%s' (mldg.py:221-231) is not built" % avg)
         else:
+            # "moving_mean": K.moving_average_update(ag, g, 0.999) per batch (mldg.py:222-223); "drop": Dropout(0.2) on
+            # the rank-1 gradients in a K.function that never feeds the learning phase = the identity (see maml.py)
+            if avg == "moving_mean":
+                self.model.set_moving_average(0.999)
             grad_scale = 1.0
         windows = self.build_meta_windows()
         self._get_model_meta_parms()

@@ -18,9 +18,11 @@ class PCGrad(MAML):
         avg = tc["average_meta_grad"]
         if avg == "mean" and tc["meta_train_step"] > 0:
             grad_scale = 1.0 / float(self.n_domain * tc["meta_train_step"])
-        elif avg in ("moving_mean", "drop"):
-            raise NotImplementedError("average_meta_grad '%s' is not built" % avg)
         else:
+            # "moving_mean": K.moving_average_update(ag, g, 0.999) per batch (pcgrad.py:229-230); "drop": the identity
+            # (Dropout(0.2) in a K.function that never feeds the learning phase, see maml.py)
+            if avg == "moving_mean":
+                self.model.set_moving_average(0.999)
             grad_scale = 1.0
         windows = self.build_meta_windows()
         self._get_model_meta_parms()

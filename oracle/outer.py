@@ -88,3 +88,25 @@ def pcgrad_project(final, aux):
             flat_aux[hit] -= (dots[hit] / norms)[:, None] * flat_cur[hit]
         flat_cur += flat_aux
     return final
+
+
+def moving_average_update(unbiased, biased, value, momentum, local_step):
+    """`K.moving_average_update(ag, g, 0.999)` of average_meta_grad == "moving_mean" (model_zoo/maml.py:219-220,
+    mldg.py:222-223, pcgrad.py:229-230), in place on float32 arrays; returns the new local_step.
+
+    TensorFlow is a dependency the reference tree does not hold (requirements: tensorflow 1.12); this restates
+    its published code -- parity unpinned.  tensorflow/python/keras/backend.py (r1.12) moving_average_update:
+        moving_averages.assign_moving_average(x, value, momentum, zero_debias=True)
+    tensorflow/python/training/moving_averages.py (r1.12) assign_moving_average / _zero_debias:
+        decay = convert_to_tensor(1.0 - decay)            # python double, then a float32 tensor
+        biased       -= (biased - value) * decay          # hidden variable "biased", zeros at creation
+        local_step   += 1                                 # hidden variable "local_step"
+        unbiased_var -= unbiased_var - biased / (1 - pow(1.0 - decay, local_step))
+    The hidden variables belong to the accumulator variable and are NOT touched by `clear_grads`
+    (maml.py:203): the average runs over every meta batch since the start of training."""
+    decay = F32(1.0 - momentum)
+    biased -= (biased - value) * decay
+    local_step = int(local_step) + 1
+    denom = F32(1.0) - np.power(F32(1.0) - decay, F32(local_step), dtype=F32)
+    unbiased -= unbiased - biased / denom
+    return local_step

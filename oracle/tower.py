@@ -330,7 +330,12 @@ class OracleModel(object):
         learning phase 0 = dropout off.  The dropout counter still advances (one per step)."""
         _, g, _ = loss_and_grads(self.params, uid, pid, dom, label, None, 0.0, self.emb_trainable,
                                  self.frozen_sumsq(), self.deepfm, self.uncertainty)
-        acc += flatten(g, self.names)
+        if getattr(self, "moving_average", None) is not None:       # average_meta_grad == "moving_mean" (maml.py:219-220)
+            from . import outer
+            ma = self.moving_average
+            ma["step"] = outer.moving_average_update(acc, ma["biased"], flatten(g, self.names), ma["momentum"], ma["step"])
+        else:
+            acc += flatten(g, self.names)
         self.step += 1
 
     def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):

@@ -37,6 +37,7 @@ class FakeEngine(object):
         self.n_meta = off
         self.data = {}
         self.calls = []
+        self._ema = None
 
     # flat vectors
     def keras_name(self, segment):
@@ -122,6 +123,13 @@ class FakeEngine(object):
         for s in range(first_step, first_step + n_steps):
             idx = p[s * bs:(s + 1) * bs]
             if optimizer == "accumulate":
+                if self._ema is not None:
+                    g = np.zeros(self.n_params, F32)
+                    self.oracle.accumulate_on_batch(g, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                                    cols["label"][idx])
+                    self._ema["step"] = oouter.moving_average_update(self._acc.numpy(), self._ema["biased"], g,
+                                                                     self._ema["momentum"], self._ema["step"])
+                    continue
                 self.oracle.accumulate_on_batch(self._acc.numpy(), cols["uid"][idx], cols["pid"][idx],
                                                 cols["domain"][idx], cols["label"][idx])
                 continue
@@ -136,6 +144,9 @@ class FakeEngine(object):
 
     def bind_accumulator(self, acc):
         self._acc = acc
+
+    def set_moving_average(self, momentum):
+        self._ema = {"momentum": float(momentum), "step": 0, "biased": np.zeros(self.n_params, F32)}
 
     def adam_apply(self, p, m, v, g, lr, beta1_power, beta2_power, grad_scale=1.0):
         o = otower.OuterAdam(p.numel())

@@ -788,6 +788,56 @@ def test_maml_epoch_matches_oracle(env):
     eng.close()
 
 
+def test_moving_average_op_and_meta_pass(env):
+    """average_meta_grad == "moving_mean" (maml.py:219-220): mamdr_moving_average is bit-exact against the oracle's
+    restatement of TF 1.12's zero-debiased moving average; an accumulate pass under set_moving_average leaves the
+    debiased average of the batch gradients in the accumulator (hidden state kept across a cleared accumulator)."""
+    engine, synthetic = env
+    from mamdr_amd import _lib as L
+    shape = dict(synthetic.SHAPES["taobao10"], n_domain=3)
+    g, eng, model = make_problem(env, scale=0.05, batch=256, dropout=0.5, shape=shape)
+    rs = np.random.RandomState(5)
+    n = 100003
+    u = rs.standard_normal(n).astype(F32)
+    b = (rs.standard_normal(n) * 0.1).astype(F32)
+    ud, bd = torch.from_numpy(u).to(eng.device), torch.from_numpy(b).to(eng.device)
+    step = 0
+    for k in range(4):
+        v = rs.standard_normal(n).astype(F32)
+        step = oouter.moving_average_update(u, b, v, 0.999, step)
+        decay = F32(1.0 - 0.999)
+        denom = F32(1.0) - np.power(F32(1.0) - decay, F32(step), dtype=F32)
+        vd = torch.from_numpy(v).to(eng.device)
+        L.check(eng.lib.mamdr_moving_average(ud.data_ptr(), bd.data_ptr(), vd.data_ptr(), float(decay), float(denom), n, None))
+        assert np.array_equal(ud.cpu().numpy(), u) and np.array_equal(bd.cpu().numpy(), b)
+    # the meta pass
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(3)]
+    acc = eng.new_vector()
+    eng.set_moving_average(0.999)
+    eng.bind_accumulator(acc)
+    model.moving_average = {"momentum": 0.999, "step": 0, "biased": np.zeros(model.get_flat().size, F32)}
+    acc_o = np.zeros(model.get_flat().size, F32)
+    for rnd, d in enumerate((0, 2)):
+        perm = orng.shuffle_perm(sizes[d], 10000, seed=3 + rnd)
+        eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), first_step=0, n_steps=3, optimizer="accumulate")
+        cols = g["data"]["train"][d]
+        for s_ in range(3):
+            ii = perm[s_ * 256:(s_ + 1) * 256]
+            model.accumulate_on_batch(acc_o, cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+        got = eng.unpack(acc)
+        o = 0
+        for nme in model.names:
+            sz = model.params[nme].size
+            want = acc_o[o:o + sz]
+            # (an average of batch gradients of either sign: each agrees to 2e-4 of ITS size, the bar is absolute)
+            np.testing.assert_allclose(got[nme], want, rtol=3e-4, atol=1e-3 * max(np.abs(want).max(), 1e-3), err_msg=nme)
+            o += sz
+        acc.zero_()                 # clear_grads (maml.py:203) leaves `biased` / `local_step` alone
+        acc_o[...] = 0
+    assert eng._ema["step"] == 6 == model.moving_average["step"]
+    eng.close()
+
+
 # ------------------------------------------------------------------ full size: size-independent properties
 def test_full_size_properties_taobao10(env):
     """BASELINE config sizes (Taobao-10, bs 1024): bit-exact gather, bitwise run-to-run

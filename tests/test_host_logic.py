@@ -205,6 +205,61 @@ def test_meta_epochs_follow_oracle_loops():
             assert tr_g[:4] == [("reptile", 2, 2), ("target_step", 1, 1), ("reptile", 0, 2), ("target_step", 1, 1)]
 
 
+def test_moving_average_update_known_answers():
+    """TF 1.12's zero-debiased moving average behind K.moving_average_update (oracle/outer.py): a constant gradient
+    is reproduced from the first update on (that is what the debiasing is for), the hidden `biased` follows
+    b_t = g (1 - 0.999^t), and a cleared accumulator is overwritten, not averaged with."""
+    from oracle import outer as oouter
+    g = np.array([1.0, -2.5, 0.0, 3e-3], np.float32)
+    u, b, step = np.zeros(4, np.float32), np.zeros(4, np.float32), 0
+    for t in range(1, 6):
+        step = oouter.moving_average_update(u, b, g, 0.999, step)
+        assert step == t
+        np.testing.assert_allclose(u, g, rtol=1e-3, atol=1e-9)       # fp32 cancellation in 1 - 0.999^t: ~1e-4 relative
+        np.testing.assert_allclose(b, g * (1.0 - 0.999 ** t), rtol=1e-3, atol=1e-9)
+        u[...] = 0                                                   # clear_grads (maml.py:203)
+    # first update in exact arithmetic: b = 0.001 g, u = b / 0.001 -- in float32, bit for bit
+    u, b = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    oouter.moving_average_update(u, b, np.array([0.7], np.float32), 0.999, 0)
+    d = np.float32(1.0 - 0.999)
+    b1 = np.float32(0) - (np.float32(0) - np.float32(0.7)) * d
+    den = np.float32(1) - np.power(np.float32(1) - d, np.float32(1), dtype=np.float32)
+    assert b[0] == b1 and u[0] == np.float32(0) - (np.float32(0) - b1 / den)
+    # two different gradients: the debiased value is their weighted mean (weights 0.999 : 1)
+    u, b, step = np.zeros(1, np.float32), np.zeros(1, np.float32), 0
+    step = oouter.moving_average_update(u, b, np.array([1.0], np.float32), 0.999, step)
+    step = oouter.moving_average_update(u, b, np.array([3.0], np.float32), 0.999, step)
+    np.testing.assert_allclose(u[0], (0.999 * 1.0 + 3.0) / 1.999, rtol=1e-3)
+
+
+@pytest.mark.parametrize("avg", ["moving_mean", "drop"])
+def test_run_main_average_meta_grad(tmp_path, monkeypatch, avg):
+    """train.average_meta_grad "moving_mean" / "drop" (maml.py:218-229) through run.py's entry: "drop" is the plain sum
+    (Dropout in a K.function that never feeds the learning phase), "moving_mean" keeps the debiased moving average
+    with its hidden state alive across the cleared accumulator."""
+    patch_emb_dim(monkeypatch)
+    results = {}
+    for mode in ("none", avg):
+        cfg = tiny_config(tmp_path, "mlp_meta_maml")
+        cfg["train"]["average_meta_grad"] = mode
+        holder = {}
+        real_build = cli.build_model
+        monkeypatch.setattr(cli, "build_model", lambda *a, real_build=real_build, holder=holder, **k:
+                            holder.setdefault("m", real_build(*a, **k)))
+        out = cli.main(cfg, FakeEngine)
+        monkeypatch.setattr(cli, "build_model", real_build)
+        results[mode] = (out, holder["m"])
+    (o_none, m_none), (o_avg, m_avg) = results["none"], results[avg]
+    assert m_avg.trace == m_none.trace and np.isfinite(o_avg[0])
+    if avg == "drop":
+        assert o_avg == o_none and m_avg.model._ema is None
+    else:
+        ema = m_avg.model._ema
+        n_meta_batches = sum(n for p, _, n in m_avg.trace if p == "maml_meta")
+        assert ema["step"] == n_meta_batches > 0 and np.abs(ema["biased"]).max() > 0
+        assert o_avg != o_none                           # a different outer gradient
+
+
 @pytest.mark.parametrize("name, extra", [("mlp_meta_domain_negotiation", {"target_domain": 1, "meta_train_step": 2}),
                                          ("mlp_meta_reptile", {"target_domain": 1}),
                                          ("mlp_meta_mamdr", {"target_domain": 2, "finetune_every_epoch": True}),
