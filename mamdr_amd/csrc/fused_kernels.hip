@@ -608,6 +608,10 @@ void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live
 // lane l copies float4 l of the 1-KB [user | item] row.  Replaces, per step, the tower kernel's chain of three
 // dependent loads (perm -> uid / pid -> table rows) and its copy of x into the activation workspace.
 __global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
+    if ((int)blockIdx.x >= a.n_prep_wgs) {       // the call's transposed weight copies (k_transpose_w) in the same launch
+        transpose_w_elem(a.tw_dense, a.tw_L, a.tw_wT, ((int)blockIdx.x - a.n_prep_wgs) * 256 + (int)threadIdx.x);
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= a.n) {
@@ -637,9 +641,11 @@ __global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
         a.plabel[i] = a.label[src];
     }
 }
-void launch_pass_prep(const PassPrepArgs& a, hipStream_t s) {
-    if (a.n <= 0) return;
-    hipLaunchKernelGGL(k_pass_prep, dim3((unsigned)(((a.n + 15) / 16 * 16 + 3) / 4)), dim3(256), 0, s, a);
+void launch_pass_prep(const PassPrepArgs& a0, hipStream_t s) {
+    if (a0.n <= 0) return;
+    PassPrepArgs a = a0;
+    a.n_prep_wgs = (int)(((a.n + 15) / 16 * 16 + 3) / 4);
+    hipLaunchKernelGGL(k_pass_prep, dim3((unsigned)(a.n_prep_wgs + (a.tw_wT ? TRANSPOSE_WGS : 0))), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

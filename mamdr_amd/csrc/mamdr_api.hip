@@ -1004,7 +1004,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
     const bool may_use4 = !c->star && c->tower_tile != 16;
-    if (may_use4 && n_steps > 0) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
+    const bool need_wT = may_use4 && n_steps > 0;
 
     c->rows_ready = false;
     c->catchup_ready = false;
@@ -1047,7 +1047,14 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         pa.xpre = c->xpre;
         pa.pdom = c->pdom;
         pa.plabel = c->plabel;
+        if (need_wT) {                 // ... in k_pass_prep's launch (one launch less per call)
+            pa.tw_dense = c->params + c->table_floats;
+            pa.tw_L = c->L;
+            pa.tw_wT = c->wT;
+        }
         launch_pass_prep(pa, c->stream);
+    } else if (need_wT) {
+        launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
     }
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;

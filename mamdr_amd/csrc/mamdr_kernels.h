@@ -504,7 +504,29 @@ struct PassPrepArgs {
     float* xpre;
     int32_t* pdom;
     float* plabel;
+    // k_transpose_w's work riding in the same launch (both open a mamdr_train_steps call): workgroups
+    // [n_prep_wgs, n_prep_wgs + TRANSPOSE_WGS) when tw_wT is set
+    const float* tw_dense;
+    DenseLayout tw_L;
+    float* tw_wT;
+    int n_prep_wgs;
 };
+constexpr int TRANSPOSE_WGS = (WT_FLOATS + 255) / 256;
+// W1T / W2T / W0T element e from the live weights (see k_transpose_w)
+__device__ __forceinline__ void transpose_w_elem(const float* dense, const DenseLayout& L, float* wT, int e) {
+    if (e < H1 * H2) {
+        const int r = e / H2, c = e - r * H2;               // W1[r][c], r < 256, c < 128
+        wT[W1T_OFF + c * H1 + r] = dense[L.w1 + e];
+    } else if (e < H1 * H2 + H2 * H3) {
+        const int f = e - H1 * H2;
+        const int r = f / H3, c = f - r * H3;               // W2[r][c], r < 128, c < 64
+        wT[W2T_OFF + c * H2 + r] = dense[L.w2 + f];
+    } else if (e < WT_FLOATS) {
+        const int f = e - (H1 * H2 + H2 * H3);
+        const int r = f / H1, c = f - r * H1;               // W0[r][c], r < 256 (user | item rows), c < 256
+        wT[W0T_OFF + c * (2 * EMB) + r] = dense[L.w0 + f];
+    }
+}
 void launch_pass_prep(const PassPrepArgs& a, hipStream_t s);
 // materialise a pending domain-table step (end of a mamdr_train_steps call): live p / m / v := dm_step4
 void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live_v, hipStream_t s);

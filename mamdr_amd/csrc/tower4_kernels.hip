@@ -827,22 +827,10 @@ void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
 
 // W1T / W2T from the live weights (start of every mamdr_train_steps call; k_update keeps them current)
 __global__ __launch_bounds__(256) void k_transpose_w(const float* dense, DenseLayout L, float* wT) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < H1 * H2) {
-        const int r = e / H2, c = e - r * H2;               // W1[r][c], r < 256, c < 128
-        wT[W1T_OFF + c * H1 + r] = dense[L.w1 + e];
-    } else if (e < H1 * H2 + H2 * H3) {
-        const int f = e - H1 * H2;
-        const int r = f / H3, c = f - r * H3;               // W2[r][c], r < 128, c < 64
-        wT[W2T_OFF + c * H2 + r] = dense[L.w2 + f];
-    } else if (e < WT_FLOATS) {
-        const int f = e - (H1 * H2 + H2 * H3);
-        const int r = f / H1, c = f - r * H1;               // W0[r][c], r < 256 (user | item rows), c < 256
-        wT[W0T_OFF + c * (2 * EMB) + r] = dense[L.w0 + f];
-    }
+    transpose_w_elem(dense, L, wT, (int)(blockIdx.x * 256 + threadIdx.x));
 }
 void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_w, dim3((WT_FLOATS + 255) / 256), dim3(256), 0, s, dense, L, wT);
+    hipLaunchKernelGGL(k_transpose_w, dim3(TRANSPOSE_WGS), dim3(256), 0, s, dense, L, wT);
 }
 
 }  // namespace mamdr
