@@ -511,6 +511,31 @@ struct PassPrepArgs {
     float* tw_wT;
     int n_prep_wgs;
 };
+// ---- W1 [256][128] as an LDS image (both towers, when a workgroup has its CU to itself).  LDS-DMA
+// (global_load_lds_dwordx4: 16 B per lane, two rows per wave instruction, no registers) writes a lane-linear image, so
+// the swizzle sits on the SOURCE address: the 16-B chunk q of row r lives at chunk position q ^ (r & 31) -- row reads
+// (layer 1's B operand) and column-chunk reads (its backward contraction) are both bank-conflict free.
+// The requests are inline asm, i.e. NOT in the compiler's vmcnt bookkeeping: a counted LDS-DMA makes hipcc wait
+// vmcnt(0) at the next use of any load.  Uncounted, they only make the counted waits behind them conservative (vmcnt
+// retires in order); w1_image_landed() is the wait, a workgroup barrier must follow before another wave reads.
+template <int ROWS>
+__device__ __forceinline__ void w1_image_request(const float* __restrict__ W1, float* w1s, const int row0) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(w1s + row0 * H2));
+#pragma unroll
+    for (int kk = 0; kk < ROWS; kk += 2) {
+        const int k = row0 + kk + (lane >> 5);
+        const float* src = W1 + k * H2 + 4 * ((lane & 31) ^ (k & 31));
+        const uint32_t dst = base + kk * H2 * 4;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+}
+__device__ __forceinline__ void w1_image_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// float offset of W1[row][4 chunk + c] in the image
+__device__ __forceinline__ int w1_image_at(int row, int chunk) { return row * H2 + 4 * (chunk ^ (row & 31)); }
+
 constexpr int TRANSPOSE_WGS = (WT_FLOATS + 255) / 256;
 // W1T / W2T / W0T element e from the live weights (see k_transpose_w)
 __device__ __forceinline__ void transpose_w_elem(const float* dense, const DenseLayout& L, float* wT, int e) {

@@ -539,7 +539,15 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     // layer-0 weights and the output-unit parameters do not depend on the gather: request them first
     FwdW<XDIM, H1, PF0, 8> fw0;
     FwdW<H1, H2, PF1, 8> fw1;
-    FwdW<H2, H3, PF2, 4> fw2;
+    // EARLY2 (training): layer 2's weights -- all of a wave's share, 32 registers -- are requested
+    // one layer early, behind layer 0's K loop, and the backward copy of W2 behind layer 1's: the two short layers
+    // otherwise start on a cold miss each (stamps at 4,096 rows: layer 2 6.3 K -> 4.8 K cycles, output / loss
+    // 4.0 K -> 1.8 K; k_tower 26.2 -> 24.6 us).  A W1 image in LDS on top of this (as in k_tower4; built and measured:
+    // requests at kernel start, gather + 2.5 K cycles; spread over layer 0's K loop, + 6.5 K) gained nothing here --
+    // with 16 rows per tile layers 0 and 1 are paced by their MFMAs and epilogues, not by the weight stream.
+    // (not the 384-wide Star variant: it keeps its registers under 128 so that two workgroups share a CU)
+    constexpr bool EARLY2 = TRAIN && DXW <= 2 * EMB;
+    FwdW<H2, H3, EARLY2 ? H2 / 16 : PF2, 4> fw2;
     BwdW<H3, H2, H3, PFB2, 8> bw2;
     BwdW<H2, H1, H2, PFB1, 8> bw1;
     // (the 384-wide variant keeps a 2-deep ring: 120 instead of 168 VGPRs, so that two workgroups share a CU)
@@ -592,13 +600,19 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
 
     fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(fw0, P + a.L.w0, smem + XS_OFF, smem + H1S_OFF, TRAIN ? acts_t + XDIM : nullptr,
                                              key0, a.drop_thresh, scale, a.use_dropout != 0, row0,
-                                             [&]() { fw1.prefetch(P + a.L.w1, P + a.L.b1); });
+                                             [&]() {
+                                                 fw1.prefetch(P + a.L.w1, P + a.L.b1);
+                                                 if (EARLY2) fw2.prefetch(P + a.L.w2, P + a.L.b2);
+                                             });
     STAMP(2);
     __syncthreads();
     fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN>(fw1, P + a.L.w1, smem + H1S_OFF, smem + H2S_OFF,
                                            TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
                                            a.use_dropout != 0, row0,
-                                           [&]() { fw2.prefetch(P + a.L.w2, P + a.L.b2); });
+                                           [&]() {
+                                               if (EARLY2) bw2.prefetch(P + a.L.w2);
+                                               else fw2.prefetch(P + a.L.w2, P + a.L.b2);
+                                           });
     STAMP(3);
     __syncthreads();
     // the backward weights are requested ahead of layer 2's epilogue stores
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
                                            TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh, scale,
                                            a.use_dropout != 0, row0, [&]() {
                                                if (TRAIN) {
-                                                   bw2.prefetch(P + a.L.w2);
+                                                   if (!EARLY2) bw2.prefetch(P + a.L.w2);
                                                    bw1.prefetch(P + a.L.w1);
                                                }
                                            });

@@ -275,20 +275,10 @@ __device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict
 // nobody until t4_w1_landed() at the end of layer 0.
 template <int ROWS>
 __device__ __forceinline__ void t4_w1_request(const float* __restrict__ W1, float* w1s, const int row0) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(w1s + row0 * H2));
-#pragma unroll
-    for (int kk = 0; kk < ROWS; kk += 2) {
-        const int k = row0 + kk + (lane >> 5);
-        const float* src = W1 + k * H2 + 4 * ((lane & 31) ^ (k & 31));
-        const uint32_t dst = base + kk * H2 * 4;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    }
+    w1_image_request<ROWS>(W1, w1s, row0);       // mamdr_kernels.h
 }
 // every request of this wave has landed (a workgroup barrier must follow before another wave reads the image)
-__device__ __forceinline__ void t4_w1_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void t4_w1_landed() { w1_image_landed(); }
 
 // forward: the wave's 32 rows in chunks of 8, the next chunk's reads issued before the current chunk's MFMAs
 template <typename Mid>
