@@ -101,6 +101,7 @@ struct mamdr_ctx {
     // mlp tower with frozen tables: weight gradients + optimiser step in one launch (k_wgrad_adam) + k_dm_finish
     // instead of k_wgrad -> slabs -> k_update (MAMDR_FUSED=0 keeps the slab path)
     bool fused = false;
+    int t4_no_w1l = 0;              // MAMDR_T4_NO_W1L=1: k_tower4 without the W1 image in LDS (diagnostic)
     int fused_max_batch = 2048;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size)
     float* pdm = nullptr;           // [32][n_domain][EMB] partial domain-table gradients
     // the domain table's step stays pending until the next tower kernel applies it (DmStep, mamdr_kernels.h):
@@ -731,6 +732,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->loss_part, (rp / 4) * sizeof(float));
     ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
     {
+        if (const char* nw = getenv("MAMDR_T4_NO_W1L")) c->t4_no_w1l = atoi(nw) != 0;
         const char* fe = getenv("MAMDR_FUSED");
         c->fused = cfg->tower == MAMDR_TOWER_MLP && !cfg->emb_trainable && !cfg->uncertainty_weight && c->lin_w0dom &&
                    cfg->n_domain <= 64 && !(fe && atoi(fe) == 0);
@@ -1129,6 +1131,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.stamps = c->stamps ? c->stamps + (c->global_step & 1) * 16384 : nullptr;      // two steps side by side
 #endif
         ta.wT = c->wT;
+        ta.no_w1l = c->t4_no_w1l;
         float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
         if (fused) {

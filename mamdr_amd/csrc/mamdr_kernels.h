@@ -153,6 +153,7 @@ struct TowerArgs {
     const float* xpre;         // [rows][2 EMB], null = gather through perm / uid / pid
     const int32_t* pdom;
     const float* plabel;
+    int no_w1l;                // k_tower4: keep streaming W1 / W1^T (MAMDR_T4_NO_W1L=1, diagnostic)
     DmStep dms;
     int dm_hint;               // the domain the caller expects every row of the batch to carry (the pass's domain)
     float* dm_live_p;

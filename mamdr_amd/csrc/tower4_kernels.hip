@@ -796,7 +796,6 @@ static int t4_cu_count() {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
         if (n <= 0) n = 1;
-        if (const char* e = getenv("MAMDR_T4_NO_W1L")) if (atoi(e)) n = -1;        // diagnostic: streaming variant only
     }
     return n;
 }
@@ -804,7 +803,7 @@ void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
     const dim3 grid(tiles);
     const bool dx = a.dxe != nullptr;
-    const bool w1l = tiles <= t4_cu_count();
+    const bool w1l = !a.no_w1l && tiles <= t4_cu_count();
     if (a.deepfm) {
         if (dx) launch_tower4_inst<true, true>(a, grid, w1l, s);
         else launch_tower4_inst<false, true>(a, grid, w1l, s);

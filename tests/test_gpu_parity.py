@@ -415,6 +415,30 @@ def test_pending_domain_table_step_is_bitwise(env, batch, mixed):
         assert same_bits(a, b), (name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
 
 
+def test_tower4_w1_image_is_bitwise(env):
+    """k_tower4 with W1 as an LDS image (grids of up to one tile per CU) against the variant that streams W1 / W1^T
+    (MAMDR_T4_NO_W1L=1): the same MFMA sequences per output element and the same split-k sums -- identical bits, on the
+    k_wgrad_adam path (pre-gathered passes) and on the slab path."""
+    engine, synthetic = env
+    out = {}
+    for fused in ("1", "0"):
+        for mode in ("image", "stream"):
+            os.environ["MAMDR_T4_NO_W1L"] = "1" if mode == "stream" else "0"
+            os.environ["MAMDR_FUSED"] = fused
+            try:
+                g, eng, model = make_problem(env, scale=0.05, batch=1024, dropout=0.5)
+            finally:
+                os.environ.pop("MAMDR_T4_NO_W1L", None)
+                os.environ.pop("MAMDR_FUSED", None)
+            d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+            n = g["data"]["train"][d]["uid"].shape[0]
+            perm = torch.from_numpy(orng.shuffle_perm(n, 10000, seed=11)).to(eng.device)
+            eng.train_steps(d, perm=perm, first_step=0, n_steps=min(4, -(-n // 1024)), lr=1e-3)
+            out[(fused, mode)] = eng.get_weights().cpu().numpy().copy()
+            eng.close()
+        assert np.array_equal(out[(fused, "image")], out[(fused, "stream")])
+
+
 @pytest.mark.parametrize("batch", [256, 1024, 4096])
 def test_fused_wgrad_adam_matches_the_slab_path(env, batch):
     """k_wgrad_adam (output-stationary tiles, optimiser step in the same launch, S workgroups for the domain-row
