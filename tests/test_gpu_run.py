@@ -117,6 +117,25 @@ def test_bench_gpus2_starts_two_ranks(tmp_path):
     assert rec["config"]["domain_steps_per_epoch"] > 1000 and 1.0 < rec["partition_speedup_bound"] <= 2.0
 
 
+def test_rccl_communicator_on_this_gpu():
+    """backend "nccl" is RCCL here: a one-rank communicator on the MI355X reduces device memory (float32 and the
+    float64 timings bench.py reduces) and passes a barrier.  The N > 1 code paths themselves are covered by the gloo
+    world-size-2 tests; one GPU cannot host two RCCL ranks."""
+    import socket
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "rccl_one_rank.py"), str(port)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("ok ")]
+    assert ok and ok[0].split()[1:] == ["12345.0", "1.5", "nccl", "1"], p.stdout[-2000:]
+
+
 def test_epoch_shuffles_equal_per_pass_shuffles():
     """plan.EpochShuffles (every permutation of an epoch from one C call, one upload) hands out exactly the
     permutations PassShuffler would have produced pass by pass."""
