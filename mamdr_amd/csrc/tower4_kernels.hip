@@ -38,13 +38,17 @@ constexpr int T4_DEEP = MAMDR_T4_DEEP;   // ring depth of the short layers (diag
 // LDS map (floats).  dz_l overwrites h_l in place (the gate is read by the thread that writes the gradient); the
 // split-k partials of the 256-column contractions share a slot between waves w and w + 4 (t4_put), so that everything
 // but the W1 image is 30 KB and the image (128 KB) fits beside it in the CU's 160 KB.
-constexpr int T4_XS = 0;                               // [4][384]
-constexpr int T4_H1 = T4_XS + T4_ROWS * XDIM;          // [4][256]  h1, then dz1 (trainable tables: input of the dx contraction)
-constexpr int T4_H2 = T4_H1 + T4_ROWS * H1;            // [4][128]  h2, then dz2
-constexpr int T4_DZ3 = T4_H2 + T4_ROWS * H2;           // [4][64]
+// Row strides of the four activation tiles: + 4 floats, so that the A fragment reads of a contraction -- lane l reads
+// 16 B of row l & 3 -- fall into four different bank groups (unpadded, every stride is a multiple of 32 banks and the
+// four rows collide: SQ_LDS_BANK_CONFLICT 2.9 K cycles per CU and launch at 1,024 rows).
+constexpr int T4_XLD = XDIM + 4, T4_H1LD = H1 + 4, T4_H2LD = H2 + 4, T4_H3LD = H3 + 4;
+constexpr int T4_XS = 0;                               // [4][384 + 4]
+constexpr int T4_H1 = T4_XS + T4_ROWS * T4_XLD;        // [4][256 + 4]  h1, then dz1 (trainable tables: input of the dx contraction)
+constexpr int T4_H2 = T4_H1 + T4_ROWS * T4_H1LD;       // [4][128 + 4]  h2, then dz2
+constexpr int T4_DZ3 = T4_H2 + T4_ROWS * T4_H2LD;      // [4][64 + 4]
 constexpr int T4_DZ2 = T4_H2;
 constexpr int T4_DZ1 = T4_H1;
-constexpr int T4_RED = T4_DZ3 + T4_ROWS * H3;          // split-k partials: [8 waves][4][N <= 128] or [4 wave pairs][4][256]
+constexpr int T4_RED = T4_DZ3 + T4_ROWS * T4_H3LD;     // split-k partials: [8 waves][4][N <= 128] or [4 wave pairs][4][256]
 constexpr int T4_RED_FLOATS = 4 * T4_ROWS * H1;
 constexpr int T4_ROWI = T4_RED + T4_RED_FLOATS;
 constexpr int T4_W1S = T4_ROWI + 64;                   // W1L: [256][128] image of W1, 16-B chunks XOR-swizzled per row
@@ -234,8 +238,8 @@ __device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* wp1 = T4L0::wptr1(W);
     const float* wp2 = T4L0::wptr2(W);
-    const float* ap1 = xs + (lane & 3) * XDIM + 32 * w;
-    const float* ap2 = xs + (lane & 3) * XDIM + 2 * EMB + 16 * w;
+    const float* ap1 = xs + (lane & 3) * T4_XLD + 32 * w;
+    const float* ap2 = xs + (lane & 3) * T4_XLD + 2 * EMB + 16 * w;
     auto chunk = [&](const float* ap, const float* next, bool reload) {
 #pragma unroll
         for (int q = 0; q < T4_PF; q += 4) {
@@ -284,7 +288,7 @@ __device__ __forceinline__ void t4_w1_landed() { w1_image_landed(); }
 template <typename Mid>
 __device__ __forceinline__ void t4_contract_w1f(const float* w1s, const float* As, float* red, Mid mid) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float* ap = As + (lane & 3) * H1 + 32 * w;
+    const float* ap = As + (lane & 3) * T4_H1LD + 32 * w;
     const float* wp = w1s + (32 * w) * H2 + 2 * (lane & 1);
     const int half = lane >> 1;
     f32x4 acc[2];
@@ -320,7 +324,7 @@ __device__ __forceinline__ void t4_contract_w1f(const float* w1s, const float* A
 template <typename Mid>
 __device__ __forceinline__ void t4_contract_w1b(const float* w1s, const float* As, float* red, Mid mid) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float* ap = As + (lane & 3) * H2 + 16 * w;
+    const float* ap = As + (lane & 3) * T4_H2LD + 16 * w;
     const float* rp = w1s + lane * H2;
     const int sw = lane & 31;                                     // (l + 64 t) & 31
     f32x4 acc[4];
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
         if (tid < 256) {
             const int row = tid >> 6;
             if (r0 + row >= a.rows) xv = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + 4 * (tid & 63)) = xv;
+            *reinterpret_cast<f32x4*>(smem + T4_XS + row * T4_XLD + 4 * (tid & 63)) = xv;
         }
     } else if (tid < T4_ROWS) {
         const bool valid = (r0 + tid) < a.rows;
@@ -525,13 +529,13 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                 f32x4 pn, mn, vn;
                 dm_step4(a.dms, rowi[8 + row], c4 & 31, pn, mn, vn);
                 if (!rowi[12 + row]) pn = (f32x4){0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = pn;
+                *reinterpret_cast<f32x4*>(smem + T4_XS + row * T4_XLD + c4 * 4) = pn;
             }
         } else if (!(pre && seg < 2)) {         // (pre-gathered pass: the user / item part is in LDS already)
             const float* base = seg == 0 ? a.user_tab : (seg == 1 ? a.item_tab : a.dense + a.L.dm);
             f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)rowi[seg * 4 + row] * EMB + off);
             if (!rowi[12 + row]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(smem + T4_XS + row * XDIM + c4 * 4) = v;
+            *reinterpret_cast<f32x4*>(smem + T4_XS + row * T4_XLD + c4 * 4) = v;
         }
     }
     // (pending + one-domain tile: the domain columns of x are filled between layer 0's two segments, see midseg)
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     if (FM) {
         // thread (row, k): FM second-order term sum_k (u i + (u + i) d), reduced over the row's two waves
         const int row = tid >> 7, k = tid & 127;
-        const float* xr = smem + T4_XS + row * XDIM;
+        const float* xr = smem + T4_XS + row * T4_XLD;
         const float u = xr[k], it = xr[EMB + k], dd = xr[2 * EMB + k];
         float s = a.deepfm == 1 ? u * it + (u + it) * dd : 0.f;      // 2 = WDL: no FM term
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                            dm_apply1(a.dms, dm_wave_sum(dmt.r), p, m, v);
                            if (lane < 16) {
 #pragma unroll
-                               for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * XDIM + 2 * EMB + c] = rowi[12 + rr] ? p : 0.f;
+                               for (int rr = 0; rr < T4_ROWS; ++rr) smem[T4_XS + rr * T4_XLD + 2 * EMB + c] = rowi[12 + rr] ? p : 0.f;
                            }
                        }
                        T4STAMP(14);
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                                                   // a pre-gathered pass in place)
         const int row = tid / (XDIM / 4), c4 = tid - row * (XDIM / 4);
         *reinterpret_cast<f32x4*>(acts_t + (size_t)row * ACT_LD + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(smem + T4_XS + row * XDIM + c4 * 4);
+            *reinterpret_cast<const f32x4*>(smem + T4_XS + row * T4_XLD + c4 * 4);
     }
     __syncthreads();
     {
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
                 const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H1 + (uint32_t)ecol);
                 h = (u >= a.drop_thresh) ? h * scale : 0.f;
             }
-            smem[T4_H1 + row * H1 + ecol] = h;
+            smem[T4_H1 + row * T4_H1LD + ecol] = h;
             T4_WS_STORE(&acts_t[(size_t)row * ACT_LD + XDIM + ecol], h);
         }
     }
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     T4STAMP(3);
     // ---- layer 1: 256 -> 128
     if (W1L) t4_contract_w1f(w1s, smem + T4_H1, red, [&]() { v2.prefetch(a.wT + W2T_OFF); });
-    else t4_contract(w1, P + a.L.w1, smem + T4_H1, H1, red, [&]() { w2.prefetch(P + a.L.w2); });
+    else t4_contract(w1, P + a.L.w1, smem + T4_H1, T4_H1LD, red, [&]() { w2.prefetch(P + a.L.w2); });
     __syncthreads();
     T4STAMP(4);
     {
@@ -653,14 +657,14 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
             const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H2 + (uint32_t)col);
             h = (u >= a.drop_thresh) ? h * scale : 0.f;
         }
-        smem[T4_H2 + row * H2 + col] = h;
+        smem[T4_H2 + row * T4_H2LD + col] = h;
         T4_WS_STORE(&acts_t[(size_t)row * ACT_LD + XDIM + H1 + col], h);
     }
     __syncthreads();
 
     T4STAMP(5);
     // ---- layer 2: 128 -> 64 (the backward weights are requested behind its K loop)
-    t4_contract(w2, P + a.L.w2, smem + T4_H2, H2, red, [&]() {
+    t4_contract(w2, P + a.L.w2, smem + T4_H2, T4_H2LD, red, [&]() {
         if (!W1L) {
             v2.prefetch(a.wT + W2T_OFF);
             v1.prefetch(a.wT + W1T_OFF);
@@ -718,47 +722,47 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
             }
         }
         const float d = (h > 0.f) ? (dl * wor) * scale : 0.f;
-        smem[T4_DZ3 + row * H3 + col] = d;
+        smem[T4_DZ3 + row * T4_H3LD + col] = d;
         T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + H1 + H2 + col], d);
     }
     __syncthreads();
     if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
     if (FM) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
         const int row = tid >> 7, k = tid & 127;
-        const float* xr = smem + T4_XS + row * XDIM;
+        const float* xr = smem + T4_XS + row * T4_XLD;
         a.fmq[(size_t)(r0 + row) * EMB + k] = a.deepfm == 1 ? rowf[12 + row] * (xr[k] + xr[EMB + k]) : 0.f;
     }
 
     T4STAMP(7);
     // ---- backward: dz2 = (dz3 . W2^T) * gate(h2)
-    t4_contract(v2, a.wT + W2T_OFF, smem + T4_DZ3, H3, red, []() {});
+    t4_contract(v2, a.wT + W2T_OFF, smem + T4_DZ3, T4_H3LD, red, []() {});
     __syncthreads();
     {
         const int row = tid >> 7, col = tid & 127;
         const float v = t4_sum<H2>(red, row, col);
-        const float d = (smem[T4_H2 + row * H2 + col] > 0.f) ? v * scale : 0.f;
-        smem[T4_DZ2 + row * H2 + col] = d;
+        const float d = (smem[T4_H2 + row * T4_H2LD + col] > 0.f) ? v * scale : 0.f;
+        smem[T4_DZ2 + row * T4_H2LD + col] = d;
         T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + H1 + col], d);
     }
     __syncthreads();
     T4STAMP(8);
     // ---- dz1 = (dz2 . W1^T) * gate(h1); the domain-table gradient follows from dz1 by linearity
     if (W1L) t4_contract_w1b(w1s, smem + T4_DZ2, red, []() {});
-    else t4_contract(v1, a.wT + W1T_OFF, smem + T4_DZ2, H2, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
+    else t4_contract(v1, a.wT + W1T_OFF, smem + T4_DZ2, T4_H2LD, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = erow2 + 2 * rr;
         const float v = t4_sum<H1>(red, row, ecol);
-        const float d = (smem[T4_H1 + row * H1 + ecol] > 0.f) ? v * scale : 0.f;
+        const float d = (smem[T4_H1 + row * T4_H1LD + ecol] > 0.f) ? v * scale : 0.f;
         T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + ecol], d);
-        if (DX) smem[T4_DZ1 + row * H1 + ecol] = d;
+        if (DX) smem[T4_DZ1 + row * T4_H1LD + ecol] = d;
     }
     T4STAMP(9);
     T4REAL(11);
     if (DX) {
         __syncthreads();           // dz1 complete, `red` free again
-        t4_contract(v0, a.wT + W0T_OFF, smem + T4_DZ1, H1, red, []() {});
+        t4_contract(v0, a.wT + W0T_OFF, smem + T4_DZ1, T4_H1LD, red, []() {});
         __syncthreads();
         float* dxe_t = a.dxe + (size_t)r0 * (2 * EMB);
 #pragma unroll
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
             const int row = erow2 + 2 * rr;
             float v = t4_sum<2 * EMB>(red, row, ecol);
             if (FM) {              // d fm / d e_f = sum of the other two fields
-                const float* xr = smem + T4_XS + row * XDIM;
+                const float* xr = smem + T4_XS + row * T4_XLD;
                 const int k = ecol & (EMB - 1);
                 const float other = (ecol < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
                 if (a.deepfm == 1) v = fmaf(rowf[12 + row], other, v);
