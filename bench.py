@@ -422,11 +422,18 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
             # template <DX, FM, W1L>; W1L (the W1 image in LDS) at one 4-row tile per CU or less (tower4_kernels.hip)
             tiles4 = -(-batch // 16) * 4
             w1l = tiles4 <= torch.cuda.get_device_properties(eng.device).multi_processor_count
-            kname = ("k_tower4<true" if trainable else "k_tower4<false") + fm[:-1] + (", true>" if w1l else ", false>")
+            # ... PRE (the instance for pre-gathered passes) on the k_wgrad_adam path
+            pre4 = not trainable and tower == "mlp" and os.environ.get("MAMDR_NO_PREGATHER", "0") in ("", "0") and \
+                eng.step_kernel_names(batch)[L.KERNEL_WGRAD] == "k_wgrad_adam"
+            kname = ("k_tower4<true" if trainable else "k_tower4<false") + fm[:-1] + (", true" if w1l else ", false") + \
+                (", true>" if pre4 else ", false>")
         else:
-            kname = ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm
+            # template <TRAIN, DXW, FM, FZ>; FZ (k_wgrad_adam's duties compiled in) only on that path
+            fz = ", true>" if (not trainable and tower == "mlp" and eng.step_kernel_names(batch)[L.KERNEL_WGRAD] == "k_wgrad_adam") \
+                else ", false>"
+            kname = ("k_tower<true, 256" if trainable else "k_tower<true, 0") + fm[:-1] + fz
         if tower == "star":
-            kname = "k_tower<true, 384, false>"
+            kname = "k_tower<true, 384, false, false>"
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows,
                                    tower_flops_per_row(384 if tower == "star" else (256 if trainable else 0)))
         roofline["rocprofv3_avg_us"] = rocprof_avg_us(kname, wl["shape"])

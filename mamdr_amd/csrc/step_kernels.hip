@@ -521,8 +521,10 @@ constexpr int PFB2 = 2, PFB1 = MAMDR_PFB1, PFB0 = 4;
 // FM: DeepFM tower: logit += sum_f w_f[id_f] + sum_k (u i + u d + i d)_k.
 // DXW: width of the input gradient written to a.dxe: 0 none, 256 = [user | item] (trainable tables),
 // 384 = all three fields (Star: PartitionedNorm's backward needs d loss / d normalised input).
-template <bool TRAIN, int DXW, bool FM>
+// FZ: the k_wgrad_adam path's duties compiled in (pre-gathered passes, the pending domain-table step, the W0 snapshot)
+template <bool TRAIN, int DXW, bool FM, bool FZ = false>
 __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
+    static_assert(!FZ || (TRAIN && DXW == 0 && !FM), "k_wgrad_adam serves the frozen-table mlp tower");
     constexpr bool DX = DXW > 0;
     constexpr int DXN = DX ? DXW : 2 * EMB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -554,14 +556,18 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     constexpr int PFB0V = DXN > 2 * EMB ? 2 : PFB0;
     BwdW<H1, DXN, H1, PFB0V, 8> bw0;
     STAMP(0);
-    const bool pre = TRAIN && a.xpre != nullptr;
+    // the k_wgrad_adam path (pre-gathered passes, the pending domain-table step) exists for the frozen-table mlp tower
+    // only and is an instance of its own: compiled into every instance, its registers cost the 384-wide Star variant
+    // the second co-resident workgroup per CU (202 instead of <= 128 VGPRs: k_tower<384> 64.9 -> 72 us at 8,192 rows)
+    constexpr bool FUSED_OK = FZ;
+    const bool pre = FUSED_OK && a.xpre != nullptr;
     PreTile pt;
     if (pre) early_pre(a, r0, pt);
     const int perm_src = pre ? 0 : early_perm(a, r0);
     __builtin_amdgcn_sched_barrier(0);
     fw0.prefetch(P + a.L.w0, P + a.L.b0);
-    if (TRAIN) tower_snapshots(a, TOWER_THREADS, n_tiles);
-    const bool dmw = TRAIN && a.dm_snap_out != nullptr;      // k_wgrad_adam path: domain-table duty (DmStep)
+    if (FUSED_OK) tower_snapshots(a, TOWER_THREADS, n_tiles);
+    const bool dmw = FUSED_OK && a.dm_snap_out != nullptr;   // k_wgrad_adam path: domain-table duty (DmStep)
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
     const float gb_reg = P[a.L.gb];
 
@@ -765,6 +771,8 @@ void launch_tower_train(const TowerArgs& a, hipStream_t s) {
         MAMDR_LAUNCH((k_tower<true, 384, false>), grid, block, lds, s, a);
     } else if (a.dxe) {
         MAMDR_LAUNCH((k_tower<true, 256, false>), grid, block, lds, s, a);
+    } else if (a.xpre || a.dm_snap_out || a.dms.snap || a.w0dom_snap) {
+        MAMDR_LAUNCH((k_tower<true, 0, false, true>), grid, block, lds, s, a);
     } else {
         MAMDR_LAUNCH((k_tower<true, 0, false>), grid, block, lds, s, a);
     }

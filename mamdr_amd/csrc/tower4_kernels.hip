@@ -401,8 +401,11 @@ __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ?
 // DX: trainable user / item tables -> d loss / d [user | item] row = dz1 . W0[0:256,:]^T through the
 // transposed copy W0T (kept current by k_update), row ids + representatives for the table update.
 // FM: DeepFM tower (logit += linear tables + FM second-order term), as in k_tower.
-template <bool DX, bool FM, bool W1L>
+// PRE: the instance for pre-gathered passes (k_pass_prep; k_wgrad_adam path) -- the perm / uid / pid / table-row gather
+// is compiled out of it, and the pre-gather out of the other one
+template <bool DX, bool FM, bool W1L, bool PRE = false>
 __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
+    static_assert(!PRE || (!DX && !FM), "pre-gathered passes serve the frozen-table mlp tower");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
@@ -438,7 +441,10 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     int perm_src = 0;
     // pre-gathered pass (k_pass_prep): the tile's four [user | item] rows, domains and labels sit at known addresses;
     // every lane loads (clamped rows; lanes 256.. repeat rows 0..3), no dependent chain
-    const bool pre = a.xpre != nullptr;
+    // (the k_wgrad_adam path's duties -- pre-gathered passes, the pending domain-table step, the W0 snapshot -- exist
+    // for the frozen-table mlp tower only: compiled out of the DX / FM instances, see k_tower)
+    constexpr bool FUSED_OK = !DX && !FM;
+    constexpr bool pre = PRE;
     f32x4 xv = (f32x4){0.f, 0.f, 0.f, 0.f};
     int pre_dom = 0;
     float pre_lab = 0.f;
@@ -454,8 +460,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     w0.prefetch(P + a.L.w0);
-    tower_snapshots(a, T4_THREADS, n_tiles);
-    const bool dmw = a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
+    if (FUSED_OK) tower_snapshots(a, T4_THREADS, n_tiles);
+    const bool dmw = FUSED_OK && a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
     // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
     // the caller's expected domain, its loads -- misses to HBM -- delayed the x rows by 1.5 K cycles; measured)
     DmWave dmt;
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     __syncthreads();
     // domain-table step still pending (DmStep): the domain rows as that step leaves them.  `same`: one domain per tile
     // AND the one the caller announced (the addresses were formed from it); otherwise every lane works alone.
-    const bool pend = a.dms.snap != nullptr;
+    const bool pend = FUSED_OK && a.dms.snap != nullptr;
     const bool same = pend && rowi[8] == a.dm_hint && rowi[9] == rowi[8] && rowi[10] == rowi[8] && rowi[11] == rowi[8];
     T4STAMP(12);
     T4STAMP_W4(0);
@@ -782,17 +788,17 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
 
 // W1L needs the whole LDS of a CU: one workgroup per CU, i.e. grids of up to one tile per CU; larger grids keep the
 // streaming variant (30 KB of LDS, several workgroups per CU overlap each other's phases).
-template <bool DX, bool FM>
+template <bool DX, bool FM, bool PRE>
 static void launch_tower4_inst(const TowerArgs& a, dim3 grid, bool w1l, hipStream_t s) {
     static int raised = 0;         // 1: the LDS limit of the W1L instance is raised, -1: refused (streaming variant only)
     if (w1l && raised == 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true, PRE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true));
         raised = e == hipSuccess ? 1 : -1;
         if (e != hipSuccess) fprintf(stderr, "mamdr: k_tower4 keeps streaming W1 (%s)\n", hipGetErrorString(e));
     }
-    if (w1l && raised == 1) MAMDR_LAUNCH((k_tower4<DX, FM, true>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a);
-    else MAMDR_LAUNCH((k_tower4<DX, FM, false>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a);
+    if (w1l && raised == 1) MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a);
+    else MAMDR_LAUNCH((k_tower4<DX, FM, false, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a);
 }
 static int t4_cu_count() {
     static int n = 0;
@@ -809,12 +815,14 @@ void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const bool dx = a.dxe != nullptr;
     const bool w1l = !a.no_w1l && tiles <= t4_cu_count();
     if (a.deepfm) {
-        if (dx) launch_tower4_inst<true, true>(a, grid, w1l, s);
-        else launch_tower4_inst<false, true>(a, grid, w1l, s);
+        if (dx) launch_tower4_inst<true, true, false>(a, grid, w1l, s);
+        else launch_tower4_inst<false, true, false>(a, grid, w1l, s);
     } else if (dx) {
-        launch_tower4_inst<true, false>(a, grid, w1l, s);
+        launch_tower4_inst<true, false, false>(a, grid, w1l, s);
+    } else if (a.xpre) {
+        launch_tower4_inst<false, false, true>(a, grid, w1l, s);
     } else {
-        launch_tower4_inst<false, false>(a, grid, w1l, s);
+        launch_tower4_inst<false, false, false>(a, grid, w1l, s);
     }
 }
 
