@@ -422,13 +422,17 @@ def test_tower4_w1_image_is_bitwise(env):
     engine, synthetic = env
     out = {}
     for fused in ("1", "0"):
-        for mode in ("image", "stream"):
+        # ("gather": the k_wgrad_adam path without pre-gathered passes = the PRE = false instance with the domain-table
+        # duty; MAMDR_NO_PREGATHER promises bit-identical results)
+        for mode in ("image", "stream") + (("gather",) if fused == "1" else ()):
             os.environ["MAMDR_T4_NO_W1L"] = "1" if mode == "stream" else "0"
+            os.environ["MAMDR_NO_PREGATHER"] = "1" if mode == "gather" else "0"
             os.environ["MAMDR_FUSED"] = fused
             try:
                 g, eng, model = make_problem(env, scale=0.05, batch=1024, dropout=0.5)
             finally:
                 os.environ.pop("MAMDR_T4_NO_W1L", None)
+                os.environ.pop("MAMDR_NO_PREGATHER", None)
                 os.environ.pop("MAMDR_FUSED", None)
             d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
             n = g["data"]["train"][d]["uid"].shape[0]
@@ -437,6 +441,8 @@ def test_tower4_w1_image_is_bitwise(env):
             out[(fused, mode)] = eng.get_weights().cpu().numpy().copy()
             eng.close()
         assert np.array_equal(out[(fused, "image")], out[(fused, "stream")])
+        if fused == "1":
+            assert np.array_equal(out[(fused, "image")], out[(fused, "gather")])
 
 
 @pytest.mark.parametrize("batch", [256, 1024, 4096])
