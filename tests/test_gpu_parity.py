@@ -69,11 +69,14 @@ def assert_adam_close(got, want, n_steps, lr, name, max_frac=1e-3):
     gradient is within rounding of zero -- or a hidden unit whose pre-activation sits within rounding of
     the relu kink (a handful per batch once the weights differ by 1e-5) -- can legitimately move by up to
     lr per step in different directions (a flipped unit drags the small-gradient elements of its whole
-    weight column along).  Bar: all but 1e-3 of the elements within 5 % of k*lr, none
+    weight column along).  Bar: all but 1e-3 of the elements within 5 % of k*lr (2e-3 where the callers say so: the
+    worst fraction any test of this file has shown is 3.4e-4, MAMDR_TEST_REPORT_FRAC=1 prints them), none
     beyond the 2*k*lr Adam can produce, and the typical element far tighter."""
     diff = np.abs(np.asarray(got, F32).ravel() - np.asarray(want, F32).ravel())
     bound = 0.05 * n_steps * lr
     frac = float(np.mean(diff > bound))
+    if os.environ.get("MAMDR_TEST_REPORT_FRAC"):
+        print("ADAMFRAC %s n=%d frac=%.3e max_frac=%.0e maxdiff/klr=%.3f med/klr=%.5f" % (name, diff.size, frac, max_frac, diff.max() / (n_steps * lr), np.median(diff) / (n_steps * lr)))
     assert frac <= max_frac, (name, "fraction beyond %.1e: %.2e" % (bound, frac), float(diff.max()))
     assert diff.max() <= 2.02 * n_steps * lr, (name, float(diff.max()))
     assert float(np.median(diff)) < 0.002 * n_steps * lr, (name, float(np.median(diff)))
@@ -469,7 +472,7 @@ def test_fused_wgrad_adam_matches_the_slab_path(env, batch):
     np.testing.assert_allclose(ga, gb, rtol=2e-4, atol=2e-6 * max(np.abs(gb).max(), 1e-3))
     n_adam = 2 * 3 * 12
     for a, b, name in zip(runs["fused"][:1], runs["slabs"][:1], ("weights",)):
-        assert_adam_close(a, b, n_adam, 1e-3, name, max_frac=1e-2)
+        assert_adam_close(a, b, n_adam, 1e-3, name, max_frac=2e-3)
 
 
 @pytest.mark.parametrize("tower", ["mlp", "deepfm"])
@@ -519,7 +522,7 @@ def test_trainable_tables_heavy_duplicates(env, tower):
         model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
     got = eng.unpack(eng.get_weights())
     for name in model.names:
-        assert_adam_close(got[name], model.params[name], 2, 1e-3, name, max_frac=1e-2)
+        assert_adam_close(got[name], model.params[name], 2, 1e-3, name, max_frac=2e-3)
     eng.close()
 
 
@@ -547,7 +550,7 @@ def test_deepfm_gradients_adam_eval(env, emb_trainable, tower):
         model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
     got = eng.unpack(eng.get_weights())
     for name in model.names:
-        assert_adam_close(got[name], model.params[name], n_steps - first, 1e-3, name, max_frac=1e-2)
+        assert_adam_close(got[name], model.params[name], n_steps - first, 1e-3, name, max_frac=2e-3)
     eng.set_weights(eng.pack(model.params))      # re-synchronise before the tight gradient comparison
     for step in (0, n_steps - 1):          # a full batch and the final (partial) batch
         idx = perm[step * 256:(step + 1) * 256]
@@ -627,7 +630,7 @@ def test_large_batch_gradients_match_oracle(env, tower, emb_trainable, batch):
         model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
     got = eng.unpack(eng.get_weights())
     for name in model.names:
-        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=1e-2)
+        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=2e-3)
     eng.close()
 
 
@@ -813,7 +816,7 @@ def test_maml_epoch_matches_oracle(env):
         # three outer Adam steps of size ~meta_lr each (see assert_adam_close for the bar).  The outer Adam's
         # first steps are sign-like: a hidden unit that is dead on one path and revived by one rounding-level
         # activation on the other moves its incoming weight column and outgoing weight row (<1 % of a tensor) by ~meta_lr.
-        assert_adam_close(got[nme], theta_o[o:o + sz], 3, 0.01, nme, max_frac=1e-2)
+        assert_adam_close(got[nme], theta_o[o:o + sz], 3, 0.01, nme, max_frac=2e-3)
         o += sz
     eng.close()
 
@@ -1320,7 +1323,7 @@ def test_uncertainty_weighted_step_matches_oracle(env, batch):
         model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
     got = eng.unpack(eng.get_weights())
     for name in model.names:
-        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=1e-2)
+        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=2e-3)
     # evaluation is the base model's: unweighted loss
     loss_g, _ = eng.evaluate(d, "val")
     loss_o, _ = model.evaluate(g["data"]["val"][d], eng.eval_batch)
@@ -1379,7 +1382,7 @@ def test_pcgrad_epoch_matches_oracle(env):
     assert tr_g == tr_o
     got = eng.unpack(eng.get_weights())
     for name in model.names:
-        assert_adam_close(got[name], model.params[name], 3, 0.003, name, max_frac=1e-2)
+        assert_adam_close(got[name], model.params[name], 3, 0.003, name, max_frac=2e-3)
     assert int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == 0          # the inner optimiser never stepped
     eng.close()
 
