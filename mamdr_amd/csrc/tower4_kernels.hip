@@ -403,8 +403,14 @@ __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ?
 // FM: DeepFM tower (logit += linear tables + FM second-order term), as in k_tower.
 // PRE: the instance for pre-gathered passes (k_pass_prep; k_wgrad_adam path) -- the perm / uid / pid / table-row gather
 // is compiled out of it, and the pre-gather out of the other one
+// The leading scalar arguments repeat what the prologue's first loads need (pass pointers, rows, W0, W1): with
+// -mllvm -amdgpu-kernarg-preload-count (mamdr_amd/build.py) they arrive in SGPRs with the wave, and those loads go out
+// without waiting for the argument block's own fetch (probe, tools/probes/kernarg_preload_probe.hip: entry -> first
+// load returned 840 -> 380 cycles).  `a` carries the same values; only the prologue reads the copies.
 template <bool DX, bool FM, bool W1L, bool PRE = false>
-__global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
+__global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__ k_xpre, const int32_t* __restrict__ k_pdom,
+                                                       const float* __restrict__ k_plabel, const float* __restrict__ k_w0,
+                                                       const float* __restrict__ k_w1, const int k_rows, const TowerArgs a) {
     static_assert(!PRE || (!DX && !FM), "pre-gathered passes serve the frozen-table mlp tower");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -449,17 +455,17 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     int pre_dom = 0;
     float pre_lab = 0.f;
     if (pre) {
-        const int rr = min(r0 + ((tid >> 6) & 3), max(a.rows - 1, 0));
-        xv = *reinterpret_cast<const f32x4*>(a.xpre + (size_t)rr * (2 * EMB) + 4 * (tid & 63));
-        const int rb = min(r0 + (tid & 3), max(a.rows - 1, 0));
-        pre_dom = a.pdom[rb];
-        pre_lab = a.plabel[rb];
+        const int rr = min(r0 + ((tid >> 6) & 3), max(k_rows - 1, 0));
+        xv = *reinterpret_cast<const f32x4*>(k_xpre + (size_t)rr * (2 * EMB) + 4 * (tid & 63));
+        const int rb = min(r0 + (tid & 3), max(k_rows - 1, 0));
+        pre_dom = k_pdom[rb];
+        pre_lab = k_plabel[rb];
     } else if (a.perm) {       // uniform
         const int64_t pc = a.row_base + min(r0 + (tid & (T4_ROWS - 1)), max(a.rows - 1, 0));
         perm_src = a.perm[pc];
     }
     __builtin_amdgcn_sched_barrier(0);
-    w0.prefetch(P + a.L.w0);
+    w0.prefetch(k_w0);
     if (FUSED_OK) tower_snapshots(a, T4_THREADS, n_tiles);
     const bool dmw = FUSED_OK && a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
     // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // consume nothing before layer 0) 14.3-14.6 -- they sit in the issue queue until most of the image has landed and
     // hold the bookkeeping barrier; the same without that barrier (domains by scalar loads) 14.9; counted requests
     // (__builtin_amdgcn_global_load_lds: vmcnt(0) at the first use of any load) 14.6; no image 15.1-15.3.
-    if (W1L && pre) t4_w1_request<32>(P + a.L.w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
+    if (W1L && pre) t4_w1_request<32>(k_w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- row bookkeeping + embedding gather (4 rows x 96 float4)
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     // (pending + one-domain tile: the domain columns of x are filled between layer 0's two segments, see midseg)
     // (no pre-gathered pass: the gather's dependent loads are younger than anything requested above and would wait
     // for the image as well -- it is requested only now)
-    if (W1L && !pre) t4_w1_request<32>(P + a.L.w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
+    if (W1L && !pre) t4_w1_request<32>(k_w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
     T4STAMP_W4(2);
     __syncthreads();
     if (FM) {
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const TowerArgs a) {
     const bool drop = a.use_dropout != 0;
 
     // ---- layer 0: 384 -> 256
-    t4_contract_l0(w0, P + a.L.w0, smem + T4_XS, red, acc0,
+    t4_contract_l0(w0, k_w0, smem + T4_XS, red, acc0,
                    [&]() {
                        if (!dmw) return;
                        // every wave finishes the 16 domain columns ITS second segment contracts (partials requested
@@ -797,8 +803,14 @@ static void launch_tower4_inst(const TowerArgs& a, dim3 grid, bool w1l, hipStrea
         raised = e == hipSuccess ? 1 : -1;
         if (e != hipSuccess) fprintf(stderr, "mamdr: k_tower4 keeps streaming W1 (%s)\n", hipGetErrorString(e));
     }
-    if (w1l && raised == 1) MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a);
-    else MAMDR_LAUNCH((k_tower4<DX, FM, false, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a);
+    const float* w0 = a.dense + a.L.w0;
+    const float* w1 = a.dense + a.L.w1;
+    if (w1l && raised == 1)
+        MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a.xpre, a.pdom, a.plabel, w0, w1,
+                     a.rows, a);
+    else
+        MAMDR_LAUNCH((k_tower4<DX, FM, false, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a.xpre, a.pdom, a.plabel, w0,
+                     w1, a.rows, a);
 }
 static int t4_cu_count() {
     static int n = 0;
