@@ -14,11 +14,11 @@ BUILD = os.path.join(HERE, "build")
 
 # (source, extra flags).  outer_kernels must not fuse multiply-adds (bit-exact vs numpy).
 SOURCES = [
-    ("step_kernels.hip", []),
+    # (kernarg preload: the leading scalar arguments of k_tower / k_tower4 arrive in SGPRs with the wave)
+    ("step_kernels.hip", ["-mllvm", "-amdgpu-kernarg-preload-count=14"]),
     # emb_kernels: the lazy and the dense table updates must round identically -> no implicit fma fusion
     # (HIP's __fmul_rn / __fadd_rn are plain operators; explicit __fmaf_rn where an fma is wanted)
     ("emb_kernels.hip", ["-ffp-contract=off"]),
-    # kernarg preload: the leading scalar arguments of k_tower4 arrive in SGPRs with the wave
     ("tower4_kernels.hip", ["-mllvm", "-amdgpu-kernarg-preload-count=14"]),
     ("fused_kernels.hip", []),
     ("star_kernels.hip", []),

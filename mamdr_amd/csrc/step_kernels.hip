@@ -523,7 +523,11 @@ constexpr int PFB2 = 2, PFB1 = MAMDR_PFB1, PFB0 = 4;
 // 384 = all three fields (Star: PartitionedNorm's backward needs d loss / d normalised input).
 // FZ: the k_wgrad_adam path's duties compiled in (pre-gathered passes, the pending domain-table step, the W0 snapshot)
 template <bool TRAIN, int DXW, bool FM, bool FZ = false>
-__global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
+__global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restrict__ k_perm, const int64_t k_row_base,
+                                                        const float* __restrict__ k_w0, const float* __restrict__ k_b0,
+                                                        const int k_rows, const TowerArgs a) {
+    // (leading scalar arguments = what the prologue's first loads need, preloaded into SGPRs with the wave -- see
+    // k_tower4 -- `a` carries the same values)
     static_assert(!FZ || (TRAIN && DXW == 0 && !FM), "k_wgrad_adam serves the frozen-table mlp tower");
     constexpr bool DX = DXW > 0;
     constexpr int DXN = DX ? DXW : 2 * EMB;
@@ -563,9 +567,10 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const TowerArgs a) {
     const bool pre = FUSED_OK && a.xpre != nullptr;
     PreTile pt;
     if (pre) early_pre(a, r0, pt);
-    const int perm_src = pre ? 0 : early_perm(a, r0);
+    int perm_src = 0;
+    if (!pre && k_perm) perm_src = k_perm[k_row_base + min(r0 + (int)(threadIdx.x & (TILE_ROWS - 1)), max(k_rows - 1, 0))];
     __builtin_amdgcn_sched_barrier(0);
-    fw0.prefetch(P + a.L.w0, P + a.L.b0);
+    fw0.prefetch(k_w0, k_b0);
     if (FUSED_OK) tower_snapshots(a, TOWER_THREADS, n_tiles);
     const bool dmw = FUSED_OK && a.dm_snap_out != nullptr;   // k_wgrad_adam path: domain-table duty (DmStep)
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
@@ -765,24 +770,26 @@ void launch_tower_train(const TowerArgs& a, hipStream_t s) {
     const dim3 grid(tiles), block(TOWER_THREADS);
     const size_t lds = tower_lds_bytes();
     if (a.deepfm) {
-        if (a.dxe) MAMDR_LAUNCH((k_tower<true, 256, true>), grid, block, lds, s, a);
-        else MAMDR_LAUNCH((k_tower<true, 0, true>), grid, block, lds, s, a);
+        if (a.dxe) MAMDR_LAUNCH((k_tower<true, 256, true>), grid, block, lds, s, a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a);
+        else MAMDR_LAUNCH((k_tower<true, 0, true>), grid, block, lds, s, a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a);
     } else if (a.dxe && a.dx_ld == XDIM) {
-        MAMDR_LAUNCH((k_tower<true, 384, false>), grid, block, lds, s, a);
+        MAMDR_LAUNCH((k_tower<true, 384, false>), grid, block, lds, s, a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a);
     } else if (a.dxe) {
-        MAMDR_LAUNCH((k_tower<true, 256, false>), grid, block, lds, s, a);
+        MAMDR_LAUNCH((k_tower<true, 256, false>), grid, block, lds, s, a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a);
     } else if (a.xpre || a.dm_snap_out || a.dms.snap || a.w0dom_snap) {
-        MAMDR_LAUNCH((k_tower<true, 0, false, true>), grid, block, lds, s, a);
+        MAMDR_LAUNCH((k_tower<true, 0, false, true>), grid, block, lds, s, a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a);
     } else {
-        MAMDR_LAUNCH((k_tower<true, 0, false>), grid, block, lds, s, a);
+        MAMDR_LAUNCH((k_tower<true, 0, false>), grid, block, lds, s, a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a);
     }
 }
 void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
     const int tiles = (a.rows + TILE_ROWS - 1) / TILE_ROWS;
     if (a.deepfm)
-        hipLaunchKernelGGL((k_tower<false, 0, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        hipLaunchKernelGGL((k_tower<false, 0, true>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a.perm, a.row_base, a.dense + a.L.w0,
+                           a.dense + a.L.b0, a.rows, a);
     else
-        hipLaunchKernelGGL((k_tower<false, 0, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a);
+        hipLaunchKernelGGL((k_tower<false, 0, false>), dim3(tiles), dim3(TOWER_THREADS), tower_lds_bytes(), s, a.perm, a.row_base, a.dense + a.L.w0,
+                           a.dense + a.L.b0, a.rows, a);
 }
 
 // ------------------------------------------------------------------ standalone gather
