@@ -1122,8 +1122,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& g, const int bid, fl
     }
     WSTAMP(4);
 }
-__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
+// (leading scalar arguments: preloaded into SGPRs with the wave -- see k_tower4 -- so that the tile descriptor and the
+// first operand rows are requested before the argument block has been fetched; `g0` carries the same values)
+#define WGRAD_EARLY_PARAMS                                                                                             \
+    const float *__restrict__ k_acts, const float *__restrict__ k_dz, const TileDesc *__restrict__ k_tiles,            \
+        const int k_n_tiles, const int k_rows_pad, const int k_n_groups, const int k_rows_per_group
+#define WGRAD_EARLY_ARGS(a) (a).acts, (a).dz, (a).tiles, (a).n_tiles, (a).rows_pad, (a).n_groups, (a).rows_per_group
+#define WGRAD_EARLY_APPLY(g, g0)                                                                                       \
+    WgradArgs g = g0;                                                                                                  \
+    g.acts = k_acts; g.dz = k_dz; g.tiles = k_tiles; g.n_tiles = k_n_tiles; g.rows_pad = k_rows_pad;                  \
+    g.n_groups = k_n_groups; g.rows_per_group = k_rows_per_group
+__global__ __launch_bounds__(256) void k_wgrad(WGRAD_EARLY_PARAMS, const WgradArgs g0) {
     __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
+    WGRAD_EARLY_APPLY(g, g0);
     wgrad_body(g, (int)blockIdx.x, red);
 }
 // k_wgrad and k_emb_reduce only need the tower's outputs and write disjoint state: one launch, the table
@@ -1131,9 +1142,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs g) {
 // ... and the NEXT step's k_emb_rows (n_rows workgroups): it writes the other half of the row-id / map double
 // buffer, so this step's reduction still sees its own maps
 // ... and (Star tower) the domain-row column sums of PartitionedNorm's backward, n_dm workgroups of 16 columns
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradArgs g, const EmbStepArgs e, const int n_wgrad,
-                                                      const EmbRowsArgs nr, const int n_rows, const StarPnBwdArgs sd,
-                                                      const int n_dm) {
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WGRAD_EARLY_PARAMS, const WgradArgs g0, const EmbStepArgs e,
+                                                      const int n_wgrad, const EmbRowsArgs nr, const int n_rows,
+                                                      const StarPnBwdArgs sd, const int n_dm) {
+    WGRAD_EARLY_APPLY(g, g0);
     __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
     int bid = (int)blockIdx.x;
     if (bid < n_dm) {
@@ -1164,11 +1176,11 @@ void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRows
     memset(&sd, 0, sizeof(sd));
     if (star_dm) sd = *star_dm;
     const int n_dm = star_dm ? EMB / 16 : 0;
-    MAMDR_LAUNCH(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, a, e, n_wgrad,
+    MAMDR_LAUNCH(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a, e, n_wgrad,
                        nr, n_rows, sd, n_dm);
 }
 void launch_wgrad(const WgradArgs& a, hipStream_t s) {
-    MAMDR_LAUNCH(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a);
 }
 
 // sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
@@ -1355,16 +1367,26 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
         u.p[el] = p;
     }
 }
-__global__ __launch_bounds__(256) void k_update(const UpdateArgs u) {
+#define UPDATE_EARLY_PARAMS                                                                                            \
+    float *__restrict__ k_p, float *__restrict__ k_m, float *__restrict__ k_v, const float *__restrict__ k_slabs,      \
+        const int k_n_groups, const int k_slab_ld, const int k_count4, const int k_dm_count, const int k_optimizer
+#define UPDATE_EARLY_ARGS(a) (a).p, (a).m, (a).v, (a).slabs, (a).n_groups, (a).slab_ld, (a).count4, (a).dm_count, (a).optimizer
+#define UPDATE_EARLY_APPLY(u, u0)                                                                                      \
+    UpdateArgs u = u0;                                                                                                 \
+    u.p = k_p; u.m = k_m; u.v = k_v; u.slabs = k_slabs; u.n_groups = k_n_groups; u.slab_ld = k_slab_ld;               \
+    u.count4 = k_count4; u.dm_count = k_dm_count; u.optimizer = k_optimizer
+__global__ __launch_bounds__(256) void k_update(UPDATE_EARLY_PARAMS, const UpdateArgs u0) {
     __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];     // n_domain <= 64
+    UPDATE_EARLY_APPLY(u, u0);
     update_body(u, (int)blockIdx.x, s_l);
 }
 // k_update and DeepFM's k_lin_sweep touch disjoint state: one launch
 // ... and so does the NEXT step's k_emb_catchup (n_cu workgroups per table; its rows were resolved in the previous
 // launch, k_wgrad_reduce): the rows of the next batch are brought up to this step while the dense block steps
-__global__ __launch_bounds__(256) void k_update_lin(const UpdateArgs u, const EmbStepArgs e, const int n_update, const int n_lin,
-                                                    const EmbStepArgs nc, const int n_cu) {
+__global__ __launch_bounds__(256) void k_update_lin(UPDATE_EARLY_PARAMS, const UpdateArgs u0, const EmbStepArgs e,
+                                                    const int n_update, const int n_lin, const EmbStepArgs nc, const int n_cu) {
     __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
+    UPDATE_EARLY_APPLY(u, u0);
     const int bid = (int)blockIdx.x;
     if (bid < 2 * n_cu) emb_catchup_body(nc, bid % n_cu, bid / n_cu);
     else if (bid < 2 * n_cu + n_update) update_body(u, bid - 2 * n_cu, s_l);
@@ -1375,7 +1397,7 @@ static int update_blocks(const UpdateArgs& a) {
     return n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0);
 }
 void launch_update(const UpdateArgs& a, hipStream_t s) {
-    MAMDR_LAUNCH(k_update, dim3(update_blocks(a)), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_update, dim3(update_blocks(a)), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a);
 }
 void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s) {
     const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
@@ -1384,8 +1406,8 @@ void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, cons
     const int n_update = update_blocks(a);
     const EmbStepArgs& nc = next_catchup ? *next_catchup : e;
     const int n_cu = next_catchup ? (nc.rows + 7) / 8 : 0;
-    MAMDR_LAUNCH(k_update_lin, dim3(2 * n_cu + n_update + (int)n_lin), dim3(256), 0, s, a, e, n_update, (int)n_lin, nc,
-                       n_cu);
+    MAMDR_LAUNCH(k_update_lin, dim3(2 * n_cu + n_update + (int)n_lin), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a, e, n_update,
+                 (int)n_lin, nc, n_cu);
 }
 
 }  // namespace mamdr
