@@ -415,8 +415,11 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         # every launch is one batch; a pass of n_steps launches covers min(rows of the domain, n_steps*batch) rows
         prof_rows = sum(min(sizes[d], n * batch) for (_, d, n) in prof_trace)
         assert cnt == sum(n for (_, _, n) in prof_trace)
-        # batches <= 2048 rows launch the 4-row-tile kernel (mamdr_api.hip: use4), template <DX, FM>
-        use4 = batch <= 2048 and tower != "star" and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
+        # the 4-row-tile kernel (mamdr_api.hip: use4 / tower4_max_rows): up to one round of workgroups (4 rows x CUs) for
+        # the frozen-table mlp tower, up to 2,048 rows with trainable tables / DeepFM; template <DX, FM, W1L, PRE>
+        n_cu = torch.cuda.get_device_properties(eng.device).multi_processor_count
+        t4_max = min(2048, max(256, 4 * n_cu)) if (tower == "mlp" and not trainable) else 2048
+        use4 = batch <= t4_max and tower != "star" and os.environ.get("MAMDR_TOWER_TILE", "") != "16"
         fm = ", true>" if tower == "deepfm" else ", false>"
         if use4:
             # template <DX, FM, W1L>; W1L (the W1 image in LDS) at one 4-row tile per CU or less (tower4_kernels.hip)

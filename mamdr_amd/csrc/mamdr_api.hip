@@ -102,7 +102,9 @@ struct mamdr_ctx {
     // instead of k_wgrad -> slabs -> k_update (MAMDR_FUSED=0 keeps the slab path)
     bool fused = false;
     int t4_no_w1l = 0;              // MAMDR_T4_NO_W1L=1: k_tower4 without the W1 image in LDS (diagnostic)
-    int fused_max_batch = 2048;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size)
+    int fused_max_batch = 1024;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size):
+                                    // 4 rows x the CU count, set at mamdr_create
+    int tower4_max_rows = 2048;     // steps of up to this many (padded) rows run k_tower4, see mamdr_create
     float* pdm = nullptr;           // [32][n_domain][EMB] partial domain-table gradients
     // the domain table's step stays pending until the next tower kernel applies it (DmStep, mamdr_kernels.h):
     // two snapshots [3][n_domain][EMB] of (p, m, v) alternate between steps
@@ -733,6 +735,21 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
     {
         if (const char* nw = getenv("MAMDR_T4_NO_W1L")) c->t4_no_w1l = atoi(nw) != 0;
+        // Which tower for how many rows (frozen-table mlp, measured at 2,048 rows of Taobao-10, us / step): k_tower4 +
+        // k_wgrad_adam 40.4 (512 four-row tiles: two rounds of workgroups, no W1 image), k_tower + k_wgrad_adam 39.0,
+        // k_tower + k_wgrad + k_update 38.6 (128 sixteen-row tiles, the lean instance: 21.4 us against k_tower4's 26.9).
+        // So the four-row tower and the fused path serve what fits ONE round of workgroups (4 rows x CUs = 1,024 rows);
+        // with trainable tables or the DeepFM terms the four-row tower stays ahead up to 2,048 rows (Amazon-6 at
+        // 2,048: 29.3 vs 34.2 us).
+        {
+            int dev = 0, n_cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                n_cu <= 0)
+                n_cu = 256;
+            const int one_round = std::min(2048, std::max(256, 4 * n_cu));
+            c->fused_max_batch = one_round;
+            if (cfg->tower == MAMDR_TOWER_MLP && !cfg->emb_trainable) c->tower4_max_rows = one_round;
+        }
         const char* fe = getenv("MAMDR_FUSED");
         c->fused = cfg->tower == MAMDR_TOWER_MLP && !cfg->emb_trainable && !cfg->uncertainty_weight && c->lin_w0dom &&
                    cfg->n_domain <= 64 && !(fe && atoi(fe) == 0);
@@ -1133,7 +1150,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.wT = c->wT;
         ta.no_w1l = c->t4_no_w1l;
         float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
-        const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= 2048);
+        const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= c->tower4_max_rows);
         if (fused) {
             ta.w0dom_snap = c->w0dom_copy;
             c->dm_cur ^= 1;
