@@ -1023,7 +1023,15 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
     const bool may_use4 = !c->star && c->tower_tile != 16;
-    const bool need_wT = may_use4 && n_steps > 0;
+    // ... only when a step of THIS call is small enough for that tower (the rows of a pass's steps never grow: the
+    // last one is the smallest) -- a 4,096-row call over a domain without a short last batch needs no copies at all
+    bool need_wT = false;
+    if (may_use4 && n_steps > 0) {
+        const int64_t last_base = (first_step + n_steps - 1) * (int64_t)batch;
+        const int64_t last_rows = std::min<int64_t>(batch, pass_rows - last_base);
+        const int64_t last_pad = (last_rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+        need_wT = c->tower_tile == 4 || last_pad <= c->tower4_max_rows;
+    }
 
     c->rows_ready = false;
     c->catchup_ready = false;
@@ -1190,7 +1198,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             fa.w0dom_snap = c->w0dom_copy;
             fa.dm_snap = c->dmsnap[c->dm_cur];         // p plane: the domain table as this step's forward pass saw it
             fa.pdm = c->pdm;
-            fa.wT = (may_use4 && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
+            fa.wT = (need_wT && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
             fa.optimizer = optimizer;
             fa.alpha = step_alpha;
             fa.omb1 = omb1;
@@ -1344,7 +1352,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.omb1 = omb1;
         ua.omb2 = omb2;
         ua.eps = c->cfg.adam_eps;
-        ua.wT = (may_use4 && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
+        ua.wT = (need_wT && optimizer != MAMDR_OPT_ACCUMULATE) ? c->wT : nullptr;
         ua.w1_off = c->L.w1;
         ua.w2_off = c->L.w2;
         ua.w0_off = c->L.w0;
