@@ -101,6 +101,8 @@ struct mamdr_ctx {
     // mlp tower with frozen tables: weight gradients + optimiser step in one launch (k_wgrad_adam) + k_dm_finish
     // instead of k_wgrad -> slabs -> k_update (MAMDR_FUSED=0 keeps the slab path)
     bool fused = false;
+    float* star_alpha = nullptr;    // Star tower: alphas of the current call's steps (lazy replay of the other domains' slices)
+    int star_dense_slices = 0;      // MAMDR_STAR_DENSE_SLICES=1: every slice swept every step (diagnostic; same bits)
     int t4_no_w1l = 0;              // MAMDR_T4_NO_W1L=1: k_tower4 without the W1 image in LDS (diagnostic)
     int fused_max_batch = 1024;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size):
                                     // 4 rows x the CU count, set at mamdr_create
@@ -355,6 +357,7 @@ static void fill_emb_args(const mamdr_ctx* c, int32_t optimizer, float alpha, fl
     }
 }
 
+constexpr int STAR_ALPHA_CAP = 1 << 12;      // steps between two replays of the lagging Star slices (power of two)
 static float table_two_l2(const mamdr_ctx* c) { return c->star ? 0.f : 2.0f * c->cfg.l2_emb; }
 
 // every table row -> current at adam_t (no-op when nothing lags)
@@ -451,9 +454,11 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
 
 // ---- Star tower: one training step on `rows` rows of domain `domain` (star.py:70-97; kernels in star_kernels.hip)
 // next_rows (nullable): the NEXT step's k_emb_rows arguments (alternate buffers), riding in this step's last launch
+// lazy_idx >= 0: only slice `domain` of the per-domain tensors is stepped (the others are replayed by the caller,
+// k_star_catchup) and the step's alpha is logged at that slot
 static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const int32_t* d_perm, int64_t row_base, int rows,
                            int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out,
-                           const EmbRowsArgs* next_rows, const EmbStepArgs* next_catchup) {
+                           const EmbRowsArgs* next_rows, const EmbStepArgs* next_catchup, int lazy_idx) {
     const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
     const int chunks = (rows + STAR_CHUNK - 1) / STAR_CHUNK;
     float* blk = c->params + c->table_floats;
@@ -596,6 +601,11 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ua.opt.omb2 = omb2;
     ua.opt.eps = c->cfg.adam_eps;
     ua.opt.two_l2 = 0.f;
+    if (lazy_idx >= 0) {
+        ua.only_live = 1;
+        ua.alpha_log = c->star_alpha;
+        ua.log_idx = lazy_idx;
+    }
     {
         Prof p(c, MAMDR_KERNEL_UPDATE);
         if (tail && next_catchup) launch_star_update_catchup(ua, *next_catchup, c->stream);
@@ -694,6 +704,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         const size_t chunks = (rp + STAR_CHUNK - 1) / STAR_CHUNK;
         ALLOC(c->eff, (size_t)c->L.alloc * sizeof(float));
         ALLOC(c->pn, (size_t)PN_WS_FLOATS * sizeof(float));
+        ALLOC(c->star_alpha, (size_t)STAR_ALPHA_CAP * sizeof(float));
+        if (const char* sd = getenv("MAMDR_STAR_DENSE_SLICES")) c->star_dense_slices = atoi(sd) != 0;
         ALLOC(c->star_part, chunks * 2 * XDIM * sizeof(float));
         ALLOC(c->star_sums, (2 * XDIM + EMB) * sizeof(float));
         ALLOC(c->star_dmpart, chunks * EMB * sizeof(float));
@@ -804,7 +816,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             (void)hipEventDestroy(p.b);
         }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->pdm, c->dmsnap[0], c->dmsnap[1], c->xpre, c->pdom, c->plabel, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->star_alpha, c->pdm, c->dmsnap[0], c->dmsnap[1], c->xpre, c->pdom, c->plabel, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1083,6 +1095,14 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     } else if (need_wT) {
         launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
     }
+    // Star tower: a batch carries one domain, so D - 1 of the D slices of every per-domain tensor see a zero gradient
+    // and only decay -- TF1's dense Adam still moves them every step (star_kernels.hip).  Inside a call those steps are
+    // postponed: k_star_update covers the live slice only and logs the step's alpha, k_star_catchup replays the
+    // skipped steps when the call ends (the same arithmetic in the same order: bit-identical; one sweep of the 13
+    // slices per call instead of one per step).  Calls of a single step gain nothing and sweep as before.
+    const bool star_lazy = c->star && optimizer == MAMDR_OPT_ADAM && n_steps >= 2 && !d_loss_out && !c->star_dense_slices &&
+                           c->cfg.n_domain > 1;
+    int64_t star_lag = 0;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         const int rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
@@ -1119,9 +1139,34 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
                 nea.t[1].map = c->map_i_alt;
             }
             const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, step_alpha, omb1, omb2,
-                                           d_loss_out ? d_loss_out + s : nullptr, pre ? &nr : nullptr, pre ? &nea : nullptr);
+                                           d_loss_out ? d_loss_out + s : nullptr, pre ? &nr : nullptr, pre ? &nea : nullptr,
+                                           star_lazy ? (int)(star_lag & (STAR_ALPHA_CAP - 1)) : -1);
             if (rc) return rc;
             c->global_step += 1;
+            if (star_lazy) {
+                star_lag += 1;
+                if (star_lag == STAR_ALPHA_CAP || s + 1 == n_steps) {       // the other slices catch up: log full / call over
+                    StarCatchArgs ca;
+                    memset(&ca, 0, sizeof(ca));
+                    ca.p = c->params + c->table_floats;
+                    ca.m = c->adam_m + c->table_floats;
+                    ca.v = c->adam_v + c->table_floats;
+                    ca.SL = c->SL;
+                    ca.n_domain = c->cfg.n_domain;
+                    ca.d_live = domain;
+                    ca.alpha_log = c->star_alpha;
+                    ca.first_idx = 0;
+                    ca.n_steps = (int)star_lag;
+                    ca.log_mask = STAR_ALPHA_CAP - 1;
+                    ca.omb1 = omb1;
+                    ca.omb2 = omb2;
+                    ca.eps = c->cfg.adam_eps;
+                    prof_break(c);
+                    launch_star_catchup(ca, c->stream);
+                    prof_break(c);
+                    star_lag = 0;
+                }
+            }
             continue;
         }
 

@@ -684,7 +684,24 @@ struct StarUpdateArgs {
     const float* dmsum;        // [EMB] gradient of the domain-table row d
     const float* xdom;         // [EMB] the batch's normalised domain row (k_star_prep)
     OptArgsLite opt;
+    // lazy replay of the other domains' slices (Adam only): the launch covers slice d alone and logs the step's alpha
+    int only_live;
+    float* alpha_log;          // [log_mask + 1] alphas of this call's steps, slot = step index inside the call
+    int log_idx;
 };
+// k_star_catchup: every slice but d_live takes the n_steps zero-gradient Adam steps it skipped (same arithmetic, same
+// order: bit-identical to the per-step sweep)
+struct StarCatchArgs {
+    float* p;
+    float* m;
+    float* v;
+    StarLayout SL;
+    int n_domain, d_live;
+    const float* alpha_log;
+    int first_idx, n_steps, log_mask;
+    float omb1, omb2, eps;
+};
+void launch_star_catchup(const StarCatchArgs& a, hipStream_t s);
 void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hipStream_t s);
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
 void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s);

@@ -26,6 +26,26 @@ namespace mamdr {
 namespace {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// One Adam step of an element whose gradient is exactly zero (the Star slices of the domains a batch does not carry):
+// explicit roundings, shared by the per-step sweep and by k_star_catchup's replay -- the same bits either way.
+// (square root and reciprocal on the hardware units, v_sqrt_f32 / v_rcp_f32, 1 ulp, as emb_bodies.h's adam_elem: the
+// replay of a long call is bound by exactly this sequence -- with the correctly rounded library forms it cost 2.6 us per
+// replayed step on Amazon-13 -- and both sites share it)
+__device__ __forceinline__ void adam_zero_step(float& p, float& m, float& v, float alpha, float omb1, float omb2, float eps) {
+#pragma clang fp contract(off)
+    m = m + (0.f - m) * omb1;
+    v = v + (0.f - v) * omb2;
+    p = p - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+}
+// (SGD and accumulate steps leave a zero-gradient element alone)
+__device__ __forceinline__ void opt_zero(const OptArgsLite& o, float* p, float* m, float* v, size_t i) {
+    if (o.optimizer != 0) return;
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_zero_step(pp, mm, vv, o.alpha, o.omb1, o.omb2, o.eps);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+}
 __device__ __forceinline__ void opt_apply(const OptArgsLite& o, float g, float* p, float* m, float* v, size_t i) {
     if (o.optimizer == 0) {
         float mm = m[i], vv = v[i];
@@ -348,7 +368,7 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
         const int i = e - (l == 0 ? 0 : (l == 1 ? K0 : K0 + K1));
         const size_t wi = (size_t)u.SL.wd[l] + (size_t)dd * StarLayout::ksize(l) + i;
         if (!live) {
-            opt_apply(u.opt, 0.f, u.p, u.m, u.v, wi);
+            opt_zero(u.opt, u.p, u.m, u.v, wi);
             return;
         }
         float gK;
@@ -372,7 +392,7 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
         const int i = e - (l == 0 ? 0 : (l == 1 ? H1 : H1 + H2));
         const size_t bi = (size_t)u.SL.bd[l] + (size_t)dd * StarLayout::bsize(l) + i;
         if (!live) {
-            opt_apply(u.opt, 0.f, u.p, u.m, u.v, bi);
+            opt_zero(u.opt, u.p, u.m, u.v, bi);
             return;
         }
         const float gb = slab_sum(u, (l == 0 ? u.L.b0 : (l == 1 ? u.L.b1 : u.L.b2)) + i);
@@ -384,8 +404,8 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
     if (e < XDIM) {               // PartitionedNorm gamma / beta
         const size_t gi = (size_t)u.SL.pgd + dd * XDIM + e, bi = (size_t)u.SL.pbd + dd * XDIM + e;
         if (!live) {
-            opt_apply(u.opt, 0.f, u.p, u.m, u.v, gi);
-            opt_apply(u.opt, 0.f, u.p, u.m, u.v, bi);
+            opt_zero(u.opt, u.p, u.m, u.v, gi);
+            opt_zero(u.opt, u.p, u.m, u.v, bi);
             return;
         }
         const float s1 = u.sums[e], s2 = u.sums[XDIM + e];
@@ -405,13 +425,20 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
     }
     e -= H3 + 1;
     if (e < EMB) {                // domain table row dd: only row d is touched (PN's rounding residue)
-        opt_apply(u.opt, live ? u.dmsum[e] : 0.f, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
+        if (live) opt_apply(u.opt, u.dmsum[e], u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
+        else opt_zero(u.opt, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
     }
 }
 constexpr int STAR_UPDATE_N = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + EMB;
 constexpr int STAR_UPDATE_BX = (STAR_UPDATE_N + 255) / 256;
+// (only_live: the grid covers slice d alone -- the other slices are replayed by k_star_catchup -- and the step's
+// alpha goes into the call's log)
+__device__ __forceinline__ void star_log_alpha(const StarUpdateArgs& u, int bx) {
+    if (u.alpha_log && bx == 0 && threadIdx.x == 0) u.alpha_log[u.log_idx] = u.opt.alpha;
+}
 __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
-    star_update_body(u, (int)blockIdx.x, (int)blockIdx.y);
+    star_log_alpha(u, (int)blockIdx.x);
+    star_update_body(u, (int)blockIdx.x, u.only_live ? u.d : (int)blockIdx.y);
 }
 // the chain rule + optimiser on the Star block and the NEXT step's k_emb_catchup touch disjoint state: one launch,
 // the catch-up workgroups first (their chains are the longer ones).  (This step's k_emb_reduce and the next step's
@@ -423,14 +450,58 @@ __global__ __launch_bounds__(256) void k_star_update_catchup(const StarUpdateArg
         return;
     }
     const int idx = bid - 2 * n_cu;
-    star_update_body(u, idx % STAR_UPDATE_BX, idx / STAR_UPDATE_BX);
+    star_log_alpha(u, idx);
+    star_update_body(u, idx % STAR_UPDATE_BX, u.only_live ? u.d : idx / STAR_UPDATE_BX);
+}
+
+// ---- the skipped zero-gradient steps of every slice but d_live, element by element (the same element map as
+// star_update_body's other-slice branches): grid (STAR_UPDATE_BX, n_domain)
+__global__ __launch_bounds__(256) void k_star_catchup(const StarCatchArgs a) {
+    const int dd = (int)blockIdx.y;
+    if (dd == a.d_live) return;
+    const int K0 = XDIM * H1, K1 = H1 * H2, K2 = H2 * H3;
+    const int n_kernel = K0 + K1 + K2, n_bias = H1 + H2 + H3;
+    int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    size_t idx[2];
+    int n_idx = 0;
+    if (e < n_kernel) {
+        const int l = e < K0 ? 0 : (e < K0 + K1 ? 1 : 2);
+        const int i = e - (l == 0 ? 0 : (l == 1 ? K0 : K0 + K1));
+        idx[n_idx++] = (size_t)a.SL.wd[l] + (size_t)dd * StarLayout::ksize(l) + i;
+    } else if ((e -= n_kernel) < n_bias) {
+        const int l = e < H1 ? 0 : (e < H1 + H2 ? 1 : 2);
+        const int i = e - (l == 0 ? 0 : (l == 1 ? H1 : H1 + H2));
+        idx[n_idx++] = (size_t)a.SL.bd[l] + (size_t)dd * StarLayout::bsize(l) + i;
+    } else if ((e -= n_bias) < XDIM) {
+        idx[n_idx++] = (size_t)a.SL.pgd + dd * XDIM + e;
+        idx[n_idx++] = (size_t)a.SL.pbd + dd * XDIM + e;
+    } else if ((e -= XDIM) < H3 + 1) {
+        return;                   // output unit: shared, stepped with the live slice
+    } else if ((e -= H3 + 1) < EMB) {
+        idx[n_idx++] = (size_t)a.SL.dm + (size_t)dd * EMB + e;
+    } else {
+        return;
+    }
+    for (int k = 0; k < n_idx; ++k) {
+        float p = a.p[idx[k]], m = a.m[idx[k]], v = a.v[idx[k]];
+        for (int t = 0; t < a.n_steps; ++t)
+            adam_zero_step(p, m, v, a.alpha_log[(a.first_idx + t) & a.log_mask], a.omb1, a.omb2, a.eps);
+        a.p[idx[k]] = p;
+        a.m[idx[k]] = m;
+        a.v[idx[k]] = v;
+    }
 }
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
-    MAMDR_LAUNCH(k_star_update, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_star_update, dim3(STAR_UPDATE_BX, a.only_live ? 1 : a.n_domain), dim3(256), 0, s, a);
 }
 void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& nc, hipStream_t s) {
     const int n_cu = (nc.rows + 7) / 8;
-    MAMDR_LAUNCH(k_star_update_catchup, dim3(2 * n_cu + STAR_UPDATE_BX * a.n_domain), dim3(256), 0, s, a, nc, n_cu);
+    MAMDR_LAUNCH(k_star_update_catchup, dim3(2 * n_cu + STAR_UPDATE_BX * (a.only_live ? 1 : a.n_domain)), dim3(256), 0, s, a, nc,
+                 n_cu);
+}
+void launch_star_catchup(const StarCatchArgs& a, hipStream_t s) {
+    if (a.n_steps <= 0 || a.n_domain <= 1) return;
+    hipLaunchKernelGGL(k_star_catchup, dim3(STAR_UPDATE_BX, a.n_domain), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

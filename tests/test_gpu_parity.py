@@ -937,6 +937,36 @@ def make_star_problem(env, emb_trainable, scale=0.1, batch=256, seed=11):
 
 
 @pytest.mark.parametrize("emb_trainable", [True, False])
+def test_star_lazy_slices_equal_the_per_step_sweep(env, emb_trainable):
+    """Star tower: the per-domain slices of the domains a batch does not carry only decay (zero gradient, TF1 dense
+    Adam).  Inside a mamdr_train_steps call they are replayed once, at its end (k_star_catchup), instead of being swept
+    every step (MAMDR_STAR_DENSE_SLICES=1): weights and both Adam slots identical bit for bit, over calls on different
+    domains, single-step calls (swept as before), a call starting in the middle of a pass and SGD steps in between."""
+    out = {}
+    for mode in ("lazy", "dense"):
+        os.environ["MAMDR_STAR_DENSE_SLICES"] = "1" if mode == "dense" else "0"
+        try:
+            g, eng, model = make_star_problem(env, emb_trainable, batch=256)
+        finally:
+            os.environ.pop("MAMDR_STAR_DENSE_SLICES", None)
+        sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(g["n_domain"])]
+        order = sorted(range(g["n_domain"]), key=lambda d: -sizes[d])[:4]
+        for k, d in enumerate(order):
+            perm = torch.from_numpy(orng.shuffle_perm(sizes[d], 10000, seed=21 + k)).to(eng.device)
+            n = -(-sizes[d] // 256)
+            eng.train_steps(d, perm=perm, first_step=0, n_steps=min(n, 5), lr=1e-3)          # several steps: replayed
+            eng.train_steps(d, perm=perm, first_step=min(n, 5) - 1, n_steps=1, lr=1e-3)     # one step: swept
+            if k == 1:
+                eng.train_steps(d, perm=perm, first_step=1, n_steps=2, lr=1e-3, optimizer="sgd")
+                eng.train_steps(d, perm=perm, first_step=2, n_steps=3, lr=1e-3)             # from the middle of a pass
+        out[mode] = [eng.get_weights().cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy()]
+        eng.close()
+    for a, b, what in zip(out["lazy"], out["dense"], ("weights", "adam m", "adam v")):
+        assert same_bits(a, b), (what, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+    assert np.abs(out["lazy"][0]).max() > 0
+
+
+@pytest.mark.parametrize("emb_trainable", [True, False])
 def test_star_step_adam_eval(env, emb_trainable):
     """PartitionedNorm (batch statistics, zero-debiased moving statistics, backward through the statistics)
     + StarFCN (shared * specific kernels): gradients of every tensor incl. the zero-gradient slices of the
