@@ -551,8 +551,10 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
     // 4.0 K -> 1.8 K; k_tower 26.2 -> 24.6 us).  A W1 image in LDS on top of this (as in k_tower4; built and measured:
     // requests at kernel start, gather + 2.5 K cycles; spread over layer 0's K loop, + 6.5 K) gained nothing here --
     // with 16 rows per tile layers 0 and 1 are paced by their MFMAs and epilogues, not by the weight stream.
-    // (not the 384-wide Star variant: it keeps its registers under 128 so that two workgroups share a CU)
+    // (the whole share only where registers allow: the 384-wide Star variant stays under 128 for two workgroups per CU)
     constexpr bool EARLY2 = TRAIN && DXW <= 2 * EMB;
+    // (the 384-wide Star variant: the same request points at the normal ring depth -- still 120 VGPRs; 65.0 -> 64.0 us)
+    constexpr bool EARLY2S = TRAIN && DXW > 2 * EMB;
     FwdW<H2, H3, EARLY2 ? H2 / 16 : PF2, 4> fw2;
     BwdW<H3, H2, H3, PFB2, 8> bw2;
     BwdW<H2, H1, H2, PFB1, 8> bw1;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
                                              key0, a.drop_thresh, scale, a.use_dropout != 0, row0,
                                              [&]() {
                                                  fw1.prefetch(P + a.L.w1, P + a.L.b1);
-                                                 if (EARLY2) fw2.prefetch(P + a.L.w2, P + a.L.b2);
+                                                 if (EARLY2 || EARLY2S) fw2.prefetch(P + a.L.w2, P + a.L.b2);
                                              });
     STAMP(2);
     __syncthreads();
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
                                            TRAIN ? acts_t + XDIM + H1 : nullptr, key1, a.drop_thresh, scale,
                                            a.use_dropout != 0, row0,
                                            [&]() {
-                                               if (EARLY2) bw2.prefetch(P + a.L.w2);
+                                               if (EARLY2 || EARLY2S) bw2.prefetch(P + a.L.w2);
                                                else fw2.prefetch(P + a.L.w2, P + a.L.b2);
                                            });
     STAMP(3);
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
                                            TRAIN ? acts_t + XDIM + H1 + H2 : nullptr, key2, a.drop_thresh, scale,
                                            a.use_dropout != 0, row0, [&]() {
                                                if (TRAIN) {
-                                                   if (!EARLY2) bw2.prefetch(P + a.L.w2);
+                                                   if (!EARLY2 && !EARLY2S) bw2.prefetch(P + a.L.w2);
                                                    bw1.prefetch(P + a.L.w1);
                                                }
                                            });
