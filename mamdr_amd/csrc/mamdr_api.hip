@@ -458,7 +458,8 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
 // k_star_catchup) and the step's alpha is logged at that slot
 static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const int32_t* d_perm, int64_t row_base, int rows,
                            int32_t optimizer, float alpha, float omb1, float omb2, float* loss_out,
-                           const EmbRowsArgs* next_rows, const EmbStepArgs* next_catchup, int lazy_idx) {
+                           const EmbRowsArgs* next_rows, const EmbStepArgs* next_catchup, int lazy_idx, bool eff_current,
+                           bool eff_for_next) {
     const int rows_pad = (rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
     const int chunks = (rows + STAR_CHUNK - 1) / STAR_CHUNK;
     float* blk = c->params + c->table_floats;
@@ -487,6 +488,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     pa.aux = c->aux;
     pa.AL = c->AL;
     pa.train = 1;
+    pa.skip_eff = eff_current ? 1 : 0;      // (the previous step of this call wrote it: k_star_update, eff_out)
     launch_star_prep(pa, c->stream);
     prof_break(c);
 
@@ -605,6 +607,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
         ua.only_live = 1;
         ua.alpha_log = c->star_alpha;
         ua.log_idx = lazy_idx;
+        if (eff_for_next) ua.eff_out = c->eff;
     }
     {
         Prof p(c, MAMDR_KERNEL_UPDATE);
@@ -1140,7 +1143,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             }
             const int rc = star_train_step(c, *d, domain, d_perm, row_base, rows, optimizer, step_alpha, omb1, omb2,
                                            d_loss_out ? d_loss_out + s : nullptr, pre ? &nr : nullptr, pre ? &nea : nullptr,
-                                           star_lazy ? (int)(star_lag & (STAR_ALPHA_CAP - 1)) : -1);
+                                           star_lazy ? (int)(star_lag & (STAR_ALPHA_CAP - 1)) : -1, star_lazy && s > 0,
+                                           star_lazy && s + 1 < n_steps);
             if (rc) return rc;
             c->global_step += 1;
             if (star_lazy) {

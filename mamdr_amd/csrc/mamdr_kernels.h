@@ -656,6 +656,7 @@ struct StarPrepArgs {
     float* aux;                // moving statistics (read at eval, updated in training)
     StarAuxLayout AL;
     int train;
+    int skip_eff;              // the effective block is current already (written by the previous step's k_star_update)
 };
 struct StarPnBwdArgs {
     const float* user_tab;
@@ -688,6 +689,9 @@ struct StarUpdateArgs {
     int only_live;
     float* alpha_log;          // [log_mask + 1] alphas of this call's steps, slot = step index inside the call
     int log_idx;
+    float* eff_out;            // nullable: the NEXT step's effective dense block (same domain) -- K_l = Ws_l * Wd_l[d],
+                               // b_l = bs_l + bd_l[d], the output unit, row d of the domain table -- from the values
+                               // just stepped (k_star_prep then skips that part)
 };
 // k_star_catchup: every slice but d_live takes the n_steps zero-gradient Adam steps it skipped (same arithmetic, same
 // order: bit-identical to the per-step sweep)

@@ -46,19 +46,24 @@ __device__ __forceinline__ void opt_zero(const OptArgsLite& o, float* p, float* 
     m[i] = mm;
     v[i] = vv;
 }
-__device__ __forceinline__ void opt_apply(const OptArgsLite& o, float g, float* p, float* m, float* v, size_t i) {
+// (returns the parameter as the step leaves it)
+__device__ __forceinline__ float opt_apply(const OptArgsLite& o, float g, float* p, float* m, float* v, size_t i) {
+    float pn = p[i];
     if (o.optimizer == 0) {
         float mm = m[i], vv = v[i];
         mm = mm + (g - mm) * o.omb1;
         vv = vv + (g * g - vv) * o.omb2;
         m[i] = mm;
         v[i] = vv;
-        p[i] = p[i] - (mm * o.alpha) / (sqrtf(vv) + o.eps);
+        pn = pn - (mm * o.alpha) / (sqrtf(vv) + o.eps);
+        p[i] = pn;
     } else if (o.optimizer == 1) {
-        p[i] = p[i] - g * o.alpha;
+        pn = pn - g * o.alpha;
+        p[i] = pn;
     } else {
         m[i] = m[i] + g;          // accumulate only: m is the meta-gradient accumulator
     }
+    return pn;
 }
 }  // namespace
 
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
         }
         return;
     }
-    // effective dense block, one element per thread
+    // effective dense block, one element per thread (not launched with skip_eff)
     const int e = ((int)blockIdx.x - PN_BLOCKS) * 512 + tid;
     const DenseLayout& L = a.L;
     if (e >= L.count) return;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
     a.eff[e] = v;
 }
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_star_prep, dim3(PN_BLOCKS + (a.L.count + 511) / 512), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(k_star_prep, dim3(PN_BLOCKS + (a.skip_eff ? 0 : (a.L.count + 511) / 512)), dim3(512), 0, s, a);
 }
 
 // ------------------------------------------------------------------ PartitionedNorm backward
@@ -382,8 +387,9 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
         }
         const size_t si = (size_t)u.SL.ws[l] + i;
         const float ws = u.p[si], wd = u.p[wi];
-        opt_apply(u.opt, gK * ws, u.p, u.m, u.v, wi);
-        opt_apply(u.opt, gK * wd, u.p, u.m, u.v, si);
+        const float wdn = opt_apply(u.opt, gK * ws, u.p, u.m, u.v, wi);
+        const float wsn = opt_apply(u.opt, gK * wd, u.p, u.m, u.v, si);
+        if (u.eff_out) u.eff_out[(l == 0 ? u.L.w0 : (l == 1 ? u.L.w1 : u.L.w2)) + i] = wsn * wdn;
         return;
     }
     e -= n_kernel;
@@ -396,8 +402,9 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
             return;
         }
         const float gb = slab_sum(u, (l == 0 ? u.L.b0 : (l == 1 ? u.L.b1 : u.L.b2)) + i);
-        opt_apply(u.opt, gb, u.p, u.m, u.v, bi);
-        opt_apply(u.opt, gb, u.p, u.m, u.v, (size_t)u.SL.bs[l] + i);
+        const float bdn = opt_apply(u.opt, gb, u.p, u.m, u.v, bi);
+        const float bsn = opt_apply(u.opt, gb, u.p, u.m, u.v, (size_t)u.SL.bs[l] + i);
+        if (u.eff_out) u.eff_out[(l == 0 ? u.L.b0 : (l == 1 ? u.L.b1 : u.L.b2)) + i] = bsn + bdn;
         return;
     }
     e -= n_bias;
@@ -420,12 +427,16 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
     if (e < H3 + 1) {             // output unit (owned by the live slice's threads)
         if (!live) return;
         const float g = slab_sum(u, e < H3 ? u.L.wo + e : u.L.gb);
-        opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)(e < H3 ? u.SL.wo + e : u.SL.gb));
+        const float pn = opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)(e < H3 ? u.SL.wo + e : u.SL.gb));
+        if (u.eff_out) u.eff_out[e < H3 ? u.L.wo + e : u.L.gb] = pn;
         return;
     }
     e -= H3 + 1;
     if (e < EMB) {                // domain table row dd: only row d is touched (PN's rounding residue)
-        if (live) opt_apply(u.opt, u.dmsum[e], u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
+        if (live) {
+            const float pn = opt_apply(u.opt, u.dmsum[e], u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
+            if (u.eff_out) u.eff_out[u.L.dm + dd * EMB + e] = pn;
+        }
         else opt_zero(u.opt, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
     }
 }
