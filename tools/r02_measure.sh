@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof10" -o run -- python3 "$REPO/bench
 rocprofv3 --kernel-trace --stats -d "$OUT/prof30" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 2 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/prof30.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o run -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o run -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc30_fetch" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc30_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc30_write" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc30_write.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/gather_trace" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/gather_fetch" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/gather_write" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_write.log" 2>&1
@@ -27,7 +29,9 @@ python tools/rocpd_summary.py stats "$(db gather_trace)" "$OUT/kernel_stats_gath
 python tools/rocpd_summary.py pmc "$(db pmc_fetch)" "$(db pmc_write)" "$OUT/pmc_hbm_taobao10.json"
 cp "$OUT/pmc_hbm_taobao10.json" "$OUT/pmc_hbm_latest.json"
 python tools/rocpd_summary.py pmc1 "$(db gather_fetch)" "$(db gather_write)" k_gather k_gather@amazon6 "$OUT/pmc_hbm_latest.json"
-rm -rf "$OUT"/prof10 "$OUT"/prof30 "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/gather_trace "$OUT"/gather_fetch "$OUT"/gather_write
+# the 16-row tower of the Taobao-30 target (bench.py: targets.taobao30.tower.traffic)
+python tools/rocpd_summary.py pmc1 "$(db pmc30_fetch)" "$(db pmc30_write)" "k_tower<true, 0, false, false>" "k_tower<true, 0, false, false>" "$OUT/pmc_hbm_latest.json"
+rm -rf "$OUT"/prof10 "$OUT"/prof30 "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc30_fetch "$OUT"/pmc30_write "$OUT"/gather_trace "$OUT"/gather_fetch "$OUT"/gather_write
 grep "mamdr::" "$OUT/kernel_stats_taobao10.csv" | cut -c1-160 | head -8
 grep "mamdr::" "$OUT/kernel_stats_taobao30.csv" | cut -c1-160 | head -8
 python - <<PY
