@@ -14,7 +14,12 @@
 //   (k_emb_reduce / k_emb_sweep with trainable tables)
 //   k_star_update   chain rule onto shared / specific tensors + TF1 Adam over EVERY slice (the
 //                   specific tensors of the other domains get zero gradient but still decay and move,
-//                   as tf.train.AdamOptimizer's sparse rule does)
+//                   as tf.train.AdamOptimizer's sparse rule does).  Inside a mamdr_train_steps call the
+//                   other domains' slices are not swept step by step: the launch covers the live slice,
+//                   logs the step's alpha, and k_star_catchup replays the skipped zero-gradient steps at
+//                   the end of the call (adam_zero_step: the same roundings either way, bit-identical);
+//                   it also writes the next step's effective block (eff_out) so that k_star_prep only
+//                   merges the batch statistics
 // Every reduction runs in a fixed order (no float atomics).
 #include <cstring>
 
