@@ -55,14 +55,17 @@ WORKLOADS = {
     "taobao30": dict(shape="taobao30", batch=4096, name="mlp_meta_mamdr Taobao-30 bs=4096 (frozen pretrained tables)"),
     # trainable 128-d tables (79 M parameters): every step ends with TF1's dense Adam over all rows
     # (BASELINE.json configs[2]: DeepFM tower under Domain Negotiation)
-    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", row_scale=0.1, tower="deepfm",
+    "amazon6": dict(shape="amazon6", batch=1024, emb_trainable=True, wrapper="dn", tower="deepfm",
                     name="deepfm_meta_domain_negotiation Amazon-6 bs=1024 (trainable tables, full-size tables, "
                          "{rows} of the rows per epoch)"),
     # (BASELINE.json configs[4]: Star tower under MAMDR, theta / phi over the tables + shared kernels / biases)
-    "amazon13": dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", row_scale=0.1, tower="star",
+    "amazon13": dict(shape="amazon13", batch=8192, emb_trainable=True, wrapper="mamdr", tower="star",
                      name="star_meta_mamdr Amazon-13 bs=8192 (PartitionedNorm + StarFCN, trainable tables, "
                           "full-size tables, {rows} of the rows per epoch)"),
 }
+TARGET_KEYS = ("workload", "value", "unit", "us_per_domain_step", "ms_per_step", "epochs_timed", "domain_steps_per_epoch",
+               "roofline", "tower", "table_update", "kernels_avg_us", "cpu_baseline", "gpu_over_cpu",
+               "partition_speedup_bound", "host_ms_per_epoch")
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
 
@@ -122,12 +125,56 @@ def _time_steps(step_fn, cols, n, perm, batch, budget_s):
     return steps, time.time() - t0
 
 
+def _pin_to_one_socket():
+    """pin every thread of this process to one hardware thread per physical core of ONE socket (the socket of the first
+    allowed cpu).  -> (cpus pinned to, restore()).  Falls back to no pinning when the topology cannot be read."""
+    def no():
+        pass
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        base = "/sys/devices/system/cpu/cpu%d/topology/"
+
+        def rd(c, f):
+            with open(base % c + f) as fh:
+                return fh.read().strip()
+        pkg0 = rd(allowed[0], "physical_package_id")
+        seen, cpus = set(), []
+        for c in allowed:
+            if rd(c, "physical_package_id") != pkg0:
+                continue
+            core = rd(c, "core_id")
+            if core not in seen:                 # first hardware thread of each physical core
+                seen.add(core)
+                cpus.append(c)
+        if len(cpus) < 2:
+            return [], no
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+        old = {}
+        for t in tids:
+            try:
+                old[t] = os.sched_getaffinity(t)
+                os.sched_setaffinity(t, cpus)
+            except OSError:
+                pass
+
+        def restore():
+            for t in os.listdir("/proc/self/task"):      # threads created meanwhile inherited the narrow mask
+                try:
+                    os.sched_setaffinity(int(t), old.get(int(t), allowed))
+                except OSError:
+                    pass
+        return cpus, restore
+    except Exception:
+        return [], no
+
+
 def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, tower="mlp"):
     """The reference's CPU path (TF1.12, not installable here) is represented by restatements of the same step
     (oracle/, test infrastructure), timed on this box's host cores on a bounded sample of the same workload:
       * "value": torch-CPU fp32, autograd + dense TF1 Adam, at the fastest thread count of a sweep --
         the reported baseline;
       * "numpy_oracle": the numpy fp32 parity oracle on the same steps (a checker, not tuned for speed)."""
+    import numpy as np
     import torch
     from oracle import rng as orng
     from oracle import torch_ref as tref
@@ -154,32 +201,45 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
         t = time.time()
         model.train_on_batch(cols["uid"][idx], cols["pid"][idx], cols["domain"][idx], cols["label"][idx])
         return time.time() - t
-    # the thread count is the baseline's own tuning knob: at these sizes (0.4 - 3.4 GFLOP per step) all hardware
+    # The thread count is the baseline's own tuning knob: at these sizes (0.4 - 3.4 GFLOP per step) all hardware
     # threads of a big host are far slower than a fraction of them (fork / join per small op; with every SMT
-    # sibling busy a step took SECONDS on the 256-thread GPU host).  Doubling sweep from 8 threads up to half the
-    # visible hardware threads, each trial 1 warm + 4 timed steps, stopped once a trial is clearly slower than
-    # the best so far; the timed sample then runs at the best count (reported as `cores`).
-    cap = cores // 2 if cores >= 16 else cores
-    trials, best_nt, best_t, nt = [], None, None, min(8, cap)
-    while True:
-        torch.set_num_threads(nt)
-        one(0)
-        t = sum(one(k) for k in range(1, 5)) / 4.0
-        trials.append((nt, t))
-        if best_t is None or t < best_t:
-            best_nt, best_t = nt, t
-        if nt >= cap or t > 1.25 * best_t:
-            break
-        nt = min(2 * nt, cap)
-    torch.set_num_threads(best_nt)
-    steps, dt = _time_steps(model.train_on_batch, cols, n, perm, batch, budget_s * 0.6)
-    out = {"value": steps / dt, "unit": "domain-steps/s", "cores": int(best_nt), "kind": "port",
-           "host_cores_visible": int(cores),
+    # sibling busy a step took SECONDS on the 256-thread GPU host).  Every thread of this process is pinned to the
+    # PHYSICAL cores of ONE socket for this leg (one hardware thread per core: no SMT siblings, no cross-socket
+    # traffic; restored afterwards); doubling sweep from 8 threads up to that core count, each trial 1 warm + 5
+    # timed steps (median), stopped once a trial is clearly slower than the best so far; the timed sample then runs
+    # at the best count in THREE repeats: value = the median repeat, spread = [min, max].
+    pinned, restore = _pin_to_one_socket()
+    try:
+        cap = len(pinned) if pinned else (cores // 2 if cores >= 16 else cores)
+        trials, best_nt, best_t, nt = [], None, None, min(8, cap)
+        while True:
+            torch.set_num_threads(nt)
+            one(0)
+            t = float(np.median([one(k) for k in range(1, 6)]))
+            trials.append((nt, t))
+            if best_t is None or t < best_t:
+                best_nt, best_t = nt, t
+            if nt >= cap or t > 1.25 * best_t:
+                break
+            nt = min(2 * nt, cap)
+        torch.set_num_threads(best_nt)
+        reps = []
+        for _ in range(3):
+            steps_r, dt_r = _time_steps(model.train_on_batch, cols, n, perm, batch, budget_s * 0.2)
+            reps.append((steps_r / dt_r, steps_r, dt_r))
+    finally:
+        restore()
+    reps.sort()
+    value, steps, dt = reps[1]
+    out = {"value": value, "unit": "domain-steps/s", "cores": int(best_nt), "kind": "port",
+           "host_cores_visible": int(cores), "pinned_to": "%d physical cores of one socket" % len(pinned) if pinned else "not pinned",
+           "repeats": [round(r[0], 2) for r in reps], "spread": [round(reps[0][0], 2), round(reps[-1][0], 2)],
            "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 2) for k, v in trials},
-           "sample": "%d inner steps (bs=%d, domain %d of the same synthetic workload) in %.1f s: torch-CPU fp32 "
-                     "restatement of the TF1.12 step (gather, tower forward, Keras BCE, autograd backward, dense "
-                     "TF1 Adam, dropout masks from a pre-drawn pool; oracle/torch_ref.py) on %d threads (the fastest of a doubling sweep up to "
-                     "half of the %d visible hardware threads); a restatement, not TF" % (steps, batch, d, dt, best_nt, cores)}
+           "sample": "median of 3 repeats of ~%d inner steps each (bs=%d, domain %d of the same synthetic workload, %.1f s per "
+                     "repeat): torch-CPU fp32 restatement of the TF1.12 step (gather, tower forward, Keras BCE, autograd "
+                     "backward, dense TF1 Adam, dropout masks from a pre-drawn pool; oracle/torch_ref.py) on %d threads "
+                     "(the fastest of a doubling sweep), pinned to one socket's physical cores (%d of the %d visible "
+                     "hardware threads); a restatement, not TF" % (steps, batch, d, dt, best_nt, len(pinned) or cores, cores)}
     del model
     # second leg: the numpy parity oracle
     if tower == "star":
@@ -188,7 +248,7 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
     else:
         omodel = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=TRAIN["dropout"],
                                     lr=TRAIN["learning_rate"], tower=tower)
-    osteps, odt = _time_steps(omodel.train_on_batch, cols, n, perm, batch, budget_s * 0.3)
+    osteps, odt = _time_steps(omodel.train_on_batch, cols, n, perm, batch, budget_s * 0.25)
     out["numpy_oracle"] = {"value": osteps / odt, "unit": "domain-steps/s",
                            "sample": "%d steps of the numpy fp32 oracle in %.1f s" % (osteps, odt)}
     return out
@@ -294,7 +354,8 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     batch = int(os.environ.get("MAMDR_BENCH_BATCH", wl["batch"]))      # (exploration only: the named config fixes it)
     row_scale = float(os.environ.get("MAMDR_BENCH_ROW_SCALE", wl.get("row_scale", 1.0)))
     trainable = bool(wl.get("emb_trainable"))
-    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=row_scale)
+    # (only the train split is bound here; val / test are not drawn: 17 M rows less to generate on Amazon-6)
+    g = synthetic.generate(wl["shape"], batch_size=batch, seed=TRAIN["seed"], row_scale=row_scale, splits=("train",))
     D = g["n_domain"]
     tower = wl.get("tower", "mlp")
     eng = setup_engine(g, batch, trainable, tower)
@@ -313,7 +374,37 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         return p
     sizes = [eng.n_rows(d, "train") for d in range(D)]
     steps_per_domain = [-(-n // batch) for n in sizes]
-    full0 = eng.pack(full_params())
+
+    def initial_vector(seed=1024):
+        """one random initialisation of the whole model as a flat device vector.  Frozen-table workloads: packed on
+        the host (0.56 MB).  Trainable tables (79 - 92 M floats): the dense tensors come from the same host
+        initialisers, the two big tables are drawn ON the device with their layer's distribution (deepctr
+        SparseFeat N(0, 1e-4^2), Keras Embedding U(-0.05, 0.05) for the Star tower) -- D + 1 host draws of 92 M
+        normals would cost the default run half a minute."""
+        if not trainable:
+            return eng.pack(full_params(seed))
+        keep = (g["n_user"], g["n_item"])
+        g["n_user"], g["n_item"] = 8, 8                      # host initialisers for everything but the two tables
+        try:
+            small = full_params(seed)
+        finally:
+            g["n_user"], g["n_item"] = keep
+        v = torch.zeros(eng.n_params, dtype=torch.float32, device=eng.device)
+        gen = torch.Generator(device=eng.device)
+        gen.manual_seed(seed)
+        for name, (off, cnt) in eng.segments.items():
+            if name in ("user_emb", "item_emb"):
+                if tower == "star":
+                    v[off:off + cnt].uniform_(-0.05, 0.05, generator=gen)
+                else:
+                    v[off:off + cnt].normal_(0.0, 1e-4, generator=gen)
+            elif name in ("lin_user", "lin_item"):
+                pass                                             # DeepFM linear tables start at zero
+            else:
+                v[off:off + cnt] = torch.from_numpy(np.ascontiguousarray(small[name], np.float32).ravel()).to(eng.device)
+        return v
+
+    full0 = initial_vector()
     eng.set_weights(full0)                 # tensors outside theta (Star: PN, specific kernels, output unit)
     theta = full0[:eng.n_meta].clone()
     del full0
@@ -321,7 +412,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     # phi_d starts as a second random init of the whole model (mamdr.py:31-33); every rank draws all of them
     balanced = None
     if wrapper == "mamdr":
-        phis = {d: eng.pack(full_params(seed=2000 + d))[:eng.n_meta] for d in range(D)}
+        phis = {d: initial_vector(seed=2000 + d)[:eng.n_meta] for d in range(D)}
         balanced = parallel.BalancedMAMDR(eng, meta, theta, phis, steps_per_domain)
         del phis
     delta, zero = eng.new_vector(meta=True), eng.new_vector(meta=True)
@@ -358,22 +449,26 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     barrier()
     del loads[:]
     t0 = time.perf_counter()
-    local_steps, global_steps, local_passes = 0, 0, 0
+    local_steps, global_steps, local_passes, host_s = 0, 0, 0, 0.0
     for _ in range(steps):
+        th = time.perf_counter()
         tr, b = epoch()
+        host_s += time.perf_counter() - th       # enqueue-only: plan, LPT, shuffles + upload, the launches (no sync)
         local_steps += sum(t[2] for t in tr)
         local_passes += len(tr)
         global_steps += b
     barrier()
     dt = time.perf_counter() - t0
+    host_ms = [host_s / steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt, float(local_steps), float(local_passes)], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([dt, float(local_steps), float(local_passes), host_s], dtype=torch.float64, device=eng.device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         assert int(round(float(t[1]))) == global_steps, (float(t[1]), global_steps)
         local_passes = int(round(float(t[2])))
+        host_ms = [float(t[3]) / world / steps * 1e3, float(tmax[3]) / steps * 1e3]      # mean, max over ranks
 
     # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
     #      the same workload; reported for the dominant kernel, k_tower<train>
@@ -383,13 +478,31 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         eng.profile_reset()
         epoch()                       # fills the library's event pool: the measured epoch below creates no events
         eng.profile_reset()
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
         prof_trace, _ = epoch()
+        torch.cuda.synchronize()
+        prof_wall_us = (time.perf_counter() - tp0) * 1e6
         names = {L.KERNEL_EMB_SWEEP: L.KERNEL_NAMES[L.KERNEL_EMB_SWEEP]}
         names.update(eng.step_kernel_names(batch))
-        for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE, L.KERNEL_EMB_SWEEP):
+        if trainable and os.environ.get("MAMDR_DENSE_ADAM", "0") in ("", "0"):
+            names[L.KERNEL_EMB_SWEEP] = "k_emb_reduce"
+        names[L.KERNEL_AUX] = {"star": "k_star_stats+prep | k_star_pnb_* (PartitionedNorm backward) | k_emb_rows | "
+                                       "k_emb_catchup | k_star_catchup (timed groups)",
+                               "deepfm": "k_emb_rows | k_emb_catchup | k_lin_sweep"}.get(tower, "k_pass_prep (once per call)")
+        names[L.KERNEL_FLUSH] = "k_emb_flush"
+        prof_steps = sum(n for (_, _, n) in prof_trace)
+        accounted = 0.0
+        for k in (L.KERNEL_FWD_BWD, L.KERNEL_WGRAD, L.KERNEL_UPDATE, L.KERNEL_EMB_SWEEP, L.KERNEL_AUX, L.KERNEL_FLUSH):
             ms, cnt = eng.profile_read(k)
             if cnt:
-                kernels[names[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3}
+                kernels[names[k]] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3,
+                                     "us_per_domain_step": ms * 1e3 / max(prof_steps, 1)}
+                accounted += ms * 1e3 / max(prof_steps, 1)
+        # (the profiled epoch launches every kernel on its own -- the timed epochs fuse the tails of a step with
+        # trainable tables -- so the slots add up to the profiled epoch's device time, not to us_per_domain_step)
+        kernels["_sum_us_per_domain_step"] = accounted
+        kernels["_profiled_epoch_wall_us_per_domain_step"] = prof_wall_us / max(prof_steps, 1)
         dense_adam = os.environ.get("MAMDR_DENSE_ADAM", "0") not in ("", "0")
         if trainable and not dense_adam:
             # default: lazy replay of TF1's dense table Adam (csrc/emb_kernels.hip) -- per step only the rows of
@@ -471,6 +584,9 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0)) else roofline,
         "tower": roofline, "table_update": table_info or sweep_info, "gather_l2": l2_gather,
         "kernels_avg_us": kernels, "cpu_baseline": cpu,
+        # host side of an epoch (plan + LPT + shuffle generation / upload + every launch), enqueue only: the floor
+        # per epoch however many ranks share the device work ([mean, max] over ranks when world > 1)
+        "host_ms_per_epoch": host_ms,
     }
     if loads:
         # what the per-epoch partition allows: sum of the ranks' planned steps / the largest rank's
@@ -547,16 +663,21 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     main_rec = run_workload(args.workload, args.steps, args.warmup, rank, world, not args.no_profile,
-                            args.cpu_budget * (0.6 if not args.no_targets and args.workload == "taobao10" else 1.0))
+                            args.cpu_budget * (0.5 if not args.no_targets and args.workload == "taobao10" else 1.0))
     targets, gather = {}, None
     if not args.no_targets and args.workload == "taobao10":
         # north_star's target configuration in the same run: Taobao-30 bs 4096
         t30 = run_workload("taobao30", max(3, args.steps // 4), min(args.warmup, 2), rank, world, not args.no_profile,
-                           args.cpu_budget * 0.4)
-        targets["taobao30"] = {k: t30[k] for k in ("workload", "value", "unit", "us_per_domain_step", "ms_per_step",
-                                                    "epochs_timed", "domain_steps_per_epoch", "tower", "kernels_avg_us",
-                                                    "cpu_baseline", "gpu_over_cpu", "partition_speedup_bound")
-                               if k in t30}
+                           args.cpu_budget * 0.3)
+        targets["taobao30"] = {k: t30[k] for k in TARGET_KEYS if k in t30}
+    if not args.no_targets and args.workload == "taobao10" and world == 1:
+        # BASELINE.json configs[2] and configs[4] at FULL rows in the same run (single GPU: their multi-GPU numbers
+        # come from `--workload amazon6|amazon13 --gpus N`): one warm-up epoch + two timed ones
+        for wname in ("amazon6", "amazon13"):
+            if os.environ.get("MAMDR_BENCH_SKIP_" + wname.upper()):
+                continue
+            rec = run_workload(wname, 2, 1, rank, world, not args.no_profile, min(args.cpu_budget * 0.3, 8.0))
+            targets[wname] = {k: rec[k] for k in TARGET_KEYS if k in rec}
     if not args.no_targets and rank == 0 and world == 1 and not args.no_profile:
         gather = gather_hbm_record(torch.device("cuda", torch.cuda.current_device()))
     if rank == 0:
@@ -577,7 +698,7 @@ def main():
             "domain_passes_per_sec": r["domain_passes_per_sec"], "epoch_time_ms": r["ms_per_step"],
             "roofline": r["roofline"], "tower": r["tower"], "table_update": r["table_update"],
             "gather": gather, "gather_l2": r["gather_l2"], "kernels_avg_us": r["kernels_avg_us"],
-            "cpu_baseline": r["cpu_baseline"], "targets": targets,
+            "cpu_baseline": r["cpu_baseline"], "host_ms_per_epoch": r["host_ms_per_epoch"], "targets": targets,
         }
         if world > 1:
             result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0

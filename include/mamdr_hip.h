@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 7
+#define MAMDR_ABI_VERSION 8
 
 enum {
     MAMDR_OK = 0,
@@ -75,7 +75,13 @@ enum {
 };
 /* kernels whose device time can be profiled (mamdr_profile_*) */
 enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
-       MAMDR_KERNEL_EVAL = 3, MAMDR_KERNEL_GATHER = 4, MAMDR_KERNEL_EMB_SWEEP = 5, MAMDR_KERNEL_COUNT = 6 };
+       MAMDR_KERNEL_EVAL = 3, MAMDR_KERNEL_GATHER = 4, MAMDR_KERNEL_EMB_SWEEP = 5,
+       /* every other launch of a training call, so that the slots add up to the whole step: k_pass_prep, k_emb_rows,
+          k_emb_catchup, k_lin_sweep, k_star_catchup, and as ONE timed group each [k_star_stats + k_star_prep] and
+          PartitionedNorm's backward [k_star_pnb_partial + _final + _apply (+ k_star_dm_final)] */
+       MAMDR_KERNEL_AUX = 6,
+       /* k_emb_flush: the lazy table Adam's replay of every lagging row (forced every 32 Adam steps) */
+       MAMDR_KERNEL_FLUSH = 7, MAMDR_KERNEL_COUNT = 8 };
 
 typedef struct mamdr_ctx mamdr_ctx;
 

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -23,8 +23,9 @@ SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1",
              "Ws0", "Ws1", "Ws2", "bs0", "bs1", "bs2", "pn_gamma_shared", "pn_beta_shared", "pn_gamma_spec",
              "pn_beta_spec", "Wd0", "Wd1", "Wd2", "bd0", "bd1", "bd2",
              "log_var")
-KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP = range(6)
-KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep")
+KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP, KERNEL_AUX, KERNEL_FLUSH = range(8)
+KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep",
+                "other launches of a step (include/mamdr_hip.h: MAMDR_KERNEL_AUX)", "k_emb_flush")
 
 
 class MamdrError(RuntimeError):

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_lin_sweep(const EmbStepArgs a) { lin_sw
 // HBM traffic of a step drops from the whole table to the rows of the batch.
 __global__ __launch_bounds__(256) void k_emb_rows(const EmbRowsArgs a) { emb_rows_body(a, (int)blockIdx.x); }
 void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_rows, dim3((a.rows_pad + 255) / 256), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_emb_rows, dim3((a.rows_pad + 255) / 256), dim3(256), 0, s, a);
 }
 
 // 8 batch positions per workgroup, 32 lanes x float4 per 512-B row.  A representative replays its row's
@@ -121,7 +121,7 @@ void launch_emb_rows(const EmbRowsArgs& a, hipStream_t s) {
 // representative as "row occurs more than once" for k_emb_reduce.
 __global__ __launch_bounds__(256) void k_emb_catchup(const EmbStepArgs a) { emb_catchup_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 void launch_emb_catchup(const EmbStepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_catchup, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_emb_catchup, dim3((a.rows + 7) / 8, 2), dim3(256), 0, s, a);
 }
 
 // every row of both tables -> current at t_now (one float4 per thread; rows already current cost one
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_emb_flush(const EmbStepArgs a) {
 }
 void launch_emb_flush(const EmbStepArgs& a, hipStream_t s) {
     const int64_t n4 = (a.t[0].n_rows + a.t[1].n_rows) * (EMB / 4);
-    hipLaunchKernelGGL(k_emb_flush, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_emb_flush, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_emb_reduce(const EmbStepArgs& a, hipStream_t s) {
@@ -177,7 +177,7 @@ void launch_lin_sweep(const EmbStepArgs& a, hipStream_t s) {
     const int64_t n_all = a.t[0].n_rows + a.t[1].n_rows;
     int64_t blocks = (n_all + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(k_lin_sweep, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    MAMDR_LAUNCH(k_lin_sweep, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

@@ -615,10 +615,11 @@ __global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= a.n) {
-        // rows up to the next multiple of 16: k_wgrad_adam contracts whole 16-row tiles (against zero gradients for
-        // the padding rows, but 0 x garbage must stay 0)
+        // 16 more rows: k_wgrad_adam contracts whole 16-row tiles counted from EVERY step's own first row (against
+        // zero gradients for the padding rows, but 0 x garbage must stay 0); with a batch size that is no multiple of
+        // 16 the last step's tile ends up to 15 rows past the call's last row, wherever that row sits
         // (and carry the pass's domain: a tower tile compares all of its rows' domains with the caller's)
-        if (i < (a.n + 15) / 16 * 16) {
+        if (i < a.n + 16) {
             *reinterpret_cast<f32x4*>(a.xpre + (size_t)i * (2 * EMB) + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (lane == 0) {
                 a.pdom[i] = a.pad_dom;
@@ -644,8 +645,8 @@ __global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
 void launch_pass_prep(const PassPrepArgs& a0, hipStream_t s) {
     if (a0.n <= 0) return;
     PassPrepArgs a = a0;
-    a.n_prep_wgs = (int)(((a.n + 15) / 16 * 16 + 3) / 4);
-    hipLaunchKernelGGL(k_pass_prep, dim3((unsigned)(a.n_prep_wgs + (a.tw_wT ? TRANSPOSE_WGS : 0))), dim3(256), 0, s, a);
+    a.n_prep_wgs = (int)((a.n + 16 + 3) / 4);
+    MAMDR_LAUNCH(k_pass_prep, dim3((unsigned)(a.n_prep_wgs + (a.tw_wT ? TRANSPOSE_WGS : 0))), dim3(256), 0, s, a);
 }
 
 }  // namespace mamdr

@@ -366,8 +366,10 @@ static void sync_tables(mamdr_ctx* c) {
     EmbStepArgs ea;
     fill_emb_args(c, MAMDR_OPT_ADAM, 0.f, 1.0f - c->cfg.adam_beta1, 1.0f - c->cfg.adam_beta2, table_two_l2(c), 0,
                   c->star ? XDIM : 2 * EMB, ea);
-    launch_emb_flush(ea, c->stream);
-    prof_break(c);
+    {
+        Prof p(c, MAMDR_KERNEL_FLUSH);
+        launch_emb_flush(ea, c->stream);
+    }
     c->tables_dirty = false;
     c->flush_t = c->adam_t;
 }
@@ -408,15 +410,15 @@ static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm
     if (!c->rows_ready) {
         EmbRowsArgs ra;
         fill_rows_args(c, d, d_perm, row_base, rows, rows_pad, alpha, c->adam_t, false, ra);
+        Prof p(c, MAMDR_KERNEL_AUX);
         launch_emb_rows(ra, c->stream);
-        prof_break(c);
     }
     c->rows_ready = false;
     if (!c->catchup_ready) {
         EmbStepArgs ea;
         fill_emb_args(c, MAMDR_OPT_ADAM, alpha, omb1, omb2, table_two_l2(c), rows, c->star ? XDIM : 2 * EMB, ea);
+        Prof p(c, MAMDR_KERNEL_AUX);
         launch_emb_catchup(ea, c->stream);
-        prof_break(c);
     }
     c->catchup_ready = false;
     c->tables_dirty = true;
@@ -435,8 +437,8 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
             launch_emb_reduce(ea, c->stream);
         }
         if (c->deepfm) {
+            Prof p(c, MAMDR_KERNEL_AUX);
             launch_lin_sweep(ea, c->stream);     // reads the row maps, then releases them
-            prof_break(c);
         }
         return;
     }
@@ -447,8 +449,8 @@ static void emb_post_step(mamdr_ctx* c, int32_t optimizer, float alpha, float om
         launch_emb_sweep(ea, c->stream);
     }
     if (c->deepfm) {
+        Prof p(c, MAMDR_KERNEL_AUX);
         launch_lin_sweep(ea, c->stream);
-        prof_break(c);
     }
 }
 
@@ -471,8 +473,6 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ta.batch = rows;
     if (c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM)
         emb_pre_step(c, d, d_perm, row_base, rows, rows_pad, alpha, omb1, omb2);
-    // forward statistics read the raw rows (domain table straight from the flat vector: SL.dm == L.dm == 0)
-    launch_star_stats(ta, c->star_part, c->aux + c->AL.steps + domain, c->stream);
     StarPrepArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.blk = blk;
@@ -489,8 +489,12 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     pa.AL = c->AL;
     pa.train = 1;
     pa.skip_eff = eff_current ? 1 : 0;      // (the previous step of this call wrote it: k_star_update, eff_out)
-    launch_star_prep(pa, c->stream);
-    prof_break(c);
+    {
+        Prof p(c, MAMDR_KERNEL_AUX);            // k_star_stats + k_star_prep as one timed group
+        // forward statistics read the raw rows (domain table straight from the flat vector: SL.dm == L.dm == 0)
+        launch_star_stats(ta, c->star_part, c->aux + c->AL.steps + domain, c->stream);
+        launch_star_prep(pa, c->stream);
+    }
 
     ta.dense = c->eff;
     ta.pn_aff = c->pn;
@@ -564,8 +568,10 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile &&
                       !loss_out;
     if (tail) {
-        launch_star_pn_bwd(ba, false, c->stream);       // (its last kernel, the domain-row column sums, rides below)
-        prof_break(c);
+        {
+            Prof p(c, MAMDR_KERNEL_AUX);
+            launch_star_pn_bwd(ba, false, c->stream);   // (its last kernel, the domain-row column sums, rides below)
+        }
         EmbStepArgs tea;
         fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
         tea.flags_done = 1;
@@ -577,8 +583,8 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
             Prof p(c, MAMDR_KERNEL_WGRAD);
             launch_wgrad(wa, c->stream);
         }
+        Prof p(c, MAMDR_KERNEL_AUX);                  // PartitionedNorm's backward: 4 launches as one timed group
         launch_star_pn_bwd(ba, true, c->stream);
-        prof_break(c);
     }
 
     float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
@@ -1094,6 +1100,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             pa.tw_L = c->L;
             pa.tw_wT = c->wT;
         }
+        Prof p(c, MAMDR_KERNEL_AUX);
         launch_pass_prep(pa, c->stream);
     } else if (need_wT) {
         launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
@@ -1165,9 +1172,10 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
                     ca.omb1 = omb1;
                     ca.omb2 = omb2;
                     ca.eps = c->cfg.adam_eps;
-                    prof_break(c);
-                    launch_star_catchup(ca, c->stream);
-                    prof_break(c);
+                    {
+                        Prof p(c, MAMDR_KERNEL_AUX);
+                        launch_star_catchup(ca, c->stream);
+                    }
                     star_lag = 0;
                 }
             }

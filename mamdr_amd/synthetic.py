@@ -40,9 +40,29 @@ def _domain_sizes(total, n_domain, min_size, rs):
     return sizes
 
 
-def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128, signal=10.0, row_scale=1.0):
+def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128, signal=10.0, row_scale=1.0,
+             splits=("train", "val", "test"), threads=None):
     """returns dict(tables, data, info).  scale < 1 shrinks users/items/rows (tests);
-    row_scale < 1 shrinks only the number of rows (full-size tables, shorter epochs)."""
+    row_scale < 1 shrinks only the number of rows (full-size tables, shorter epochs).
+    splits: which splits to draw (bench.py binds the train split only; skipping the others changes the random
+    stream of the later domains, i.e. gives a different sample of the same distribution).
+    threads: worker threads for the planted model's logits (default: up to 16 of the visible cores)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if threads is None:
+        try:
+            threads = min(16, len(os.sched_getaffinity(0)))
+        except Exception:
+            threads = min(16, os.cpu_count() or 1)
+    pool = ThreadPoolExecutor(threads) if threads > 1 else None
+    try:
+        return _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, tuple(splits), pool)
+    finally:
+        if pool is not None:
+            pool.shutdown()
+
+
+def _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, splits, pool):
     spec = dict(SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     rs = np.random.RandomState(seed)
     D = spec["n_domain"]
@@ -71,15 +91,24 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
         items = rs.choice(n_item, n_i_d, replace=False)
         info[d] = {"ctr_ratio": r}
         dir_d = dir_shared + 0.7 * rs.standard_normal((2, emb_dim)) / np.sqrt(emb_dim)
-        for split in ("train", "val", "test"):
+        for split in splits:
             n = int(sizes[split][d])
             uid = users[rs.randint(0, n_u_d, n)].astype(np.int32)
             pid = items[rs.randint(0, n_i_d, n)].astype(np.int32)
             logit = np.empty(n, np.float64)
-            for c0 in range(0, n, 1 << 18):          # chunked: the gathered rows are 1 KiB per sample
-                sl = slice(c0, min(n, c0 + (1 << 18)))
+
+            def chunk(c0, uid=uid, pid=pid, logit=logit, dir_d=dir_d, bias=bias, n=n):
+                sl = slice(c0, min(n, c0 + (1 << 18)))       # chunked: the gathered rows are 1 KiB per sample
                 ue, ie = user_emb[uid[sl]].astype(np.float64), item_emb[pid[sl]].astype(np.float64)
                 logit[sl] = signal * (ue @ dir_d[0] + ie @ dir_d[1]) + 0.5 * signal * np.einsum("ij,ij->i", ue, ie) + bias
+            # (chunks are independent and each is computed by the same calls whatever the thread count: the labels
+            # do not depend on it; numpy's gathers / contractions release the GIL)
+            starts = range(0, n, 1 << 18)
+            if pool is not None and len(starts) > 1:
+                list(pool.map(chunk, starts))
+            else:
+                for c0 in starts:
+                    chunk(c0)
             label = (rs.uniform(size=n) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
             data[split][d] = {"uid": uid, "pid": pid, "domain": np.full(n, d, np.int32), "label": label}
             info[d]["n_" + split] = n

@@ -274,6 +274,34 @@ def test_adam_pass_matches_oracle(env):
     eng.close()
 
 
+@pytest.mark.parametrize("batch", [1000, 250])
+def test_adam_pass_with_a_batch_size_that_is_no_multiple_of_16(env, batch):
+    """Every step's 16-row padding is counted from its own first row (s * batch), so with batch % 16 != 0 the
+    tiles of consecutive steps overlap in the pre-gathered pass buffer and the last step's tile ends past the
+    call's rows (k_pass_prep zero-fills 16 rows behind them).  Whole shuffled pass on the k_wgrad_adam path
+    (mlp tower, frozen tables) incl. a short last batch, against the oracle."""
+    g, eng, model = make_problem(env, scale=0.25 if batch == 1000 else 0.05, batch=batch, dropout=0.5)
+    assert int(eng.lib.mamdr_step_path(eng.ctx, batch)) == 1
+    sizes = [g["data"]["train"][k]["uid"].shape[0] for k in range(10)]
+    # a domain whose last batch is short and not a multiple of 16 either
+    d = max((k for k in range(10) if sizes[k] % batch and (sizes[k] % batch) % 16), key=lambda k: sizes[k])
+    cols = g["data"]["train"][d]
+    perm = orng.shuffle_perm(sizes[d], 10000, seed=8)
+    n_steps = -(-sizes[d] // batch)
+    first = max(0, n_steps - 5)
+    model.step = 0
+    eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), first_step=first, n_steps=n_steps - first, lr=1e-3,
+                    batch_size=batch)
+    for s_ in range(first, n_steps):
+        ii = perm[s_ * batch:(s_ + 1) * batch]
+        model.train_on_batch(cols["uid"][ii], cols["pid"][ii], cols["domain"][ii], cols["label"][ii])
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        assert np.isfinite(got[name]).all(), name
+        assert_adam_close(got[name], model.params[name], n_steps - first, 1e-3, name, max_frac=2e-3)
+    eng.close()
+
+
 # ------------------------------------------------------------------ trainable user / item tables
 def test_trainable_tables_gradients_and_adam(env):
     """emb_trainable: scatter-add of row gradients + dense regulariser on EVERY row, dense Adam
