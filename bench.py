@@ -413,7 +413,8 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     balanced = None
     if wrapper == "mamdr":
         phis = {d: initial_vector(seed=2000 + d)[:eng.n_meta] for d in range(D)}
-        balanced = parallel.BalancedMAMDR(eng, meta, theta, phis, steps_per_domain)
+        balanced = parallel.BalancedMAMDR(eng, meta, theta, phis, steps_per_domain,
+                                          dn_mode=os.environ.get("MAMDR_BENCH_DN_MODE", "sharded"))
         del phis
     delta, zero = eng.new_vector(meta=True), eng.new_vector(meta=True)
     planner = mplan.EpochPlanner(range(D), TRAIN["sample_num"], TRAIN["add_query_domain"], True, TRAIN["seed"])
@@ -588,6 +589,11 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         # per epoch however many ranks share the device work ([mean, max] over ranks when world > 1)
         "host_ms_per_epoch": host_ms,
     }
+    if balanced is not None and balanced.wire_bytes:
+        # payload this rank put on the wire per epoch: the DN all-reduce (+ Star tail) and the phi slots it sent
+        wb = balanced.wire_bytes[-steps:]
+        rec["wire_bytes_per_epoch_rank0"] = float(np.mean(wb))
+        rec["dn_mode"] = balanced.dn_mode
     if loads:
         # what the per-epoch partition allows: sum of the ranks' planned steps / the largest rank's
         rec["partition_speedup_bound"] = float(np.mean([sum(l) / max(l) for l in loads]))
@@ -703,6 +709,9 @@ def main():
         if world > 1:
             result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
             result["backend"] = backend
+            for k in ("wire_bytes_per_epoch_rank0", "dn_mode"):
+                if k in r:
+                    result[k] = r[k]
             if "partition_speedup_bound" in r:
                 # (Taobao-10 has 10 query domains: the partition itself bounds the speed-up, ~5x on 8 ranks)
                 result["partition_speedup_bound"] = r["partition_speedup_bound"]

@@ -29,16 +29,19 @@ class MAMDR(SpecificBase):
         self._get_model_meta_parms()
         self.meta_weights = self._get_meta_weights()
         # one process per GPU: every rank draws all D initialisations (the streams stay aligned with the
-        # single-process run) and keeps every phi; the DR queries and DN passes of an epoch are dealt by
+        # single-process run) and keeps a slot for every phi; the DR queries and DN passes of an epoch are dealt by
         # longest-processing-time on the cost THAT epoch's sampled plan will execute, one all-reduce per epoch carries
-        # the DN displacement and hands the phis over (parallel.BalancedMAMDR); before validation every phi is made
-        # current everywhere and the domains are dealt round-robin
+        # the DN displacement (+ the displacement of the tensors outside theta / phi, Star tower), a phi whose owner
+        # changes travels point to point (parallel.BalancedMAMDR); validation, test and finetune of domain d run on the
+        # rank that holds the current phi_d.  train.dn_mode "replicated" (not in the reference's configs; default
+        # "sharded"): every rank runs the whole DN chain, the reference's sequential update, DR stays sharded.
         rank, world = parallel.world()
         steps = [self.dataset.train_dataset[d]["n_step"] for d in range(self.n_domain)]
         phis = {}
         for domain_idx in range(self.n_domain):
             phis[domain_idx] = self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
-        self.balanced = parallel.BalancedMAMDR(self.model, meta, self.meta_weights, phis, steps)
+        self.balanced = parallel.BalancedMAMDR(self.model, meta, self.meta_weights, phis, steps,
+                                               dn_mode=tc.get("dn_mode", "sharded"))
         self.domain_weights = self.balanced.phis
         self.model.optimizer_reset()
         planner = EpochPlanner(self.build_meta_sequence(), tc["sample_num"], tc["add_query_domain"],
@@ -56,10 +59,11 @@ class MAMDR(SpecificBase):
                                               tc["domain_regulation_step"], batch_variant, tc["sample_num"],
                                               bool(tc["finetune_every_epoch"]))
             if epoch % tc["val_every_step"] == 0:
-                self.balanced.sync_phis()
+                self.balanced.sync_tail()           # Star: one model outside theta / phi again before it is scored
                 _, val_avg_auc, _, val_domain_auc = self.val()
                 if self.early_stop_step(self._val_metric(val_avg_auc, val_domain_auc)):
                     break
                 print("Test Result: ")
                 self.val_and_test("test")
-        self.balanced.sync_phis()
+        self.balanced.sync_tail()
+        self.balanced.sync_phis()           # every slot current on every rank once training is over

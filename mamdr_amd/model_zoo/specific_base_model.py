@@ -19,6 +19,7 @@ class SpecificBase(MAML):
         self.domain_weights = {}
         self.best_shared_weights = None
         self.best_domain_weights = None
+        self.best_where = None
 
     def build_meta_sequence(self):
         t = self.train_config["target_domain"]
@@ -39,9 +40,23 @@ class SpecificBase(MAML):
         self.model.merge(out, shared_weights, specific_weights, method)
         return out
 
+    def _owner(self, d, i, best=False):
+        """rank that evaluates / finetunes domain d (the i-th of its split): the holder of the current phi_d -- of the
+        best phi_d for the test / finetune stages -- under the sharded MAMDR loop, round-robin where every rank holds
+        the same values."""
+        rank, world = parallel.world()
+        if world == 1:
+            return 0
+        where = self.best_where if best else getattr(getattr(self, "balanced", None), "where", None)
+        w = where.get(d) if where else None
+        return i % world if w is None else w
+
     def _snapshot_best(self):
         self.best_shared_weights = self.meta_weights.clone()
+        # (a rank's copy of a slot it does not hold is stale and never read: best_where says who holds which)
         self.best_domain_weights = {d: w.clone() for d, w in self.domain_weights.items()}
+        bal = getattr(self, "balanced", None)
+        self.best_where = dict(bal.where) if bal is not None else None
 
     def early_stop_step(self, metric):
         base = self.base_model
@@ -71,6 +86,9 @@ class SpecificBase(MAML):
             # the tensors outside theta / phi (PartitionedNorm gamma / beta and moving statistics, the specific
             # kernels, the output unit), and training goes on from them afterwards, as in the reference
             self.load_model(self.checkpoint_path)
+            bal = getattr(self, "balanced", None)
+            if bal is not None:                        # (the restored tail is the same on every rank: the new common value)
+                bal.tail.rebase()
             shared, specific = self.best_shared_weights, self.best_domain_weights
             store = self.dataset.test_dataset
         else:
@@ -79,8 +97,8 @@ class SpecificBase(MAML):
         merged = self.model.new_vector(meta=True)
         rank, world = parallel.world()
         for i, idx in enumerate(store):
-            if world > 1 and i % world != rank:        # every rank holds every phi: the domains are dealt out
-                continue
+            if world > 1 and self._owner(idx, i, best=(mode == "test")) != rank:
+                continue                               # the holder of phi_idx scores the domain
             self._set_model_meta_parms(self._merge_weights(shared, specific[idx], out=merged))
             p_loss, p_auc = self.evaluate_domain(idx, mode)
             domain_loss[idx], domain_auc[idx] = float(p_loss), float(p_auc)
@@ -97,8 +115,8 @@ class SpecificBase(MAML):
         def start(d):
             return self._merge_weights(self.best_shared_weights, self.best_domain_weights[d], out=merged)
         rank, world = parallel.world()
-        if world > 1:                                  # every rank holds every best phi: the domains are dealt out
-            mine = [d for i, d in enumerate(self.dataset.train_dataset) if i % world == rank]
+        if world > 1:                                  # the holder of the best phi_d finetunes domain d
+            mine = [d for i, d in enumerate(self.dataset.train_dataset) if self._owner(d, i, best=True) == rank]
             _, _, dl, da = self.base_model._finetune_domains(start, "sgd", FINETUNE_SGD_LR, domains=mine, summarise=False)
             dl, da = parallel.gather_domain_scalars({d: (dl[d], da[d]) for d in dl}, self.n_domain, self.model.device)
             return self.base_model._summarise("test", dl, da)

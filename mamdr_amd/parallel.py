@@ -153,54 +153,182 @@ def epoch_assignment(plan, steps_per_domain, n_parts, domain_regulation_step=0):
     return dr_owner, dn_owner, load
 
 
+class TailSync(object):
+    """The tensors OUTSIDE theta / phi (Star tower: PartitionedNorm gamma / beta, the per-domain kernels and biases, the
+    output unit -- `weights[n_meta:]` -- and the non-trainable moving statistics `aux`) are trained by the inner steps
+    only and live in each rank's engine.  The reference updates them in ONE sequence of passes
+    (model_zoo/Star/star.py:70-127 under mamdr.py:41-108); sharded, every rank applies its own passes to its own
+    copy.  `sync()` makes them one model again, the way the DN displacement is: since the last common value every
+    rank moved its copy by delta_g, the new common value is common + sum_g delta_g (first order = all passes applied
+    in sequence; one rank: the value itself).  The moving statistics of domain d are exponential averages of batch
+    statistics, not sums: ranks are combined weighted by the number of steps k_g each took on d since the last sync,
+    mov_d = sum_g k_g mov_d,g / sum_g k_g, and the zero-debias slots are rebuilt for the summed step count
+    (partitioned_norm.py:177-193: biased = mov * (1 - 0.99^steps)).  Adam's moments stay per rank, like every
+    other optimiser slot.  No-op for towers whose flat vector is all meta (mlp / deepfm / wdl)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.n_meta, self.n_tail = eng.n_meta, eng.n_params - eng.n_meta
+        self.aux = getattr(eng, "aux", None)
+        self.active = self.n_tail > 0
+        if not self.active:
+            return
+        self.common = eng.weights[self.n_meta:].clone()
+        self.aux_common = self.aux.clone() if self.aux is not None else None
+
+    def floats(self):
+        """payload of one sync (floats all-reduced)."""
+        if not self.active:
+            return 0
+        D = self.eng.n_domain
+        return self.n_tail + ((self.aux.numel() - D) // 2 + D if self.aux is not None else 0)
+
+    def _aux_views(self, a):
+        D = self.eng.n_domain
+        X = (a.numel() - D) // (4 * D)
+        dx = D * X
+        return a[0:dx].view(D, X), a[dx:2 * dx].view(D, X), a[2 * dx:3 * dx].view(D, X), a[3 * dx:4 * dx].view(D, X), \
+            a[4 * dx:4 * dx + D]
+
+    def rebase(self):
+        """the live tail IS the common value (every rank holds the same one: after a broadcast / at start)."""
+        if self.active:
+            self.common.copy_(self.eng.weights[self.n_meta:])
+            if self.aux is not None:
+                self.aux_common.copy_(self.aux)
+
+    def fill(self, buf):
+        """write this rank's payload (floats() elements) into `buf`: [tail - common | k * mov_mean | k * mov_var | k]."""
+        live = self.eng.weights[self.n_meta:]
+        torch.sub(live, self.common, out=buf[:self.n_tail])
+        if self.aux is not None:
+            mm, mv, _, _, steps = self._aux_views(self.aux)
+            D, X = mm.shape
+            k = (steps - self._aux_views(self.aux_common)[4]).clamp_(min=0.0)
+            o = self.n_tail
+            buf[o:o + D * X].view(D, X).copy_(mm * k[:, None])
+            buf[o + D * X:o + 2 * D * X].view(D, X).copy_(mv * k[:, None])
+            buf[o + 2 * D * X:o + 2 * D * X + D].copy_(k)
+
+    def apply(self, buf):
+        """`buf` summed over the ranks -> the new common value, on every rank."""
+        live = self.eng.weights[self.n_meta:]
+        live.copy_(self.common + buf[:self.n_tail])
+        if self.aux is not None:
+            mm, mv, bm, bv, steps = self._aux_views(self.aux)
+            D, X = mm.shape
+            o = self.n_tail
+            smm, smv = buf[o:o + D * X].view(D, X), buf[o + D * X:o + 2 * D * X].view(D, X)
+            sk = buf[o + 2 * D * X:o + 2 * D * X + D]
+            cm, cv, _, _, csteps = self._aux_views(self.aux_common)
+            moved = sk > 0
+            w = torch.where(moved, sk, torch.ones_like(sk))[:, None]
+            mm.copy_(torch.where(moved[:, None], smm / w, cm))
+            mv.copy_(torch.where(moved[:, None], smv / w, cv))
+            steps.copy_(csteps + sk)
+            factor = (1.0 - torch.pow(torch.full_like(steps, 0.99), steps))[:, None]
+            bm.copy_(mm * factor)
+            bv.copy_(mv * factor)
+        self.rebase()
+
+    def sync(self):
+        """a collective of its own (before validation / checkpoints; inside an epoch the payload rides in the DN
+        all-reduce: BalancedMAMDR.epoch)."""
+        rank, ws = world()
+        if not self.active or ws == 1:
+            return
+        buf = torch.empty(self.floats(), dtype=torch.float32, device=self.common.device)
+        self.fill(buf)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        self.apply(buf)
+
+
 class BalancedMAMDR(object):
-    """DN + DR epochs sharded over the ranks with a per-epoch assignment and ONE collective per epoch.
+    """DN + DR epochs sharded over the ranks with a per-epoch assignment and ONE data-path collective per epoch.
 
-    Every rank keeps theta and ALL phi_d in one packed buffer [delta | phi_0 | ... | phi_{D-1}].  An epoch:
+    Every rank keeps theta and a slot for every phi_d; `where[d]` is the rank whose slot holds the CURRENT phi_d
+    (None: identical everywhere).  An epoch:
       1. the plan (same seed everywhere) -> epoch_assignment -> this rank's DN sub-sequence and DR queries;
-      2. DN passes from theta; delta = theta~ - theta;
-      3. the phi slots this rank did NOT update in the previous epoch are zeroed and the whole buffer is
-         all-reduced (sum): delta becomes sum_g delta_g and every phi slot its last owner's value -- the phi
-         hand-over to this epoch's owners rides in the DN collective, so an epoch still has exactly one;
+      2. phi hand-over: a slot whose next owner differs from `where` travels owner -> next owner point to point
+         (RCCL send / recv over the xGMI link of that pair; every rank computes the same move list) -- with trainable
+         tables a phi is 0.3 GB, and only the slots that change hands move (round 2 all-reduced all D of them);
+      3. DN passes from theta; ONE all-reduce (sum) of [theta~ - theta | tail displacement] (TailSync);
       4. theta += beta * sum_g delta_g;  5. DR of the owned queries (meta.dr_query), phi slots updated in place.
+    dn_mode "replicated" (SURVEY 8e's fallback): every rank runs the WHOLE DN sequence -- one sequential chain,
+    the reference's update (domain_negotiation.py:53-88) -- and rank 0's theta~ (+ tail) is broadcast so that all
+    ranks continue from the same bits (their Adam step counts differ); DR stays sharded.
     With one rank no collective runs and the epoch is meta.mamdr_epoch's (the reference's loop).
-    `sync_phis()` makes every slot current everywhere (before validation / checkpoints)."""
+    `sync_phis()` makes every slot current everywhere; `owner(d)` says who evaluates / finetunes domain d."""
 
-    def __init__(self, eng, meta, theta, phis, steps_per_domain):
+    def __init__(self, eng, meta, theta, phis, steps_per_domain, dn_mode="sharded"):
         """phis: {domain: vector}, the SAME initial values on every rank (every rank draws all D initialisations)."""
+        if dn_mode not in ("sharded", "replicated"):
+            raise ValueError("dn_mode must be 'sharded' or 'replicated', not: {}".format(dn_mode))
         self.eng, self.meta, self.theta = eng, meta, theta
+        self.dn_mode = dn_mode
         self.steps = list(steps_per_domain)
         self.domains = sorted(phis)
         P = theta.numel()
         self.P = P
-        self.pack = torch.zeros((1 + len(self.domains)) * P, dtype=torch.float32, device=theta.device)
+        self.tail = TailSync(eng)
+        T = self.tail.floats()
+        T = (T + 3) // 4 * 4
+        # [delta | tail payload | phi_0 ... phi_{D-1}]: the DN collective reduces the first P + T floats in place
+        self.pack = torch.zeros((1 + len(self.domains)) * P + T, dtype=torch.float32, device=theta.device)
         self.delta = self.pack[:P]
+        self.tail_buf = self.pack[P:P + T]
         self.phis = {}
         for k, d in enumerate(self.domains):
-            v = self.pack[(1 + k) * P:(2 + k) * P]
+            v = self.pack[T + (1 + k) * P:T + (2 + k) * P]
             v.copy_(phis[d])
             self.phis[d] = v
         self.zero = torch.zeros_like(theta)
         self.merged = torch.empty_like(theta)
-        self.mine = None            # queries whose phi this rank updated last (None: every slot is current)
-        self.last_queries = set()   # queries ANY rank updated in that epoch (the plan is global)
+        self.where = {d: None for d in self.domains}
+        self.mine = None            # queries this rank ran in the last epoch
         self.last_load = None
+        self.wire_bytes = []        # per epoch: payload bytes this rank put into collectives + point-to-point sends
 
-    def _keep_only_current(self):
-        """zero every phi slot another rank holds the current value of; a slot nobody updated is identical
-        everywhere and stays on rank 0 only, so that the sum over ranks returns it unchanged."""
-        rank, _ = world()
-        for d in self.domains:
-            if d in self.mine or (d not in self.last_queries and rank == 0):
-                continue
-            self.phis[d].zero_()
+    def owner(self, d, fallback=0):
+        """rank holding the current phi_d (`fallback` when every rank does)."""
+        w = self.where.get(d)
+        return fallback if w is None else w
+
+    def _transfer(self, moves):
+        """moves: [(domain, src rank, dst rank)] in the same order on every rank."""
+        rank, ws = world()
+        sent = 0
+        if not moves:
+            return sent
+        p2p = dist.get_backend() == "nccl" or self.pack.device.type == "cpu"
+        if p2p:
+            ops = []
+            for d, src, dst in moves:
+                if rank == src:
+                    ops.append(dist.P2POp(dist.isend, self.phis[d], dst))
+                    sent += self.P * 4
+                elif rank == dst:
+                    ops.append(dist.P2POp(dist.irecv, self.phis[d], src))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        else:                       # gloo with device tensors (ranks sharing one GPU in tests): no send / recv there
+            for d, src, dst in moves:
+                dist.broadcast(self.phis[d], src=src)
+                sent += self.P * 4 if rank == src else 0
+        return sent
 
     def sync_phis(self):
         rank, ws = world()
-        if ws > 1 and self.mine is not None:
-            self._keep_only_current()
-            dist.all_reduce(self.pack[self.P:], op=dist.ReduceOp.SUM)
-        self.mine = None
+        if ws > 1:
+            for d in self.domains:
+                if self.where[d] is not None:
+                    dist.broadcast(self.phis[d], src=self.where[d])
+        self.where = {d: None for d in self.domains}
+
+    def sync_tail(self):
+        """tensors outside theta / phi -> one model on every rank (before validation / checkpoints)."""
+        self.tail.sync()
 
     def epoch(self, plan, perm_prepare, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
               domain_regulation_step=0, batch_variant=False, sample_num=None, finetune_every_epoch=False):
@@ -209,31 +337,61 @@ class BalancedMAMDR(object):
         from . import plan as mplan
         rank, ws = world()
         eng, meta, theta = self.eng, self.meta, self.theta
+        if perm_prepare is not None and finetune_every_epoch:
+            raise ValueError("pre-drawn epoch shuffles do not cover the per-query finetune passes")
         if ws == 1:
             if perm_prepare is not None:
                 perm_prepare(mplan.epoch_passes(plan, domain_regulation_step))
             return meta.mamdr_epoch(eng, theta, self.phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method,
                                     domain_regulation_step, batch_variant, sample_num, scratch=self.merged,
                                     finetune_every_epoch=finetune_every_epoch)
-        dr_owner, dn_owner, load = epoch_assignment(plan, self.steps, ws, domain_regulation_step)
+        replicated = self.dn_mode == "replicated"
+        if replicated:              # DN is not dealt out: the DR queries alone are balanced
+            dr_owner, _, load = epoch_assignment({"seq": [], "dr": plan["dr"]}, self.steps, ws, domain_regulation_step)
+            dn_owner = {d: rank for d in plan["seq"]}
+            load = [l + sum(self.steps[d] for d in plan["seq"]) for l in load]
+        else:
+            dr_owner, dn_owner, load = epoch_assignment(plan, self.steps, ws, domain_regulation_step)
         self.last_load = load
         local = {"seq": [d for d in plan["seq"] if dn_owner[d] == rank],
                  "dr": [(q, s) for (q, s) in plan["dr"] if dr_owner[q] == rank]}
         if perm_prepare is not None:
-            if finetune_every_epoch:
-                raise ValueError("pre-drawn epoch shuffles do not cover the per-query finetune passes")
             perm_prepare(mplan.epoch_passes(local, domain_regulation_step))
+        wire = self._transfer([(q, self.where[q], dr_owner[q]) for q, _ in sorted(plan["dr"])
+                               if self.where[q] is not None and self.where[q] != dr_owner[q]])
         trace = []
         acc = torch.zeros_like(theta) if batch_variant else None
+        if replicated and self.tail.active:
+            self.tail.sync()            # the previous epoch's DR displacements of the tail, before DN moves it again
+            wire += self.tail.floats() * 4
         eng.set_weights(theta)
         for d in local["seq"]:
             meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
-        eng.sub(self.delta, eng.weights, theta)
-        if self.mine is None:                       # every slot is current everywhere: only delta travels
-            dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+        if replicated:
+            # one chain; rank 0's result is everybody's (bit-identical continuation on every rank)
+            live = eng.weights
+            if self.tail.active:
+                dist.broadcast(live, src=0)
+                if self.tail.aux is not None:
+                    dist.broadcast(self.tail.aux, src=0)
+                self.tail.rebase()
+                wire += live.numel() * 4 if rank == 0 else 0
+                eng.sub(self.delta, live[:self.P], theta)
+            else:
+                eng.sub(self.delta, live, theta)
+                dist.broadcast(self.delta, src=0)
+                wire += self.P * 4 if rank == 0 else 0
         else:
-            self._keep_only_current()
-            dist.all_reduce(self.pack, op=dist.ReduceOp.SUM)
+            eng.sub(self.delta, eng.weights, theta)
+            if self.tail.active:
+                # [delta | tail displacement | statistics] in ONE collective
+                self.tail.fill(self.tail_buf)
+                dist.all_reduce(self.pack[:self.P + self.tail_buf.numel()], op=dist.ReduceOp.SUM)
+                self.tail.apply(self.tail_buf)
+                wire += (self.P + self.tail_buf.numel()) * 4
+            else:
+                dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+                wire += self.P * 4
         eng.interp(theta, self.delta, self.zero, meta_lr)
         for query, support in local["dr"]:
             meta.dr_query(eng, theta, self.phis[query], query, support, perm_fn, batch_size, lr, meta_lr, trace,
@@ -242,7 +400,9 @@ class BalancedMAMDR(object):
                 meta.finetune_query(eng, theta, self.phis[query], query, perm_fn, batch_size, lr, trace, self.merged,
                                     merged_method)
         self.mine = set(q for q, _ in local["dr"])
-        self.last_queries = set(q for q, _ in plan["dr"])
+        for q, _ in plan["dr"]:
+            self.where[q] = dr_owner[q]
+        self.wire_bytes.append(wire)
         return trace
 
 

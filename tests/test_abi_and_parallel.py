@@ -214,7 +214,7 @@ eng = make_engine()
 sizes = [eng.n_rows(d, "train") for d in range(D)]
 spd = [-(-n // 64) for n in sizes]
 theta, phis = initial(eng)
-bal = parallel.BalancedMAMDR(eng, meta, theta, phis, spd)
+bal = parallel.BalancedMAMDR(eng, meta, theta, phis, spd, dn_mode={dn_mode!r})
 planner = mplan.EpochPlanner(range(D), 2, True, True, 11)
 shuf = mplan.PassShuffler(sizes, 10000, 77 + rank, shuffle_fn=orng.shuffle_perm)
 total, owners = 0, []
@@ -223,24 +223,28 @@ for ep in range(3):
     tr = bal.epoch(p, None, shuf, 64, 1e-3, 0.1)
     total += sum(t[2] for t in tr)
     owners.append(sorted(bal.mine))
-    want = mplan.plan_steps(p, spd)
+    want = mplan.plan_steps(p, spd) + ((world - 1) * sum(spd[d] for d in p["seq"]) if {dn_mode!r} == "replicated" else 0)
     st = torch.tensor([float(sum(t[2] for t in tr))]); dist.all_reduce(st)
     assert int(st.item()) == want, (st.item(), want)
+moved = sum(b > 4 * eng.n_params for b in bal.wire_bytes)       # epochs in which this rank SENT a phi slot
+where = dict(bal.where)
 bal.sync_phis()
-np.savez({out!r} % rank, theta=theta.numpy(), owners=np.array([str(o) for o in owners]),
-         **{{"phi%d" % d: bal.phis[d].numpy() for d in range(D)}})
+np.savez({out!r} % rank, theta=theta.numpy(), owners=np.array([str(o) for o in owners]), moved=np.array(moved),
+         where=np.array([where[d] for d in range(D)]), **{{"phi%d" % d: bal.phis[d].numpy() for d in range(D)}})
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
 
 
-def test_balanced_mamdr_epochs_gloo_world2(tmp_path):
-    """BalancedMAMDR: per-epoch LPT of queries / DN passes, phi hand-over inside the ONE all-reduce per epoch.
-    Two gloo ranks against an in-process emulation of the same two ranks (two engines, sums in numpy):
-    theta and every phi identical on both ranks after sync_phis() and bit-equal to the emulation; ownership
-    really moves between epochs."""
+@pytest.mark.parametrize("dn_mode", ["sharded", "replicated"])
+def test_balanced_mamdr_epochs_gloo_world2(tmp_path, dn_mode):
+    """BalancedMAMDR: per-epoch LPT of queries / DN passes, ONE all-reduce per epoch (the DN displacement), a phi
+    whose owner changes travels point to point.  Two gloo ranks against an in-process emulation of the same two
+    ranks (two engines, sums in numpy): theta and every phi identical on both ranks after sync_phis() and bit-equal
+    to the emulation; ownership really moves between epochs.  dn_mode "replicated": every rank runs the whole DN
+    chain and rank 0's result is everybody's -- theta follows the reference's sequential DN update exactly."""
     script = tmp_path / "bal_worker.py"
-    script.write_text(BAL_WORKER.format(root=ROOT, here=HERE, out=str(tmp_path / "bal_%d.npz")))
+    script.write_text(BAL_WORKER.format(root=ROOT, here=HERE, out=str(tmp_path / "bal_%d.npz"), dn_mode=dn_mode))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
@@ -254,9 +258,11 @@ def test_balanced_mamdr_epochs_gloo_world2(tmp_path):
         assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
     res = [np.load(str(tmp_path / ("bal_%d.npz" % r))) for r in range(2)]
     for k in res[0].files:
-        if k != "owners":
+        if k not in ("owners", "moved"):
             assert np.array_equal(res[0][k], res[1][k]), k
     assert len(set(res[0]["owners"])) > 1 or len(set(res[1]["owners"])) > 1      # the assignment moved
+    assert int(res[0]["moved"]) + int(res[1]["moved"]) > 0                      # ... and slots travelled point to point
+    assert set(res[0]["where"]) <= {0, 1}
     # ---- emulation of the two ranks in this process
     ns = {}
     exec(BAL_SETUP.format(root=ROOT, here=HERE), ns)
@@ -274,15 +280,19 @@ def test_balanced_mamdr_epochs_gloo_world2(tmp_path):
     shufs = [mplan.PassShuffler(sizes, 10000, 77 + r, shuffle_fn=orng.shuffle_perm) for r in range(2)]
     for ep in range(3):
         p = planner.next_epoch()
-        dr_owner, dn_owner, _ = parallel.epoch_assignment(p, spd, 2)
+        if dn_mode == "replicated":
+            dr_owner, _, _ = parallel.epoch_assignment({"seq": [], "dr": p["dr"]}, spd, 2)
+        else:
+            dr_owner, dn_owner, _ = parallel.epoch_assignment(p, spd, 2)
         deltas = []
         for r in range(2):
             engs[r].set_weights(theta)
             for d in p["seq"]:
-                if dn_owner[d] == r:
+                if dn_mode == "replicated" or dn_owner[d] == r:
                     meta.run_pass(engs[r], d, shufs[r], 64, 1e-3, [], "dn")
             deltas.append((engs[r].weights.numpy() - theta.numpy()).astype(np.float32))
-        tot = (deltas[0] + deltas[1]).astype(np.float32)
+        # replicated: rank 0's chain is everybody's (== the single-process DN update on rank 0's state)
+        tot = deltas[0] if dn_mode == "replicated" else (deltas[0] + deltas[1]).astype(np.float32)
         engs[0].interp(theta, torch.from_numpy(tot), torch.zeros_like(theta), 0.1)
         for r in range(2):
             merged = torch.empty_like(theta)
@@ -351,6 +361,7 @@ def test_run_entry_sharded_reptile_batch_gloo_world2(tmp_path):
     ("mlp_meta_mamdr", {"finetune_every_epoch": True}),             # mamdr.py:110-143
     ("mlp_meta_domain_negotiation", {"meta_train_step": 2, "target_domain": 1}),   # domain_negotiation.py:44-45,67,89-93
     ("mlp_meta_reptile", {}),                                       # reptile.py:45-99, per-domain interpolation
+    ("mlp_meta_mamdr_finetune", {"dn_mode": "replicated"}),         # SURVEY 8e fallback: one DN chain, DR sharded
 ])
 def test_run_entry_sharded_variants_gloo_world2(tmp_path, name, extra):
     """the remaining multi-process variants through run.py's entry, 2 gloo ranks: identical results on every rank,
@@ -386,3 +397,65 @@ def _run_entry_worlds(tmp_path, name, extra=None):
     a, b = results[2]
     assert a == b and sorted(a["domain_auc"]) == ["0", "1", "2"]          # every rank holds every domain's result
     assert np.isfinite(a["avg_loss"]) and abs(a["avg_auc"] - results[1][0]["avg_auc"]) < 0.1
+
+
+TAIL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from mamdr_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+D, X, NM, NT = 3, 4, 10, 6
+class Eng(object):                      # what TailSync touches of a TowerEngine
+    n_domain, n_meta, n_params = D, NM, NM + NT
+    def __init__(self):
+        self.weights = torch.arange(NM + NT, dtype=torch.float32).clone()
+        self.aux = torch.zeros(4 * D * X + D)
+        self.aux[D * X:2 * D * X] = 1.0
+eng = Eng()
+ts = parallel.TailSync(eng)
+assert ts.active and ts.floats() == NT + 2 * D * X + D
+# each rank trains: the tail moves by (rank + 1) * 0.5 everywhere; domain `rank` takes (rank + 2) steps with statistics
+# mean = 10 * (rank + 1), var = 2 + rank; domain 2 is touched by nobody
+eng.weights[NM:] += (rank + 1) * 0.5
+mm, mv, bm, bv, steps = ts._aux_views(eng.aux)
+mm[rank] = 10.0 * (rank + 1); mv[rank] = 2.0 + rank; steps[rank] = rank + 2
+ts.sync()
+want_tail = torch.arange(NM, NM + NT, dtype=torch.float32) + 0.5 + 1.0
+assert torch.equal(eng.weights[NM:], want_tail), eng.weights
+assert torch.equal(eng.weights[:NM], torch.arange(NM, dtype=torch.float32))          # theta's part is not the tail's business
+for r in range(2):
+    assert torch.allclose(mm[r], torch.full((X,), 10.0 * (r + 1))) and torch.allclose(mv[r], torch.full((X,), 2.0 + r))
+    assert float(steps[r]) == r + 2
+    assert torch.allclose(bm[r], mm[r] * (1 - 0.99 ** (r + 2)))
+assert torch.equal(mm[2], torch.zeros(X)) and torch.equal(mv[2], torch.ones(X)) and float(steps[2]) == 0
+# second round: BOTH ranks train domain 0 (1 and 3 more steps): step-weighted average of their statistics
+eng.weights[NM:] -= 0.25
+mm[0] = 4.0 if rank == 0 else 8.0
+steps[0] += 1.0 if rank == 0 else 3.0
+ts.sync()
+assert torch.allclose(eng.weights[NM:], want_tail - 0.5)
+assert torch.allclose(mm[0], torch.full((X,), (1 * 4.0 + 3 * 8.0) / 4.0)) and float(steps[0]) == 2 + 4
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_tail_sync_gloo_world2(tmp_path):
+    """parallel.TailSync (the tensors outside theta / phi of the Star tower under several ranks): the tail becomes
+    common + the sum of the ranks' displacements, a domain's moving statistics the step-weighted average of the ranks
+    that trained it, the zero-debias slots follow the summed step count, untouched domains keep their values."""
+    script = tmp_path / "tail_worker.py"
+    script.write_text(TAIL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
