@@ -65,7 +65,7 @@ WORKLOADS = {
 }
 TARGET_KEYS = ("workload", "value", "unit", "us_per_domain_step", "ms_per_step", "epochs_timed", "domain_steps_per_epoch",
                "roofline", "tower", "table_update", "kernels_avg_us", "cpu_baseline", "gpu_over_cpu",
-               "partition_speedup_bound", "host_ms_per_epoch")
+               "partition_speedup_bound", "host_ms_per_epoch", "host_prep_ms_per_epoch")
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
 
@@ -421,19 +421,23 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     shuffles = mplan.EpochShuffles(mplan.PassShuffler(sizes, TRAIN["shuffle_buffer_size"], TRAIN["seed"] + rank),
                                    eng.device)
     loads = []
+    host_prep_s = [0.0]
 
     def epoch():
+        th0 = time.perf_counter()
         if wrapper == "dn":               # Domain Negotiation only (domain_negotiation.py:37-88)
             p = planner.next_epoch(with_dr=False)
             owner = parallel.lpt_partition(steps_per_domain, world)
             local = [d for d in p["seq"] if owner[d] == rank]
             shuffles.prepare([(d, 0) for d in local])
+            host_prep_s[0] += time.perf_counter() - th0
             tr = []
             parallel.dn_phase_sharded(eng, meta, theta, local, shuffles, batch, TRAIN["learning_rate"],
                                       TRAIN["meta_learning_rate"], tr, delta, zero)
             eng.set_weights(theta)
             return tr, mplan.plan_steps(p, steps_per_domain)
         p = planner.next_epoch()          # same seed on every rank -> same global plan
+        host_prep_s[0] += time.perf_counter() - th0
         tr = balanced.epoch(p, shuffles.prepare, shuffles, batch, TRAIN["learning_rate"], TRAIN["meta_learning_rate"],
                             TRAIN["merged_method"])
         if balanced.last_load is not None:
@@ -449,6 +453,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         epoch()
     barrier()
     del loads[:]
+    host_prep0 = host_prep_s[0] + (balanced.host_prep_s if balanced is not None else 0.0)
     t0 = time.perf_counter()
     local_steps, global_steps, local_passes, host_s = 0, 0, 0, 0.0
     for _ in range(steps):
@@ -585,9 +590,13 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0)) else roofline,
         "tower": roofline, "table_update": table_info or sweep_info, "gather_l2": l2_gather,
         "kernels_avg_us": kernels, "cpu_baseline": cpu,
-        # host side of an epoch (plan + LPT + shuffle generation / upload + every launch), enqueue only: the floor
-        # per epoch however many ranks share the device work ([mean, max] over ranks when world > 1)
+        # host side of an epoch.  host_ms_per_epoch = wall time spent inside the epoch call before any synchronisation
+        # (plan + LPT + shuffle generation / upload + every launch; [mean, max] over ranks when world > 1): an UPPER
+        # bound -- the HIP queue blocks the host once it is a few hundred launches ahead, so at N = 1 this tracks the
+        # device time.  host_prep_ms_per_epoch = the part that does not shrink with the rank count (drawing the epoch's
+        # plan, the per-epoch assignment, drawing + uploading this rank's shuffles), timed on its own.
         "host_ms_per_epoch": host_ms,
+        "host_prep_ms_per_epoch": (host_prep_s[0] + (balanced.host_prep_s if balanced is not None else 0.0) - host_prep0) / steps * 1e3,
     }
     if balanced is not None and balanced.wire_bytes:
         # payload this rank put on the wire per epoch: the DN all-reduce (+ Star tail) and the phi slots it sent
@@ -704,7 +713,8 @@ def main():
             "domain_passes_per_sec": r["domain_passes_per_sec"], "epoch_time_ms": r["ms_per_step"],
             "roofline": r["roofline"], "tower": r["tower"], "table_update": r["table_update"],
             "gather": gather, "gather_l2": r["gather_l2"], "kernels_avg_us": r["kernels_avg_us"],
-            "cpu_baseline": r["cpu_baseline"], "host_ms_per_epoch": r["host_ms_per_epoch"], "targets": targets,
+            "cpu_baseline": r["cpu_baseline"], "host_ms_per_epoch": r["host_ms_per_epoch"],
+            "host_prep_ms_per_epoch": r["host_prep_ms_per_epoch"], "targets": targets,
         }
         if world > 1:
             result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0

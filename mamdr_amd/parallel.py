@@ -288,6 +288,7 @@ class BalancedMAMDR(object):
         self.mine = None            # queries this rank ran in the last epoch
         self.last_load = None
         self.wire_bytes = []        # per epoch: payload bytes this rank put into collectives + point-to-point sends
+        self.host_prep_s = 0.0      # host work that no rank count divides: assignment + drawing / uploading the shuffles
 
     def owner(self, d, fallback=0):
         """rank holding the current phi_d (`fallback` when every rank does)."""
@@ -339,9 +340,12 @@ class BalancedMAMDR(object):
         eng, meta, theta = self.eng, self.meta, self.theta
         if perm_prepare is not None and finetune_every_epoch:
             raise ValueError("pre-drawn epoch shuffles do not cover the per-query finetune passes")
+        import time
+        t_host = time.perf_counter()
         if ws == 1:
             if perm_prepare is not None:
                 perm_prepare(mplan.epoch_passes(plan, domain_regulation_step))
+            self.host_prep_s += time.perf_counter() - t_host
             return meta.mamdr_epoch(eng, theta, self.phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method,
                                     domain_regulation_step, batch_variant, sample_num, scratch=self.merged,
                                     finetune_every_epoch=finetune_every_epoch)
@@ -357,6 +361,7 @@ class BalancedMAMDR(object):
                  "dr": [(q, s) for (q, s) in plan["dr"] if dr_owner[q] == rank]}
         if perm_prepare is not None:
             perm_prepare(mplan.epoch_passes(local, domain_regulation_step))
+        self.host_prep_s += time.perf_counter() - t_host
         wire = self._transfer([(q, self.where[q], dr_owner[q]) for q, _ in sorted(plan["dr"])
                                if self.where[q] is not None and self.where[q] != dr_owner[q]])
         trace = []
