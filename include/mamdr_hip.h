@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 8
+#define MAMDR_ABI_VERSION 9
 
 enum {
     MAMDR_OK = 0,
@@ -290,6 +290,58 @@ int mamdr_step_path(const mamdr_ctx* ctx, int32_t batch);
 int64_t mamdr_dropout_steps(const mamdr_ctx* ctx);
 int mamdr_profile_reset(mamdr_ctx* ctx);
 int mamdr_profile_read(mamdr_ctx* ctx, int32_t kernel, double* total_ms, int64_t* launches);
+
+/* ====================================================================================================
+ * Towers built from generic dense layers: the reference's multi-task baselines
+ * (model_zoo/DeepMTLCTR/deep_mtl_ctr.py).  `DeepMTLCTR.build_model` (:21-67) builds deepctr's
+ * SharedBottom / MMOE / PLE with one binary task per domain and compiles, per domain, `Model(inputs, outputs[d])` on ONE
+ * shared tf.train.AdamOptimizer; `train()` (:69-96) fits domain d's model on domain d's batches.  A handle of its own
+ * (the hot path's context is specialised to the 384-256-128-64 tower); same conventions as above.
+ * The flat vector lists, in order: the domain table, the experts every task mixes, then per task its own experts (PLE),
+ * its gate DNN + gate kernel, its tower DNN, its output unit and global bias (tensor names: mamdr_graph_tensor_info).
+ * User / item tables are frozen (bound through mamdr_graph_bind_table); emb_trainable = 1 returns MAMDR_ENOTBUILT. */
+enum { MAMDR_GRAPH_SHARED_BOTTOM = 0,   /* deep_mtl_ctr.py:25-30  models.SharedBottom */
+       MAMDR_GRAPH_MMOE = 1,            /* deep_mtl_ctr.py:31-38  models.MMOE */
+       MAMDR_GRAPH_PLE = 2 };           /* deep_mtl_ctr.py:39-49  models.PLE (num_levels = 1, as in every reference config) */
+typedef struct mamdr_graph mamdr_graph;
+typedef struct mamdr_graph_config {
+    int32_t abi_version;        /* MAMDR_ABI_VERSION */
+    int32_t kind;               /* MAMDR_GRAPH_* */
+    int32_t n_user, n_item, n_domain, emb_dim, max_batch, emb_trainable;
+    int32_t n_expert_hidden; int32_t expert_hidden[4];   /* model.hidden_dim: bottom / expert DNN (deep_mtl_ctr.py:26,33,44) */
+    int32_t n_tower_hidden;  int32_t tower_hidden[4];    /* model.tower_hidden_dim (:27,34,43) */
+    int32_t n_gate_hidden;   int32_t gate_hidden[4];     /* model.gate_dnn_hidden_units (:36,45); unused by shared_bottom */
+    int32_t num_experts;                                 /* mmoe (:32) */
+    int32_t shared_expert_num, specific_expert_num;      /* ple (:40-41) */
+    float dropout, l2_emb, adam_beta1, adam_beta2, adam_eps;
+} mamdr_graph_config;
+const char* mamdr_graph_last_error(void);
+int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph** out);   /* build_model, deep_mtl_ctr.py:21-67 */
+int mamdr_graph_destroy(mamdr_graph* g);
+int64_t mamdr_graph_param_count(const mamdr_graph* g);
+int32_t mamdr_graph_tensor_count(const mamdr_graph* g);
+/* tensor i of the flat vector: Keras-style name ("expert_0/W1", "gate_3/Wg", "tower_3/b0", "head_3/w", ...), element offset
+ * and shape (biases and scalars: rows = 1) -- model.trainable_weights of deep_mtl_ctr.py:51 */
+int mamdr_graph_tensor_info(const mamdr_graph* g, int32_t i, char* name, int32_t name_cap, int64_t* offset, int64_t* rows,
+                            int64_t* cols);
+/* the two ranges of the flat vector a step on `domain` trains = trainable_weights of Model(inputs, outputs[domain])
+ * (deep_mtl_ctr.py:62-66): the shared block and that task's block; everything else neither moves nor decays */
+int mamdr_graph_task_ranges(const mamdr_graph* g, int domain, int64_t* shared_off, int64_t* shared_count, int64_t* task_off,
+                            int64_t* task_count);
+int mamdr_graph_bind_state(mamdr_graph* g, float* d_params, float* d_adam_m, float* d_adam_v);
+int mamdr_graph_optimizer_reset(mamdr_graph* g);
+int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g);
+int64_t mamdr_graph_dropout_steps(const mamdr_graph* g);
+int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t n_rows);     /* deep_mtl_ctr.py:98-121 */
+int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const int32_t* d_uid, const int32_t* d_pid,
+                                 const int32_t* d_domain, const float* d_label, int64_t n_rows);
+/* n_steps x `domain_model_dict[domain]` train_on_batch: deep_mtl_ctr.py:79-80 (Adam) / :158-172 (per-domain fit).
+ * Same batch / permutation / dropout-stream conventions as mamdr_train_steps; MAMDR_OPT_ADAM or MAMDR_OPT_SGD. */
+int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, int64_t first_step, int64_t n_steps,
+                            int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr, float* d_loss_out);
+/* `domain_model_dict[domain].evaluate(data, steps=n_step)`: deep_mtl_ctr.py:207; outputs as mamdr_eval_domain */
+int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch, float* d_loss_out, uint32_t* d_hist,
+                            float* d_pred_out);
 
 #ifdef __cplusplus
 }

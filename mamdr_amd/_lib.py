@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -45,6 +45,22 @@ class Config(C.Structure):
         ("emb_trainable", C.c_int32), ("dropout", C.c_float), ("l2_emb", C.c_float), ("l2_linear", C.c_float),
         ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("uncertainty_weight", C.c_int32),
+    ]
+
+
+GRAPH_SHARED_BOTTOM, GRAPH_MMOE, GRAPH_PLE = 0, 1, 2
+
+
+class GraphConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("kind", C.c_int32), ("n_user", C.c_int32), ("n_item", C.c_int32),
+        ("n_domain", C.c_int32), ("emb_dim", C.c_int32), ("max_batch", C.c_int32), ("emb_trainable", C.c_int32),
+        ("n_expert_hidden", C.c_int32), ("expert_hidden", C.c_int32 * 4),
+        ("n_tower_hidden", C.c_int32), ("tower_hidden", C.c_int32 * 4),
+        ("n_gate_hidden", C.c_int32), ("gate_hidden", C.c_int32 * 4),
+        ("num_experts", C.c_int32), ("shared_expert_num", C.c_int32), ("specific_expert_num", C.c_int32),
+        ("dropout", C.c_float), ("l2_emb", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
+        ("adam_eps", C.c_float),
     ]
 
 
@@ -89,6 +105,22 @@ SIGNATURES = {
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
     "mamdr_profile_reset": (C.c_int, [_VP]),
     "mamdr_profile_read": (C.c_int, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    # towers built from generic dense layers (shared_bottom / mmoe / ple)
+    "mamdr_graph_last_error": (C.c_char_p, []),
+    "mamdr_graph_create": (C.c_int, [C.POINTER(GraphConfig), _VP, C.POINTER(_VP)]),
+    "mamdr_graph_destroy": (C.c_int, [_VP]),
+    "mamdr_graph_param_count": (_I64, [_VP]),
+    "mamdr_graph_tensor_count": (_I32, [_VP]),
+    "mamdr_graph_tensor_info": (C.c_int, [_VP, _I32, C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    "mamdr_graph_task_ranges": (C.c_int, [_VP, C.c_int, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    "mamdr_graph_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "mamdr_graph_optimizer_reset": (C.c_int, [_VP]),
+    "mamdr_graph_optimizer_steps": (_I64, [_VP]),
+    "mamdr_graph_dropout_steps": (_I64, [_VP]),
+    "mamdr_graph_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
+    "mamdr_graph_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),
+    "mamdr_graph_train_steps": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
+    "mamdr_graph_eval_domain": (C.c_int, [_VP, C.c_int, C.c_int, _I32, _VP, _VP, _VP]),
 }
 
 _lib = None
@@ -117,9 +149,9 @@ def load():
     return lib
 
 
-def check(code):
+def check(code, graph=False):
     if code != OK:
-        text = load().mamdr_last_error().decode("utf-8", "replace")
+        text = (load().mamdr_graph_last_error() if graph else load().mamdr_last_error()).decode("utf-8", "replace")
         if code == ENOTBUILT:
             raise NotBuiltError(code, text)
         raise MamdrError(code, text)

@@ -23,6 +23,7 @@ SOURCES = [
     ("fused_kernels.hip", []),
     ("star_kernels.hip", []),
     ("outer_kernels.hip", ["-ffp-contract=off"]),
+    ("graph_engine.hip", []),
     ("mamdr_api.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]

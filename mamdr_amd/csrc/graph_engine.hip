@@ -1,0 +1,1064 @@
+// Towers built from GENERIC dense layers: deepctr's SharedBottom / MMOE / PLE under the reference's per-domain
+// compiled models (model_zoo/DeepMTLCTR/deep_mtl_ctr.py:21-96).  SURVEY.md section 8 f4: comparison baselines next
+// to the hot path -- layer widths, expert counts and gate shapes vary per config (config/*/{shared_bottom,mmoe,ple}.json:
+// hidden_dim [512,256,128] ... [256], 2-5 experts, PLE 3-15 specific + 2 shared experts per task), so nothing here is
+// specialised to one shape the way step_kernels.hip is to 384-256-128-64.
+//
+// One training step of task d on a batch (what `domain_model_dict[d].fit` executes per batch, deep_mtl_ctr.py:79-80):
+//   gather x = [U[uid] | I[pid] | Dm[dom]]                                   k_graph_gather   (hbm)
+//   every expert task d mixes: DNN = per layer  relu(h W + b) * dropout       k_graph_gemm<0>  (mfma, 64x64 tiles)
+//   gate_d: DNN, then softmax(q Wg) and the mixture sum_e gate_e expert_e     k_graph_gate_fwd (one wave per row)
+//   tower_d: DNN;  head: sigmoid(t w + gb), Keras BCE, d loss / d logit       k_graph_head     (one wave per row)
+//   backward, layer by layer: dW = in^T dz (k_graph_gemm<2>), db = column sums (k_graph_colsum),
+//   d in = dz W^T times the producer's relu / dropout gate (k_graph_gemm<1>); the mixture's backward
+//   (k_graph_gate_bwd) between tower and experts; the first layers add into d x[:, domain columns]
+//   domain table: segment sum of d x over the batch's domain ids + 2 l2 Dm    k_graph_domain_grad
+//   TF1 Adam (or SGD) on the two ranges of the flat vector task d's model trains: the shared block (domain table +
+//   shared experts) and task d's block (its experts, gate, tower, head)       k_graph_adam     (hbm)
+// All fp32 (`v_mfma_f32_32x32x2_f32`: exact fp32 products), every reduction in a fixed order (no float atomics).
+// The user / item tables are frozen in this engine (every Taobao config of these towers; the Amazon ones train
+// them: MAMDR_ENOTBUILT).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mamdr_hip.h"
+#include "mamdr_device.h"
+
+namespace mamdr {
+void launch_sumsq(const float* x, int64_t n, float* partials, float* out, hipStream_t s);   // step_kernels.hip
+}
+
+using namespace mamdr;
+
+namespace {
+
+thread_local char g_gerr[512] = "";
+int gfail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_gerr, sizeof(g_gerr), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define GHIP(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return gfail(MAMDR_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int GT = 64;      // output tile (rows and columns)
+constexpr int GK = 16;      // reduction depth per staged tile
+constexpr int GLD = 68;     // LDS row stride (floats): the two half-waves of an operand read hit disjoint banks
+constexpr int MAX_MIX = 32; // experts one task mixes (PLE: specific + shared)
+
+// ------------------------------------------------------------------ gather
+struct GatherArgs {
+    const float *user_tab, *item_tab, *dm;
+    const int32_t *uid, *pid, *dom, *perm;
+    const float* label;
+    int64_t row_base, n_rows_split;
+    int rows, rows_pad, n_user, n_item, n_domain;
+    float* x;
+    int ld;
+    int32_t* domrow;
+    float* y;
+};
+// one wave per batch position: lanes 0..31 copy the user row, 32..63 the item row, then lanes 0..31 the domain row
+__global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    float* xr = a.x + (size_t)r * a.ld;
+    if (r >= a.rows) {          // padding rows: zeros in, nothing out (their d loss / d logit is zero)
+        *reinterpret_cast<f32x4*>(xr + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (lane < 32) *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) { a.domrow[r] = -1; a.y[r] = 0.f; }
+        return;
+    }
+    int64_t src = a.perm ? (int64_t)a.perm[a.row_base + r] : a.row_base + r;
+    src = src < 0 ? 0 : (src >= a.n_rows_split ? a.n_rows_split - 1 : src);
+    int u = a.uid[src], it = a.pid[src], d = a.dom[src];
+    u = u < 0 ? 0 : (u >= a.n_user ? a.n_user - 1 : u);
+    it = it < 0 ? 0 : (it >= a.n_item ? a.n_item - 1 : it);
+    d = d < 0 ? 0 : (d >= a.n_domain ? a.n_domain - 1 : d);
+    const float* row = lane < 32 ? a.user_tab + (size_t)u * EMB + 4 * lane : a.item_tab + (size_t)it * EMB + 4 * (lane - 32);
+    *reinterpret_cast<f32x4*>(xr + 4 * lane) = *reinterpret_cast<const f32x4*>(row);
+    if (lane < 32)
+        *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = *reinterpret_cast<const f32x4*>(a.dm + (size_t)d * EMB + 4 * lane);
+    if (lane == 0) { a.domrow[r] = d; a.y[r] = a.label[src]; }
+}
+
+// ------------------------------------------------------------------ dense contractions
+// MODE 0:  C[M x N] = A[M x K] . B[K x N]        + bias, relu, dropout           (layer forward)
+// MODE 1:  C[M x N] = A[M x K] . B[N x K]^T      x the gate of gate_y, += C        (d input = dz . W^T)
+// MODE 2:  C[M x N] = A[K x M]^T . B[K x N]                                        (dW = in^T . dz, K = batch rows)
+// M, N multiples of 64, K a multiple of 16.  64x64 tile per workgroup, 4 waves own its 32x32 quadrants
+// (`32x32x2`, A / B fragments read from LDS as one float per lane: [k][m] images, conflict-free).
+struct GemmArgs {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int K;
+    const float* bias; int relu;
+    uint32_t drop_key, drop_thresh; float keep_scale; int n_cols; int use_dropout;
+    const float* gate_y; int gate_ld; float gate_scale; int accumulate;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    constexpr bool A_KC = MODE != 2;        // A's reduction index is the contiguous one in memory
+    constexpr bool B_KC = MODE == 1;
+    const int r4 = tid >> 2, k4 = (tid & 3) * 4;        // k-contiguous operand: row r4 of the tile, 4 k's
+    const int kr = tid >> 4, c4 = (tid & 15) * 4;       // otherwise: k row kr, 4 columns
+    f32x4 ra, rb;
+    auto gload = [&](int kt) {
+        const int k0 = kt * GK;
+        ra = A_KC ? *reinterpret_cast<const f32x4*>(a.A + (size_t)(m0 + r4) * a.lda + k0 + k4)
+                  : *reinterpret_cast<const f32x4*>(a.A + (size_t)(k0 + kr) * a.lda + m0 + c4);
+        rb = B_KC ? *reinterpret_cast<const f32x4*>(a.B + (size_t)(n0 + r4) * a.ldb + k0 + k4)
+                  : *reinterpret_cast<const f32x4*>(a.B + (size_t)(k0 + kr) * a.ldb + n0 + c4);
+    };
+    auto lstore = [&](int buf) {
+        if (A_KC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[buf][(k4 + j) * GLD + r4] = ra[j];
+        } else {
+            *reinterpret_cast<f32x4*>(&As[buf][kr * GLD + c4]) = ra;
+        }
+        if (B_KC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bs[buf][(k4 + j) * GLD + r4] = rb[j];
+        } else {
+            *reinterpret_cast<f32x4*>(&Bs[buf][kr * GLD + c4]) = rb;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nk = a.K / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int kk = lane >> 5, c = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* ap = &As[buf][kk * GLD + wm + c];
+        const float* bp = &Bs[buf][kk * GLD + wn + c];
+#pragma unroll
+        for (int i = 0; i < GK / 2; ++i) acc = MAMDR_MFMA32(ap[2 * i * GLD], bp[2 * i * GLD], acc);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int col = n0 + wn + c;
+    const float bias = (MODE == 0 && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        float v = acc[r];
+        if (MODE == 0) {
+            v += bias;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.use_dropout) {
+                const uint32_t u = mamdr_dropout_u32(a.drop_key, (uint32_t)row * (uint32_t)a.n_cols + (uint32_t)col);
+                v = u >= a.drop_thresh ? v * a.keep_scale : 0.f;
+            }
+        } else if (MODE == 1) {
+            if (a.gate_y) v = a.gate_y[(size_t)row * a.gate_ld + col] > 0.f ? v * a.gate_scale : 0.f;
+            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
+        }
+        a.C[(size_t)row * a.ldc + col] = v;
+    }
+}
+
+// db[n] = sum over the batch rows of dz[b][n]: 64 columns per workgroup, 4 row groups summed through LDS in order
+__global__ __launch_bounds__(256) void k_graph_colsum(const float* dz, int ld, int rows, float* out) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float s = 0.f;
+    for (int b = g; b < rows; b += 4) s += dz[(size_t)b * ld + col];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0) out[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1)
+__global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_ld, const float* d, int d_ld, int rows,
+                                                        int n_j, int n_e, float* out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_j * n_e) return;
+    const int j = idx / n_e, e = idx - j * n_e;
+    float s = 0.f;
+    for (int b = 0; b < rows; ++b) s = fmaf(in[(size_t)b * in_ld + j], d[(size_t)b * d_ld + e], s);
+    out[idx] = s;
+}
+
+// ------------------------------------------------------------------ gate: softmax(q Wg) and the mixture, one wave per row
+struct GateArgs {
+    float* act; float* dact; int ld;
+    int q_col, n_q;             // gate DNN output
+    const float* wg; int n_e;   // [n_q][n_e]
+    int e_col[MAX_MIX];         // last-layer output of each mixed expert
+    int n_h;                    // expert width
+    int g_col, m_col;           // gate probabilities (n_e columns), mixture (n_h columns)
+    int rows_pad;
+    float gate_scale;           // 1 / keep of the dropout behind every DNN layer (1 in inference)
+};
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_graph_gate_fwd(const GateArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    float* row = a.act + (size_t)r * a.ld;
+    float logit[MAX_MIX];       // (every loop over it is fully unrolled: registers, no scratch)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int e = 0; e < MAX_MIX; ++e) {
+        logit[e] = -3.0e38f;
+        if (e < a.n_e) {
+            float s = 0.f;
+            for (int j = lane; j < a.n_q; j += 64) s = fmaf(row[a.q_col + j], a.wg[j * a.n_e + e], s);
+            logit[e] = wave_sum(s);
+            mx = fmaxf(mx, logit[e]);
+        }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAX_MIX; ++e) {
+        logit[e] = e < a.n_e ? __expf(logit[e] - mx) : 0.f;
+        den += logit[e];
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAX_MIX; ++e) {
+        logit[e] = logit[e] / den;
+        mine = (e == lane) ? logit[e] : mine;
+    }
+    if (lane < a.n_e) row[a.g_col + lane] = mine;
+    for (int cidx = lane; cidx < a.n_h; cidx += 64) {
+        float m = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAX_MIX; ++e)
+            if (e < a.n_e) m += logit[e] * row[a.e_col[e] + cidx];
+        row[a.m_col + cidx] = m;
+    }
+}
+// d mixture -> d expert outputs (times their relu / dropout gate = d z of the experts' last layers), d gate logits
+// (kept: dWg = q^T dgl) and d q (times q's gate = d z of the gate DNN's last layer)
+__global__ __launch_bounds__(256) void k_graph_gate_bwd(const GateArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    const float* row = a.act + (size_t)r * a.ld;
+    float* drow = a.dact + (size_t)r * a.ld;
+    float dg[MAX_MIX], gp[MAX_MIX];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAX_MIX; ++e) {
+        dg[e] = 0.f;
+        gp[e] = 0.f;
+        if (e < a.n_e) {
+            float t = 0.f;
+            for (int cidx = lane; cidx < a.n_h; cidx += 64) t = fmaf(drow[a.m_col + cidx], row[a.e_col[e] + cidx], t);
+            dg[e] = wave_sum(t);
+            gp[e] = row[a.g_col + e];
+            s = fmaf(gp[e], dg[e], s);
+        }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAX_MIX; ++e) {
+        dg[e] = gp[e] * (dg[e] - s);        // d gate logit
+        mine = (e == lane) ? dg[e] : mine;
+    }
+    for (int cidx = lane; cidx < a.n_h; cidx += 64) {
+        const float dm = drow[a.m_col + cidx];
+#pragma unroll
+        for (int e = 0; e < MAX_MIX; ++e)
+            if (e < a.n_e) {
+                const float h = row[a.e_col[e] + cidx];
+                drow[a.e_col[e] + cidx] = h > 0.f ? (gp[e] * dm) * a.gate_scale : 0.f;
+            }
+    }
+    if (lane < a.n_e) drow[a.g_col + lane] = mine;
+    for (int j = lane; j < a.n_q; j += 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAX_MIX; ++e)
+            if (e < a.n_e) v = fmaf(dg[e], a.wg[j * a.n_e + e], v);
+        drow[a.q_col + j] = row[a.q_col + j] > 0.f ? v * a.gate_scale : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ head: Dense(1, no bias) + global bias, sigmoid, Keras BCE
+struct HeadArgs {
+    const float* act; float* dact; int ld;
+    int t_col, n_t;
+    const float* w; const float* gb;
+    const float* y; int rows, rows_pad;
+    float* dlogit; float* rowloss;
+    int train; float gate_scale;
+    const float* thresholds; uint32_t* hist; float* pred_out;       // inference
+};
+__global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    const float* row = a.act + (size_t)r * a.ld;
+    float s = 0.f;
+    for (int cidx = lane; cidx < a.n_t; cidx += 64) s = fmaf(row[a.t_col + cidx], a.w[cidx], s);
+    const float logit = wave_sum(s) + a.gb[0];
+    float p;
+    if (logit >= 0.f) {
+        p = 1.0f / (1.0f + __expf(-logit));
+    } else {
+        const float ez = __expf(logit);
+        p = ez / (1.0f + ez);
+    }
+    const bool valid = r < a.rows;
+    const float y = a.y[r];
+    const float lo = 1e-7f, hi = 1.0f - 1e-7f;
+    const float pc = fminf(fmaxf(p, lo), hi);
+    const float zc = __logf(pc / (1.0f - pc));
+    const float loss = fmaxf(zc, 0.f) - zc * y + __logf(1.0f + __expf(-fabsf(zc)));
+    if (lane == 0) a.rowloss[r] = valid ? loss : 0.f;
+    if (a.train) {
+        const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
+        const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.f;
+        if (lane == 0) a.dlogit[r] = dl;
+        float* drow = a.dact + (size_t)r * a.ld;
+        for (int cidx = lane; cidx < a.n_t; cidx += 64)
+            drow[a.t_col + cidx] = row[a.t_col + cidx] > 0.f ? (dl * a.w[cidx]) * a.gate_scale : 0.f;
+    } else if (lane == 0 && valid) {
+        int blo = 0, bhi = 500;          // AUC bin = number of thresholds strictly below p (utils/metrics_utils.py:309)
+        while (blo < bhi) {
+            const int mid = (blo + bhi) >> 1;
+            if (a.thresholds[mid] < p) blo = mid + 1; else bhi = mid;
+        }
+        atomicAdd(a.hist + (y != 0.f ? 501 : 0) + blo, 1u);
+        if (a.pred_out) a.pred_out[r] = p;
+    }
+}
+
+// batch loss = mean of the rows' BCE + l2 (sum of squares of the three tables); one workgroup, fixed order.
+// mode 0: out[0] = loss;  mode 1 (evaluation): out[0] += loss
+__global__ __launch_bounds__(256) void k_graph_loss(const float* rowloss, int rows, const float* dm, int dm_count, float l2,
+                                                    const float* frozen_sumsq, float* out, int mode) {
+    __shared__ float red[256];
+    float s = 0.f, q = 0.f;
+    for (int b = threadIdx.x; b < rows; b += 256) s += rowloss[b];
+    for (int e = threadIdx.x; e < dm_count; e += 256) q = fmaf(dm[e], dm[e], q);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float tot = red[0];
+    __syncthreads();
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float loss = tot / (float)rows + l2 * ((frozen_sumsq[0] + frozen_sumsq[1]) + red[0]);
+        out[0] = mode ? out[0] + loss : loss;
+    }
+}
+__global__ void k_graph_scale(float* x, float s) { x[0] *= s; }
+// out[0] = sum of x[0..n) in a fixed order (d global bias = sum of d loss / d logit)
+__global__ __launch_bounds__(256) void k_graph_sum1(const float* x, int n, float* out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n; b += 256) s += x[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// ------------------------------------------------------------------ domain table gradient
+// g[d][c] = sum over the batch rows of domain d of d x[b][256 + c]  +  2 l2 Dm[d][c]   (rows in batch order)
+__global__ __launch_bounds__(128) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
+                                                           const float* dm, float two_l2, float* g) {
+    const int d = blockIdx.x, c = threadIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < rows; ++b)
+        if (domrow[b] == d) s += dx[(size_t)b * ld + x_col + c];
+    g[d * EMB + c] = s + two_l2 * dm[d * EMB + c];
+}
+
+// ------------------------------------------------------------------ optimiser on a range of the flat vector
+struct AdamArgs {
+    float *p, *m, *v;
+    const float* g;
+    int64_t n4;             // float4 elements
+    int optimizer;          // MAMDR_OPT_ADAM / MAMDR_OPT_SGD
+    float alpha, omb1, omb2, eps;
+};
+__global__ __launch_bounds__(256) void k_graph_adam(const AdamArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n4) return;
+    f32x4 p = reinterpret_cast<const f32x4*>(a.p)[i];
+    const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
+    if (a.optimizer == MAMDR_OPT_SGD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = p[k] - g[k] * a.alpha;
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        return;
+    }
+    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[i], v = reinterpret_cast<const f32x4*>(a.v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {       // TF1 ApplyAdam: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p -= m alpha / (sqrt(v) + eps)
+        m[k] = m[k] + (g[k] - m[k]) * a.omb1;
+        v[k] = v[k] + (g[k] * g[k] - v[k]) * a.omb2;
+        p[k] = p[k] - (m[k] * a.alpha) / (sqrtf(v[k]) + a.eps);
+    }
+    reinterpret_cast<f32x4*>(a.p)[i] = p;
+    reinterpret_cast<f32x4*>(a.m)[i] = m;
+    reinterpret_cast<f32x4*>(a.v)[i] = v;
+}
+
+// ------------------------------------------------------------------ host side: structure of the tower
+struct Layer {
+    int64_t w_off, b_off;
+    int in, out;
+    uint32_t id;            // dropout stream id = position among all DNN kernels in flat-vector order
+};
+struct Dnn {
+    std::string name;
+    std::vector<Layer> layers;
+    int in_dim;
+};
+struct TensorInfo {
+    std::string name;
+    int64_t off, rows, cols;
+};
+struct Task {
+    std::vector<int> mix;   // indices into dnns: the experts this task mixes (specific ones first, then the shared ones)
+    int gate = -1;          // gate DNN
+    int64_t wg_off = 0;
+    int tower = -1;
+    int64_t head_w = 0, head_gb = 0;
+    int64_t blk_off = 0, blk_end = 0;
+    // column plan of the activation / gradient workspaces for this task's path
+    std::vector<std::vector<int>> col;  // col[dnn index in `path`][layer] -> first column of that layer's output
+    std::vector<int> path;              // dnns on the path: mix..., gate, tower
+    int g_col = 0, m_col = 0, n_cols = 0;
+};
+struct SplitData {
+    const int32_t *uid = nullptr, *pid = nullptr, *dom = nullptr;
+    const float* label = nullptr;
+    int64_t n = 0;
+};
+
+}  // namespace
+
+struct mamdr_graph {
+    mamdr_graph_config cfg;
+    hipStream_t stream = nullptr;
+    std::vector<Dnn> dnns;
+    std::vector<Task> tasks;
+    std::vector<TensorInfo> tensors;
+    int64_t n_params = 0, dm_off = 0, shared_end = 0;
+    bool gated = false;
+    int n_h = 0;                // expert width
+    // bound state
+    float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    const float *user_tab = nullptr, *item_tab = nullptr;
+    std::vector<SplitData> data;
+    int64_t adam_t = 0;
+    float b1p = 1.f, b2p = 1.f;
+    uint32_t global_step = 0;
+    // workspace
+    int rows_pad_max = 0, ld = 0;
+    float *act = nullptr, *dact = nullptr, *grad = nullptr, *dlogit = nullptr, *rowloss = nullptr, *y = nullptr;
+    int32_t* domrow = nullptr;
+    float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
+};
+
+namespace {
+
+int64_t add_tensor(mamdr_graph* g, const std::string& name, int64_t rows, int64_t cols) {
+    const int64_t off = g->n_params;
+    g->tensors.push_back(TensorInfo{name, off, rows, cols});
+    g->n_params = (off + rows * cols + 3) & ~(int64_t)3;
+    return off;
+}
+int add_dnn(mamdr_graph* g, const std::string& name, int in_dim, const int32_t* hidden, int n_hidden, uint32_t& next_id) {
+    Dnn d;
+    d.name = name;
+    d.in_dim = in_dim;
+    int in = in_dim;
+    for (int l = 0; l < n_hidden; ++l) {
+        Layer L;
+        L.in = in;
+        L.out = hidden[l];
+        L.w_off = add_tensor(g, name + "/W" + std::to_string(l), in, hidden[l]);
+        L.b_off = add_tensor(g, name + "/b" + std::to_string(l), 1, hidden[l]);
+        L.id = next_id++;
+        d.layers.push_back(L);
+        in = hidden[l];
+    }
+    g->dnns.push_back(d);
+    return (int)g->dnns.size() - 1;
+}
+
+void launch_gemm(int mode, const GemmArgs& a, int M, int N, hipStream_t s) {
+    const dim3 grid(N / GT, M / GT), block(256);
+    if (mode == 0) hipLaunchKernelGGL(k_graph_gemm<0>, grid, block, 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(k_graph_gemm<1>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_graph_gemm<2>, grid, block, 0, s, a);
+}
+
+struct StepCtx {
+    int rows, rp;               // rows of the batch, padded to 64
+    bool train;
+    uint32_t seed, step, drop_thresh;
+    float keep_scale;
+    bool use_dropout;
+};
+
+// forward of one DNN: input columns `in_col` (width in_dim) of the activation workspace
+void dnn_forward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, int in_col, const StepCtx& sc) {
+    int src = in_col;
+    for (size_t l = 0; l < d.layers.size(); ++l) {
+        const Layer& L = d.layers[l];
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.A = g->act + src;
+        a.lda = g->ld;
+        a.B = g->params + L.w_off;
+        a.ldb = L.out;
+        a.C = g->act + cols[l];
+        a.ldc = g->ld;
+        a.K = L.in;
+        a.bias = g->params + L.b_off;
+        a.relu = 1;
+        a.use_dropout = sc.use_dropout ? 1 : 0;
+        a.drop_key = dropout_layer_key(sc.seed, sc.step, L.id);
+        a.drop_thresh = sc.drop_thresh;
+        a.keep_scale = sc.keep_scale;
+        a.n_cols = L.out;
+        launch_gemm(0, a, sc.rp, L.out, g->stream);
+        src = cols[l];
+    }
+}
+// backward of one DNN whose last layer's d z already sits in the gradient workspace.  The input's gradient goes to
+// `din_col` of the gradient workspace: times the gate of `in_gate_col` (the producer's relu / dropout) when >= 0;
+// accumulated when `din_acc`; only columns [din_first, din_first + din_n) of the input when din_n > 0 (first layers
+// on x: the domain columns alone matter while the tables are frozen); skipped when din_col < 0.
+void dnn_backward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, int in_col, int din_col, int in_gate_col,
+                  bool din_acc, int din_first, int din_n, const StepCtx& sc) {
+    for (int l = (int)d.layers.size() - 1; l >= 0; --l) {
+        const Layer& L = d.layers[l];
+        const int src = l == 0 ? in_col : cols[l - 1];
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.A = g->act + src;             // dW = in^T dz
+        a.lda = g->ld;
+        a.B = g->dact + cols[l];
+        a.ldb = g->ld;
+        a.C = g->grad + L.w_off;
+        a.ldc = L.out;
+        a.K = sc.rp;
+        launch_gemm(2, a, L.in, L.out, g->stream);
+        hipLaunchKernelGGL(k_graph_colsum, dim3(L.out / 64), dim3(256), 0, g->stream, g->dact + cols[l], g->ld, sc.rp,
+                           g->grad + L.b_off);
+        memset(&a, 0, sizeof(a));
+        a.A = g->dact + cols[l];        // d in = dz W^T
+        a.lda = g->ld;
+        a.K = L.out;
+        a.gate_scale = sc.keep_scale;
+        if (l > 0) {
+            a.B = g->params + L.w_off;
+            a.ldb = L.out;
+            a.C = g->dact + cols[l - 1];
+            a.ldc = g->ld;
+            a.gate_y = g->act + cols[l - 1];
+            a.gate_ld = g->ld;
+            launch_gemm(1, a, sc.rp, L.in, g->stream);
+        } else if (din_col >= 0) {
+            const int first = din_n > 0 ? din_first : 0, n = din_n > 0 ? din_n : L.in;
+            a.B = g->params + L.w_off + (size_t)first * L.out;
+            a.ldb = L.out;
+            a.C = g->dact + din_col + first;
+            a.ldc = g->ld;
+            if (in_gate_col >= 0) {
+                a.gate_y = g->act + in_gate_col + first;
+                a.gate_ld = g->ld;
+            }
+            a.accumulate = din_acc ? 1 : 0;
+            launch_gemm(1, a, sc.rp, n, g->stream);
+        }
+    }
+}
+
+void fill_gate(const mamdr_graph* g, const Task& t, const StepCtx& sc, GateArgs& ga) {
+    memset(&ga, 0, sizeof(ga));
+    ga.act = g->act;
+    ga.dact = g->dact;
+    ga.ld = g->ld;
+    const size_t gi = t.mix.size();                 // position of the gate DNN in `path`
+    const Dnn& gd = g->dnns[t.gate];
+    ga.q_col = t.col[gi].back();
+    ga.n_q = gd.layers.back().out;
+    ga.wg = g->params + t.wg_off;
+    ga.n_e = (int)t.mix.size();
+    for (size_t e = 0; e < t.mix.size(); ++e) ga.e_col[e] = t.col[e].back();
+    ga.n_h = g->n_h;
+    ga.g_col = t.g_col;
+    ga.m_col = t.m_col;
+    ga.rows_pad = sc.rp;
+    ga.gate_scale = sc.keep_scale;
+}
+
+// forward of task d on the gathered batch; -> column of the tower's output
+int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
+    for (size_t e = 0; e < t.mix.size(); ++e) dnn_forward(g, g->dnns[t.mix[e]], t.col[e], 0, sc);
+    int tower_in;
+    if (g->gated) {
+        const size_t gi = t.mix.size();
+        dnn_forward(g, g->dnns[t.gate], t.col[gi], 0, sc);
+        GateArgs ga;
+        fill_gate(g, t, sc, ga);
+        hipLaunchKernelGGL(k_graph_gate_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
+        tower_in = t.m_col;
+    } else {
+        tower_in = t.col[0].back();
+    }
+    const size_t ti = t.path.size() - 1;
+    dnn_forward(g, g->dnns[t.tower], t.col[ti], tower_in, sc);
+    return t.col[ti].back();
+}
+
+int check(const mamdr_graph* g) {
+    if (!g) return gfail(MAMDR_EINVAL, "null graph context");
+    return MAMDR_OK;
+}
+int ready(const mamdr_graph* g) {
+    if (!g->params) return gfail(MAMDR_ESTATE, "mamdr_graph_bind_state has not been called");
+    if (!g->user_tab || !g->item_tab) return gfail(MAMDR_ESTATE, "frozen user / item tables are not bound");
+    return MAMDR_OK;
+}
+SplitData* split_of(mamdr_graph* g, int domain, int split) {
+    if (domain < 0 || domain >= g->cfg.n_domain || split < 0 || split > 2) return nullptr;
+    return &g->data[(size_t)domain * 3 + split];
+}
+void fill_gather(const mamdr_graph* g, const SplitData& d, const int32_t* perm, int64_t row_base, const StepCtx& sc,
+                 GatherArgs& ga) {
+    memset(&ga, 0, sizeof(ga));
+    ga.user_tab = g->user_tab;
+    ga.item_tab = g->item_tab;
+    ga.dm = g->params + g->dm_off;
+    ga.uid = d.uid;
+    ga.pid = d.pid;
+    ga.dom = d.dom;
+    ga.perm = perm;
+    ga.label = d.label;
+    ga.row_base = row_base;
+    ga.n_rows_split = d.n;
+    ga.rows = sc.rows;
+    ga.rows_pad = sc.rp;
+    ga.n_user = g->cfg.n_user;
+    ga.n_item = g->cfg.n_item;
+    ga.n_domain = g->cfg.n_domain;
+    ga.x = g->act;
+    ga.ld = g->ld;
+    ga.domrow = g->domrow;
+    ga.y = g->y;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mamdr_graph_last_error(void) { return g_gerr; }
+
+int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph** out) {
+    if (!cfg || !out) return gfail(MAMDR_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != MAMDR_ABI_VERSION) return gfail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
+    if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
+    if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");
+    if (cfg->emb_trainable)
+        return gfail(MAMDR_ENOTBUILT, "the generic-layer towers run with frozen user / item tables only (every Taobao config of "
+                                      "shared_bottom / mmoe / ple; the Amazon configs train their tables: not built)");
+    if (cfg->kind != MAMDR_GRAPH_SHARED_BOTTOM && cfg->kind != MAMDR_GRAPH_MMOE && cfg->kind != MAMDR_GRAPH_PLE)
+        return gfail(MAMDR_EINVAL, "unknown graph tower kind %d", cfg->kind);
+    if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return gfail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
+    const bool gated = cfg->kind != MAMDR_GRAPH_SHARED_BOTTOM;
+    if (cfg->n_expert_hidden < 1 || cfg->n_expert_hidden > 4 || cfg->n_tower_hidden < 1 || cfg->n_tower_hidden > 4 ||
+        (gated && (cfg->n_gate_hidden < 1 || cfg->n_gate_hidden > 4)))
+        return gfail(MAMDR_EINVAL, "hidden_dim / tower_hidden_dim%s need 1..4 layers", gated ? " / gate_dnn_hidden_units" : "");
+    auto widths_ok = [](const int32_t* h, int n) {
+        for (int i = 0; i < n; ++i)
+            if (h[i] <= 0 || h[i] % 64) return false;
+        return true;
+    };
+    if (!widths_ok(cfg->expert_hidden, cfg->n_expert_hidden) || !widths_ok(cfg->tower_hidden, cfg->n_tower_hidden) ||
+        (gated && !widths_ok(cfg->gate_hidden, cfg->n_gate_hidden)))
+        return gfail(MAMDR_EINVAL, "layer widths must be multiples of 64 (the reference's configs use 64 ... 512)");
+    int n_shared = 1, n_specific = 0;
+    if (cfg->kind == MAMDR_GRAPH_MMOE) n_shared = cfg->num_experts;
+    if (cfg->kind == MAMDR_GRAPH_PLE) { n_shared = cfg->shared_expert_num; n_specific = cfg->specific_expert_num; }
+    if (n_shared < 0 || n_specific < 0 || n_shared + n_specific < 1 || n_shared + n_specific > MAX_MIX)
+        return gfail(MAMDR_EINVAL, "a task must mix 1..%d experts", MAX_MIX);
+
+    mamdr_graph* g = new (std::nothrow) mamdr_graph();
+    if (!g) return gfail(MAMDR_EHIP, "out of host memory");
+    g->cfg = *cfg;
+    g->stream = (hipStream_t)stream;
+    g->gated = gated;
+    g->n_h = cfg->expert_hidden[cfg->n_expert_hidden - 1];
+    g->data.resize((size_t)cfg->n_domain * 3);
+    // ---- flat vector: the block every task's model trains, then one block per task (oracle/mtl.py Spec.tensors)
+    uint32_t next_id = 0;
+    g->dm_off = add_tensor(g, "domain_emb", cfg->n_domain, EMB);
+    std::vector<int> shared;
+    for (int e = 0; e < n_shared; ++e) {
+        const std::string nm = cfg->kind == MAMDR_GRAPH_SHARED_BOTTOM ? "bottom"
+                               : (cfg->kind == MAMDR_GRAPH_MMOE ? "expert_" + std::to_string(e) : "shared_expert_" + std::to_string(e));
+        shared.push_back(add_dnn(g, nm, XDIM, cfg->expert_hidden, cfg->n_expert_hidden, next_id));
+    }
+    g->shared_end = g->n_params;
+    g->tasks.resize(cfg->n_domain);
+    int max_cols = 0;
+    for (int d = 0; d < cfg->n_domain; ++d) {
+        Task& t = g->tasks[d];
+        t.blk_off = g->n_params;
+        for (int e = 0; e < n_specific; ++e)
+            t.mix.push_back(add_dnn(g, "task_" + std::to_string(d) + "_expert_" + std::to_string(e), XDIM, cfg->expert_hidden,
+                                    cfg->n_expert_hidden, next_id));
+        for (int s : shared) t.mix.push_back(s);
+        if (gated) {
+            t.gate = add_dnn(g, "gate_" + std::to_string(d), XDIM, cfg->gate_hidden, cfg->n_gate_hidden, next_id);
+            t.wg_off = add_tensor(g, "gate_" + std::to_string(d) + "/Wg", cfg->gate_hidden[cfg->n_gate_hidden - 1], (int64_t)t.mix.size());
+        }
+        t.tower = add_dnn(g, "tower_" + std::to_string(d), g->n_h, cfg->tower_hidden, cfg->n_tower_hidden, next_id);
+        t.head_w = add_tensor(g, "head_" + std::to_string(d) + "/w", cfg->tower_hidden[cfg->n_tower_hidden - 1], 1);
+        t.head_gb = add_tensor(g, "head_" + std::to_string(d) + "/gb", 1, 1);
+        t.blk_end = g->n_params;
+        // column plan: x | every layer output on the path | gate probabilities | mixture
+        int c = XDIM;
+        t.path = t.mix;
+        if (gated) t.path.push_back(t.gate);
+        t.path.push_back(t.tower);
+        for (int di : t.path) {
+            std::vector<int> cols;
+            for (const Layer& L : g->dnns[di].layers) { cols.push_back(c); c += L.out; }
+            t.col.push_back(cols);
+        }
+        if (gated) {
+            t.g_col = c; c += ((int)t.mix.size() + 3) & ~3;
+            t.m_col = c; c += g->n_h;
+        }
+        t.n_cols = c;
+        if (c > max_cols) max_cols = c;
+    }
+    g->ld = (max_cols + 3) & ~3;
+    g->rows_pad_max = (cfg->max_batch + GT - 1) / GT * GT;
+    float thr[500];
+    thr[0] = (float)(0.0 - 1e-7);
+    for (int i = 0; i < 498; ++i) thr[i + 1] = (float)((double)(i + 1) * 1.0 / (double)(500 - 1));
+    thr[499] = (float)(1.0 + 1e-7);
+    const size_t rp = (size_t)g->rows_pad_max;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc((void**)&g->act, rp * g->ld * sizeof(float));
+    alloc((void**)&g->dact, rp * g->ld * sizeof(float));
+    alloc((void**)&g->grad, (size_t)g->n_params * sizeof(float));
+    alloc((void**)&g->dlogit, rp * sizeof(float));
+    alloc((void**)&g->rowloss, rp * sizeof(float));
+    alloc((void**)&g->y, rp * sizeof(float));
+    alloc((void**)&g->domrow, rp * sizeof(int32_t));
+    alloc((void**)&g->thresholds, sizeof(thr));
+    alloc((void**)&g->frozen_sumsq, 4 * sizeof(float));
+    alloc((void**)&g->sumsq_partials, 1024 * sizeof(float));
+    alloc((void**)&g->eval_acc, 4 * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(g->grad, 0, (size_t)g->n_params * sizeof(float), g->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->dact, 0, rp * g->ld * sizeof(float), g->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->frozen_sumsq, 0, 4 * sizeof(float), g->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->thresholds, thr, sizeof(thr), hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) {
+        mamdr_graph_destroy(g);
+        return gfail(MAMDR_EHIP, "workspace: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return MAMDR_OK;
+}
+
+int mamdr_graph_destroy(mamdr_graph* g) {
+    if (!g) return MAMDR_OK;
+    (void)hipStreamSynchronize(g->stream);
+    void* ptrs[] = {g->act, g->dact, g->grad, g->dlogit, g->rowloss, g->y, g->domrow, g->thresholds, g->frozen_sumsq,
+                    g->sumsq_partials, g->eval_acc};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+    return MAMDR_OK;
+}
+
+int64_t mamdr_graph_param_count(const mamdr_graph* g) { return g ? g->n_params : 0; }
+int32_t mamdr_graph_tensor_count(const mamdr_graph* g) { return g ? (int32_t)g->tensors.size() : 0; }
+int mamdr_graph_tensor_info(const mamdr_graph* g, int32_t i, char* name, int32_t name_cap, int64_t* offset, int64_t* rows,
+                            int64_t* cols) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (i < 0 || i >= (int32_t)g->tensors.size() || !name || name_cap < 2 || !offset || !rows || !cols)
+        return gfail(MAMDR_EINVAL, "bad tensor query");
+    const TensorInfo& t = g->tensors[i];
+    snprintf(name, (size_t)name_cap, "%s", t.name.c_str());
+    *offset = t.off;
+    *rows = t.rows;
+    *cols = t.cols;
+    return MAMDR_OK;
+}
+/* the two ranges of the flat vector a step of task `domain` trains */
+int mamdr_graph_task_ranges(const mamdr_graph* g, int domain, int64_t* shared_off, int64_t* shared_count, int64_t* task_off,
+                            int64_t* task_count) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (domain < 0 || domain >= g->cfg.n_domain) return gfail(MAMDR_EINVAL, "domain out of range");
+    *shared_off = g->dm_off;
+    *shared_count = g->shared_end - g->dm_off;
+    *task_off = g->tasks[domain].blk_off;
+    *task_count = g->tasks[domain].blk_end - g->tasks[domain].blk_off;
+    return MAMDR_OK;
+}
+
+int mamdr_graph_bind_state(mamdr_graph* g, float* d_params, float* d_m, float* d_v) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (!d_params || !d_m || !d_v) return gfail(MAMDR_EINVAL, "null state pointer");
+    if (((uintptr_t)d_params | (uintptr_t)d_m | (uintptr_t)d_v) & 15) return gfail(MAMDR_EINVAL, "state pointers must be 16-byte aligned");
+    g->params = d_params;
+    g->adam_m = d_m;
+    g->adam_v = d_v;
+    return MAMDR_OK;
+}
+int mamdr_graph_optimizer_reset(mamdr_graph* g) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (!g->params) return gfail(MAMDR_ESTATE, "state not bound");
+    GHIP(hipMemsetAsync(g->adam_m, 0, (size_t)g->n_params * sizeof(float), g->stream));
+    GHIP(hipMemsetAsync(g->adam_v, 0, (size_t)g->n_params * sizeof(float), g->stream));
+    g->adam_t = 0;
+    g->b1p = g->b2p = 1.f;
+    return MAMDR_OK;
+}
+int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g) { return g ? g->adam_t : 0; }
+int64_t mamdr_graph_dropout_steps(const mamdr_graph* g) { return g ? (int64_t)g->global_step : 0; }
+
+int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t n_rows) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (!d_rows || ((uintptr_t)d_rows & 15)) return gfail(MAMDR_EINVAL, "table pointer null or not 16-byte aligned");
+    if (seg == MAMDR_SEG_USER_EMB) {
+        if (n_rows != g->cfg.n_user) return gfail(MAMDR_EINVAL, "user table has %lld rows, config says %d", (long long)n_rows, g->cfg.n_user);
+        g->user_tab = d_rows;
+        launch_sumsq(d_rows, n_rows * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
+    } else if (seg == MAMDR_SEG_ITEM_EMB) {
+        if (n_rows != g->cfg.n_item) return gfail(MAMDR_EINVAL, "item table has %lld rows, config says %d", (long long)n_rows, g->cfg.n_item);
+        g->item_tab = d_rows;
+        launch_sumsq(d_rows, n_rows * EMB, g->sumsq_partials, g->frozen_sumsq + 1, g->stream);
+    } else {
+        return gfail(MAMDR_EINVAL, "segment %d is not a bindable table", seg);
+    }
+    GHIP(hipGetLastError());
+    return MAMDR_OK;
+}
+
+int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const int32_t* d_uid, const int32_t* d_pid,
+                                 const int32_t* d_domain, const float* d_label, int64_t n_rows) {
+    if (check(g)) return MAMDR_EINVAL;
+    SplitData* d = split_of(g, domain, split);
+    if (!d) return gfail(MAMDR_EINVAL, "domain %d / split %d out of range", domain, split);
+    if (n_rows < 0 || n_rows > 0x7fffffff) return gfail(MAMDR_EINVAL, "n_rows out of range");
+    if (n_rows > 0 && (!d_uid || !d_pid || !d_domain || !d_label)) return gfail(MAMDR_EINVAL, "null column pointer");
+    d->uid = d_uid;
+    d->pid = d_pid;
+    d->dom = d_domain;
+    d->label = d_label;
+    d->n = n_rows;
+    return MAMDR_OK;
+}
+
+int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, int64_t first_step, int64_t n_steps,
+                            int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr, float* d_loss_out) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (ready(g)) return MAMDR_ESTATE;
+    SplitData* d = split_of(g, domain, MAMDR_SPLIT_TRAIN);
+    if (!d || !d->uid) return gfail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
+    if (batch <= 0 || batch > g->cfg.max_batch) return gfail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, g->cfg.max_batch);
+    if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD) return gfail(MAMDR_EINVAL, "optimizer %d not supported here", optimizer);
+    if (first_step < 0 || n_steps < 0) return gfail(MAMDR_EINVAL, "negative step range");
+    const int64_t pass_steps = (d->n + batch - 1) / batch;
+    if (first_step + n_steps > pass_steps)
+        return gfail(MAMDR_EINVAL, "steps [%lld,%lld) exceed the %lld batches of domain %d", (long long)first_step,
+                     (long long)(first_step + n_steps), (long long)pass_steps, domain);
+    const Task& t = g->tasks[domain];
+    const float rate = g->cfg.dropout;
+    double thr = (double)rate * 4294967296.0;
+    const float omb1 = 1.0f - g->cfg.adam_beta1, omb2 = 1.0f - g->cfg.adam_beta2;
+    for (int64_t s = 0; s < n_steps; ++s) {
+        const int64_t row_base = (first_step + s) * batch;
+        StepCtx sc;
+        sc.rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
+        sc.rp = (sc.rows + GT - 1) / GT * GT;
+        sc.train = true;
+        sc.seed = dropout_seed;
+        sc.step = g->global_step;
+        sc.drop_thresh = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(int64_t)thr;
+        sc.keep_scale = (float)(1.0 / (1.0 - (double)rate));
+        sc.use_dropout = rate > 0.f;
+        if (!sc.use_dropout) sc.keep_scale = 1.0f;
+        float alpha = lr;
+        if (optimizer == MAMDR_OPT_ADAM) {      // ONE optimizer object for all domain models: its beta powers advance every step
+            g->adam_t += 1;
+            g->b1p *= g->cfg.adam_beta1;
+            g->b2p *= g->cfg.adam_beta2;
+            alpha = lr * sqrtf(1.0f - g->b2p) / (1.0f - g->b1p);
+        }
+        GatherArgs ga;
+        fill_gather(g, *d, d_perm, row_base, sc, ga);
+        hipLaunchKernelGGL(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
+        const int t_col = task_forward(g, t, sc);
+        const Dnn& tower = g->dnns[t.tower];
+        HeadArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.act = g->act;
+        ha.dact = g->dact;
+        ha.ld = g->ld;
+        ha.t_col = t_col;
+        ha.n_t = tower.layers.back().out;
+        ha.w = g->params + t.head_w;
+        ha.gb = g->params + t.head_gb;
+        ha.y = g->y;
+        ha.rows = sc.rows;
+        ha.rows_pad = sc.rp;
+        ha.dlogit = g->dlogit;
+        ha.rowloss = g->rowloss;
+        ha.train = 1;
+        ha.gate_scale = sc.keep_scale;
+        hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
+        if (d_loss_out)
+            hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
+                               g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out + s, 0);
+        // ---- backward
+        // head: dw = t^T dlogit, dgb = sum dlogit
+        hipLaunchKernelGGL(k_graph_small_tn, dim3((ha.n_t + 255) / 256), dim3(256), 0, g->stream, g->act + t_col, g->ld, g->dlogit, 1,
+                           sc.rp, ha.n_t, 1, g->grad + t.head_w);
+        hipLaunchKernelGGL(k_graph_sum1, dim3(1), dim3(256), 0, g->stream, g->dlogit, sc.rp, g->grad + t.head_gb);
+        const size_t ti = t.path.size() - 1;
+        // the x columns of the gradient workspace collect d x (domain columns) from every first layer: cleared by the first
+        bool dx_started = false;
+        if (g->gated) {
+            dnn_backward(g, tower, t.col[ti], t.m_col, t.m_col, -1, false, 0, 0, sc);
+            GateArgs gta;
+            fill_gate(g, t, sc, gta);
+            hipLaunchKernelGGL(k_graph_gate_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, gta);
+            const size_t gi = t.mix.size();
+            const Dnn& gd = g->dnns[t.gate];
+            hipLaunchKernelGGL(k_graph_small_tn, dim3((gta.n_q * gta.n_e + 255) / 256), dim3(256), 0, g->stream, g->act + gta.q_col,
+                               g->ld, g->dact + t.g_col, g->ld, sc.rp, gta.n_q, gta.n_e, g->grad + t.wg_off);
+            dnn_backward(g, gd, t.col[gi], 0, 0, -1, dx_started, 2 * EMB, EMB, sc);
+            dx_started = true;
+            for (size_t e = 0; e < t.mix.size(); ++e) {
+                dnn_backward(g, g->dnns[t.mix[e]], t.col[e], 0, 0, -1, dx_started, 2 * EMB, EMB, sc);
+                dx_started = true;
+            }
+        } else {
+            // the tower's input IS the bottom's output: its gradient passes through the bottom's last relu / dropout gate
+            dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
+            dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, 2 * EMB, EMB, sc);
+        }
+        hipLaunchKernelGGL(k_graph_domain_grad, dim3(g->cfg.n_domain), dim3(EMB), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
+                           sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->grad + g->dm_off);
+        // ---- optimiser on the two ranges this task's model trains
+        const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
+        for (int k = 0; k < 2; ++k) {
+            AdamArgs aa;
+            aa.p = g->params + off[k];
+            aa.m = g->adam_m + off[k];
+            aa.v = g->adam_v + off[k];
+            aa.g = g->grad + off[k];
+            aa.n4 = cnt[k] / 4;
+            aa.optimizer = optimizer;
+            aa.alpha = alpha;
+            aa.omb1 = omb1;
+            aa.omb2 = omb2;
+            aa.eps = g->cfg.adam_eps;
+            hipLaunchKernelGGL(k_graph_adam, dim3((unsigned)((aa.n4 + 255) / 256)), dim3(256), 0, g->stream, aa);
+        }
+        g->global_step += 1;
+    }
+    GHIP(hipGetLastError());
+    return MAMDR_OK;
+}
+
+int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch, float* d_loss_out, uint32_t* d_hist,
+                            float* d_pred_out) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (ready(g)) return MAMDR_ESTATE;
+    SplitData* d = split_of(g, domain, split);
+    if (!d || !d->uid) return gfail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
+    if (batch <= 0 || batch > g->cfg.max_batch) return gfail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, g->cfg.max_batch);
+    if (!d_loss_out || !d_hist) return gfail(MAMDR_EINVAL, "null output pointer");
+    if (d->n <= 0) return gfail(MAMDR_EINVAL, "empty split");
+    const Task& t = g->tasks[domain];
+    GHIP(hipMemsetAsync(d_hist, 0, 2 * 501 * sizeof(uint32_t), g->stream));
+    GHIP(hipMemsetAsync(g->eval_acc, 0, sizeof(float), g->stream));
+    const int64_t n_batches = (d->n + batch - 1) / batch;
+    for (int64_t b = 0; b < n_batches; ++b) {
+        StepCtx sc;
+        memset(&sc, 0, sizeof(sc));
+        const int64_t row_base = b * batch;
+        sc.rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
+        sc.rp = (sc.rows + GT - 1) / GT * GT;
+        sc.keep_scale = 1.0f;
+        GatherArgs ga;
+        fill_gather(g, *d, nullptr, row_base, sc, ga);
+        hipLaunchKernelGGL(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
+        const int t_col = task_forward(g, t, sc);
+        HeadArgs ha;
+        memset(&ha, 0, sizeof(ha));
+        ha.act = g->act;
+        ha.dact = g->dact;
+        ha.ld = g->ld;
+        ha.t_col = t_col;
+        ha.n_t = g->dnns[t.tower].layers.back().out;
+        ha.w = g->params + t.head_w;
+        ha.gb = g->params + t.head_gb;
+        ha.y = g->y;
+        ha.rows = sc.rows;
+        ha.rows_pad = sc.rp;
+        ha.dlogit = g->dlogit;
+        ha.rowloss = g->rowloss;
+        ha.gate_scale = 1.0f;
+        ha.thresholds = g->thresholds;
+        ha.hist = d_hist;
+        ha.pred_out = d_pred_out ? d_pred_out + row_base : nullptr;
+        hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
+        hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
+                           g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, g->eval_acc, 1);
+    }
+    hipLaunchKernelGGL(k_graph_scale, dim3(1), dim3(1), 0, g->stream, g->eval_acc, 1.0f / (float)n_batches);
+    GHIP(hipMemcpyAsync(d_loss_out, g->eval_acc, sizeof(float), hipMemcpyDeviceToDevice, g->stream));
+    GHIP(hipGetLastError());
+    return MAMDR_OK;
+}
+
+}  // extern "C"

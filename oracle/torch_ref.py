@@ -95,6 +95,44 @@ def star_forward(P, state, uid, pid, dom, training):
     return torch.sigmoid(logit), mean.detach(), var.detach()
 
 
+def mtl_forward(P, spec, d, uid, pid, dom, masks, keep_scale):
+    """multi-task towers (deep_mtl_ctr.py:21-49; deepctr SharedBottom / MMOE / PLE with num_levels = 1), output of task d:
+    experts = DNN(hidden_dim) on x; MMOE / PLE: gate_d = softmax(DNN(gate_dnn_hidden_units)(x) . Wg_d) over the experts
+    the task mixes, mix = sum_e gate_e expert_e; tower_d = DNN(tower_hidden_dim); Dense(1, no bias) + global_bias_d ->
+    sigmoid.  Every DNN layer: Dense -> relu -> dropout.  `spec` = oracle/mtl.Spec (structure only)."""
+    x = torch.cat([_rows(P["user_emb"], uid), _rows(P["item_emb"], pid), _rows(P["domain_emb"], dom)], dim=1)
+
+    def dnn(name, hidden, h):
+        for l in range(len(hidden)):
+            h = torch.relu(torch.addmm(P["%s/b%d" % (name, l)], h, P["%s/W%d" % (name, l)]))
+            if masks is not None:
+                h = h * keep_scale * masks["%s/W%d" % (name, l)]
+        return h
+    outs = [dnn(e, spec.expert_hidden, x) for e in spec.mix(d)]
+    if spec.gated:
+        q = dnn("gate_%d" % d, spec.gate_hidden, x)
+        gate = torch.softmax(q @ P["gate_%d/Wg" % d], dim=1)
+        m = sum(gate[:, k:k + 1] * o for k, o in enumerate(outs))
+    else:
+        m = outs[0]
+    t = dnn("tower_%d" % d, spec.tower_hidden, m)
+    return torch.sigmoid((t @ P["head_%d/w" % d])[:, 0] + P["head_%d/gb" % d][0])
+
+
+def mtl_loss_and_grads(params, names, spec, d, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64):
+    """loss (mean Keras BCE + l2 on the three tables) of task d and its autograd gradients for `names`."""
+    P = _as_tensors(params, names, dtype, set(names))
+    ui, pi, di = (torch.from_numpy(np.asarray(a, np.int64)) for a in (uid, pid, dom))
+    y = torch.from_numpy(np.asarray(label, np.float32)).to(dtype)
+    m = {k: torch.from_numpy(np.asarray(v, np.float32)).to(dtype) for k, v in masks.items()} if masks is not None else None
+    keep = 1.0 / (1.0 - rate) if masks is not None else 1.0
+    p = mtl_forward(P, spec, d, ui, pi, di, m, keep)
+    loss = keras_bce(p, y).mean() + L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum())
+    grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
+    g = {n: (gr.numpy() if gr is not None else None) for n, gr in zip(names, grads)}
+    return float(loss.detach()), g, p.detach().numpy()
+
+
 def _as_tensors(params, names, dtype, trainable):
     out = {}
     for n, a in params.items():

@@ -159,3 +159,57 @@ def test_torch_cpu_model_follows_the_oracle():
     for n in names:
         diff = np.abs(cpu.P[n].detach().numpy() - model.params[n])
         assert np.mean(diff > 1.5e-4) < 2e-3 and diff.max() <= 6.1e-3, n
+
+
+# ------------------------------------------------------------------ multi-task towers (oracle/mtl.py)
+@pytest.mark.parametrize("kind,emb_trainable,rate", [
+    ("shared_bottom", False, 0.5), ("shared_bottom", True, 0.0), ("mmoe", False, 0.5), ("mmoe", True, 0.5),
+    ("ple", False, 0.5), ("ple", False, 0.0)])
+def test_mtl_towers_gradients_vs_float64_autograd(kind, emb_trainable, rate):
+    """oracle/mtl.py (deepctr SharedBottom / MMOE / PLE under deep_mtl_ctr.py's per-domain models): the hand-derived
+    gradients of task d -- experts, softmax gate and its DNN, tower, head, domain table, trainable tables with
+    repeated rows -- against float64 autograd of oracle/torch_ref.mtl_forward; tensors outside task d's model get no
+    gradient on either side."""
+    from oracle import mtl as omtl
+    rs = np.random.RandomState(23)
+    n_user, n_item, D, B = 60, 40, 4, 48
+    spec = omtl.Spec(kind, D, expert_hidden=(32, 16), tower_hidden=(8,), gate_hidden=(8,), num_experts=3,
+                     shared_expert_num=2, specific_expert_num=2, emb_dim=8)
+    p = omtl.init_params(rs, spec, n_user, n_item)
+    for n in p:
+        if "/b" in n or n.endswith("/gb") or n == "domain_emb":
+            p[n] = (rs.standard_normal(p[n].shape) * 0.05).astype(F32)
+    names = [n for n, _ in spec.tensors(emb_trainable, n_user, n_item)]
+    for d in (0, 2):
+        uid, pid, dom, label = _batch(rs, n_user, n_item, D, B)
+        masks = omtl.train_masks(spec, 1024, 5, B, rate) if rate > 0 else None
+        loss, g, pred = omtl.loss_and_grads(p, spec, d, uid, pid, dom, label, masks, rate, emb_trainable)
+        loss64, g64, pred64 = tref.mtl_loss_and_grads(p, names, spec, d, uid, pid, dom, label, masks, rate)
+        assert abs(float(loss) - loss64) < 2e-6 * max(1.0, abs(loss64))
+        np.testing.assert_allclose(pred, pred64, rtol=2e-5, atol=2e-7)
+        on_path = [n for n in names if g64[n] is not None]
+        assert sorted(on_path) == sorted(g), (sorted(set(on_path) ^ set(g)))
+        keep, owners = spec.task_tensors(d, emb_trainable)
+        assert all(n in keep or n.split("/")[0] in owners for n in on_path)
+        _check_grads(g, g64, on_path)
+
+
+def test_mtl_adam_shares_the_beta_powers_between_the_domain_models():
+    """ONE tf.train.AdamOptimizer for all D compiled models (deep_mtl_ctr.py:53-66): a step of any domain advances the
+    beta powers, only that domain's variables move; first step of a variable moves it by ~alpha_t (m / sqrt(v) = 1)."""
+    from oracle import mtl as omtl
+    rs = np.random.RandomState(4)
+    spec = omtl.Spec("mmoe", 3, (16,), (8,), (8,), num_experts=2, emb_dim=8)
+    p = omtl.init_params(rs, spec, 30, 20)
+    model = omtl.OracleMTL({k: v.copy() for k, v in p.items()}, spec, dropout=0.0, lr=1e-3)
+    uid, pid, dom, label = _batch(rs, 30, 20, 3, 32)
+    model.train_on_batch(0, uid, pid, dom, label)
+    assert np.array_equal(model.params["tower_1/W0"], p["tower_1/W0"]) and not np.array_equal(model.params["tower_0/W0"], p["tower_0/W0"])
+    model.train_on_batch(1, uid, pid, dom, label)
+    assert model.t == 2
+    # tower_1's first own step happens at t = 2: |dp| = alpha_2 * (0.1 g) / (sqrt(0.001 g^2) + eps) for every element with g != 0
+    a2 = 1e-3 * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    moved = np.abs(model.params["tower_1/W0"] - p["tower_1/W0"])
+    nz = moved > 0
+    want = a2 * 0.1 / np.sqrt(0.001)            # (elements with a gradient near eps = 1e-8 move a little less)
+    assert abs(np.median(moved[nz]) - want) < 2e-3 * want and moved.max() <= want * 1.002 and moved[nz].min() > 0.9 * want
