@@ -7,8 +7,8 @@ Dispatch is by substring of config.model.name, in the reference's order (run.py:
            reptile | mldg | <else> MAML)
   modes    'separate' -> per-domain training; otherwise train() + val_and_test("test");
            'finetune' -> load best + separate_train_val_test(init_parms=False)
-Entries outside the hot path stay in the registry and raise
-NotImplementedError naming why.
+Entries that are not built (deepctr nfm / autoint / ccpm / pnn, the multi-task towers with trainable tables) stay in
+the registry and raise NotImplementedError naming why.
 """
 import argparse
 import json
@@ -29,8 +29,8 @@ def build_model(config, dataset, engine_factory=None):
     elif in_name_list(name, DEEP_CTR_LIST):
         model = DeepCTR(dataset, config, engine_factory)
     elif in_name_list(name, MTL_DEEP_CTR_LIST):
-        raise NotImplementedError("DeepMTLCTR towers (shared_bottom / mmoe / ple) are comparison baselines "
-                                  "outside the hot path (SURVEY.md section 2.1 #15)")
+        from .model_zoo import DeepMTLCTR
+        model = DeepMTLCTR(dataset, config, engine_factory)
     else:
         raise ValueError("model: {} not found".format(name))
     if "uncertainty_weight" in name:

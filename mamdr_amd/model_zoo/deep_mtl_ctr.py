@@ -1,0 +1,130 @@
+"""DeepMTLCTR -- host-side mirror of model_zoo/DeepMTLCTR/deep_mtl_ctr.py (shared_bottom / mmoe / ple).
+
+`build_model` keeps the reference's substring registry (deep_mtl_ctr.py:25-49): one binary task per domain on deepctr's
+SharedBottom / MMOE / PLE, and, as the reference compiles `Model(inputs, outputs[d])` per domain on ONE shared Adam
+optimizer (:53-67), every step on domain d trains the variables on the path to output d only -- the multi-task engine
+(`GraphEngine`, csrc/graph_engine.hip) takes the domain with every call.  `train()` is the alternate loop of :69-96,
+`val_and_test` scores domain d with domain d's model (:189-222), `separate_train_val_test` restarts every domain from the
+same weights (:128-187: Adam-by-name when init_parms, plain SGD for the finetune stage, Keras EarlyStopping(val_AUC,
+min_delta=1e-4) + best-only checkpoint).  Initial tensors: deepctr's initialisers (glorot normal kernels, zero biases,
+N(0, 1e-4^2) domain table, pretrained constants for the user / item tables) from a numpy stream seeded with dataset.seed.
+"""
+import random
+
+import numpy as np
+
+from .base_model import BaseModel
+from .deepctr import glorot_normal
+
+KINDS = ("shared_bottom", "mmoe", "ple")
+
+
+def tensor_plan(kind, n_domain, emb_dim, expert_hidden, tower_hidden, gate_hidden, num_experts, shared_expert_num,
+                specific_expert_num):
+    """[(name, shape)] of every trainable tensor behind the tables, in the engine's flat-vector order."""
+    xdim = 3 * emb_dim
+
+    def dnn(name, in_dim, hidden):
+        out, i = [], in_dim
+        for l, h in enumerate(hidden):
+            out += [("%s/W%d" % (name, l), (i, h)), ("%s/b%d" % (name, l), (h,))]
+            i = h
+        return out
+    if kind == "shared_bottom":
+        shared, specific = ["bottom"], 0
+    elif kind == "mmoe":
+        shared, specific = ["expert_%d" % e for e in range(num_experts)], 0
+    else:
+        shared, specific = ["shared_expert_%d" % e for e in range(shared_expert_num)], specific_expert_num
+    t = [("domain_emb", (n_domain, emb_dim))]
+    for e in shared:
+        t += dnn(e, xdim, expert_hidden)
+    for d in range(n_domain):
+        for e in range(specific):
+            t += dnn("task_%d_expert_%d" % (d, e), xdim, expert_hidden)
+        if kind != "shared_bottom":
+            t += dnn("gate_%d" % d, xdim, gate_hidden)
+            t.append(("gate_%d/Wg" % d, (gate_hidden[-1], specific + len(shared))))
+        t += dnn("tower_%d" % d, expert_hidden[-1], tower_hidden)
+        t += [("head_%d/w" % d, (tower_hidden[-1], 1)), ("head_%d/gb" % d, (1,))]
+    return t
+
+
+def initial_tensors(rs, plan, emb_dim):
+    t = {}
+    for name, shape in plan:
+        if name == "domain_emb":
+            t[name] = (rs.standard_normal(shape) * 1e-4).astype(np.float32)        # deepctr SparseFeat default
+        elif len(shape) == 2:
+            t[name] = glorot_normal(rs, shape[0], shape[1], shape)                 # Dense kernels (DNN, gate, head)
+        else:
+            t[name] = np.zeros(shape, np.float32)                                  # biases, PredictionLayer global_bias
+    return t
+
+
+class DeepMTLCTR(BaseModel):
+    def __init__(self, dataset, config, engine_factory=None):
+        super(DeepMTLCTR, self).__init__(dataset, config, engine_factory)
+
+    def tower_kind(self):
+        name = self.model_config["name"]
+        for k in KINDS:                       # deep_mtl_ctr.py:25,31,39: substring tests in this order
+            if k in name:
+                return k
+        raise ValueError("model: {} not found".format(name))
+
+    def build_model(self):
+        kind = self.tower_kind()
+        mc, tc = self.model_config, self.train_config
+        if not (mc["user_dim"] == mc["item_dim"] == mc["domain_dim"]):
+            raise ValueError("user_dim, item_dim and domain_dim must be equal")
+        if kind == "ple" and mc.get("num_levels", 1) != 1:
+            raise NotImplementedError("ple with num_levels = %r: the reference's configs all use one level" % mc.get("num_levels"))
+        factory = self.engine_factory
+        if factory is None:
+            from ..graph_engine import GraphEngine
+            factory = GraphEngine
+        self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
+        gate = tuple(mc.get("gate_dnn_hidden_units", ())) if kind != "shared_bottom" else ()
+        shape = dict(expert_hidden=tuple(mc["hidden_dim"]), tower_hidden=tuple(mc["tower_hidden_dim"]), gate_hidden=gate,
+                     num_experts=int(mc.get("num_experts", 0)), shared_expert_num=int(mc.get("shared_expert_num", 0)),
+                     specific_expert_num=int(mc.get("specific_expert_num", 0)))
+        eng = factory(kind, self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
+                      emb_trainable=self.tables_trainable, emb_dim=mc["user_dim"], **shape)
+        self.init_rs = np.random.RandomState(self.dataset.seed)
+        pre = bool(tc["load_pretrain_emb"])
+        if pre and self.dataset.user_emb is None:
+            raise ValueError("load_pretrain_emb is set but the dataset has no pretrained tables")
+        self.plan = tensor_plan(kind, self.n_domain, mc["user_dim"], **shape)
+        tensors = initial_tensors(self.init_rs, self.plan, mc["user_dim"])
+        eng.bind_table("user_emb", self.dataset.user_emb)
+        eng.bind_table("item_emb", self.dataset.item_emb)
+        for split, store in (("train", self.dataset.train_dataset), ("val", self.dataset.val_dataset),
+                             ("test", self.dataset.test_dataset)):
+            for d, v in store.items():
+                c = v["data"]
+                eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
+        eng.set_weights(eng.pack(tensors))
+        if tc["optimizer"] != "adam":
+            raise NotImplementedError("optimizer '%s': the reference configs all use adam (deep_mtl_ctr.py:53-56)" % tc["optimizer"])
+        if tc["loss"] != "binary_crossentropy":
+            raise NotImplementedError("loss '%s': only binary_crossentropy is built" % tc["loss"])
+        return eng
+
+    def train(self):
+        """deep_mtl_ctr.py:69-96: per epoch one full pass per domain through that domain's model, shuffled order."""
+        self.model.optimizer_reset()
+        train_sequence = list(range(self.n_domain))
+        rng = random.Random(self.dataset.seed)
+        for epoch in range(self.train_config["epoch"]):
+            print("Epoch: {}".format(epoch), "-" * 30)
+            rng.shuffle(train_sequence)
+            for idx in train_sequence:
+                print("Train on: Domain {}".format(idx))
+                self.fit_domain(idx, phase="alt")
+            print("Val Result: ")
+            avg_loss, avg_auc, domain_loss, domain_auc = self.val_and_test("val")
+            if self.early_stop_step(avg_auc):
+                break
+            print("Test Result: ")
+            self.val_and_test("test")

@@ -98,7 +98,8 @@ def test_one_step_gradients_match_oracle(kind, dropout):
                 if name in grads:
                     want = grads[name].ravel()
                     scale = max(np.abs(want).max(), 1e-3)
-                    np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=2e-6 * scale, err_msg=name)
+                    # (the gradient is read back as w0 - (w0 - g): quantised to the weights' ulp, 7.5e-9 at |w| ~ 0.1)
+                    np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * scale, 1.5e-8), err_msg=name)
                 else:                         # not on task d's path: untouched, bit for bit
                     off, cnt = eng.segments[name]
                     assert np.array_equal(after[off:off + cnt], w0.cpu().numpy()[off:off + cnt]), name
@@ -120,7 +121,7 @@ def test_mixed_domain_ids_in_one_batch():
     eng.train_steps(d, first_step=0, n_steps=1, lr=1.0, optimizer="sgd")
     got = eng.unpack(w0 - eng.get_weights())
     want = grads["domain_emb"].ravel()
-    np.testing.assert_allclose(got["domain_emb"], want, rtol=2e-4, atol=2e-6 * np.abs(want).max())
+    np.testing.assert_allclose(got["domain_emb"], want, rtol=2e-4, atol=max(2e-6 * np.abs(want).max(), 1.5e-8))
     eng.close()
 
 

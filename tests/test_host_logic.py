@@ -538,3 +538,47 @@ def test_synthetic_shapes_match_table_one():
         assert set(np.unique(c["label"])) <= {0.0, 1.0} and np.all(c["domain"] == d)
         r = g["info"][d]["ctr_ratio"]
         assert 0.2 <= r <= 0.5
+
+
+# ------------------------------------------------------------------ multi-task baselines (deep_mtl_ctr.py)
+@pytest.mark.parametrize("name,extra", [
+    ("shared_bottom", {}),
+    ("mmoe", {"num_experts": 2, "gate_dnn_hidden_units": [4]}),
+    ("ple", {"shared_expert_num": 1, "specific_expert_num": 2, "gate_dnn_hidden_units": [4], "num_levels": 1}),
+])
+def test_mtl_towers_run_entry(tmp_path, monkeypatch, name, extra):
+    """run.py's entry for the multi-task names (run.py:44-45 -> DeepMTLCTR): alternate training through the
+    per-domain models (deep_mtl_ctr.py:69-96), per-domain evaluation, early stopping, result files; the engine sees
+    the domain with every pass and trains that task's variables only."""
+    from fake_engine import FakeGraphEngine
+    from mamdr_amd.model_zoo import DeepMTLCTR
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, name, epochs=2)
+    cfg["model"].update(hidden_dim=[16, 8], tower_hidden_dim=[4], **extra)
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    model = cli.build_model(cfg, ds, FakeGraphEngine)
+    assert type(model) is DeepMTLCTR and model.model.kind == name
+    # the initial tensors cover the engine's flat vector exactly, in its order
+    assert [n for n, _ in model.plan] == list(model.model.segments)
+    before = model.model.get_weights().numpy().copy()
+    avg_loss, avg_auc, dl, da = cli.main(cfg, FakeGraphEngine)
+    assert sorted(da) == [0, 1, 2] and np.isfinite(avg_loss) and 0.3 < avg_auc < 1.0
+    res = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path / "result")) for f in fs if f == "result.json"]
+    assert len(res) == 1 and json.load(open(res[0]))["avg_auc"] == avg_auc
+    # every pass named its domain; each epoch covers every domain once
+    model.train()
+    doms = [c[0] for c in model.model.calls]
+    assert sorted(doms[:3]) == [0, 1, 2]
+    after = model.model.get_weights().numpy()
+    assert not np.array_equal(before, after)
+
+
+def test_mtl_ple_levels_and_trainable_tables_are_named(tmp_path, monkeypatch):
+    from fake_engine import FakeGraphEngine
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "ple", epochs=1)
+    cfg["model"].update(hidden_dim=[16], tower_hidden_dim=[4], shared_expert_num=1, specific_expert_num=1,
+                        gate_dnn_hidden_units=[4], num_levels=2)
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    with pytest.raises(NotImplementedError, match="num_levels"):
+        cli.build_model(cfg, ds, FakeGraphEngine)

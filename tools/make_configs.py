@@ -4,8 +4,10 @@ The reference ships one directory of JSON files per dataset split (config/{Taoba
 Amazon_13}): the files of a split differ from the Taobao-10 ones only in the dataset section (name, paths), in
 `train.sample_num`, and -- for Amazon, which has no pretrained embeddings -- in `load_pretrain_emb: false,
 emb_trainable: true`.  This script writes those variants for the towers built here (mlp, star; the plain,
-Domain Negotiation and MAMDR entries), keeping every other value of the templates.  mmoe / ple / shared_bottom
-configurations are not written: those towers are not built (mamdr_amd/cli.py raises for them).
+Domain Negotiation and MAMDR entries), keeping every other value of the templates.  The multi-task baselines
+(shared_bottom / mmoe / ple) get their per-split hyperparameters from the table MTL below (the values of the
+reference's config/*/{shared_bottom,mmoe,ple}.json: layer widths, expert counts, learning rate); the Amazon ones
+train their tables, which the generic-layer engine does not build yet (it says so when run).
 
 usage: python tools/make_configs.py    (idempotent; writes under config/)"""
 import copy
@@ -40,8 +42,59 @@ FILES = {
 }
 
 
+# multi-task baselines: split -> file -> (model overrides, learning rate)
+MTL = {
+    "Taobao-10": {"shared_bottom": (dict(hidden_dim=[512, 256, 128], tower_hidden_dim=[64]), 1e-4),
+                  "mmoe": (dict(hidden_dim=[512, 256, 128], tower_hidden_dim=[64], num_experts=2, gate_dnn_hidden_units=[64]), 1e-4),
+                  "ple": (dict(hidden_dim=[256], tower_hidden_dim=[64], specific_expert_num=10, shared_expert_num=2,
+                               gate_dnn_hidden_units=[64], num_levels=1), 1e-4)},
+    "Taobao_20": {"shared_bottom": (dict(hidden_dim=[512, 256], tower_hidden_dim=[128]), 1e-4),
+                  "mmoe": (dict(hidden_dim=[512, 256], tower_hidden_dim=[128], num_experts=2, gate_dnn_hidden_units=[64]), 1e-4),
+                  "ple": (dict(hidden_dim=[256], tower_hidden_dim=[64], specific_expert_num=15, shared_expert_num=2,
+                               gate_dnn_hidden_units=[64], num_levels=1), 1e-4)},
+    "Taobao_30": {"shared_bottom": (dict(hidden_dim=[512, 256], tower_hidden_dim=[128]), 1e-4),
+                  "mmoe": (dict(hidden_dim=[512, 256], tower_hidden_dim=[128], num_experts=2, gate_dnn_hidden_units=[64]), 1e-4),
+                  "ple": (dict(hidden_dim=[512, 256], tower_hidden_dim=[64], specific_expert_num=3, shared_expert_num=2,
+                               gate_dnn_hidden_units=[64], num_levels=1), 1e-4)},
+    "Amazon_6": {"shared_bottom": (dict(hidden_dim=[256, 128], tower_hidden_dim=[64]), 1e-3),
+                 "mmoe": (dict(hidden_dim=[256, 128], tower_hidden_dim=[64], num_experts=5, gate_dnn_hidden_units=[64]), 1e-4),
+                 "ple": (dict(hidden_dim=[512, 256], tower_hidden_dim=[64], specific_expert_num=5, shared_expert_num=2,
+                              gate_dnn_hidden_units=[64], num_levels=1), 1e-4)},
+    "Amazon_13": {"shared_bottom": (dict(hidden_dim=[256, 128], tower_hidden_dim=[64]), 1e-3),
+                  "mmoe": (dict(hidden_dim=[256, 128], tower_hidden_dim=[64], num_experts=5, gate_dnn_hidden_units=[64]), 1e-4),
+                  "ple": (dict(hidden_dim=[512, 256], tower_hidden_dim=[64], specific_expert_num=5, shared_expert_num=2,
+                               gate_dnn_hidden_units=[64], num_levels=1), 1e-4)},
+}
+# the train section of the plain (non-meta) entries: the reference's mmoe.json keys
+PLAIN_TRAIN_KEYS = ("load_pretrain_emb", "emb_trainable", "epoch", "learning_rate", "result_save_path", "checkpoint_path",
+                    "loss", "optimizer", "patience", "histogram_freq", "shuffle_buff_size")
+
+
+def write_mtl(written):
+    base = load("deepctr_taobao_10.json")
+    for split, files in MTL.items():
+        ds_over, tr_over = ({}, {}) if split == "Taobao-10" else SPLITS[split][:2]
+        for name, (model_over, lr) in files.items():
+            cfg = copy.deepcopy(base)
+            cfg["model"]["name"] = name
+            cfg["model"].update(model_over)
+            cfg["train"] = {k: cfg["train"][k] for k in PLAIN_TRAIN_KEYS if k in cfg["train"]}
+            cfg["train"].update(tr_over)
+            cfg["train"]["learning_rate"] = lr
+            cfg["dataset"].update(ds_over)
+            cfg["dataset"]["batch_size"] = 1024
+            path = os.path.join(CFG, split, name + ".json")
+            if os.path.exists(path):
+                continue
+            with open(path, "w") as f:
+                json.dump(cfg, f, indent=2)
+                f.write("\n")
+            written.append(os.path.relpath(path, ROOT))
+
+
 def main():
     written = []
+    write_mtl(written)
     for split, (ds_over, tr_over, sample_num, star_name) in SPLITS.items():
         os.makedirs(os.path.join(CFG, split), exist_ok=True)
         for out, (template, extra) in FILES.items():
