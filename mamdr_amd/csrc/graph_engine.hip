@@ -16,8 +16,10 @@
 //   TF1 Adam (or SGD) on the two ranges of the flat vector task d's model trains: the shared block (domain table +
 //   shared experts) and task d's block (its experts, gate, tower, head)       k_graph_adam     (hbm)
 // All fp32 (`v_mfma_f32_32x32x2_f32`: exact fp32 products), every reduction in a fixed order (no float atomics).
-// The user / item tables are frozen in this engine (every Taobao config of these towers; the Amazon ones train
-// them: MAMDR_ENOTBUILT).
+// Trainable user / item tables (the Amazon configs: no pretraining) sit at the head of the flat vector; their step is
+// TF1's dense Adam over every row -- regulariser gradient 2 l2 p + the scatter-add of the batch's row gradients --
+// through the table kernels of emb_kernels.hip in their per-step form (k_emb_flag / k_emb_reduce: duplicates summed
+// in batch order by the row's first position; k_emb_sweep: one HBM pass over both tables).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -27,11 +29,7 @@
 #include <vector>
 
 #include "../../include/mamdr_hip.h"
-#include "mamdr_device.h"
-
-namespace mamdr {
-void launch_sumsq(const float* x, int64_t n, float* partials, float* out, hipStream_t s);   // step_kernels.hip
-}
+#include "mamdr_kernels.h"
 
 using namespace mamdr;
 
@@ -67,6 +65,7 @@ struct GatherArgs {
     int ld;
     int32_t* domrow;
     float* y;
+    int32_t *urow, *irow, *map_u, *map_i;      // trainable tables: row of each position, first position of each row
 };
 // one wave per batch position: lanes 0..31 copy the user row, 32..63 the item row, then lanes 0..31 the domain row
 __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
@@ -76,7 +75,11 @@ __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
     if (r >= a.rows) {          // padding rows: zeros in, nothing out (their d loss / d logit is zero)
         *reinterpret_cast<f32x4*>(xr + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (lane < 32) *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (lane == 0) { a.domrow[r] = -1; a.y[r] = 0.f; }
+        if (lane == 0) {
+            a.domrow[r] = -1;
+            a.y[r] = 0.f;
+            if (a.urow) { a.urow[r] = -1; a.irow[r] = -1; }
+        }
         return;
     }
     int64_t src = a.perm ? (int64_t)a.perm[a.row_base + r] : a.row_base + r;
@@ -89,7 +92,16 @@ __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
     *reinterpret_cast<f32x4*>(xr + 4 * lane) = *reinterpret_cast<const f32x4*>(row);
     if (lane < 32)
         *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = *reinterpret_cast<const f32x4*>(a.dm + (size_t)d * EMB + 4 * lane);
-    if (lane == 0) { a.domrow[r] = d; a.y[r] = a.label[src]; }
+    if (lane == 0) {
+        a.domrow[r] = d;
+        a.y[r] = a.label[src];
+        if (a.urow) {       // representative of a table row = its smallest batch position (integer atomicMin: exact)
+            a.urow[r] = u;
+            a.irow[r] = it;
+            atomicMin(a.map_u + u, r);
+            atomicMin(a.map_i + it, r);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ dense contractions
@@ -491,6 +503,12 @@ struct mamdr_graph {
     float *act = nullptr, *dact = nullptr, *grad = nullptr, *dlogit = nullptr, *rowloss = nullptr, *y = nullptr;
     int32_t* domrow = nullptr;
     float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
+    // trainable tables
+    bool tables = false;
+    int64_t table_floats = 0;
+    int32_t *urow = nullptr, *irow = nullptr, *map_u = nullptr, *map_i = nullptr, *hasdup_u = nullptr, *hasdup_i = nullptr;
+    float *gbuf_u = nullptr, *gbuf_i = nullptr;
+    float* G(int64_t off) const { return grad + (off - table_floats); }      // gradient of the flat vector's element `off`
 };
 
 namespace {
@@ -575,12 +593,12 @@ void dnn_backward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, in
         a.lda = g->ld;
         a.B = g->dact + cols[l];
         a.ldb = g->ld;
-        a.C = g->grad + L.w_off;
+        a.C = g->G(L.w_off);
         a.ldc = L.out;
         a.K = sc.rp;
         launch_gemm(2, a, L.in, L.out, g->stream);
         hipLaunchKernelGGL(k_graph_colsum, dim3(L.out / 64), dim3(256), 0, g->stream, g->dact + cols[l], g->ld, sc.rp,
-                           g->grad + L.b_off);
+                           g->G(L.b_off));
         memset(&a, 0, sizeof(a));
         a.A = g->dact + cols[l];        // d in = dz W^T
         a.lda = g->ld;
@@ -654,7 +672,7 @@ int check(const mamdr_graph* g) {
 }
 int ready(const mamdr_graph* g) {
     if (!g->params) return gfail(MAMDR_ESTATE, "mamdr_graph_bind_state has not been called");
-    if (!g->user_tab || !g->item_tab) return gfail(MAMDR_ESTATE, "frozen user / item tables are not bound");
+    if (!g->tables && (!g->user_tab || !g->item_tab)) return gfail(MAMDR_ESTATE, "frozen user / item tables are not bound");
     return MAMDR_OK;
 }
 SplitData* split_of(mamdr_graph* g, int domain, int split) {
@@ -683,6 +701,12 @@ void fill_gather(const mamdr_graph* g, const SplitData& d, const int32_t* perm, 
     ga.ld = g->ld;
     ga.domrow = g->domrow;
     ga.y = g->y;
+    if (g->tables && sc.train) {
+        ga.urow = g->urow;
+        ga.irow = g->irow;
+        ga.map_u = g->map_u;
+        ga.map_i = g->map_i;
+    }
 }
 
 }  // namespace
@@ -697,9 +721,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (cfg->abi_version != MAMDR_ABI_VERSION) return gfail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
     if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
     if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");
-    if (cfg->emb_trainable)
-        return gfail(MAMDR_ENOTBUILT, "the generic-layer towers run with frozen user / item tables only (every Taobao config of "
-                                      "shared_bottom / mmoe / ple; the Amazon configs train their tables: not built)");
+    if (cfg->emb_trainable && cfg->max_batch > 16384) return gfail(MAMDR_EINVAL, "trainable tables: max_batch <= 16384");
     if (cfg->kind != MAMDR_GRAPH_SHARED_BOTTOM && cfg->kind != MAMDR_GRAPH_MMOE && cfg->kind != MAMDR_GRAPH_PLE)
         return gfail(MAMDR_EINVAL, "unknown graph tower kind %d", cfg->kind);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return gfail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
@@ -730,6 +752,12 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     g->data.resize((size_t)cfg->n_domain * 3);
     // ---- flat vector: the block every task's model trains, then one block per task (oracle/mtl.py Spec.tensors)
     uint32_t next_id = 0;
+    g->tables = cfg->emb_trainable != 0;
+    if (g->tables) {        // [user table | item table] contiguous at the head (k_emb_sweep walks them as one range)
+        add_tensor(g, "user_emb", cfg->n_user, EMB);
+        add_tensor(g, "item_emb", cfg->n_item, EMB);
+        g->table_floats = g->n_params;
+    }
     g->dm_off = add_tensor(g, "domain_emb", cfg->n_domain, EMB);
     std::vector<int> shared;
     for (int e = 0; e < n_shared; ++e) {
@@ -783,7 +811,17 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void**)&g->act, rp * g->ld * sizeof(float));
     alloc((void**)&g->dact, rp * g->ld * sizeof(float));
-    alloc((void**)&g->grad, (size_t)g->n_params * sizeof(float));
+    alloc((void**)&g->grad, (size_t)(g->n_params - g->table_floats) * sizeof(float));
+    if (g->tables) {
+        alloc((void**)&g->urow, rp * sizeof(int32_t));
+        alloc((void**)&g->irow, rp * sizeof(int32_t));
+        alloc((void**)&g->hasdup_u, rp * sizeof(int32_t));
+        alloc((void**)&g->hasdup_i, rp * sizeof(int32_t));
+        alloc((void**)&g->map_u, (size_t)cfg->n_user * sizeof(int32_t));
+        alloc((void**)&g->map_i, (size_t)cfg->n_item * sizeof(int32_t));
+        alloc((void**)&g->gbuf_u, rp * EMB * sizeof(float));
+        alloc((void**)&g->gbuf_i, rp * EMB * sizeof(float));
+    }
     alloc((void**)&g->dlogit, rp * sizeof(float));
     alloc((void**)&g->rowloss, rp * sizeof(float));
     alloc((void**)&g->y, rp * sizeof(float));
@@ -792,7 +830,15 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     alloc((void**)&g->frozen_sumsq, 4 * sizeof(float));
     alloc((void**)&g->sumsq_partials, 1024 * sizeof(float));
     alloc((void**)&g->eval_acc, 4 * sizeof(float));
-    if (e == hipSuccess) e = hipMemsetAsync(g->grad, 0, (size_t)g->n_params * sizeof(float), g->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->grad, 0, (size_t)(g->n_params - g->table_floats) * sizeof(float), g->stream);
+    if (g->tables && e == hipSuccess) {
+        e = hipMemsetAsync(g->hasdup_u, 0, rp * sizeof(int32_t), g->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(g->hasdup_i, 0, rp * sizeof(int32_t), g->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(g->urow, 0xff, rp * sizeof(int32_t), g->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(g->irow, 0xff, rp * sizeof(int32_t), g->stream);
+        launch_emb_map_init(g->map_u, cfg->n_user, g->stream);
+        launch_emb_map_init(g->map_i, cfg->n_item, g->stream);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(g->dact, 0, rp * g->ld * sizeof(float), g->stream);
     if (e == hipSuccess) e = hipMemsetAsync(g->frozen_sumsq, 0, 4 * sizeof(float), g->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(g->thresholds, thr, sizeof(thr), hipMemcpyHostToDevice, g->stream);
@@ -809,7 +855,8 @@ int mamdr_graph_destroy(mamdr_graph* g) {
     if (!g) return MAMDR_OK;
     (void)hipStreamSynchronize(g->stream);
     void* ptrs[] = {g->act, g->dact, g->grad, g->dlogit, g->rowloss, g->y, g->domrow, g->thresholds, g->frozen_sumsq,
-                    g->sumsq_partials, g->eval_acc};
+                    g->sumsq_partials, g->eval_acc, g->urow, g->irow, g->map_u, g->map_i, g->hasdup_u, g->hasdup_i,
+                    g->gbuf_u, g->gbuf_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -849,6 +896,10 @@ int mamdr_graph_bind_state(mamdr_graph* g, float* d_params, float* d_m, float* d
     g->params = d_params;
     g->adam_m = d_m;
     g->adam_v = d_v;
+    if (g->tables) {
+        g->user_tab = d_params;
+        g->item_tab = d_params + (size_t)g->cfg.n_user * EMB;
+    }
     return MAMDR_OK;
 }
 int mamdr_graph_optimizer_reset(mamdr_graph* g) {
@@ -865,6 +916,7 @@ int64_t mamdr_graph_dropout_steps(const mamdr_graph* g) { return g ? (int64_t)g-
 
 int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t n_rows) {
     if (check(g)) return MAMDR_EINVAL;
+    if (g->tables) return gfail(MAMDR_ESTATE, "tables are trainable: they live in the flat vector");
     if (!d_rows || ((uintptr_t)d_rows & 15)) return gfail(MAMDR_EINVAL, "table pointer null or not 16-byte aligned");
     if (seg == MAMDR_SEG_USER_EMB) {
         if (n_rows != g->cfg.n_user) return gfail(MAMDR_EINVAL, "user table has %lld rows, config says %d", (long long)n_rows, g->cfg.n_user);
@@ -954,17 +1006,24 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         ha.train = 1;
         ha.gate_scale = sc.keep_scale;
         hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
+        if (d_loss_out && g->tables) {
+            launch_sumsq(g->params, (int64_t)g->cfg.n_user * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
+            launch_sumsq(g->params + (size_t)g->cfg.n_user * EMB, (int64_t)g->cfg.n_item * EMB, g->sumsq_partials,
+                         g->frozen_sumsq + 1, g->stream);
+        }
         if (d_loss_out)
             hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
                                g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out + s, 0);
         // ---- backward
         // head: dw = t^T dlogit, dgb = sum dlogit
         hipLaunchKernelGGL(k_graph_small_tn, dim3((ha.n_t + 255) / 256), dim3(256), 0, g->stream, g->act + t_col, g->ld, g->dlogit, 1,
-                           sc.rp, ha.n_t, 1, g->grad + t.head_w);
-        hipLaunchKernelGGL(k_graph_sum1, dim3(1), dim3(256), 0, g->stream, g->dlogit, sc.rp, g->grad + t.head_gb);
+                           sc.rp, ha.n_t, 1, g->G(t.head_w));
+        hipLaunchKernelGGL(k_graph_sum1, dim3(1), dim3(256), 0, g->stream, g->dlogit, sc.rp, g->G(t.head_gb));
         const size_t ti = t.path.size() - 1;
-        // the x columns of the gradient workspace collect d x (domain columns) from every first layer: cleared by the first
+        // the x columns of the gradient workspace collect d x from every first layer (the domain columns alone while the
+        // tables are frozen): the first writer overwrites, the others add
         bool dx_started = false;
+        const int dx_first = g->tables ? 0 : 2 * EMB, dx_n = g->tables ? 0 : EMB;
         if (g->gated) {
             dnn_backward(g, tower, t.col[ti], t.m_col, t.m_col, -1, false, 0, 0, sc);
             GateArgs gta;
@@ -973,20 +1032,52 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             const size_t gi = t.mix.size();
             const Dnn& gd = g->dnns[t.gate];
             hipLaunchKernelGGL(k_graph_small_tn, dim3((gta.n_q * gta.n_e + 255) / 256), dim3(256), 0, g->stream, g->act + gta.q_col,
-                               g->ld, g->dact + t.g_col, g->ld, sc.rp, gta.n_q, gta.n_e, g->grad + t.wg_off);
-            dnn_backward(g, gd, t.col[gi], 0, 0, -1, dx_started, 2 * EMB, EMB, sc);
+                               g->ld, g->dact + t.g_col, g->ld, sc.rp, gta.n_q, gta.n_e, g->G(t.wg_off));
+            dnn_backward(g, gd, t.col[gi], 0, 0, -1, dx_started, dx_first, dx_n, sc);
             dx_started = true;
             for (size_t e = 0; e < t.mix.size(); ++e) {
-                dnn_backward(g, g->dnns[t.mix[e]], t.col[e], 0, 0, -1, dx_started, 2 * EMB, EMB, sc);
+                dnn_backward(g, g->dnns[t.mix[e]], t.col[e], 0, 0, -1, dx_started, dx_first, dx_n, sc);
                 dx_started = true;
             }
         } else {
             // the tower's input IS the bottom's output: its gradient passes through the bottom's last relu / dropout gate
             dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
-            dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, 2 * EMB, EMB, sc);
+            dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
         hipLaunchKernelGGL(k_graph_domain_grad, dim3(g->cfg.n_domain), dim3(EMB), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
-                           sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->grad + g->dm_off);
+                           sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
+        if (g->tables) {
+            // TF1's dense step over both tables: g = 2 l2 p + scatter-add of d x[:, user | item columns]
+            EmbStepArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.p = g->params;
+            ea.m = g->adam_m;
+            ea.v = g->adam_v;
+            ea.dxe = g->dact;
+            ea.dx_ld = g->ld;
+            ea.dlogit = g->dlogit;
+            ea.rows = sc.rows;
+            ea.opt.optimizer = optimizer;
+            ea.opt.alpha = alpha;
+            ea.opt.omb1 = omb1;
+            ea.opt.omb2 = omb2;
+            ea.opt.eps = g->cfg.adam_eps;
+            ea.opt.two_l2 = 2.0f * g->cfg.l2_emb;
+            ea.t[0].n_rows = g->cfg.n_user;
+            ea.t[0].brow = g->urow;
+            ea.t[0].map = g->map_u;
+            ea.t[0].gbuf = g->gbuf_u;
+            ea.t[0].hasdup = g->hasdup_u;
+            ea.t[0].dx_off = 0;
+            ea.t[1].n_rows = g->cfg.n_item;
+            ea.t[1].brow = g->irow;
+            ea.t[1].map = g->map_i;
+            ea.t[1].gbuf = g->gbuf_i;
+            ea.t[1].hasdup = g->hasdup_i;
+            ea.t[1].dx_off = EMB;
+            launch_emb_reduce(ea, g->stream);
+            launch_emb_sweep(ea, g->stream);
+        }
         // ---- optimiser on the two ranges this task's model trains
         const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
         for (int k = 0; k < 2; ++k) {
@@ -994,7 +1085,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             aa.p = g->params + off[k];
             aa.m = g->adam_m + off[k];
             aa.v = g->adam_v + off[k];
-            aa.g = g->grad + off[k];
+            aa.g = g->G(off[k]);
             aa.n4 = cnt[k] / 4;
             aa.optimizer = optimizer;
             aa.alpha = alpha;
@@ -1021,6 +1112,11 @@ int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch
     const Task& t = g->tasks[domain];
     GHIP(hipMemsetAsync(d_hist, 0, 2 * 501 * sizeof(uint32_t), g->stream));
     GHIP(hipMemsetAsync(g->eval_acc, 0, sizeof(float), g->stream));
+    if (g->tables) {
+        launch_sumsq(g->params, (int64_t)g->cfg.n_user * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
+        launch_sumsq(g->params + (size_t)g->cfg.n_user * EMB, (int64_t)g->cfg.n_item * EMB, g->sumsq_partials,
+                     g->frozen_sumsq + 1, g->stream);
+    }
     const int64_t n_batches = (d->n + batch - 1) / batch;
     for (int64_t b = 0; b < n_batches; ++b) {
         StepCtx sc;

@@ -97,8 +97,16 @@ class DeepMTLCTR(BaseModel):
             raise ValueError("load_pretrain_emb is set but the dataset has no pretrained tables")
         self.plan = tensor_plan(kind, self.n_domain, mc["user_dim"], **shape)
         tensors = initial_tensors(self.init_rs, self.plan, mc["user_dim"])
-        eng.bind_table("user_emb", self.dataset.user_emb)
-        eng.bind_table("item_emb", self.dataset.item_emb)
+        # deep_mtl_ctr.py:108-121: pretrained constants when load_pretrain_emb, deepctr's N(0, 1e-4^2) otherwise
+        E = mc["user_dim"]
+        user = self.dataset.user_emb if pre else (self.init_rs.standard_normal((self.n_uid, E)) * 1e-4).astype(np.float32)
+        item = self.dataset.item_emb if pre else (self.init_rs.standard_normal((self.n_pid, E)) * 1e-4).astype(np.float32)
+        if self.tables_trainable:
+            tensors["user_emb"], tensors["item_emb"] = user, item
+            self.plan = [("user_emb", (self.n_uid, E)), ("item_emb", (self.n_pid, E))] + self.plan
+        else:
+            eng.bind_table("user_emb", user)
+            eng.bind_table("item_emb", item)
         for split, store in (("train", self.dataset.train_dataset), ("val", self.dataset.val_dataset),
                              ("test", self.dataset.test_dataset)):
             for d, v in store.items():

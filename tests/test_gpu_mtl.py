@@ -27,7 +27,7 @@ SHAPES = {
 }
 
 
-def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, n_domain=4):
+def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, n_domain=4, emb_trainable=False):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     from mamdr_amd import graph_engine, synthetic
@@ -43,20 +43,21 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, n_domain=4):
         if "/b" in n or n.endswith("/gb") or n == "domain_emb":
             params[n] = (rs.standard_normal(params[n].shape) * 0.05).astype(F32)
     eng = graph_engine.GraphEngine(kind, g["n_user"], g["n_item"], D, batch, eh, th, gh, num_experts=ne,
-                                   shared_expert_num=se, specific_expert_num=sp, dropout=dropout)
-    eng.bind_table("user_emb", params["user_emb"])
-    eng.bind_table("item_emb", params["item_emb"])
+                                   shared_expert_num=se, specific_expert_num=sp, dropout=dropout, emb_trainable=emb_trainable)
+    if not emb_trainable:
+        eng.bind_table("user_emb", params["user_emb"])
+        eng.bind_table("item_emb", params["item_emb"])
     for split in ("train", "val", "test"):
         for d in range(D):
             c = g["data"][split][d]
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
-    names = [n for n, _ in spec.tensors(False)]
-    assert list(eng.segments) == names                   # same tensors, same order as the oracle's flat vector
-    for n, shp in spec.tensors(False):
+    plan = spec.tensors(emb_trainable, g["n_user"], g["n_item"])
+    assert list(eng.segments) == [n for n, _ in plan]     # same tensors, same order as the oracle's flat vector
+    for n, shp in plan:
         assert eng.segments[n][1] == int(np.prod(shp)), n
     eng.set_weights(eng.pack(params))
-    model = omtl.OracleMTL({k: v.copy() for k, v in params.items()}, spec, dropout=dropout, lr=1e-3,
-                           dropout_seed=eng.dropout_seed)
+    model = omtl.OracleMTL({k: v.copy() for k, v in params.items()}, spec, emb_trainable=emb_trainable, dropout=dropout,
+                           lr=1e-3, dropout_seed=eng.dropout_seed)
     return g, eng, model, spec
 
 
@@ -204,14 +205,60 @@ def test_alternate_training_auc_parity(kind):
     eng.close()
 
 
-def test_unbuilt_and_invalid_configurations_say_so():
+def test_invalid_configurations_say_so():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     from mamdr_amd import _lib as L
     from mamdr_amd import graph_engine
-    with pytest.raises(L.NotBuiltError):
-        graph_engine.GraphEngine("mmoe", 100, 100, 3, 256, (128,), (64,), (64,), num_experts=2, emb_trainable=True)
     with pytest.raises(L.MamdrError):
         graph_engine.GraphEngine("mmoe", 100, 100, 3, 256, (100,), (64,), (64,), num_experts=2)       # width not a multiple of 64
     with pytest.raises(L.MamdrError):
         graph_engine.GraphEngine("mmoe", 100, 100, 3, 256, (128,), (64,), (), num_experts=2)          # gated tower without a gate DNN
+
+
+@pytest.mark.parametrize("kind", ["shared_bottom", "mmoe"])
+def test_trainable_tables_gradients_and_adam(kind):
+    """the Amazon configurations of these towers train their tables (load_pretrain_emb false): scatter-add of the row
+    gradients (rows repeated inside a batch summed in batch order) + the dense regulariser gradient on EVERY row, TF1's
+    dense Adam over the whole tables; one SGD step at lr 1 shows every gradient, then Adam steps on two domains."""
+    g, eng, model, spec = make_problem(kind, dropout=0.5, scale=0.1, emb_trainable=True)
+    assert "user_emb" in eng.segments and eng.segments["user_emb"][0] == 0
+    d = max(range(g["n_domain"]), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    perm = orng.shuffle_perm(cols["uid"].shape[0], 10000, seed=4)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    idx = perm[:256]
+    assert len(np.unique(cols["uid"][idx])) < 256          # repeated rows exercise the ordered segment sum
+    masks = omtl.train_masks(spec, model.seed, model.step, 256, 0.5)
+    loss, grads, _ = omtl.loss_and_grads(model.params, spec, d, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                         cols["label"][idx], masks, 0.5, True)
+    w0 = eng.get_weights()
+    loss_t = torch.zeros(1, device=eng.device)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+    got = eng.unpack(w0 - eng.get_weights())
+    eng.set_weights(w0)
+    model.step += 1
+    assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    for name, want in grads.items():
+        want = want.ravel()
+        np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * max(np.abs(want).max(), 1e-3), 1.5e-8), err_msg=name)
+    # untouched rows still move by the regulariser: g = 2 l2 w
+    untouched = np.setdiff1d(np.arange(g["n_user"]), cols["uid"][idx])[:5]
+    for r in untouched:
+        np.testing.assert_allclose(got["user_emb"][r * 128:(r + 1) * 128], 2e-5 * model.params["user_emb"][r], rtol=1e-3, atol=2e-8)
+    n_steps = 0
+    for dd in (d, (d + 1) % g["n_domain"]):
+        c2 = g["data"]["train"][dd]
+        pm = orng.shuffle_perm(c2["uid"].shape[0], 10000, seed=9 + dd)
+        k = min(3, -(-pm.shape[0] // 256))
+        eng.train_steps(dd, perm=torch.from_numpy(pm).to(eng.device), n_steps=k, lr=1e-3)
+        model.lr = 1e-3
+        model.train_pass(dd, c2, pm, 256, max_steps=k)
+        n_steps += k
+    got = eng.unpack(eng.get_weights())
+    for name in eng.segments:
+        assert_adam_close(got[name], model.params[name], n_steps, 1e-3, name)
+    loss_g, auc_g = eng.evaluate(d, "val")
+    loss_o, preds = model.evaluate(d, g["data"]["val"][d], 256)
+    assert abs(loss_g - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))
+    eng.close()
