@@ -95,7 +95,10 @@ class MultiDomainDataset(object):
         self.user_emb = None
         self.item_emb = None
         if conf.get("synthetic"):
-            self._from_generated(synthetic.generate(conf["synthetic"], batch_size=self.batch_size, seed=self.seed,
+            # (synthetic_seed: the generated logs' own seed, so that runs with different `seed` -- planner, shuffles,
+            # initial tensors -- can share one data set; default: the run's seed)
+            self._from_generated(synthetic.generate(conf["synthetic"], batch_size=self.batch_size,
+                                                    seed=int(conf.get("synthetic_seed", self.seed)),
                                                     scale=float(conf.get("synthetic_scale", 1.0))))
         else:
             self._from_files()

@@ -241,7 +241,9 @@ def test_trainable_tables_gradients_and_adam(kind):
     assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
     for name, want in grads.items():
         want = want.ravel()
-        np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * max(np.abs(want).max(), 1e-3), 1.5e-8), err_msg=name)
+        # (read back as w0 - (w0 - g): quantised to the weights' ulp -- 3e-8 for the largest table entries, |w| up to 0.5)
+        floor = 4e-8 if name in ("user_emb", "item_emb") else 1.5e-8
+        np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * max(np.abs(want).max(), 1e-3), floor), err_msg=name)
     # untouched rows still move by the regulariser: g = 2 l2 w
     untouched = np.setdiff1d(np.arange(g["n_user"]), cols["uid"][idx])[:5]
     for r in untouched:
