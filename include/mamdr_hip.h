@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 9
+#define MAMDR_ABI_VERSION 10
 
 enum {
     MAMDR_OK = 0,
@@ -302,7 +302,12 @@ int mamdr_profile_read(mamdr_ctx* ctx, int32_t kernel, double* total_ms, int64_t
  * User / item tables are frozen (bound through mamdr_graph_bind_table); emb_trainable = 1 returns MAMDR_ENOTBUILT. */
 enum { MAMDR_GRAPH_SHARED_BOTTOM = 0,   /* deep_mtl_ctr.py:25-30  models.SharedBottom */
        MAMDR_GRAPH_MMOE = 1,            /* deep_mtl_ctr.py:31-38  models.MMOE */
-       MAMDR_GRAPH_PLE = 2 };           /* deep_mtl_ctr.py:39-49  models.PLE (num_levels = 1, as in every reference config) */
+       MAMDR_GRAPH_PLE = 2,             /* deep_mtl_ctr.py:39-49  models.PLE (num_levels = 1, as in every reference config) */
+       /* single-output towers of the deepctr family on the same generic layers (model_zoo/DeepCTR/deepctr.py): ONE model
+          serves every domain; flat vector = [user_emb item_emb (lin_user lin_item) if trainable] domain_emb W0 W1 W2 b0 b1 b2
+          wo gb (lin_domain); hidden_dim in expert_hidden, tower / gate fields unused */
+       MAMDR_GRAPH_NFM = 3,             /* deepctr.py:33-35  models.NFM: linear tables + DNN(BiInteractionPooling) */
+       MAMDR_GRAPH_PNN = 4 };           /* deepctr.py:44-46  models.PNN: DNN([fields | pairwise inner products]) */
 typedef struct mamdr_graph mamdr_graph;
 typedef struct mamdr_graph_config {
     int32_t abi_version;        /* MAMDR_ABI_VERSION */
@@ -314,6 +319,7 @@ typedef struct mamdr_graph_config {
     int32_t num_experts;                                 /* mmoe (:32) */
     int32_t shared_expert_num, specific_expert_num;      /* ple (:40-41) */
     float dropout, l2_emb, adam_beta1, adam_beta2, adam_eps;
+    float l2_linear;                                     /* NFM: deepctr l2_reg_linear (1e-5) on the 1-d linear tables */
 } mamdr_graph_config;
 const char* mamdr_graph_last_error(void);
 int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph** out);   /* build_model, deep_mtl_ctr.py:21-67 */

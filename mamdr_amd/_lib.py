@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -48,7 +48,7 @@ class Config(C.Structure):
     ]
 
 
-GRAPH_SHARED_BOTTOM, GRAPH_MMOE, GRAPH_PLE = 0, 1, 2
+GRAPH_SHARED_BOTTOM, GRAPH_MMOE, GRAPH_PLE, GRAPH_NFM, GRAPH_PNN = 0, 1, 2, 3, 4
 
 
 class GraphConfig(C.Structure):
@@ -60,7 +60,7 @@ class GraphConfig(C.Structure):
         ("n_gate_hidden", C.c_int32), ("gate_hidden", C.c_int32 * 4),
         ("num_experts", C.c_int32), ("shared_expert_num", C.c_int32), ("specific_expert_num", C.c_int32),
         ("dropout", C.c_float), ("l2_emb", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
-        ("adam_eps", C.c_float),
+        ("adam_eps", C.c_float), ("l2_linear", C.c_float),
     ]
 
 

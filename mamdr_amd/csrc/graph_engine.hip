@@ -66,6 +66,8 @@ struct GatherArgs {
     int32_t* domrow;
     float* y;
     int32_t *urow, *irow, *map_u, *map_i;      // trainable tables: row of each position, first position of each row
+    const float *lin_u, *lin_i, *lin_d;         // NFM: 1-d linear tables (lin_u / lin_i null while frozen at their zero init)
+    float* extra;                               // NFM: sum of the linear terms per position
 };
 // one wave per batch position: lanes 0..31 copy the user row, 32..63 the item row, then lanes 0..31 the domain row
 __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
             a.domrow[r] = -1;
             a.y[r] = 0.f;
             if (a.urow) { a.urow[r] = -1; a.irow[r] = -1; }
+            if (a.extra) a.extra[r] = 0.f;
         }
         return;
     }
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
     if (lane == 0) {
         a.domrow[r] = d;
         a.y[r] = a.label[src];
+        if (a.extra) a.extra[r] = ((a.lin_u ? a.lin_u[u] : 0.f) + (a.lin_i ? a.lin_i[it] : 0.f)) + a.lin_d[d];
         if (a.urow) {       // representative of a table row = its smallest batch position (integer atomicMin: exact)
             a.urow[r] = u;
             a.irow[r] = it;
@@ -118,6 +122,9 @@ struct GemmArgs {
     const float* bias; int relu;
     uint32_t drop_key, drop_thresh; float keep_scale; int n_cols; int use_dropout;
     const float* gate_y; int gate_ld; float gate_scale; int accumulate;
+    // forward only: + sum_{j < n_xe} xe[row][j] * we[j][col] before the bias (PNN: the inner products feed the last three
+    // rows of the first kernel, whose 384 + 3 rows are no multiple of the tile depth)
+    const float* xe; int xe_ld; const float* we; int n_xe;
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
         const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kk;
         float v = acc[r];
         if (MODE == 0) {
+            for (int j = 0; j < a.n_xe; ++j) v = fmaf(a.xe[(size_t)row * a.xe_ld + j], a.we[(size_t)j * a.n_cols + col], v);
             v += bias;
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.use_dropout) {
@@ -215,6 +223,97 @@ __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_
     out[idx] = s;
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// ------------------------------------------------------------------ NFM / PNN: interactions of the three fields, one wave per row
+// kind 0 (NFM): f[c] = u i + u d + i d (= 1/2 ((u+i+d)^2 - u^2 - i^2 - d^2), BiInteractionPooling), 128 columns
+// kind 1 (PNN): f[0..2] = <u,i>, <u,d>, <i,d> (InnerProductLayer over the pairs (0,1), (0,2), (1,2))
+struct FeatArgs {
+    float* act; float* dact; int ld; int f_col; int rows_pad; int kind; int dx_all;
+    const float* w_ip;      // PNN: rows 384..386 of the first kernel [3][n_out]
+    int z_col, n_out;       // PNN: d z of the first layer
+};
+__global__ __launch_bounds__(256) void k_graph_feat_fwd(const FeatArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    float* row = a.act + (size_t)r * a.ld;
+    const f32x2 u = *reinterpret_cast<const f32x2*>(row + 2 * lane), it = *reinterpret_cast<const f32x2*>(row + EMB + 2 * lane),
+                d = *reinterpret_cast<const f32x2*>(row + 2 * EMB + 2 * lane);
+    if (a.kind == 0) {
+        f32x2 f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) f[k] = fmaf(it[k], d[k], fmaf(u[k], d[k], u[k] * it[k]));
+        *reinterpret_cast<f32x2*>(row + a.f_col + 2 * lane) = f;
+    } else {
+        const float ui = wave_sum(fmaf(u[1], it[1], u[0] * it[0])), ud = wave_sum(fmaf(u[1], d[1], u[0] * d[0])),
+                    id = wave_sum(fmaf(it[1], d[1], it[0] * d[0]));
+        if (lane == 0) {
+            row[a.f_col + 0] = ui;
+            row[a.f_col + 1] = ud;
+            row[a.f_col + 2] = id;
+            row[a.f_col + 3] = 0.f;
+        }
+    }
+}
+// d f -> d x.  NFM: d u = df (i + d), d i = df (u + d), d d = df (u + i), WRITTEN (nothing else feeds d x).
+// PNN: dip_j = sum_c dz[c] W0[384 + j][c]; d u += dip0 i + dip1 d, d i += dip0 u + dip2 d, d d += dip1 u + dip2 i, ADDED
+// to what the first layer's d x = dz W0[0:384]^T left there.  User / item columns only when the tables train.
+__global__ __launch_bounds__(256) void k_graph_feat_bwd(const FeatArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    const float* row = a.act + (size_t)r * a.ld;
+    float* drow = a.dact + (size_t)r * a.ld;
+    const f32x2 u = *reinterpret_cast<const f32x2*>(row + 2 * lane), it = *reinterpret_cast<const f32x2*>(row + EMB + 2 * lane),
+                d = *reinterpret_cast<const f32x2*>(row + 2 * EMB + 2 * lane);
+    f32x2 du, di, dd;
+    if (a.kind == 0) {
+        const f32x2 df = *reinterpret_cast<const f32x2*>(drow + a.f_col + 2 * lane);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            du[k] = df[k] * (it[k] + d[k]);
+            di[k] = df[k] * (u[k] + d[k]);
+            dd[k] = df[k] * (u[k] + it[k]);
+        }
+    } else {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (int c = lane; c < a.n_out; c += 64) {
+            const float z = drow[a.z_col + c];
+            p0 = fmaf(z, a.w_ip[c], p0);
+            p1 = fmaf(z, a.w_ip[a.n_out + c], p1);
+            p2 = fmaf(z, a.w_ip[2 * a.n_out + c], p2);
+        }
+        p0 = wave_sum(p0);
+        p1 = wave_sum(p1);
+        p2 = wave_sum(p2);
+        const f32x2 du0 = *reinterpret_cast<const f32x2*>(drow + 2 * lane), di0 = *reinterpret_cast<const f32x2*>(drow + EMB + 2 * lane),
+                    dd0 = *reinterpret_cast<const f32x2*>(drow + 2 * EMB + 2 * lane);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            du[k] = du0[k] + (p0 * it[k] + p1 * d[k]);
+            di[k] = di0[k] + (p0 * u[k] + p2 * d[k]);
+            dd[k] = dd0[k] + (p1 * u[k] + p2 * it[k]);
+        }
+    }
+    if (a.dx_all) {
+        *reinterpret_cast<f32x2*>(drow + 2 * lane) = du;
+        *reinterpret_cast<f32x2*>(drow + EMB + 2 * lane) = di;
+    }
+    *reinterpret_cast<f32x2*>(drow + 2 * EMB + 2 * lane) = dd;
+}
+// NFM's linear domain table: g[d] = sum over the batch rows of domain d of d loss / d logit  +  2 l2_lin w[d]
+__global__ __launch_bounds__(64) void k_graph_lin_domain_grad(const float* dlogit, const int32_t* domrow, int rows, const float* w,
+                                                              float two_l2, int n_domain, float* g) {
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    if (d >= n_domain) return;
+    float s = 0.f;
+    for (int b = 0; b < rows; ++b)
+        if (domrow[b] == d) s += dlogit[b];
+    g[d] = s + two_l2 * w[d];
+}
+
 // ------------------------------------------------------------------ gate: softmax(q Wg) and the mixture, one wave per row
 struct GateArgs {
     float* act; float* dact; int ld;
@@ -226,11 +325,6 @@ struct GateArgs {
     int rows_pad;
     float gate_scale;           // 1 / keep of the dropout behind every DNN layer (1 in inference)
 };
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 __global__ __launch_bounds__(256) void k_graph_gate_fwd(const GateArgs a) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= a.rows_pad) return;
@@ -320,6 +414,7 @@ struct HeadArgs {
     int t_col, n_t;
     const float* w; const float* gb;
     const float* y; int rows, rows_pad;
+    const float* extra;         // NFM: the linear logit of every position (null otherwise)
     float* dlogit; float* rowloss;
     int train; float gate_scale;
     const float* thresholds; uint32_t* hist; float* pred_out;       // inference
@@ -330,7 +425,7 @@ __global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
     const float* row = a.act + (size_t)r * a.ld;
     float s = 0.f;
     for (int cidx = lane; cidx < a.n_t; cidx += 64) s = fmaf(row[a.t_col + cidx], a.w[cidx], s);
-    const float logit = wave_sum(s) + a.gb[0];
+    const float logit = wave_sum(s) + a.gb[0] + (a.extra ? a.extra[r] : 0.f);
     float p;
     if (logit >= 0.f) {
         p = 1.0f / (1.0f + __expf(-logit));
@@ -366,11 +461,17 @@ __global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
 // batch loss = mean of the rows' BCE + l2 (sum of squares of the three tables); one workgroup, fixed order.
 // mode 0: out[0] = loss;  mode 1 (evaluation): out[0] += loss
 __global__ __launch_bounds__(256) void k_graph_loss(const float* rowloss, int rows, const float* dm, int dm_count, float l2,
-                                                    const float* frozen_sumsq, float* out, int mode) {
+                                                    const float* frozen_sumsq, float* out, int mode, const float* lin_d,
+                                                    int n_lin_d, float l2_lin) {
     __shared__ float red[256];
     float s = 0.f, q = 0.f;
     for (int b = threadIdx.x; b < rows; b += 256) s += rowloss[b];
     for (int e = threadIdx.x; e < dm_count; e += 256) q = fmaf(dm[e], dm[e], q);
+    float ql = 0.f;         // NFM: l2_lin * (sum of squares of the three 1-d linear tables)
+    if (threadIdx.x == 0 && lin_d) {
+        for (int e = 0; e < n_lin_d; ++e) ql = fmaf(lin_d[e], lin_d[e], ql);
+        ql = l2_lin * ((frozen_sumsq[2] + frozen_sumsq[3]) + ql);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -386,7 +487,7 @@ __global__ __launch_bounds__(256) void k_graph_loss(const float* rowloss, int ro
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float loss = tot / (float)rows + l2 * ((frozen_sumsq[0] + frozen_sumsq[1]) + red[0]);
+        const float loss = tot / (float)rows + l2 * ((frozen_sumsq[0] + frozen_sumsq[1]) + red[0]) + ql;
         out[0] = mode ? out[0] + loss : loss;
     }
 }
@@ -491,6 +592,12 @@ struct mamdr_graph {
     int64_t n_params = 0, dm_off = 0, shared_end = 0;
     bool gated = false;
     int n_h = 0;                // expert width
+    // single-output towers of the deepctr family on the same layers (NFM, PNN): ONE task serves every domain
+    bool single = false;
+    int f_col = 0;              // interaction features: NFM 128 columns, PNN 3 (+ 1 pad)
+    int64_t lin_d_off = 0;      // NFM: 1-d linear table of the domain feature (behind the global bias)
+    int64_t lin_u_off = 0, lin_i_off = 0;       // ... of the user / item features (trainable tables only)
+    float *extra = nullptr, *glin_u = nullptr, *glin_i = nullptr;
     // bound state
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     const float *user_tab = nullptr, *item_tab = nullptr;
@@ -554,12 +661,18 @@ struct StepCtx {
 };
 
 // forward of one DNN: input columns `in_col` (width in_dim) of the activation workspace
-void dnn_forward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, int in_col, const StepCtx& sc) {
+void dnn_forward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, int in_col, const StepCtx& sc, int xe_col = -1) {
     int src = in_col;
     for (size_t l = 0; l < d.layers.size(); ++l) {
         const Layer& L = d.layers[l];
         GemmArgs a;
         memset(&a, 0, sizeof(a));
+        if (l == 0 && xe_col >= 0) {        // PNN: the three inner products times rows 384..386 of the first kernel
+            a.xe = g->act + xe_col;
+            a.xe_ld = g->ld;
+            a.we = g->params + L.w_off + (size_t)L.in * L.out;
+            a.n_xe = 3;
+        }
         a.A = g->act + src;
         a.lda = g->ld;
         a.B = g->params + L.w_off;
@@ -648,7 +761,30 @@ void fill_gate(const mamdr_graph* g, const Task& t, const StepCtx& sc, GateArgs&
 }
 
 // forward of task d on the gathered batch; -> column of the tower's output
+void fill_feat(const mamdr_graph* g, const Task& t, const StepCtx& sc, FeatArgs& fa) {
+    memset(&fa, 0, sizeof(fa));
+    fa.act = g->act;
+    fa.dact = g->dact;
+    fa.ld = g->ld;
+    fa.f_col = g->f_col;
+    fa.rows_pad = sc.rp;
+    fa.kind = g->cfg.kind == MAMDR_GRAPH_NFM ? 0 : 1;
+    fa.dx_all = g->tables ? 1 : 0;
+    const Layer& L0 = g->dnns[t.tower].layers[0];
+    fa.w_ip = g->params + L0.w_off + (size_t)L0.in * L0.out;
+    fa.z_col = t.col[0][0];
+    fa.n_out = L0.out;
+}
+
 int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
+    if (g->single) {
+        FeatArgs fa;
+        fill_feat(g, t, sc, fa);
+        hipLaunchKernelGGL(k_graph_feat_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
+        const bool nfm = g->cfg.kind == MAMDR_GRAPH_NFM;
+        dnn_forward(g, g->dnns[t.tower], t.col[0], nfm ? g->f_col : 0, sc, nfm ? -1 : g->f_col);
+        return t.col[0].back();
+    }
     for (size_t e = 0; e < t.mix.size(); ++e) dnn_forward(g, g->dnns[t.mix[e]], t.col[e], 0, sc);
     int tower_in;
     if (g->gated) {
@@ -669,6 +805,16 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
 int check(const mamdr_graph* g) {
     if (!g) return gfail(MAMDR_EINVAL, "null graph context");
     return MAMDR_OK;
+}
+// trainable tables: the regulariser term of a reported loss needs their current sums of squares
+void refresh_sumsq(mamdr_graph* g) {
+    launch_sumsq(g->params, (int64_t)g->cfg.n_user * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
+    launch_sumsq(g->params + (size_t)g->cfg.n_user * EMB, (int64_t)g->cfg.n_item * EMB, g->sumsq_partials, g->frozen_sumsq + 1,
+                 g->stream);
+    if (g->cfg.kind == MAMDR_GRAPH_NFM) {
+        launch_sumsq(g->params + g->lin_u_off, g->cfg.n_user, g->sumsq_partials, g->frozen_sumsq + 2, g->stream);
+        launch_sumsq(g->params + g->lin_i_off, g->cfg.n_item, g->sumsq_partials, g->frozen_sumsq + 3, g->stream);
+    }
 }
 int ready(const mamdr_graph* g) {
     if (!g->params) return gfail(MAMDR_ESTATE, "mamdr_graph_bind_state has not been called");
@@ -701,6 +847,14 @@ void fill_gather(const mamdr_graph* g, const SplitData& d, const int32_t* perm, 
     ga.ld = g->ld;
     ga.domrow = g->domrow;
     ga.y = g->y;
+    if (g->extra) {
+        ga.extra = g->extra;
+        ga.lin_d = g->params + g->lin_d_off;
+        if (g->tables) {
+            ga.lin_u = g->params + g->lin_u_off;
+            ga.lin_i = g->params + g->lin_i_off;
+        }
+    }
     if (g->tables && sc.train) {
         ga.urow = g->urow;
         ga.irow = g->irow;
@@ -722,25 +876,27 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
     if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");
     if (cfg->emb_trainable && cfg->max_batch > 16384) return gfail(MAMDR_EINVAL, "trainable tables: max_batch <= 16384");
-    if (cfg->kind != MAMDR_GRAPH_SHARED_BOTTOM && cfg->kind != MAMDR_GRAPH_MMOE && cfg->kind != MAMDR_GRAPH_PLE)
+    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_PNN)
         return gfail(MAMDR_EINVAL, "unknown graph tower kind %d", cfg->kind);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return gfail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
-    const bool gated = cfg->kind != MAMDR_GRAPH_SHARED_BOTTOM;
-    if (cfg->n_expert_hidden < 1 || cfg->n_expert_hidden > 4 || cfg->n_tower_hidden < 1 || cfg->n_tower_hidden > 4 ||
+    const bool single = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_PNN;
+    const bool gated = cfg->kind == MAMDR_GRAPH_MMOE || cfg->kind == MAMDR_GRAPH_PLE;
+    if (cfg->n_expert_hidden < 1 || cfg->n_expert_hidden > 4 || (!single && (cfg->n_tower_hidden < 1 || cfg->n_tower_hidden > 4)) ||
         (gated && (cfg->n_gate_hidden < 1 || cfg->n_gate_hidden > 4)))
-        return gfail(MAMDR_EINVAL, "hidden_dim / tower_hidden_dim%s need 1..4 layers", gated ? " / gate_dnn_hidden_units" : "");
+        return gfail(MAMDR_EINVAL, "hidden_dim%s need 1..4 layers", single ? "" : (gated ? " / tower_hidden_dim / gate_dnn_hidden_units"
+                                                                                           : " / tower_hidden_dim"));
     auto widths_ok = [](const int32_t* h, int n) {
         for (int i = 0; i < n; ++i)
             if (h[i] <= 0 || h[i] % 64) return false;
         return true;
     };
-    if (!widths_ok(cfg->expert_hidden, cfg->n_expert_hidden) || !widths_ok(cfg->tower_hidden, cfg->n_tower_hidden) ||
+    if (!widths_ok(cfg->expert_hidden, cfg->n_expert_hidden) || (!single && !widths_ok(cfg->tower_hidden, cfg->n_tower_hidden)) ||
         (gated && !widths_ok(cfg->gate_hidden, cfg->n_gate_hidden)))
         return gfail(MAMDR_EINVAL, "layer widths must be multiples of 64 (the reference's configs use 64 ... 512)");
-    int n_shared = 1, n_specific = 0;
+    int n_shared = single ? 0 : 1, n_specific = 0;
     if (cfg->kind == MAMDR_GRAPH_MMOE) n_shared = cfg->num_experts;
     if (cfg->kind == MAMDR_GRAPH_PLE) { n_shared = cfg->shared_expert_num; n_specific = cfg->specific_expert_num; }
-    if (n_shared < 0 || n_specific < 0 || n_shared + n_specific < 1 || n_shared + n_specific > MAX_MIX)
+    if (!single && (n_shared < 0 || n_specific < 0 || n_shared + n_specific < 1 || n_shared + n_specific > MAX_MIX))
         return gfail(MAMDR_EINVAL, "a task must mix 1..%d experts", MAX_MIX);
 
     mamdr_graph* g = new (std::nothrow) mamdr_graph();
@@ -748,6 +904,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     g->cfg = *cfg;
     g->stream = (hipStream_t)stream;
     g->gated = gated;
+    g->single = single;
     g->n_h = cfg->expert_hidden[cfg->n_expert_hidden - 1];
     g->data.resize((size_t)cfg->n_domain * 3);
     // ---- flat vector: the block every task's model trains, then one block per task (oracle/mtl.py Spec.tensors)
@@ -756,6 +913,10 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (g->tables) {        // [user table | item table] contiguous at the head (k_emb_sweep walks them as one range)
         add_tensor(g, "user_emb", cfg->n_user, EMB);
         add_tensor(g, "item_emb", cfg->n_item, EMB);
+        if (cfg->kind == MAMDR_GRAPH_NFM) {     // their 1-d linear tables train with them (deepctr: same feature column)
+            g->lin_u_off = add_tensor(g, "lin_user", cfg->n_user, 1);
+            g->lin_i_off = add_tensor(g, "lin_item", cfg->n_item, 1);
+        }
         g->table_floats = g->n_params;
     }
     g->dm_off = add_tensor(g, "domain_emb", cfg->n_domain, EMB);
@@ -766,9 +927,46 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         shared.push_back(add_dnn(g, nm, XDIM, cfg->expert_hidden, cfg->n_expert_hidden, next_id));
     }
     g->shared_end = g->n_params;
-    g->tasks.resize(cfg->n_domain);
+    g->tasks.resize(single ? 1 : cfg->n_domain);
     int max_cols = 0;
-    for (int d = 0; d < cfg->n_domain; ++d) {
+    if (single) {
+        // oracle/fmnets.py param_names: domain_emb | W0 W1 W2 | b0 b1 b2 | wo | gb | (NFM) lin_domain -- one block, all of it
+        // trained by every step.  NFM: DNN on the 128 interaction columns; PNN: on x (+ 3 inner products into W0's last rows)
+        Task& t = g->tasks[0];
+        Dnn d;
+        d.name = "dnn";
+        const int nfm = cfg->kind == MAMDR_GRAPH_NFM;
+        d.in_dim = nfm ? EMB : XDIM;
+        int in = d.in_dim;
+        for (int l = 0; l < cfg->n_expert_hidden; ++l) {
+            Layer L;
+            L.in = in;
+            L.out = cfg->expert_hidden[l];
+            L.w_off = add_tensor(g, "W" + std::to_string(l), (l == 0 && !nfm) ? in + 3 : in, L.out);
+            L.b_off = 0;
+            L.id = (uint32_t)l;
+            d.layers.push_back(L);
+            in = L.out;
+        }
+        for (int l = 0; l < cfg->n_expert_hidden; ++l) d.layers[l].b_off = add_tensor(g, "b" + std::to_string(l), 1, d.layers[l].out);
+        g->dnns.push_back(d);
+        t.tower = 0;
+        t.head_w = add_tensor(g, "wo", in, 1);
+        t.head_gb = add_tensor(g, "gb", 1, 1);
+        if (nfm) g->lin_d_off = add_tensor(g, "lin_domain", cfg->n_domain, 1);
+        g->shared_end = g->n_params;
+        t.blk_off = t.blk_end = g->n_params;
+        int c = XDIM;
+        g->f_col = c;
+        c += nfm ? EMB : 4;
+        t.path.push_back(0);
+        std::vector<int> cols;
+        for (const Layer& L : d.layers) { cols.push_back(c); c += L.out; }
+        t.col.push_back(cols);
+        t.n_cols = c;
+        max_cols = c;
+    }
+    for (int d = 0; d < (single ? 0 : cfg->n_domain); ++d) {
         Task& t = g->tasks[d];
         t.blk_off = g->n_params;
         for (int e = 0; e < n_specific; ++e)
@@ -830,6 +1028,13 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     alloc((void**)&g->frozen_sumsq, 4 * sizeof(float));
     alloc((void**)&g->sumsq_partials, 1024 * sizeof(float));
     alloc((void**)&g->eval_acc, 4 * sizeof(float));
+    if (cfg->kind == MAMDR_GRAPH_NFM) {
+        alloc((void**)&g->extra, rp * sizeof(float));
+        if (g->tables) {
+            alloc((void**)&g->glin_u, rp * sizeof(float));
+            alloc((void**)&g->glin_i, rp * sizeof(float));
+        }
+    }
     if (e == hipSuccess) e = hipMemsetAsync(g->grad, 0, (size_t)(g->n_params - g->table_floats) * sizeof(float), g->stream);
     if (g->tables && e == hipSuccess) {
         e = hipMemsetAsync(g->hasdup_u, 0, rp * sizeof(int32_t), g->stream);
@@ -856,7 +1061,7 @@ int mamdr_graph_destroy(mamdr_graph* g) {
     (void)hipStreamSynchronize(g->stream);
     void* ptrs[] = {g->act, g->dact, g->grad, g->dlogit, g->rowloss, g->y, g->domrow, g->thresholds, g->frozen_sumsq,
                     g->sumsq_partials, g->eval_acc, g->urow, g->irow, g->map_u, g->map_i, g->hasdup_u, g->hasdup_i,
-                    g->gbuf_u, g->gbuf_i};
+                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -884,8 +1089,9 @@ int mamdr_graph_task_ranges(const mamdr_graph* g, int domain, int64_t* shared_of
     if (domain < 0 || domain >= g->cfg.n_domain) return gfail(MAMDR_EINVAL, "domain out of range");
     *shared_off = g->dm_off;
     *shared_count = g->shared_end - g->dm_off;
-    *task_off = g->tasks[domain].blk_off;
-    *task_count = g->tasks[domain].blk_end - g->tasks[domain].blk_off;
+    const Task& t = g->tasks[g->single ? 0 : domain];
+    *task_off = t.blk_off;
+    *task_count = t.blk_end - t.blk_off;
     return MAMDR_OK;
 }
 
@@ -961,7 +1167,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
     if (first_step + n_steps > pass_steps)
         return gfail(MAMDR_EINVAL, "steps [%lld,%lld) exceed the %lld batches of domain %d", (long long)first_step,
                      (long long)(first_step + n_steps), (long long)pass_steps, domain);
-    const Task& t = g->tasks[domain];
+    const Task& t = g->tasks[g->single ? 0 : domain];
     const float rate = g->cfg.dropout;
     double thr = (double)rate * 4294967296.0;
     const float omb1 = 1.0f - g->cfg.adam_beta1, omb2 = 1.0f - g->cfg.adam_beta2;
@@ -1003,17 +1209,15 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         ha.rows_pad = sc.rp;
         ha.dlogit = g->dlogit;
         ha.rowloss = g->rowloss;
+        ha.extra = g->extra;
         ha.train = 1;
         ha.gate_scale = sc.keep_scale;
         hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
-        if (d_loss_out && g->tables) {
-            launch_sumsq(g->params, (int64_t)g->cfg.n_user * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
-            launch_sumsq(g->params + (size_t)g->cfg.n_user * EMB, (int64_t)g->cfg.n_item * EMB, g->sumsq_partials,
-                         g->frozen_sumsq + 1, g->stream);
-        }
+        if (d_loss_out && g->tables) refresh_sumsq(g);
         if (d_loss_out)
             hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
-                               g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out + s, 0);
+                               g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out + s, 0,
+                               g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear);
         // ---- backward
         // head: dw = t^T dlogit, dgb = sum dlogit
         hipLaunchKernelGGL(k_graph_small_tn, dim3((ha.n_t + 255) / 256), dim3(256), 0, g->stream, g->act + t_col, g->ld, g->dlogit, 1,
@@ -1024,7 +1228,26 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         // tables are frozen): the first writer overwrites, the others add
         bool dx_started = false;
         const int dx_first = g->tables ? 0 : 2 * EMB, dx_n = g->tables ? 0 : EMB;
-        if (g->gated) {
+        if (g->single) {
+            const bool nfm = g->cfg.kind == MAMDR_GRAPH_NFM;
+            FeatArgs fa;
+            fill_feat(g, t, sc, fa);
+            if (nfm) {
+                // d(interaction columns) from the first layer, then d x = df (sum of the other two fields)
+                dnn_backward(g, tower, t.col[0], g->f_col, g->f_col, -1, false, 0, 0, sc);
+            } else {
+                // rows 0..383 of the first kernel as any first layer on x; rows 384..386 against the inner products
+                dnn_backward(g, tower, t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
+                const Layer& L0 = tower.layers[0];
+                hipLaunchKernelGGL(k_graph_small_tn, dim3((3 * L0.out + 255) / 256), dim3(256), 0, g->stream, g->act + g->f_col, g->ld,
+                                   g->dact + t.col[0][0], g->ld, sc.rp, 3, L0.out, g->G(L0.w_off + (int64_t)L0.in * L0.out));
+            }
+            hipLaunchKernelGGL(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
+            if (nfm)
+                hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3((g->cfg.n_domain + 63) / 64), dim3(64), 0, g->stream, g->dlogit,
+                                   g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
+                                   g->G(g->lin_d_off));
+        } else if (g->gated) {
             dnn_backward(g, tower, t.col[ti], t.m_col, t.m_col, -1, false, 0, 0, sc);
             GateArgs gta;
             fill_gate(g, t, sc, gta);
@@ -1075,8 +1298,20 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             ea.t[1].gbuf = g->gbuf_i;
             ea.t[1].hasdup = g->hasdup_i;
             ea.t[1].dx_off = EMB;
+            if (g->cfg.kind == MAMDR_GRAPH_NFM) {       // their 1-d linear tables: scatter-add of d loss / d logit, same rule
+                ea.two_l2_lin = 2.0f * g->cfg.l2_linear;
+                ea.t[0].lin_p = g->params + g->lin_u_off;
+                ea.t[0].lin_m = g->adam_m + g->lin_u_off;
+                ea.t[0].lin_v = g->adam_v + g->lin_u_off;
+                ea.t[0].glin = g->glin_u;
+                ea.t[1].lin_p = g->params + g->lin_i_off;
+                ea.t[1].lin_m = g->adam_m + g->lin_i_off;
+                ea.t[1].lin_v = g->adam_v + g->lin_i_off;
+                ea.t[1].glin = g->glin_i;
+            }
             launch_emb_reduce(ea, g->stream);
             launch_emb_sweep(ea, g->stream);
+            if (g->cfg.kind == MAMDR_GRAPH_NFM) launch_lin_sweep(ea, g->stream);      // (reads the row maps, then resets them)
         }
         // ---- optimiser on the two ranges this task's model trains
         const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
@@ -1087,6 +1322,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             aa.v = g->adam_v + off[k];
             aa.g = g->G(off[k]);
             aa.n4 = cnt[k] / 4;
+            if (aa.n4 == 0) continue;
             aa.optimizer = optimizer;
             aa.alpha = alpha;
             aa.omb1 = omb1;
@@ -1109,14 +1345,10 @@ int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch
     if (batch <= 0 || batch > g->cfg.max_batch) return gfail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, g->cfg.max_batch);
     if (!d_loss_out || !d_hist) return gfail(MAMDR_EINVAL, "null output pointer");
     if (d->n <= 0) return gfail(MAMDR_EINVAL, "empty split");
-    const Task& t = g->tasks[domain];
+    const Task& t = g->tasks[g->single ? 0 : domain];
     GHIP(hipMemsetAsync(d_hist, 0, 2 * 501 * sizeof(uint32_t), g->stream));
     GHIP(hipMemsetAsync(g->eval_acc, 0, sizeof(float), g->stream));
-    if (g->tables) {
-        launch_sumsq(g->params, (int64_t)g->cfg.n_user * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
-        launch_sumsq(g->params + (size_t)g->cfg.n_user * EMB, (int64_t)g->cfg.n_item * EMB, g->sumsq_partials,
-                     g->frozen_sumsq + 1, g->stream);
-    }
+    if (g->tables) refresh_sumsq(g);
     const int64_t n_batches = (d->n + batch - 1) / batch;
     for (int64_t b = 0; b < n_batches; ++b) {
         StepCtx sc;
@@ -1143,13 +1375,15 @@ int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch
         ha.rows_pad = sc.rp;
         ha.dlogit = g->dlogit;
         ha.rowloss = g->rowloss;
+        ha.extra = g->extra;
         ha.gate_scale = 1.0f;
         ha.thresholds = g->thresholds;
         ha.hist = d_hist;
         ha.pred_out = d_pred_out ? d_pred_out + row_base : nullptr;
         hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
         hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
-                           g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, g->eval_acc, 1);
+                           g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, g->eval_acc, 1,
+                           g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear);
     }
     hipLaunchKernelGGL(k_graph_scale, dim3(1), dim3(1), 0, g->stream, g->eval_acc, 1.0f / (float)n_batches);
     GHIP(hipMemcpyAsync(d_loss_out, g->eval_acc, sizeof(float), hipMemcpyDeviceToDevice, g->stream));

@@ -59,7 +59,49 @@ def auc_from_histogram(hist):
     return float(np.sum((fpr[:-1] - fpr[1:]) * heights, dtype=np.float32)), (tp, fp, tn, fn)
 
 
-class TowerEngine(object):
+class FlatVectorOps(object):
+    """the outer (meta) updates on flat device vectors: stateless entry points of the library, shared by every engine
+    (bit-exact vs the reference's numpy, see include/mamdr_hip.h).  Needs self.lib, self.stream, self.weights."""
+
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    # outer updates (bit-exact vs the reference's numpy, see include/mamdr_hip.h)
+    def interp(self, dst, a, b, scale):
+        L.check(self.lib.mamdr_interp(_ptr(dst), _ptr(a), _ptr(b), float(scale), dst.numel(), self._s()))
+
+    def merge(self, dst, theta, phi, method="plus"):
+        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        L.check(self.lib.mamdr_merge(_ptr(dst), _ptr(theta), _ptr(phi), mode, dst.numel(), self._s()))
+
+    def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
+        """one DR support step in a single pass: phi += (live - merged) * gamma; merged = theta (+|*) phi; and, for
+        the next support, model := merged (mamdr.py:103-105,74) -- bit-identical to interp + merge + set_weights."""
+        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        # self.weights (not _weights): the live table rows must be brought up to the current Adam step before they
+        # are read into phi / replaced by merged (include/mamdr_hip.h: sync before reading or replacing the state)
+        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self.weights), _ptr(merged), _ptr(theta), float(gamma), mode,
+                                          1 if assign_model else 0, phi.numel(), self._s()))
+
+    def sub(self, dst, a, b):
+        L.check(self.lib.mamdr_sub(_ptr(dst), _ptr(a), _ptr(b), dst.numel(), self._s()))
+
+    def accumulate(self, acc, a, b, shared=None, divisor=1.0):
+        L.check(self.lib.mamdr_accumulate(_ptr(acc), _ptr(a), _ptr(b), _ptr(shared), float(divisor),
+                                          acc.numel(), self._s()))
+
+    def apply_accumulated(self, dst, acc, divisor, scale):
+        L.check(self.lib.mamdr_apply_accumulated(_ptr(dst), _ptr(acc), float(divisor), float(scale),
+                                                 dst.numel(), self._s()))
+
+
+    def adam_apply(self, p, m, v, g, lr, beta1_power, beta2_power, grad_scale=1.0):
+        """outer TF1 Adam on flat vectors (maml.py:236-243)."""
+        L.check(self.lib.mamdr_adam_apply(_ptr(p), _ptr(m), _ptr(v), _ptr(g), float(grad_scale), float(lr), 0.9, 0.999,
+                                          1e-8, float(beta1_power), float(beta2_power), p.numel(), self._s()))
+
+
+class TowerEngine(FlatVectorOps):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False,
                  tower="mlp", emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None,
                  dropout_seed=1024, l2_linear=1e-5, uncertainty_weight=False):
@@ -201,37 +243,6 @@ class TowerEngine(object):
         L.check(self.lib.mamdr_copy(_ptr(out), _ptr(self.weights), self.n_params, self._s()))
         return out
 
-    def _s(self):
-        return C.c_void_p(self.stream.cuda_stream)
-
-    # outer updates (bit-exact vs the reference's numpy, see include/mamdr_hip.h)
-    def interp(self, dst, a, b, scale):
-        L.check(self.lib.mamdr_interp(_ptr(dst), _ptr(a), _ptr(b), float(scale), dst.numel(), self._s()))
-
-    def merge(self, dst, theta, phi, method="plus"):
-        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
-        L.check(self.lib.mamdr_merge(_ptr(dst), _ptr(theta), _ptr(phi), mode, dst.numel(), self._s()))
-
-    def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
-        """one DR support step in a single pass: phi += (live - merged) * gamma; merged = theta (+|*) phi; and, for
-        the next support, model := merged (mamdr.py:103-105,74) -- bit-identical to interp + merge + set_weights."""
-        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
-        # self.weights (not _weights): the live table rows must be brought up to the current Adam step before they
-        # are read into phi / replaced by merged (include/mamdr_hip.h: sync before reading or replacing the state)
-        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self.weights), _ptr(merged), _ptr(theta), float(gamma), mode,
-                                          1 if assign_model else 0, phi.numel(), self._s()))
-
-    def sub(self, dst, a, b):
-        L.check(self.lib.mamdr_sub(_ptr(dst), _ptr(a), _ptr(b), dst.numel(), self._s()))
-
-    def accumulate(self, acc, a, b, shared=None, divisor=1.0):
-        L.check(self.lib.mamdr_accumulate(_ptr(acc), _ptr(a), _ptr(b), _ptr(shared), float(divisor),
-                                          acc.numel(), self._s()))
-
-    def apply_accumulated(self, dst, acc, divisor, scale):
-        L.check(self.lib.mamdr_apply_accumulated(_ptr(dst), _ptr(acc), float(divisor), float(scale),
-                                                 dst.numel(), self._s()))
-
     def segment_shapes(self):
         """{segment: (slices along the last axis, slice length)} of the Keras variables behind the segments --
         what numpy's axis=-1 reductions in the reference's PCGrad see (model_zoo/pcgrad.py:152-160)."""
@@ -365,11 +376,6 @@ class TowerEngine(object):
         self._ema = {"momentum": float(momentum), "step": 0, "biased": self.new_vector(), "scratch": self.new_vector()}
         if self._acc is not None:
             self.bind_accumulator(self._acc)
-
-    def adam_apply(self, p, m, v, g, lr, beta1_power, beta2_power, grad_scale=1.0):
-        """outer TF1 Adam on flat vectors (maml.py:236-243)."""
-        L.check(self.lib.mamdr_adam_apply(_ptr(p), _ptr(m), _ptr(v), _ptr(g), float(grad_scale), float(lr), 0.9, 0.999,
-                                          1e-8, float(beta1_power), float(beta2_power), p.numel(), self._s()))
 
     def optimizer_reset(self):
         L.check(self.lib.mamdr_optimizer_reset(self.ctx))

@@ -15,9 +15,9 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .engine import _ptr, auc_from_histogram
+from .engine import FlatVectorOps, _ptr, auc_from_histogram
 
-KINDS = {"shared_bottom": L.GRAPH_SHARED_BOTTOM, "mmoe": L.GRAPH_MMOE, "ple": L.GRAPH_PLE}
+KINDS = {"shared_bottom": L.GRAPH_SHARED_BOTTOM, "mmoe": L.GRAPH_MMOE, "ple": L.GRAPH_PLE, "nfm": L.GRAPH_NFM, "pnn": L.GRAPH_PNN}
 
 
 def _arr4(values):
@@ -25,10 +25,10 @@ def _arr4(values):
     return (C.c_int32 * 4)(*v)
 
 
-class GraphEngine(object):
+class GraphEngine(FlatVectorOps):
     def __init__(self, kind, n_user, n_item, n_domain, batch_size, expert_hidden, tower_hidden, gate_hidden=(),
                  num_experts=0, shared_expert_num=0, specific_expert_num=0, dropout=0.5, emb_trainable=False, emb_dim=128,
-                 l2_emb=1e-5, device=None, dropout_seed=1024):
+                 l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("GraphEngine needs a HIP device (no CPU fallback)")
@@ -47,7 +47,8 @@ class GraphEngine(object):
         cfg = L.GraphConfig(L.ABI_VERSION, KINDS[kind], self.n_user, self.n_item, self.n_domain, emb_dim, max_batch,
                             1 if emb_trainable else 0, len(expert_hidden), _arr4(expert_hidden), len(tower_hidden),
                             _arr4(tower_hidden), len(gate_hidden), _arr4(gate_hidden), int(num_experts),
-                            int(shared_expert_num), int(specific_expert_num), float(dropout), float(l2_emb), 0.9, 0.999, 1e-8)
+                            int(shared_expert_num), int(specific_expert_num), float(dropout), float(l2_emb), 0.9, 0.999, 1e-8,
+                            float(l2_linear))
         handle = C.c_void_p()
         L.check(self.lib.mamdr_graph_create(C.byref(cfg), C.c_void_p(self.stream.cuda_stream), C.byref(handle)), graph=True)
         self.ctx = handle

@@ -4,8 +4,9 @@
 containing `mlp` build the 3 x 128-d embedding -> DNN(hidden_dim) -> Dense(1) -> sigmoid
 tower (deepctr.py:95-136) on the HIP engine; names containing `deepfm` add the linear
 tables and the FM second-order term to the logit (deepctr.py:36-38, SURVEY A.8);
-`wdl` is the same without the FM term (deepctr.py:29-32); nfm / autoint / ccpm / pnn are out of scope
- and raise.  Initial tensors follow the reference's initialisers (glorot normal for the
+`wdl` is the same without the FM term (deepctr.py:29-32); `nfm` (deepctr.py:33-35: linear tables + DNN over the
+bi-interaction of the three fields) and `pnn` (deepctr.py:44-46: DNN over the fields and their pairwise inner
+products) run on the generic-layer engine (`GraphEngine`, csrc/graph_engine.hip); autoint / ccpm raise.  Initial tensors follow the reference's initialisers (glorot normal for the
 kernels, zeros for biases, N(0, 1e-4^2) for the domain table and for user/item tables
 without pretraining, constants from the pretrained tables otherwise) drawn from a numpy
 stream seeded with dataset.seed -- TF's own streams are not reproducible.
@@ -16,7 +17,8 @@ import numpy as np
 
 from .base_model import BaseModel
 
-OUT_OF_SCOPE = ("nfm", "autoint", "ccpm", "pnn")
+OUT_OF_SCOPE = ("autoint", "ccpm")
+GRAPH_TOWERS = ("nfm", "pnn")
 
 
 def glorot_normal(rs, fan_in, fan_out, shape):
@@ -62,9 +64,13 @@ class DeepCTR(BaseModel):
             tower = "mlp"
         elif "wdl" in name:               # deepctr.py:29-32: linear tables + DNN (DeepFM without the FM term)
             tower = "wdl"
-        elif any(k in name for k in OUT_OF_SCOPE):
-            raise NotImplementedError("tower '%s': deepctr WDL/NFM/AutoInt/CCPM/PNN are outside the hot path "
-                                      "(SURVEY.md section 2.1) and are not built" % name)
+        elif "nfm" in name:               # deepctr.py:33-35
+            tower = "nfm"
+        elif any(k in name for k in OUT_OF_SCOPE):     # deepctr.py:37-43
+            raise NotImplementedError("tower '%s': deepctr AutoInt (multi-head self-attention over the fields) and CCPM "
+                                      "(convolution + k-max pooling) are not built" % name)
+        elif "pnn" in name:               # deepctr.py:44-46
+            tower = "pnn"
         elif "deepfm" in name:
             tower = "deepfm"
         else:
@@ -77,7 +83,15 @@ class DeepCTR(BaseModel):
         if not (mc["user_dim"] == mc["item_dim"] == mc["domain_dim"]):
             raise ValueError("user_dim, item_dim and domain_dim must be equal")
         factory = self.engine_factory
-        if factory is None:
+        if tower in GRAPH_TOWERS:         # generic-layer engine; an injected factory offers it as `.graph` (tests)
+            if factory is not None:
+                factory = getattr(factory, "graph", None)
+                if factory is None:
+                    raise NotImplementedError("the injected engine factory has no '%s' tower" % tower)
+            else:
+                from ..graph_engine import GraphEngine
+                factory = GraphEngine
+        elif factory is None:
             from ..engine import TowerEngine
             factory = TowerEngine
         kw = {}
@@ -86,9 +100,17 @@ class DeepCTR(BaseModel):
         # deepctr.py:104-116: `trainable=emb_trainable` reaches SparseFeat only on the pretrained branch; without
         # pretrained tables the column is built with deepctr's default (trainable) WHATEVER emb_trainable says
         self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
-        eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
-                      emb_trainable=self.tables_trainable, tower=tower, emb_dim=mc["user_dim"],
-                      hidden=tuple(mc["hidden_dim"]), **kw)
+        if tower in GRAPH_TOWERS:
+            if kw:
+                raise NotImplementedError("uncertainty weighting on the '%s' tower is not built" % tower)
+            eng = factory(tower, self.n_uid, self.n_pid, self.n_domain, self.batch_size, expert_hidden=tuple(mc["hidden_dim"]),
+                          tower_hidden=(), dropout=mc.get("dropout", 0.0), emb_trainable=self.tables_trainable,
+                          emb_dim=mc["user_dim"])
+        else:
+            eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
+                          emb_trainable=self.tables_trainable, tower=tower, emb_dim=mc["user_dim"],
+                          hidden=tuple(mc["hidden_dim"]), **kw)
+        self.tower = tower
         self.init_rs = np.random.RandomState(self.dataset.seed)
         pre = bool(tc["load_pretrain_emb"])
         self.pretrained = (self.dataset.user_emb, self.dataset.item_emb) if pre else (None, None)
@@ -114,8 +136,14 @@ class DeepCTR(BaseModel):
 
     def draw_initial_tensors(self):
         mc = self.model_config
-        return initial_tensors(self.init_rs, self.n_uid, self.n_pid, self.n_domain, mc["user_dim"],
-                               tuple(mc["hidden_dim"]), self.pretrained[0], self.pretrained[1])
+        t = initial_tensors(self.init_rs, self.n_uid, self.n_pid, self.n_domain, mc["user_dim"],
+                            tuple(mc["hidden_dim"]), self.pretrained[0], self.pretrained[1])
+        tower = getattr(self, "tower", None)
+        if tower in GRAPH_TOWERS:         # first kernel: NFM on the 128 interaction columns, PNN on the fields + 3 inner products
+            E, h0 = mc["user_dim"], mc["hidden_dim"][0]
+            in_dim = E if tower == "nfm" else 3 * E + 3
+            t["W0"] = glorot_normal(self.init_rs, in_dim, h0, (in_dim, h0))
+        return t
 
     def train(self):
         """alternate ('joint') training, deepctr.py:63-93."""

@@ -95,6 +95,37 @@ def star_forward(P, state, uid, pid, dom, training):
     return torch.sigmoid(logit), mean.detach(), var.detach()
 
 
+def fmnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64):
+    """deepctr NFM / PNN (deepctr.py:33-35,44-46), float64 autograd.  NFM: linear tables + DNN(BiInteractionPooling of the
+    three fields); PNN: DNN([fields | inner products of the field pairs (0,1), (0,2), (1,2)]).  l2 1e-5 on the tables
+    (+ the linear tables for NFM)."""
+    P = _as_tensors(params, names, dtype, set(names))
+    ui, pi, di = (torch.from_numpy(np.asarray(a, np.int64)) for a in (uid, pid, dom))
+    y = torch.from_numpy(np.asarray(label, np.float32)).to(dtype)
+    u, i, d = _rows(P["user_emb"], ui), _rows(P["item_emb"], pi), _rows(P["domain_emb"], di)
+    if kind == "nfm":
+        s = u + i + d
+        h = 0.5 * (s * s - (u * u + i * i + d * d))
+    else:
+        ip = torch.stack([(u * i).sum(1), (u * d).sum(1), (i * d).sum(1)], dim=1)
+        h = torch.cat([u, i, d, ip], dim=1)
+    keep = 1.0 / (1.0 - rate) if masks is not None else 1.0
+    for l in range(3):
+        h = torch.relu(torch.addmm(P["b%d" % l], h, P["W%d" % l]))
+        if masks is not None:
+            h = h * keep * torch.from_numpy(np.asarray(masks[l], np.float32)).to(dtype)
+    logit = (h @ P["wo"])[:, 0] + P["gb"][0]
+    reg = L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum())
+    if kind == "nfm":
+        logit = logit + P["lin_user"][ui] + P["lin_item"][pi] + P["lin_domain"][di]
+        reg = reg + L2_LIN * (P["lin_user"].pow(2).sum() + P["lin_item"].pow(2).sum() + P["lin_domain"].pow(2).sum())
+    p = torch.sigmoid(logit)
+    loss = keras_bce(p, y).mean() + reg
+    grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
+    g = {n: (gr.numpy() if gr is not None else np.zeros(params[n].shape)) for n, gr in zip(names, grads)}
+    return float(loss.detach()), g, p.detach().numpy()
+
+
 def mtl_forward(P, spec, d, uid, pid, dom, masks, keep_scale):
     """multi-task towers (deep_mtl_ctr.py:21-49; deepctr SharedBottom / MMOE / PLE with num_levels = 1), output of task d:
     experts = DNN(hidden_dim) on x; MMOE / PLE: gate_d = softmax(DNN(gate_dnn_hidden_units)(x) . Wg_d) over the experts

@@ -258,3 +258,31 @@ class FakeGraphEngine(object):
 
     def close(self):
         pass
+
+
+class FakeFmEngine(FakeEngine):
+    """CPU stand-in for GraphEngine's single-output kinds (nfm / pnn), built on oracle/fmnets.py (tests only)."""
+
+    def __init__(self, kind, n_user, n_item, n_domain, batch_size, expert_hidden, tower_hidden=(), dropout=0.5,
+                 emb_trainable=False, emb_dim=128, **kw):
+        from oracle import fmnets as ofm
+        if kind not in ("nfm", "pnn"):
+            raise NotImplementedError(kind)
+        self.tower = self.kind = kind
+        self.n_user, self.n_item, self.n_domain = n_user, n_item, n_domain
+        self.batch_size = batch_size
+        self.device = torch.device("cpu")
+        self.dropout_seed = 1024
+        params = ofm.init_params(np.random.RandomState(0), kind, n_user, n_item, n_domain, emb_dim, tuple(expert_hidden))
+        self.oracle = ofm.OracleNet(params, kind, emb_trainable=emb_trainable, dropout=dropout, hidden=tuple(expert_hidden))
+        self.segments, off = {}, 0
+        for name in self.oracle.names:
+            self.segments[name] = (off, params[name].size)
+            off += params[name].size
+        self.n_params = self.n_meta = off
+        self.data, self.calls = {}, []
+        self._ema = None
+        self.aux = None
+
+
+FakeEngine.graph = FakeFmEngine

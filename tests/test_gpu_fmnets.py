@@ -1,0 +1,161 @@
+"""GPU parity of deepctr's NFM and PNN towers (model_zoo/DeepCTR/deepctr.py:33-35,44-46): the
+generic-layer HIP engine (`mamdr_graph_*`, kinds MAMDR_GRAPH_NFM / MAMDR_GRAPH_PNN) against oracle/fmnets.py (parity
+unpinned: deepctr is not in the reference tree; the oracle's gradients are held to float64 autograd in
+tests/test_oracle_crosscheck.py).  Bars as for the other towers: one-step gradients rtol 2e-4, loss 2e-6, evaluation
+predictions rtol 2e-5, per-domain AUC within 1e-3 after a Domain Negotiation run on the tower.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import auc as oauc          # noqa: E402
+from oracle import fmnets as ofm        # noqa: E402
+from oracle import loops as oloops      # noqa: E402
+from oracle import rng as orng          # noqa: E402
+from oracle import tower as otower      # noqa: E402
+
+F32 = np.float32
+HIDDEN = (256, 128, 64)
+
+
+def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable=False):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import graph_engine, synthetic
+    g = synthetic.generate("taobao10", batch_size=batch, seed=seed, scale=scale)
+    D = g["n_domain"]
+    rs = np.random.RandomState(seed)
+    params = ofm.init_params(rs, kind, g["n_user"], g["n_item"], D, hidden=HIDDEN)
+    params["user_emb"], params["item_emb"] = g["tables"]["user_emb"].copy(), g["tables"]["item_emb"].copy()
+    params["domain_emb"] = (rs.standard_normal(params["domain_emb"].shape) * 0.05).astype(F32)
+    for n in ("b0", "b1", "b2", "lin_domain", "lin_user", "lin_item"):
+        params[n] = (rs.standard_normal(params[n].shape) * 0.05).astype(F32)
+    params["gb"] = np.array([0.1], F32)
+    if not emb_trainable:           # frozen linear tables stay at their zero initialisation (deepctr: same feature column)
+        params["lin_user"][...] = 0
+        params["lin_item"][...] = 0
+    eng = graph_engine.GraphEngine(kind, g["n_user"], g["n_item"], D, batch, HIDDEN, (), dropout=dropout,
+                                   emb_trainable=emb_trainable)
+    if not emb_trainable:
+        eng.bind_table("user_emb", params["user_emb"])
+        eng.bind_table("item_emb", params["item_emb"])
+    for split in ("train", "val", "test"):
+        for d in range(D):
+            c = g["data"][split][d]
+            eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
+    names = list(ofm.param_names(kind, emb_trainable))
+    assert list(eng.segments) == names, (list(eng.segments), names)
+    eng.set_weights(eng.pack(params))
+    model = ofm.OracleNet({k: v.copy() for k, v in params.items()}, kind, emb_trainable=emb_trainable, dropout=dropout,
+                          lr=1e-3, hidden=HIDDEN, dropout_seed=eng.dropout_seed)
+    return g, eng, model
+
+
+@pytest.mark.parametrize("kind", ["nfm", "pnn"])
+@pytest.mark.parametrize("emb_trainable", [False, True])
+def test_one_step_gradients_match_oracle(kind, emb_trainable):
+    g, eng, model = make_problem(kind, dropout=0.5, scale=0.1 if emb_trainable else 0.05, emb_trainable=emb_trainable)
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = {k: v.copy() for k, v in g["data"]["train"][d].items()}
+    cols["domain"] = (np.arange(cols["domain"].shape[0]) % 3).astype(np.int32)      # mixed domain ids in one batch
+    eng.bind_domain_data(d, "train", cols["uid"], cols["pid"], cols["domain"], cols["label"])
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=11)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_step = -(-n // 256)
+    for step in (0, n_step - 1):
+        idx = perm[step * 256:(step + 1) * 256]
+        masks = otower.train_masks(model.seed, model.step, len(idx), HIDDEN, 0.5)
+        loss, grads, _ = ofm.loss_and_grads(model.params, kind, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                            cols["label"][idx], masks, 0.5, emb_trainable, model.frozen_sumsq())
+        loss_t = torch.zeros(1, device=eng.device)
+        w0 = eng.get_weights()
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = eng.unpack(w0 - eng.get_weights())
+        eng.set_weights(w0)
+        model.step += 1
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+        for name, want in grads.items():
+            want = want.ravel()
+            floor = 4e-8 if name in ("user_emb", "item_emb") else 1.5e-8       # read back as w0 - (w0 - g): the weights' ulp
+            np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * max(np.abs(want).max(), 1e-3), floor),
+                                       err_msg=name)
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["nfm", "pnn"])
+def test_adam_pass_and_eval(kind):
+    g, eng, model = make_problem(kind, dropout=0.5)
+    d = 9
+    cols = g["data"]["train"][d]
+    perm = orng.shuffle_perm(cols["uid"].shape[0], 10000, seed=3)
+    n_steps = min(6, -(-perm.shape[0] // 256))
+    losses_t = torch.zeros(n_steps, device=eng.device)
+    eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), n_steps=n_steps, lr=1e-3, loss_out=losses_t)
+    want_losses = model.train_pass(cols, perm, 256, max_steps=n_steps)
+    np.testing.assert_allclose(losses_t.cpu().numpy(), np.array(want_losses, F32), rtol=2e-5, atol=2e-6)
+    got = eng.unpack(eng.get_weights())
+    for name in model.names:
+        diff = np.abs(got[name].reshape(model.params[name].shape) - model.params[name]).max()
+        assert diff < 0.05 * n_steps * 1e-3, (name, diff)
+    for dd in (0, 5):
+        c = g["data"]["val"][dd]
+        loss, auc, hist, preds = eng.evaluate(dd, "val", want_preds=True)
+        loss_o, preds_o = model.evaluate(c, 256)
+        np.testing.assert_allclose(preds, preds_o, rtol=3e-3, atol=3e-5)
+        assert abs(loss - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))
+    eng.close()
+
+
+def test_eval_predictions_at_equal_weights():
+    for kind in ("nfm", "pnn"):
+        g, eng, model = make_problem(kind)
+        for d in (1, 5):
+            c = g["data"]["test"][d]
+            loss, auc, hist, preds = eng.evaluate(d, "test", want_preds=True)
+            loss_o, preds_o = model.evaluate(c, 256)
+            np.testing.assert_allclose(preds, preds_o, rtol=2e-5, atol=2e-7)
+            assert abs(loss - float(loss_o)) < 2e-6 * max(1.0, abs(float(loss_o)))
+            assert abs(auc - float(oauc.auc500(c["label"], preds_o, 256))) < 1e-4
+        eng.close()
+
+
+@pytest.mark.parametrize("kind", ["nfm", "pnn"])
+def test_domain_negotiation_auc_parity(kind):
+    """the meta wrappers run on these towers too (deepctr.py's registry is orthogonal to run.py's wrappers): three
+    Domain Negotiation epochs (domain_negotiation.py:49-88) on 4 domains, same order / shuffles / masks on both sides,
+    per-domain validation AUC within 1e-3."""
+    from mamdr_amd import meta, synthetic
+    g, eng, model = make_problem(kind, scale=0.15)
+    D = 4
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+
+    def make_perm_fn():
+        k = [0]
+
+        def f(d):
+            k[0] += 1
+            return orng.shuffle_perm(sizes[d], 10000, seed=700 + k[0])
+        return f
+    theta_o = model.get_flat().copy()
+    theta_g = eng.get_weights()
+    pf_o, pf_g = make_perm_fn(), make_perm_fn()
+    for seq in ([2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3]):
+        tr_o = oloops.dn_epoch(model, theta_o, g["data"]["train"], seq, pf_o, 256, 0.5)
+        tr_g = meta.dn_epoch(eng, theta_g, seq, pf_g, 256, lr=1e-3, meta_lr=0.5)
+        assert tr_o == tr_g
+    eng.set_weights(theta_g)
+    model.set_flat(theta_o)
+    aucs = []
+    for d in range(D):
+        _, auc_g = eng.evaluate(d, "val")
+        _, preds = model.evaluate(g["data"]["val"][d], 256)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
+        print("%s domain %d: AUC hip %.5f oracle %.5f" % (kind, d, auc_g, auc_o))
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+        aucs.append(auc_o)
+    assert np.mean(aucs) > 0.6
+    eng.close()

@@ -65,9 +65,12 @@ def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_uncertainty_weight"), ds, FakeEngine)) is UncertaintyWeight
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_pcgrad"), ds, FakeEngine)) is PCGrad
     assert type(cli.build_model(tiny_config(tmp_path, "wdl"), ds, FakeEngine)) is DeepCTR
-    for bad in ("mmoe", "nfm"):
+    for bad in ("autoint", "ccpm"):             # deepctr.py:37-43: not built
         with pytest.raises(NotImplementedError):
             cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
+    for name in ("nfm", "pnn"):                 # deepctr.py:33-35,44-46: the generic-layer engine (factory.graph)
+        m = cli.build_model(tiny_config(tmp_path, name), ds, FakeEngine)
+        assert type(m) is DeepCTR and m.model.kind == name
     with pytest.raises(NotImplementedError):      # the CPU stand-in engine has no Star tower (the HIP engine does)
         cli.build_model(tiny_config(tmp_path, "star_meta_mamdr"), ds, FakeEngine)
     with pytest.raises(ValueError):
@@ -582,3 +585,13 @@ def test_mtl_ple_levels_and_trainable_tables_are_named(tmp_path, monkeypatch):
     ds = mds.MultiDomainDataset(cfg["dataset"])
     with pytest.raises(NotImplementedError, match="num_levels"):
         cli.build_model(cfg, ds, FakeGraphEngine)
+
+
+@pytest.mark.parametrize("name", ["nfm", "pnn", "nfm_meta_domain_negotiation"])
+def test_nfm_pnn_run_entry(tmp_path, monkeypatch, name):
+    """deepctr NFM / PNN through run.py's entry (plain alternate training; Domain Negotiation on top: the outer updates
+    are the same flat-vector operations whatever the tower)."""
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, name, epochs=2)
+    avg_loss, avg_auc, dl, da = cli.main(cfg, FakeEngine)
+    assert sorted(da) == [0, 1, 2] and np.isfinite(avg_loss) and 0.3 < avg_auc < 1.0

@@ -213,3 +213,27 @@ def test_mtl_adam_shares_the_beta_powers_between_the_domain_models():
     nz = moved > 0
     want = a2 * 0.1 / np.sqrt(0.001)            # (elements with a gradient near eps = 1e-8 move a little less)
     assert abs(np.median(moved[nz]) - want) < 2e-3 * want and moved.max() <= want * 1.002 and moved[nz].min() > 0.9 * want
+
+
+# ------------------------------------------------------------------ NFM / PNN (oracle/fmnets.py)
+@pytest.mark.parametrize("kind,emb_trainable,rate", [("nfm", False, 0.5), ("nfm", True, 0.5), ("pnn", False, 0.5),
+                                                      ("pnn", True, 0.0)])
+def test_nfm_pnn_gradients_vs_float64_autograd(kind, emb_trainable, rate):
+    from oracle import fmnets as ofm
+    rs = np.random.RandomState(31)
+    n_user, n_item, D, B = 60, 40, 4, 48
+    p = ofm.init_params(rs, kind, n_user, n_item, D, emb_dim=8, hidden=(16, 8, 4))
+    p["domain_emb"] = (rs.standard_normal(p["domain_emb"].shape) * 0.05).astype(F32)
+    for n in ("b0", "b1", "b2", "lin_user", "lin_item", "lin_domain"):
+        p[n] = (rs.standard_normal(p[n].shape) * 0.05).astype(F32)
+    p["gb"] = np.array([0.1], F32)      # (a logit of exactly 0 -- all four last units dropped -- sits on the kinks of
+    #                                      torch's clamp / abs in keras_bce, where autograd's subgradient is not the derivative)
+    names = list(ofm.param_names(kind, emb_trainable))
+    uid, pid, dom, label = _batch(rs, n_user, n_item, D, B)
+    masks = otower.train_masks(1024, 3, B, (16, 8, 4), rate) if rate > 0 else None
+    loss, g, pred = ofm.loss_and_grads(p, kind, uid, pid, dom, label, masks, rate, emb_trainable)
+    loss64, g64, pred64 = tref.fmnet_loss_and_grads(p, names, kind, uid, pid, dom, label, masks, rate)
+    assert abs(float(loss) - loss64) < 2e-6 * max(1.0, abs(loss64))
+    np.testing.assert_allclose(pred, pred64, rtol=2e-5, atol=2e-7)
+    assert sorted(g) == sorted(names)
+    _check_grads(g, g64, names)
