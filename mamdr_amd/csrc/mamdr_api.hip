@@ -103,6 +103,8 @@ struct mamdr_ctx {
     bool fused = false;
     float* star_alpha = nullptr;    // Star tower: alphas of the current call's steps (lazy replay of the other domains' slices)
     int star_dense_slices = 0;      // MAMDR_STAR_DENSE_SLICES=1: every slice swept every step (diagnostic; same bits)
+    bool star_pn_in_tower = true;   // PartitionedNorm backward: per-tile sums in the tower's tail (MAMDR_STAR_PNB_KERNEL=1:
+                                    // k_star_pnb_partial as a launch of its own; same bits)
     int t4_no_w1l = 0;              // MAMDR_T4_NO_W1L=1: k_tower4 without the W1 image in LDS (diagnostic)
     int fused_max_batch = 1024;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size):
                                     // 4 rows x the CU count, set at mamdr_create
@@ -498,6 +500,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
 
     ta.dense = c->eff;
     ta.pn_aff = c->pn;
+    ta.pn_part = c->star_pn_in_tower ? c->star_part : nullptr;
     ta.use_dropout = 0;
     ta.keep_scale = 1.0f;
     ta.acts = c->acts;
@@ -570,7 +573,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     if (tail) {
         {
             Prof p(c, MAMDR_KERNEL_AUX);
-            launch_star_pn_bwd(ba, false, c->stream);   // (its last kernel, the domain-row column sums, rides below)
+            launch_star_pn_bwd(ba, false, c->stream, c->star_pn_in_tower);   // (its last kernel, the domain-row column sums, rides below)
         }
         EmbStepArgs tea;
         fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
@@ -584,7 +587,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
             launch_wgrad(wa, c->stream);
         }
         Prof p(c, MAMDR_KERNEL_AUX);                  // PartitionedNorm's backward: 4 launches as one timed group
-        launch_star_pn_bwd(ba, true, c->stream);
+        launch_star_pn_bwd(ba, true, c->stream, c->star_pn_in_tower);
     }
 
     float* slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m;
@@ -784,6 +787,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         }
     }
     if (const char* ev = getenv("MAMDR_NO_TAILFUSE")) c->tail_fuse = atoi(ev) == 0;
+    if (const char* ev = getenv("MAMDR_STAR_PNB_KERNEL")) c->star_pn_in_tower = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));

@@ -128,7 +128,9 @@ struct TowerArgs {
     // trainable user / item tables only (null otherwise)
     float* dxe;                // [rows_pad][dx_ld]  d loss / d [user | item (| domain)] embedding row
     int dx_ld;                 // 256, or 384 for the Star tower
-    const float* pn_aff;       // Star: [scale 384 | shift 384] of PartitionedNorm, null otherwise
+    const float* pn_aff;       // Star: [scale 384 | shift 384 | mean 384 | inv 384 | ...] of PartitionedNorm, null otherwise
+    float* pn_part;            // Star training: [tiles][2][384] per-tile sums of PartitionedNorm's backward (s1 = sum dxn,
+                               // s2 = sum dxn * xhat), written by the tower's tail -- k_star_pnb_partial's work without its launch
     int32_t* urow;             // [rows_pad] user row of each batch position (-1 = padding)
     int32_t* irow;             // [rows_pad]
     int32_t* map_u;            // [n_user] / [n_item]: atomicMin of the batch position touching the row (null: frozen tables)
@@ -708,7 +710,7 @@ struct StarCatchArgs {
 void launch_star_catchup(const StarCatchArgs& a, hipStream_t s);
 void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hipStream_t s);
 void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
-void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s);
+void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s, bool partial_done = false);
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s);
 // k_star_update + the NEXT step's k_emb_catchup in one launch (lazy table Adam)
 void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& next_catchup, hipStream_t s);

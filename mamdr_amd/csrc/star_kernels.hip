@@ -120,14 +120,18 @@ void launch_star_stats(const TowerArgs& a, float* part, float* step_counter, hip
 }
 
 // ------------------------------------------------------------------ per-step preparation
-constexpr int PN_COLS = 32;                    // columns per finalize block
-constexpr int PN_LANES = 16;                   // chunk lanes per column (PN_COLS * PN_LANES = 512 threads)
-constexpr int PN_BLOCKS = XDIM / PN_COLS;      // 12
+// (round 3: 16 columns x 32 lanes, 24 blocks -- with 32 x 16 on 12 blocks a thread walked 32 of the 512 chunks of an
+// 8,192-row batch in four dependent rounds of loads and the launch took 10.4 us; the lane count is part of the
+// summation order, the same for every batch size)
+constexpr int PN_COLS = 16;                    // columns per finalize block
+constexpr int PN_LANES = 32;                   // chunk lanes per column (PN_COLS * PN_LANES = 512 threads)
+constexpr int PN_BLOCKS = XDIM / PN_COLS;      // 24
+constexpr int DMF_COLS = 32;                   // k_star_dm_final: columns per block (x STAR_DM_LANES = 512 threads)
 
 __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < PN_BLOCKS) {
-        // thread (column cl, lane j) merges chunks j, j + 16, ... (Chan et al.), then the 16 lanes of a
+        // thread (column cl, lane j) merges chunks j, j + PN_LANES, ... (Chan et al.), then the lanes of a
         // column are merged in lane order by lane 0 -- a fixed order for every batch size
         __shared__ float sh_n[PN_LANES][PN_COLS], sh_mean[PN_LANES][PN_COLS], sh_m2[PN_LANES][PN_COLS];
         const int cl = tid & (PN_COLS - 1), j = tid / PN_COLS;
@@ -339,17 +343,18 @@ __global__ __launch_bounds__(XDIM) void k_star_pnb_apply(const StarPnBwdArgs a) 
 }
 // column sums of dx[:, 256:384]: star_bodies.h (the body also rides in k_wgrad_reduce)
 __global__ __launch_bounds__(512) void k_star_dm_final(const StarPnBwdArgs a) {
-    __shared__ float sh[STAR_DM_LANES * PN_COLS];
-    star_dm_final_body<PN_COLS>(a, (int)blockIdx.x, sh);
+    __shared__ float sh[STAR_DM_LANES * DMF_COLS];
+    star_dm_final_body<DMF_COLS>(a, (int)blockIdx.x, sh);
 }
 // dm_final = false: the caller lets the domain-row column sums ride in its next launch (k_wgrad_reduce)
-void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s) {
-    hipLaunchKernelGGL(k_star_pnb_partial, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
+// partial_done: the tower's tail already wrote the per-tile sums (TowerArgs::pn_part)
+void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s, bool partial_done) {
+    if (!partial_done) hipLaunchKernelGGL(k_star_pnb_partial, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
     hipLaunchKernelGGL(k_star_pnb_final, dim3(PN_BLOCKS), dim3(512), 0, s, a);
     // (the group's LAST launch carries a profiling scope's stop event: MAMDR_KERNEL_AUX times the group)
     if (dm_final) {
         hipLaunchKernelGGL(k_star_pnb_apply, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
-        MAMDR_LAUNCH(k_star_dm_final, dim3(EMB / PN_COLS), dim3(512), 0, s, a);
+        MAMDR_LAUNCH(k_star_dm_final, dim3(EMB / DMF_COLS), dim3(512), 0, s, a);
     } else {
         MAMDR_LAUNCH(k_star_pnb_apply, dim3(a.n_chunks), dim3(XDIM), 0, s, a);
     }
