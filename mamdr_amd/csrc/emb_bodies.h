@@ -86,6 +86,14 @@ __device__ __forceinline__ void emb_apply_row4(const EmbStepArgs& a, const EmbTa
     }
 }
 
+// Star: one element of PartitionedNorm's backward (see EmbStepArgs::pn_sums); c = column of the 384-wide input
+__device__ __forceinline__ float pn_fix1(const EmbStepArgs& a, int c, float g, float x) {
+#pragma clang fp contract(off)
+    const float m1 = a.pn_sums[c] / a.pn_rows, m2 = a.pn_sums[XDIM + c] / a.pn_rows;
+    const float xh = nc_mul(nc_sub(x, a.pn[2 * XDIM + c]), a.pn[3 * XDIM + c]);
+    return nc_mul(a.pn[4 * XDIM + c], nc_sub(nc_sub(g, m1), nc_mul(xh, m2)));
+}
+
 __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {
 #pragma clang fp contract(off)
     if (o.optimizer == 0) {
@@ -133,7 +141,12 @@ __device__ __forceinline__ void emb_reduce_body(const EmbStepArgs& a, int bx, in
     }
     // ---- phase A
     if (r >= 0 && !dupf) {
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.dxe + (size_t)b * a.dx_ld + T.dx_off + 4 * c4);
+        f32x4 g4 = *reinterpret_cast<const f32x4*>(a.dxe + (size_t)b * a.dx_ld + T.dx_off + 4 * c4);
+        if (a.pn_sums) {
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(a.p + ((size_t)(second ? a.t[0].n_rows : 0) + r) * EMB + 4 * c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g4[k] = pn_fix1(a, T.dx_off + 4 * c4 + k, g4[k], x4[k]);
+        }
         if (T.lin_p && c4 == 0) T.glin[b] = a.dlogit[b];
         if (a.apply_now) emb_apply_row4(a, T, second, r, c4, g4);
         else *reinterpret_cast<f32x4*>(T.gbuf + (size_t)b * EMB + 4 * c4) = g4;
@@ -151,7 +164,18 @@ __device__ __forceinline__ void emb_reduce_body(const EmbStepArgs& a, int bx, in
         const int bs = bx * 8 + w * 2 + s;
         const int rs = __shfl(r, 32 * s);
         const float* gcol = a.dxe + T.dx_off + 2 * lane;
-        f32x2 acc = *reinterpret_cast<const f32x2*>(gcol + (size_t)bs * a.dx_ld);
+        // Star: every position's gradient goes through PartitionedNorm's backward before it is added (the row's own
+        // values: the same for all positions of the row)
+        f32x2 xrow = (f32x2){0.f, 0.f};
+        if (a.pn_sums) xrow = *reinterpret_cast<const f32x2*>(a.p + ((size_t)(second ? a.t[0].n_rows : 0) + rs) * EMB + 2 * lane);
+        auto fix = [&](f32x2 gq) {
+            if (a.pn_sums) {
+                gq[0] = pn_fix1(a, T.dx_off + 2 * lane, gq[0], xrow[0]);
+                gq[1] = pn_fix1(a, T.dx_off + 2 * lane + 1, gq[1], xrow[1]);
+            }
+            return gq;
+        };
+        f32x2 acc = fix(*reinterpret_cast<const f32x2*>(gcol + (size_t)bs * a.dx_ld));
         float accl = T.lin_p ? a.dlogit[bs] : 0.f;         // DeepFM: the 1-d linear table's row gradient
         int cnt = 0;                           // wave-uniform
         auto drain = [&]() {
@@ -162,9 +186,9 @@ __device__ __forceinline__ void emb_reduce_body(const EmbStepArgs& a, int bx, in
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v8[u] = *reinterpret_cast<const f32x2*>(gcol + (size_t)L[k + u] * a.dx_ld);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v8[u];
+                for (int u = 0; u < 8; ++u) acc += fix(v8[u]);
             }
-            for (; k < cnt; ++k) acc += *reinterpret_cast<const f32x2*>(gcol + (size_t)L[k] * a.dx_ld);
+            for (; k < cnt; ++k) acc += fix(*reinterpret_cast<const f32x2*>(gcol + (size_t)L[k] * a.dx_ld));
             if (T.lin_p)
                 for (int q = 0; q < cnt; ++q) accl += a.dlogit[L[q]];
             __builtin_amdgcn_wave_barrier();

@@ -331,6 +331,11 @@ static void fill_emb_args(const mamdr_ctx* c, int32_t optimizer, float alpha, fl
     ea.alpha_log = c->alpha_log;
     ea.log_mask = c->log_cap - 1;
     ea.t_now = (int)c->adam_t;
+    if (c->star && c->star_pn_in_tower) {      // PartitionedNorm's backward rides in k_emb_reduce (EmbStepArgs::pn_sums)
+        ea.pn_sums = c->star_sums;
+        ea.pn = c->pn;
+        ea.pn_rows = (float)rows;
+    }
     EmbTable& tu = ea.t[0];
     EmbTable& ti = ea.t[1];
     tu.n_rows = c->cfg.n_user;
@@ -566,6 +571,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ba.sums = c->star_sums;
     ba.dmpart = c->star_dmpart;
     ba.dmsum = c->star_sums + 2 * XDIM;
+    ba.fused = c->star_pn_in_tower ? 1 : 0;
     // lazy table Adam with fused tails: PartitionedNorm's backward first (it only needs the tower's outputs), then
     // [k_wgrad + k_emb_reduce(t) + k_emb_rows(t+1)], then [k_star_update + k_emb_catchup(t+1)]
     const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile &&
@@ -580,7 +586,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
         tea.flags_done = 1;
         tea.apply_now = 1;
         Prof p(c, MAMDR_KERNEL_WGRAD);
-        launch_wgrad_reduce(wa, tea, next_rows, &ba, c->stream);
+        launch_wgrad_reduce(wa, tea, next_rows, ba.fused ? nullptr : &ba, c->stream);
     } else {
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);

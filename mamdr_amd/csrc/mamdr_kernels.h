@@ -615,6 +615,12 @@ struct EmbStepArgs {
     int t_now;
     int flags_done;            // duplicate flags were set by k_emb_catchup (lazy mode): skip k_emb_flag
     int apply_now;             // lazy mode: k_emb_reduce applies Adam step t_now to the rows it reduces
+    // Star tower: dxe holds d loss / d NORMALISED input; PartitionedNorm's backward through the batch statistics,
+    // dx = coef (( dxn - s1 / B) - xhat s2 / B), xhat = (x - mean) inv, is applied to every gathered gradient row on the
+    // fly (x = the table row itself) -- k_star_pnb_apply's arithmetic without its pass over the batch.  null = dxe is d x
+    const float* pn_sums;      // [2][384] column sums s1, s2 over the batch (k_star_pnb_final)
+    const float* pn;           // PartitionedNorm workspace [scale | shift | mean | inv | coef | ...] x 384
+    float pn_rows;             // B
 };
 struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the batch BEFORE the tower runs
     const int32_t* uid;
@@ -673,6 +679,8 @@ struct StarPnBwdArgs {
     float* sums;               // [2][384] s1 = sum dxn, s2 = sum dxn * xhat
     float* dmpart;             // [chunks][EMB] column sums of dx[:, 256:384]
     float* dmsum;              // [EMB] their total
+    int fused;                 // 1: k_star_pnb_final is the only launch (it also finishes dmsum; the table rows get their
+                               // d x inside k_emb_reduce); 0: k_star_pnb_apply rewrites dxe, k_star_dm_final sums dmpart
 };
 struct StarUpdateArgs {
     float* p;                  // Star block of weights / Adam m / Adam v (or accumulator)
