@@ -35,6 +35,16 @@ __device__ __forceinline__ void adam_elem(float g, float& p, float& m, float& v,
     // bound by exactly this sequence, and both paths share it, so they still agree bit for bit
     p = nc_sub(p, nc_mul(nc_mul(m, alpha), __builtin_amdgcn_rcpf(nc_add(__builtin_amdgcn_sqrtf(v), eps))));
 }
+// the same step for a gradient that is exactly zero (a row no batch touches in a tower WITHOUT the table regulariser:
+// the Star tower, two_l2 = 0).  adam_elem(0 * p, ...) evaluates g - m = -m and g g - v = -v exactly, so dropping those
+// operations leaves every bit in place (signed zeros included: the fma adds m / v back) -- 8 instead of 13 operations in
+// the replay loops, which are bound by exactly this sequence.
+__device__ __forceinline__ void adam_elem_zero(float& p, float& m, float& v, float alpha, float omb1, float omb2, float eps) {
+#pragma clang fp contract(off)
+    m = __builtin_fmaf(-m, omb1, m);
+    v = __builtin_fmaf(-v, omb2, v);
+    p = nc_sub(p, nc_mul(nc_mul(m, alpha), __builtin_amdgcn_rcpf(nc_add(__builtin_amdgcn_sqrtf(v), eps))));
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // lazy mode: the representative wave of k_emb_reduce applies Adam step t_now to its row right away
@@ -328,13 +338,25 @@ __device__ __forceinline__ void emb_catchup_body(const EmbStepArgs& a, int bx, i
     f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
     f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
     f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
-    for (int t = last + 1; t <= t_prev; ++t) {
-        const float alpha = a.alpha_log[t & a.log_mask];
+    if (a.opt.two_l2 == 0.f) {                 // no regulariser: the missed steps have a zero gradient (same bits, fewer operations)
+        for (int t = last + 1; t <= t_prev; ++t) {
+            const float alpha = a.alpha_log[t & a.log_mask];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float pk = p[k], mk = m[k], vk = v[k];
-            adam_elem(nc_mul(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
-            p[k] = pk; m[k] = mk; v[k] = vk;
+            for (int k = 0; k < 4; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam_elem_zero(pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+            }
+        }
+    } else {
+        for (int t = last + 1; t <= t_prev; ++t) {
+            const float alpha = a.alpha_log[t & a.log_mask];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam_elem(nc_mul(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+            }
         }
     }
     reinterpret_cast<f32x4*>(a.p)[e4] = p;

@@ -139,13 +139,25 @@ __global__ __launch_bounds__(256) void k_emb_flush(const EmbStepArgs a) {
     f32x4 p = reinterpret_cast<const f32x4*>(a.p)[e4];
     f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e4];
     f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e4];
-    for (int t = last + 1; t <= a.t_now; ++t) {
-        const float alpha = a.alpha_log[t & a.log_mask];
+    if (a.opt.two_l2 == 0.f) {                 // Star tower: zero-gradient steps (adam_elem_zero: the same bits)
+        for (int t = last + 1; t <= a.t_now; ++t) {
+            const float alpha = a.alpha_log[t & a.log_mask];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float pk = p[k], mk = m[k], vk = v[k];
-            adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
-            p[k] = pk; m[k] = mk; v[k] = vk;
+            for (int k = 0; k < 4; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam_elem_zero(pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+            }
+        }
+    } else {
+        for (int t = last + 1; t <= a.t_now; ++t) {
+            const float alpha = a.alpha_log[t & a.log_mask];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pk = p[k], mk = m[k], vk = v[k];
+                adam_elem(__fmul_rn(a.opt.two_l2, pk), pk, mk, vk, alpha, a.opt.omb1, a.opt.omb2, a.opt.eps);
+                p[k] = pk; m[k] = mk; v[k] = vk;
+            }
         }
     }
     reinterpret_cast<f32x4*>(a.p)[e4] = p;

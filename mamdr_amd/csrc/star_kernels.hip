@@ -137,19 +137,39 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
         const int cl = tid & (PN_COLS - 1), j = tid / PN_COLS;
         const int c = blockIdx.x * PN_COLS + cl;
         float mean = 0.f, var = 1.f;
+        // everything lane 0 needs besides the chunks is requested first: the kernel is a chain of cold round trips
+        // (the chunk partials were written by the previous kernel on other XCDs), not arithmetic
+        const size_t o = (size_t)a.d * XDIM + c;
+        float t_step = 0.f, bm = 0.f, bv = 0.f, mov_m = 0.f, mov_v = 1.f;
+        float gam_s = 0.f, gam_d = 0.f, bet_s = 0.f, bet_d = 0.f, raw_dm = 0.f;
+        if (j == 0) {
+            gam_s = a.blk[a.SL.pgs + c];
+            gam_d = a.blk[a.SL.pgd + a.d * XDIM + c];
+            bet_s = a.blk[a.SL.pbs + c];
+            bet_d = a.blk[a.SL.pbd + a.d * XDIM + c];
+            if (c >= 2 * EMB) raw_dm = a.blk[a.SL.dm + (size_t)a.d * EMB + (c - 2 * EMB)];
+            if (a.train) {
+                t_step = a.aux[a.AL.steps + a.d];
+                bm = a.aux[a.AL.biased_mean + o];
+                bv = a.aux[a.AL.biased_var + o];
+            } else {
+                mov_m = a.aux[a.AL.mov_mean + o];
+                mov_v = a.aux[a.AL.mov_var + o];
+            }
+        }
         if (a.train) {
             float n = 0.f, M2 = 0.f;
-            // (8 chunks' partials in flight; the merge itself stays in chunk order)
-            for (int ch0 = j; ch0 < a.n_chunks; ch0 += 8 * PN_LANES) {
-                float mb[8], Mb[8];
+            // (16 chunks' partials in flight = a thread's whole share at 8,192 rows; the merge itself stays in chunk order)
+            for (int ch0 = j; ch0 < a.n_chunks; ch0 += 16 * PN_LANES) {
+                float mb[16], Mb[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int ch = min(ch0 + u * PN_LANES, a.n_chunks - 1);
                     mb[u] = a.part[(size_t)ch * 2 * XDIM + c];
                     Mb[u] = a.part[(size_t)ch * 2 * XDIM + XDIM + c];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int ch = ch0 + u * PN_LANES;
                     if (ch < a.n_chunks) {
                         const float nb = (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK);
@@ -182,11 +202,8 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
             var = M2 / (float)a.rows;      // population variance (nn.moments)
             // assign_moving_average(zero_debias=True): biased += (value - biased) * (1 - momentum);
             // moving = biased / (1 - momentum^step); the step was bumped by k_star_stats
-            const float t = a.aux[a.AL.steps + a.d];
-            const float factor = 1.0f - powf(PN_MOMENTUM, t);
+            const float factor = 1.0f - powf(PN_MOMENTUM, t_step);
             const float omm = 1.0f - PN_MOMENTUM;
-            const size_t o = (size_t)a.d * XDIM + c;
-            float bm = a.aux[a.AL.biased_mean + o], bv = a.aux[a.AL.biased_var + o];
             bm += (mean - bm) * omm;
             bv += (var - bv) * omm;
             a.aux[a.AL.biased_mean + o] = bm;
@@ -194,12 +211,12 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
             a.aux[a.AL.mov_mean + o] = bm / factor;
             a.aux[a.AL.mov_var + o] = bv / factor;
         } else {
-            mean = a.aux[a.AL.mov_mean + (size_t)a.d * XDIM + c];
-            var = a.aux[a.AL.mov_var + (size_t)a.d * XDIM + c];
+            mean = mov_m;
+            var = mov_v;
         }
         const float inv = 1.0f / sqrtf(var + PN_EPS);
-        const float gamma = a.blk[a.SL.pgs + c] * a.blk[a.SL.pgd + a.d * XDIM + c];
-        const float beta = a.blk[a.SL.pbs + c] + a.blk[a.SL.pbd + a.d * XDIM + c];
+        const float gamma = gam_s * gam_d;
+        const float beta = bet_s + bet_d;
         const float scale = __fmul_rn(inv, gamma);
         a.pn[c] = scale;
         a.pn[XDIM + c] = __fsub_rn(beta, __fmul_rn(mean, scale));
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
         // the normalised domain row, rounded exactly as the tower's gather rounds it: every sample of the batch
         // carries it in x[256:384], so dW0[256:384, :] = xdom (x) column sums of dz1 (k_star_update)
         if (c >= 2 * EMB) {
-            const float raw = a.blk[a.SL.dm + (size_t)a.d * EMB + (c - 2 * EMB)];
+            const float raw = raw_dm;
             a.pn[PN_XDOM_OFF + (c - 2 * EMB)] = __fadd_rn(__fmul_rn(raw, scale), __fsub_rn(beta, __fmul_rn(mean, scale)));
         }
         return;
@@ -293,16 +310,16 @@ __global__ __launch_bounds__(512) void k_star_pnb_final(const StarPnBwdArgs a) {
     const int cl = threadIdx.x & (PN_COLS - 1), j = threadIdx.x / PN_COLS;
     const int c = blockIdx.x * PN_COLS + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int ch0 = j; ch0 < a.n_chunks; ch0 += 8 * PN_LANES) {      // 8 chunks' partials in flight, summed in order
-        float t1[8], t2[8];
+    for (int ch0 = j; ch0 < a.n_chunks; ch0 += 16 * PN_LANES) {     // 16 chunks' partials in flight, summed in order
+        float t1[16], t2[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int ch = min(ch0 + u * PN_LANES, a.n_chunks - 1);
             t1[u] = a.part[(size_t)ch * 2 * XDIM + c];
             t2[u] = a.part[(size_t)ch * 2 * XDIM + XDIM + c];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             if (ch0 + u * PN_LANES < a.n_chunks) {
                 s1 += t1[u];
                 s2 += t2[u];
