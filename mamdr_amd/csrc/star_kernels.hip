@@ -3,7 +3,7 @@
 // Per training step on domain d (model_zoo/Star/star.py:70-97, partitioned_norm.py:102-203,
 // star_fcn.py:105-139):
 //   k_star_stats    per-chunk mean / M2 of the 384 raw input columns of the batch (gathered rows)
-//   k_star_prep     first 12 blocks: merge the chunks (Chan) -> batch mean / variance, update domain d's
+//   k_star_prep     first 24 blocks: combine the chunks (mean, then M2 about it) -> batch mean / variance, update domain d's
 //                   zero-debiased moving statistics, emits the PartitionedNorm affine
 //                   (scale = gamma_s * gamma_d[d] * rsqrt(var + eps), shift = beta_s + beta_d[d] - mean * scale);
 //                   other blocks: effective dense block  K_l = W_shared_l * W_specific_l[d],
@@ -131,9 +131,9 @@ constexpr int DMF_COLS = 32;                   // k_star_dm_final: columns per b
 __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < PN_BLOCKS) {
-        // thread (column cl, lane j) merges chunks j, j + PN_LANES, ... (Chan et al.), then the lanes of a
-        // column are merged in lane order by lane 0 -- a fixed order for every batch size
-        __shared__ float sh_n[PN_LANES][PN_COLS], sh_mean[PN_LANES][PN_COLS], sh_m2[PN_LANES][PN_COLS];
+        // thread (column cl, lane j) owns chunks j, j + PN_LANES, ...; the lanes of a column are combined in lane
+        // order -- a fixed order for every batch size
+        __shared__ float sh_mean[PN_LANES][PN_COLS], sh_m2[PN_LANES][PN_COLS];
         const int cl = tid & (PN_COLS - 1), j = tid / PN_COLS;
         const int c = blockIdx.x * PN_COLS + cl;
         float mean = 0.f, var = 1.f;
@@ -158,47 +158,46 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
             }
         }
         if (a.train) {
-            float n = 0.f, M2 = 0.f;
-            // (16 chunks' partials in flight = a thread's whole share at 8,192 rows; the merge itself stays in chunk order)
-            for (int ch0 = j; ch0 < a.n_chunks; ch0 += 16 * PN_LANES) {
-                float mb[16], Mb[16];
+            // Round 3: two passes over the chunk partials instead of a chain of Chan merges (each with two divisions,
+            // 16 per thread and then 31 more on lane 0: the launch took 9.6 us for 24 blocks).  mean = sum n_i mean_i / B,
+            // M2 = sum (M2_i + n_i (mean_i - mean)^2): plain sums, every lane adds the 32 lane sums of its column in lane
+            // order (fixed for every batch size), one division per column.
+            float mb[16], Mb[16], nbv[16];
+            float s = 0.f;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int ch = min(ch0 + u * PN_LANES, a.n_chunks - 1);
-                    mb[u] = a.part[(size_t)ch * 2 * XDIM + c];
-                    Mb[u] = a.part[(size_t)ch * 2 * XDIM + XDIM + c];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int ch = ch0 + u * PN_LANES;
-                    if (ch < a.n_chunks) {
-                        const float nb = (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK);
-                        const float delta = mb[u] - mean;
-                        const float nn = n + nb;
-                        mean += delta * (nb / nn);
-                        M2 += Mb[u] + delta * delta * (n * nb / nn);
-                        n = nn;
-                    }
-                }
+            for (int u = 0; u < 16; ++u) {       // a thread's whole share at 8,192 rows (512 chunks / 32 lanes) in flight
+                const int ch = j + u * PN_LANES;
+                const int chc = min(ch, a.n_chunks - 1);
+                mb[u] = a.part[(size_t)chc * 2 * XDIM + c];
+                Mb[u] = a.part[(size_t)chc * 2 * XDIM + XDIM + c];
+                nbv[u] = ch < a.n_chunks ? (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK) : 0.f;
             }
-            sh_n[j][cl] = n;
-            sh_mean[j][cl] = mean;
-            sh_m2[j][cl] = M2;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += nbv[u] * mb[u];
+            for (int ch = j + 16 * PN_LANES; ch < a.n_chunks; ch += PN_LANES)       // (batches beyond 8,192 rows)
+                s += (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK) * a.part[(size_t)ch * 2 * XDIM + c];
+            sh_mean[j][cl] = s;
+            __syncthreads();
+            float tot = 0.f;
+            for (int q = 0; q < PN_LANES; ++q) tot += sh_mean[q][cl];
+            mean = tot / (float)a.rows;
+            float m2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float dlt = mb[u] - mean;
+                m2 += nbv[u] > 0.f ? Mb[u] + nbv[u] * dlt * dlt : 0.f;
+            }
+            for (int ch = j + 16 * PN_LANES; ch < a.n_chunks; ch += PN_LANES) {
+                const float dlt = a.part[(size_t)ch * 2 * XDIM + c] - mean;
+                m2 += a.part[(size_t)ch * 2 * XDIM + XDIM + c] + (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK) * dlt * dlt;
+            }
+            sh_m2[j][cl] = m2;
         }
         __syncthreads();
         if (j != 0) return;
         if (a.train) {
-            float n = sh_n[0][cl], M2 = sh_m2[0][cl];
-            mean = sh_mean[0][cl];
-            for (int q = 1; q < PN_LANES; ++q) {
-                const float nb = sh_n[q][cl];
-                if (nb == 0.f) continue;
-                const float delta = sh_mean[q][cl] - mean;
-                const float nn = n + nb;
-                mean += delta * (nb / nn);
-                M2 += sh_m2[q][cl] + delta * delta * (n * nb / nn);
-                n = nn;
-            }
+            float M2 = 0.f;
+            for (int q = 0; q < PN_LANES; ++q) M2 += sh_m2[q][cl];
             var = M2 / (float)a.rows;      // population variance (nn.moments)
             // assign_moving_average(zero_debias=True): biased += (value - biased) * (1 - momentum);
             // moving = biased / (1 - momentum^step); the step was bumped by k_star_stats
