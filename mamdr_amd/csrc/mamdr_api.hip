@@ -71,7 +71,7 @@ struct mamdr_ctx {
     float* aux = nullptr;           // bound PartitionedNorm state (Star)
     float* eff = nullptr;           // Star: effective dense block of the step's domain
     float* pn = nullptr;            // Star: [PN_WS_FLOATS]
-    float* star_part = nullptr;     // Star: [chunks][2][384] partials (forward statistics, then backward sums)
+    float* star_part = nullptr;     // Star: [chunks][2][384] partials (forward statistics as doubles, then backward sums as floats)
     float* star_sums = nullptr;     // Star: [2][384] PN sums + [128] domain-row gradient
     float* star_dmpart = nullptr;   // Star: [chunks][EMB]
     int64_t lin_user_off = 0;   // DeepFM + trainable tables: 1-d linear tables behind the embedding tables
@@ -724,7 +724,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->pn, (size_t)PN_WS_FLOATS * sizeof(float));
         ALLOC(c->star_alpha, (size_t)STAR_ALPHA_CAP * sizeof(float));
         if (const char* sd = getenv("MAMDR_STAR_DENSE_SLICES")) c->star_dense_slices = atoi(sd) != 0;
-        ALLOC(c->star_part, chunks * 2 * XDIM * sizeof(float));
+        ALLOC(c->star_part, chunks * 2 * XDIM * sizeof(double));    // forward: double sums; backward: float sums
         ALLOC(c->star_sums, (2 * XDIM + EMB) * sizeof(float));
         ALLOC(c->star_dmpart, chunks * EMB * sizeof(float));
     }

@@ -659,7 +659,7 @@ struct StarPrepArgs {
     int n_domain, d;
     float* eff;                // effective dense block [L.alloc]
     float* pn;                 // [PN_WS_FLOATS]
-    const float* part;         // training: [chunks][2][384] chunk mean / M2 of the raw input columns
+    const float* part;         // training: [chunks][2][384] DOUBLES: sum x / sum x^2 of the raw input columns per chunk
     int n_chunks, rows;
     float* aux;                // moving statistics (read at eval, updated in training)
     StarAuxLayout AL;

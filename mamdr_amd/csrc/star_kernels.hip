@@ -2,8 +2,8 @@
 //
 // Per training step on domain d (model_zoo/Star/star.py:70-97, partitioned_norm.py:102-203,
 // star_fcn.py:105-139):
-//   k_star_stats    per-chunk mean / M2 of the 384 raw input columns of the batch (gathered rows)
-//   k_star_prep     first 24 blocks: combine the chunks (mean, then M2 about it) -> batch mean / variance, update domain d's
+//   k_star_stats    per-chunk sum x / sum x^2 (double) of the 384 raw input columns of the batch (gathered rows)
+//   k_star_prep     first 24 blocks: add the chunks -> batch mean / population variance, update domain d's
 //                   zero-debiased moving statistics, emits the PartitionedNorm affine
 //                   (scale = gamma_s * gamma_d[d] * rsqrt(var + eps), shift = beta_s + beta_d[d] - mean * scale);
 //                   other blocks: effective dense block  K_l = W_shared_l * W_specific_l[d],
@@ -98,18 +98,19 @@ __global__ __launch_bounds__(XDIM) void k_star_stats(const TowerArgs a, float* p
     float x[STAR_CHUNK];
 #pragma unroll
     for (int r = 0; r < STAR_CHUNK; ++r) x[r] = base[(size_t)rowi[seg * STAR_CHUNK + r] * EMB + k];
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < STAR_CHUNK; ++r) s += (r < nb) ? x[r] : 0.f;
-    const float mean = s / (float)nb;
-    float m2 = 0.f;
+    // sum x and sum x^2 of the chunk's rows in double (round 3): the batch moments k_star_prep forms from them are the
+    // correctly rounded ones up to ~1e-16 -- what nn.moments' float64-accurate reference value is -- instead of fp32
+    // chunk statistics merged in fp32 (1e-7 apart: enough to send two fp32 runs of this tower down different paths)
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < STAR_CHUNK; ++r) {
-        const float dlt = x[r] - mean;
-        m2 += (r < nb) ? dlt * dlt : 0.f;
+        const double xv = (r < nb) ? (double)x[r] : 0.0;
+        s1 += xv;
+        s2 += xv * xv;
     }
-    part[(size_t)ch * 2 * XDIM + c] = mean;
-    part[(size_t)ch * 2 * XDIM + XDIM + c] = m2;
+    double* dpart = reinterpret_cast<double*>(part);
+    dpart[(size_t)ch * 2 * XDIM + c] = s1;
+    dpart[(size_t)ch * 2 * XDIM + XDIM + c] = s2;
     // local step of domain d's moving averages: bumped here so that every block of k_star_prep reads
     // the same, final value
     if (ch == 0 && c == 0) *step_counter += 1.0f;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
     if ((int)blockIdx.x < PN_BLOCKS) {
         // thread (column cl, lane j) owns chunks j, j + PN_LANES, ...; the lanes of a column are combined in lane
         // order -- a fixed order for every batch size
-        __shared__ float sh_mean[PN_LANES][PN_COLS], sh_m2[PN_LANES][PN_COLS];
+        __shared__ double sh_s1[PN_LANES][PN_COLS], sh_s2[PN_LANES][PN_COLS];
         const int cl = tid & (PN_COLS - 1), j = tid / PN_COLS;
         const int c = blockIdx.x * PN_COLS + cl;
         float mean = 0.f, var = 1.f;
@@ -158,47 +159,48 @@ __global__ __launch_bounds__(512) void k_star_prep(const StarPrepArgs a) {
             }
         }
         if (a.train) {
-            // Round 3: two passes over the chunk partials instead of a chain of Chan merges (each with two divisions,
-            // 16 per thread and then 31 more on lane 0: the launch took 9.6 us for 24 blocks).  mean = sum n_i mean_i / B,
-            // M2 = sum (M2_i + n_i (mean_i - mean)^2): plain sums, every lane adds the 32 lane sums of its column in lane
-            // order (fixed for every batch size), one division per column.
-            float mb[16], Mb[16], nbv[16];
-            float s = 0.f;
+            // Round 3: the chunks carry sum x and sum x^2 in DOUBLE (k_star_stats) and are simply added -- no chain of
+            // Chan merges (two divisions each, 16 per thread and then 31 more on lane 0: the launch took 9.6 us for
+            // 24 blocks), and batch moments accurate to ~1e-16 before their one rounding to fp32.
+            const double* dpart = reinterpret_cast<const double*>(a.part);
+            double q1[16], q2[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {       // a thread's whole share at 8,192 rows (512 chunks / 32 lanes) in flight
-                const int ch = j + u * PN_LANES;
-                const int chc = min(ch, a.n_chunks - 1);
-                mb[u] = a.part[(size_t)chc * 2 * XDIM + c];
-                Mb[u] = a.part[(size_t)chc * 2 * XDIM + XDIM + c];
-                nbv[u] = ch < a.n_chunks ? (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK) : 0.f;
+                const int ch = min(j + u * PN_LANES, a.n_chunks - 1);
+                q1[u] = dpart[(size_t)ch * 2 * XDIM + c];
+                q2[u] = dpart[(size_t)ch * 2 * XDIM + XDIM + c];
             }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s += nbv[u] * mb[u];
-            for (int ch = j + 16 * PN_LANES; ch < a.n_chunks; ch += PN_LANES)       // (batches beyond 8,192 rows)
-                s += (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK) * a.part[(size_t)ch * 2 * XDIM + c];
-            sh_mean[j][cl] = s;
-            __syncthreads();
-            float tot = 0.f;
-            for (int q = 0; q < PN_LANES; ++q) tot += sh_mean[q][cl];
-            mean = tot / (float)a.rows;
-            float m2 = 0.f;
+            double t1 = 0.0, t2 = 0.0;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const float dlt = mb[u] - mean;
-                m2 += nbv[u] > 0.f ? Mb[u] + nbv[u] * dlt * dlt : 0.f;
+                if (j + u * PN_LANES < a.n_chunks) {
+                    t1 += q1[u];
+                    t2 += q2[u];
+                }
             }
-            for (int ch = j + 16 * PN_LANES; ch < a.n_chunks; ch += PN_LANES) {
-                const float dlt = a.part[(size_t)ch * 2 * XDIM + c] - mean;
-                m2 += a.part[(size_t)ch * 2 * XDIM + XDIM + c] + (float)min(STAR_CHUNK, a.rows - ch * STAR_CHUNK) * dlt * dlt;
+            for (int ch = j + 16 * PN_LANES; ch < a.n_chunks; ch += PN_LANES) {       // (batches beyond 8,192 rows)
+                t1 += dpart[(size_t)ch * 2 * XDIM + c];
+                t2 += dpart[(size_t)ch * 2 * XDIM + XDIM + c];
             }
-            sh_m2[j][cl] = m2;
+            sh_s1[j][cl] = t1;
+            sh_s2[j][cl] = t2;
         }
         __syncthreads();
         if (j != 0) return;
         if (a.train) {
-            float M2 = 0.f;
-            for (int q = 0; q < PN_LANES; ++q) M2 += sh_m2[q][cl];
-            var = M2 / (float)a.rows;      // population variance (nn.moments)
+            double S1 = 0.0, S2 = 0.0;
+            for (int q = 0; q < PN_LANES; ++q) {        // lane order: fixed for every batch size
+                S1 += sh_s1[q][cl];
+                S2 += sh_s2[q][cl];
+            }
+            const double B = (double)a.rows;
+            const double mu = S1 / B;
+            mean = (float)mu;
+            // population variance about the fp32 mean the tower normalises with (nn.moments: mean((x - mean)^2)):
+            // E[x^2] - 2 mean E[x] + mean^2, in double
+            const double mf = (double)mean;
+            const double vd = S2 / B - 2.0 * mf * mu + mf * mf;
+            var = (float)(vd > 0.0 ? vd : 0.0);
             // assign_moving_average(zero_debias=True): biased += (value - biased) * (1 - momentum);
             // moving = biased / (1 - momentum^step); the step was bumped by k_star_stats
             const float factor = 1.0f - powf(PN_MOMENTUM, t_step);

@@ -74,13 +74,28 @@ class FlatVectorOps(object):
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
         L.check(self.lib.mamdr_merge(_ptr(dst), _ptr(theta), _ptr(phi), mode, dst.numel(), self._s()))
 
+    # ---- meta parameters (MAML._get_model_meta_parms, maml.py:153-179): theta / phi vectors cover ONE contiguous range
+    # [meta_off, meta_off + n_meta) of the flat vector -- the whole vector ("all"), the Star filter's prefix, or e.g.
+    # "all_hidden" (everything behind the embedding tables)
+    meta_off = 0
+
+    def set_meta_range(self, off, count):
+        if off < 0 or count <= 0 or off + count > self.n_params:
+            raise ValueError("meta range [%d, %d) outside the flat vector of %d floats" % (off, off + count, self.n_params))
+        self.meta_off, self.n_meta = int(off), int(count)
+
+    @property
+    def meta_weights(self):
+        """live values of the meta parameters (a view: no copy)."""
+        return self.weights[self.meta_off:self.meta_off + self.n_meta]
+
     def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
         """one DR support step in a single pass: phi += (live - merged) * gamma; merged = theta (+|*) phi; and, for
         the next support, model := merged (mamdr.py:103-105,74) -- bit-identical to interp + merge + set_weights."""
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
         # self.weights (not _weights): the live table rows must be brought up to the current Adam step before they
         # are read into phi / replaced by merged (include/mamdr_hip.h: sync before reading or replacing the state)
-        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self.weights), _ptr(merged), _ptr(theta), float(gamma), mode,
+        L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self.meta_weights), _ptr(merged), _ptr(theta), float(gamma), mode,
                                           1 if assign_model else 0, phi.numel(), self._s()))
 
     def sub(self, dst, a, b):
@@ -200,7 +215,11 @@ class TowerEngine(FlatVectorOps):
                    "bd0": "bias_specific_0", "bd1": "bias_specific_1", "bd2": "bias_specific_2",
                    "pn_gamma_shared": "gamma_shared", "pn_beta_shared": "beta_shared",
                    "pn_gamma_spec": "gamma_specific", "pn_beta_spec": "beta_specific",
-                   "wo": "dense/kernel", "gb": "dense/bias"}
+                   "wo": "dense/kernel", "gb": "dense/bias",
+                   # deepctr's embedding layers: "sparse_emb_<feature>", the 1-d linear ones "linear...sparse_emb_<feature>"
+                   "user_emb": "sparse_emb_uid", "item_emb": "sparse_emb_pid", "domain_emb": "sparse_emb_domain",
+                   "lin_user": "linear0sparse_emb_uid", "lin_item": "linear0sparse_emb_pid",
+                   "lin_domain": "linear0sparse_emb_domain"}
 
     def keras_name(self, segment):
         return self.KERAS_NAMES.get(segment, segment)
@@ -234,7 +253,8 @@ class TowerEngine(FlatVectorOps):
     def set_weights(self, vec):
         """SetVarOp.__call__ (utils/tool.py:36-45): device copy into the live weights.  A vector of
         meta length assigns the meta prefix only (MAML._set_model_meta_parms, maml.py:181-187)."""
-        L.check(self.lib.mamdr_copy(_ptr(self.weights), _ptr(vec), vec.numel(), self._s()))
+        dst = self.meta_weights if (self.meta_off and vec.numel() == self.n_meta) else self.weights
+        L.check(self.lib.mamdr_copy(_ptr(dst), _ptr(vec), vec.numel(), self._s()))
 
     def get_weights(self, out=None):
         """K.batch_get_value (maml.py:189-194): snapshot of the live weights."""

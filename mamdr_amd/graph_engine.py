@@ -110,7 +110,8 @@ class GraphEngine(FlatVectorOps):
         return {name: host[off:off + cnt].copy() for name, (off, cnt) in self.segments.items()}
 
     def set_weights(self, vec):
-        self._weights[:vec.numel()].copy_(vec)
+        dst = self.meta_weights if (self.meta_off and vec.numel() == self.n_meta) else self._weights[:vec.numel()]
+        dst.copy_(vec)
 
     def get_weights(self, out=None):
         if out is None:

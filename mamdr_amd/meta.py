@@ -69,7 +69,7 @@ def dn_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, meta_train_step=
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
     if target >= 0:
         run_pass(eng, target, perm_fn, batch_size, lr, trace, "dn")
-    eng.interp(theta, eng.weights, theta, meta_lr)     # theta += (theta~ - theta) * beta
+    eng.interp(theta, eng.meta_weights, theta, meta_lr)     # theta += (theta~ - theta) * beta
     eng.set_weights(theta)
     if target >= 0:
         run_pass(eng, target, perm_fn, batch_size, lr, trace, "target")
@@ -92,9 +92,9 @@ def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_varia
         if target >= 0:
             run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
         if batch_variant:
-            eng.accumulate(acc, eng.weights, theta)
+            eng.accumulate(acc, eng.meta_weights, theta)
         else:
-            eng.interp(theta, eng.weights, theta, meta_lr)
+            eng.interp(theta, eng.meta_weights, theta, meta_lr)
     if batch_variant:
         eng.apply_accumulated(theta, acc, 0.0, meta_lr)
     eng.set_weights(theta)
@@ -115,10 +115,17 @@ class OuterAdamState(object):
         self.b2p = np.float32(1.0)
 
     def apply(self, eng, theta, acc, lr, grad_scale=1.0, clear=True):
+        """theta (n_meta or n_params floats) takes one outer Adam step with the gradient `acc`; a full-size accumulator
+        under a meta range contributes its slice of that range (the slots are indexed like the full vector)."""
         import numpy as np
         self.b1p = np.float32(self.b1p * np.float32(0.9))
         self.b2p = np.float32(self.b2p * np.float32(0.999))
-        eng.adam_apply(theta, self.m, self.v, acc, lr, float(self.b1p), float(self.b2p), grad_scale)
+        n = theta.numel()
+        off = getattr(eng, "meta_off", 0) if (n != acc.numel() or n != self.m.numel()) else 0
+        g = acc if acc.numel() == n else acc[off:off + n]
+        m = self.m if self.m.numel() == n else self.m[off:off + n]
+        v = self.v if self.v.numel() == n else self.v[off:off + n]
+        eng.adam_apply(theta, m, v, g, lr, float(self.b1p), float(self.b2p), grad_scale)
         if clear:
             acc.zero_()
 
@@ -161,7 +168,7 @@ def mldg_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
         eng.set_weights(theta)
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "mldg_train", meta_train_step, optimizer="accumulate",
                  window=wt)
-        live = eng.get_weights()[:theta.numel()].clone()
+        live = eng.meta_weights.clone()
         outer.apply(eng, live, acc, meta_lr, grad_scale, clear=False)
         eng.set_weights(live)
         dm = d
@@ -188,6 +195,12 @@ def pcgrad_epoch(eng, outer, cur, aux, seq, aux_plan, perm_fn, batch_size, lr, m
     one outer-Adam step of the live model with the result.  cur / aux: two full-size flat vectors.
     aux_plan = {domain: [auxiliary domains]}."""
     trace = []
+    # the projection and the outer step cover the meta parameters only (pcgrad.py:152-160 walks `self.model_meta_parms`)
+    tensors = None
+    if eng.n_meta != eng.n_params and hasattr(eng, "segment_shapes"):
+        shapes = eng.segment_shapes()
+        lo, hi = eng.meta_off, eng.meta_off + eng.n_meta
+        tensors = [(off, shapes[n][0], shapes[n][1]) for n, (off, cnt) in eng.segments.items() if off >= lo and off + cnt <= hi]
     for d in seq:
         eng.bind_accumulator(cur)
         cur.zero_()
@@ -198,8 +211,8 @@ def pcgrad_epoch(eng, outer, cur, aux, seq, aux_plan, perm_fn, batch_size, lr, m
             aux.zero_()
             run_pass(eng, a, perm_fn, batch_size, lr, trace, "pcgrad_aux", 0, optimizer="accumulate",
                      window=windows[a][0] if windows else None)
-            eng.pcgrad_project(cur, aux)
-        live = eng.get_weights().clone()
+            eng.pcgrad_project(cur, aux, tensors)
+        live = eng.meta_weights.clone()
         outer.apply(eng, live, cur, meta_lr, grad_scale)
         eng.set_weights(live)
     return trace
@@ -220,7 +233,7 @@ def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, 
         run_pass(eng, query, perm_fn, batch_size, lr, trace, "dr_query", domain_regulation_step)
         if batch_variant:
             shared = theta if merged_method == "times" else None
-            eng.accumulate(acc, eng.weights, merged, shared, 1.0)
+            eng.accumulate(acc, eng.meta_weights, merged, shared, 1.0)
         else:
             # phi += (theta~ - merged) * gamma; merged = theta (+|*) phi; model := merged for the next support --
             # one pass over the vectors instead of three launches (bit-identical to interp + merge + set_weights)
@@ -236,7 +249,7 @@ def finetune_query(eng, theta, phi, query, perm_fn, batch_size, lr, trace, merge
     eng.merge(merged, theta, phi, merged_method)
     eng.set_weights(merged)
     run_pass(eng, query, perm_fn, batch_size, lr, trace, "dr_finetune")
-    eng.sub(phi, eng.weights, merged)
+    eng.sub(phi, eng.meta_weights, merged)
 
 
 def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
@@ -248,7 +261,7 @@ def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged
     eng.set_weights(theta)
     for d in plan["seq"]:
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
-    eng.interp(theta, eng.weights, theta, meta_lr)
+    eng.interp(theta, eng.meta_weights, theta, meta_lr)
     # DR phase (mamdr.py:59-108)
     merged = scratch if scratch is not None else torch.empty_like(theta)
     acc = torch.zeros_like(theta) if batch_variant else None

@@ -39,7 +39,8 @@ class MAMDR(SpecificBase):
         steps = [self.dataset.train_dataset[d]["n_step"] for d in range(self.n_domain)]
         phis = {}
         for domain_idx in range(self.n_domain):
-            phis[domain_idx] = self.model.pack(self.base_model.draw_initial_tensors())[:self.model.n_meta].clone()
+            full = self.model.pack(self.base_model.draw_initial_tensors())
+            phis[domain_idx] = full[self.model.meta_off:self.model.meta_off + self.model.n_meta].clone()
         self.balanced = parallel.BalancedMAMDR(self.model, meta, self.meta_weights, phis, steps,
                                                dn_mode=tc.get("dn_mode", "sharded"))
         self.domain_weights = self.balanced.phis

@@ -29,7 +29,8 @@ class MAML(object):
         if names[0] == "all":
             self.model_meta_parms = list(self.model.segments.keys())
         elif names[0] == "all_hidden":
-            self.model_meta_parms = [s for s in self.model.segments if "emb" not in s]
+            # maml.py:160-166: every variable whose NAME lacks "emb" (deepctr names the linear tables "linear...sparse_emb_*" too)
+            self.model_meta_parms = [s for s in self.model.segments if "emb" not in self.model.keras_name(s)]
         else:
             chosen = []
             for name in names:
@@ -38,21 +39,33 @@ class MAML(object):
                     raise ValueError("meta parms: {} not found in the model".format(name))
                 chosen += hit
             self.model_meta_parms = chosen
-        # The engine lays the flat vector out so that ONE meta set is a prefix of it: everything for the
-        # mlp / deepfm towers, the reference's Star filter (tables, kernel_shared, bias_shared;
-        # config/Taobao-10/star_taobao.json:37-41) for the Star tower.  Other subsets are not built.
-        n_meta = self.model.n_meta
-        prefix = set(s for s, (off, cnt) in self.model.segments.items() if off + cnt <= n_meta)
-        if set(self.model_meta_parms) != prefix:
-            raise NotImplementedError("meta_parms %s select %s; this tower's engine supports exactly %s"
-                                      % (self.train_config["meta_parms"], sorted(self.model_meta_parms),
-                                         sorted(prefix)))
+        # theta / phi cover ONE contiguous range of the flat vector (alignment padding between two selected tensors aside):
+        # everything ("all"), the reference's Star filter (tables, kernel_shared, bias_shared;
+        # config/Taobao-10/star_taobao.json:37-41: the prefix the Star block is laid out for), "all_hidden" (everything
+        # behind the embedding tables), or any name list that selects neighbouring tensors.  Scattered sets are not built.
+        segs = self.model.segments
+        chosen = sorted(self.model_meta_parms, key=lambda n: segs[n][0])
+        lo, hi = segs[chosen[0]][0], segs[chosen[0]][0] + segs[chosen[0]][1]
+        between = set()
+        for n in chosen[1:]:
+            off, cnt = segs[n]
+            if off - hi > 3:
+                between = set(k for k, (o, c) in segs.items() if hi <= o < off)
+                raise NotImplementedError("meta_parms %s select tensors that are not neighbours in the flat vector (%s sit "
+                                          "between them): scattered meta sets are not built"
+                                          % (self.train_config["meta_parms"], sorted(between)))
+            hi = off + cnt
+        if lo == 0 and hi >= self.model.n_params - 3:
+            hi = self.model.n_params
+        if lo == 0 and getattr(self.model, "tower", "") == "star" and hi == self.model.n_meta:
+            return                                  # the engine's own prefix (its default)
+        self.model.set_meta_range(lo, hi - lo)
 
     def _set_model_meta_parms(self, meta_weights):
         self.model.set_weights(meta_weights)
 
     def _get_meta_weights(self):
-        return self.model.get_weights()[:self.model.n_meta].clone()
+        return self.model.meta_weights.clone()
 
     # ------------------------------------------------------------------ validation
     def val(self):

@@ -26,8 +26,6 @@ class PCGrad(MAML):
             grad_scale = 1.0
         windows = self.build_meta_windows()
         self._get_model_meta_parms()
-        if self.model.n_meta != self.model.n_params:
-            raise NotImplementedError("PCGrad over a meta-parameter subset (Star) is not built")
         self.model.optimizer_reset()
         outer = meta.OuterAdamState(self.model)
         cur, aux = self.model.new_vector(), self.model.new_vector()

@@ -47,7 +47,7 @@ def shard_plan(plan, owner, rank):
 
 def allreduce_delta(eng, theta, delta_buf):
     """delta = live - theta on every rank; sum over ranks (ONE collective)."""
-    eng.sub(delta_buf, eng.weights, theta)
+    eng.sub(delta_buf, eng.meta_weights, theta)
     rank, ws = world()
     if ws > 1:
         dist.all_reduce(delta_buf, op=dist.ReduceOp.SUM)
@@ -68,7 +68,7 @@ def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_
         meta.run_pass(eng, target, perm_fn, batch_size, lr, trace, "dn")
     rank, ws = world()
     if ws == 1:
-        eng.interp(theta, eng.weights, theta, meta_lr)
+        eng.interp(theta, eng.meta_weights, theta, meta_lr)
     else:
         allreduce_delta(eng, theta, delta_buf)
         eng.interp(theta, delta_buf, zero_buf, meta_lr)
@@ -85,7 +85,7 @@ def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, 
     for d in seq_local:
         eng.set_weights(local)
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
-        eng.interp(local, eng.weights, local, meta_lr)
+        eng.interp(local, eng.meta_weights, local, meta_lr)
     rank, ws = world()
     if ws == 1:
         theta.copy_(local)
@@ -107,7 +107,7 @@ def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size
     for d in seq_local:
         eng.set_weights(theta)
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
-        eng.accumulate(acc, eng.weights, theta)
+        eng.accumulate(acc, eng.meta_weights, theta)
     rank, ws = world()
     if ws > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
@@ -168,7 +168,12 @@ class TailSync(object):
 
     def __init__(self, eng):
         self.eng = eng
+        if getattr(eng, "meta_off", 0) and eng.n_meta != eng.n_params and world()[1] > 1:
+            raise NotImplementedError("multi-process runs support meta parameters that form a prefix of the flat vector "
+                                      "(\"all\", the Star filter); got the range [%d, %d)" % (eng.meta_off, eng.meta_off + eng.n_meta))
         self.n_meta, self.n_tail = eng.n_meta, eng.n_params - eng.n_meta
+        if getattr(eng, "meta_off", 0):
+            self.n_tail = 0
         self.aux = getattr(eng, "aux", None)
         self.active = self.n_tail > 0
         if not self.active:
@@ -387,7 +392,7 @@ class BalancedMAMDR(object):
                 dist.broadcast(self.delta, src=0)
                 wire += self.P * 4 if rank == 0 else 0
         else:
-            eng.sub(self.delta, eng.weights, theta)
+            eng.sub(self.delta, eng.meta_weights, theta)
             if self.tail.active:
                 # [delta | tail displacement | statistics] in ONE collective
                 self.tail.fill(self.tail_buf)

@@ -44,7 +44,7 @@ class FakeEngine(object):
         return segment
 
     def new_vector(self, like=None, meta=False):
-        return like.clone() if like is not None else torch.zeros(self.n_params, dtype=torch.float32)
+        return like.clone() if like is not None else torch.zeros(self.n_meta if meta else self.n_params, dtype=torch.float32)
 
     def pack(self, named):
         return torch.from_numpy(np.concatenate([np.asarray(named[n], F32).ravel() for n in self.segments]))
@@ -57,8 +57,24 @@ class FakeEngine(object):
     def weights(self):
         return torch.from_numpy(self.oracle.get_flat())
 
+    meta_off = 0
+
+    def set_meta_range(self, off, count):
+        self.meta_off, self.n_meta = int(off), int(count)
+
+    @property
+    def meta_weights(self):
+        return self.weights[self.meta_off:self.meta_off + self.n_meta]
+
     def set_weights(self, vec):
-        self.oracle.set_flat(vec.numpy().copy())
+        n = vec.numel()
+        if n == self.n_params:
+            self.oracle.set_flat(vec.numpy().copy())
+            return
+        full = self.oracle.get_flat()
+        off = self.meta_off if n == self.n_meta else 0
+        full[off:off + n] = vec.numpy()
+        self.oracle.set_flat(full)
 
     def get_weights(self, out=None):
         w = self.weights
@@ -75,7 +91,7 @@ class FakeEngine(object):
         dst.copy_(torch.from_numpy(oouter.merge(theta.numpy(), phi.numpy(), method)))
 
     def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
-        self.interp(phi, self.weights[:phi.numel()], merged, gamma)
+        self.interp(phi, self.meta_weights, merged, gamma)
         self.merge(merged, theta, phi, method)
         if assign_model:
             self.set_weights(merged)

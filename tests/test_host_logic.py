@@ -595,3 +595,62 @@ def test_nfm_pnn_run_entry(tmp_path, monkeypatch, name):
     cfg = tiny_config(tmp_path, name, epochs=2)
     avg_loss, avg_auc, dl, da = cli.main(cfg, FakeEngine)
     assert sorted(da) == [0, 1, 2] and np.isfinite(avg_loss) and 0.3 < avg_auc < 1.0
+
+
+# ------------------------------------------------------------------ meta parameter filters (maml.py:153-179)
+def test_all_hidden_meta_range_follows_the_reference_semantics():
+    """meta_parms ["all_hidden"] (maml.py:160-166): theta covers every variable whose name lacks "emb" -- here one contiguous
+    range behind the domain table.  A Domain Negotiation epoch then resets / interpolates the hidden weights only; the
+    domain table is trained by the inner steps and never reset.  Checked against the same loop written out on the oracle."""
+    g = small_gen()
+    sizes = {d: g["data"]["train"][d]["uid"].shape[0] for d in range(3)}
+
+    def fresh():
+        eng = FakeEngine(g["n_user"], g["n_item"], 3, 64, emb_dim=8, hidden=(16, 8, 4))
+        eng.bind_table("user_emb", g["tables"]["user_emb"])
+        eng.bind_table("item_emb", g["tables"]["item_emb"])
+        for d in range(3):
+            c = g["data"]["train"][d]
+            eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+        return eng
+    eng, ref = fresh(), fresh()
+    off = eng.segments["W0"][0]
+    assert off == 3 * 8                                        # the domain table sits in front
+    eng.set_meta_range(off, eng.n_params - off)
+    theta = eng.meta_weights.clone()
+    assert theta.numel() == eng.n_params - 24
+    sh = [mplan.PassShuffler(sizes, 10000, 9, shuffle_fn=orng.shuffle_perm) for _ in range(2)]
+    seq = [2, 0, 1]
+    meta.dn_epoch(eng, theta, seq, sh[0], 64, 1e-3, 0.5)
+    # the same on the oracle-backed twin, by hand: model[hidden] := theta; passes; theta += (model[hidden] - theta) * 0.5
+    full = ref.oracle.get_flat()
+    th = full[off:].copy()
+    for d in seq:
+        meta.run_pass(ref, d, sh[1], 64, 1e-3, [], "dn")
+    after = ref.oracle.get_flat()
+    th = (th + (after[off:] - th) * np.float32(0.5)).astype(np.float32)
+    np.testing.assert_array_equal(theta.numpy(), th)
+    live = eng.oracle.get_flat()
+    np.testing.assert_array_equal(live[off:], th)              # hidden weights := theta
+    np.testing.assert_array_equal(live[:off], after[:off])     # the domain table keeps what the inner steps made of it
+    assert not np.array_equal(after[:off], full[:off])
+
+
+@pytest.mark.parametrize("name", ["mlp_meta_domain_negotiation", "mlp_meta", "mlp_meta_mamdr", "mlp_pcgrad", "mlp_meta_mldg"])
+def test_all_hidden_through_the_run_entry(tmp_path, monkeypatch, name):
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, name, epochs=2)
+    cfg["train"]["meta_parms"] = ["all_hidden"]
+    avg_loss, avg_auc, dl, da = cli.main(cfg, FakeEngine)
+    assert sorted(da) == [0, 1, 2] and np.isfinite(avg_loss) and 0.3 < avg_auc < 1.0
+
+
+def test_scattered_meta_parms_say_so(tmp_path, monkeypatch):
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "mlp_meta_domain_negotiation", epochs=1)
+    cfg["train"]["meta_parms"] = ["W0", "b2"]                 # W1, W2, b0, b1 sit between them
+    with pytest.raises(NotImplementedError, match="neighbours"):
+        cli.main(cfg, FakeEngine)
+    cfg["train"]["meta_parms"] = ["W1", "W2"]                 # neighbours: fine
+    avg_loss, avg_auc, _, da = cli.main(cfg, FakeEngine)
+    assert np.isfinite(avg_loss) and sorted(da) == [0, 1, 2]

@@ -59,13 +59,18 @@ __global__ __launch_bounds__(256) void k_exchange(f32x4* buf, unsigned* counters
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int m0 = 0; m0 < G; m0 += 8) {
             f32x4 v[8];
+            const f32x4* p[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int m = (m0 + u) % G;
-                const f32x4* p = buf + ((size_t)(cluster * 2 + (r & 1)) * G + m) * SLICE_F4 + tid;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(p) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int u = 0; u < 8; ++u) p[u] = buf + ((size_t)(cluster * 2 + (r & 1)) * G + (m0 + u) % G) * SLICE_F4 + tid;
+            // (eight loads in flight and their wait in ONE statement: the compiler must not touch the results earlier)
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+                "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+                "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+                "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                : "memory");
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int m = (m0 + u) % G;
