@@ -59,6 +59,8 @@ class MAMDR(SpecificBase):
                                               tc["meta_learning_rate"], tc["merged_method"],
                                               tc["domain_regulation_step"], batch_variant, tc["sample_num"],
                                               bool(tc["finetune_every_epoch"]))
+            if plan["dr"]:                       # (meta_finetune_val: the model of the rank that ran the plan's last query)
+                self.live_src = self.balanced.owner(plan["dr"][-1][0])
             if epoch % tc["val_every_step"] == 0:
                 self.balanced.sync_tail()           # Star: one model outside theta / phi again before it is scored
                 _, val_avg_auc, _, val_domain_auc = self.val()

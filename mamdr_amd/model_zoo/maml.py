@@ -79,13 +79,20 @@ class MAML(object):
         split, each starting from the current model weights (the optimiser slots are NOT restored between
         domains: Keras' set_weights leaves them alone); the model is put back afterwards."""
         from .. import meta, parallel
-        if parallel.world()[1] > 1:
-            raise NotImplementedError("meta_finetune_step > 0 in a multi-process run is not built")
+        rank, world = parallel.world()
         weights = self.model.get_weights().clone()
+        if world > 1:
+            # several processes: every rank starts from the SAME weights -- the ones the single-process loop would hold
+            # here: theta for the wrappers that leave theta in the model, the model of the rank that ran the plan's last
+            # pass otherwise (`live_src`, set by the sharded MAMDR loop) -- and the domains are dealt round-robin
+            import torch.distributed as dist
+            dist.broadcast(weights, src=int(getattr(self, "live_src", 0)))
         aux = getattr(self.model, "aux", None)      # Star: PartitionedNorm moving statistics move while training
         aux = aux.clone() if aux is not None else None
         domain_loss, domain_auc = {}, {}
-        for idx in self.dataset.train_dataset:
+        for i, idx in enumerate(self.dataset.train_dataset):
+            if world > 1 and i % world != rank:
+                continue
             self.model.set_weights(weights)
             print("Finetune on domain: {}".format(idx))
             for _ in range(self.train_config["meta_finetune_step"]):
@@ -95,6 +102,9 @@ class MAML(object):
         self.model.set_weights(weights)
         if aux is not None:
             self.model.aux.copy_(aux)
+        if world > 1:
+            local = {d: (domain_loss[d], domain_auc[d]) for d in domain_loss}
+            domain_loss, domain_auc = parallel.gather_domain_scalars(local, self.n_domain, self.model.device)
         return self._summarise("val", domain_loss, domain_auc)
 
     def build_meta_windows(self):
