@@ -105,6 +105,12 @@ struct mamdr_ctx {
     int star_dense_slices = 0;      // MAMDR_STAR_DENSE_SLICES=1: every slice swept every step (diagnostic; same bits)
     bool star_pn_in_tower = true;   // PartitionedNorm backward: per-tile sums in the tower's tail (MAMDR_STAR_PNB_KERNEL=1:
                                     // k_star_pnb_partial as a launch of its own; same bits)
+    // MAMDR_STAR_PNB_FUSED=1 (measured, not adopted -- DESIGN.md section 8): no k_star_pnb_apply either; the table rows
+    // get PartitionedNorm's backward inside k_emb_reduce and the domain row's gradient comes in closed form from
+    // k_star_pnb_final.  Saves the 6.3 us launch, costs 2.3 us in k_wgrad_reduce -- and the closed form is EXACTLY zero
+    // where the per-row sum leaves rounding residue, which Adam turns into a random walk of the domain row (in the
+    // reference too): the moving statistics then lag differently and validation AUC moves by ~1e-3.
+    bool star_pn_fused = false;
     int t4_no_w1l = 0;              // MAMDR_T4_NO_W1L=1: k_tower4 without the W1 image in LDS (diagnostic)
     int fused_max_batch = 1024;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size):
                                     // 4 rows x the CU count, set at mamdr_create
@@ -331,7 +337,7 @@ static void fill_emb_args(const mamdr_ctx* c, int32_t optimizer, float alpha, fl
     ea.alpha_log = c->alpha_log;
     ea.log_mask = c->log_cap - 1;
     ea.t_now = (int)c->adam_t;
-    if (c->star && c->star_pn_in_tower) {      // PartitionedNorm's backward rides in k_emb_reduce (EmbStepArgs::pn_sums)
+    if (c->star && c->star_pn_fused) {         // PartitionedNorm's backward rides in k_emb_reduce (EmbStepArgs::pn_sums)
         ea.pn_sums = c->star_sums;
         ea.pn = c->pn;
         ea.pn_rows = (float)rows;
@@ -571,7 +577,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ba.sums = c->star_sums;
     ba.dmpart = c->star_dmpart;
     ba.dmsum = c->star_sums + 2 * XDIM;
-    ba.fused = c->star_pn_in_tower ? 1 : 0;
+    ba.fused = c->star_pn_fused ? 1 : 0;
     // lazy table Adam with fused tails: PartitionedNorm's backward first (it only needs the tower's outputs), then
     // [k_wgrad + k_emb_reduce(t) + k_emb_rows(t+1)], then [k_star_update + k_emb_catchup(t+1)]
     const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile &&
@@ -794,6 +800,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     }
     if (const char* ev = getenv("MAMDR_NO_TAILFUSE")) c->tail_fuse = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_STAR_PNB_KERNEL")) c->star_pn_in_tower = atoi(ev) == 0;
+    if (const char* ev = getenv("MAMDR_STAR_PNB_FUSED")) c->star_pn_fused = atoi(ev) != 0 && c->star_pn_in_tower;
     if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
