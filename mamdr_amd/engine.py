@@ -346,6 +346,8 @@ class TowerEngine(FlatVectorOps):
             # average_meta_grad == "moving_mean": every meta batch updates the accumulator's moving average
             # (maml.py:219-220) -- one step at a time into a scratch gradient, then mamdr_moving_average
             ema = self._ema
+            if loss_out is not None:
+                raise ValueError("accumulate passes under average_meta_grad = moving_mean report no per-step loss")
             for s in range(first_step, first_step + n_steps):
                 ema["scratch"].zero_()
                 L.check(self.lib.mamdr_train_steps_n(self.ctx, domain, _ptr(perm), -1 if pass_rows is None else n,
