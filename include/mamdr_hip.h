@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 10
+#define MAMDR_ABI_VERSION 11
 
 enum {
     MAMDR_OK = 0,
@@ -307,7 +307,10 @@ enum { MAMDR_GRAPH_SHARED_BOTTOM = 0,   /* deep_mtl_ctr.py:25-30  models.SharedB
           serves every domain; flat vector = [user_emb item_emb (lin_user lin_item) if trainable] domain_emb W0 W1 W2 b0 b1 b2
           wo gb (lin_domain); hidden_dim in expert_hidden, tower / gate fields unused */
        MAMDR_GRAPH_NFM = 3,             /* deepctr.py:33-35  models.NFM: linear tables + DNN(BiInteractionPooling) */
-       MAMDR_GRAPH_PNN = 4 };           /* deepctr.py:44-46  models.PNN: DNN([fields | pairwise inner products]) */
+       MAMDR_GRAPH_PNN = 4,             /* deepctr.py:44-46  models.PNN: DNN([fields | pairwise inner products]) */
+       /* deepctr.py:41-43  models.CCPM: convolutions (6, 1) x 4 and (5, 1) x 4 over the field axis with tanh and k-max pooling
+          (k = 1 with three fields) -> DNN + linear tables; conv tensors conv1_w [6][4] conv1_b conv2_w [4][4] conv2_b precede W0 */
+       MAMDR_GRAPH_CCPM = 5 };
 typedef struct mamdr_graph mamdr_graph;
 typedef struct mamdr_graph_config {
     int32_t abi_version;        /* MAMDR_ABI_VERSION */

@@ -201,15 +201,16 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
 }
 
 // db[n] = sum over the batch rows of dz[b][n]: 64 columns per workgroup, 4 row groups summed through LDS in order
-__global__ __launch_bounds__(256) void k_graph_colsum(const float* dz, int ld, int rows, float* out) {
+__global__ __launch_bounds__(256) void k_graph_colsum(const float* dz, int ld, int rows, float* out, int n_valid) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int b = g; b < rows; b += 4) s += dz[(size_t)b * ld + col];
+    if (col < n_valid)
+        for (int b = g; b < rows; b += 4) s += dz[(size_t)b * ld + col];
     red[g][c] = s;
     __syncthreads();
-    if (g == 0) out[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (g == 0 && col < n_valid) out[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1)
@@ -312,6 +313,115 @@ __global__ __launch_bounds__(64) void k_graph_lin_domain_grad(const float* dlogi
     for (int b = 0; b < rows; ++b)
         if (domrow[b] == d) s += dlogit[b];
     g[d] = s + two_l2 * w[d];
+}
+
+// ------------------------------------------------------------------ CCPM: convolutions over the FIELD axis, one wave per row
+// (deepctr CCPM with the three fields of this model, conv_kernel_width (6, 5), conv_filters (4, 4) -- oracle/fmnets.py:
+// Conv2D((6, 1), 'same', tanh) over [3 fields x 128], maximum over the fields (KMaxPooling, k = 1), Conv2D((5, 1)) on the
+// one row left = its centre tap, tanh; features [128 x 4]).  conv = [w1 6x4 | b1 4 | w2 4x4 (in, out) | b2 4] = 48 floats.
+struct CcpmArgs {
+    float* act; float* dact; int ld; int f_col, cg_col; int rows_pad; int dx_all;
+    const float* conv;
+};
+// a1 of (position, filter) for the three raw values of one embedding column, its maximum and where it sits
+__device__ __forceinline__ void ccpm_unit(const float* __restrict__ cv, const float (&x)[3], float (&m1)[4], int (&arg)[4],
+                                          float (&a2)[4]) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        float best = -3.0e38f;
+        int at = 0;
+#pragma unroll
+        for (int pos = 0; pos < 3; ++pos) {
+            float pre = 0.f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int src = pos + t - 2;        // TF 'same' for an even kernel: 2 taps before, 3 after
+                if (src >= 0 && src < 3) pre += x[src] * cv[t * 4 + f];
+            }
+            const float a = tanhf(pre + cv[24 + f]);
+            if (a > best) { best = a; at = pos; }  // (the first maximum wins a tie, as numpy's argmax)
+        }
+        m1[f] = best;
+        arg[f] = at;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float pre = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) pre += m1[f] * cv[28 + f * 4 + o];
+        a2[o] = tanhf(pre + cv[44 + o]);
+    }
+}
+__global__ __launch_bounds__(256) void k_graph_ccpm_fwd(const CcpmArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    float* row = a.act + (size_t)r * a.ld;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = 2 * lane + q;
+        const float x[3] = {row[e], row[EMB + e], row[2 * EMB + e]};
+        float m1[4], a2[4];
+        int arg[4];
+        ccpm_unit(a.conv, x, m1, arg, a2);
+        *reinterpret_cast<f32x4*>(row + a.f_col + 4 * e) = (f32x4){a2[0], a2[1], a2[2], a2[3]};
+    }
+}
+// d features -> d x and the row's share of the 48 convolution gradients (summed over the batch by k_graph_colsum)
+__global__ __launch_bounds__(256) void k_graph_ccpm_bwd(const CcpmArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= a.rows_pad) return;
+    const float* row = a.act + (size_t)r * a.ld;
+    float* drow = a.dact + (size_t)r * a.ld;
+    const float* cv = a.conv;
+    float gc[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) gc[k] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = 2 * lane + q;
+        const float x[3] = {row[e], row[EMB + e], row[2 * EMB + e]};
+        float m1[4], a2[4], dx[3] = {0.f, 0.f, 0.f};
+        int arg[4];
+        ccpm_unit(cv, x, m1, arg, a2);
+        const f32x4 df = *reinterpret_cast<const f32x4*>(drow + a.f_col + 4 * e);
+        float dm1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float dp2 = df[o] * (1.0f - a2[o] * a2[o]);
+            gc[44 + o] += dp2;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                gc[28 + f * 4 + o] += m1[f] * dp2;
+                dm1[f] += dp2 * cv[28 + f * 4 + o];
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float dp1 = dm1[f] * (1.0f - m1[f] * m1[f]);      // m1 = a1 at its maximum
+            gc[24 + f] += dp1;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                for (int pos = 0; pos < 3; ++pos) {
+                    const int src = pos + t - 2;
+                    if (src >= 0 && src < 3 && pos == arg[f]) {
+                        gc[t * 4 + f] += x[src] * dp1;
+                        dx[src] += dp1 * cv[t * 4 + f];
+                    }
+                }
+            }
+        }
+        if (a.dx_all) {
+            drow[e] = dx[0];
+            drow[EMB + e] = dx[1];
+        }
+        drow[2 * EMB + e] = dx[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+        const float v = wave_sum(gc[k]);
+        if (lane == 0) drow[a.cg_col + k] = v;
+    }
 }
 
 // ------------------------------------------------------------------ gate: softmax(q Wg) and the mixture, one wave per row
@@ -594,7 +704,10 @@ struct mamdr_graph {
     int n_h = 0;                // expert width
     // single-output towers of the deepctr family on the same layers (NFM, PNN): ONE task serves every domain
     bool single = false;
-    int f_col = 0;              // interaction features: NFM 128 columns, PNN 3 (+ 1 pad)
+    bool has_lin = false;       // NFM / CCPM / AutoInt: the three 1-d linear tables (deepctr get_linear_logit)
+    int f_col = 0;              // interaction features: NFM 128 columns, PNN 3 (+ 1 pad), CCPM 512
+    int cg_col = 0;             // CCPM: 64 columns of the gradient workspace for the rows' shares of the 48 conv gradients
+    int64_t conv_off = 0;       // CCPM: [w1 6x4 | b1 | w2 4x4 | b2]
     int64_t lin_d_off = 0;      // NFM: 1-d linear table of the domain feature (behind the global bias)
     int64_t lin_u_off = 0, lin_i_off = 0;       // ... of the user / item features (trainable tables only)
     float *extra = nullptr, *glin_u = nullptr, *glin_i = nullptr;
@@ -711,7 +824,7 @@ void dnn_backward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, in
         a.K = sc.rp;
         launch_gemm(2, a, L.in, L.out, g->stream);
         hipLaunchKernelGGL(k_graph_colsum, dim3(L.out / 64), dim3(256), 0, g->stream, g->dact + cols[l], g->ld, sc.rp,
-                           g->G(L.b_off));
+                           g->G(L.b_off), L.out);
         memset(&a, 0, sizeof(a));
         a.A = g->dact + cols[l];        // d in = dz W^T
         a.lda = g->ld;
@@ -776,8 +889,27 @@ void fill_feat(const mamdr_graph* g, const Task& t, const StepCtx& sc, FeatArgs&
     fa.n_out = L0.out;
 }
 
+void fill_ccpm(const mamdr_graph* g, const StepCtx& sc, CcpmArgs& ca) {
+    memset(&ca, 0, sizeof(ca));
+    ca.act = g->act;
+    ca.dact = g->dact;
+    ca.ld = g->ld;
+    ca.f_col = g->f_col;
+    ca.cg_col = g->cg_col;
+    ca.rows_pad = sc.rp;
+    ca.dx_all = g->tables ? 1 : 0;
+    ca.conv = g->params + g->conv_off;
+}
+
 int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
     if (g->single) {
+        if (g->cfg.kind == MAMDR_GRAPH_CCPM) {
+            CcpmArgs ca;
+            fill_ccpm(g, sc, ca);
+            hipLaunchKernelGGL(k_graph_ccpm_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
+            dnn_forward(g, g->dnns[t.tower], t.col[0], g->f_col, sc);
+            return t.col[0].back();
+        }
         FeatArgs fa;
         fill_feat(g, t, sc, fa);
         hipLaunchKernelGGL(k_graph_feat_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
@@ -811,7 +943,7 @@ void refresh_sumsq(mamdr_graph* g) {
     launch_sumsq(g->params, (int64_t)g->cfg.n_user * EMB, g->sumsq_partials, g->frozen_sumsq + 0, g->stream);
     launch_sumsq(g->params + (size_t)g->cfg.n_user * EMB, (int64_t)g->cfg.n_item * EMB, g->sumsq_partials, g->frozen_sumsq + 1,
                  g->stream);
-    if (g->cfg.kind == MAMDR_GRAPH_NFM) {
+    if (g->has_lin) {
         launch_sumsq(g->params + g->lin_u_off, g->cfg.n_user, g->sumsq_partials, g->frozen_sumsq + 2, g->stream);
         launch_sumsq(g->params + g->lin_i_off, g->cfg.n_item, g->sumsq_partials, g->frozen_sumsq + 3, g->stream);
     }
@@ -876,10 +1008,11 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
     if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");
     if (cfg->emb_trainable && cfg->max_batch > 16384) return gfail(MAMDR_EINVAL, "trainable tables: max_batch <= 16384");
-    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_PNN)
+    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_CCPM)
         return gfail(MAMDR_EINVAL, "unknown graph tower kind %d", cfg->kind);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return gfail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
-    const bool single = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_PNN;
+    const bool single = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_PNN || cfg->kind == MAMDR_GRAPH_CCPM;
+    const bool has_lin = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_CCPM;
     const bool gated = cfg->kind == MAMDR_GRAPH_MMOE || cfg->kind == MAMDR_GRAPH_PLE;
     if (cfg->n_expert_hidden < 1 || cfg->n_expert_hidden > 4 || (!single && (cfg->n_tower_hidden < 1 || cfg->n_tower_hidden > 4)) ||
         (gated && (cfg->n_gate_hidden < 1 || cfg->n_gate_hidden > 4)))
@@ -905,6 +1038,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     g->stream = (hipStream_t)stream;
     g->gated = gated;
     g->single = single;
+    g->has_lin = has_lin;
     g->n_h = cfg->expert_hidden[cfg->n_expert_hidden - 1];
     g->data.resize((size_t)cfg->n_domain * 3);
     // ---- flat vector: the block every task's model trains, then one block per task (oracle/mtl.py Spec.tensors)
@@ -913,7 +1047,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (g->tables) {        // [user table | item table] contiguous at the head (k_emb_sweep walks them as one range)
         add_tensor(g, "user_emb", cfg->n_user, EMB);
         add_tensor(g, "item_emb", cfg->n_item, EMB);
-        if (cfg->kind == MAMDR_GRAPH_NFM) {     // their 1-d linear tables train with them (deepctr: same feature column)
+        if (has_lin) {      // their 1-d linear tables train with them (deepctr: same feature column)
             g->lin_u_off = add_tensor(g, "lin_user", cfg->n_user, 1);
             g->lin_i_off = add_tensor(g, "lin_item", cfg->n_item, 1);
         }
@@ -936,13 +1070,20 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         Dnn d;
         d.name = "dnn";
         const int nfm = cfg->kind == MAMDR_GRAPH_NFM;
-        d.in_dim = nfm ? EMB : XDIM;
+        const bool ccpm = cfg->kind == MAMDR_GRAPH_CCPM;
+        if (ccpm) {         // conv1_w [6][4] | conv1_b [4] | conv2_w [4 in][4 out] | conv2_b [4]: 48 contiguous floats
+            g->conv_off = add_tensor(g, "conv1_w", 6, 4);
+            add_tensor(g, "conv1_b", 1, 4);
+            add_tensor(g, "conv2_w", 4, 4);
+            add_tensor(g, "conv2_b", 1, 4);
+        }
+        d.in_dim = nfm ? EMB : (ccpm ? 4 * EMB : XDIM);
         int in = d.in_dim;
         for (int l = 0; l < cfg->n_expert_hidden; ++l) {
             Layer L;
             L.in = in;
             L.out = cfg->expert_hidden[l];
-            L.w_off = add_tensor(g, "W" + std::to_string(l), (l == 0 && !nfm) ? in + 3 : in, L.out);
+            L.w_off = add_tensor(g, "W" + std::to_string(l), (l == 0 && cfg->kind == MAMDR_GRAPH_PNN) ? in + 3 : in, L.out);
             L.b_off = 0;
             L.id = (uint32_t)l;
             d.layers.push_back(L);
@@ -953,12 +1094,13 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         t.tower = 0;
         t.head_w = add_tensor(g, "wo", in, 1);
         t.head_gb = add_tensor(g, "gb", 1, 1);
-        if (nfm) g->lin_d_off = add_tensor(g, "lin_domain", cfg->n_domain, 1);
+        if (has_lin) g->lin_d_off = add_tensor(g, "lin_domain", cfg->n_domain, 1);
         g->shared_end = g->n_params;
         t.blk_off = t.blk_end = g->n_params;
         int c = XDIM;
         g->f_col = c;
-        c += nfm ? EMB : 4;
+        c += nfm ? EMB : (ccpm ? 4 * EMB : 4);
+        if (ccpm) { g->cg_col = c; c += 64; }
         t.path.push_back(0);
         std::vector<int> cols;
         for (const Layer& L : d.layers) { cols.push_back(c); c += L.out; }
@@ -1028,7 +1170,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     alloc((void**)&g->frozen_sumsq, 4 * sizeof(float));
     alloc((void**)&g->sumsq_partials, 1024 * sizeof(float));
     alloc((void**)&g->eval_acc, 4 * sizeof(float));
-    if (cfg->kind == MAMDR_GRAPH_NFM) {
+    if (has_lin) {
         alloc((void**)&g->extra, rp * sizeof(float));
         if (g->tables) {
             alloc((void**)&g->glin_u, rp * sizeof(float));
@@ -1228,7 +1370,18 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         // tables are frozen): the first writer overwrites, the others add
         bool dx_started = false;
         const int dx_first = g->tables ? 0 : 2 * EMB, dx_n = g->tables ? 0 : EMB;
-        if (g->single) {
+        if (g->single && g->cfg.kind == MAMDR_GRAPH_CCPM) {
+            // d features from the first layer; the convolutions' backward per row; their 48 gradients summed over the batch
+            dnn_backward(g, tower, t.col[0], g->f_col, g->f_col, -1, false, 0, 0, sc);
+            CcpmArgs ca;
+            fill_ccpm(g, sc, ca);
+            hipLaunchKernelGGL(k_graph_ccpm_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
+            hipLaunchKernelGGL(k_graph_colsum, dim3(1), dim3(256), 0, g->stream, g->dact + g->cg_col, g->ld, sc.rp,
+                               g->G(g->conv_off), 48);
+            hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3((g->cfg.n_domain + 63) / 64), dim3(64), 0, g->stream, g->dlogit,
+                               g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
+                               g->G(g->lin_d_off));
+        } else if (g->single) {
             const bool nfm = g->cfg.kind == MAMDR_GRAPH_NFM;
             FeatArgs fa;
             fill_feat(g, t, sc, fa);
@@ -1298,7 +1451,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             ea.t[1].gbuf = g->gbuf_i;
             ea.t[1].hasdup = g->hasdup_i;
             ea.t[1].dx_off = EMB;
-            if (g->cfg.kind == MAMDR_GRAPH_NFM) {       // their 1-d linear tables: scatter-add of d loss / d logit, same rule
+            if (g->has_lin) {       // their 1-d linear tables: scatter-add of d loss / d logit, same rule
                 ea.two_l2_lin = 2.0f * g->cfg.l2_linear;
                 ea.t[0].lin_p = g->params + g->lin_u_off;
                 ea.t[0].lin_m = g->adam_m + g->lin_u_off;
@@ -1311,7 +1464,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             }
             launch_emb_reduce(ea, g->stream);
             launch_emb_sweep(ea, g->stream);
-            if (g->cfg.kind == MAMDR_GRAPH_NFM) launch_lin_sweep(ea, g->stream);      // (reads the row maps, then resets them)
+            if (g->has_lin) launch_lin_sweep(ea, g->stream);      // (reads the row maps, then resets them)
         }
         // ---- optimiser on the two ranges this task's model trains
         const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};

@@ -6,7 +6,8 @@ tower (deepctr.py:95-136) on the HIP engine; names containing `deepfm` add the l
 tables and the FM second-order term to the logit (deepctr.py:36-38, SURVEY A.8);
 `wdl` is the same without the FM term (deepctr.py:29-32); `nfm` (deepctr.py:33-35: linear tables + DNN over the
 bi-interaction of the three fields) and `pnn` (deepctr.py:44-46: DNN over the fields and their pairwise inner
-products) run on the generic-layer engine (`GraphEngine`, csrc/graph_engine.hip); autoint / ccpm raise.  Initial tensors follow the reference's initialisers (glorot normal for the
+products) and `ccpm` (deepctr.py:41-43: convolutions over the field axis) run on the generic-layer engine
+(`GraphEngine`, csrc/graph_engine.hip); autoint raises.  Initial tensors follow the reference's initialisers (glorot normal for the
 kernels, zeros for biases, N(0, 1e-4^2) for the domain table and for user/item tables
 without pretraining, constants from the pretrained tables otherwise) drawn from a numpy
 stream seeded with dataset.seed -- TF's own streams are not reproducible.
@@ -17,8 +18,8 @@ import numpy as np
 
 from .base_model import BaseModel
 
-OUT_OF_SCOPE = ("autoint", "ccpm")
-GRAPH_TOWERS = ("nfm", "pnn")
+OUT_OF_SCOPE = ("autoint",)
+GRAPH_TOWERS = ("nfm", "pnn", "ccpm")
 
 
 def glorot_normal(rs, fan_in, fan_out, shape):
@@ -66,9 +67,10 @@ class DeepCTR(BaseModel):
             tower = "wdl"
         elif "nfm" in name:               # deepctr.py:33-35
             tower = "nfm"
-        elif any(k in name for k in OUT_OF_SCOPE):     # deepctr.py:37-43
-            raise NotImplementedError("tower '%s': deepctr AutoInt (multi-head self-attention over the fields) and CCPM "
-                                      "(convolution + k-max pooling) are not built" % name)
+        elif any(k in name for k in OUT_OF_SCOPE):     # deepctr.py:37-40
+            raise NotImplementedError("tower '%s': deepctr AutoInt (multi-head self-attention over the fields) is not built" % name)
+        elif "ccpm" in name:              # deepctr.py:41-43
+            tower = "ccpm"
         elif "pnn" in name:               # deepctr.py:44-46
             tower = "pnn"
         elif "deepfm" in name:
@@ -139,10 +141,16 @@ class DeepCTR(BaseModel):
         t = initial_tensors(self.init_rs, self.n_uid, self.n_pid, self.n_domain, mc["user_dim"],
                             tuple(mc["hidden_dim"]), self.pretrained[0], self.pretrained[1])
         tower = getattr(self, "tower", None)
-        if tower in GRAPH_TOWERS:         # first kernel: NFM on the 128 interaction columns, PNN on the fields + 3 inner products
-            E, h0 = mc["user_dim"], mc["hidden_dim"][0]
-            in_dim = E if tower == "nfm" else 3 * E + 3
+        if tower in GRAPH_TOWERS:         # first kernel: NFM on the 128 interaction columns, PNN on the fields + 3 inner products,
+            E, h0 = mc["user_dim"], mc["hidden_dim"][0]       # CCPM on the [128 x 4] convolution features
+            in_dim = {"nfm": E, "pnn": 3 * E + 3, "ccpm": 4 * E}[tower]
             t["W0"] = glorot_normal(self.init_rs, in_dim, h0, (in_dim, h0))
+            if tower == "ccpm":           # Keras Conv2D defaults: glorot_uniform kernels [6,1,1,4] / [5,1,4,4] (centre tap kept), zero biases
+                lim1, lim2 = np.sqrt(6.0 / (6 * 1 + 6 * 4)), np.sqrt(6.0 / (5 * 4 + 5 * 4))
+                t["conv1_w"] = self.init_rs.uniform(-lim1, lim1, (6, 4)).astype(np.float32)
+                t["conv1_b"] = np.zeros(4, np.float32)
+                t["conv2_w"] = self.init_rs.uniform(-lim2, lim2, (4, 4)).astype(np.float32)
+                t["conv2_b"] = np.zeros(4, np.float32)
         return t
 
     def train(self):

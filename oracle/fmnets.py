@@ -128,14 +128,16 @@ class OracleNet(T.OracleModel):
     def __init__(self, params, kind, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64), dropout_seed=1024):
         T.OracleModel.__init__(self, params, emb_trainable, dropout, lr, hidden, dropout_seed, "mlp", False)
         self.kind = kind
-        self.names = param_names(kind, emb_trainable)
+        self.conv = kind in ("ccpm", "autoint")
+        self.names = (ccpm_param_names(emb_trainable) if kind == "ccpm" else autoint_param_names(emb_trainable)) if self.conv \
+            else param_names(kind, emb_trainable)
         self.opt = T.Optimizer(params, self.names)
 
     def train_on_batch(self, uid, pid, dom, label):
         B = uid.shape[0]
         masks = T.train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else None
-        loss, g, _ = loss_and_grads(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
-                                    self.frozen_sumsq())
+        fn = loss_and_grads_conv if self.conv else loss_and_grads
+        loss, g, _ = fn(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable, self.frozen_sumsq())
         if self.use_sgd:
             self.opt.sgd(self.params, g, self.lr)
         else:
@@ -144,11 +146,11 @@ class OracleNet(T.OracleModel):
         return loss
 
     def predict(self, uid, pid, dom):
-        return forward(self.params, self.kind, uid, pid, dom)[0]
+        return (forward_conv if self.conv else forward)(self.params, self.kind, uid, pid, dom)[0]
 
     def evaluate(self, data, batch_size):
         n = data["uid"].shape[0]
-        reg = reg_loss(self.params, self.kind, self.frozen_sumsq())
+        reg = reg_loss(self.params, "nfm" if self.conv else self.kind, self.frozen_sumsq())
         batch_losses, preds = [], np.empty(n, F32)
         for s in range(0, n, batch_size):
             sl = slice(s, min(n, s + batch_size))
@@ -156,3 +158,202 @@ class OracleNet(T.OracleModel):
             preds[sl] = p
             batch_losses.append(F32(np.mean(T.bce_per_row(p, data["label"][sl].astype(F32)), dtype=np.float64)) + reg)
         return F32(np.mean(np.array(batch_losses, np.float64))), preds
+
+
+# ====================================================================================================
+# CCPM and AutoInt (deepctr.py:37-43).  Same file conventions; tensor names are this build's own.
+#
+# CCPM  `models.CCPM(linear, dnn, dnn_hidden_units, dnn_dropout)`, defaults conv_kernel_width = (6, 5), conv_filters = (4, 4):
+#       the three field embeddings as an image [3 fields x 128 x 1 channel]; layer 1: Conv2D(4 filters, kernel (6, 1), 'same',
+#       tanh, bias) along the FIELD axis (TF 'same' for an even width: 2 taps before, 3 after), then KMaxPooling over the
+#       fields with k = min(max(1, int((1 - (1/2)^1) 3)), 3) = 1, i.e. the maximum over the three fields; layer 2:
+#       Conv2D(4, (5, 1), 'same', tanh, bias) on the single remaining row (only the centre tap meets data), k = min(3, 1) = 1;
+#       flatten [128 x 4] -> DNN(hidden_dim) -> Dense(1, no bias) + linear tables + global bias -> sigmoid.
+# AutoInt `models.AutoInt(linear, dnn, dnn_hidden_units, att_head_num=4, dnn_dropout)`, defaults att_layer_num = 3,
+#       att_embedding_size = 8, att_res = True: three InteractingLayers on the [3 x d] field matrix (d = 128, then 32):
+#       Q, K, V, R = X W_q, X W_k, X W_v, X W_res (each [d, 32]); per head h (8 columns): softmax(Q_h K_h^T) V_h over the
+#       three fields (no scaling); concat heads, + R, relu.  Output [3 x 32] flattened (96) next to DNN(hidden_dim)(x);
+#       Dense(1, no bias) on the 96 + 64 columns + linear tables + global bias -> sigmoid.
+CCPM_W1, CCPM_F = 6, 4
+ATT_LAYERS, ATT_HEADS, ATT_DIM = 3, 4, 8
+ATT_OUT = ATT_HEADS * ATT_DIM          # 32
+
+
+def ccpm_param_names(emb_trainable):
+    emb = ("user_emb", "item_emb", "lin_user", "lin_item") if emb_trainable else ()
+    return emb + ("domain_emb", "conv1_w", "conv1_b", "conv2_w", "conv2_b") + T.DENSE_NAMES + ("lin_domain",)
+
+
+def autoint_param_names(emb_trainable):
+    emb = ("user_emb", "item_emb", "lin_user", "lin_item") if emb_trainable else ()
+    att = tuple("att%d_w" % l for l in range(ATT_LAYERS))
+    return emb + ("domain_emb",) + att + T.DENSE_NAMES + ("lin_domain",)
+
+
+def init_params_conv(rs, kind, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64), pretrained=True):
+    p = T.init_params(rs, n_user, n_item, n_domain, emb_dim, hidden, pretrained)
+    if kind == "ccpm":
+        p["conv1_w"] = (rs.standard_normal((CCPM_W1, CCPM_F)) * 0.3).astype(F32)          # Conv2D kernel [6, 1, 1, 4]
+        p["conv1_b"] = np.zeros(CCPM_F, F32)
+        p["conv2_w"] = (rs.standard_normal((CCPM_F, CCPM_F)) * 0.3).astype(F32)           # centre tap of [5, 1, 4, 4]: [in, out]
+        p["conv2_b"] = np.zeros(CCPM_F, F32)
+        in_dim = emb_dim * CCPM_F
+        s = np.sqrt(2.0 / (in_dim + hidden[0]))
+        p["W0"] = (np.clip(rs.standard_normal((in_dim, hidden[0])), -2, 2) * s).astype(F32)
+    else:
+        d = emb_dim
+        for l in range(ATT_LAYERS):             # [d, 4 * 32]: W_query | W_key | W_value | W_res, TruncatedNormal(0.05)
+            p["att%d_w" % l] = (np.clip(rs.standard_normal((d, 4 * ATT_OUT)), -2, 2) * 0.05).astype(F32)
+            d = ATT_OUT
+        s = np.sqrt(2.0 / (3 * ATT_OUT + hidden[2] + 1))
+        p["wo"] = (np.clip(rs.standard_normal((3 * ATT_OUT + hidden[2], 1)), -2, 2) * s).astype(F32)
+    return p
+
+
+def ccpm_features(P, x, E):
+    """-> (f [B, E * 4] in (embedding column, filter) order, cache)."""
+    B = x.shape[0]
+    X = x.reshape(B, 3, E)
+    w1, b1 = P["conv1_w"], P["conv1_b"]
+    # 'same' padding of an even kernel in TF: pad_before = (6 - 1) // 2 = 2, pad_after = 3: out[p] = sum_t in[p + t - 2] w[t]
+    pre1 = np.zeros((B, 3, E, CCPM_F), F32)
+    for pos in range(3):
+        for t in range(CCPM_W1):
+            src = pos + t - 2
+            if 0 <= src < 3:
+                pre1[:, pos] += X[:, src, :, None] * w1[t][None, None, :]
+    a1 = np.tanh((pre1 + b1).astype(F32), dtype=F32)
+    arg = np.argmax(a1, axis=1)                                 # KMaxPooling k = 1: the maximum over the three fields
+    m1 = np.take_along_axis(a1, arg[:, None], axis=1)[:, 0]     # [B, E, 4]
+    pre2 = (m1 @ P["conv2_w"] + P["conv2_b"]).astype(F32)       # centre tap only: [B, E, 4]
+    a2 = np.tanh(pre2, dtype=F32)
+    return a2.reshape(B, E * CCPM_F), dict(X=X, a1=a1, arg=arg, m1=m1, a2=a2)
+
+
+def ccpm_features_backward(P, c, df, g, E):
+    """df = d loss / d f [B, E * 4]; fills the conv gradients; -> d x [B, 3 E]."""
+    B = df.shape[0]
+    dpre2 = (df.reshape(B, E, CCPM_F) * (F32(1) - c["a2"] * c["a2"])).astype(F32)
+    g["conv2_w"] = np.einsum("bei,beo->io", c["m1"].astype(np.float64), dpre2.astype(np.float64)).astype(F32)
+    g["conv2_b"] = np.sum(dpre2.astype(np.float64), axis=(0, 1)).astype(F32)
+    dm1 = (dpre2 @ P["conv2_w"].T).astype(F32)
+    da1 = np.zeros_like(c["a1"])
+    np.put_along_axis(da1, c["arg"][:, None], dm1[:, None], axis=1)
+    dpre1 = (da1 * (F32(1) - c["a1"] * c["a1"])).astype(F32)
+    g["conv1_b"] = np.sum(dpre1.astype(np.float64), axis=(0, 1, 2)).astype(F32)
+    gw = np.zeros((CCPM_W1, CCPM_F), np.float64)
+    dX = np.zeros_like(c["X"])
+    for pos in range(3):
+        for t in range(CCPM_W1):
+            src = pos + t - 2
+            if 0 <= src < 3:
+                gw[t] += np.einsum("be,bef->f", c["X"][:, src].astype(np.float64), dpre1[:, pos].astype(np.float64))
+                dX[:, src] += (dpre1[:, pos] @ P["conv1_w"][t]).astype(F32)
+    g["conv1_w"] = gw.astype(F32)
+    return dX.reshape(B, 3 * E)
+
+
+def att_layer_forward(W, X):
+    """InteractingLayer: X [B, 3, d] -> relu(concat_h softmax(Q_h K_h^T) V_h + X W_res) [B, 3, 32]."""
+    Pj = (X @ W).astype(F32)                                    # [B, 3, 128] = Q | K | V | R
+    Q, K, V, R = (Pj[..., i * ATT_OUT:(i + 1) * ATT_OUT] for i in range(4))
+    B = X.shape[0]
+    Qh, Kh, Vh = (a.reshape(B, 3, ATT_HEADS, ATT_DIM).transpose(0, 2, 1, 3) for a in (Q, K, V))      # [B, H, 3, 8]
+    S = (Qh @ Kh.transpose(0, 1, 3, 2)).astype(F32)             # [B, H, 3, 3]
+    S = S - S.max(axis=-1, keepdims=True)
+    A = np.exp(S, dtype=F32)
+    A = (A / A.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    O = (A @ Vh).astype(F32).transpose(0, 2, 1, 3).reshape(B, 3, ATT_OUT)
+    Y = np.maximum((O + R).astype(F32), F32(0))
+    return Y, dict(X=X, Qh=Qh, Kh=Kh, Vh=Vh, A=A, Y=Y)
+
+
+def att_layer_backward(W, c, dY):
+    """-> (dX [B, 3, d], dW [d, 128])."""
+    B = dY.shape[0]
+    dZ = (dY * (c["Y"] > 0)).astype(F32)                        # relu
+    dR = dZ
+    dOh = dZ.reshape(B, 3, ATT_HEADS, ATT_DIM).transpose(0, 2, 1, 3)
+    dA = (dOh @ c["Vh"].transpose(0, 1, 3, 2)).astype(F32)
+    dVh = (c["A"].transpose(0, 1, 3, 2) @ dOh).astype(F32)
+    dS = (c["A"] * (dA - np.sum((dA * c["A"]).astype(np.float64), axis=-1, keepdims=True).astype(F32))).astype(F32)
+    dQh = (dS @ c["Kh"]).astype(F32)
+    dKh = (dS.transpose(0, 1, 3, 2) @ c["Qh"]).astype(F32)
+    back = lambda a: a.transpose(0, 2, 1, 3).reshape(B, 3, ATT_OUT)
+    dP = np.concatenate([back(dQh), back(dKh), back(dVh), dR], axis=-1).astype(F32)      # [B, 3, 128]
+    dW = np.einsum("btd,bte->de", c["X"].astype(np.float64), dP.astype(np.float64)).astype(F32)
+    dX = (dP @ W.T).astype(F32)
+    return dX, dW
+
+
+def forward_conv(P, kind, uid, pid, dom, masks=None, keep_scale=F32(1)):
+    E = P["domain_emb"].shape[1]
+    x = T.gather(P, uid, pid, dom)
+    c = {"x": x}
+    if kind == "ccpm":
+        f, c["conv"] = ccpm_features(P, x, E)
+        h = f
+    else:
+        X = x.reshape(x.shape[0], 3, E)
+        c["att"] = []
+        for l in range(ATT_LAYERS):
+            X, cl = att_layer_forward(P["att%d_w" % l], X)
+            c["att"].append(cl)
+        c["att_out"] = X.reshape(x.shape[0], 3 * ATT_OUT)
+        h = x
+    hs = [h]
+    for l in range(3):
+        a = np.maximum((h @ P["W%d" % l] + P["b%d" % l]).astype(F32), F32(0))
+        if masks is not None:
+            a = (a * keep_scale * masks[l]).astype(F32)
+        hs.append(a)
+        h = a
+    top = h if kind == "ccpm" else np.concatenate([c["att_out"], h], axis=1).astype(F32)
+    logit = (top @ P["wo"]).astype(F32)[:, 0] + P["gb"][0]
+    logit = (logit + (P["lin_user"][uid] + P["lin_item"][pid] + P["lin_domain"][dom]).astype(F32)).astype(F32)
+    c.update(hs=hs, top=top)
+    return T.sigmoid(logit), c
+
+
+def loss_and_grads_conv(P, kind, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None):
+    B = uid.shape[0]
+    E = P["domain_emb"].shape[1]
+    keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
+    p, c = forward_conv(P, kind, uid, pid, dom, masks, keep_scale)
+    y = label.astype(F32)
+    loss = F32(np.mean(T.bce_per_row(p, y), dtype=np.float64)) + reg_loss(P, "nfm", frozen_sumsq)
+    inside = ((p >= T.EPS_CLIP) & (p <= F32(1) - T.EPS_CLIP)).astype(F32)
+    dlogit = ((p - y) * inside / F32(B)).astype(F32)
+    g = {}
+    g["wo"] = (c["top"].T @ dlogit[:, None]).astype(F32)
+    g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
+    dtop = (dlogit[:, None] * P["wo"][:, 0][None, :]).astype(F32)
+    hs = c["hs"]
+    dh = dtop if kind == "ccpm" else dtop[:, 3 * ATT_OUT:]
+    for l in (2, 1, 0):
+        dz = (dh * ((hs[l + 1] > 0).astype(F32) * keep_scale)).astype(F32)
+        g["W%d" % l] = (hs[l].T @ dz).astype(F32)
+        g["b%d" % l] = np.sum(dz, axis=0, dtype=np.float64).astype(F32)
+        dh = (dz @ P["W%d" % l].T).astype(F32)
+    if kind == "ccpm":
+        dx = ccpm_features_backward(P, c["conv"], dh, g, E)
+    else:
+        dx = dh
+        dX = dtop[:, :3 * ATT_OUT].reshape(B, 3, ATT_OUT)
+        for l in range(ATT_LAYERS - 1, -1, -1):
+            dX, g["att%d_w" % l] = att_layer_backward(P["att%d_w" % l], c["att"][l], dX)
+        dx = (dx + dX.reshape(B, 3 * E)).astype(F32)
+    two_l2_lin = F32(2) * T.L2_LIN
+    gl = np.bincount(dom, weights=dlogit.astype(np.float64), minlength=P["lin_domain"].shape[0])
+    g["lin_domain"] = (gl.astype(F32) + two_l2_lin * P["lin_domain"]).astype(F32)
+    two_l2 = F32(2) * T.L2_EMB
+    onehot = (dom[:, None] == np.arange(P["domain_emb"].shape[0])[None, :]).astype(np.float64)
+    g["domain_emb"] = ((onehot.T @ dx[:, 2 * E:].astype(np.float64)).astype(F32) + two_l2 * P["domain_emb"]).astype(F32)
+    if emb_trainable:
+        for name, ids, sl in (("user", uid, slice(0, E)), ("item", pid, slice(E, 2 * E))):
+            gu = np.zeros_like(P[name + "_emb"], dtype=np.float64)
+            np.add.at(gu, ids, dx[:, sl].astype(np.float64))
+            g[name + "_emb"] = (gu.astype(F32) + two_l2 * P[name + "_emb"]).astype(F32)
+            gl = np.bincount(ids, weights=dlogit.astype(np.float64), minlength=P["lin_" + name].shape[0])
+            g["lin_" + name] = (gl.astype(F32) + two_l2_lin * P["lin_" + name]).astype(F32)
+    return loss, g, p

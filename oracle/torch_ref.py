@@ -126,6 +126,53 @@ def fmnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, 
     return float(loss.detach()), g, p.detach().numpy()
 
 
+def convnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64):
+    """deepctr CCPM / AutoInt (deepctr.py:37-43) in float64 autograd -- written with torch's own conv2d / softmax, not with
+    the oracle's loops.  CCPM: Conv2D((6, 1), 'same', tanh) over the field axis (TF pads an even kernel 2 before / 3 after),
+    max over the fields, Conv2D((5, 1)) on the remaining row = its centre tap, tanh, flatten [128 x 4], DNN, linear tables.
+    AutoInt: three InteractingLayers (4 heads x 8, residual, relu, no scaling) beside the DNN, one Dense(1) on both."""
+    import torch.nn.functional as Fn
+    P = _as_tensors(params, names, dtype, set(names))
+    ui, pi, di = (torch.from_numpy(np.asarray(a, np.int64)) for a in (uid, pid, dom))
+    y = torch.from_numpy(np.asarray(label, np.float32)).to(dtype)
+    u, i, d = _rows(P["user_emb"], ui), _rows(P["item_emb"], pi), _rows(P["domain_emb"], di)
+    x = torch.cat([u, i, d], dim=1)
+    B, E = u.shape
+    if kind == "ccpm":
+        img = torch.stack([u, i, d], dim=1)[:, None]                         # [B, 1, 3 fields, E]
+        k1 = P["conv1_w"].t()[:, None, :, None]                              # [4 out, 1 in, 6, 1]
+        a1 = torch.tanh(Fn.conv2d(Fn.pad(img, (0, 0, 2, 3)), k1) + P["conv1_b"][None, :, None, None])      # [B, 4, 3, E]
+        m1 = a1.max(dim=2).values                                            # [B, 4, E]
+        a2 = torch.tanh(torch.einsum("bie,io->beo", m1, P["conv2_w"]) + P["conv2_b"])                         # [B, E, 4]
+        h = a2.reshape(B, E * 4)
+        att = None
+    else:
+        X = torch.stack([u, i, d], dim=1)                                    # [B, 3, E]
+        for l in range(3):
+            Pj = X @ P["att%d_w" % l]
+            Q, K, V, R = (Pj[..., k * 32:(k + 1) * 32] for k in range(4))
+            heads = lambda a: a.reshape(B, 3, 4, 8).permute(0, 2, 1, 3)
+            A = torch.softmax(heads(Q) @ heads(K).transpose(-1, -2), dim=-1)
+            O = (A @ heads(V)).permute(0, 2, 1, 3).reshape(B, 3, 32)
+            X = torch.relu(O + R)
+        att = X.reshape(B, 96)
+        h = x
+    keep = 1.0 / (1.0 - rate) if masks is not None else 1.0
+    for l in range(3):
+        h = torch.relu(torch.addmm(P["b%d" % l], h, P["W%d" % l]))
+        if masks is not None:
+            h = h * keep * torch.from_numpy(np.asarray(masks[l], np.float32)).to(dtype)
+    top = h if att is None else torch.cat([att, h], dim=1)
+    logit = (top @ P["wo"])[:, 0] + P["gb"][0] + P["lin_user"][ui] + P["lin_item"][pi] + P["lin_domain"][di]
+    reg = L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum()) + \
+        L2_LIN * (P["lin_user"].pow(2).sum() + P["lin_item"].pow(2).sum() + P["lin_domain"].pow(2).sum())
+    p = torch.sigmoid(logit)
+    loss = keras_bce(p, y).mean() + reg
+    grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
+    g = {n: (gr.numpy() if gr is not None else np.zeros(params[n].shape)) for n, gr in zip(names, grads)}
+    return float(loss.detach()), g, p.detach().numpy()
+
+
 def mtl_forward(P, spec, d, uid, pid, dom, masks, keep_scale):
     """multi-task towers (deep_mtl_ctr.py:21-49; deepctr SharedBottom / MMOE / PLE with num_levels = 1), output of task d:
     experts = DNN(hidden_dim) on x; MMOE / PLE: gate_d = softmax(DNN(gate_dnn_hidden_units)(x) . Wg_d) over the experts

@@ -28,7 +28,12 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
     g = synthetic.generate("taobao10", batch_size=batch, seed=seed, scale=scale)
     D = g["n_domain"]
     rs = np.random.RandomState(seed)
-    params = ofm.init_params(rs, kind, g["n_user"], g["n_item"], D, hidden=HIDDEN)
+    if kind == "ccpm":
+        params = ofm.init_params_conv(rs, kind, g["n_user"], g["n_item"], D, hidden=HIDDEN)
+        params["conv1_b"] = (rs.standard_normal(4) * 0.1).astype(F32)
+        params["conv2_b"] = (rs.standard_normal(4) * 0.1).astype(F32)
+    else:
+        params = ofm.init_params(rs, kind, g["n_user"], g["n_item"], D, hidden=HIDDEN)
     params["user_emb"], params["item_emb"] = g["tables"]["user_emb"].copy(), g["tables"]["item_emb"].copy()
     params["domain_emb"] = (rs.standard_normal(params["domain_emb"].shape) * 0.05).astype(F32)
     for n in ("b0", "b1", "b2", "lin_domain", "lin_user", "lin_item"):
@@ -46,7 +51,7 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
         for d in range(D):
             c = g["data"][split][d]
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
-    names = list(ofm.param_names(kind, emb_trainable))
+    names = list(ofm.ccpm_param_names(emb_trainable) if kind == "ccpm" else ofm.param_names(kind, emb_trainable))
     assert list(eng.segments) == names, (list(eng.segments), names)
     eng.set_weights(eng.pack(params))
     model = ofm.OracleNet({k: v.copy() for k, v in params.items()}, kind, emb_trainable=emb_trainable, dropout=dropout,
@@ -54,7 +59,7 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
     return g, eng, model
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm"])
 @pytest.mark.parametrize("emb_trainable", [False, True])
 def test_one_step_gradients_match_oracle(kind, emb_trainable):
     g, eng, model = make_problem(kind, dropout=0.5, scale=0.1 if emb_trainable else 0.05, emb_trainable=emb_trainable)
@@ -69,8 +74,9 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable):
     for step in (0, n_step - 1):
         idx = perm[step * 256:(step + 1) * 256]
         masks = otower.train_masks(model.seed, model.step, len(idx), HIDDEN, 0.5)
-        loss, grads, _ = ofm.loss_and_grads(model.params, kind, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
-                                            cols["label"][idx], masks, 0.5, emb_trainable, model.frozen_sumsq())
+        fn = ofm.loss_and_grads_conv if kind == "ccpm" else ofm.loss_and_grads
+        loss, grads, _ = fn(model.params, kind, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                            cols["label"][idx], masks, 0.5, emb_trainable, model.frozen_sumsq())
         loss_t = torch.zeros(1, device=eng.device)
         w0 = eng.get_weights()
         eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
@@ -86,7 +92,7 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm"])
 def test_adam_pass_and_eval(kind):
     g, eng, model = make_problem(kind, dropout=0.5)
     d = 9
@@ -111,7 +117,7 @@ def test_adam_pass_and_eval(kind):
 
 
 def test_eval_predictions_at_equal_weights():
-    for kind in ("nfm", "pnn"):
+    for kind in ("nfm", "pnn", "ccpm"):
         g, eng, model = make_problem(kind)
         for d in (1, 5):
             c = g["data"]["test"][d]
@@ -123,7 +129,7 @@ def test_eval_predictions_at_equal_weights():
         eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm"])
 def test_domain_negotiation_auc_parity(kind):
     """the meta wrappers run on these towers too (deepctr.py's registry is orthogonal to run.py's wrappers): five
     Domain Negotiation epochs (domain_negotiation.py:49-88) on 4 domains, same order / shuffles / masks on both sides,

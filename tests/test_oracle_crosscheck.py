@@ -237,3 +237,36 @@ def test_nfm_pnn_gradients_vs_float64_autograd(kind, emb_trainable, rate):
     np.testing.assert_allclose(pred, pred64, rtol=2e-5, atol=2e-7)
     assert sorted(g) == sorted(names)
     _check_grads(g, g64, names)
+
+
+@pytest.mark.parametrize("kind,emb_trainable,rate", [("ccpm", False, 0.5), ("ccpm", True, 0.0), ("autoint", False, 0.5),
+                                                      ("autoint", True, 0.5)])
+def test_ccpm_autoint_gradients_vs_float64_autograd(kind, emb_trainable, rate):
+    """oracle/fmnets.py's CCPM (convolution over the field axis, max over the fields, tanh) and AutoInt (three multi-head
+    self-attention layers with residuals) -- hand-derived fp32 backward passes -- against float64 autograd of a forward
+    written with torch's own conv2d / softmax."""
+    from oracle import fmnets as ofm
+    rs = np.random.RandomState(37)
+    n_user, n_item, D, B = 60, 40, 4, 48
+    E = 128 if kind == "autoint" else 8            # (the attention layers' second and third inputs are 32 wide whatever E is)
+    E = 8
+    p = ofm.init_params_conv(rs, kind, n_user, n_item, D, emb_dim=E, hidden=(16, 8, 4))
+    p["domain_emb"] = (rs.standard_normal(p["domain_emb"].shape) * 0.05).astype(F32)
+    for n in ("b0", "b1", "b2", "lin_user", "lin_item", "lin_domain"):
+        p[n] = (rs.standard_normal(p[n].shape) * 0.05).astype(F32)
+    if kind == "ccpm":
+        p["conv1_b"] = (rs.standard_normal(4) * 0.1).astype(F32)
+        p["conv2_b"] = (rs.standard_normal(4) * 0.1).astype(F32)
+    else:
+        for l in range(3):                         # larger kernels: the softmax is off its uniform point
+            p["att%d_w" % l] = (p["att%d_w" % l] * 8).astype(F32)
+    p["gb"] = np.array([0.1], F32)
+    names = list(ofm.ccpm_param_names(emb_trainable) if kind == "ccpm" else ofm.autoint_param_names(emb_trainable))
+    uid, pid, dom, label = _batch(rs, n_user, n_item, D, B)
+    masks = otower.train_masks(1024, 3, B, (16, 8, 4), rate) if rate > 0 else None
+    loss, g, pred = ofm.loss_and_grads_conv(p, kind, uid, pid, dom, label, masks, rate, emb_trainable)
+    loss64, g64, pred64 = tref.convnet_loss_and_grads(p, names, kind, uid, pid, dom, label, masks, rate)
+    assert abs(float(loss) - loss64) < 2e-6 * max(1.0, abs(loss64))
+    np.testing.assert_allclose(pred, pred64, rtol=2e-5, atol=2e-7)
+    assert sorted(g) == sorted(names)
+    _check_grads(g, g64, names)
