@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 11
+#define MAMDR_ABI_VERSION 12
 
 enum {
     MAMDR_OK = 0,
@@ -310,7 +310,11 @@ enum { MAMDR_GRAPH_SHARED_BOTTOM = 0,   /* deep_mtl_ctr.py:25-30  models.SharedB
        MAMDR_GRAPH_PNN = 4,             /* deepctr.py:44-46  models.PNN: DNN([fields | pairwise inner products]) */
        /* deepctr.py:41-43  models.CCPM: convolutions (6, 1) x 4 and (5, 1) x 4 over the field axis with tanh and k-max pooling
           (k = 1 with three fields) -> DNN + linear tables; conv tensors conv1_w [6][4] conv1_b conv2_w [4][4] conv2_b precede W0 */
-       MAMDR_GRAPH_CCPM = 5 };
+       MAMDR_GRAPH_CCPM = 5,
+       /* deepctr.py:37-40  models.AutoInt(att_head_num=4): three InteractingLayers (4 heads x 8, residual, relu) over the three
+          fields beside the DNN, Dense(1) on [attention output 96 | DNN output] + linear tables; att<l>_w = [W_query | W_key |
+          W_value | W_res] ([128][128], then [32][128] twice) precede W0, wo has 96 + hidden[-1] rows */
+       MAMDR_GRAPH_AUTOINT = 6 };
 typedef struct mamdr_graph mamdr_graph;
 typedef struct mamdr_graph_config {
     int32_t abi_version;        /* MAMDR_ABI_VERSION */

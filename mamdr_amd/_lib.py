@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -48,7 +48,7 @@ class Config(C.Structure):
     ]
 
 
-GRAPH_SHARED_BOTTOM, GRAPH_MMOE, GRAPH_PLE, GRAPH_NFM, GRAPH_PNN, GRAPH_CCPM = 0, 1, 2, 3, 4, 5
+GRAPH_SHARED_BOTTOM, GRAPH_MMOE, GRAPH_PLE, GRAPH_NFM, GRAPH_PNN, GRAPH_CCPM, GRAPH_AUTOINT = 0, 1, 2, 3, 4, 5, 6
 
 
 class GraphConfig(C.Structure):

@@ -68,6 +68,7 @@ struct GatherArgs {
     int32_t *urow, *irow, *map_u, *map_i;      // trainable tables: row of each position, first position of each row
     const float *lin_u, *lin_i, *lin_d;         // NFM: 1-d linear tables (lin_u / lin_i null while frozen at their zero init)
     float* extra;                               // NFM: sum of the linear terms per position
+    float* xt;                                  // AutoInt: compact [rows_pad][384] copy of x (token-major: row 3 b + t)
 };
 // one wave per batch position: lanes 0..31 copy the user row, 32..63 the item row, then lanes 0..31 the domain row
 __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
     if (r >= a.rows) {          // padding rows: zeros in, nothing out (their d loss / d logit is zero)
         *reinterpret_cast<f32x4*>(xr + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (lane < 32) *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.xt) {
+            *reinterpret_cast<f32x4*>(a.xt + (size_t)r * XDIM + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (lane < 32) *reinterpret_cast<f32x4*>(a.xt + (size_t)r * XDIM + 2 * EMB + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         if (lane == 0) {
             a.domrow[r] = -1;
             a.y[r] = 0.f;
@@ -92,9 +97,14 @@ __global__ __launch_bounds__(256) void k_graph_gather(const GatherArgs a) {
     it = it < 0 ? 0 : (it >= a.n_item ? a.n_item - 1 : it);
     d = d < 0 ? 0 : (d >= a.n_domain ? a.n_domain - 1 : d);
     const float* row = lane < 32 ? a.user_tab + (size_t)u * EMB + 4 * lane : a.item_tab + (size_t)it * EMB + 4 * (lane - 32);
-    *reinterpret_cast<f32x4*>(xr + 4 * lane) = *reinterpret_cast<const f32x4*>(row);
-    if (lane < 32)
-        *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = *reinterpret_cast<const f32x4*>(a.dm + (size_t)d * EMB + 4 * lane);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+    *reinterpret_cast<f32x4*>(xr + 4 * lane) = v0;
+    if (a.xt) *reinterpret_cast<f32x4*>(a.xt + (size_t)r * XDIM + 4 * lane) = v0;
+    if (lane < 32) {
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.dm + (size_t)d * EMB + 4 * lane);
+        *reinterpret_cast<f32x4*>(xr + 2 * EMB + 4 * lane) = v1;
+        if (a.xt) *reinterpret_cast<f32x4*>(a.xt + (size_t)r * XDIM + 2 * EMB + 4 * lane) = v1;
+    }
     if (lane == 0) {
         a.domrow[r] = d;
         a.y[r] = a.label[src];
@@ -424,6 +434,127 @@ __global__ __launch_bounds__(256) void k_graph_ccpm_bwd(const CcpmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ AutoInt: multi-head self-attention over the three fields
+// (deepctr InteractingLayer, att_embedding_size 8, 4 heads, residual, no scaling -- oracle/fmnets.py).  Token-major compact
+// buffers: row 3 b + t = field t of batch row b.  Per layer: P = X W (k_graph_gemm, W = [W_query | W_key | W_value | W_res],
+// [d][128]) -> per batch row (one wave): scores Q_h K_h^T [3 x 3] per head, softmax over the fields, A V, + R, relu.
+constexpr int ATT_OUT = 32, ATT_HEADS = 4, ATT_DIM = 8, ATT_P = 4 * ATT_OUT;      // 128 projection columns per token
+struct AttArgs {
+    const float* P;      // [3 rows_pad][128]
+    float* A;            // [rows_pad][36]: probabilities [head][field][field]
+    float* Y;            // [3 rows_pad][32]
+    const float* dY;     // [3 rows_pad][32] (backward)
+    float* dP;           // [3 rows_pad][128] (backward)
+    float* top; int top_ld;      // forward, last layer: also [rows_pad][96] inside the activation workspace (for the head)
+    const float* dtop; int dtop_ld;   // backward, last layer: d Y comes from the gradient workspace
+    int rows_pad;
+};
+__global__ __launch_bounds__(256) void k_graph_att_fwd(const AttArgs a) {
+    __shared__ float lds[4][3 * ATT_P + 48];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= a.rows_pad) return;
+    float* p = lds[w];
+    float* sc = p + 3 * ATT_P;
+    for (int i = lane; i < 3 * ATT_P; i += 64) p[i] = a.P[(size_t)r * 3 * ATT_P + i];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int h = lane / 9, t = (lane % 9) / 3, s_ = lane % 3;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < ATT_DIM; ++j) v = fmaf(p[t * ATT_P + h * ATT_DIM + j], p[s_ * ATT_P + ATT_OUT + h * ATT_DIM + j], v);
+        sc[lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int base = lane - lane % 3;
+        const float m = fmaxf(fmaxf(sc[base], sc[base + 1]), sc[base + 2]);
+        const float e0 = __expf(sc[base] - m), e1 = __expf(sc[base + 1] - m), e2 = __expf(sc[base + 2] - m);
+        const float mine = __expf(sc[lane] - m) / ((e0 + e1) + e2);
+        a.A[(size_t)r * 36 + lane] = mine;
+        __builtin_amdgcn_wave_barrier();
+        sc[lane] = mine;
+    } else {
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 3 * ATT_OUT; i += 64) {
+        const int t = i / ATT_OUT, c = i % ATT_OUT, h = c / ATT_DIM;
+        float o = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) o = fmaf(sc[h * 9 + t * 3 + s_], p[s_ * ATT_P + 2 * ATT_OUT + c], o);
+        const float y = fmaxf(o + p[t * ATT_P + 3 * ATT_OUT + c], 0.f);
+        a.Y[(size_t)r * 3 * ATT_OUT + i] = y;
+        if (a.top) a.top[(size_t)r * a.top_ld + i] = y;
+    }
+}
+__global__ __launch_bounds__(256) void k_graph_att_bwd(const AttArgs a) {
+    __shared__ float lds[4][3 * ATT_P + 48 + 48 + 96];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= a.rows_pad) return;
+    float* p = lds[w];
+    float* pa = p + 3 * ATT_P;       // probabilities
+    float* ds = pa + 48;             // d scores
+    float* dz = ds + 48;             // d (O + R) = d Y through the relu
+    for (int i = lane; i < 3 * ATT_P; i += 64) p[i] = a.P[(size_t)r * 3 * ATT_P + i];
+    if (lane < 36) pa[lane] = a.A[(size_t)r * 36 + lane];
+    for (int i = lane; i < 3 * ATT_OUT; i += 64) {
+        const float dy = a.dtop ? a.dtop[(size_t)r * a.dtop_ld + i] : a.dY[(size_t)r * 3 * ATT_OUT + i];
+        dz[i] = a.Y[(size_t)r * 3 * ATT_OUT + i] > 0.f ? dy : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float da = 0.f;
+    if (lane < 36) {
+        const int h = lane / 9, t = (lane % 9) / 3, s_ = lane % 3;
+#pragma unroll
+        for (int j = 0; j < ATT_DIM; ++j) da = fmaf(dz[t * ATT_OUT + h * ATT_DIM + j], p[s_ * ATT_P + 2 * ATT_OUT + h * ATT_DIM + j], da);
+        ds[lane] = da * pa[lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int base = lane - lane % 3;
+        const float dot = (ds[base] + ds[base + 1]) + ds[base + 2];
+        const float v = pa[lane] * (da - dot);
+        __builtin_amdgcn_wave_barrier();
+        ds[lane] = v;
+    } else {
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* dp = a.dP + (size_t)r * 3 * ATT_P;
+    for (int i = lane; i < 3 * ATT_OUT; i += 64) {
+        const int t = i / ATT_OUT, c = i % ATT_OUT, h = c / ATT_DIM;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            dq = fmaf(ds[h * 9 + t * 3 + s_], p[s_ * ATT_P + ATT_OUT + c], dq);           // d Q[t] = sum_s dS[t][s] K[s]
+            dk = fmaf(ds[h * 9 + s_ * 3 + t], p[s_ * ATT_P + c], dk);                      // d K[t] = sum_s dS[s][t] Q[s]
+            dv = fmaf(pa[h * 9 + s_ * 3 + t], dz[s_ * ATT_OUT + c], dv);                   // d V[t] = sum_s A[s][t] dZ[s]
+        }
+        dp[t * ATT_P + c] = dq;
+        dp[t * ATT_P + ATT_OUT + c] = dk;
+        dp[t * ATT_P + 2 * ATT_OUT + c] = dv;
+        dp[t * ATT_P + 3 * ATT_OUT + c] = dz[i];
+    }
+}
+// out[r][k] = sum_c d[r][c] W[k][c] for a NARROW result (k < n_k <= 32; c < n_c): d X of the 32-wide attention layers
+__global__ __launch_bounds__(256) void k_graph_small_nt(const float* d, int n_c, const float* W, int n_k, int rows, float* out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * n_k) return;
+    const int r = idx / n_k, k = idx - r * n_k;
+    float s = 0.f;
+    for (int c = 0; c < n_c; ++c) s = fmaf(d[(size_t)r * n_c + c], W[(size_t)k * n_c + c], s);
+    out[idx] = s;
+}
+// d x[:, first .. first + n) (+)= compact [rows][384] columns first .. first + n
+__global__ __launch_bounds__(256) void k_graph_add_x(float* dact, int ld, const float* src, int rows, int first, int n) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * n) return;
+    const int r = idx / n, c = first + (idx - r * n);
+    dact[(size_t)r * ld + c] += src[(size_t)r * XDIM + c];
+}
+
 // ------------------------------------------------------------------ gate: softmax(q Wg) and the mixture, one wave per row
 struct GateArgs {
     float* act; float* dact; int ld;
@@ -522,6 +653,7 @@ __global__ __launch_bounds__(256) void k_graph_gate_bwd(const GateArgs a) {
 struct HeadArgs {
     const float* act; float* dact; int ld;
     int t_col, n_t;
+    int n_plain;                // leading columns that no dropout follows (AutoInt: the attention output): gate only
     const float* w; const float* gb;
     const float* y; int rows, rows_pad;
     const float* extra;         // NFM: the linear logit of every position (null otherwise)
@@ -556,7 +688,7 @@ __global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
         if (lane == 0) a.dlogit[r] = dl;
         float* drow = a.dact + (size_t)r * a.ld;
         for (int cidx = lane; cidx < a.n_t; cidx += 64)
-            drow[a.t_col + cidx] = row[a.t_col + cidx] > 0.f ? (dl * a.w[cidx]) * a.gate_scale : 0.f;
+            drow[a.t_col + cidx] = row[a.t_col + cidx] > 0.f ? (dl * a.w[cidx]) * (cidx < a.n_plain ? 1.0f : a.gate_scale) : 0.f;
     } else if (lane == 0 && valid) {
         int blo = 0, bhi = 500;          // AUC bin = number of thresholds strictly below p (utils/metrics_utils.py:309)
         while (blo < bhi) {
@@ -708,6 +840,12 @@ struct mamdr_graph {
     int f_col = 0;              // interaction features: NFM 128 columns, PNN 3 (+ 1 pad), CCPM 512
     int cg_col = 0;             // CCPM: 64 columns of the gradient workspace for the rows' shares of the 48 conv gradients
     int64_t conv_off = 0;       // CCPM: [w1 6x4 | b1 | w2 4x4 | b2]
+    // AutoInt: three attention layers on compact token-major buffers (row 3 b + t = field t of batch row b)
+    int64_t att_w[3] = {0, 0, 0};
+    int top_col = 0;            // [attention output 96 | last DNN layer] contiguous in the activation workspace (head input)
+    float *xt = nullptr, *dxt = nullptr;
+    float *attP[3] = {nullptr, nullptr, nullptr}, *attdP[3] = {nullptr, nullptr, nullptr};
+    float *attA[3] = {nullptr, nullptr, nullptr}, *attY[3] = {nullptr, nullptr, nullptr}, *attdY[3] = {nullptr, nullptr, nullptr};
     int64_t lin_d_off = 0;      // NFM: 1-d linear table of the domain feature (behind the global bias)
     int64_t lin_u_off = 0, lin_i_off = 0;       // ... of the user / item features (trainable tables only)
     float *extra = nullptr, *glin_u = nullptr, *glin_i = nullptr;
@@ -902,6 +1040,35 @@ void fill_ccpm(const mamdr_graph* g, const StepCtx& sc, CcpmArgs& ca) {
 }
 
 int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
+    if (g->single && g->cfg.kind == MAMDR_GRAPH_AUTOINT) {
+        for (int l = 0; l < 3; ++l) {
+            const int d_in = l == 0 ? EMB : ATT_OUT;
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.A = l == 0 ? g->xt : g->attY[l - 1];     // token-major [3 rows_pad][d]
+            a.lda = d_in;
+            a.B = g->params + g->att_w[l];
+            a.ldb = ATT_P;
+            a.C = g->attP[l];
+            a.ldc = ATT_P;
+            a.K = d_in;
+            a.n_cols = ATT_P;
+            launch_gemm(0, a, 3 * sc.rp, ATT_P, g->stream);
+            AttArgs aa;
+            memset(&aa, 0, sizeof(aa));
+            aa.P = g->attP[l];
+            aa.A = g->attA[l];
+            aa.Y = g->attY[l];
+            aa.rows_pad = sc.rp;
+            if (l == 2) {
+                aa.top = g->act + g->top_col;
+                aa.top_ld = g->ld;
+            }
+            hipLaunchKernelGGL(k_graph_att_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, aa);
+        }
+        dnn_forward(g, g->dnns[t.tower], t.col[0], 0, sc);
+        return g->top_col;
+    }
     if (g->single) {
         if (g->cfg.kind == MAMDR_GRAPH_CCPM) {
             CcpmArgs ca;
@@ -979,6 +1146,7 @@ void fill_gather(const mamdr_graph* g, const SplitData& d, const int32_t* perm, 
     ga.ld = g->ld;
     ga.domrow = g->domrow;
     ga.y = g->y;
+    ga.xt = g->xt;
     if (g->extra) {
         ga.extra = g->extra;
         ga.lin_d = g->params + g->lin_d_off;
@@ -1008,11 +1176,11 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
     if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");
     if (cfg->emb_trainable && cfg->max_batch > 16384) return gfail(MAMDR_EINVAL, "trainable tables: max_batch <= 16384");
-    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_CCPM)
+    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_AUTOINT)
         return gfail(MAMDR_EINVAL, "unknown graph tower kind %d", cfg->kind);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return gfail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
-    const bool single = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_PNN || cfg->kind == MAMDR_GRAPH_CCPM;
-    const bool has_lin = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_CCPM;
+    const bool single = cfg->kind >= MAMDR_GRAPH_NFM;
+    const bool has_lin = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_CCPM || cfg->kind == MAMDR_GRAPH_AUTOINT;
     const bool gated = cfg->kind == MAMDR_GRAPH_MMOE || cfg->kind == MAMDR_GRAPH_PLE;
     if (cfg->n_expert_hidden < 1 || cfg->n_expert_hidden > 4 || (!single && (cfg->n_tower_hidden < 1 || cfg->n_tower_hidden > 4)) ||
         (gated && (cfg->n_gate_hidden < 1 || cfg->n_gate_hidden > 4)))
@@ -1077,6 +1245,12 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
             add_tensor(g, "conv2_w", 4, 4);
             add_tensor(g, "conv2_b", 1, 4);
         }
+        const bool autoint = cfg->kind == MAMDR_GRAPH_AUTOINT;
+        if (autoint) {      // [W_query | W_key | W_value | W_res] per layer: [128][128], then [32][128] twice
+            g->att_w[0] = add_tensor(g, "att0_w", EMB, ATT_P);
+            g->att_w[1] = add_tensor(g, "att1_w", ATT_OUT, ATT_P);
+            g->att_w[2] = add_tensor(g, "att2_w", ATT_OUT, ATT_P);
+        }
         d.in_dim = nfm ? EMB : (ccpm ? 4 * EMB : XDIM);
         int in = d.in_dim;
         for (int l = 0; l < cfg->n_expert_hidden; ++l) {
@@ -1092,7 +1266,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         for (int l = 0; l < cfg->n_expert_hidden; ++l) d.layers[l].b_off = add_tensor(g, "b" + std::to_string(l), 1, d.layers[l].out);
         g->dnns.push_back(d);
         t.tower = 0;
-        t.head_w = add_tensor(g, "wo", in, 1);
+        t.head_w = add_tensor(g, "wo", autoint ? 3 * ATT_OUT + in : in, 1);
         t.head_gb = add_tensor(g, "gb", 1, 1);
         if (has_lin) g->lin_d_off = add_tensor(g, "lin_domain", cfg->n_domain, 1);
         g->shared_end = g->n_params;
@@ -1103,7 +1277,14 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         if (ccpm) { g->cg_col = c; c += 64; }
         t.path.push_back(0);
         std::vector<int> cols;
-        for (const Layer& L : d.layers) { cols.push_back(c); c += L.out; }
+        for (size_t l = 0; l < d.layers.size(); ++l) {
+            if (autoint && l + 1 == d.layers.size()) {      // head input = [attention output 96 | last DNN layer]
+                g->top_col = c;
+                c += 3 * ATT_OUT;
+            }
+            cols.push_back(c);
+            c += d.layers[l].out;
+        }
         t.col.push_back(cols);
         t.n_cols = c;
         max_cols = c;
@@ -1170,6 +1351,17 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     alloc((void**)&g->frozen_sumsq, 4 * sizeof(float));
     alloc((void**)&g->sumsq_partials, 1024 * sizeof(float));
     alloc((void**)&g->eval_acc, 4 * sizeof(float));
+    if (cfg->kind == MAMDR_GRAPH_AUTOINT) {
+        alloc((void**)&g->xt, rp * XDIM * sizeof(float));
+        alloc((void**)&g->dxt, rp * XDIM * sizeof(float));
+        for (int l = 0; l < 3; ++l) {
+            alloc((void**)&g->attP[l], 3 * rp * ATT_P * sizeof(float));
+            alloc((void**)&g->attdP[l], 3 * rp * ATT_P * sizeof(float));
+            alloc((void**)&g->attA[l], rp * 36 * sizeof(float));
+            alloc((void**)&g->attY[l], 3 * rp * ATT_OUT * sizeof(float));
+            alloc((void**)&g->attdY[l], 3 * rp * ATT_OUT * sizeof(float));
+        }
+    }
     if (has_lin) {
         alloc((void**)&g->extra, rp * sizeof(float));
         if (g->tables) {
@@ -1203,7 +1395,9 @@ int mamdr_graph_destroy(mamdr_graph* g) {
     (void)hipStreamSynchronize(g->stream);
     void* ptrs[] = {g->act, g->dact, g->grad, g->dlogit, g->rowloss, g->y, g->domrow, g->thresholds, g->frozen_sumsq,
                     g->sumsq_partials, g->eval_acc, g->urow, g->irow, g->map_u, g->map_i, g->hasdup_u, g->hasdup_i,
-                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i};
+                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i, g->xt, g->dxt,
+                    g->attP[0], g->attP[1], g->attP[2], g->attdP[0], g->attdP[1], g->attdP[2], g->attA[0], g->attA[1], g->attA[2],
+                    g->attY[0], g->attY[1], g->attY[2], g->attdY[0], g->attdY[1], g->attdY[2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1344,6 +1538,10 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         ha.ld = g->ld;
         ha.t_col = t_col;
         ha.n_t = tower.layers.back().out;
+        if (g->cfg.kind == MAMDR_GRAPH_AUTOINT) {       // head on [attention output | last DNN layer]
+            ha.n_t += 3 * ATT_OUT;
+            ha.n_plain = 3 * ATT_OUT;
+        }
         ha.w = g->params + t.head_w;
         ha.gb = g->params + t.head_gb;
         ha.y = g->y;
@@ -1370,7 +1568,59 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         // tables are frozen): the first writer overwrites, the others add
         bool dx_started = false;
         const int dx_first = g->tables ? 0 : 2 * EMB, dx_n = g->tables ? 0 : EMB;
-        if (g->single && g->cfg.kind == MAMDR_GRAPH_CCPM) {
+        if (g->single && g->cfg.kind == MAMDR_GRAPH_AUTOINT) {
+            // DNN on x as any first layer; then the attention stack from the head's d [attention output] down to d x
+            dnn_backward(g, tower, t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
+            for (int l = 2; l >= 0; --l) {
+                const int d_in = l == 0 ? EMB : ATT_OUT;
+                AttArgs aa;
+                memset(&aa, 0, sizeof(aa));
+                aa.P = g->attP[l];
+                aa.A = g->attA[l];
+                aa.Y = g->attY[l];
+                aa.dY = g->attdY[l];
+                aa.dP = g->attdP[l];
+                aa.rows_pad = sc.rp;
+                if (l == 2) {
+                    aa.dtop = g->dact + g->top_col;
+                    aa.dtop_ld = g->ld;
+                }
+                hipLaunchKernelGGL(k_graph_att_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, aa);
+                const float* xin = l == 0 ? g->xt : g->attY[l - 1];
+                if (l == 0) {
+                    GemmArgs a;
+                    memset(&a, 0, sizeof(a));
+                    a.A = xin;                      // dW = X^T dP over the 3 B token rows
+                    a.lda = d_in;
+                    a.B = g->attdP[l];
+                    a.ldb = ATT_P;
+                    a.C = g->G(g->att_w[l]);
+                    a.ldc = ATT_P;
+                    a.K = 3 * sc.rp;
+                    launch_gemm(2, a, d_in, ATT_P, g->stream);
+                    memset(&a, 0, sizeof(a));
+                    a.A = g->attdP[l];              // d X = dP W^T
+                    a.lda = ATT_P;
+                    a.B = g->params + g->att_w[l];
+                    a.ldb = ATT_P;
+                    a.C = g->dxt;
+                    a.ldc = d_in;
+                    a.K = ATT_P;
+                    launch_gemm(1, a, 3 * sc.rp, d_in, g->stream);
+                    const int first = g->tables ? 0 : 2 * EMB, n = g->tables ? XDIM : EMB;
+                    hipLaunchKernelGGL(k_graph_add_x, dim3((sc.rp * n + 255) / 256), dim3(256), 0, g->stream, g->dact, g->ld, g->dxt,
+                                       sc.rp, first, n);
+                } else {
+                    hipLaunchKernelGGL(k_graph_small_tn, dim3((d_in * ATT_P + 255) / 256), dim3(256), 0, g->stream, xin, d_in,
+                                       g->attdP[l], ATT_P, 3 * sc.rp, d_in, ATT_P, g->G(g->att_w[l]));
+                    hipLaunchKernelGGL(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
+                                       ATT_P, g->params + g->att_w[l], d_in, 3 * sc.rp, g->attdY[l - 1]);
+                }
+            }
+            hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3((g->cfg.n_domain + 63) / 64), dim3(64), 0, g->stream, g->dlogit,
+                               g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
+                               g->G(g->lin_d_off));
+        } else if (g->single && g->cfg.kind == MAMDR_GRAPH_CCPM) {
             // d features from the first layer; the convolutions' backward per row; their 48 gradients summed over the batch
             dnn_backward(g, tower, t.col[0], g->f_col, g->f_col, -1, false, 0, 0, sc);
             CcpmArgs ca;
@@ -1520,7 +1770,7 @@ int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch
         ha.dact = g->dact;
         ha.ld = g->ld;
         ha.t_col = t_col;
-        ha.n_t = g->dnns[t.tower].layers.back().out;
+        ha.n_t = g->dnns[t.tower].layers.back().out + (g->cfg.kind == MAMDR_GRAPH_AUTOINT ? 3 * ATT_OUT : 0);
         ha.w = g->params + t.head_w;
         ha.gb = g->params + t.head_gb;
         ha.y = g->y;

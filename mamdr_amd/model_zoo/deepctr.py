@@ -7,7 +7,8 @@ tables and the FM second-order term to the logit (deepctr.py:36-38, SURVEY A.8);
 `wdl` is the same without the FM term (deepctr.py:29-32); `nfm` (deepctr.py:33-35: linear tables + DNN over the
 bi-interaction of the three fields) and `pnn` (deepctr.py:44-46: DNN over the fields and their pairwise inner
 products) and `ccpm` (deepctr.py:41-43: convolutions over the field axis) run on the generic-layer engine
-(`GraphEngine`, csrc/graph_engine.hip); autoint raises.  Initial tensors follow the reference's initialisers (glorot normal for the
+(`GraphEngine`, csrc/graph_engine.hip), and so does `autoint` (deepctr.py:37-40: three multi-head self-attention
+layers over the fields beside the DNN).  Initial tensors follow the reference's initialisers (glorot normal for the
 kernels, zeros for biases, N(0, 1e-4^2) for the domain table and for user/item tables
 without pretraining, constants from the pretrained tables otherwise) drawn from a numpy
 stream seeded with dataset.seed -- TF's own streams are not reproducible.
@@ -18,8 +19,7 @@ import numpy as np
 
 from .base_model import BaseModel
 
-OUT_OF_SCOPE = ("autoint",)
-GRAPH_TOWERS = ("nfm", "pnn", "ccpm")
+GRAPH_TOWERS = ("nfm", "pnn", "ccpm", "autoint")
 
 
 def glorot_normal(rs, fan_in, fan_out, shape):
@@ -67,8 +67,8 @@ class DeepCTR(BaseModel):
             tower = "wdl"
         elif "nfm" in name:               # deepctr.py:33-35
             tower = "nfm"
-        elif any(k in name for k in OUT_OF_SCOPE):     # deepctr.py:37-40
-            raise NotImplementedError("tower '%s': deepctr AutoInt (multi-head self-attention over the fields) is not built" % name)
+        elif "autoint" in name:           # deepctr.py:37-40
+            tower = "autoint"
         elif "ccpm" in name:              # deepctr.py:41-43
             tower = "ccpm"
         elif "pnn" in name:               # deepctr.py:44-46
@@ -143,8 +143,20 @@ class DeepCTR(BaseModel):
         tower = getattr(self, "tower", None)
         if tower in GRAPH_TOWERS:         # first kernel: NFM on the 128 interaction columns, PNN on the fields + 3 inner products,
             E, h0 = mc["user_dim"], mc["hidden_dim"][0]       # CCPM on the [128 x 4] convolution features
-            in_dim = {"nfm": E, "pnn": 3 * E + 3, "ccpm": 4 * E}[tower]
+            in_dim = {"nfm": E, "pnn": 3 * E + 3, "ccpm": 4 * E, "autoint": 3 * E}[tower]
             t["W0"] = glorot_normal(self.init_rs, in_dim, h0, (in_dim, h0))
+            if tower == "autoint":        # InteractingLayer: W_Query | W_key | W_Value | W_Res, TruncatedNormal(stddev 0.05) each
+                d_in = E
+                for l in range(3):
+                    w = self.init_rs.standard_normal((d_in, 128))
+                    bad = np.abs(w) > 2.0
+                    while bad.any():
+                        w[bad] = self.init_rs.standard_normal(int(bad.sum()))
+                        bad = np.abs(w) > 2.0
+                    t["att%d_w" % l] = (w * 0.05).astype(np.float32)
+                    d_in = 32
+                h_last = mc["hidden_dim"][-1]
+                t["wo"] = glorot_normal(self.init_rs, 96 + h_last, 1, (96 + h_last, 1))
             if tower == "ccpm":           # Keras Conv2D defaults: glorot_uniform kernels [6,1,1,4] / [5,1,4,4] (centre tap kept), zero biases
                 lim1, lim2 = np.sqrt(6.0 / (6 * 1 + 6 * 4)), np.sqrt(6.0 / (5 * 4 + 5 * 4))
                 t["conv1_w"] = self.init_rs.uniform(-lim1, lim1, (6, 4)).astype(np.float32)

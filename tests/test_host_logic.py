@@ -65,7 +65,7 @@ def test_registry_dispatch_and_errors(tmp_path, monkeypatch):
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_uncertainty_weight"), ds, FakeEngine)) is UncertaintyWeight
     assert type(cli.build_model(tiny_config(tmp_path, "mlp_pcgrad"), ds, FakeEngine)) is PCGrad
     assert type(cli.build_model(tiny_config(tmp_path, "wdl"), ds, FakeEngine)) is DeepCTR
-    for bad in ("autoint", "ccpm"):             # autoint: not built; ccpm: the CPU stand-in has no such tower (the HIP engine does)
+    for bad in ("autoint", "ccpm"):             # the CPU stand-in has no such towers (the HIP engine does)
         with pytest.raises(NotImplementedError):
             cli.build_model(tiny_config(tmp_path, bad), ds, FakeEngine)
     for name in ("nfm", "pnn"):                 # deepctr.py:33-35,44-46: the generic-layer engine (factory.graph)
