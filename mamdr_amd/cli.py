@@ -7,8 +7,10 @@ Dispatch is by substring of config.model.name, in the reference's order (run.py:
            reptile | mldg | <else> MAML)
   modes    'separate' -> per-domain training; otherwise train() + val_and_test("test");
            'finetune' -> load best + separate_train_val_test(init_parms=False)
-Entries that are not built (deepctr nfm / autoint / ccpm / pnn, the multi-task towers with trainable tables) stay in
-the registry and raise NotImplementedError naming why.
+Every tower name of the reference's registries is built (run.py:37-47; deepctr.py:24-50: mlp wdl nfm autoint ccpm pnn
+deepfm; deep_mtl_ctr.py:25-49: shared_bottom mmoe ple; star); what is not (Star's auxiliary net, ple with more than one
+level, uncertainty weighting on the generic-layer towers, meta wrappers that accumulate gradients on them) raises
+NotImplementedError naming why.
 """
 import argparse
 import json

@@ -1,0 +1,66 @@
+"""Throughput of the generic-layer engine (csrc/graph_engine.hip) on the reference's Taobao-10 multi-task configurations
+and on the deepctr single-output towers it hosts: domain-steps/s of the alternate training loop (deep_mtl_ctr.py:69-96 /
+deepctr.py:63-93: one full pass per domain per epoch), synthetic Taobao-10 logs, batch 1024, inputs resident in HBM.
+usage: python tools/graph_bench.py [epochs]    -> one JSON line per tower"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from mamdr_amd import cli, synthetic  # noqa: E402
+from mamdr_amd.plan import PassShuffler  # noqa: E402
+from mamdr_amd.utils import MultiDomainDataset  # noqa: E402
+
+EPOCHS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def flops_per_row(model):
+    """2 x MACs of forward + backward (d input + d weights) of every dense layer on a step's path: 6 x the forward MACs."""
+    eng = model.model
+    macs = 0
+    for name, (rows, cols) in eng.shapes.items():
+        if "/W" in name or name in ("W0", "W1", "W2") or name.endswith("_w") and name.startswith("att"):
+            macs += rows * cols * (3 if name.startswith("att") else 1)
+    return macs
+
+
+for cfg_name in ("shared_bottom", "mmoe", "ple", "nfm", "pnn", "ccpm", "autoint"):
+    path = os.path.join(ROOT, "config", "Taobao-10", cfg_name + ".json")
+    if os.path.exists(path):
+        cfg = json.load(open(path))
+    else:
+        cfg = json.load(open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_taobao_10.json")))
+        cfg["model"]["name"] = cfg_name
+    cfg["train"].update(result_save_path="/tmp/graph_bench/result", checkpoint_path="/tmp/graph_bench/ckpt")
+    ds = MultiDomainDataset(cfg["dataset"])
+    model = cli.build_model(cfg, ds)
+    eng = model.model
+    D = ds.n_domain
+    sizes = {d: v["n_data"] for d, v in ds.train_dataset.items()}
+    sh = PassShuffler(sizes, 10000, 123)
+    perms = {d: torch.from_numpy(sh(d)).to(eng.device) for d in range(D)}
+    steps_per_epoch = sum(-(-sizes[d] // ds.batch_size) for d in range(D))
+
+    def epoch():
+        for d in range(D):
+            eng.train_steps(d, perm=perms[d], lr=cfg["train"]["learning_rate"])
+    epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(EPOCHS):
+        epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_path = 0
+    if hasattr(eng, "task_ranges") and cfg_name in ("shared_bottom", "mmoe", "ple"):
+        n_path = sum(c for _, c in eng.task_ranges(0))
+    print(json.dumps({"tower": cfg_name, "value": steps_per_epoch * EPOCHS / dt, "unit": "domain-steps/s",
+                      "us_per_domain_step": dt / (steps_per_epoch * EPOCHS) * 1e6, "batch": ds.batch_size,
+                      "params": int(eng.n_params), "params_on_a_step_path": int(n_path) or int(eng.n_params),
+                      "model": {k: cfg["model"][k] for k in cfg["model"] if "hidden" in k or "expert" in k}}))
+    eng.close()
