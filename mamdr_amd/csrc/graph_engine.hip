@@ -135,6 +135,8 @@ struct GemmArgs {
     // forward only: + sum_{j < n_xe} xe[row][j] * we[j][col] before the bias (PNN: the inner products feed the last three
     // rows of the first kernel, whose 384 + 3 rows are no multiple of the tile depth)
     const float* xe; int xe_ld; const float* we; int n_xe;
+    // MODE 2 only: blockIdx.z owns K rows [z K, (z + 1) K) of A and B and writes its partial product at C + z zstride
+    size_t zstride;
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
@@ -148,12 +150,19 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
     const int r4 = tid >> 2, k4 = (tid & 3) * 4;        // k-contiguous operand: row r4 of the tile, 4 k's
     const int kr = tid >> 4, c4 = (tid & 15) * 4;       // otherwise: k row kr, 4 columns
     f32x4 ra, rb;
+    const float *A = a.A, *B = a.B;
+    float* C = a.C;
+    if (MODE == 2) {
+        A += (size_t)blockIdx.z * a.K * a.lda;
+        B += (size_t)blockIdx.z * a.K * a.ldb;
+        C += (size_t)blockIdx.z * a.zstride;
+    }
     auto gload = [&](int kt) {
         const int k0 = kt * GK;
-        ra = A_KC ? *reinterpret_cast<const f32x4*>(a.A + (size_t)(m0 + r4) * a.lda + k0 + k4)
-                  : *reinterpret_cast<const f32x4*>(a.A + (size_t)(k0 + kr) * a.lda + m0 + c4);
-        rb = B_KC ? *reinterpret_cast<const f32x4*>(a.B + (size_t)(n0 + r4) * a.ldb + k0 + k4)
-                  : *reinterpret_cast<const f32x4*>(a.B + (size_t)(k0 + kr) * a.ldb + n0 + c4);
+        ra = A_KC ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r4) * a.lda + k0 + k4)
+                  : *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + kr) * a.lda + m0 + c4);
+        rb = B_KC ? *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + r4) * a.ldb + k0 + k4)
+                  : *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + kr) * a.ldb + n0 + c4);
     };
     auto lstore = [&](int buf) {
         if (A_KC) {
@@ -204,34 +213,123 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
             }
         } else if (MODE == 1) {
             if (a.gate_y) v = a.gate_y[(size_t)row * a.gate_ld + col] > 0.f ? v * a.gate_scale : 0.f;
-            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
+            if (a.accumulate) v += C[(size_t)row * a.ldc + col];
         }
-        a.C[(size_t)row * a.ldc + col] = v;
+        C[(size_t)row * a.ldc + col] = v;
     }
 }
 
-// db[n] = sum over the batch rows of dz[b][n]: 64 columns per workgroup, 4 row groups summed through LDS in order
+// db[n] = sum over the batch rows of dz[b][n]: 16 columns per workgroup, 16 row groups (8 loads in flight each) summed
+// through LDS in a fixed order
+constexpr int CS_COLS = 16, CS_GROUPS = 16;
 __global__ __launch_bounds__(256) void k_graph_colsum(const float* dz, int ld, int rows, float* out, int n_valid) {
-    __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + c;
+    __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
+    const int col = blockIdx.x * CS_COLS + c;
     float s = 0.f;
-    if (col < n_valid)
-        for (int b = g; b < rows; b += 4) s += dz[(size_t)b * ld + col];
+    if (col < n_valid) {
+        const float* p = dz + col;
+        int b = g;
+        for (; b + 7 * CS_GROUPS < rows; b += 8 * CS_GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(b + k * CS_GROUPS) * ld];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < rows; b += CS_GROUPS) s += p[(size_t)b * ld];
+    }
     red[g][c] = s;
     __syncthreads();
-    if (g == 0 && col < n_valid) out[col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (g == 0 && col < n_valid) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
+        out[col] = t;
+    }
+}
+// the end of a layer's weight gradient: workgroups [0, nb_red) add the split-K partial products of dW in a fixed order,
+// the rest are the bias column sums above
+__global__ __launch_bounds__(256) void k_graph_wfinish(const float* part, int n_split, size_t stride, int64_t n4, float* out,
+                                                       int nb_red, const float* dz, int ld, int rows, float* db, int n_valid) {
+    if ((int)blockIdx.x < nb_red) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n4) return;
+        f32x4 t = reinterpret_cast<const f32x4*>(part)[i];
+        for (int z = 1; z < n_split; ++z) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(part + z * stride)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += v[k];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = t;
+        return;
+    }
+    __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
+    const int col = ((int)blockIdx.x - nb_red) * CS_COLS + c;
+    float s = 0.f;
+    if (col < n_valid) {
+        const float* p = dz + col;
+        int b = g;
+        for (; b + 7 * CS_GROUPS < rows; b += 8 * CS_GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(b + k * CS_GROUPS) * ld];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < rows; b += CS_GROUPS) s += p[(size_t)b * ld];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && col < n_valid) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
+        db[col] = t;
+    }
+}
+static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, float* out, int n_valid) {
+    hipLaunchKernelGGL(k_graph_colsum, dim3((n_valid + CS_COLS - 1) / CS_COLS), dim3(256), 0, s, dz, ld, rows, out, n_valid);
 }
 
-// out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1)
+// out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1; the
+// attention projections: n_e = 128): 16 outputs per workgroup, the rows split over 16 groups summed through LDS in order
 __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_ld, const float* d, int d_ld, int rows,
                                                         int n_j, int n_e, float* out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_j * n_e) return;
-    const int j = idx / n_e, e = idx - j * n_e;
+    __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
+    const int idx = blockIdx.x * CS_COLS + c;
     float s = 0.f;
-    for (int b = 0; b < rows; ++b) s = fmaf(in[(size_t)b * in_ld + j], d[(size_t)b * d_ld + e], s);
-    out[idx] = s;
+    if (idx < n_j * n_e) {
+        const int j = idx / n_e, e = idx - j * n_e;
+        const float *pi = in + j, *pd = d + e;
+        int b = g;
+        for (; b + 3 * CS_GROUPS < rows; b += 4 * CS_GROUPS) {
+            float x[4], y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[k] = pi[(size_t)(b + k * CS_GROUPS) * in_ld];
+                y[k] = pd[(size_t)(b + k * CS_GROUPS) * d_ld];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s = fmaf(x[k], y[k], s);
+        }
+        for (; b < rows; b += CS_GROUPS) s = fmaf(pi[(size_t)b * in_ld], pd[(size_t)b * d_ld], s);
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && idx < n_j * n_e) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
+        out[idx] = t;
+    }
+}
+static void launch_small_tn(hipStream_t s, const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
+                            float* out) {
+    hipLaunchKernelGGL(k_graph_small_tn, dim3((n_j * n_e + CS_COLS - 1) / CS_COLS), dim3(256), 0, s, in, in_ld, d, d_ld, rows,
+                       n_j, n_e, out);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -315,14 +413,25 @@ __global__ __launch_bounds__(256) void k_graph_feat_bwd(const FeatArgs a) {
     *reinterpret_cast<f32x2*>(drow + 2 * EMB + 2 * lane) = dd;
 }
 // NFM's linear domain table: g[d] = sum over the batch rows of domain d of d loss / d logit  +  2 l2_lin w[d]
-__global__ __launch_bounds__(64) void k_graph_lin_domain_grad(const float* dlogit, const int32_t* domrow, int rows, const float* w,
-                                                              float two_l2, int n_domain, float* g) {
-    const int d = blockIdx.x * 64 + threadIdx.x;
-    if (d >= n_domain) return;
+// one workgroup per domain: rows strided over the 256 threads, LDS tree in a fixed order
+__global__ __launch_bounds__(256) void k_graph_lin_domain_grad(const float* dlogit, const int32_t* domrow, int rows, const float* w,
+                                                               float two_l2, int n_domain, float* g) {
+    __shared__ float red[256];
+    const int d = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < rows; ++b)
-        if (domrow[b] == d) s += dlogit[b];
-    g[d] = s + two_l2 * w[d];
+    for (int b = threadIdx.x; b < rows; b += 256) s += domrow[b] == d ? dlogit[b] : 0.f;
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g[d] = red[0] + two_l2 * w[d];
+}
+static void launch_lin_domain_grad(hipStream_t s, const float* dlogit, const int32_t* domrow, int rows, const float* w, float two_l2,
+                                   int n_domain, float* g) {
+    hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3(n_domain), dim3(256), 0, s, dlogit, domrow, rows, w, two_l2, n_domain, g);
 }
 
 // ------------------------------------------------------------------ CCPM: convolutions over the FIELD axis, one wave per row
@@ -750,13 +859,42 @@ __global__ __launch_bounds__(256) void k_graph_sum1(const float* x, int n, float
 
 // ------------------------------------------------------------------ domain table gradient
 // g[d][c] = sum over the batch rows of domain d of d x[b][256 + c]  +  2 l2 Dm[d][c]   (rows in batch order)
-__global__ __launch_bounds__(128) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
-                                                           const float* dm, float two_l2, float* g) {
-    const int d = blockIdx.x, c = threadIdx.x;
+// one workgroup per domain; a domain with no row in the batch (all but one of them in a domain step) leaves after one look
+// at the ids.  128 columns x 8 row groups, 4 loads in flight, summed through LDS in a fixed order.
+constexpr int DG_GROUPS = 8;
+__global__ __launch_bounds__(1024) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
+                                                            const float* dm, float two_l2, float* g) {
+    __shared__ float red[DG_GROUPS][EMB];
+    const int d = blockIdx.x, c = threadIdx.x & (EMB - 1), rg = threadIdx.x / EMB;
+    int mine = 0;
+    for (int b = threadIdx.x; b < rows; b += 1024) mine |= domrow[b] == d;
+    if (!__syncthreads_or(mine)) {
+        if (rg == 0) g[d * EMB + c] = two_l2 * dm[d * EMB + c];
+        return;
+    }
+    const float* p = dx + x_col + c;
     float s = 0.f;
-    for (int b = 0; b < rows; ++b)
-        if (domrow[b] == d) s += dx[(size_t)b * ld + x_col + c];
-    g[d * EMB + c] = s + two_l2 * dm[d * EMB + c];
+    int b = rg;
+    for (; b + 3 * DG_GROUPS < rows; b += 4 * DG_GROUPS) {
+        float v[4];
+        int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            id[k] = domrow[b + k * DG_GROUPS];
+            v[k] = p[(size_t)(b + k * DG_GROUPS) * ld];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += id[k] == d ? v[k] : 0.f;
+    }
+    for (; b < rows; b += DG_GROUPS) s += domrow[b] == d ? p[(size_t)b * ld] : 0.f;
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < DG_GROUPS; ++k) t += red[k][c];
+        g[d * EMB + c] = t + two_l2 * dm[d * EMB + c];
+    }
 }
 
 // ------------------------------------------------------------------ optimiser on a range of the flat vector
@@ -859,6 +997,8 @@ struct mamdr_graph {
     // workspace
     int rows_pad_max = 0, ld = 0;
     float *act = nullptr, *dact = nullptr, *grad = nullptr, *dlogit = nullptr, *rowloss = nullptr, *y = nullptr;
+    float* wpart = nullptr;     // split-K partial products of one weight gradient (launch_wgrad)
+    size_t wpart_floats = 0;
     int32_t* domrow = nullptr;
     float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
     // trainable tables
@@ -894,6 +1034,27 @@ int add_dnn(mamdr_graph* g, const std::string& name, int in_dim, const int32_t* 
     }
     g->dnns.push_back(d);
     return (int)g->dnns.size() - 1;
+}
+
+// dW[M x N] = A[rows x M]^T . B[rows x N], the rows split over up to 16 workgroups per tile when the tiles alone leave
+// most of the 256 CUs idle (a 384 x 512 kernel is 48 tiles); the partial products meet in k_graph_wfinish, which also
+// carries the layer's bias gradient (column sums of `dz` into `db`, skipped when db is null)
+void launch_wgrad(mamdr_graph* g, GemmArgs a, int M, int N, int rows, const float* dz, float* db) {
+    const int tiles = (M / GT) * (N / GT), nkt = rows / GK;
+    int split = 1;
+    while (split < 16 && tiles * split < 256 && nkt % (2 * split) == 0 && nkt / (2 * split) >= 4 &&
+           (size_t)(2 * split) * M * N <= g->wpart_floats)
+        split *= 2;
+    float* out = a.C;
+    a.K = rows / split;
+    a.zstride = (size_t)M * N;
+    if (split > 1) a.C = g->wpart;
+    hipLaunchKernelGGL(k_graph_gemm<2>, dim3(N / GT, M / GT, split), dim3(256), 0, g->stream, a);
+    const int64_t n4 = (int64_t)M * N / 4;
+    const int nb_red = split > 1 ? (int)((n4 + 255) / 256) : 0, nb_cs = db ? (N + CS_COLS - 1) / CS_COLS : 0;
+    if (nb_red + nb_cs)
+        hipLaunchKernelGGL(k_graph_wfinish, dim3(nb_red + nb_cs), dim3(256), 0, g->stream, g->wpart, split, a.zstride, n4, out,
+                           nb_red, dz, g->ld, rows, db, N);
 }
 
 void launch_gemm(int mode, const GemmArgs& a, int M, int N, hipStream_t s) {
@@ -959,10 +1120,7 @@ void dnn_backward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, in
         a.ldb = g->ld;
         a.C = g->G(L.w_off);
         a.ldc = L.out;
-        a.K = sc.rp;
-        launch_gemm(2, a, L.in, L.out, g->stream);
-        hipLaunchKernelGGL(k_graph_colsum, dim3(L.out / 64), dim3(256), 0, g->stream, g->dact + cols[l], g->ld, sc.rp,
-                           g->G(L.b_off), L.out);
+        launch_wgrad(g, a, L.in, L.out, sc.rp, g->dact + cols[l], g->G(L.b_off));
         memset(&a, 0, sizeof(a));
         a.A = g->dact + cols[l];        // d in = dz W^T
         a.lda = g->ld;
@@ -1333,6 +1491,11 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     alloc((void**)&g->act, rp * g->ld * sizeof(float));
     alloc((void**)&g->dact, rp * g->ld * sizeof(float));
     alloc((void**)&g->grad, (size_t)(g->n_params - g->table_floats) * sizeof(float));
+    size_t max_w = (size_t)EMB * ATT_P;
+    for (const Dnn& d : g->dnns)
+        for (const Layer& L : d.layers) max_w = std::max(max_w, (size_t)L.in * L.out);
+    g->wpart_floats = 16 * max_w;
+    alloc((void**)&g->wpart, g->wpart_floats * sizeof(float));
     if (g->tables) {
         alloc((void**)&g->urow, rp * sizeof(int32_t));
         alloc((void**)&g->irow, rp * sizeof(int32_t));
@@ -1395,7 +1558,7 @@ int mamdr_graph_destroy(mamdr_graph* g) {
     (void)hipStreamSynchronize(g->stream);
     void* ptrs[] = {g->act, g->dact, g->grad, g->dlogit, g->rowloss, g->y, g->domrow, g->thresholds, g->frozen_sumsq,
                     g->sumsq_partials, g->eval_acc, g->urow, g->irow, g->map_u, g->map_i, g->hasdup_u, g->hasdup_i,
-                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i, g->xt, g->dxt,
+                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i, g->xt, g->dxt, g->wpart,
                     g->attP[0], g->attP[1], g->attP[2], g->attdP[0], g->attdP[1], g->attdP[2], g->attA[0], g->attA[1], g->attA[2],
                     g->attY[0], g->attY[1], g->attY[2], g->attdY[0], g->attdY[1], g->attdY[2]};
     for (void* p : ptrs)
@@ -1560,7 +1723,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
                                g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear);
         // ---- backward
         // head: dw = t^T dlogit, dgb = sum dlogit
-        hipLaunchKernelGGL(k_graph_small_tn, dim3((ha.n_t + 255) / 256), dim3(256), 0, g->stream, g->act + t_col, g->ld, g->dlogit, 1,
+        launch_small_tn(g->stream, g->act + t_col, g->ld, g->dlogit, 1,
                            sc.rp, ha.n_t, 1, g->G(t.head_w));
         hipLaunchKernelGGL(k_graph_sum1, dim3(1), dim3(256), 0, g->stream, g->dlogit, sc.rp, g->G(t.head_gb));
         const size_t ti = t.path.size() - 1;
@@ -1596,8 +1759,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
                     a.ldb = ATT_P;
                     a.C = g->G(g->att_w[l]);
                     a.ldc = ATT_P;
-                    a.K = 3 * sc.rp;
-                    launch_gemm(2, a, d_in, ATT_P, g->stream);
+                    launch_wgrad(g, a, d_in, ATT_P, 3 * sc.rp, nullptr, nullptr);
                     memset(&a, 0, sizeof(a));
                     a.A = g->attdP[l];              // d X = dP W^T
                     a.lda = ATT_P;
@@ -1611,13 +1773,13 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
                     hipLaunchKernelGGL(k_graph_add_x, dim3((sc.rp * n + 255) / 256), dim3(256), 0, g->stream, g->dact, g->ld, g->dxt,
                                        sc.rp, first, n);
                 } else {
-                    hipLaunchKernelGGL(k_graph_small_tn, dim3((d_in * ATT_P + 255) / 256), dim3(256), 0, g->stream, xin, d_in,
+                    launch_small_tn(g->stream, xin, d_in,
                                        g->attdP[l], ATT_P, 3 * sc.rp, d_in, ATT_P, g->G(g->att_w[l]));
                     hipLaunchKernelGGL(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
                                        ATT_P, g->params + g->att_w[l], d_in, 3 * sc.rp, g->attdY[l - 1]);
                 }
             }
-            hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3((g->cfg.n_domain + 63) / 64), dim3(64), 0, g->stream, g->dlogit,
+            launch_lin_domain_grad(g->stream, g->dlogit,
                                g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                g->G(g->lin_d_off));
         } else if (g->single && g->cfg.kind == MAMDR_GRAPH_CCPM) {
@@ -1626,9 +1788,9 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             CcpmArgs ca;
             fill_ccpm(g, sc, ca);
             hipLaunchKernelGGL(k_graph_ccpm_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
-            hipLaunchKernelGGL(k_graph_colsum, dim3(1), dim3(256), 0, g->stream, g->dact + g->cg_col, g->ld, sc.rp,
+            launch_colsum(g->stream, g->dact + g->cg_col, g->ld, sc.rp,
                                g->G(g->conv_off), 48);
-            hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3((g->cfg.n_domain + 63) / 64), dim3(64), 0, g->stream, g->dlogit,
+            launch_lin_domain_grad(g->stream, g->dlogit,
                                g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                g->G(g->lin_d_off));
         } else if (g->single) {
@@ -1642,12 +1804,12 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
                 // rows 0..383 of the first kernel as any first layer on x; rows 384..386 against the inner products
                 dnn_backward(g, tower, t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
                 const Layer& L0 = tower.layers[0];
-                hipLaunchKernelGGL(k_graph_small_tn, dim3((3 * L0.out + 255) / 256), dim3(256), 0, g->stream, g->act + g->f_col, g->ld,
+                launch_small_tn(g->stream, g->act + g->f_col, g->ld,
                                    g->dact + t.col[0][0], g->ld, sc.rp, 3, L0.out, g->G(L0.w_off + (int64_t)L0.in * L0.out));
             }
             hipLaunchKernelGGL(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
             if (nfm)
-                hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3((g->cfg.n_domain + 63) / 64), dim3(64), 0, g->stream, g->dlogit,
+                launch_lin_domain_grad(g->stream, g->dlogit,
                                    g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                    g->G(g->lin_d_off));
         } else if (g->gated) {
@@ -1657,7 +1819,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             hipLaunchKernelGGL(k_graph_gate_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, gta);
             const size_t gi = t.mix.size();
             const Dnn& gd = g->dnns[t.gate];
-            hipLaunchKernelGGL(k_graph_small_tn, dim3((gta.n_q * gta.n_e + 255) / 256), dim3(256), 0, g->stream, g->act + gta.q_col,
+            launch_small_tn(g->stream, g->act + gta.q_col,
                                g->ld, g->dact + t.g_col, g->ld, sc.rp, gta.n_q, gta.n_e, g->G(t.wg_off));
             dnn_backward(g, gd, t.col[gi], 0, 0, -1, dx_started, dx_first, dx_n, sc);
             dx_started = true;
@@ -1670,7 +1832,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
             dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
-        hipLaunchKernelGGL(k_graph_domain_grad, dim3(g->cfg.n_domain), dim3(EMB), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
+        hipLaunchKernelGGL(k_graph_domain_grad, dim3(g->cfg.n_domain), dim3(EMB * DG_GROUPS), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
                            sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
         if (g->tables) {
             // TF1's dense step over both tables: g = 2 l2 p + scatter-add of d x[:, user | item columns]

@@ -179,28 +179,39 @@ def test_eval_predictions_match_oracle_at_equal_weights():
 @pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
 def test_alternate_training_auc_parity(kind):
     """DeepMTLCTR.train (deep_mtl_ctr.py:69-96): epochs of one full pass per domain through that domain's model, in a
-    shuffled order; same order / shuffles / dropout masks on both sides; per-domain validation AUC within 1e-3."""
+    shuffled order; same order / shuffles / dropout masks on both sides; per-domain validation AUC within 1e-3 -- plus
+    twice the ORACLE'S OWN AUC shift under a 2e-7 relative perturbation of its initial weights, measured here (as
+    tests/test_gpu_fmnets.py): the summation order of the batch reductions is the kernels' own, and fp32 training
+    amplifies such last-bit differences (mmoe: up to 1e-3 on this problem after 16 passes)."""
     g, eng, model, spec = make_problem(kind, dropout=0.5, scale=0.15)
     D = g["n_domain"]
     sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
     order = [[2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0]]
-    k = 0
     LR = 2e-3               # (the configs' 1e-4 needs tens of epochs; the comparison wants a model that has learnt)
+    twin = omtl.OracleMTL({k: (v * F32(1 + 2e-7)).astype(F32) if v.dtype == F32 and "emb" not in k else v.copy()
+                           for k, v in model.params.items()}, spec, emb_trainable=False, dropout=0.5, lr=LR,
+                          dropout_seed=eng.dropout_seed)
     model.lr = LR
+    k = 0
     for seq in order:
         for d in seq:
             k += 1
             perm = orng.shuffle_perm(sizes[d], 10000, seed=500 + k)
             eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), lr=LR)
             model.train_pass(d, g["data"]["train"][d], perm, 256)
-    aucs = []
+            twin.train_pass(d, g["data"]["train"][d], perm, 256)
+    aucs, got, shift = [], [], []
     for d in range(D):
         _, auc_g = eng.evaluate(d, "val")
         _, preds = model.evaluate(d, g["data"]["val"][d], 256)
         auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
-        print("%s domain %d: AUC hip %.5f oracle %.5f" % (kind, d, auc_g, auc_o))
-        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+        _, preds_t = twin.evaluate(d, g["data"]["val"][d], 256)
+        shift.append(abs(auc_o - float(oauc.auc500(g["data"]["val"][d]["label"], preds_t, 256))))
+        print("%s domain %d: AUC hip %.5f oracle %.5f (oracle self-divergence %.1e)" % (kind, d, auc_g, auc_o, shift[-1]))
         aucs.append(auc_o)
+        got.append(auc_g)
+    for d in range(D):      # the largest shift over the domains: one domain's shift is a noisy sample of the chaos scale
+        assert abs(got[d] - aucs[d]) <= 1e-3 + 2 * max(shift), (d, got[d], aucs[d], shift)
     assert np.mean(aucs) > 0.6
     eng.close()
 
