@@ -1,12 +1,15 @@
 #!/bin/bash
+exec < /dev/null
 # round-3 measurement pass (through gpurun): tools/r03_measure.sh <tag> [stages]
 #   stages (default "test bench prof pmc gather"): test = pytest -m gpu; bench = the default bench line (Taobao-10 +
 #   targets taobao30 / amazon6 / amazon13 at full rows + gather + CPU baseline) and the 2-ranks-on-one-GPU line;
 #   prof = rocprofv3 --kernel-trace --stats of the four BASELINE workloads; pmc = FETCH_SIZE / WRITE_SIZE passes
-#   (separate, --kernel-trace only, the program directly after `--`); gather = trace + counters of tools/gather_hbm.py.
+#   (separate, --kernel-trace only, the program directly after `--`); gather = trace + counters of tools/gather_hbm.py;
+#   graph = throughput + kernel trace of the generic-layer towers (tools/graph_bench.py).
+# Every command is bounded by `timeout` and reads /dev/null: a hung profiler must not eat the GPU budget.
 # Summaries land in gpurun_out/<tag>/; copy what is to be judged into profiles/ by hand.
 TAG=${1:-r03a}
-STAGES=${2:-"test bench prof pmc gather"}
+STAGES=${2:-"test bench prof pmc gather graph"}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -14,22 +17,22 @@ REPO=$PWD
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 db() { find "$OUT/$1" -name "*.db" | head -1; }
 if has test; then
-    python -m pytest tests -m gpu -x -q -s > "$OUT/pytest_gpu.log" 2>&1
+    timeout 1500 python -m pytest tests -m gpu -x -q -s > "$OUT/pytest_gpu.log" 2>&1
     tail -3 "$OUT/pytest_gpu.log"
     grep -E "worst|bs [0-9]+:" "$OUT/pytest_gpu.log"
 fi
 if has bench; then
     T0=$(date +%s)
-    python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+    timeout 600 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
     echo "default bench.py run: $(( $(date +%s) - T0 )) s wall"
-    MAMDR_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu-budget 0 --no-targets > "$OUT/bench_taobao10_2ranks_shared.json" 2> "$OUT/bench_2ranks.err"
+    MAMDR_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu-budget 0 --no-targets > "$OUT/bench_taobao10_2ranks_shared.json" 2> "$OUT/bench_2ranks.err"
 fi
 cd /tmp
 if has prof; then
-    rocprofv3 --kernel-trace --stats -d "$OUT/prof10" -o run -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --cpu-budget 0 --no-targets > "$OUT/prof10.log" 2>&1
-    rocprofv3 --kernel-trace --stats -d "$OUT/prof30" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 2 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/prof30.log" 2>&1
-    rocprofv3 --kernel-trace --stats -d "$OUT/profa6" -o run -- python3 "$REPO/bench.py" --workload amazon6 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa6.log" 2>&1
-    rocprofv3 --kernel-trace --stats -d "$OUT/profa13" -o run -- python3 "$REPO/bench.py" --workload amazon13 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa13.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof10" -o run -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --cpu-budget 0 --no-targets > "$OUT/prof10.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof30" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 2 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/prof30.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa6" -o run -- python3 "$REPO/bench.py" --workload amazon6 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa6.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa13" -o run -- python3 "$REPO/bench.py" --workload amazon13 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa13.log" 2>&1
 fi
 if has pmc; then
     for W in ${PMC_WORKLOADS:-taobao10 taobao30 amazon6 amazon13}; do
@@ -37,16 +40,25 @@ if has pmc; then
             # (Amazon-13's full-row epoch is 39 K steps x 10 kernels of counter records: rocprofv3 itself crashed on it;
             # the bytes a launch moves do not depend on how many rows an epoch has -> 10 % of the rows for that pass)
             RS=1; [ $W = amazon13 ] && RS=0.1
-            MAMDR_BENCH_ROW_SCALE=$RS rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_${W}_$C" -o run -- python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc_${W}_$C.log" 2>&1
+            MAMDR_BENCH_ROW_SCALE=$RS timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_${W}_$C" -o run -- python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc_${W}_$C.log" 2>&1
         done
     done
 fi
 if has gather; then
-    rocprofv3 --kernel-trace --stats -d "$OUT/gather_trace" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_trace.log" 2>&1
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/gather_fetch" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_fetch.log" 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/gather_write" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_write.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/gather_trace" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_trace.log" 2>&1
+    timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/gather_fetch" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_fetch.log" 2>&1
+    timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/gather_write" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_write.log" 2>&1
+fi
+if has graph; then
+    timeout 200 python3 "$REPO/tools/graph_bench.py" 3 2>/dev/null | grep tower > "$OUT/graph_bench.jsonl"
+    timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/graph_trace" -o run -- python3 "$REPO/tools/graph_bench.py" 1 > "$OUT/graph_trace.log" 2>&1
 fi
 cd "$REPO"
+if has graph; then
+    G=$(db graph_trace); [ -n "$G" ] && python tools/rocpd_summary.py stats "$G" "$OUT/kernel_stats_graph_towers.csv"
+    rm -rf "$OUT/graph_trace"
+    cut -c1-110 "$OUT/graph_bench.jsonl"
+fi
 if has prof; then
     python tools/rocpd_summary.py stats "$(db prof10)" "$OUT/kernel_stats_taobao10.csv"
     python tools/rocpd_summary.py stats "$(db prof30)" "$OUT/kernel_stats_taobao30.csv"
