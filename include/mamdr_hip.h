@@ -299,7 +299,8 @@ int mamdr_profile_read(mamdr_ctx* ctx, int32_t kernel, double* total_ms, int64_t
  * (the hot path's context is specialised to the 384-256-128-64 tower); same conventions as above.
  * The flat vector lists, in order: the domain table, the experts every task mixes, then per task its own experts (PLE),
  * its gate DNN + gate kernel, its tower DNN, its output unit and global bias (tensor names: mamdr_graph_tensor_info).
- * User / item tables are frozen (bound through mamdr_graph_bind_table); emb_trainable = 1 returns MAMDR_ENOTBUILT. */
+ * Frozen user / item tables are bound through mamdr_graph_bind_table; with emb_trainable = 1 (the Amazon configs) they sit
+ * at the head of the flat vector and take TF1's dense Adam step (every row, every step) like any other tensor. */
 enum { MAMDR_GRAPH_SHARED_BOTTOM = 0,   /* deep_mtl_ctr.py:25-30  models.SharedBottom */
        MAMDR_GRAPH_MMOE = 1,            /* deep_mtl_ctr.py:31-38  models.MMOE */
        MAMDR_GRAPH_PLE = 2,             /* deep_mtl_ctr.py:39-49  models.PLE (num_levels = 1, as in every reference config) */

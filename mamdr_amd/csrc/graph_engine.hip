@@ -9,7 +9,8 @@
 //   every expert task d mixes: DNN = per layer  relu(h W + b) * dropout       k_graph_gemm<0>  (mfma, 64x64 tiles)
 //   gate_d: DNN, then softmax(q Wg) and the mixture sum_e gate_e expert_e     k_graph_gate_fwd (one wave per row)
 //   tower_d: DNN;  head: sigmoid(t w + gb), Keras BCE, d loss / d logit       k_graph_head     (one wave per row)
-//   backward, layer by layer: dW = in^T dz (k_graph_gemm<2>), db = column sums (k_graph_colsum),
+//   backward, layer by layer: dW = in^T dz (k_graph_gemm<2>, the batch rows split over up to 16 workgroups per tile,
+//   launch_wgrad), k_graph_wfinish = the partial products summed in a fixed order + db = column sums in the same launch,
 //   d in = dz W^T times the producer's relu / dropout gate (k_graph_gemm<1>); the mixture's backward
 //   (k_graph_gate_bwd) between tower and experts; the first layers add into d x[:, domain columns]
 //   domain table: segment sum of d x over the batch's domain ids + 2 l2 Dm    k_graph_domain_grad
@@ -20,6 +21,13 @@
 // TF1's dense Adam over every row -- regulariser gradient 2 l2 p + the scatter-add of the batch's row gradients --
 // through the table kernels of emb_kernels.hip in their per-step form (k_emb_flag / k_emb_reduce: duplicates summed
 // in batch order by the row's first position; k_emb_sweep: one HBM pass over both tables).
+//
+// The single-output deepctr towers on the same layers (deepctr.py:33-46; ONE task serves every domain):
+//   NFM      f = bi-interaction of the three fields (k_graph_feat_fwd/bwd), DNN over f, + deepctr's linear logit
+//   PNN      DNN over [x | the 3 pairwise inner products] (the 3 extra kernel rows ride as a rank-3 epilogue of the GEMM)
+//   CCPM     Conv2D (6,1) -> max over the fields -> Conv2D (5,1) centre tap, tanh (k_graph_ccpm_fwd/bwd), DNN over 512 features
+//   AutoInt  3 x multi-head self-attention over the 3 field tokens on compact token-major buffers (projections as GEMMs
+//            over 3 B token rows, the 3 x 3 attention core in k_graph_att_fwd/bwd), beside the DNN; head over [96 | DNN]
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
