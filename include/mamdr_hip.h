@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 12
+#define MAMDR_ABI_VERSION 13
 
 enum {
     MAMDR_OK = 0,
@@ -350,9 +350,19 @@ int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t
 int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const int32_t* d_uid, const int32_t* d_pid,
                                  const int32_t* d_domain, const float* d_label, int64_t n_rows);
 /* n_steps x `domain_model_dict[domain]` train_on_batch: deep_mtl_ctr.py:79-80 (Adam) / :158-172 (per-domain fit).
- * Same batch / permutation / dropout-stream conventions as mamdr_train_steps; MAMDR_OPT_ADAM or MAMDR_OPT_SGD. */
+ * Same batch / permutation / dropout-stream conventions as mamdr_train_steps; MAMDR_OPT_ADAM, MAMDR_OPT_SGD or
+ * MAMDR_OPT_ACCUMULATE (after mamdr_graph_bind_accumulator). */
 int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, int64_t first_step, int64_t n_steps,
                             int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr, float* d_loss_out);
+/* as mamdr_train_steps_n: the pass covers `pass_rows` positions, d_perm lists that many rows of the split (the take / skip
+ * sub-datasets of the meta-train / meta-val split, maml.py:300-330, mldg.py:309-325); pass_rows < 0 = the whole split */
+int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm, int64_t pass_rows, int64_t first_step,
+                              int64_t n_steps, int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr,
+                              float* d_loss_out);
+/* MAMDR_OPT_ACCUMULATE steps of the meta wrappers on these towers (maml.py:107-109,196-229; mldg.py; pcgrad.py): dropout off,
+ * no update, the step's gradient (every tensor the task's model trains, tables included) added to this flat vector of
+ * mamdr_graph_param_count floats; NULL unbinds */
+int mamdr_graph_bind_accumulator(mamdr_graph* g, float* d_acc);
 /* `domain_model_dict[domain].evaluate(data, steps=n_step)`: deep_mtl_ctr.py:207; outputs as mamdr_eval_domain */
 int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch, float* d_loss_out, uint32_t* d_hist,
                             float* d_pred_out);

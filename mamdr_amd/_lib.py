@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -120,6 +120,8 @@ SIGNATURES = {
     "mamdr_graph_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
     "mamdr_graph_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),
     "mamdr_graph_train_steps": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
+    "mamdr_graph_train_steps_n": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I64, _I32, _U32, _I32, _F, _VP]),
+    "mamdr_graph_bind_accumulator": (C.c_int, [_VP, _VP]),
     "mamdr_graph_eval_domain": (C.c_int, [_VP, C.c_int, C.c_int, _I32, _VP, _VP, _VP]),
 }
 

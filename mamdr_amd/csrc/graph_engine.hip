@@ -910,7 +910,7 @@ struct AdamArgs {
     float *p, *m, *v;
     const float* g;
     int64_t n4;             // float4 elements
-    int optimizer;          // MAMDR_OPT_ADAM / MAMDR_OPT_SGD
+    int optimizer;          // MAMDR_OPT_ADAM / MAMDR_OPT_SGD / MAMDR_OPT_ACCUMULATE (m = the accumulator: m += g, nothing else)
     float alpha, omb1, omb2, eps;
 };
 __global__ __launch_bounds__(256) void k_graph_adam(const AdamArgs a) {
@@ -922,6 +922,13 @@ __global__ __launch_bounds__(256) void k_graph_adam(const AdamArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) p[k] = p[k] - g[k] * a.alpha;
         reinterpret_cast<f32x4*>(a.p)[i] = p;
+        return;
+    }
+    if (a.optimizer == MAMDR_OPT_ACCUMULATE) {
+        f32x4 acc = reinterpret_cast<const f32x4*>(a.m)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] + g[k];
+        reinterpret_cast<f32x4*>(a.m)[i] = acc;
         return;
     }
     f32x4 m = reinterpret_cast<const f32x4*>(a.m)[i], v = reinterpret_cast<const f32x4*>(a.v)[i];
@@ -967,6 +974,7 @@ struct SplitData {
     const int32_t *uid = nullptr, *pid = nullptr, *dom = nullptr;
     const float* label = nullptr;
     int64_t n = 0;
+    bool bound = false;     // an empty split (n = 0) is bound too
 };
 
 }  // namespace
@@ -997,6 +1005,7 @@ struct mamdr_graph {
     float *extra = nullptr, *glin_u = nullptr, *glin_i = nullptr;
     // bound state
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float* accum = nullptr;     // meta-gradient accumulator of MAMDR_OPT_ACCUMULATE steps (mamdr_graph_bind_accumulator)
     const float *user_tab = nullptr, *item_tab = nullptr;
     std::vector<SplitData> data;
     int64_t adam_t = 0;
@@ -1653,6 +1662,7 @@ int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const in
     if (!d) return gfail(MAMDR_EINVAL, "domain %d / split %d out of range", domain, split);
     if (n_rows < 0 || n_rows > 0x7fffffff) return gfail(MAMDR_EINVAL, "n_rows out of range");
     if (n_rows > 0 && (!d_uid || !d_pid || !d_domain || !d_label)) return gfail(MAMDR_EINVAL, "null column pointer");
+    d->bound = true;
     d->uid = d_uid;
     d->pid = d_pid;
     d->dom = d_domain;
@@ -1663,17 +1673,31 @@ int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const in
 
 int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, int64_t first_step, int64_t n_steps,
                             int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr, float* d_loss_out) {
+    return mamdr_graph_train_steps_n(g, domain, d_perm, -1, first_step, n_steps, batch, dropout_seed, optimizer, lr, d_loss_out);
+}
+
+int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm, int64_t pass_rows, int64_t first_step,
+                              int64_t n_steps, int32_t batch, uint32_t dropout_seed, int32_t optimizer, float lr,
+                              float* d_loss_out) {
     if (check(g)) return MAMDR_EINVAL;
     if (ready(g)) return MAMDR_ESTATE;
     SplitData* d = split_of(g, domain, MAMDR_SPLIT_TRAIN);
-    if (!d || !d->uid) return gfail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
+    if (!d || !d->bound) return gfail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
     if (batch <= 0 || batch > g->cfg.max_batch) return gfail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, g->cfg.max_batch);
-    if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD) return gfail(MAMDR_EINVAL, "optimizer %d not supported here", optimizer);
+    if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD && optimizer != MAMDR_OPT_ACCUMULATE)
+        return gfail(MAMDR_EINVAL, "unknown optimizer %d", optimizer);
+    if (optimizer == MAMDR_OPT_ACCUMULATE && !g->accum)
+        return gfail(MAMDR_ESTATE, "MAMDR_OPT_ACCUMULATE needs mamdr_graph_bind_accumulator first");
     if (first_step < 0 || n_steps < 0) return gfail(MAMDR_EINVAL, "negative step range");
-    const int64_t pass_steps = (d->n + batch - 1) / batch;
+    if (pass_rows < 0) pass_rows = d->n;                 // the whole split
+    if (pass_rows > d->n) return gfail(MAMDR_EINVAL, "pass of %lld rows exceeds the %lld rows of domain %d",
+                                       (long long)pass_rows, (long long)d->n, domain);
+    if (pass_rows < d->n && !d_perm) return gfail(MAMDR_EINVAL, "a pass over part of a split needs its permutation");
+    const int64_t pass_steps = (pass_rows + batch - 1) / batch;
     if (first_step + n_steps > pass_steps)
         return gfail(MAMDR_EINVAL, "steps [%lld,%lld) exceed the %lld batches of domain %d", (long long)first_step,
                      (long long)(first_step + n_steps), (long long)pass_steps, domain);
+    if (n_steps == 0) return MAMDR_OK;
     const Task& t = g->tasks[g->single ? 0 : domain];
     const float rate = g->cfg.dropout;
     double thr = (double)rate * 4294967296.0;
@@ -1681,14 +1705,14 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
         StepCtx sc;
-        sc.rows = (int)((d->n - row_base) < batch ? (d->n - row_base) : batch);
+        sc.rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
         sc.rp = (sc.rows + GT - 1) / GT * GT;
         sc.train = true;
         sc.seed = dropout_seed;
         sc.step = g->global_step;
         sc.drop_thresh = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)(int64_t)thr;
         sc.keep_scale = (float)(1.0 / (1.0 - (double)rate));
-        sc.use_dropout = rate > 0.f;
+        sc.use_dropout = rate > 0.f && optimizer != MAMDR_OPT_ACCUMULATE;     // the meta pass runs in learning phase 0 (maml.py:107-109)
         if (!sc.use_dropout) sc.keep_scale = 1.0f;
         float alpha = lr;
         if (optimizer == MAMDR_OPT_ADAM) {      // ONE optimizer object for all domain models: its beta powers advance every step
@@ -1846,8 +1870,9 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             // TF1's dense step over both tables: g = 2 l2 p + scatter-add of d x[:, user | item columns]
             EmbStepArgs ea;
             memset(&ea, 0, sizeof(ea));
+            float* const slot_m = optimizer == MAMDR_OPT_ACCUMULATE ? g->accum : g->adam_m;
             ea.p = g->params;
-            ea.m = g->adam_m;
+            ea.m = slot_m;
             ea.v = g->adam_v;
             ea.dxe = g->dact;
             ea.dx_ld = g->ld;
@@ -1874,11 +1899,11 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
             if (g->has_lin) {       // their 1-d linear tables: scatter-add of d loss / d logit, same rule
                 ea.two_l2_lin = 2.0f * g->cfg.l2_linear;
                 ea.t[0].lin_p = g->params + g->lin_u_off;
-                ea.t[0].lin_m = g->adam_m + g->lin_u_off;
+                ea.t[0].lin_m = slot_m + g->lin_u_off;
                 ea.t[0].lin_v = g->adam_v + g->lin_u_off;
                 ea.t[0].glin = g->glin_u;
                 ea.t[1].lin_p = g->params + g->lin_i_off;
-                ea.t[1].lin_m = g->adam_m + g->lin_i_off;
+                ea.t[1].lin_m = slot_m + g->lin_i_off;
                 ea.t[1].lin_v = g->adam_v + g->lin_i_off;
                 ea.t[1].glin = g->glin_i;
             }
@@ -1891,7 +1916,7 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
         for (int k = 0; k < 2; ++k) {
             AdamArgs aa;
             aa.p = g->params + off[k];
-            aa.m = g->adam_m + off[k];
+            aa.m = (optimizer == MAMDR_OPT_ACCUMULATE ? g->accum : g->adam_m) + off[k];
             aa.v = g->adam_v + off[k];
             aa.g = g->G(off[k]);
             aa.n4 = cnt[k] / 4;
@@ -1909,12 +1934,19 @@ int mamdr_graph_train_steps(mamdr_graph* g, int domain, const int32_t* d_perm, i
     return MAMDR_OK;
 }
 
+int mamdr_graph_bind_accumulator(mamdr_graph* g, float* d_acc) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (d_acc && ((uintptr_t)d_acc & 15)) return gfail(MAMDR_EINVAL, "accumulator is not 16-byte aligned");
+    g->accum = d_acc;
+    return MAMDR_OK;
+}
+
 int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch, float* d_loss_out, uint32_t* d_hist,
                             float* d_pred_out) {
     if (check(g)) return MAMDR_EINVAL;
     if (ready(g)) return MAMDR_ESTATE;
     SplitData* d = split_of(g, domain, split);
-    if (!d || !d->uid) return gfail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
+    if (!d || !d->bound) return gfail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
     if (batch <= 0 || batch > g->cfg.max_batch) return gfail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, g->cfg.max_batch);
     if (!d_loss_out || !d_hist) return gfail(MAMDR_EINVAL, "null output pointer");
     if (d->n <= 0) return gfail(MAMDR_EINVAL, "empty split");

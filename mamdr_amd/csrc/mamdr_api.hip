@@ -49,6 +49,7 @@ struct SplitData {
     const int32_t* dom = nullptr;
     const float* label = nullptr;
     int64_t n = 0;
+    bool bound = false;     // an EMPTY split (n = 0, null columns) is bound too: a pass over it has no steps
 };
 
 struct EventPair {
@@ -1008,6 +1009,7 @@ int mamdr_bind_domain_data(mamdr_ctx* c, int domain, int split, const int32_t* d
     if (!d) return fail(MAMDR_EINVAL, "domain %d / split %d out of range", domain, split);
     if (n_rows < 0 || n_rows > 0x7fffffff) return fail(MAMDR_EINVAL, "n_rows out of range");
     if (n_rows > 0 && (!d_uid || !d_pid || !d_domain || !d_label)) return fail(MAMDR_EINVAL, "null column pointer");
+    d->bound = true;
     d->uid = d_uid;
     d->pid = d_pid;
     d->dom = d_domain;
@@ -1035,7 +1037,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (ready(c)) return MAMDR_ESTATE;
     SplitData* d = split_of(c, domain, MAMDR_SPLIT_TRAIN);
-    if (!d || !d->uid) return fail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
+    if (!d || !d->bound) return fail(MAMDR_ESTATE, "train split of domain %d is not bound", domain);
     if (batch <= 0 || batch > c->cfg.max_batch) return fail(MAMDR_EINVAL, "batch %d outside (0, max_batch=%d]", batch, c->cfg.max_batch);
     if (optimizer != MAMDR_OPT_ADAM && optimizer != MAMDR_OPT_SGD && optimizer != MAMDR_OPT_ACCUMULATE)
         return fail(MAMDR_EINVAL, "unknown optimizer %d", optimizer);
@@ -1049,6 +1051,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     if (first_step + n_steps > pass_steps)
         return fail(MAMDR_EINVAL, "steps [%lld,%lld) exceed the %lld batches of domain %d", (long long)first_step,
                     (long long)(first_step + n_steps), (long long)pass_steps, domain);
+    if (n_steps == 0) return MAMDR_OK;      // an empty pass (empty domain, meta_train_step window of nothing): no launch, no state change
 
     const float rate = c->cfg.dropout;
     double thr = (double)rate * 4294967296.0;
@@ -1460,7 +1463,7 @@ int mamdr_eval_domain(mamdr_ctx* c, int domain, int split, int32_t batch, float*
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (ready(c)) return MAMDR_ESTATE;
     SplitData* d = split_of(c, domain, split);
-    if (!d || !d->uid) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
+    if (!d || !d->bound) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
     if (!d_loss_out || !d_hist) return fail(MAMDR_EINVAL, "null output pointer");
     sync_tables(c);
     if (batch <= 0 || batch % TILE_ROWS != 0) return fail(MAMDR_EINVAL, "eval batch must be a positive multiple of %d", TILE_ROWS);
@@ -1528,7 +1531,7 @@ int mamdr_gather_rows(mamdr_ctx* c, int domain, int split, const int32_t* d_perm
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (ready(c)) return MAMDR_ESTATE;
     SplitData* d = split_of(c, domain, split);
-    if (!d || !d->uid) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
+    if (!d || !d->bound) return fail(MAMDR_ESTATE, "split %d of domain %d is not bound", split, domain);
     if (!d_out) return fail(MAMDR_EINVAL, "null output pointer");
     if (first_row < 0 || n_rows < 0 || first_row + n_rows > d->n) return fail(MAMDR_EINVAL, "row range outside the split");
     if (n_rows == 0) return MAMDR_OK;
@@ -1552,11 +1555,13 @@ static int check_vec(const void* p, const char* name) {
     if ((uintptr_t)p & 15) return fail(MAMDR_EINVAL, "%s is not 16-byte aligned", name);
     return MAMDR_OK;
 }
-#define CHECK_VEC(p) do { if (check_vec((p), #p)) return MAMDR_EINVAL; } while (0)
+// (an empty vector -- n = 0 -- may be a null pointer: nothing is read or written)
+#define CHECK_VEC(p) do { if (n != 0 && check_vec((p), #p)) return MAMDR_EINVAL; } while (0)
 
 int mamdr_interp(float* d_dst, const float* d_a, const float* d_b, float scale, int64_t n, void* stream) {
     CHECK_VEC(d_dst); CHECK_VEC(d_a); CHECK_VEC(d_b);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     launch_interp(d_dst, d_a, d_b, scale, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
@@ -1565,6 +1570,7 @@ int mamdr_moving_average(float* d_unbiased, float* d_biased, const float* d_valu
                          void* stream) {
     CHECK_VEC(d_unbiased); CHECK_VEC(d_biased); CHECK_VEC(d_value);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     if (!(denom > 0.f)) return fail(MAMDR_EINVAL, "moving average: debias denominator %g (local step < 1?)", (double)denom);
     launch_moving_average(d_unbiased, d_biased, d_value, decay, denom, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1573,6 +1579,7 @@ int mamdr_moving_average(float* d_unbiased, float* d_biased, const float* d_valu
 int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t mode, int64_t n, void* stream) {
     CHECK_VEC(d_dst); CHECK_VEC(d_theta); CHECK_VEC(d_phi);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     if (mode != MAMDR_MERGE_PLUS && mode != MAMDR_MERGE_TIMES) return fail(MAMDR_EINVAL, "unknown merge mode %d", mode);
     launch_merge(d_dst, d_theta, d_phi, mode, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1582,6 +1589,7 @@ int mamdr_dr_advance(float* d_phi, float* d_w, float* d_merged, const float* d_t
                      int32_t assign_model, int64_t n, void* stream) {
     CHECK_VEC(d_phi); CHECK_VEC(d_w); CHECK_VEC(d_merged); CHECK_VEC(d_theta);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     if (mode != MAMDR_MERGE_PLUS && mode != MAMDR_MERGE_TIMES) return fail(MAMDR_EINVAL, "unknown merge mode %d", mode);
     launch_dr_advance(d_phi, d_w, d_merged, d_theta, gamma, mode == MAMDR_MERGE_PLUS ? 0 : 1, assign_model != 0, n,
                       (hipStream_t)stream);
@@ -1591,6 +1599,7 @@ int mamdr_dr_advance(float* d_phi, float* d_w, float* d_merged, const float* d_t
 int mamdr_sub(float* d_dst, const float* d_a, const float* d_b, int64_t n, void* stream) {
     CHECK_VEC(d_dst); CHECK_VEC(d_a); CHECK_VEC(d_b);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     launch_sub(d_dst, d_a, d_b, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
@@ -1600,6 +1609,7 @@ int mamdr_accumulate(float* d_acc, const float* d_a, const float* d_b, const flo
     CHECK_VEC(d_acc); CHECK_VEC(d_a); CHECK_VEC(d_b);
     if (d_shared && ((uintptr_t)d_shared & 15)) return fail(MAMDR_EINVAL, "d_shared is not 16-byte aligned");
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     if (divisor == 0.f) return fail(MAMDR_EINVAL, "divisor must be non-zero");
     launch_accumulate(d_acc, d_a, d_b, d_shared, divisor, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1608,6 +1618,7 @@ int mamdr_accumulate(float* d_acc, const float* d_a, const float* d_b, const flo
 int mamdr_apply_accumulated(float* d_dst, float* d_acc, float divisor, float scale, int64_t n, void* stream) {
     CHECK_VEC(d_dst); CHECK_VEC(d_acc);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     launch_apply_accumulated(d_dst, d_acc, divisor, scale, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
@@ -1616,6 +1627,7 @@ int mamdr_adam_apply(float* d_p, float* d_m, float* d_v, const float* d_g, float
                      float beta2, float eps, float beta1_power, float beta2_power, int64_t n, void* stream) {
     CHECK_VEC(d_p); CHECK_VEC(d_m); CHECK_VEC(d_v); CHECK_VEC(d_g);
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     const float alpha = lr * sqrtf(1.0f - beta2_power) / (1.0f - beta1_power);
     launch_adam_apply(d_p, d_m, d_v, d_g, grad_scale, alpha, 1.0f - beta1, 1.0f - beta2, eps, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1644,6 +1656,7 @@ int mamdr_pcgrad_project(float* d_final, float* d_aux, const int64_t* h_offsets,
 int mamdr_copy(float* d_dst, const float* d_src, int64_t n, void* stream) {
     if (!d_dst || !d_src) return fail(MAMDR_EINVAL, "null pointer");
     if (n < 0) return fail(MAMDR_EINVAL, "negative length");
+    if (n == 0) return MAMDR_OK;
     if (n == 0) return MAMDR_OK;
     HIP_TRY(hipMemcpyAsync(d_dst, d_src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MAMDR_OK;

@@ -69,6 +69,7 @@ class GraphEngine(FlatVectorOps):
         L.check(self.lib.mamdr_graph_bind_state(self.ctx, _ptr(self._weights), _ptr(self._adam_m), _ptr(self._adam_v)), graph=True)
         self.aux = None
         self.tables, self.data = {}, {}
+        self._acc, self._ema = None, None
         self._hist = torch.zeros(2 * 501, dtype=torch.int32, device=self.device)
         self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
 
@@ -89,10 +90,18 @@ class GraphEngine(FlatVectorOps):
     def weights(self):
         return self._weights
 
+    @property
+    def adam_m(self):
+        return self._adam_m
+
+    @property
+    def adam_v(self):
+        return self._adam_v
+
     def new_vector(self, like=None, meta=False):
         if like is not None:
             return like.clone()
-        return torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        return torch.zeros(self.n_meta if meta else self.n_params, dtype=torch.float32, device=self.device)
 
     def keras_name(self, segment):
         return segment
@@ -154,16 +163,41 @@ class GraphEngine(FlatVectorOps):
     # ------------------------------------------------------------ steps / evaluation
     def train_steps(self, domain, perm=None, first_step=0, n_steps=None, lr=1e-3, optimizer="adam", loss_out=None,
                     batch_size=None, pass_rows=None):
-        if pass_rows is not None:
-            raise NotImplementedError("windowed passes are a meta-learning feature; the multi-task towers have none")
+        """as TowerEngine.train_steps (same optimiser names, windows and moving-average accumulate passes)."""
         bs = batch_size or self.batch_size
-        n = self.n_rows(domain, "train")
+        n = self.n_rows(domain, "train") if pass_rows is None else int(pass_rows)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
-        opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD}[optimizer]
-        L.check(self.lib.mamdr_graph_train_steps(self.ctx, domain, _ptr(perm), first_step, n_steps, bs, self.dropout_seed, opt,
-                                                 float(lr), _ptr(loss_out)), graph=True)
+        opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD, "accumulate": L.OPT_ACCUMULATE}[optimizer]
+        rows = -1 if pass_rows is None else n
+        if optimizer == "accumulate" and self._ema is not None:       # average_meta_grad == "moving_mean" (maml.py:219-220)
+            ema = self._ema
+            if loss_out is not None:
+                raise ValueError("accumulate passes under average_meta_grad = moving_mean report no per-step loss")
+            for s in range(first_step, first_step + n_steps):
+                ema["scratch"].zero_()
+                L.check(self.lib.mamdr_graph_train_steps_n(self.ctx, domain, _ptr(perm), rows, s, 1, bs, self.dropout_seed, opt,
+                                                           float(lr), _ptr(None)), graph=True)
+                ema["step"] += 1
+                decay = np.float32(1.0 - ema["momentum"])
+                denom = np.float32(1.0) - np.power(np.float32(1.0) - decay, np.float32(ema["step"]), dtype=np.float32)
+                L.check(self.lib.mamdr_moving_average(_ptr(self._acc), _ptr(ema["biased"]), _ptr(ema["scratch"]),
+                                                      float(decay), float(denom), self._acc.numel(), self._s()))
+            return n_steps
+        L.check(self.lib.mamdr_graph_train_steps_n(self.ctx, domain, _ptr(perm), rows, first_step, n_steps, bs,
+                                                   self.dropout_seed, opt, float(lr), _ptr(loss_out)), graph=True)
         return n_steps
+
+    def bind_accumulator(self, acc):
+        """meta-gradient accumulator of the MAML / MLDG / PCGrad meta passes (maml.py:202)."""
+        self._acc = acc
+        L.check(self.lib.mamdr_graph_bind_accumulator(self.ctx, _ptr(acc if self._ema is None else self._ema["scratch"])),
+                graph=True)
+
+    def set_moving_average(self, momentum):
+        self._ema = {"momentum": float(momentum), "step": 0, "biased": self.new_vector(), "scratch": self.new_vector()}
+        if self._acc is not None:
+            self.bind_accumulator(self._acc)
 
     def evaluate(self, domain, split, want_preds=False):
         n = self.n_rows(domain, split)

@@ -145,6 +145,19 @@ class OracleNet(T.OracleModel):
         self.step += 1
         return loss
 
+    def accumulate_on_batch(self, acc, uid, pid, dom, label):
+        """the meta pass of first-order MAML / MLDG / PCGrad on these towers (maml.py:107-109,196-229): gradient of the
+        total loss at the current weights added to `acc`, learning phase 0 (dropout off), no update."""
+        fn = loss_and_grads_conv if self.conv else loss_and_grads
+        _, g, _ = fn(self.params, self.kind, uid, pid, dom, label, None, 0.0, self.emb_trainable, self.frozen_sumsq())
+        if getattr(self, "moving_average", None) is not None:
+            from . import outer
+            ma = self.moving_average
+            ma["step"] = outer.moving_average_update(acc, ma["biased"], T.flatten(g, self.names), ma["momentum"], ma["step"])
+        else:
+            acc += T.flatten(g, self.names)
+        self.step += 1
+
     def predict(self, uid, pid, dom):
         return (forward_conv if self.conv else forward)(self.params, self.kind, uid, pid, dom)[0]
 

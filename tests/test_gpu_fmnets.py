@@ -135,6 +135,43 @@ def test_eval_predictions_at_equal_weights():
 
 
 @pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
+@pytest.mark.parametrize("emb_trainable", [False, True])
+def test_accumulate_steps_match_oracle(kind, emb_trainable):
+    """MAMDR_OPT_ACCUMULATE on the generic-layer engine (the meta passes of MAML / MLDG / PCGrad, maml.py:107-109,196-229):
+    dropout off, weights and Adam slots bit-unchanged, the gradients of the steps ADDED to the bound accumulator; on a
+    window of the split (`mamdr_graph_train_steps_n`: the meta-train / meta-val sub-datasets, maml.py:300-330)."""
+    g, eng, model = make_problem(kind, emb_trainable=emb_trainable)
+    d = 1
+    c = g["data"]["train"][d]
+    n = c["uid"].shape[0]
+    window = min(n, 600)
+    perm = orng.shuffle_perm(n, 10000, seed=33)[:window].copy()
+    acc = eng.new_vector()
+    acc.fill_(0.25)                         # added to, not overwritten
+    eng.bind_accumulator(acc)
+    w0, m0, v0 = eng.weights.clone(), eng.adam_m.clone(), eng.adam_v.clone()
+    n_steps = eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), optimizer="accumulate", pass_rows=window)
+    assert n_steps == -(-window // 256)
+    assert torch.equal(eng.weights, w0) and torch.equal(eng.adam_m, m0) and torch.equal(eng.adam_v, v0)
+    acc_o = np.full(eng.n_params, 0.25, F32)
+    flat_names = list(eng.segments)
+    want = {}
+    tmp = np.zeros(sum(model.params[k].size for k in model.names), F32)
+    model.train_pass(c, perm, 256, accumulate_into=tmp)
+    off = 0
+    for k in model.names:
+        want[k] = tmp[off:off + model.params[k].size]
+        off += model.params[k].size
+    got = eng.unpack(acc)
+    for k in model.names:
+        gk = np.asarray(got[k], F32).ravel() - F32(0.25)
+        scale = max(float(np.abs(want[k]).max()), 1e-6)
+        np.testing.assert_allclose(gk, want[k], rtol=3e-4, atol=3e-4 * scale + 6e-8, err_msg=k)
+    assert flat_names == list(model.names)
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
 def test_domain_negotiation_auc_parity(kind):
     """the meta wrappers run on these towers too (deepctr.py's registry is orthogonal to run.py's wrappers): five
     Domain Negotiation epochs (domain_negotiation.py:49-88) on 4 domains, same order / shuffles / masks on both sides.

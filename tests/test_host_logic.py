@@ -587,12 +587,18 @@ def test_mtl_ple_levels_and_trainable_tables_are_named(tmp_path, monkeypatch):
         cli.build_model(cfg, ds, FakeGraphEngine)
 
 
-@pytest.mark.parametrize("name", ["nfm", "pnn", "nfm_meta_domain_negotiation"])
+@pytest.mark.parametrize("name", ["nfm", "pnn", "nfm_meta_domain_negotiation", "pnn_meta_maml", "nfm_meta_mldg", "pnn_pcgrad",
+                                  "nfm_meta_mamdr_finetune"])
 def test_nfm_pnn_run_entry(tmp_path, monkeypatch, name):
-    """deepctr NFM / PNN through run.py's entry (plain alternate training; Domain Negotiation on top: the outer updates
-    are the same flat-vector operations whatever the tower)."""
+    """deepctr NFM / PNN through run.py's entry (plain alternate training; the meta wrappers on top: the outer updates
+    are the same flat-vector operations whatever the tower, the accumulate passes of MAML / MLDG / PCGrad run the tower's
+    step in learning phase 0)."""
     patch_emb_dim(monkeypatch)
     cfg = tiny_config(tmp_path, name, epochs=2)
+    if "maml" in name or "mldg" in name or "pcgrad" in name:
+        cfg["train"]["meta_learning_rate"] = 0.003
+    if "mldg" in name:
+        cfg["train"].update(meta_split="meta-train/val", meta_split_ratio=0.8)
     avg_loss, avg_auc, dl, da = cli.main(cfg, FakeEngine)
     assert sorted(da) == [0, 1, 2] and np.isfinite(avg_loss) and 0.3 < avg_auc < 1.0
 
