@@ -119,9 +119,9 @@ def test_empty_split_and_bad_arguments_are_errors():
     with pytest.raises(L.MamdrError):
         eng.train_steps(0, batch_size=eng.batch_size + 16)      # beyond max_batch
     with pytest.raises(L.MamdrError):
-        eng.train_steps(0, batch_size=0)
-    with pytest.raises(L.MamdrError):
-        eng.train_steps(g["n_domain"])                  # no such domain
+        eng.train_steps(0, batch_size=-16)
+    with pytest.raises(L.MamdrError):                   # no such domain (through the C entry point: the binding has no columns for it)
+        L.check(eng.lib.mamdr_train_steps(eng.ctx, g["n_domain"], None, 0, 1, eng.batch_size, eng.dropout_seed, L.OPT_ADAM, 1e-3, None))
     with pytest.raises(ValueError):
         bad = data[("train", 0)]
         eng.bind_domain_data(0, "train", bad["uid"] + g["n_user"], bad["pid"], bad["domain"], bad["label"])   # ids beyond the table
