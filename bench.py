@@ -422,11 +422,13 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
                                    eng.device)
     loads = []
     host_prep_s = [0.0]
+    next_plan = [None]
+    prefetch = os.environ.get("MAMDR_BENCH_NO_PREFETCH", "0") in ("", "0")      # A/B switch
 
     def epoch():
         th0 = time.perf_counter()
         if wrapper == "dn":               # Domain Negotiation only (domain_negotiation.py:37-88)
-            p = planner.next_epoch(with_dr=False)
+            p = next_plan[0] if next_plan[0] is not None else planner.next_epoch(with_dr=False)
             owner = parallel.lpt_partition(steps_per_domain, world)
             local = [d for d in p["seq"] if owner[d] == rank]
             shuffles.prepare([(d, 0) for d in local])
@@ -435,11 +437,23 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
             parallel.dn_phase_sharded(eng, meta, theta, local, shuffles, batch, TRAIN["learning_rate"],
                                       TRAIN["meta_learning_rate"], tr, delta, zero)
             eng.set_weights(theta)
+            if prefetch:
+                th1 = time.perf_counter()
+                next_plan[0] = planner.next_epoch(with_dr=False)
+                shuffles.prefetch([(d, 0) for d in next_plan[0]["seq"] if owner[d] == rank])
+                host_prep_s[0] += time.perf_counter() - th1
             return tr, mplan.plan_steps(p, steps_per_domain)
-        p = planner.next_epoch()          # same seed on every rank -> same global plan
+        p = next_plan[0] if next_plan[0] is not None else planner.next_epoch()    # same seed on every rank -> same global plan
         host_prep_s[0] += time.perf_counter() - th0
         tr = balanced.epoch(p, shuffles.prepare, shuffles, batch, TRAIN["learning_rate"], TRAIN["meta_learning_rate"],
                             TRAIN["merged_method"])
+        # the NEXT epoch's plan is a function of the seed alone: its shuffles are drawn on a worker thread while the
+        # stream runs this epoch (plan.EpochShuffles.prefetch; the work stays inside the timed region, off the critical path)
+        if prefetch:
+            th1 = time.perf_counter()
+            next_plan[0] = planner.next_epoch()
+            shuffles.prefetch(balanced.local_passes(next_plan[0]))
+            host_prep_s[0] += time.perf_counter() - th1
         if balanced.last_load is not None:
             loads.append(balanced.last_load)
         return tr, mplan.plan_steps(p, steps_per_domain)
@@ -608,6 +622,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         rec["partition_speedup_bound"] = float(np.mean([sum(l) / max(l) for l in loads]))
     if cpu:
         rec["gpu_over_cpu"] = rec["value"] / cpu["value"]
+    shuffles.cancel()           # the prefetch of an epoch that will not run
     eng.close()
     return rec
 

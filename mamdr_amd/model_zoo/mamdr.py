@@ -52,13 +52,28 @@ class MAMDR(SpecificBase):
         if tc["merged_method"] not in ("plus", "times"):
             raise ValueError("merged_method must be 'plus' or 'times', not: {}".format(tc["merged_method"]))
         self.trace = []
+        # On the GPU the shuffles of a whole epoch are drawn by one C call and uploaded in one copy, and the NEXT epoch's
+        # are drawn on a worker thread while the stream runs this one (plan.EpochShuffles: the same stream of seeds in the
+        # same order as one draw per pass).  Only where nothing else draws from the shuffler between two epochs.
+        from ..plan import EpochShuffles
+        shuffles, next_plan = None, None
+        dev = getattr(self.model, "device", None)
+        if (dev is not None and getattr(dev, "type", "cpu") == "cuda" and self.shuffler.shuffle
+                and not tc["finetune_every_epoch"] and not tc.get("meta_finetune_step")
+                and getattr(self.shuffler.shuffle_fn, "__module__", "") == "mamdr_amd.engine"):
+            shuffles = EpochShuffles(self.shuffler, dev)
         for epoch in range(tc["epoch"]):
             print("Epoch: {}".format(epoch), "-" * 30)
-            plan = planner.next_epoch()
-            self.trace += self.balanced.epoch(plan, None, self.shuffler, self.batch_size, self.learning_rate,
-                                              tc["meta_learning_rate"], tc["merged_method"],
+            plan = next_plan if next_plan is not None else planner.next_epoch()
+            next_plan = None
+            self.trace += self.balanced.epoch(plan, shuffles.prepare if shuffles is not None else None,
+                                              shuffles if shuffles is not None else self.shuffler, self.batch_size,
+                                              self.learning_rate, tc["meta_learning_rate"], tc["merged_method"],
                                               tc["domain_regulation_step"], batch_variant, tc["sample_num"],
                                               bool(tc["finetune_every_epoch"]))
+            if shuffles is not None and epoch + 1 < tc["epoch"]:
+                next_plan = planner.next_epoch()
+                shuffles.prefetch(self.balanced.local_passes(next_plan, tc["domain_regulation_step"]))
             if plan["dr"]:                       # (meta_finetune_val: the model of the rank that ran the plan's last query)
                 self.live_src = self.balanced.owner(plan["dr"][-1][0])
             if epoch % tc["val_every_step"] == 0:
@@ -68,5 +83,7 @@ class MAMDR(SpecificBase):
                     break
                 print("Test Result: ")
                 self.val_and_test("test")
+        if shuffles is not None:
+            shuffles.cancel()               # a prefetched epoch that will not run gives its seeds back (the finetune stage draws next)
         self.balanced.sync_tail()
         self.balanced.sync_phis()           # every slot current on every rank once training is over

@@ -336,6 +336,28 @@ class BalancedMAMDR(object):
         """tensors outside theta / phi -> one model on every rank (before validation / checkpoints)."""
         self.tail.sync()
 
+    def _assign(self, plan, domain_regulation_step=0):
+        """this epoch's owners (a pure function of the plan, the same on every rank) and this rank's part of it."""
+        rank, ws = world()
+        if self.dn_mode == "replicated":    # DN is not dealt out: the DR queries alone are balanced
+            dr_owner, _, load = epoch_assignment({"seq": [], "dr": plan["dr"]}, self.steps, ws, domain_regulation_step)
+            dn_owner = {d: rank for d in plan["seq"]}
+            load = [l + sum(self.steps[d] for d in plan["seq"]) for l in load]
+        else:
+            dr_owner, dn_owner, load = epoch_assignment(plan, self.steps, ws, domain_regulation_step)
+        local = {"seq": [d for d in plan["seq"] if dn_owner[d] == rank],
+                 "dr": [(q, s) for (q, s) in plan["dr"] if dr_owner[q] == rank]}
+        return dr_owner, dn_owner, load, local
+
+    def local_passes(self, plan, domain_regulation_step=0):
+        """the passes `epoch(plan, ...)` will run on THIS rank, in execution order (what plan.EpochShuffles.prefetch wants
+        for the next epoch while the current one runs)."""
+        from . import plan as mplan
+        rank, ws = world()
+        if ws == 1:
+            return mplan.epoch_passes(plan, domain_regulation_step)
+        return mplan.epoch_passes(self._assign(plan, domain_regulation_step)[3], domain_regulation_step)
+
     def epoch(self, plan, perm_prepare, perm_fn, batch_size, lr, meta_lr, merged_method="plus",
               domain_regulation_step=0, batch_variant=False, sample_num=None, finetune_every_epoch=False):
         """perm_prepare(passes) (optional) is told this rank's passes in execution order before they run
@@ -355,15 +377,8 @@ class BalancedMAMDR(object):
                                     domain_regulation_step, batch_variant, sample_num, scratch=self.merged,
                                     finetune_every_epoch=finetune_every_epoch)
         replicated = self.dn_mode == "replicated"
-        if replicated:              # DN is not dealt out: the DR queries alone are balanced
-            dr_owner, _, load = epoch_assignment({"seq": [], "dr": plan["dr"]}, self.steps, ws, domain_regulation_step)
-            dn_owner = {d: rank for d in plan["seq"]}
-            load = [l + sum(self.steps[d] for d in plan["seq"]) for l in load]
-        else:
-            dr_owner, dn_owner, load = epoch_assignment(plan, self.steps, ws, domain_regulation_step)
+        dr_owner, dn_owner, load, local = self._assign(plan, domain_regulation_step)
         self.last_load = load
-        local = {"seq": [d for d in plan["seq"] if dn_owner[d] == rank],
-                 "dr": [(q, s) for (q, s) in plan["dr"] if dr_owner[q] == rank]}
         if perm_prepare is not None:
             perm_prepare(mplan.epoch_passes(local, domain_regulation_step))
         self.host_prep_s += time.perf_counter() - t_host

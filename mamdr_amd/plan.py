@@ -96,8 +96,9 @@ class EpochShuffles(object):
     """perm_fn for the meta loops that draws EVERY permutation of an epoch up front -- the same PassShuffler
     stream in the same order, so the passes see the same shuffles as with one upload per pass -- into one pinned
     staging buffer (one C call: mamdr_shuffle_perms) and uploads them in ONE copy; the passes then take device
-    slices.  Two staging / device buffers alternate so that the host may prepare epoch e + 1 while the stream
-    still runs epoch e."""
+    slices.  Two staging / device buffers alternate, and `prefetch(passes)` draws the NEXT epoch's permutations on a
+    worker thread while the caller enqueues / the stream runs the current one (the C call releases the GIL): on
+    Amazon-13 drawing an epoch's 39 K shuffles takes 0.3 s, ten times what the launch queue can hide."""
 
     def __init__(self, shuffler, device):
         import torch
@@ -109,16 +110,11 @@ class EpochShuffles(object):
         self.done = [None, None]
         self.k = 0
         self.queue = []
+        self.pending = None         # (passes, job, thread) of a prefetch in flight
 
-    def prepare(self, passes):
-        """passes: [(domain, max_steps)] in execution order (epoch_passes) for THIS rank."""
-        import ctypes as C
-        torch = self.torch
-        sh = self.sh
-        self.pos = 0
-        if not sh.shuffle:
-            self.queue = [(d, None) for d, _ in passes]
-            return
+    def _stage(self, passes):
+        """seeds (consumed from the shuffler's stream, in pass order) and the staging buffer of one epoch."""
+        torch, sh = self.torch, self.sh
         n = np.array([sh.sizes[d] for d, _ in passes], np.int64)
         seeds = np.empty(len(passes), np.uint64)
         for i in range(len(passes)):
@@ -133,10 +129,60 @@ class EpochShuffles(object):
             self.done[k] = None
         if self.done[k] is not None:
             self.done[k].synchronize()          # the previous upload from this staging buffer has been read
-        lib = _engine.L.load()
-        _engine.L.check(lib.mamdr_shuffle_perms(len(passes), n.ctypes.data_as(C.c_void_p), sh.buffer_size,
-                                                seeds.ctypes.data_as(C.c_void_p),
-                                                C.c_void_p(self.host[k].data_ptr())))
+        return {"k": k, "n": n, "seeds": seeds, "total": total, "error": None}
+
+    def _draw(self, job):
+        import ctypes as C
+        try:
+            lib = _engine.L.load()
+            _engine.L.check(lib.mamdr_shuffle_perms(len(job["n"]), job["n"].ctypes.data_as(C.c_void_p), self.sh.buffer_size,
+                                                    job["seeds"].ctypes.data_as(C.c_void_p),
+                                                    C.c_void_p(self.host[job["k"]].data_ptr())))
+        except Exception as e:      # surfaces in prepare(), on the caller's thread
+            job["error"] = e
+
+    def prefetch(self, passes):
+        """start drawing the permutations of the epoch whose passes these are; `prepare` of the SAME passes then only
+        uploads.  Nothing else may draw from the shuffler in between (the stream order is the pass order)."""
+        import threading
+        if not self.sh.shuffle:
+            return
+        self.cancel()
+        passes = list(passes)
+        job = self._stage(passes)
+        t = threading.Thread(target=self._draw, args=(job,))
+        t.start()
+        self.pending = (passes, job, t)
+
+    def cancel(self):
+        """drop a prefetch nobody asked for (training stopped early, another plan came): its seeds go back."""
+        if self.pending is not None:
+            passes, job, t = self.pending
+            t.join()
+            self.sh.counter -= len(passes)
+            self.k ^= 1
+            self.pending = None
+
+    def prepare(self, passes):
+        """passes: [(domain, max_steps)] in execution order (epoch_passes) for THIS rank."""
+        torch = self.torch
+        sh = self.sh
+        self.pos = 0
+        if not sh.shuffle:
+            self.queue = [(d, None) for d, _ in passes]
+            return
+        passes = list(passes)
+        if self.pending is not None and self.pending[0] == passes:
+            _, job, t = self.pending
+            self.pending = None
+            t.join()
+        else:
+            self.cancel()
+            job = self._stage(passes)
+            self._draw(job)
+        if job["error"] is not None:
+            raise job["error"]
+        k, n, total = job["k"], job["n"], job["total"]
         self.dev[k][:total].copy_(self.host[k][:total], non_blocking=True)
         self.done[k] = torch.cuda.Event()
         self.done[k].record(torch.cuda.current_stream(self.device))
