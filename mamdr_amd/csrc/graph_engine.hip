@@ -32,6 +32,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -146,12 +147,22 @@ struct GemmArgs {
     // MODE 2 only: blockIdx.z owns K rows [z K, (z + 1) K) of A and B and writes its partial product at C + z zstride
     size_t zstride;
 };
-template <int MODE>
-__global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
+constexpr int MAX_GROUP = 32;
+struct GroupTab {
+    int n, tiles_y;
+    int64_t a_off[MAX_GROUP], b_off[MAX_GROUP], c_off[MAX_GROUP];      // floats added to A / B / C
+    int64_t bias_off[MAX_GROUP];                                       // ... to bias (MODE 0) or to the bias gradient (finish)
+    int64_t gate_off[MAX_GROUP];                                       // ... to gate_y (MODE 1)
+    uint32_t drop_key[MAX_GROUP];
+};
+// KCAT (MODE 1 only): C = sum over the group's members of A_e . B_e^T -- ONE contraction whose reduction index runs through
+// every member (the first layers' d x, which adds up over the experts: d x = [dz_1 .. dz_E] . [W_1 .. W_E]^T)
+template <int MODE, bool KCAT = false>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const int by, const int bz, const GroupTab* tab = nullptr) {
     __shared__ __attribute__((aligned(16))) float As[2][GK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int m0 = by * GT, n0 = bx * GT;
     const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
     constexpr bool A_KC = MODE != 2;        // A's reduction index is the contiguous one in memory
     constexpr bool B_KC = MODE == 1;
@@ -161,12 +172,19 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
     const float *A = a.A, *B = a.B;
     float* C = a.C;
     if (MODE == 2) {
-        A += (size_t)blockIdx.z * a.K * a.lda;
-        B += (size_t)blockIdx.z * a.K * a.ldb;
-        C += (size_t)blockIdx.z * a.zstride;
+        A += (size_t)bz * a.K * a.lda;
+        B += (size_t)bz * a.K * a.ldb;
+        C += (size_t)bz * a.zstride;
     }
+    const int nk = a.K / GK;
     auto gload = [&](int kt) {
-        const int k0 = kt * GK;
+        int k0 = kt * GK;
+        if (KCAT) {
+            const int e = kt / nk;
+            k0 = (kt - e * nk) * GK;
+            A = a.A + tab->a_off[e];
+            B = a.B + tab->b_off[e];
+        }
         ra = A_KC ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r4) * a.lda + k0 + k4)
                   : *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + kr) * a.lda + m0 + c4);
         rb = B_KC ? *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + r4) * a.ldb + k0 + k4)
@@ -189,19 +207,19 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nk = a.K / GK;
+    const int nkt = KCAT ? nk * tab->n : nk;
     gload(0);
     lstore(0);
     __syncthreads();
     const int kk = lane >> 5, c = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nkt) gload(kt + 1);
         const float* ap = &As[buf][kk * GLD + wm + c];
         const float* bp = &Bs[buf][kk * GLD + wn + c];
 #pragma unroll
         for (int i = 0; i < GK / 2; ++i) acc = MAMDR_MFMA32(ap[2 * i * GLD], bp[2 * i * GLD], acc);
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nkt) lstore(buf ^ 1);
         __syncthreads();
     }
     // D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -225,6 +243,38 @@ __global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
         }
         C[(size_t)row * a.ldc + col] = v;
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_graph_gemm(const GemmArgs a) {
+    gemm_tile<MODE>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- the same contraction for a GROUP of problems of one shape in ONE launch: the experts a task mixes share their input
+// and their layer shapes (deep_mtl_ctr.py:31-49: num_experts / specific + shared experts, every one DNN(hidden_dim)), so a
+// layer of all of them is one grid -- 12 experts x 64 tiles instead of 12 launches of 64 workgroups on 256 CUs.
+// MODE 0 / 1: blockIdx.z = the problem; MODE 2: blockIdx.y = problem x row tile (blockIdx.z stays the split of the rows).
+__global__ __launch_bounds__(256) void k_graph_gemm_kcat(const GemmArgs a, const GroupTab t) {
+    gemm_tile<1, true>(a, blockIdx.x, blockIdx.y, 0, &t);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_graph_gemm_group(GemmArgs a, const GroupTab t) {
+    int gi, by = blockIdx.y, bz = blockIdx.z;
+    if (MODE == 2) {
+        gi = (int)blockIdx.y / t.tiles_y;
+        by = (int)blockIdx.y - gi * t.tiles_y;
+    } else {
+        gi = blockIdx.z;
+        bz = 0;
+    }
+    a.A += t.a_off[gi];
+    a.B += t.b_off[gi];
+    a.C += t.c_off[gi];
+    if (MODE == 0) {
+        a.bias += t.bias_off[gi];
+        a.drop_key = t.drop_key[gi];
+    }
+    if (MODE == 1 && a.gate_y) a.gate_y += t.gate_off[gi];
+    gemm_tile<MODE>(a, blockIdx.x, by, bz);
 }
 
 // db[n] = sum over the batch rows of dz[b][n]: 16 columns per workgroup, 16 row groups (8 loads in flight each) summed
@@ -295,6 +345,50 @@ __global__ __launch_bounds__(256) void k_graph_wfinish(const float* part, int n_
 #pragma unroll
         for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
         db[col] = t;
+    }
+}
+// the same for a group of weight gradients (blockIdx.y = the problem): partial products at part + (y n_split + z) stride,
+// outputs at out + c_off[y], bias column sums of dz + a_off[y] into db + bias_off[y]
+__global__ __launch_bounds__(256) void k_graph_wfinish_group(const float* part, int n_split, size_t stride, int64_t n4, float* out,
+                                                             int nb_red, const float* dz, int ld, int rows, float* db, int n_valid,
+                                                             const GroupTab t) {
+    const int gi = blockIdx.y;
+    if ((int)blockIdx.x < nb_red) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n4) return;
+        const float* p0 = part + (size_t)gi * n_split * stride;
+        f32x4 v0 = reinterpret_cast<const f32x4*>(p0)[i];
+        for (int z = 1; z < n_split; ++z) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(p0 + z * stride)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v0[k] += v[k];
+        }
+        reinterpret_cast<f32x4*>(out + t.c_off[gi])[i] = v0;
+        return;
+    }
+    __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
+    const int col = ((int)blockIdx.x - nb_red) * CS_COLS + c;
+    float s = 0.f;
+    if (col < n_valid) {
+        const float* p = dz + t.a_off[gi] + col;
+        int b = g;
+        for (; b + 7 * CS_GROUPS < rows; b += 8 * CS_GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(b + k * CS_GROUPS) * ld];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < rows; b += CS_GROUPS) s += p[(size_t)b * ld];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && col < n_valid) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_GROUPS; ++k) v += red[k][c];
+        db[t.bias_off[gi] + col] = v;
     }
 }
 static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, float* out, int n_valid) {
@@ -1016,6 +1110,7 @@ struct mamdr_graph {
     float *act = nullptr, *dact = nullptr, *grad = nullptr, *dlogit = nullptr, *rowloss = nullptr, *y = nullptr;
     float* wpart = nullptr;     // split-K partial products of one weight gradient (launch_wgrad)
     size_t wpart_floats = 0;
+    bool group_ok = true;       // MAMDR_GRAPH_NO_GROUP=1: one launch per expert and layer (A/B, parity of the grouped launches)
     int32_t* domrow = nullptr;
     float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
     // trainable tables
@@ -1167,6 +1262,148 @@ void dnn_backward(mamdr_graph* g, const Dnn& d, const std::vector<int>& cols, in
     }
 }
 
+// ---- a group of DNNs of ONE shape on ONE input (the experts a task mixes), layer by layer in single launches
+bool same_shape(const mamdr_graph* g, const std::vector<int>& ids) {
+    if (ids.size() < 2 || ids.size() > (size_t)MAX_GROUP) return false;
+    const Dnn& d0 = g->dnns[ids[0]];
+    for (int id : ids) {
+        const Dnn& d = g->dnns[id];
+        if (d.in_dim != d0.in_dim || d.layers.size() != d0.layers.size()) return false;
+        for (size_t l = 0; l < d.layers.size(); ++l)
+            if (d.layers[l].in != d0.layers[l].in || d.layers[l].out != d0.layers[l].out) return false;
+    }
+    return true;
+}
+void dnn_forward_group(mamdr_graph* g, const std::vector<int>& ids, const std::vector<std::vector<int>>& cols, int in_col,
+                       const StepCtx& sc) {
+    const Dnn& d0 = g->dnns[ids[0]];
+    const int n = (int)ids.size();
+    for (size_t l = 0; l < d0.layers.size(); ++l) {
+        const Layer& L0 = d0.layers[l];
+        GemmArgs a;
+        memset(&a, 0, sizeof(a));
+        GroupTab t;
+        memset(&t, 0, sizeof(t));
+        t.n = n;
+        a.A = g->act;
+        a.lda = g->ld;
+        a.B = g->params;
+        a.ldb = L0.out;
+        a.C = g->act;
+        a.ldc = g->ld;
+        a.K = L0.in;
+        a.bias = g->params;
+        a.relu = 1;
+        a.use_dropout = sc.use_dropout ? 1 : 0;
+        a.drop_thresh = sc.drop_thresh;
+        a.keep_scale = sc.keep_scale;
+        a.n_cols = L0.out;
+        for (int e = 0; e < n; ++e) {
+            const Layer& L = g->dnns[ids[e]].layers[l];
+            t.a_off[e] = l == 0 ? in_col : cols[e][l - 1];
+            t.b_off[e] = L.w_off;
+            t.c_off[e] = cols[e][l];
+            t.bias_off[e] = L.b_off;
+            t.drop_key[e] = dropout_layer_key(sc.seed, sc.step, L.id);
+        }
+        hipLaunchKernelGGL(k_graph_gemm_group<0>, dim3(L0.out / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+    }
+}
+// backward of the group (every member's last-layer d z sits in the gradient workspace): weight / bias gradients and the
+// inner layers' d inputs in grouped launches; the FIRST layers' d x adds up over the members and stays one launch each
+void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::vector<std::vector<int>>& cols, int in_col,
+                        bool din_acc, int din_first, int din_n, const StepCtx& sc) {
+    const Dnn& d0 = g->dnns[ids[0]];
+    const int n = (int)ids.size();
+    for (int l = (int)d0.layers.size() - 1; l >= 0; --l) {
+        const Layer& L0 = d0.layers[l];
+        const int M = L0.in, N = L0.out;
+        {   // dW_e = in_e^T dz_e, db_e = column sums of dz_e
+            const int tiles = (M / GT) * (N / GT), nkt = sc.rp / GK;
+            int split = 1;
+            while (split < 16 && tiles * n * split < 256 && nkt % (2 * split) == 0 && nkt / (2 * split) >= 4 &&
+                   (size_t)(2 * split) * n * M * N <= g->wpart_floats)
+                split *= 2;
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            GroupTab t, f;
+            memset(&t, 0, sizeof(t));
+            memset(&f, 0, sizeof(f));
+            t.n = f.n = n;
+            t.tiles_y = M / GT;
+            a.A = g->act;
+            a.lda = g->ld;
+            a.B = g->dact;
+            a.ldb = g->ld;
+            a.C = split > 1 ? g->wpart : g->grad;
+            a.ldc = N;
+            a.K = sc.rp / split;
+            a.zstride = (size_t)M * N;
+            for (int e = 0; e < n; ++e) {
+                const Layer& L = g->dnns[ids[e]].layers[l];
+                t.a_off[e] = l == 0 ? in_col : cols[e][l - 1];
+                t.b_off[e] = cols[e][l];
+                t.c_off[e] = split > 1 ? (int64_t)e * split * M * N : L.w_off - g->table_floats;
+                f.a_off[e] = cols[e][l];
+                f.c_off[e] = L.w_off - g->table_floats;
+                f.bias_off[e] = L.b_off - g->table_floats;
+            }
+            hipLaunchKernelGGL(k_graph_gemm_group<2>, dim3(N / GT, (M / GT) * n, split), dim3(256), 0, g->stream, a, t);
+            const int64_t n4 = (int64_t)M * N / 4;
+            const int nb_red = split > 1 ? (int)((n4 + 255) / 256) : 0, nb_cs = (N + CS_COLS - 1) / CS_COLS;
+            hipLaunchKernelGGL(k_graph_wfinish_group, dim3(nb_red + nb_cs, n), dim3(256), 0, g->stream, g->wpart, split,
+                               a.zstride, n4, g->grad, nb_red, g->dact, g->ld, sc.rp, g->grad, N, f);
+        }
+        if (l > 0) {    // d in_e = dz_e W_e^T through the producer's relu / dropout gate
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            GroupTab t;
+            memset(&t, 0, sizeof(t));
+            t.n = n;
+            a.A = g->dact;
+            a.lda = g->ld;
+            a.B = g->params;
+            a.ldb = N;
+            a.C = g->dact;
+            a.ldc = g->ld;
+            a.K = N;
+            a.gate_scale = sc.keep_scale;
+            a.gate_y = g->act;
+            a.gate_ld = g->ld;
+            for (int e = 0; e < n; ++e) {
+                const Layer& L = g->dnns[ids[e]].layers[l];
+                t.a_off[e] = cols[e][l];
+                t.b_off[e] = L.w_off;
+                t.c_off[e] = cols[e][l - 1];
+                t.gate_off[e] = cols[e][l - 1];
+            }
+            hipLaunchKernelGGL(k_graph_gemm_group<1>, dim3(M / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+        } else {
+            // d x = sum_e dz_e W_e[first : first + nn]^T: one contraction through all members
+            const int first = din_n > 0 ? din_first : 0, nn = din_n > 0 ? din_n : M;
+            GemmArgs a;
+            memset(&a, 0, sizeof(a));
+            GroupTab t;
+            memset(&t, 0, sizeof(t));
+            t.n = n;
+            a.A = g->dact;
+            a.lda = g->ld;
+            a.K = N;
+            a.gate_scale = sc.keep_scale;
+            a.B = g->params + (size_t)first * N;
+            a.ldb = N;
+            a.C = g->dact + in_col + first;
+            a.ldc = g->ld;
+            a.accumulate = din_acc ? 1 : 0;
+            for (int e = 0; e < n; ++e) {
+                t.a_off[e] = cols[e][0];
+                t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
+            }
+            hipLaunchKernelGGL(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
+        }
+    }
+}
+
 void fill_gate(const mamdr_graph* g, const Task& t, const StepCtx& sc, GateArgs& ga) {
     memset(&ga, 0, sizeof(ga));
     ga.act = g->act;
@@ -1259,7 +1496,12 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
         dnn_forward(g, g->dnns[t.tower], t.col[0], nfm ? g->f_col : 0, sc, nfm ? -1 : g->f_col);
         return t.col[0].back();
     }
-    for (size_t e = 0; e < t.mix.size(); ++e) dnn_forward(g, g->dnns[t.mix[e]], t.col[e], 0, sc);
+    if (g->group_ok && same_shape(g, t.mix)) {
+        std::vector<std::vector<int>> mc(t.col.begin(), t.col.begin() + t.mix.size());
+        dnn_forward_group(g, t.mix, mc, 0, sc);
+    } else {
+        for (size_t e = 0; e < t.mix.size(); ++e) dnn_forward(g, g->dnns[t.mix[e]], t.col[e], 0, sc);
+    }
     int tower_in;
     if (g->gated) {
         const size_t gi = t.mix.size();
@@ -1379,6 +1621,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (!g) return gfail(MAMDR_EHIP, "out of host memory");
     g->cfg = *cfg;
     g->stream = (hipStream_t)stream;
+    if (const char* ev = getenv("MAMDR_GRAPH_NO_GROUP")) g->group_ok = atoi(ev) == 0;
     g->gated = gated;
     g->single = single;
     g->has_lin = has_lin;
@@ -1855,9 +2098,15 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                                g->ld, g->dact + t.g_col, g->ld, sc.rp, gta.n_q, gta.n_e, g->G(t.wg_off));
             dnn_backward(g, gd, t.col[gi], 0, 0, -1, dx_started, dx_first, dx_n, sc);
             dx_started = true;
-            for (size_t e = 0; e < t.mix.size(); ++e) {
-                dnn_backward(g, g->dnns[t.mix[e]], t.col[e], 0, 0, -1, dx_started, dx_first, dx_n, sc);
+            if (g->group_ok && same_shape(g, t.mix)) {
+                std::vector<std::vector<int>> mc(t.col.begin(), t.col.begin() + t.mix.size());
+                dnn_backward_group(g, t.mix, mc, 0, dx_started, dx_first, dx_n, sc);
                 dx_started = true;
+            } else {
+                for (size_t e = 0; e < t.mix.size(); ++e) {
+                    dnn_backward(g, g->dnns[t.mix[e]], t.col[e], 0, 0, -1, dx_started, dx_first, dx_n, sc);
+                    dx_started = true;
+                }
             }
         } else {
             // the tower's input IS the bottom's output: its gradient passes through the bottom's last relu / dropout gate
