@@ -391,6 +391,26 @@ __global__ __launch_bounds__(256) void k_graph_wfinish_group(const float* part, 
         db[t.bias_off[gi] + col] = v;
     }
 }
+// d x of a group's first layers: out[b][c] (+)= sum over the members of part[e][b][c], in member order
+__global__ __launch_bounds__(256) void k_graph_dx_reduce(const float* part, int n_part, size_t stride, int rows, int n4_row,
+                                                         float* out, int ld, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * n4_row) return;
+    const int b = (int)(i / n4_row), c4 = (int)(i - (int64_t)b * n4_row);
+    f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+    for (int e = 1; e < n_part; ++e) {
+        const f32x4 w = reinterpret_cast<const f32x4*>(part + e * stride)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += w[k];
+    }
+    float* o = out + (size_t)b * ld + 4 * c4;
+    if (accumulate) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = w[k] + v[k];
+    }
+    *reinterpret_cast<f32x4*>(o) = v;
+}
 static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, float* out, int n_valid) {
     hipLaunchKernelGGL(k_graph_colsum, dim3((n_valid + CS_COLS - 1) / CS_COLS), dim3(256), 0, s, dz, ld, rows, out, n_valid);
 }
@@ -1110,6 +1130,8 @@ struct mamdr_graph {
     float *act = nullptr, *dact = nullptr, *grad = nullptr, *dlogit = nullptr, *rowloss = nullptr, *y = nullptr;
     float* wpart = nullptr;     // split-K partial products of one weight gradient (launch_wgrad)
     size_t wpart_floats = 0;
+    float* dxpart = nullptr;    // the members' products of a group's first-layer d x (dnn_backward_group)
+    size_t dxpart_floats = 0;
     bool group_ok = true;       // MAMDR_GRAPH_NO_GROUP=1: one launch per expert and layer (A/B, parity of the grouped launches)
     int32_t* domrow = nullptr;
     float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
@@ -1379,7 +1401,7 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
             }
             hipLaunchKernelGGL(k_graph_gemm_group<1>, dim3(M / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
         } else {
-            // d x = sum_e dz_e W_e[first : first + nn]^T: one contraction through all members
+            // d x = sum_e dz_e W_e[first : first + nn]^T
             const int first = din_n > 0 ? din_first : 0, nn = din_n > 0 ? din_n : M;
             GemmArgs a;
             memset(&a, 0, sizeof(a));
@@ -1392,14 +1414,30 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
             a.gate_scale = sc.keep_scale;
             a.B = g->params + (size_t)first * N;
             a.ldb = N;
-            a.C = g->dact + in_col + first;
-            a.ldc = g->ld;
-            a.accumulate = din_acc ? 1 : 0;
-            for (int e = 0; e < n; ++e) {
-                t.a_off[e] = cols[e][0];
-                t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
+            const size_t stride = (size_t)sc.rp * nn;
+            if ((size_t)n * stride <= g->dxpart_floats) {
+                // every member's product as a launch-mate of the others (n x the tiles), summed in member order
+                a.C = g->dxpart;
+                a.ldc = nn;
+                for (int e = 0; e < n; ++e) {
+                    t.a_off[e] = cols[e][0];
+                    t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
+                    t.c_off[e] = (int64_t)e * stride;
+                }
+                hipLaunchKernelGGL(k_graph_gemm_group<1>, dim3(nn / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+                const int64_t tot = (int64_t)sc.rp * (nn / 4);
+                hipLaunchKernelGGL(k_graph_dx_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g->stream, g->dxpart, n,
+                                   stride, sc.rp, nn / 4, g->dact + in_col + first, g->ld, din_acc ? 1 : 0);
+            } else {    // one contraction whose reduction index runs through all members
+                a.C = g->dact + in_col + first;
+                a.ldc = g->ld;
+                a.accumulate = din_acc ? 1 : 0;
+                for (int e = 0; e < n; ++e) {
+                    t.a_off[e] = cols[e][0];
+                    t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
+                }
+                hipLaunchKernelGGL(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
             }
-            hipLaunchKernelGGL(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
         }
     }
 }
@@ -1756,6 +1794,12 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         for (const Layer& L : d.layers) max_w = std::max(max_w, (size_t)L.in * L.out);
     g->wpart_floats = 16 * max_w;
     alloc((void**)&g->wpart, g->wpart_floats * sizeof(float));
+    size_t max_mix = 0;
+    for (const Task& t : g->tasks) max_mix = std::max(max_mix, t.mix.size());
+    if (g->gated && g->group_ok && max_mix > 1) {
+        g->dxpart_floats = max_mix * rp * (size_t)(g->tables ? XDIM : EMB);
+        alloc((void**)&g->dxpart, g->dxpart_floats * sizeof(float));
+    }
     if (g->tables) {
         alloc((void**)&g->urow, rp * sizeof(int32_t));
         alloc((void**)&g->irow, rp * sizeof(int32_t));
@@ -1818,7 +1862,7 @@ int mamdr_graph_destroy(mamdr_graph* g) {
     (void)hipStreamSynchronize(g->stream);
     void* ptrs[] = {g->act, g->dact, g->grad, g->dlogit, g->rowloss, g->y, g->domrow, g->thresholds, g->frozen_sumsq,
                     g->sumsq_partials, g->eval_acc, g->urow, g->irow, g->map_u, g->map_i, g->hasdup_u, g->hasdup_i,
-                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i, g->xt, g->dxt, g->wpart,
+                    g->gbuf_u, g->gbuf_i, g->extra, g->glin_u, g->glin_i, g->xt, g->dxt, g->wpart, g->dxpart,
                     g->attP[0], g->attP[1], g->attP[2], g->attdP[0], g->attdP[1], g->attdP[2], g->attA[0], g->attA[1], g->attA[2],
                     g->attY[0], g->attY[1], g->attY[2], g->attdY[0], g->attdY[1], g->attdY[2]};
     for (void* p : ptrs)

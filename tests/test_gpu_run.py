@@ -156,6 +156,28 @@ def test_epoch_shuffles_equal_per_pass_shuffles():
     with pytest.raises(RuntimeError):
         es.prepare(passes)
         es(0)                                    # the epoch's first pass is over domain 2
+    # prefetch: the next epoch's permutations drawn on a worker thread -- the same stream of seeds; a prefetch nobody
+    # collects (another plan came, training stopped) gives its seeds back
+    a = mplan.PassShuffler(sizes, 10000, 17)
+    es = mplan.EpochShuffles(mplan.PassShuffler(sizes, 10000, 17), torch.device("cuda", 0))
+    other = [(1, 0), (3, 0)]
+    es.prepare(passes)
+    for ep in range(4):
+        nxt = other if ep == 1 else passes
+        perms = [es(d).clone() for d, _ in (other if ep == 2 else passes)]       # epoch ep runs ...
+        es.prefetch(nxt)                                                          # ... while ep + 1 is drawn
+        for (d, _), got in zip(other if ep == 2 else passes, perms):
+            assert np.array_equal(got.cpu().numpy(), a(d))
+        if ep == 0:
+            es.cancel()                          # seeds returned: the same epoch can be staged again
+            es.prefetch(nxt)
+        es.prepare(nxt)
+    for d, _ in passes:                          # the epoch the loop's last round staged
+        assert np.array_equal(es(d).cpu().numpy(), a(d))
+    es.prefetch(passes)
+    es.prepare(other)                            # a different plan than the one prefetched: redrawn from the returned seeds
+    for d, _ in other:
+        assert np.array_equal(es(d).cpu().numpy(), a(d))
 
 
 @pytest.mark.parametrize("name", ["mlp_meta_domain_negotiation_finetune", "mlp_meta_mamdr_finetune"])

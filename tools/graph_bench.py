@@ -1,7 +1,7 @@
 """Throughput of the generic-layer engine (csrc/graph_engine.hip) on the reference's Taobao-10 multi-task configurations
 and on the deepctr single-output towers it hosts: domain-steps/s of the alternate training loop (deep_mtl_ctr.py:69-96 /
 deepctr.py:63-93: one full pass per domain per epoch), synthetic Taobao-10 logs, batch 1024, inputs resident in HBM.
-usage: python tools/graph_bench.py [epochs]    -> one JSON line per tower"""
+usage: python tools/graph_bench.py [epochs [tower,tower...]]    -> one JSON line per tower"""
 import json
 import os
 import sys
@@ -16,6 +16,7 @@ from mamdr_amd.plan import PassShuffler  # noqa: E402
 from mamdr_amd.utils import MultiDomainDataset  # noqa: E402
 
 EPOCHS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,6 +31,8 @@ def flops_per_row(model):
 
 
 for cfg_name in ("shared_bottom", "mmoe", "ple", "nfm", "pnn", "ccpm", "autoint"):
+    if ONLY is not None and cfg_name not in ONLY:
+        continue
     path = os.path.join(ROOT, "config", "Taobao-10", cfg_name + ".json")
     if os.path.exists(path):
         cfg = json.load(open(path))
