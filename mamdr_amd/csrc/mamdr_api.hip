@@ -124,6 +124,7 @@ struct mamdr_ctx {
     int32_t* pdom = nullptr;
     float* plabel = nullptr;
     int64_t pre_cap = 0;
+    bool gather_pf = true;          // MAMDR_NO_GATHER_PF=1: no riders in k_update's launch touching the next step's gather
     bool use_pre = true;            // MAMDR_NO_PREGATHER=1: the towers gather through perm / uid / pid every step
     float* dmsnap[2] = {nullptr, nullptr};
     int dm_cur = 0;
@@ -804,6 +805,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (const char* ev = getenv("MAMDR_STAR_PNB_FUSED")) c->star_pn_fused = atoi(ev) != 0 && c->star_pn_in_tower;
     if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
+    if (const char* ev = getenv("MAMDR_NO_GATHER_PF")) c->gather_pf = atoi(ev) == 0;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
@@ -1448,7 +1450,33 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
                     c->tables_dirty = true;
                 }
             } else {
-                launch_update(ua, c->stream);
+                // frozen tables, another step of this call follows on the 16-row tower: its gather is touched by riders
+                // (GatherPf, mamdr_kernels.h)
+                GatherPf pf;
+                memset(&pf, 0, sizeof(pf));
+                if (c->gather_pf && !c->cfg.emb_trainable && !c->star && s + 1 < n_steps) {
+                    const int64_t nb = row_base + batch;
+                    const int nrows = (int)std::min<int64_t>(batch, pass_rows - nb);
+                    const int npad = (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+                    const bool next4 = may_use4 && (c->tower_tile == 4 || npad <= c->tower4_max_rows);
+                    if (nrows > 0 && !next4) {
+                        pf.perm = d_perm;
+                        pf.uid = d->uid;
+                        pf.pid = d->pid;
+                        pf.dom = d->dom;
+                        pf.label = d->label;
+                        pf.user_tab = c->user_tab;
+                        pf.item_tab = c->item_tab;
+                        pf.row_base = nb;
+                        pf.n_rows_split = d->n;
+                        pf.rows = nrows;
+                        pf.n_user = c->cfg.n_user;
+                        pf.n_item = c->cfg.n_item;
+                        pf.n_tiles = npad / TILE_ROWS;
+                        pf.sink = c->loss_part;
+                    }
+                }
+                launch_update(ua, c->stream, &pf);
             }
         }
         if (c->cfg.emb_trainable && !tail) emb_post_step(c, optimizer, ua.alpha, omb1, omb2, rows);

@@ -577,7 +577,20 @@ struct EvalFinishArgs {
 };
 void launch_eval_finish(const EvalFinishArgs& a, hipStream_t s);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-void launch_update(const UpdateArgs& a, hipStream_t s);
+// the NEXT step's gather, touched ahead of time by rider workgroups in k_update's launch.  What one kernel leaves in an
+// XCD's L2 survives the kernel boundary (tools/probes/l2_survive_probe.hip: 240 cycles for a line the same workgroup id
+// touched in the kernel before, 1,400 cold, 600 when another XCD touched it), and workgroup b of any 1-d grid runs on XCD
+// b mod 8: rider b' = tile (mod 8) walks tile's dependent chain perm -> uid / pid / domain / label -> table rows, so the
+// tower's three dependent misses per step become three L2 hits.
+struct GatherPf {
+    const int32_t *perm, *uid, *pid, *dom;
+    const float* label;
+    const float *user_tab, *item_tab;
+    int64_t row_base, n_rows_split;
+    int rows, n_user, n_item, n_tiles;     // n_tiles = 0: no rider
+    float* sink;
+};
+void launch_update(const UpdateArgs& a, hipStream_t s, const GatherPf* pf = nullptr);
 void launch_gather(const TowerArgs& a, float* out, hipStream_t s);
 void launch_sumsq(const float* x, int64_t n, float* partials /*>=1024 floats*/, float* out, hipStream_t s);
 

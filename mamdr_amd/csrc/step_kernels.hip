@@ -1417,6 +1417,30 @@ __global__ __launch_bounds__(256) void k_update(UPDATE_EARLY_PARAMS, const Updat
     UPDATE_EARLY_APPLY(u, u0);
     update_body(u, (int)blockIdx.x, s_l);
 }
+// rider workgroup rb (4 waves = 4 tiles of the next step's tower, all = rb mod 8): see GatherPf
+__device__ __forceinline__ void gather_prefetch_body(const GatherPf& p, const int rb) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = (rb & 7) + 8 * (4 * (rb >> 3) + w);
+    if (tile >= p.n_tiles) return;
+    const int r = lane & (TILE_ROWS - 1), part = lane >> 4;       // 16 rows x (user | item) x two 256-B halves
+    const int rr = min(tile * TILE_ROWS + r, max(p.rows - 1, 0));
+    int64_t src = p.row_base + rr;
+    if (p.perm) src = p.perm[src];
+    src = src < 0 ? 0 : (src >= p.n_rows_split ? p.n_rows_split - 1 : src);
+    const int u = clampi(p.uid[src], 0, p.n_user - 1), it = clampi(p.pid[src], 0, p.n_item - 1);
+    const float t0 = (float)p.dom[src] + p.label[src];
+    const float* base = (part < 2 ? p.user_tab + (size_t)u * EMB : p.item_tab + (size_t)it * EMB) + (part & 1) * (EMB / 2);
+    const float t1 = base[0] + base[32];                          // one word per 128-B line
+    if (t0 + t1 == 1.2345678e30f) p.sink[0] = t1;                 // (keeps the loads)
+}
+__global__ __launch_bounds__(256) void k_update_pf(UPDATE_EARLY_PARAMS, const UpdateArgs u0, const GatherPf pf, const int n_update,
+                                                   const int n_pad) {
+    __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
+    UPDATE_EARLY_APPLY(u, u0);
+    const int bid = (int)blockIdx.x;
+    if (bid < n_update) update_body(u, bid, s_l);
+    else if (bid >= n_pad) gather_prefetch_body(pf, bid - n_pad);
+}
 // k_update and DeepFM's k_lin_sweep touch disjoint state: one launch
 // ... and so does the NEXT step's k_emb_catchup (n_cu workgroups per table; its rows were resolved in the previous
 // launch, k_wgrad_reduce): the rows of the next batch are brought up to this step while the dense block steps
@@ -1433,8 +1457,15 @@ static int update_blocks(const UpdateArgs& a) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
     return n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0);
 }
-void launch_update(const UpdateArgs& a, hipStream_t s) {
-    MAMDR_LAUNCH(k_update, dim3(update_blocks(a)), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a);
+void launch_update(const UpdateArgs& a, hipStream_t s, const GatherPf* pf) {
+    const int n_update = update_blocks(a);
+    if (pf && pf->n_tiles > 0) {
+        // riders behind the update's workgroups, at block ids that are = their tiles mod 8 (the XCD of block b is b mod 8)
+        const int n_pad = (n_update + 7) / 8 * 8, n_riders = ((pf->n_tiles + 7) / 8 + 3) / 4 * 8;
+        MAMDR_LAUNCH(k_update_pf, dim3(n_pad + n_riders), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a, *pf, n_update, n_pad);
+        return;
+    }
+    MAMDR_LAUNCH(k_update, dim3(n_update), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a);
 }
 void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s) {
     const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
