@@ -15,13 +15,21 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int WG = 256, SLICE_F4 = 256, REPS = 40;
+constexpr int WG = 256, SLICE_F4 = 256, REPS = 20;
 
-__global__ __launch_bounds__(256) void k_touch(const f32x4* buf, int mode, float* sink) {
+__global__ __launch_bounds__(256) void k_touch(f32x4* buf, int mode, float* sink) {
     if (mode == 0) return;                                      // cold: nobody touches
-    const int b = mode == 1 ? blockIdx.x : (blockIdx.x + 1) % WG;     // 1: my own slice, 2: my neighbour's (another XCD)
-    const f32x4 v = buf[(size_t)b * SLICE_F4 + threadIdx.x];
-    if (v[0] == 12345.f) sink[0] = v[1];                        // keep the load
+    const int b = (mode == 1 || mode == 3 || mode == 5) ? blockIdx.x : (blockIdx.x + 1) % WG;   // own slice / the neighbour's (another XCD)
+    f32x4* p = buf + (size_t)b * SLICE_F4 + threadIdx.x;
+    if (mode <= 2) {
+        const f32x4 v = *p;
+        if (v[0] == 12345.f) sink[0] = v[1];                    // keep the load
+    } else if (mode <= 4) {                                     // 3 / 4: WRITTEN with write-through stores (what the step kernels' workspace stores are)
+        const f32x4 v = (f32x4){1.f, 2.f, 3.f, (float)b};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {                                                    // 5 / 6: plain (write-back) stores
+        *p = (f32x4){1.f, 2.f, 3.f, (float)b};
+    }
 }
 __global__ __launch_bounds__(256) void k_timed(const f32x4* buf, unsigned long long* cycles, float* sink) {
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -40,8 +48,8 @@ int main() {
     unsigned long long* cyc;
     float *sink, *scratch;
     const size_t per_rep = (size_t)WG * SLICE_F4;
-    hipMalloc(&buf, per_rep * REPS * 3 * 2 * sizeof(f32x4));
-    hipMemset(buf, 0, per_rep * REPS * 3 * 2 * sizeof(f32x4));
+    hipMalloc(&buf, per_rep * REPS * 7 * 2 * sizeof(f32x4));
+    hipMemset(buf, 0, per_rep * REPS * 7 * 2 * sizeof(f32x4));
     hipMalloc(&cyc, WG * sizeof(unsigned long long));
     hipMalloc(&sink, 16);
     hipMalloc(&scratch, WG * 256 * sizeof(float));
@@ -52,14 +60,16 @@ int main() {
     hipMalloc(&flush, (size_t)256 << 20);
     hipMemset(flush, 0, (size_t)256 << 20);
     hipDeviceSynchronize();
-    const char* names[3] = {"cold (nobody touched the slice)", "touched by the SAME workgroup id in the kernel before",
-                            "touched by workgroup id + 1 (another XCD) in the kernel before"};
+    const char* names[7] = {"cold (nobody touched the slice)", "read by the SAME workgroup id in the kernel before",
+                            "read by workgroup id + 1 (another XCD) in the kernel before",
+                            "WRITTEN (sc1 write-through) by the same workgroup id", "WRITTEN (sc1 write-through) by workgroup id + 1",
+                            "WRITTEN (plain stores) by the same workgroup id", "WRITTEN (plain stores) by workgroup id + 1"};
     for (int between = 0; between < 2; ++between) {
         printf(between ? "-- with another kernel between the two (touch, k_other, timed)\n" : "-- back to back (touch, timed)\n");
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             std::vector<unsigned long long> med;
             for (int r = 0; r < REPS; ++r) {
-                const f32x4* p = buf + ((size_t)(between * 3 + mode) * REPS + r) * per_rep;
+                f32x4* p = buf + ((size_t)(between * 7 + mode) * REPS + r) * per_rep;
                 hipLaunchKernelGGL(k_touch, dim3(WG), dim3(256), 0, 0, p, mode, sink);
                 if (between) hipLaunchKernelGGL(k_other, dim3(WG), dim3(256), 0, 0, scratch);
                 hipLaunchKernelGGL(k_timed, dim3(WG), dim3(256), 0, 0, p, cyc, sink);
