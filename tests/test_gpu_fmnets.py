@@ -185,7 +185,8 @@ def test_domain_negotiation_auc_parity(kind):
     argmax over the fields behind every unit), the shift of one domain under one perturbation is itself a noisy sample of
     that scale, and a bar tighter than the reference arithmetic's own reproducibility would test luck.  One-step
     gradients, Adam passes and evaluation (above) are what pins the arithmetic; the mean over the domains is held to the
-    same bar without the factor two."""
+    same bar without the factor two.  After the FIRST epoch -- before the amplification -- every domain is held to the plain
+    1e-3."""
     from mamdr_amd import meta
     g, eng, model = make_problem(kind, scale=0.15)
     D = 4
@@ -208,22 +209,35 @@ def test_domain_negotiation_auc_parity(kind):
                              dropout_seed=eng.dropout_seed)
         theta = theta_start.copy()
         pf, traces = make_perm_fn(), []
+
+        def val_aucs():
+            twin.set_flat(theta)
+            out = []
+            for d in range(D):
+                _, preds = twin.evaluate(g["data"]["val"][d], 256)
+                out.append(float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256)))
+            return out
+        first = None
         for seq in seqs:
             traces += oloops.dn_epoch(twin, theta, g["data"]["train"], seq, pf, 256, 0.5)
-        twin.set_flat(theta)
-        aucs = []
-        for d in range(D):
-            _, preds = twin.evaluate(g["data"]["val"][d], 256)
-            aucs.append(float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256)))
-        return aucs, traces
-    auc_o, tr_o = oracle_run(theta0)
-    auc_p, _ = oracle_run((theta0 * F32(1 + 2e-7)).astype(F32))
-    auc_m, _ = oracle_run((theta0 * F32(1 - 2e-7)).astype(F32))
+            if first is None:
+                first = val_aucs()
+        return val_aucs(), traces, first
+    auc_o, tr_o, first_o = oracle_run(theta0)
+    auc_p, _, _ = oracle_run((theta0 * F32(1 + 2e-7)).astype(F32))
+    auc_m, _, _ = oracle_run((theta0 * F32(1 - 2e-7)).astype(F32))
     chaos = max(max(abs(auc_o[d] - auc_p[d]), abs(auc_o[d] - auc_m[d])) for d in range(D))
     theta_g = eng.get_weights()
     pf_g, tr_g = make_perm_fn(), []
-    for seq in seqs:
+    for k, seq in enumerate(seqs):
         tr_g += meta.dn_epoch(eng, theta_g, seq, pf_g, 256, lr=LR, meta_lr=0.5)
+        if k == 0:
+            # after ONE epoch the rounding-level differences have not been amplified yet: the plain 1e-3 bar, every domain
+            eng.set_weights(theta_g)
+            for d in range(D):
+                _, a1 = eng.evaluate(d, "val")
+                print("%s domain %d after the first epoch: AUC hip %.5f oracle %.5f" % (kind, d, a1, first_o[d]))
+                assert abs(a1 - first_o[d]) <= 1e-3, (d, a1, first_o[d])
     assert tr_o == tr_g
     eng.set_weights(theta_g)
     got = []
