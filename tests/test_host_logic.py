@@ -660,3 +660,30 @@ def test_scattered_meta_parms_say_so(tmp_path, monkeypatch):
     cfg["train"]["meta_parms"] = ["W1", "W2"]                 # neighbours: fine
     avg_loss, avg_auc, _, da = cli.main(cfg, FakeEngine)
     assert np.isfinite(avg_loss) and sorted(da) == [0, 1, 2]
+
+
+def test_configs_mirror_the_reference():
+    """config/ carries the reference's 40 run configurations value for value (every key of the reference's file, same
+    value; this build only ADDS keys: `dataset.synthetic`, defaults the reference's loader fills in) plus three BASELINE
+    cases the reference has no file for.  Compared against /root/reference where it exists (this container)."""
+    ref = "/root/reference/config"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference tree is not here")
+    ours = os.path.join(ROOT, "config")
+    n = 0
+    for split in sorted(os.listdir(ref)):
+        for name in sorted(os.listdir(os.path.join(ref, split))):
+            if not name.endswith(".json"):
+                continue
+            with open(os.path.join(ref, split, name)) as f:
+                a = json.load(f)
+            with open(os.path.join(ours, split, name)) as f:
+                b = json.load(f)
+            for sec, kv in a.items():
+                for k, v in kv.items():
+                    assert b[sec][k] == v, (split, name, sec, k, v, b[sec].get(k))
+            n += 1
+    assert n == 40
+    extra = {"Amazon_13/star_DN+DR.json", "Amazon_6/deepfm_DN.json", "Taobao_30/deepctr_DN+DR_bs4096.json"}
+    have = {"%s/%s" % (s, f) for s in os.listdir(ours) for f in os.listdir(os.path.join(ours, s)) if f.endswith(".json")}
+    assert extra <= have and len(have) == 43

@@ -7,7 +7,11 @@ emb_trainable: true`.  This script writes those variants for the towers built he
 Domain Negotiation and MAMDR entries), keeping every other value of the templates.  The multi-task baselines
 (shared_bottom / mmoe / ple) get their per-split hyperparameters from the table MTL below (the values of the
 reference's config/*/{shared_bottom,mmoe,ple}.json: layer widths, expert counts, learning rate); the Amazon ones
-train their tables, which the generic-layer engine does not build yet (it says so when run).
+train their tables.  The files mirror the reference's VALUE FOR VALUE, quirks included (tests/test_host_logic.py::
+test_configs_mirror_the_reference pins that where /root/reference is present): batch 1,024 everywhere (BASELINE.json's
+Taobao-30 bs 4,096 case is the extra file Taobao_30/deepctr_DN+DR_bs4096.json), Taobao_30/ple.json reading the 20-domain
+split, the Amazon shared_bottom files asking for pretrained tables the Amazon datasets do not have (run.py then says so,
+as the reference's deepctr.py:104-116 would fail on `None` tables).
 
 usage: python tools/make_configs.py    (idempotent; writes under config/)"""
 import copy
@@ -26,8 +30,7 @@ def load(name):
 SPLITS = {
     # directory: dataset overrides, train overrides, MAMDR sample_num, star file name
     "Taobao_20": (dict(domain_split_path="split_by_theme_20", synthetic="taobao20"), {}, 19, "star_taobao.json"),
-    "Taobao_30": (dict(domain_split_path="split_by_theme_30", synthetic="taobao30", batch_size=4096), {}, 5,
-                  "star_taobao.json"),
+    "Taobao_30": (dict(domain_split_path="split_by_theme_30", synthetic="taobao30"), {}, 5, "star_taobao.json"),
     "Amazon_6": (dict(name="Amazon", dataset_path="dataset/Amazon", domain_split_path="split_by_category_6",
                       synthetic="amazon6"), dict(load_pretrain_emb=False, emb_trainable=True), 3, "star.json"),
     "Amazon_13": (dict(name="Amazon", dataset_path="dataset/Amazon", domain_split_path="split_by_category_13",
@@ -83,6 +86,10 @@ def write_mtl(written):
             cfg["train"]["learning_rate"] = lr
             cfg["dataset"].update(ds_over)
             cfg["dataset"]["batch_size"] = 1024
+            if name == "shared_bottom" and split.startswith("Amazon"):      # as the reference's files
+                cfg["train"].update(load_pretrain_emb=True, emb_trainable=False)
+            if name == "ple" and split == "Taobao_30":                      # as the reference's file
+                cfg["dataset"].update(domain_split_path="split_by_theme_20", synthetic="taobao20")
             path = os.path.join(CFG, split, name + ".json")
             if os.path.exists(path):
                 continue
@@ -116,6 +123,17 @@ def main():
                 json.dump(cfg, f, indent=2)
                 f.write("\n")
             written.append(os.path.relpath(path, ROOT))
+    # BASELINE.json configs[3]: mlp_meta_mamdr on Taobao-30 at batch 4,096 (the reference's file says 1,024 and _finetune)
+    path = os.path.join(CFG, "Taobao_30", "deepctr_DN+DR_bs4096.json")
+    if not os.path.exists(path):
+        with open(os.path.join(CFG, "Taobao_30", "deepctr_DN+DR.json")) as f:
+            cfg = json.load(f)
+        cfg["model"]["name"] = "mlp_meta_mamdr"
+        cfg["dataset"]["batch_size"] = 4096
+        with open(path, "w") as f:
+            json.dump(cfg, f, indent=2)
+            f.write("\n")
+        written.append(os.path.relpath(path, ROOT))
     print("\n".join(written) if written else "nothing to write")
 
 
