@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void k_graph_ccpm_bwd(const CcpmArgs a) {
 // (deepctr InteractingLayer, att_embedding_size 8, 4 heads, residual, no scaling -- oracle/fmnets.py).  Token-major compact
 // buffers: row 3 b + t = field t of batch row b.  Per layer: P = X W (k_graph_gemm, W = [W_query | W_key | W_value | W_res],
 // [d][128]) -> per batch row (one wave): scores Q_h K_h^T [3 x 3] per head, softmax over the fields, A V, + R, relu.
-constexpr int ATT_OUT = 32, ATT_HEADS = 4, ATT_DIM = 8, ATT_P = 4 * ATT_OUT;      // 128 projection columns per token
+constexpr int ATT_OUT = 32, ATT_DIM = 8, ATT_P = 4 * ATT_OUT;      // 4 heads x 8; 128 projection columns per token
 struct AttArgs {
     const float* P;      // [3 rows_pad][128]
     float* A;            // [rows_pad][36]: probabilities [head][field][field]
