@@ -158,9 +158,15 @@ class TailSync(object):
     output unit -- `weights[n_meta:]` -- and the non-trainable moving statistics `aux`) are trained by the inner steps
     only and live in each rank's engine.  The reference updates them in ONE sequence of passes
     (model_zoo/Star/star.py:70-127 under mamdr.py:41-108); sharded, every rank applies its own passes to its own
-    copy.  `sync()` makes them one model again, the way the DN displacement is: since the last common value every
-    rank moved its copy by delta_g, the new common value is common + sum_g delta_g (first order = all passes applied
-    in sequence; one rank: the value itself).  The moving statistics of domain d are exponential averages of batch
+    copy.  `sync()` makes them one model again: since the last common value every rank moved its copy by delta_g in
+    k_g steps of its own, the new common value is common + the STEP-WEIGHTED MEAN of the displacements -- a per-domain
+    slice (specific kernels / biases, PartitionedNorm's per-domain gamma / beta) weighted by the steps each rank took ON
+    THAT DOMAIN (a slice only one rank trained keeps that rank's value), shared tensors (shared gamma / beta, the output
+    unit) by each rank's total steps.  Not the sum the DN displacement of theta takes (that one is damped by the meta
+    learning rate): these tensors are stepped by Adam with no outer rate, every rank walks the whole way to where its
+    gradient vanishes, and N such walks added up overshoot N-fold -- measured with the Star tower on Taobao-10
+    (tools/dist_auc_star.sh, profiles/r03u_dist_auc_star.jsonl): summed displacements 0.8116 (N = 1) -> 0.8079 (2) ->
+    0.7703 (4) average test AUC.  MAMDR_TAIL_SYNC=sum keeps the sum for comparison.  The moving statistics of domain d are exponential averages of batch
     statistics, not sums: ranks are combined weighted by the number of steps k_g each took on d since the last sync,
     mov_d = sum_g k_g mov_d,g / sum_g k_g, and the zero-debias slots are rebuilt for the summed step count
     (partitioned_norm.py:177-193: biased = mov * (1 - 0.99^steps)).  Adam's moments stay per rank, like every
@@ -180,6 +186,24 @@ class TailSync(object):
             return
         self.common = eng.weights[self.n_meta:].clone()
         self.aux_common = self.aux.clone() if self.aux is not None else None
+        import os
+        self.mean = os.environ.get("MAMDR_TAIL_SYNC", "mean") != "sum"
+        # domain of every tail element (-1: shared): the per-domain tensors are [D][...] blocks of the flat vector
+        self.elem_dom = torch.full((self.n_tail,), -1, dtype=torch.int64, device=self.common.device)
+        D = eng.n_domain
+        for name, (off, cnt) in getattr(eng, "segments", {}).items():
+            if off >= self.n_meta and cnt % D == 0 and (name[:2] in ("Wd", "bd") or name in ("pn_gamma_spec", "pn_beta_spec")):
+                per = cnt // D
+                self.elem_dom[off - self.n_meta:off - self.n_meta + cnt] = torch.arange(cnt, device=self.common.device) // per
+        self.is_dom = self.elem_dom >= 0
+        self.dom_idx = self.elem_dom.clamp(min=0)
+
+    EPS = 1e-3      # weight of a rank's total steps inside a per-domain slice: decides only where NO rank trained the domain
+
+    def _weights(self, k):
+        """per-element weights from the per-domain step counts k [D] (one rank's own, or the sum over the ranks)."""
+        tot = k.sum()
+        return torch.where(self.is_dom, k[self.dom_idx] + self.EPS * tot, tot.expand(self.n_tail))
 
     def floats(self):
         """payload of one sync (floats all-reduced)."""
@@ -210,6 +234,8 @@ class TailSync(object):
             mm, mv, _, _, steps = self._aux_views(self.aux)
             D, X = mm.shape
             k = (steps - self._aux_views(self.aux_common)[4]).clamp_(min=0.0)
+            if self.mean:
+                buf[:self.n_tail].mul_(self._weights(k))
             o = self.n_tail
             buf[o:o + D * X].view(D, X).copy_(mm * k[:, None])
             buf[o + D * X:o + 2 * D * X].view(D, X).copy_(mv * k[:, None])
@@ -218,7 +244,13 @@ class TailSync(object):
     def apply(self, buf):
         """`buf` summed over the ranks -> the new common value, on every rank."""
         live = self.eng.weights[self.n_meta:]
-        live.copy_(self.common + buf[:self.n_tail])
+        if self.aux is not None and self.mean:
+            D = self.eng.n_domain
+            X = (self.aux.numel() - D) // (4 * D)
+            W = self._weights(buf[self.n_tail + 2 * D * X:self.n_tail + 2 * D * X + D])
+            live.copy_(self.common + torch.where(W > 0, buf[:self.n_tail] / W.clamp(min=1e-30), torch.zeros_like(W)))
+        else:
+            live.copy_(self.common + buf[:self.n_tail])
         if self.aux is not None:
             mm, mv, bm, bv, steps = self._aux_views(self.aux)
             D, X = mm.shape

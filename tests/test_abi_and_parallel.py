@@ -424,8 +424,10 @@ eng.weights[NM:] += (rank + 1) * 0.5
 mm, mv, bm, bv, steps = ts._aux_views(eng.aux)
 mm[rank] = 10.0 * (rank + 1); mv[rank] = 2.0 + rank; steps[rank] = rank + 2
 ts.sync()
-want_tail = torch.arange(NM, NM + NT, dtype=torch.float32) + 0.5 + 1.0
-assert torch.equal(eng.weights[NM:], want_tail), eng.weights
+# step-weighted mean of the displacements (this stand-in has no per-domain tensors: every element is shared, weights = each
+# rank's total steps 2 and 3)
+want_tail = torch.arange(NM, NM + NT, dtype=torch.float32) + (2 * 0.5 + 3 * 1.0) / 5
+assert torch.allclose(eng.weights[NM:], want_tail), eng.weights
 assert torch.equal(eng.weights[:NM], torch.arange(NM, dtype=torch.float32))          # theta's part is not the tail's business
 for r in range(2):
     assert torch.allclose(mm[r], torch.full((X,), 10.0 * (r + 1))) and torch.allclose(mv[r], torch.full((X,), 2.0 + r))
@@ -437,8 +439,31 @@ eng.weights[NM:] -= 0.25
 mm[0] = 4.0 if rank == 0 else 8.0
 steps[0] += 1.0 if rank == 0 else 3.0
 ts.sync()
-assert torch.allclose(eng.weights[NM:], want_tail - 0.5)
+assert torch.allclose(eng.weights[NM:], want_tail - 0.25)       # both moved by -0.25 (in 1 and 3 steps): the mean is -0.25
 assert torch.allclose(mm[0], torch.full((X,), (1 * 4.0 + 3 * 8.0) / 4.0)) and float(steps[0]) == 2 + 4
+# per-domain tensors: a slice only ONE rank trained keeps that rank's displacement, a slice both trained takes the mean
+# weighted by the steps on that domain, a slice nobody trained the mean weighted by the total steps; shared tensors as above
+class Eng2(Eng):
+    segments = {{"theta": (0, NM), "Wd0": (NM, 3), "wo": (NM + 3, 3)}}      # Wd0 = [D = 3][1], wo shared
+eng2 = Eng2()
+ts2 = parallel.TailSync(eng2)
+assert ts2.elem_dom.tolist() == [0, 1, 2, -1, -1, -1]
+_, _, _, _, st2 = ts2._aux_views(eng2.aux)
+# rank 0: 4 steps on domain 0, 1 step on domain 1;  rank 1: 3 steps on domain 1.  Everybody moves everything by (rank + 1)
+eng2.weights[NM:] += float(rank + 1)
+if rank == 0:
+    st2[0] = 4.0; st2[1] = 1.0
+else:
+    st2[1] = 3.0
+ts2.sync()
+e = parallel.TailSync.EPS
+got = (eng2.weights[NM:] - torch.arange(NM, NM + NT, dtype=torch.float32)).tolist()
+want = [(1 * (4 + e * 5) + 2 * (0 + e * 3)) / (4 + e * 8),         # domain 0: rank 0 alone trained it
+        (1 * (1 + e * 5) + 2 * (3 + e * 3)) / (4 + e * 8),         # domain 1: 1 and 3 steps
+        (1 * 5 + 2 * 3) / 8.0,                                     # domain 2: nobody -> total steps decide
+        (1 * 5 + 2 * 3) / 8.0, (1 * 5 + 2 * 3) / 8.0, (1 * 5 + 2 * 3) / 8.0]
+assert np.allclose(got, want, rtol=1e-6), (got, want)
+assert abs(got[0] - 1.0) < 2e-3 and abs(got[1] - 1.75) < 2e-3
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -446,7 +471,7 @@ print("rank", rank, "ok")
 
 def test_tail_sync_gloo_world2(tmp_path):
     """parallel.TailSync (the tensors outside theta / phi of the Star tower under several ranks): the tail becomes
-    common + the sum of the ranks' displacements, a domain's moving statistics the step-weighted average of the ranks
+    common + the step-weighted mean of the ranks' displacements, a domain's moving statistics the step-weighted average of the ranks
     that trained it, the zero-debias slots follow the summed step count, untouched domains keep their values."""
     script = tmp_path / "tail_worker.py"
     script.write_text(TAIL_WORKER.format(root=ROOT))

@@ -2,7 +2,8 @@
 Used to measure what the per-rank DN sub-sequences + one all-reduce cost in AUC against the
 single-process loop, for both DN modes, next to the run-to-run spread of the single-process loop itself;
 on a 1-GPU box: MAMDR_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node N
-tools/dist_auc.py [config] [epochs] [dn_mode] [run seed]   (the generated logs keep seed 123 whatever the run seed)"""
+tools/dist_auc.py [config] [epochs] [dn_mode] [run seed] [model name]   (the generated logs keep seed 123 whatever the
+run seed; model name default mlp_meta_mamdr, e.g. star_meta_mamdr with config/Taobao-10/star_taobao.json)"""
 import contextlib
 import io
 import json
@@ -19,10 +20,10 @@ cfg["train"].update(epoch=int(sys.argv[2]) if len(sys.argv) > 2 else 6, patience
                     result_save_path="/tmp/dist_auc/result", checkpoint_path="/tmp/dist_auc/ckpt")
 cfg["dataset"]["synthetic_seed"] = cfg["dataset"]["seed"]
 cfg["dataset"]["seed"] = seed
-cfg["model"]["name"] = "mlp_meta_mamdr"
+cfg["model"]["name"] = sys.argv[5] if len(sys.argv) > 5 else "mlp_meta_mamdr"
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     avg_loss, avg_auc, dl, da = cli.main(cfg)
 if int(os.environ.get("RANK", "0")) == 0:
-    print("DISTAUC " + json.dumps({"world": int(os.environ.get("WORLD_SIZE", "1")), "dn_mode": dn_mode, "seed": seed,
+    print("DISTAUC " + json.dumps({"world": int(os.environ.get("WORLD_SIZE", "1")), "dn_mode": dn_mode, "seed": seed, "model": cfg["model"]["name"],
                                    "avg_auc": avg_auc, "avg_loss": avg_loss, "domain_auc": [da[k] for k in sorted(da)]}))
