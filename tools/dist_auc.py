@@ -19,6 +19,8 @@ seed = int(sys.argv[4]) if len(sys.argv) > 4 else cfg["dataset"]["seed"]
 cfg["train"].update(epoch=int(sys.argv[2]) if len(sys.argv) > 2 else 6, patience=100, dn_mode=dn_mode,
                     result_save_path="/tmp/dist_auc/result", checkpoint_path="/tmp/dist_auc/ckpt")
 cfg["dataset"]["synthetic_seed"] = cfg["dataset"]["seed"]
+if os.environ.get("MAMDR_DIST_AUC_SCALE"):        # fewer rows per domain (quick runs on the big shapes)
+    cfg["dataset"]["synthetic_scale"] = float(os.environ["MAMDR_DIST_AUC_SCALE"])
 cfg["dataset"]["seed"] = seed
 cfg["model"]["name"] = sys.argv[5] if len(sys.argv) > 5 else "mlp_meta_mamdr"
 buf = io.StringIO()
