@@ -7,7 +7,7 @@
 // One training step of task d on a batch (what `domain_model_dict[d].fit` executes per batch, deep_mtl_ctr.py:79-80):
 //   gather x = [U[uid] | I[pid] | Dm[dom]]                                   k_graph_gather   (hbm)
 //   every expert task d mixes: DNN = per layer  relu(h W + b) * dropout       k_graph_gemm<0>  (mfma, 64x64 tiles)
-//   gate_d: DNN, then softmax(q Wg) and the mixture sum_e gate_e expert_e     k_graph_gate_fwd (one wave per row)
+//   gate_d: DNN, then softmax(q Wg) and the mixture sum_e gate_e expert_e     k_graph_gate_fwd (one workgroup per row)
 //   tower_d: DNN;  head: sigmoid(t w + gb), Keras BCE, d loss / d logit       k_graph_head     (one wave per row)
 //   backward, layer by layer: dW = in^T dz (k_graph_gemm<2>, the batch rows split over up to 16 workgroups per tile,
 //   launch_wgrad), k_graph_wfinish = the partial products summed in a fixed order + db = column sums in the same launch,
@@ -797,85 +797,62 @@ struct GateArgs {
     int rows_pad;
     float gate_scale;           // 1 / keep of the dropout behind every DNN layer (1 in inference)
 };
+// One workgroup per batch row (4 waves: the gate logits / the d gate sums are dealt over the waves, the expert width over all
+// 256 lanes) -- with one wave per row the 1,024 rows of a batch were 1,024 waves on 1,024 SIMDs, each walking its experts'
+// reductions one after the other (23 us for 12 experts).  Same summation orders as that form: bit-identical results.
 __global__ __launch_bounds__(256) void k_graph_gate_fwd(const GateArgs a) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= a.rows_pad) return;
+    __shared__ float sl[MAX_MIX];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* row = a.act + (size_t)r * a.ld;
-    float logit[MAX_MIX];       // (every loop over it is fully unrolled: registers, no scratch)
+    for (int e = w; e < a.n_e; e += 4) {
+        float s = 0.f;
+        for (int j = lane; j < a.n_q; j += 64) s = fmaf(row[a.q_col + j], a.wg[j * a.n_e + e], s);
+        s = wave_sum(s);
+        if (lane == 0) sl[e] = s;
+    }
+    __syncthreads();
     float mx = -3.0e38f;
-#pragma unroll
-    for (int e = 0; e < MAX_MIX; ++e) {
-        logit[e] = -3.0e38f;
-        if (e < a.n_e) {
-            float s = 0.f;
-            for (int j = lane; j < a.n_q; j += 64) s = fmaf(row[a.q_col + j], a.wg[j * a.n_e + e], s);
-            logit[e] = wave_sum(s);
-            mx = fmaxf(mx, logit[e]);
-        }
-    }
+    for (int e = 0; e < a.n_e; ++e) mx = fmaxf(mx, sl[e]);
     float den = 0.f;
-#pragma unroll
-    for (int e = 0; e < MAX_MIX; ++e) {
-        logit[e] = e < a.n_e ? __expf(logit[e] - mx) : 0.f;
-        den += logit[e];
-    }
-    float mine = 0.f;
-#pragma unroll
-    for (int e = 0; e < MAX_MIX; ++e) {
-        logit[e] = logit[e] / den;
-        mine = (e == lane) ? logit[e] : mine;
-    }
-    if (lane < a.n_e) row[a.g_col + lane] = mine;
-    for (int cidx = lane; cidx < a.n_h; cidx += 64) {
+    for (int e = 0; e < a.n_e; ++e) den += __expf(sl[e] - mx);
+    if (tid < a.n_e) row[a.g_col + tid] = __expf(sl[tid] - mx) / den;
+    for (int cidx = tid; cidx < a.n_h; cidx += 256) {
         float m = 0.f;
-#pragma unroll
-        for (int e = 0; e < MAX_MIX; ++e)
-            if (e < a.n_e) m += logit[e] * row[a.e_col[e] + cidx];
+        for (int e = 0; e < a.n_e; ++e) m += (__expf(sl[e] - mx) / den) * row[a.e_col[e] + cidx];
         row[a.m_col + cidx] = m;
     }
 }
 // d mixture -> d expert outputs (times their relu / dropout gate = d z of the experts' last layers), d gate logits
 // (kept: dWg = q^T dgl) and d q (times q's gate = d z of the gate DNN's last layer)
 __global__ __launch_bounds__(256) void k_graph_gate_bwd(const GateArgs a) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= a.rows_pad) return;
+    __shared__ float sdg[MAX_MIX], sgp[MAX_MIX];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* row = a.act + (size_t)r * a.ld;
     float* drow = a.dact + (size_t)r * a.ld;
-    float dg[MAX_MIX], gp[MAX_MIX];
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < MAX_MIX; ++e) {
-        dg[e] = 0.f;
-        gp[e] = 0.f;
-        if (e < a.n_e) {
-            float t = 0.f;
-            for (int cidx = lane; cidx < a.n_h; cidx += 64) t = fmaf(drow[a.m_col + cidx], row[a.e_col[e] + cidx], t);
-            dg[e] = wave_sum(t);
-            gp[e] = row[a.g_col + e];
-            s = fmaf(gp[e], dg[e], s);
+    for (int e = w; e < a.n_e; e += 4) {
+        float t = 0.f;
+        for (int cidx = lane; cidx < a.n_h; cidx += 64) t = fmaf(drow[a.m_col + cidx], row[a.e_col[e] + cidx], t);
+        t = wave_sum(t);
+        if (lane == 0) {
+            sdg[e] = t;
+            sgp[e] = row[a.g_col + e];
         }
     }
-    float mine = 0.f;
-#pragma unroll
-    for (int e = 0; e < MAX_MIX; ++e) {
-        dg[e] = gp[e] * (dg[e] - s);        // d gate logit
-        mine = (e == lane) ? dg[e] : mine;
-    }
-    for (int cidx = lane; cidx < a.n_h; cidx += 64) {
+    __syncthreads();
+    float s = 0.f;
+    for (int e = 0; e < a.n_e; ++e) s = fmaf(sgp[e], sdg[e], s);
+    for (int cidx = tid; cidx < a.n_h; cidx += 256) {
         const float dm = drow[a.m_col + cidx];
-#pragma unroll
-        for (int e = 0; e < MAX_MIX; ++e)
-            if (e < a.n_e) {
-                const float h = row[a.e_col[e] + cidx];
-                drow[a.e_col[e] + cidx] = h > 0.f ? (gp[e] * dm) * a.gate_scale : 0.f;
-            }
+        for (int e = 0; e < a.n_e; ++e) {
+            const float h = row[a.e_col[e] + cidx];
+            drow[a.e_col[e] + cidx] = h > 0.f ? (sgp[e] * dm) * a.gate_scale : 0.f;
+        }
     }
-    if (lane < a.n_e) drow[a.g_col + lane] = mine;
-    for (int j = lane; j < a.n_q; j += 64) {
+    __syncthreads();        // (every read of d mixture is done before g_col / q_col, which may neighbour it, are written)
+    if (tid < a.n_e) drow[a.g_col + tid] = sgp[tid] * (sdg[tid] - s);        // d gate logit
+    for (int j = tid; j < a.n_q; j += 256) {
         float v = 0.f;
-#pragma unroll
-        for (int e = 0; e < MAX_MIX; ++e)
-            if (e < a.n_e) v = fmaf(dg[e], a.wg[j * a.n_e + e], v);
+        for (int e = 0; e < a.n_e; ++e) v = fmaf(sgp[e] * (sdg[e] - s), a.wg[j * a.n_e + e], v);
         drow[a.q_col + j] = row[a.q_col + j] > 0.f ? v * a.gate_scale : 0.f;
     }
 }
@@ -1546,7 +1523,7 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
         dnn_forward(g, g->dnns[t.gate], t.col[gi], 0, sc);
         GateArgs ga;
         fill_gate(g, t, sc, ga);
-        hipLaunchKernelGGL(k_graph_gate_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
+        hipLaunchKernelGGL(k_graph_gate_fwd, dim3(sc.rp), dim3(256), 0, g->stream, ga);
         tower_in = t.m_col;
     } else {
         tower_in = t.col[0].back();
@@ -2135,7 +2112,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[ti], t.m_col, t.m_col, -1, false, 0, 0, sc);
             GateArgs gta;
             fill_gate(g, t, sc, gta);
-            hipLaunchKernelGGL(k_graph_gate_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, gta);
+            hipLaunchKernelGGL(k_graph_gate_bwd, dim3(sc.rp), dim3(256), 0, g->stream, gta);
             const size_t gi = t.mix.size();
             const Dnn& gd = g->dnns[t.gate];
             launch_small_tn(g->stream, g->act + gta.q_col,
