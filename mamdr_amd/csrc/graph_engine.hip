@@ -774,8 +774,21 @@ __global__ __launch_bounds__(256) void k_graph_small_nt(const float* d, int n_c,
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * n_k) return;
     const int r = idx / n_k, k = idx - r * n_k;
+    const f32x4* dr = reinterpret_cast<const f32x4*>(d + (size_t)r * n_c);       // n_c is a multiple of 4 (128)
+    const f32x4* wr = reinterpret_cast<const f32x4*>(W + (size_t)k * n_c);
     float s = 0.f;
-    for (int c = 0; c < n_c; ++c) s = fmaf(d[(size_t)r * n_c + c], W[(size_t)k * n_c + c], s);
+    for (int c4 = 0; c4 < n_c / 4; c4 += 4) {           // 16-B loads, eight in flight; the chain keeps its order
+        f32x4 x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x[u] = dr[c4 + u];
+            y[u] = wr[c4 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = fmaf(x[u][q], y[u][q], s);
+    }
     out[idx] = s;
 }
 // d x[:, first .. first + n) (+)= compact [rows][384] columns first .. first + n
