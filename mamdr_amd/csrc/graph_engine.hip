@@ -971,41 +971,41 @@ __global__ __launch_bounds__(256) void k_graph_sum1(const float* x, int n, float
 
 // ------------------------------------------------------------------ domain table gradient
 // g[d][c] = sum over the batch rows of domain d of d x[b][256 + c]  +  2 l2 Dm[d][c]   (rows in batch order)
-// one workgroup per domain; a domain with no row in the batch (all but one of them in a domain step) leaves after one look
-// at the ids.  128 columns x 8 row groups, 4 loads in flight, summed through LDS in a fixed order.
-constexpr int DG_GROUPS = 8;
-__global__ __launch_bounds__(1024) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
-                                                            const float* dm, float two_l2, float* g) {
-    __shared__ float red[DG_GROUPS][EMB];
-    const int d = blockIdx.x, c = threadIdx.x & (EMB - 1), rg = threadIdx.x / EMB;
+// grid (8 column blocks, domains): 16 columns x 16 row groups per workgroup, 8 loads in flight, summed through LDS in a
+// fixed order; a domain with no row in the batch (all but one of them in a domain step) leaves after one look at the ids.
+__global__ __launch_bounds__(256) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
+                                                           const float* dm, float two_l2, float* g) {
+    __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    const int d = blockIdx.y, c = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
+    const int col = blockIdx.x * CS_COLS + c;
     int mine = 0;
-    for (int b = threadIdx.x; b < rows; b += 1024) mine |= domrow[b] == d;
+    for (int b = threadIdx.x; b < rows; b += 256) mine |= domrow[b] == d;
     if (!__syncthreads_or(mine)) {
-        if (rg == 0) g[d * EMB + c] = two_l2 * dm[d * EMB + c];
+        if (rg == 0) g[d * EMB + col] = two_l2 * dm[d * EMB + col];
         return;
     }
-    const float* p = dx + x_col + c;
+    const float* p = dx + x_col + col;
     float s = 0.f;
     int b = rg;
-    for (; b + 3 * DG_GROUPS < rows; b += 4 * DG_GROUPS) {
-        float v[4];
-        int id[4];
+    for (; b + 7 * CS_GROUPS < rows; b += 8 * CS_GROUPS) {
+        float v[8];
+        int id[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            id[k] = domrow[b + k * DG_GROUPS];
-            v[k] = p[(size_t)(b + k * DG_GROUPS) * ld];
+        for (int k = 0; k < 8; ++k) {
+            id[k] = domrow[b + k * CS_GROUPS];
+            v[k] = p[(size_t)(b + k * CS_GROUPS) * ld];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s += id[k] == d ? v[k] : 0.f;
+        for (int k = 0; k < 8; ++k) s += id[k] == d ? v[k] : 0.f;
     }
-    for (; b < rows; b += DG_GROUPS) s += domrow[b] == d ? p[(size_t)b * ld] : 0.f;
+    for (; b < rows; b += CS_GROUPS) s += domrow[b] == d ? p[(size_t)b * ld] : 0.f;
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < DG_GROUPS; ++k) t += red[k][c];
-        g[d * EMB + c] = t + two_l2 * dm[d * EMB + c];
+        for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
+        g[d * EMB + col] = t + two_l2 * dm[d * EMB + col];
     }
 }
 
@@ -2147,7 +2147,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
             dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
-        hipLaunchKernelGGL(k_graph_domain_grad, dim3(g->cfg.n_domain), dim3(EMB * DG_GROUPS), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
+        hipLaunchKernelGGL(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
                            sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
         if (g->tables) {
             // TF1's dense step over both tables: g = 2 l2 p + scatter-add of d x[:, user | item columns]
