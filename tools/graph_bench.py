@@ -1,7 +1,9 @@
 """Throughput of the generic-layer engine (csrc/graph_engine.hip) on the reference's Taobao-10 multi-task configurations
 and on the deepctr single-output towers it hosts: domain-steps/s of the alternate training loop (deep_mtl_ctr.py:69-96 /
 deepctr.py:63-93: one full pass per domain per epoch), synthetic Taobao-10 logs, batch 1024, inputs resident in HBM.
-usage: python tools/graph_bench.py [epochs [tower,tower...]]    -> one JSON line per tower"""
+usage: python tools/graph_bench.py [epochs [tower,tower...|all [inproc]]]    -> one JSON line per tower
+(`inproc`: every tower in THIS process -- what a profiler needs, which must not see a process that has initialised the GPU
+start another program)"""
 import json
 import os
 import sys
@@ -16,7 +18,8 @@ from mamdr_amd.plan import PassShuffler  # noqa: E402
 from mamdr_amd.utils import MultiDomainDataset  # noqa: E402
 
 EPOCHS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None
+INPROC = len(sys.argv) > 3 and sys.argv[3] == "inproc"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,7 +33,17 @@ def flops_per_row(model):
     return macs
 
 
-for cfg_name in ("shared_bottom", "mmoe", "ple", "nfm", "pnn", "ccpm", "autoint"):
+TOWERS = ("shared_bottom", "mmoe", "ple", "nfm", "pnn", "ccpm", "autoint")
+if not INPROC and (ONLY is None or len(ONLY) > 1):
+    # one process per tower (started before this one touches the GPU): in one process a tower measured after a bigger one
+    # now and then runs 3x slower than on its own (nfm after ple: 113 us, 113 us, 367 us, ... in five identical runs)
+    import subprocess
+    for name in TOWERS:
+        if ONLY is None or name in ONLY:
+            subprocess.run([sys.executable, os.path.abspath(__file__), str(EPOCHS), name], check=False)
+    sys.exit(0)
+
+for cfg_name in TOWERS:
     if ONLY is not None and cfg_name not in ONLY:
         continue
     path = os.path.join(ROOT, "config", "Taobao-10", cfg_name + ".json")

@@ -51,7 +51,7 @@ if has gather; then
 fi
 if has graph; then
     timeout 200 python3 "$REPO/tools/graph_bench.py" 3 2>/dev/null | grep tower > "$OUT/graph_bench.jsonl"
-    timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/graph_trace" -o run -- python3 "$REPO/tools/graph_bench.py" 1 > "$OUT/graph_trace.log" 2>&1
+    timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/graph_trace" -o run -- python3 "$REPO/tools/graph_bench.py" 1 all inproc > "$OUT/graph_trace.log" 2>&1
 fi
 cd "$REPO"
 if has graph; then
