@@ -50,7 +50,7 @@ if has gather; then
     timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/gather_write" -o run -- python3 "$REPO/tools/gather_hbm.py" > "$OUT/gather_write.log" 2>&1
 fi
 if has graph; then
-    timeout 200 python3 "$REPO/tools/graph_bench.py" 3 2>/dev/null | grep tower > "$OUT/graph_bench.jsonl"
+    timeout 900 python3 "$REPO/tools/graph_bench.py" 3 2>/dev/null | grep tower > "$OUT/graph_bench.jsonl"
     timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/graph_trace" -o run -- python3 "$REPO/tools/graph_bench.py" 1 all inproc > "$OUT/graph_trace.log" 2>&1
 fi
 cd "$REPO"
