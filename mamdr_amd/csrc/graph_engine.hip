@@ -418,8 +418,21 @@ static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, floa
 // out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1; the
 // attention projections: n_e = 128): 16 outputs per workgroup, the rows split over 16 groups summed through LDS in order
 __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_ld, const float* d, int d_ld, int rows,
-                                                        int n_j, int n_e, float* out) {
+                                                        int n_j, int n_e, float* out, float* sum_out) {
     __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    if (sum_out && blockIdx.x == gridDim.x - 1) {       // one more workgroup: sum_out[0] = sum over the rows of d[b][0], fixed order
+        float* r1 = &red[0][0];                         // (the head's d global bias beside its d kernel: one launch less)
+        float s1 = 0.f;
+        for (int b = threadIdx.x; b < rows; b += 256) s1 += d[(size_t)b * d_ld];
+        r1[threadIdx.x] = s1;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) r1[threadIdx.x] += r1[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sum_out[0] = r1[0];
+        return;
+    }
     const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
     const int idx = blockIdx.x * CS_COLS + c;
     float s = 0.f;
@@ -449,9 +462,9 @@ __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_
     }
 }
 static void launch_small_tn(hipStream_t s, const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
-                            float* out) {
-    hipLaunchKernelGGL(k_graph_small_tn, dim3((n_j * n_e + CS_COLS - 1) / CS_COLS), dim3(256), 0, s, in, in_ld, d, d_ld, rows,
-                       n_j, n_e, out);
+                            float* out, float* sum_out = nullptr) {
+    hipLaunchKernelGGL(k_graph_small_tn, dim3((n_j * n_e + CS_COLS - 1) / CS_COLS + (sum_out ? 1 : 0)), dim3(256), 0, s, in, in_ld,
+                       d, d_ld, rows, n_j, n_e, out, sum_out);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -955,20 +968,6 @@ __global__ __launch_bounds__(256) void k_graph_loss(const float* rowloss, int ro
     }
 }
 __global__ void k_graph_scale(float* x, float s) { x[0] *= s; }
-// out[0] = sum of x[0..n) in a fixed order (d global bias = sum of d loss / d logit)
-__global__ __launch_bounds__(256) void k_graph_sum1(const float* x, int n, float* out) {
-    __shared__ float red[256];
-    float s = 0.f;
-    for (int b = threadIdx.x; b < n; b += 256) s += x[b];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = red[0];
-}
-
 // ------------------------------------------------------------------ domain table gradient
 // g[d][c] = sum over the batch rows of domain d of d x[b][256 + c]  +  2 l2 Dm[d][c]   (rows in batch order)
 // grid (8 column blocks, domains): 16 columns x 16 row groups per workgroup, 8 loads in flight, summed through LDS in a
@@ -2033,8 +2032,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
         // ---- backward
         // head: dw = t^T dlogit, dgb = sum dlogit
         launch_small_tn(g->stream, g->act + t_col, g->ld, g->dlogit, 1,
-                           sc.rp, ha.n_t, 1, g->G(t.head_w));
-        hipLaunchKernelGGL(k_graph_sum1, dim3(1), dim3(256), 0, g->stream, g->dlogit, sc.rp, g->G(t.head_gb));
+                           sc.rp, ha.n_t, 1, g->G(t.head_w), g->G(t.head_gb));
         const size_t ti = t.path.size() - 1;
         // the x columns of the gradient workspace collect d x from every first layer (the domain columns alone while the
         // tables are frozen): the first writer overwrites, the others add
