@@ -1009,16 +1009,18 @@ __global__ __launch_bounds__(256) void k_graph_domain_grad(const float* dx, int 
 }
 
 // ------------------------------------------------------------------ optimiser on a range of the flat vector
-struct AdamArgs {
-    float *p, *m, *v;
-    const float* g;
-    int64_t n4;             // float4 elements
-    int optimizer;          // MAMDR_OPT_ADAM / MAMDR_OPT_SGD / MAMDR_OPT_ACCUMULATE (m = the accumulator: m += g, nothing else)
+struct AdamArgs {           // up to two ranges of the flat vector in one launch (the shared block and the task's block)
+    float *p, *m, *v;       // bases of the flat vector / its slots (m: the accumulator for MAMDR_OPT_ACCUMULATE)
+    const float* g;         // gradient base, addressed like p
+    int64_t off4[2], n4[2]; // float4 offsets / counts of the ranges
+    int optimizer;          // MAMDR_OPT_ADAM / MAMDR_OPT_SGD / MAMDR_OPT_ACCUMULATE (m += g, nothing else)
     float alpha, omb1, omb2, eps;
 };
 __global__ __launch_bounds__(256) void k_graph_adam(const AdamArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n4) return;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n4[0]) i += a.off4[0];
+    else if (i - a.n4[0] < a.n4[1]) i = i - a.n4[0] + a.off4[1];
+    else return;
     f32x4 p = reinterpret_cast<const f32x4*>(a.p)[i];
     const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
     if (a.optimizer == MAMDR_OPT_SGD) {
@@ -2192,22 +2194,25 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             launch_emb_sweep(ea, g->stream);
             if (g->has_lin) launch_lin_sweep(ea, g->stream);      // (reads the row maps, then resets them)
         }
-        // ---- optimiser on the two ranges this task's model trains
-        const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
-        for (int k = 0; k < 2; ++k) {
+        // ---- optimiser on the two ranges this task's model trains (one launch)
+        {
+            const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
             AdamArgs aa;
-            aa.p = g->params + off[k];
-            aa.m = (optimizer == MAMDR_OPT_ACCUMULATE ? g->accum : g->adam_m) + off[k];
-            aa.v = g->adam_v + off[k];
-            aa.g = g->G(off[k]);
-            aa.n4 = cnt[k] / 4;
-            if (aa.n4 == 0) continue;
+            aa.p = g->params;
+            aa.m = optimizer == MAMDR_OPT_ACCUMULATE ? g->accum : g->adam_m;
+            aa.v = g->adam_v;
+            aa.g = g->grad - g->table_floats;       // G(off) = grad + off - table_floats
+            for (int k = 0; k < 2; ++k) {
+                aa.off4[k] = off[k] / 4;
+                aa.n4[k] = cnt[k] / 4;
+            }
             aa.optimizer = optimizer;
             aa.alpha = alpha;
             aa.omb1 = omb1;
             aa.omb2 = omb2;
             aa.eps = g->cfg.adam_eps;
-            hipLaunchKernelGGL(k_graph_adam, dim3((unsigned)((aa.n4 + 255) / 256)), dim3(256), 0, g->stream, aa);
+            const int64_t n4 = aa.n4[0] + aa.n4[1];
+            if (n4 > 0) hipLaunchKernelGGL(k_graph_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, g->stream, aa);
         }
         g->global_step += 1;
     }
