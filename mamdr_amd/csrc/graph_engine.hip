@@ -1980,8 +1980,29 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
     const float rate = g->cfg.dropout;
     double thr = (double)rate * 4294967296.0;
     const float omb1 = 1.0f - g->cfg.adam_beta1, omb2 = 1.0f - g->cfg.adam_beta2;
+    // DIAGNOSTIC (MAMDR_GRAPH_DIAG_REPLAY=1, wrong values, right timing): the second step of a call is captured into a
+    // hipGraph and REPLAYED for the full-batch steps that follow -- what a step costs when the host issues one graph launch
+    // instead of ~21 kernel launches (launch-rate sensitivity)
+    static const bool diag_replay = getenv("MAMDR_GRAPH_DIAG_REPLAY") && atoi(getenv("MAMDR_GRAPH_DIAG_REPLAY")) != 0;
+    hipGraph_t dgraph = nullptr;
+    hipGraphExec_t dexec = nullptr;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
+        if (diag_replay && dexec && pass_rows - row_base >= batch) {
+            (void)hipGraphLaunch(dexec, g->stream);
+            g->global_step += 1;
+            continue;
+        }
+        const bool capturing = diag_replay && !dexec && s == 1 && pass_rows - row_base >= batch && !d_loss_out;
+        if (capturing) (void)hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal);
+        struct EndCap {
+            bool on; hipStream_t st; hipGraph_t* gr; hipGraphExec_t* ex;
+            ~EndCap() {
+                if (!on) return;
+                if (hipStreamEndCapture(st, gr) == hipSuccess && hipGraphInstantiate(ex, *gr, nullptr, nullptr, 0) == hipSuccess)
+                    (void)hipGraphLaunch(*ex, st);
+            }
+        } endcap{capturing, g->stream, &dgraph, &dexec};
         StepCtx sc;
         sc.rows = (int)((pass_rows - row_base) < batch ? (pass_rows - row_base) : batch);
         sc.rp = (sc.rows + GT - 1) / GT * GT;
@@ -2216,6 +2237,8 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
         }
         g->global_step += 1;
     }
+    if (dexec) (void)hipGraphExecDestroy(dexec);
+    if (dgraph) (void)hipGraphDestroy(dgraph);
     GHIP(hipGetLastError());
     return MAMDR_OK;
 }

@@ -54,6 +54,8 @@ for cfg_name in TOWERS:
         cfg["model"]["name"] = cfg_name
     cfg["train"].update(result_save_path="/tmp/graph_bench/result", checkpoint_path="/tmp/graph_bench/ckpt")
     ds = MultiDomainDataset(cfg["dataset"])
+    if os.environ.get("MAMDR_GRAPH_DIAG_REPLAY"):      # stream capture needs a stream of its own (not the legacy default one)
+        torch.cuda.set_stream(torch.cuda.Stream())
     model = cli.build_model(cfg, ds)
     eng = model.model
     D = ds.n_domain
