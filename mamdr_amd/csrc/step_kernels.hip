@@ -1352,6 +1352,7 @@ __device__ __forceinline__ void update_w0dom_linear(const UpdateArgs& u, int wg,
     apply_vec4(u, e, g, p0, m0, v0);
 }
 
+constexpr int DM_CBLOCKS = 8;       // column blocks of the domain table's update: 16 columns per workgroup
 __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, float* s_l) {
     const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
     // the workgroups with the longest dependent chain come first in the grid
@@ -1375,33 +1376,42 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
         apply_vec4(u, e, slab_sum4(u.slabs, u.n_groups, u.slab_ld, e), p0, m0, v0);
         return;
     }
-    // domain table: one wave per element (d, c):
-    //   g = sum_k S[d][k] * W0[256 + c][k] + 2 l2 p,   S = onehot(domain)^T dz1 summed over the slabs
-    const int lane = threadIdx.x & 63;
-    const int el = (bid - n_vec_wgs) * 4 + (threadIdx.x >> 6);
-    if (el >= u.dm_count) return;
-    const int d = el / EMB, c = el - d * EMB;
-    const size_t so = (size_t)u.s_off + (size_t)d * H1 + 4 * lane;
-    // (every load of the element is requested up front; all lanes read p / m / v / S2 of the element: one address)
-    float p = u.p[el], m = u.m[el], v = u.v[el];
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
-    const float g2 = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
-    const f32x4 sv = slab_sum4(u.slabs, u.n_groups, u.slab_ld, so);
-    float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
-    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-    if (lane == 0) {
-        if (u.s2_off) g += g2;
-        g += u.two_l2 * p;
-        optimizer_step(u, g, p, m, v);
-        if (u.optimizer == 2) {
-            u.m[el] = m;
-            return;
+    // domain table, one workgroup per (domain d, 16 columns c):
+    //   g[d][c] = sum_k S[d][k] * W0[256 + c][k] + 2 l2 p,   S = onehot(domain)^T dz1 summed over the slabs
+    // S[d][:] is summed over the slabs ONCE per workgroup (thread k owns element k; LDS), then every wave contracts it with
+    // four rows of the W0 snapshot.  (One wave per element re-summed the 16 slabs of S[d][:] for each of its 128 columns:
+    // 960 workgroups x 16 KB on Taobao-30.)  Same orders as that form -- slabs in sequence, four fmas per lane, the
+    // xor tree over the lanes: bit-identical.
+    const int blk = bid - n_vec_wgs;
+    const int d = blk / DM_CBLOCKS, c0 = (blk - d * DM_CBLOCKS) * (EMB / DM_CBLOCKS);
+    if (d >= u.dm_count / EMB) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    s_l[threadIdx.x] = slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + threadIdx.x);
+    __syncthreads();
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + 4 * lane);
+    constexpr int PER_WAVE = EMB / DM_CBLOCKS / 4;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int c = c0 + w * PER_WAVE + i, el = d * EMB + c;
+        float p = u.p[el], m = u.m[el], v = u.v[el];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
+        const float g2 = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
+        float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+        if (lane == 0) {
+            if (u.s2_off) g += g2;
+            g += u.two_l2 * p;
+            optimizer_step(u, g, p, m, v);
+            if (u.optimizer == 2) {
+                u.m[el] = m;
+                continue;
+            }
+            if (u.optimizer == 0) {
+                u.m[el] = m;
+                u.v[el] = v;
+            }
+            u.p[el] = p;
         }
-        if (u.optimizer == 0) {
-            u.m[el] = m;
-            u.v[el] = v;
-        }
-        u.p[el] = p;
     }
 }
 #define UPDATE_EARLY_PARAMS                                                                                            \
@@ -1455,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_update_lin(UPDATE_EARLY_PARAMS, const U
 }
 static int update_blocks(const UpdateArgs& a) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
-    return n_vec_wgs + (a.dm_count + 3) / 4 + (a.dm_copy ? W0LIN_WGS : 0);
+    return n_vec_wgs + (a.dm_count / EMB) * DM_CBLOCKS + (a.dm_copy ? W0LIN_WGS : 0);
 }
 void launch_update(const UpdateArgs& a, hipStream_t s, const GatherPf* pf) {
     const int n_update = update_blocks(a);
