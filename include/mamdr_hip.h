@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 13
+#define MAMDR_ABI_VERSION 14
 
 enum {
     MAMDR_OK = 0,
@@ -155,6 +155,10 @@ int64_t mamdr_optimizer_steps(const mamdr_ctx* ctx);
  * A non-null d_loss_out makes every step synchronise first (its regulariser term sums over all rows).
  * MAMDR_DENSE_ADAM=1 in the environment keeps the per-step dense sweep instead. */
 int mamdr_sync_tables(mamdr_ctx* ctx);
+/* Launches of the lazy table Adam's replay kernel (k_emb_flush) so far: all of them, or (forced_only != 0) only those
+ * the flush period forced inside a training call.  Lets a parity test state how many flushes a run spanned
+ * (tests/test_gpu_fullsize.py); no reference counterpart -- TF1's dense Adam has no such event. */
+int64_t mamdr_table_flushes(const mamdr_ctx* ctx, int32_t forced_only);
 
 /* Bind the frozen user / item tables (row-major [rows, emb_dim] fp32).  Replaces
  * DeepCTR.build_emb with a Constant initializer, trainable=False

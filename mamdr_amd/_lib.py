@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -80,6 +80,7 @@ SIGNATURES = {
     "mamdr_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_optimizer_steps": (_I64, [_VP]),
+    "mamdr_table_flushes": (_I64, [_VP, _I32]),
     "mamdr_sync_tables": (C.c_int, [_VP]),
     "mamdr_bind_accumulator": (C.c_int, [_VP, _VP]),
     "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),

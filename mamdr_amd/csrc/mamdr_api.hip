@@ -153,6 +153,8 @@ struct mamdr_ctx {
     // 11.6 K at 16, 12.1 K at 32, 12.0 K at 64, 10.9 K at 256).  MAMDR_LAZY_FLUSH_EVERY overrides.
     int flush_every = 32;
     int64_t flush_t = 0;            // adam_t of the last flush
+    int64_t n_flush = 0;            // k_emb_flush launches so far / those forced by the flush period (mamdr_table_flushes)
+    int64_t n_flush_forced = 0;
     float* fmq = nullptr;           // DeepFM: [rows_pad][EMB]
     float* glin_u = nullptr;        // DeepFM + trainable tables: [rows_pad]
     float* glin_i = nullptr;
@@ -387,6 +389,7 @@ static void sync_tables(mamdr_ctx* c) {
     }
     c->tables_dirty = false;
     c->flush_t = c->adam_t;
+    c->n_flush += 1;
 }
 
 // k_emb_rows arguments of the batch at row_base for Adam step `t` (alt: into the other half of the double buffer)
@@ -419,6 +422,7 @@ static void emb_pre_step(mamdr_ctx* c, const SplitData& d, const int32_t* d_perm
     // k_emb_catchup short (the flush replays the same steps at full occupancy)
     if (c->adam_t - c->flush_t >= c->log_cap - 2 || c->adam_t - c->flush_t > c->flush_every) {
         c->adam_t -= 1;
+        if (c->tables_dirty) c->n_flush_forced += 1;
         sync_tables(c);
         c->adam_t += 1;
     }
@@ -970,6 +974,9 @@ int mamdr_optimizer_reset(mamdr_ctx* c) {
 }
 
 int64_t mamdr_optimizer_steps(const mamdr_ctx* c) { return c ? c->adam_t : 0; }
+int64_t mamdr_table_flushes(const mamdr_ctx* c, int32_t forced_only) {
+    return !c ? 0 : forced_only ? c->n_flush_forced : c->n_flush;
+}
 
 int mamdr_sync_tables(mamdr_ctx* c) {
     if (check_ctx(c)) return MAMDR_EINVAL;

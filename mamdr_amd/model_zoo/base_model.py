@@ -83,6 +83,7 @@ class BaseModel(object):
         keep = self.model.get_weights()
         best = self.model.new_vector()
         self.finetune_log = {}        # {domain: epochs run, epoch of the kept checkpoint, val AUC per epoch}
+        hook = getattr(self, "finetune_epoch_hook", None)       # tests: hook(domain, epoch, engine) after every epoch's pass
         for d in (self.dataset.train_dataset if domains is None else domains):
             self.model.set_weights(start_weights(d))
             print("Train on domain: {}".format(d))
@@ -91,6 +92,8 @@ class BaseModel(object):
             log = self.finetune_log[d] = {"epochs": 0, "best_epoch": -1, "val_auc": []}
             for epoch in range(self.train_config["epoch"]):
                 self.fit_domain(d, optimizer=optimizer, lr=lr, phase="finetune")
+                if hook is not None:
+                    hook(d, epoch, self.model)
                 _, val_auc = self.evaluate_domain(d, "val")
                 log["epochs"] = epoch + 1
                 log["val_auc"].append(float(val_auc))

@@ -41,12 +41,16 @@ def _domain_sizes(total, n_domain, min_size, rs):
 
 
 def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128, signal=10.0, row_scale=1.0,
-             splits=("train", "val", "test"), threads=None):
+             splits=("train", "val", "test"), threads=None, hot=None):
     """returns dict(tables, data, info).  scale < 1 shrinks users/items/rows (tests);
     row_scale < 1 shrinks only the number of rows (full-size tables, shorter epochs).
     splits: which splits to draw (bench.py binds the train split only; skipping the others changes the random
     stream of the later domains, i.e. gives a different sample of the same distribution).
-    threads: worker threads for the planted model's logits (default: up to 16 of the visible cores)."""
+    threads: worker threads for the planted model's logits (default: up to 16 of the visible cores).
+    hot: None or dict(users=K, items=K, share=s): a share s of every domain's rows draws its user / item from the
+    first K ids of the domain's subsets (a separate random stream: the other rows are the ones hot=None gives) --
+    short runs over FULL-SIZE tables in which part of the rows repeats often enough to be learnt while the rest of
+    the tables is touched rarely or never (the trained-model parity tests at the Amazon table sizes)."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     if threads is None:
@@ -56,13 +60,13 @@ def generate(shape="taobao10", batch_size=1024, seed=123, scale=1.0, emb_dim=128
             threads = min(16, os.cpu_count() or 1)
     pool = ThreadPoolExecutor(threads) if threads > 1 else None
     try:
-        return _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, tuple(splits), pool)
+        return _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, tuple(splits), pool, hot)
     finally:
         if pool is not None:
             pool.shutdown()
 
 
-def _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, splits, pool):
+def _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, splits, pool, hot=None):
     spec = dict(SHAPES[shape]) if isinstance(shape, str) else dict(shape)
     rs = np.random.RandomState(seed)
     D = spec["n_domain"]
@@ -95,6 +99,11 @@ def _generate(shape, batch_size, seed, scale, emb_dim, signal, row_scale, splits
             n = int(sizes[split][d])
             uid = users[rs.randint(0, n_u_d, n)].astype(np.int32)
             pid = items[rs.randint(0, n_i_d, n)].astype(np.int32)
+            if hot:
+                hrs = np.random.RandomState((seed * 1009 + d * 7 + ("train", "val", "test").index(split)) % (2 ** 31))
+                is_hot = hrs.uniform(size=n) < hot["share"]
+                uid = np.where(is_hot, users[hrs.randint(0, min(hot["users"], n_u_d), n)], uid).astype(np.int32)
+                pid = np.where(is_hot, items[hrs.randint(0, min(hot["items"], n_i_d), n)], pid).astype(np.int32)
             logit = np.empty(n, np.float64)
 
             def chunk(c0, uid=uid, pid=pid, logit=logit, dir_d=dir_d, bias=bias, n=n):

@@ -196,7 +196,7 @@ def mamdr_epoch(model, theta, phis, data, plan, perm_fn, batch_size, meta_lr, me
 
 
 def finetune_domains(model, data, start_weights, perm_fn, batch_size, epochs, patience, lr, auc_fn, domains=None,
-                     set_start=None):
+                     set_start=None, epoch_hook=None):
     """The finetune stage (`*_finetune` model names): model_zoo/base_model.py:41-109 (every domain restarts from the
     SAME saved weights, plain SGD with `learning_rate`: base_model.py:66-71) and, for MAMDR,
     model_zoo/specific_base_model.py:99-162 (restart from best theta (+|*) best phi_d, SGD lr 0.001: :118-125).
@@ -219,6 +219,8 @@ def finetune_domains(model, data, start_weights, perm_fn, batch_size, epochs, pa
         n_epochs = 0
         for epoch in range(epochs):
             _pass(model, data["train"], perm_fn, d, batch_size, trace, "finetune")
+            if epoch_hook is not None:                 # tests: the weights after every epoch's pass
+                epoch_hook(d, epoch, model)
             _, preds = model.evaluate(data["val"][d], batch_size)
             val_auc = float(auc_fn(data["val"][d]["label"], preds, batch_size))
             vals.append(val_auc)

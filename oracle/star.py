@@ -139,7 +139,8 @@ def loss_and_grads(params, state, uid, pid, dom, label, emb_trainable):
     inside = ((p >= T.EPS_CLIP) & (p <= F32(1) - T.EPS_CLIP)).astype(F32)
     dlogit = ((p - y) * inside / F32(B)).astype(F32)
     hs, K = c["hs"], c["K"]
-    g = {n: np.zeros_like(params[n]) for n in sum(param_names(emb_trainable), ())}
+    big = [n for n in ("user_emb", "item_emb") if emb_trainable and T.bigtable.use_rows(params[n])]
+    g = {n: np.zeros_like(params[n]) for n in sum(param_names(emb_trainable), ()) if n not in big}
     g["wo"] = (hs[3].T @ dlogit[:, None]).astype(F32)
     g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
     dh = (dlogit[:, None] * params["wo"][:, 0][None, :]).astype(F32)
@@ -166,12 +167,13 @@ def loss_and_grads(params, state, uid, pid, dom, label, emb_trainable):
     E = params["domain_emb"].shape[1]
     g["domain_emb"][d] = np.sum(dx[:, 2 * E:], axis=0, dtype=np.float64).astype(F32)
     if emb_trainable:
-        gu = np.zeros_like(params["user_emb"], dtype=np.float64)
-        np.add.at(gu, uid, dx[:, :E].astype(np.float64))
-        g["user_emb"] = gu.astype(F32)
-        gi = np.zeros_like(params["item_emb"], dtype=np.float64)
-        np.add.at(gi, pid, dx[:, E:2 * E].astype(np.float64))
-        g["item_emb"] = gi.astype(F32)
+        for name, ids, cols in (("user_emb", uid, slice(0, E)), ("item_emb", pid, slice(E, 2 * E))):
+            if name in big:       # the same dense gradient (zero rows included), held sparsely: oracle/bigtable.py
+                g[name] = T.bigtable.RowGrad(params[name], ids, dx[:, cols], 0.0)
+                continue
+            gt = np.zeros_like(params[name], dtype=np.float64)
+            np.add.at(gt, ids, dx[:, cols].astype(np.float64))
+            g[name] = gt.astype(F32)
     return loss, g, p, c
 
 

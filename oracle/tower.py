@@ -20,7 +20,7 @@ restates their published algorithms:
 """
 import numpy as np
 
-from . import rng
+from . import bigtable, rng
 
 F32 = np.float32
 EPS_CLIP = F32(1e-7)        # K.epsilon()
@@ -78,7 +78,7 @@ def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64)
 
 
 def flatten(params, names):
-    return np.concatenate([params[n].ravel() for n in names]).astype(F32)
+    return np.concatenate([bigtable.densify(params[n]).ravel() for n in names]).astype(F32)
 
 
 def unflatten(vec, params, names):
@@ -110,7 +110,7 @@ def bce_per_row(p, y):
 
 
 def table_sumsq(table):
-    return F32(np.sum(np.square(table, dtype=F32), dtype=np.float64))
+    return bigtable.table_sumsq(table)
 
 
 def reg_loss(params, frozen_sumsq=None, deepfm=False):
@@ -226,12 +226,14 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
     gd = onehot.T @ dh[:, 2 * E:3 * E].astype(np.float64)
     g["domain_emb"] = (gd.astype(F32) + two_l2 * params["domain_emb"]).astype(F32)
     if emb_trainable:
-        gu = np.zeros_like(params["user_emb"], dtype=np.float64)
-        np.add.at(gu, uid, dh[:, 0:E].astype(np.float64))
-        g["user_emb"] = (gu.astype(F32) + two_l2 * params["user_emb"]).astype(F32)
-        gi = np.zeros_like(params["item_emb"], dtype=np.float64)
-        np.add.at(gi, pid, dh[:, E:2 * E].astype(np.float64))
-        g["item_emb"] = (gi.astype(F32) + two_l2 * params["item_emb"]).astype(F32)
+        for name, ids, cols in (("user_emb", uid, slice(0, E)), ("item_emb", pid, slice(E, 2 * E))):
+            if bigtable.use_rows(params[name]):
+                # the same dense gradient, held as (touched rows, sums, 2 l2): oracle/bigtable.py
+                g[name] = bigtable.RowGrad(params[name], ids, dh[:, cols], two_l2)
+                continue
+            gt = np.zeros_like(params[name], dtype=np.float64)
+            np.add.at(gt, ids, dh[:, cols].astype(np.float64))
+            g[name] = (gt.astype(F32) + two_l2 * params[name]).astype(F32)
     return loss, g, p
 
 
@@ -267,12 +269,18 @@ class Optimizer(object):
         for n in self.names:
             gr = grads[n]
             m, v = self.m[n], self.v[n]
+            if isinstance(gr, bigtable.RowGrad):
+                bigtable.adam_rows(params[n], m, v, gr, alpha, omb1, omb2, ADAM_EPS)
+                continue
             m += ((gr - m) * omb1).astype(F32)
             v += ((gr * gr - v) * omb2).astype(F32)
             params[n] -= ((m * alpha) / (np.sqrt(v, dtype=F32) + ADAM_EPS)).astype(F32)
 
     def sgd(self, params, grads, lr):
         for n in self.names:
+            if isinstance(grads[n], bigtable.RowGrad):
+                bigtable.sgd_rows(params[n], grads[n], F32(lr))
+                continue
             params[n] -= (grads[n] * F32(lr)).astype(F32)
 
 

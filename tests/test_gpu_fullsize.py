@@ -141,3 +141,185 @@ def test_taobao30_bs4096_full_epoch_auc_parity():
     """BASELINE.json configs[3] / north_star target: 30 domains, 394,805 train rows, bs 4096 (slab path), 1,501
     inner steps; meta lr 0.5 as above (at the config's 0.1 one epoch leaves the oracle at AUC ~0.57)."""
     run_case("taobao30", 4096, meta_lr=0.5)
+
+
+# ------------------------------------------------------------------ configs[2] and configs[4]: trainable FULL-SIZE tables
+def _bind_splits(eng, g, domains, splits=("train", "val")):
+    for split in splits:
+        for d in domains:
+            c = g["data"][split][d]
+            eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
+
+
+def _perm_stream(sizes, base):
+    from mamdr_amd import engine
+    k = [0]
+
+    def perm_fn(d):
+        k[0] += 1
+        return engine.shuffle_perm(sizes[d], 10000, base + k[0])
+    return perm_fn
+
+
+def test_amazon6_deepfm_dn_epoch_trainable_full_tables():
+    """BASELINE.json configs[2] on its own kernel path: deepfm_meta_domain_negotiation, Amazon-6's FULL tables
+    (445,789 + 172,653 rows x 128, trainable, N(0, 1e-4^2) as deepctr initialises them: 79.2 M parameters with their
+    Adam slots), bs 1,024 -> k_tower4<DX, FM> + [k_wgrad + k_emb_reduce + k_emb_rows] + [k_update + k_lin_sweep +
+    k_emb_catchup], the lazy table Adam with its forced flushes.  One Domain Negotiation epoch
+    (model_zoo/domain_negotiation.py:53-88: sequential passes over all 6 domains from theta, theta += beta (theta~ - theta))
+    of 160+ inner steps on a row sample of the config's data in which 70 % of the rows come from 2,000 users / 1,000
+    items per domain (learnable in one epoch) and the rest from the whole per-domain subsets (rows seen once or never:
+    long replay gaps; most of the 618 K rows are only ever moved by the regulariser, as TF1's dense Adam moves them).
+    Oracle: oracle/loops.dn_epoch on oracle/tower.OracleModel -- dense Adam over every row of both tables every step
+    (oracle/bigtable.py).  Asserted: equal traces, >= 4 forced flushes inside the passes, the slab step path,
+    |AUC_hip - AUC_oracle| <= 1e-3 on every domain's validation split, oracle mean AUC > 0.6."""
+    from mamdr_amd import engine, meta, synthetic
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    batch, steps = 1024, 160
+    shape = synthetic.SHAPES["amazon6"]
+    g = synthetic.generate("amazon6", batch_size=batch, seed=123, row_scale=steps * batch / shape["n_train"],
+                           splits=("train", "val"), hot=dict(users=2000, items=1000, share=0.7))
+    D = g["n_domain"]
+    assert (g["n_user"], g["n_item"]) == (445789, 172653)
+    params = otower.init_params(np.random.RandomState(1024), g["n_user"], g["n_item"], D, pretrained=False)
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=0.5, emb_trainable=True, tower="deepfm")
+    _bind_splits(eng, g, range(D))
+    eng.set_weights(eng.pack(params))
+    model = otower.OracleModel(params, emb_trainable=True, dropout=0.5, lr=1e-3, dropout_seed=eng.dropout_seed,
+                               tower="deepfm")
+    sizes = [eng.n_rows(d, "train") for d in range(D)]
+    seq = [int(d) for d in np.random.RandomState(5).permutation(D)]
+    theta_o = model.get_flat().copy()
+    t0 = time.time()
+    trace_o = oloops.dn_epoch(model, theta_o, g["data"]["train"], seq, _perm_stream(sizes, 500), batch, 0.5)
+    secs = time.time() - t0
+    theta_g = eng.get_weights()
+    t0 = time.time()
+    trace_g = meta.dn_epoch(eng, theta_g, seq, _perm_stream(sizes, 500), batch, lr=1e-3, meta_lr=0.5)
+    torch.cuda.synchronize()
+    gsecs = time.time() - t0
+    assert trace_g == trace_o
+    n_steps = sum(t[2] for t in trace_g)
+    forced = int(eng.lib.mamdr_table_flushes(eng.ctx, 1))
+    print("amazon6 deepfm DN bs %d: %d domain-steps (%d forced flushes, %d in all); oracle %.1f s, hip %.2f s" % (
+        batch, n_steps, forced, int(eng.lib.mamdr_table_flushes(eng.ctx, 0)), secs, gsecs))
+    assert n_steps >= 150 and forced >= 4
+    assert int(eng.lib.mamdr_step_path(eng.ctx, batch)) == 0 and int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == n_steps
+    eng.set_weights(theta_g)
+    model.set_flat(theta_o)
+    worst, aucs = 0.0, []
+    for d in range(D):
+        _, auc_g = eng.evaluate(d, "val")
+        _, preds = model.evaluate(g["data"]["val"][d], batch)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch))
+        print("  domain %d: val rows %6d  AUC hip %.5f oracle %.5f  diff %+.1e" % (d, len(preds), auc_g, auc_o, auc_g - auc_o))
+        worst = max(worst, abs(auc_g - auc_o))
+        aucs.append(auc_o)
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+    assert float(np.mean(aucs)) > 0.6, aucs
+    # the trained tables themselves (theta after the outer update), all 618 K rows: TF1's dense Adam moved every one
+    w_g = eng.unpack(theta_g)
+    for name in ("user_emb", "item_emb"):
+        a, o = w_g[name].reshape(-1, 128), model.params[name]
+        diff = np.abs(a - o)
+        print("  %s: |hip - oracle| median %.1e, 99.9 %% %.1e, max %.1e (|oracle| median %.1e)" % (
+            name, float(np.median(diff)), float(np.quantile(diff[::7], 0.999)), float(diff.max()),
+            float(np.median(np.abs(o)))))
+        assert np.isfinite(a).all() and float(np.median(diff)) < 1e-6
+    print("  worst |dAUC| %.2e, mean oracle AUC %.4f" % (worst, float(np.mean(aucs))))
+    eng.close()
+
+
+class _StarMeta(object):
+    """oracle Star model seen through its meta parameters (what the MAMDR loop reads and assigns, maml.py:153-194)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def get_flat(self):
+        return self.m.get_flat(meta_only=True)
+
+    def set_flat(self, vec):
+        self.m.set_flat(vec, meta_only=True)
+
+    def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
+        assert accumulate_into is None
+        return self.m.train_pass(data, perm, batch_size, max_steps)
+
+
+def test_amazon13_star_mamdr_epoch_trainable_full_tables():
+    """BASELINE.json configs[4] on its own kernel path: star_meta_mamdr, Amazon-13's FULL tables (502,222 + 215,403
+    rows x 128, trainable: 91.9 M parameters inside theta / phi_d), bs 8,192 -> k_star_stats / k_star_prep +
+    k_tower<train, 384> + PartitionedNorm backward + [k_wgrad + k_emb_reduce + k_emb_rows] + [k_star_update +
+    k_emb_catchup], lazy table Adam, lazy per-domain slices (k_star_catchup).  One DN + DR meta-epoch
+    (model_zoo/mamdr.py:41-108) on the four largest domains of a row sample (80 % of the rows from 3,000 users / 1,500
+    items per domain), theta / phi over the reference's meta filter ["emb", "kernel_shared", "bias_shared"]
+    (config/Taobao-10/star_taobao.json:37-41, maml.py:153-179; PartitionedNorm's gamma / beta, the specific kernels and
+    the output unit stay live in the model, Star/partitioned_norm.py:102-203), 2 sampled support domains + the query.
+    Oracle: oracle/loops.mamdr_epoch on oracle/star.OracleStar with dense Adam over every table row and every
+    per-domain slice each step.  Asserted: equal traces, forced flushes, per-domain val AUC of theta + phi_d within the
+    plain 1e-3, oracle mean AUC > 0.6."""
+    from mamdr_amd import engine, meta, synthetic
+    from oracle import star as ostar
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    batch = 8192
+    shape = synthetic.SHAPES["amazon13"]
+    g = synthetic.generate("amazon13", batch_size=batch, seed=123, row_scale=90000 * 13 / shape["n_train"] / 3,
+                           splits=("train", "val"), hot=dict(users=3000, items=1500, share=0.8))
+    D = g["n_domain"]
+    assert (g["n_user"], g["n_item"], D) == (502222, 215403, 13)
+    all_sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    doms = sorted(range(D), key=lambda d: -all_sizes[d])[:4]
+    params = ostar.init_params(np.random.RandomState(1024), g["n_user"], g["n_item"], D)
+    eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=0.0, emb_trainable=True, tower="star")
+    _bind_splits(eng, g, doms)
+    eng.set_weights(eng.pack(params))
+    model = ostar.OracleStar(params, emb_trainable=True, lr=1e-3)
+    wrapped = _StarMeta(model)
+    theta_o = wrapped.get_flat().copy()
+    assert theta_o.size == eng.n_meta < eng.n_params
+    prs = np.random.RandomState(3)
+    plan = {"seq": [doms[i] for i in prs.permutation(4)], "dr": []}
+    for q in [doms[i] for i in prs.permutation(4)]:
+        plan["dr"].append((q, [doms[i] for i in prs.permutation(4) if doms[i] != q][:2] + [q]))
+    phis_o = {d: np.zeros_like(theta_o) for d in doms}
+    theta_g = torch.from_numpy(theta_o).to(eng.device)
+    phis_g = {d: eng.new_vector(meta=True) for d in doms}
+    t0 = time.time()
+    trace_o = oloops.mamdr_epoch(wrapped, theta_o, phis_o, g["data"]["train"], plan, _perm_stream(all_sizes, 900), batch, 0.5)
+    secs = time.time() - t0
+    t0 = time.time()
+    trace_g = meta.mamdr_epoch(eng, theta_g, phis_g, plan, _perm_stream(all_sizes, 900), batch, lr=1e-3, meta_lr=0.5)
+    torch.cuda.synchronize()
+    gsecs = time.time() - t0
+    assert trace_g == trace_o
+    n_steps = sum(t[2] for t in trace_g)
+    forced = int(eng.lib.mamdr_table_flushes(eng.ctx, 1))
+    print("amazon13 star MAMDR bs %d: %d domain-steps in %d passes (%d forced flushes); oracle %.1f s, hip %.2f s" % (
+        batch, n_steps, len(trace_g), forced, secs, gsecs))
+    assert n_steps >= 150 and forced >= 4 and int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == n_steps
+    assert int(eng.lib.mamdr_step_path(eng.ctx, batch)) == 0
+    merged = eng.new_vector(meta=True)
+    worst, aucs = 0.0, []
+    for d in doms:
+        eng.merge(merged, theta_g, phis_g[d], "plus")
+        eng.set_weights(merged)
+        _, auc_g = eng.evaluate(d, "val")
+        wrapped.set_flat(oouter.merge(theta_o, phis_o[d], "plus"))
+        _, preds = model.evaluate(g["data"]["val"][d], batch)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch))
+        print("  domain %2d: val rows %6d  AUC hip %.5f oracle %.5f  diff %+.1e" % (d, len(preds), auc_g, auc_o, auc_g - auc_o))
+        worst = max(worst, abs(auc_g - auc_o))
+        aucs.append(auc_o)
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+    assert float(np.mean(aucs)) > 0.6, aucs
+    # PartitionedNorm's moving statistics of the trained domains (non-trainable state, outside theta / phi)
+    aux = eng.aux_state()
+    for d in doms:
+        np.testing.assert_allclose(aux["mov_mean"][d], model.state["mov_mean"][d], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(aux["mov_var"][d], model.state["mov_var"][d], rtol=1e-3, atol=1e-6)
+    np.testing.assert_array_equal(aux["steps"], model.state["steps"])
+    print("  worst |dAUC| %.2e, mean oracle AUC %.4f" % (worst, float(np.mean(aucs))))
+    eng.close()

@@ -183,12 +183,20 @@ def test_epoch_shuffles_equal_per_pass_shuffles():
 @pytest.mark.parametrize("name", ["mlp_meta_domain_negotiation_finetune", "mlp_meta_mamdr_finetune"])
 def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
     """the finetune stage on the HIP engine against oracle/loops.finetune_domains (a restatement of
-    base_model.py:41-109 / specific_base_model.py:99-162: per-domain SGD restart, Keras EarlyStopping with
-    min_delta 1e-4, best-only checkpoint, test from the kept weights).  Both sides start from the SAME weights (the
-    HIP run's best checkpoint, copied into the oracle), the same shuffles and dropout masks.  Bars: the val AUC of
-    every epoch both sides ran and the test AUC within 1e-3; the same number of epochs and the same kept checkpoint
-    wherever the oracle's own decision is not within 2e-4 of a tie (an early-stopping comparison closer than that is
-    decided by rounding on either side)."""
+    base_model.py:41-109 / specific_base_model.py:99-162: per-domain SGD restart -- lr 0.001 hard-coded for MAMDR at
+    specific_base_model.py:120, `learning_rate` otherwise --, Keras EarlyStopping with min_delta 1e-4, best-only
+    checkpoint, test from the kept weights).  Both sides start from the SAME weights (the HIP run's best checkpoint,
+    copied into the oracle), the same shuffles and dropout masks; half of Taobao-10's rows at bs 256 (30 - 60 SGD steps
+    per domain and epoch), up to 6 finetune epochs, patience 2.
+    Compared after EVERY finetune epoch of every domain: (1) the WEIGHTS -- the displacement from the domain's start
+    weights, per tensor, relative L2 <= 2e-3 (+ the rounding of k SGD steps on the stored weights) and all but 1e-3 of
+    the elements within 1e-3 of the oracle's displacement; (2) the val AUC, within 1e-3 (north_star), measured far
+    tighter (printed).  (3) Early stopping: SGD at 0.001 moves a trained model's val AUC by ~1e-4 per epoch, so the
+    stop / keep decisions are comparisons between nearly equal numbers; they can only differ between two runs whose
+    per-epoch AUCs differ by delta if some comparison the oracle made was closer than 2 delta.  With delta_d = the
+    largest |AUC_hip - AUC_oracle| measured over domain d's epochs (+ 1e-7 for the fp32 AUC sum), every domain whose
+    oracle decisions all have margins > 2 delta_d MUST run the same epochs and keep the same checkpoint -- asserted,
+    and at least half of the domains must be such clear-cut cases.  (4) test AUC from the kept weights within 1e-3."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     from mamdr_amd import cli, plan as mplan
@@ -198,17 +206,20 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
     from oracle import outer as oouter
     from oracle import rng as orng
     from oracle import tower as otower
+    BS, FT_EPOCHS, PATIENCE = 256, 6, 2
     with open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
         cfg = copy.deepcopy(json.load(f))
     cfg["model"]["name"] = name
-    cfg["train"].update(epoch=4, patience=2, sample_num=2, meta_learning_rate=0.5, learning_rate=0.02,
+    cfg["train"].update(epoch=2, patience=PATIENCE, sample_num=2, meta_learning_rate=0.5, learning_rate=0.02,
                         result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
-    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.08)
+    cfg["dataset"].update(batch_size=BS, synthetic="taobao10", synthetic_scale=0.5)
     ds = mds.MultiDomainDataset(cfg["dataset"])
     model = cli.build_model(cfg, ds)
     model.train()
     model.load_model(model.checkpoint_path)
     eng = model.model
+    base = model.base_model if hasattr(model, "base_model") else model
+    base.train_config["epoch"] = FT_EPOCHS          # the finetune stage reads the same key (base_model.py:84)
     # the oracle twin: same tensors, same dropout stream position
     named = eng.unpack(eng.get_weights())
     named["user_emb"], named["item_emb"] = ds.user_emb, ds.item_emb
@@ -219,8 +230,11 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
                               dropout_seed=eng.dropout_seed)
     twin.step = int(eng.lib.mamdr_dropout_steps(eng.ctx))
     counter0 = model.shuffler.counter
+    n_flat = twin.get_flat().size                       # (the engine's vectors carry up to 3 floats of padding)
+    snaps_h, snaps_o = {}, {}
+    base.finetune_epoch_hook = lambda d, e, engine: snaps_h.__setitem__((d, e), engine.get_weights().cpu().numpy()[:n_flat])
     _, _, d_loss, d_auc = model.separate_train_val_test(init_parms=False)
-    log = model.base_model.finetune_log if hasattr(model, "base_model") else model.finetune_log
+    log = base.finetune_log
     sizes = {d: v["n_data"] for d, v in ds.train_dataset.items()}
     shuf = mplan.PassShuffler(sizes, ds.shuffle_buffer_size, ds.seed, shuffle_fn=orng.shuffle_perm)
     shuf.counter = counter0
@@ -228,19 +242,38 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
                                                               ("test", ds.test_dataset))}
     if "mamdr" in name:
         bs_, bd_ = model.best_shared_weights.cpu().numpy(), {d: w.cpu().numpy() for d, w in model.best_domain_weights.items()}
-        n_flat = twin.get_flat().size                   # (the engine's vectors carry up to 3 floats of padding)
         start = lambda d: oouter.merge(bs_, bd_[d], "plus")[:n_flat]
         lr = 0.001
     else:
         w0 = twin.get_flat().copy()
         start = lambda d: w0
         lr = 0.02
-    want, _ = oloops.finetune_domains(twin, data, start, shuf, 256, 4, 2, lr, oauc.auc500)
-    decided = 0
+    want, _ = oloops.finetune_domains(twin, data, start, shuf, BS, FT_EPOCHS, PATIENCE, lr, oauc.auc500,
+                                      epoch_hook=lambda d, e, m: snaps_o.__setitem__((d, e), m.get_flat().copy()))
+    seg = [(n, o, c) for n, (o, c) in eng.segments.items() if o + c <= n_flat]
+    decided, worst_rel, worst_auc = 0, 0.0, 0.0
     for d in sorted(want):
         o, h = want[d], log[d]
         k = min(o["epochs"], h["epochs"])
-        assert np.abs(np.array(o["val_auc"][:k]) - np.array(h["val_auc"][:k])).max() <= 1e-3, (d, o, h)
+        w_start = start(d)
+        steps = -(-sizes[d] // BS)
+        for e in range(k):
+            wh, wo = snaps_h[(d, e)], snaps_o[(d, e)]
+            for nme, off, cnt in seg:
+                dh_, do_, ws = wh[off:off + cnt] - w_start[off:off + cnt], wo[off:off + cnt] - w_start[off:off + cnt], \
+                    w_start[off:off + cnt]
+                nrm = float(np.linalg.norm(do_))
+                # k SGD steps round the stored weights k times: a random walk of half-ulps on either side
+                floor = 6e-8 * np.sqrt(2.0 * steps * (e + 1)) * float(np.linalg.norm(ws)) + 1e-12
+                err = float(np.linalg.norm(dh_ - do_))
+                worst_rel = max(worst_rel, max(0.0, err - floor) / max(nrm, 1e-30))
+                assert err <= 2e-3 * nrm + floor, (d, e, nme, err, nrm, floor)
+                tol = 1e-3 * np.abs(do_) + 6e-8 * np.sqrt(2.0 * steps * (e + 1)) * np.maximum(np.abs(ws), 1e-3) * 4
+                assert float(np.mean(np.abs(dh_ - do_) > tol)) <= 1e-3, (d, e, nme)
+        dv = np.abs(np.array(o["val_auc"][:k]) - np.array(h["val_auc"][:k]))
+        worst_auc = max(worst_auc, float(dv.max()))
+        assert dv.max() <= 1e-3, (d, o, h)
+        delta = float(dv.max()) + 1e-7
         # how close the oracle's own stop / keep decisions came to a tie
         v = o["val_auc"]
         margins = []
@@ -250,15 +283,18 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
             if a - 1e-4 > best:
                 best = a
         ck_margin = min([abs(a - b) for i, a in enumerate(v) for b in v[:i]] or [1.0])
-        if min(margins) > 2e-4 and ck_margin > 2e-4:
+        clear = min(margins) > 2 * delta and ck_margin > 2 * delta
+        print("finetune domain %d: epochs hip %d oracle %d, kept %d / %d, max |dAUC| %.1e, closest decision %.1e%s" % (
+            d, h["epochs"], o["epochs"], h["best_epoch"], o["best_epoch"], float(dv.max()), min(min(margins), ck_margin),
+            "" if clear else " (tie within 2 delta)"))
+        if clear:
             decided += 1
             assert (h["epochs"], h["best_epoch"]) == (o["epochs"], o["best_epoch"]), (d, o, h)
-        # the test AUC comes from the kept checkpoint: within 1e-3 also where a near-tie kept another epoch's weights
-        # (a near-tie means the candidates' val AUCs agree to 2e-4; the bar still holds the test AUC to 1e-3)
+        # the test AUC comes from the kept checkpoint: within 1e-3 also where a tie kept another epoch's weights
         assert abs(d_auc[d] - o["test_auc"]) <= 1e-3, (d, d_auc[d], o["test_auc"], o, h)
-    print("finetune parity: %d of %d domains with a clear-cut early-stopping history" % (decided, len(want)))
-    if "mamdr" not in name:       # (SGD at the hard-coded 0.001 of the MAMDR finetune moves the val AUC by < 2e-4 per epoch)
-        assert decided >= len(want) // 2
+    print("finetune parity (%s): %d of %d domains clear-cut and identical; worst per-tensor displacement error %.1e (relative), "
+          "worst per-epoch |dAUC| %.1e" % (name, decided, len(want), worst_rel, worst_auc))
+    assert decided >= (len(want) + 1) // 2
 
 
 def otower_shape(name, v, ds):

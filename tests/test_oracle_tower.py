@@ -175,3 +175,48 @@ def test_uncertainty_weighted_loss_gradients():
     want[1] = -2 * mean_bce / var ** 3 + 1 / var
     np.testing.assert_allclose(g_u["log_var"], want, rtol=1e-5, atol=1e-7)
     assert tower.param_names(False, False, True)[-1] == "log_var"
+
+
+def test_rowgrad_adam_is_bitwise_the_dense_formula(monkeypatch):
+    """oracle/bigtable.py (the table-sized tensors' Adam / SGD in row blocks on a thread pool, the gradient held as
+    touched rows + regulariser coefficient) against the literal dense formulation of oracle/tower.py and
+    oracle/star.py: same bits in every parameter and both Adam slots after Adam steps, an SGD step and a
+    flatten() of the gradient (accumulate passes), with rows repeated inside a batch and rows no batch touches."""
+    from oracle import bigtable, star
+
+    def run(big):
+        monkeypatch.setattr(bigtable, "MIN_ELEMENTS", 1 if big else 1 << 40)
+        out = {}
+        for kind in ("deepfm", "star"):
+            rs = np.random.RandomState(11)
+            n_user, n_item, D, B = 5000, 3000, 3, 96
+            if kind == "star":
+                p = star.init_params(rs, n_user, n_item, D)
+                model = star.OracleStar(p, emb_trainable=True, lr=1e-3)
+            else:
+                p = tower.init_params(rs, n_user, n_item, D, pretrained=False)
+                p["user_emb"] *= 300
+                p["item_emb"] *= 300
+                model = tower.OracleModel(p, emb_trainable=True, dropout=0.5, lr=1e-3, tower="deepfm")
+            for step in range(6):
+                uid = rs.randint(0, n_user, B).astype(np.int32)
+                uid[:8] = uid[8:16]
+                pid = rs.randint(0, 50, B).astype(np.int32)             # heavy repeats
+                dom = np.full(B, step % D, np.int32)
+                y = (rs.rand(B) < 0.4).astype(F32)
+                model.use_sgd = step == 4
+                model.train_on_batch(uid, pid, dom, y)
+            out[kind] = [model.params[n].copy() for n in model.names] + [model.opt.m[n].copy() for n in model.names] + \
+                        [model.opt.v[n].copy() for n in model.names]
+            if kind == "deepfm":
+                acc = np.zeros(model.get_flat().size, F32)
+                model.accumulate_on_batch(acc, uid, pid, dom, y)
+                out[kind].append(acc)
+                out[kind].append(np.array([model.evaluate({"uid": uid, "pid": pid, "domain": dom, "label": y}, 64)[0]]))
+        return out
+
+    dense, rows = run(False), run(True)
+    for kind in dense:
+        for a, b in zip(dense[kind], rows[kind]):
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), kind
+    assert np.abs(dense["deepfm"][0]).max() > 0
