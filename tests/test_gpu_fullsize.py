@@ -258,7 +258,7 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
     (config/Taobao-10/star_taobao.json:37-41, maml.py:153-179; PartitionedNorm's gamma / beta, the specific kernels and
     the output unit stay live in the model, Star/partitioned_norm.py:102-203), 2 sampled support domains + the query.
     Oracle: oracle/loops.mamdr_epoch on oracle/star.OracleStar with dense Adam over every table row and every
-    per-domain slice each step.  Asserted: equal traces, forced flushes, per-domain val AUC of theta + phi_d within the
+    per-domain slice each step.  Asserted: equal traces, the table replays between the passes, per-domain val AUC of theta + phi_d within the
     plain 1e-3, oracle mean AUC > 0.6."""
     from mamdr_amd import engine, meta, synthetic
     from oracle import star as ostar
@@ -273,6 +273,16 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
     all_sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
     doms = sorted(range(D), key=lambda d: -all_sizes[d])[:4]
     params = ostar.init_params(np.random.RandomState(1024), g["n_user"], g["n_item"], D)
+    # PartitionedNorm's gamma / beta and the biases off their special initial values (1 / 0), as in
+    # tests/test_gpu_parity.py::make_star_problem: with beta = 0 the normalised domain columns (constant over a
+    # single-domain batch) are pure rounding residue, their kernel rows' gradients are noise that Adam normalises to
+    # steps of +- lr -- a random walk that differs between any two fp32 evaluations (measured with this test: the tensors
+    # outside theta / phi 0.8 % apart after one epoch, one domain's AUC 2e-3 off, tools/diag/star13_phases.py)
+    irs = np.random.RandomState(7)
+    for n_ in ("pn_gamma_shared", "pn_gamma_spec"):
+        params[n_] = (params[n_] + irs.standard_normal(params[n_].shape) * 0.2).astype(np.float32)
+    for n_ in ("pn_beta_shared", "pn_beta_spec", "bs0", "bs1", "bs2", "bd0", "bd1", "bd2", "gb"):
+        params[n_] = (irs.standard_normal(params[n_].shape) * 0.05).astype(np.float32)
     eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=0.0, emb_trainable=True, tower="star")
     _bind_splits(eng, g, doms)
     eng.set_weights(eng.pack(params))
@@ -296,10 +306,12 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
     gsecs = time.time() - t0
     assert trace_g == trace_o
     n_steps = sum(t[2] for t in trace_g)
-    forced = int(eng.lib.mamdr_table_flushes(eng.ctx, 1))
-    print("amazon13 star MAMDR bs %d: %d domain-steps in %d passes (%d forced flushes); oracle %.1f s, hip %.2f s" % (
-        batch, n_steps, len(trace_g), forced, secs, gsecs))
-    assert n_steps >= 150 and forced >= 4 and int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == n_steps
+    # (a pass of this plan has at most 15 steps and the DR loop reads / replaces the live rows after every support
+    # step, so the replays happen there -- mamdr_sync_tables -- before the 32-step period can force one)
+    flushes = int(eng.lib.mamdr_table_flushes(eng.ctx, 0))
+    print("amazon13 star MAMDR bs %d: %d domain-steps in %d passes (%d table flushes); oracle %.1f s, hip %.2f s" % (
+        batch, n_steps, len(trace_g), flushes, secs, gsecs))
+    assert n_steps >= 150 and flushes >= 8 and int(eng.lib.mamdr_optimizer_steps(eng.ctx)) == n_steps
     assert int(eng.lib.mamdr_step_path(eng.ctx, batch)) == 0
     merged = eng.new_vector(meta=True)
     worst, aucs = 0.0, []

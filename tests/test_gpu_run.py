@@ -189,8 +189,8 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
     copied into the oracle), the same shuffles and dropout masks; half of Taobao-10's rows at bs 256 (30 - 60 SGD steps
     per domain and epoch), up to 6 finetune epochs, patience 2.
     Compared after EVERY finetune epoch of every domain: (1) the WEIGHTS -- the displacement from the domain's start
-    weights, per tensor, relative L2 <= 2e-3 (+ the rounding of k SGD steps on the stored weights) and all but 1e-3 of
-    the elements within 1e-3 of the oracle's displacement; (2) the val AUC, within 1e-3 (north_star), measured far
+    weights, per tensor, relative L2 <= 2e-3 (+ the rounding of k SGD steps on the stored weights) and all but 1 % of
+    the elements within 5e-3 of the oracle's displacement (+ 5e-3 of the tensor's RMS displacement); (2) the val AUC, within 1e-3 (north_star), measured far
     tighter (printed).  (3) Early stopping: SGD at 0.001 moves a trained model's val AUC by ~1e-4 per epoch, so the
     stop / keep decisions are comparisons between nearly equal numbers; they can only differ between two runs whose
     per-epoch AUCs differ by delta if some comparison the oracle made was closer than 2 delta.  With delta_d = the
@@ -251,7 +251,7 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
     want, _ = oloops.finetune_domains(twin, data, start, shuf, BS, FT_EPOCHS, PATIENCE, lr, oauc.auc500,
                                       epoch_hook=lambda d, e, m: snaps_o.__setitem__((d, e), m.get_flat().copy()))
     seg = [(n, o, c) for n, (o, c) in eng.segments.items() if o + c <= n_flat]
-    decided, worst_rel, worst_auc = 0, 0.0, 0.0
+    decided, worst_rel, worst_auc, worst_frac = 0, 0.0, 0.0, 0.0
     for d in sorted(want):
         o, h = want[d], log[d]
         k = min(o["epochs"], h["epochs"])
@@ -268,8 +268,15 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
                 err = float(np.linalg.norm(dh_ - do_))
                 worst_rel = max(worst_rel, max(0.0, err - floor) / max(nrm, 1e-30))
                 assert err <= 2e-3 * nrm + floor, (d, e, nme, err, nrm, floor)
-                tol = 1e-3 * np.abs(do_) + 6e-8 * np.sqrt(2.0 * steps * (e + 1)) * np.maximum(np.abs(ws), 1e-3) * 4
-                assert float(np.mean(np.abs(dh_ - do_) > tol)) <= 1e-3, (d, e, nme)
+                # elementwise (the distribution behind the norm): 5e-3 of the element's own displacement + 5e-3 of the
+                # tensor's RMS displacement (an element whose gradient nearly cancels is known to the summation order's
+                # rounding, not better; a hidden unit at the relu kink gates differently on the two sides and moves its
+                # column) + the rounding of the stored weight; all but 1 % of the elements
+                tol = 5e-3 * np.abs(do_) + 5e-3 * float(np.sqrt(np.mean(np.square(do_, dtype=np.float64)))) + \
+                    6e-8 * np.sqrt(2.0 * steps * (e + 1)) * np.maximum(np.abs(ws), 1e-3) * 4
+                bad = int(np.sum(np.abs(dh_ - do_) > tol))
+                worst_frac = max(worst_frac, bad / float(cnt))
+                assert bad <= max(2, int(1e-2 * cnt)), (d, e, nme, bad, cnt)
         dv = np.abs(np.array(o["val_auc"][:k]) - np.array(h["val_auc"][:k]))
         worst_auc = max(worst_auc, float(dv.max()))
         assert dv.max() <= 1e-3, (d, o, h)
@@ -293,7 +300,8 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
         # the test AUC comes from the kept checkpoint: within 1e-3 also where a tie kept another epoch's weights
         assert abs(d_auc[d] - o["test_auc"]) <= 1e-3, (d, d_auc[d], o["test_auc"], o, h)
     print("finetune parity (%s): %d of %d domains clear-cut and identical; worst per-tensor displacement error %.1e (relative), "
-          "worst per-epoch |dAUC| %.1e" % (name, decided, len(want), worst_rel, worst_auc))
+          "largest fraction of elements beyond the elementwise bar %.1e, worst per-epoch |dAUC| %.1e" % (
+              name, decided, len(want), worst_rel, worst_frac, worst_auc))
     assert decided >= (len(want) + 1) // 2
 
 
