@@ -241,6 +241,12 @@ int mamdr_merge(float* d_dst, const float* d_theta, const float* d_phi, int32_t 
  * bit-identical to mamdr_interp(phi, w, merged, gamma) + mamdr_merge(merged, theta, phi, mode) + mamdr_copy(w, merged). */
 int mamdr_dr_advance(float* d_phi, float* d_w, float* d_merged, const float* d_theta, float gamma, int32_t mode,
                      int32_t assign_model, int64_t n, void* stream);
+/* The same on the context's LIVE weights, range [meta_off, meta_off + n) of the bound vector (d_w = live + meta_off):
+ * what a caller gets from mamdr_sync_tables(ctx) followed by mamdr_dr_advance(.., live + meta_off, ..) -- the library
+ * brings the live state up to date itself, and a domain-table step the fused step path left pending is materialised
+ * inside the same launch.  Same bits. */
+int mamdr_dr_advance_live(mamdr_ctx* ctx, float* d_phi, float* d_merged, const float* d_theta, float gamma, int32_t mode,
+                          int32_t assign_model, int64_t meta_off, int64_t n);
 /* dst[i] = a[i] - b[i]   (mamdr.py:168-171) */
 int mamdr_sub(float* d_dst, const float* d_a, const float* d_b, int64_t n, void* stream);
 /* acc[i] += (a[i] - b[i]) [* shared[i]] / divisor   (reptile.py:134-137 with shared NULL,
@@ -283,6 +289,18 @@ int mamdr_shuffle_perms(int32_t n_passes, const int64_t* h_n, int64_t buffer_siz
  *     mamdr_profile_read synchronises the stream, returns the summed milliseconds
  *     and launch count since the last reset. */
 int mamdr_profile_enable(mamdr_ctx* ctx, int32_t enable);
+/* A HINT about the next calls of mamdr_train_steps(_n): they will run these passes -- (domain, permutation, rows of the
+ * pass; h_pass_rows null or an entry < 0: the whole split) at batch size `batch` -- in this order.  Where a call would
+ * resolve and gather its pass's rows itself (frozen tables on the k_wgrad_adam path: k_pass_prep, once per call) the
+ * library gathers all of them in ONE launch now, and each of those calls finds its rows ready; it matches a call by
+ * (domain, d_perm pointer, pass rows, batch), skipping entries in between, and forgets the hint when a call matches
+ * none (that call then gathers as before).  The permutations and the bound columns must not change in between.  At
+ * most 16 passes per hint (more: the first 16); everywhere else this is a no-op.  Same rows, same bits.  No reference
+ * counterpart: the reference's tf.data iterator re-reads the csv files on every pass (utils/dataset.py:20-38).
+ * mamdr_pregather_hits: how many calls found their pass gathered (tests). */
+int mamdr_pregather_passes(mamdr_ctx* ctx, int32_t n_passes, const int32_t* h_domains, const int32_t* const* h_d_perms,
+                           const int64_t* h_pass_rows, int32_t batch);
+int64_t mamdr_pregather_hits(const mamdr_ctx* ctx);
 /* which kernels a training step of `batch` rows launches (for reports; no reference counterpart):
  *   0  tower -> k_wgrad (split-K slabs) -> k_update
  *   1  [k_pass_prep once per call] tower -> k_wgrad_adam (weight gradients + optimiser step in one launch;

@@ -81,6 +81,8 @@ SIGNATURES = {
     "mamdr_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_optimizer_steps": (_I64, [_VP]),
     "mamdr_table_flushes": (_I64, [_VP, _I32]),
+    "mamdr_pregather_passes": (_I32, [_VP, _I32, _VP, _VP, _VP, _I32]),
+    "mamdr_pregather_hits": (_I64, [_VP]),
     "mamdr_sync_tables": (C.c_int, [_VP]),
     "mamdr_bind_accumulator": (C.c_int, [_VP, _VP]),
     "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "mamdr_moving_average": (C.c_int, [_VP, _VP, _VP, _F, _F, _I64, _VP]),
     "mamdr_merge": (C.c_int, [_VP, _VP, _VP, _I32, _I64, _VP]),
     "mamdr_dr_advance": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I32, _I32, _I64, _VP]),
+    "mamdr_dr_advance_live": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I32, _I32, _I64, _I64]),
     "mamdr_sub": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
     "mamdr_accumulate": (C.c_int, [_VP, _VP, _VP, _VP, _F, _I64, _VP]),
     "mamdr_apply_accumulated": (C.c_int, [_VP, _VP, _F, _F, _I64, _VP]),

@@ -607,12 +607,10 @@ void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live
 // the weights).  One wave per position: every lane resolves the position (the same addresses: broadcast loads),
 // lane l copies float4 l of the 1-KB [user | item] row.  Replaces, per step, the tower kernel's chain of three
 // dependent loads (perm -> uid / pid -> table rows) and its copy of x into the activation workspace.
-__global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
-    if ((int)blockIdx.x >= a.n_prep_wgs) {       // the call's transposed weight copies (k_transpose_w) in the same launch
-        transpose_w_elem(a.tw_dense, a.tw_L, a.tw_wT, ((int)blockIdx.x - a.n_prep_wgs) * 256 + (int)threadIdx.x);
-        return;
-    }
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+// position i of a pass (one wave): see k_pass_prep
+template <typename P>
+__device__ __forceinline__ void pass_prep_row(const P& a, const float* user_tab, const float* item_tab, int n_user, int n_item,
+                                              int n_domain, int64_t pos0, float* xpre, int32_t* pdom, float* plabel, int64_t i) {
     const int lane = threadIdx.x & 63;
     if (i >= a.n) {
         // 16 more rows: k_wgrad_adam contracts whole 16-row tiles counted from EVERY step's own first row (against
@@ -620,27 +618,48 @@ __global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
         // 16 the last step's tile ends up to 15 rows past the call's last row, wherever that row sits
         // (and carry the pass's domain: a tower tile compares all of its rows' domains with the caller's)
         if (i < a.n + 16) {
-            *reinterpret_cast<f32x4*>(a.xpre + (size_t)i * (2 * EMB) + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(xpre + (size_t)i * (2 * EMB) + 4 * lane) = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (lane == 0) {
-                a.pdom[i] = a.pad_dom;
-                a.plabel[i] = 0.f;
+                pdom[i] = a.pad_dom;
+                plabel[i] = 0.f;
             }
         }
         return;
     }
-    int64_t src = a.perm ? (int64_t)a.perm[a.pos0 + i] : a.pos0 + i;
+    int64_t src = a.perm ? (int64_t)a.perm[pos0 + i] : pos0 + i;
     src = src < 0 ? 0 : (src >= a.n_rows_split ? a.n_rows_split - 1 : src);
     int u = a.uid[src], it = a.pid[src];
-    u = u < 0 ? 0 : (u >= a.n_user ? a.n_user - 1 : u);
-    it = it < 0 ? 0 : (it >= a.n_item ? a.n_item - 1 : it);
-    const float* row = lane < 32 ? a.user_tab + (size_t)u * EMB + 4 * lane : a.item_tab + (size_t)it * EMB + 4 * (lane - 32);
+    u = u < 0 ? 0 : (u >= n_user ? n_user - 1 : u);
+    it = it < 0 ? 0 : (it >= n_item ? n_item - 1 : it);
+    const float* row = lane < 32 ? user_tab + (size_t)u * EMB + 4 * lane : item_tab + (size_t)it * EMB + 4 * (lane - 32);
     const f32x4 v = *reinterpret_cast<const f32x4*>(row);
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.xpre + (size_t)i * (2 * EMB) + 4 * lane));
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(xpre + (size_t)i * (2 * EMB) + 4 * lane));
     if (lane == 0) {
         int d = a.dom[src];
-        a.pdom[i] = d < 0 ? 0 : (d >= a.n_domain ? a.n_domain - 1 : d);
-        a.plabel[i] = a.label[src];
+        pdom[i] = d < 0 ? 0 : (d >= n_domain ? n_domain - 1 : d);
+        plabel[i] = a.label[src];
     }
+}
+__global__ __launch_bounds__(256) void k_pass_prep(const PassPrepArgs a) {
+    if ((int)blockIdx.x >= a.n_prep_wgs) {       // the call's transposed weight copies (k_transpose_w) in the same launch
+        transpose_w_elem(a.tw_dense, a.tw_L, a.tw_wT, ((int)blockIdx.x - a.n_prep_wgs) * 256 + (int)threadIdx.x);
+        return;
+    }
+    pass_prep_row(a, a.user_tab, a.item_tab, a.n_user, a.n_item, a.n_domain, a.pos0, a.xpre, a.pdom, a.plabel,
+                  (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+// the passes of several upcoming calls in one launch (mamdr_pregather_passes): the same rows, bit for bit
+__global__ __launch_bounds__(256) void k_pass_prep_multi(const PassPrepMultiArgs a) {
+    int k = 0;
+    while (k + 1 < a.n_pass && (int)blockIdx.x >= a.wg_end[k]) ++k;      // (uniform)
+    const int wg0 = k ? a.wg_end[k - 1] : 0;
+    const PassPrepMultiArgs::Pass& p = a.p[k];
+    pass_prep_row(p, a.user_tab, a.item_tab, a.n_user, a.n_item, a.n_domain, (int64_t)0, a.xpre + (size_t)p.out_off * (2 * EMB),
+                  a.pdom + p.out_off, a.plabel + p.out_off, (int64_t)((int)blockIdx.x - wg0) * 4 + (threadIdx.x >> 6));
+}
+void launch_pass_prep_multi(const PassPrepMultiArgs& a, hipStream_t s) {
+    if (a.n_pass <= 0) return;
+    MAMDR_LAUNCH(k_pass_prep_multi, dim3((unsigned)a.wg_end[a.n_pass - 1]), dim3(256), 0, s, a);
 }
 void launch_pass_prep(const PassPrepArgs& a0, hipStream_t s) {
     if (a0.n <= 0) return;

@@ -124,10 +124,24 @@ struct mamdr_ctx {
     int32_t* pdom = nullptr;
     float* plabel = nullptr;
     int64_t pre_cap = 0;
+    // passes gathered ahead of their calls (mamdr_pregather_passes): entry k's rows sit at [off, off + n + 16) of xpre
+    struct PgEntry { int domain; const int32_t* perm; int64_t n, off; int batch; };
+    std::vector<PgEntry> pg;
+    size_t pg_pos = 0;
+    int64_t pg_hits = 0;            // calls served from an entry (mamdr_pregather_hits)
     bool gather_pf = true;          // MAMDR_NO_GATHER_PF=1: no riders in k_update's launch touching the next step's gather
     bool use_pre = true;            // MAMDR_NO_PREGATHER=1: the towers gather through perm / uid / pid every step
     float* dmsnap[2] = {nullptr, nullptr};
     int dm_cur = 0;
+    // ... ACROSS calls too (round 4): an Adam call leaves its last step pending; the first tower of the next fused Adam
+    // call applies it, anything else that reads or replaces the live state materialises it first (finish_dm, from
+    // sync_tables -- the contract of mamdr_sync_tables).  MAMDR_DM_EACH=1 / MAMDR_DM_CALL=1: after every step / call.
+    DmStep dm_pending{};
+    bool dm_finish_call = false;
+    // the transposed copies in wT hold the live W1 / W2 (/ W0[0:256]): true after a call whose steps kept them current,
+    // false once the live state may have been replaced from outside (sync_tables) or stepped without them
+    bool wT_valid = false;
+    bool w2_direct_ok = true;       // MAMDR_NO_W2_DIRECT=1: always build the copies at the start of a call (k_transpose_w)
     bool dm_finish_each = false;    // MAMDR_DM_EACH=1: materialise after every step (k_dm_finish per step; A/B measurements)
     int tower_tile = 0;             // 0 auto, 4 / 16 forced (env MAMDR_TOWER_TILE)
     // trainable user / item tables
@@ -377,8 +391,23 @@ static void fill_emb_args(const mamdr_ctx* c, int32_t optimizer, float alpha, fl
 constexpr int STAR_ALPHA_CAP = 1 << 12;      // steps between two replays of the lagging Star slices (power of two)
 static float table_two_l2(const mamdr_ctx* c) { return c->star ? 0.f : 2.0f * c->cfg.l2_emb; }
 
-// every table row -> current at adam_t (no-op when nothing lags)
+// materialise a domain-table step the k_wgrad_adam path left pending
+static void finish_dm(mamdr_ctx* c) {
+    if (!c->dm_pending.snap) return;
+    float* const m = (c->dm_pending.optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats + c->L.dm;
+    {
+        Prof p(c, MAMDR_KERNEL_UPDATE);
+        launch_dm_finish(c->dm_pending, c->params + c->table_floats + c->L.dm, m, c->adam_v + c->table_floats + c->L.dm,
+                         c->stream);
+    }
+    c->dm_pending.snap = nullptr;
+}
+
+// the live state current and about to be read or replaced from outside: the pending domain-table step applied, every
+// table row at adam_t (no-op when nothing lags); the transposed weight copies can no longer be trusted
 static void sync_tables(mamdr_ctx* c) {
+    finish_dm(c);
+    c->wT_valid = false;
     if (!c->tables_dirty) return;
     EmbStepArgs ea;
     fill_emb_args(c, MAMDR_OPT_ADAM, 0.f, 1.0f - c->cfg.adam_beta1, 1.0f - c->cfg.adam_beta2, table_two_l2(c), 0,
@@ -801,6 +830,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
             ALLOC(c->dmsnap[0], (size_t)3 * cfg->n_domain * EMB * sizeof(float));
             ALLOC(c->dmsnap[1], (size_t)3 * cfg->n_domain * EMB * sizeof(float));
             if (const char* de = getenv("MAMDR_DM_EACH")) c->dm_finish_each = atoi(de) != 0;
+            if (const char* de = getenv("MAMDR_DM_CALL")) c->dm_finish_call = atoi(de) != 0;
+            if (const char* de = getenv("MAMDR_NO_W2_DIRECT")) c->w2_direct_ok = atoi(de) == 0;
             if (const char* pe = getenv("MAMDR_NO_PREGATHER")) c->use_pre = atoi(pe) == 0;
         }
     }
@@ -996,6 +1027,7 @@ int mamdr_bind_table(mamdr_ctx* c, int seg, const float* d_rows, int64_t n_rows)
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (c->cfg.emb_trainable) return fail(MAMDR_ESTATE, "tables are trainable: they live in the flat vector");
     if (!d_rows || ((uintptr_t)d_rows & 15)) return fail(MAMDR_EINVAL, "table pointer null or not 16-byte aligned");
+    c->pg.clear();              // rows gathered ahead of their calls came from the old table
     if (seg == MAMDR_SEG_USER_EMB) {
         if (n_rows != c->cfg.n_user) return fail(MAMDR_EINVAL, "user table has %lld rows, config says %d", (long long)n_rows, c->cfg.n_user);
         c->user_tab = d_rows;
@@ -1024,6 +1056,7 @@ int mamdr_bind_domain_data(mamdr_ctx* c, int domain, int split, const int32_t* d
     d->dom = d_domain;
     d->label = d_label;
     d->n = n_rows;
+    c->pg.clear();              // (a pass gathered ahead of its call may have come from the old columns)
     const int64_t tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     if (tiles > c->eval_part_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1032,6 +1065,85 @@ int mamdr_bind_domain_data(mamdr_ctx* c, int domain, int split, const int32_t* d
         HIP_TRY(hipMalloc((void**)&c->eval_part, (size_t)tiles * sizeof(float)));
         c->eval_part_cap = tiles;
     }
+    return MAMDR_OK;
+}
+
+// the pass buffer holds at least `rows` positions (contents are lost when it grows)
+static int grow_pass_buffer(mamdr_ctx* c, int64_t rows) {
+    if (rows <= c->pre_cap) return MAMDR_OK;
+    const int64_t cap = rows + rows / 4 + 1024;
+    c->pg.clear();
+    if (c->xpre) { (void)hipFree(c->xpre); (void)hipFree(c->pdom); (void)hipFree(c->plabel); }
+    c->xpre = nullptr; c->pdom = nullptr; c->plabel = nullptr; c->pre_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->xpre, (size_t)cap * 2 * EMB * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->pdom, (size_t)cap * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->plabel, (size_t)cap * sizeof(float)));
+    c->pre_cap = cap;
+    return MAMDR_OK;
+}
+
+int64_t mamdr_pregather_hits(const mamdr_ctx* c) { return c ? c->pg_hits : 0; }
+
+int mamdr_pregather_passes(mamdr_ctx* c, int32_t n_passes, const int32_t* h_domains, const int32_t* const* h_d_perms,
+                           const int64_t* h_pass_rows, int32_t batch) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (ready(c)) return MAMDR_ESTATE;
+    if (n_passes < 0 || (n_passes > 0 && !h_domains)) return fail(MAMDR_EINVAL, "pregather: bad pass list");
+    c->pg.clear();
+    c->pg_pos = 0;
+    // a hint: it only has an effect where a call would gather its pass itself (frozen tables, k_wgrad_adam path)
+    if (n_passes == 0 || batch <= 0 || batch > c->cfg.max_batch || !c->use_pre ||
+        !(c->fused && (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch))
+        return MAMDR_OK;
+    if (n_passes > PREP_MAX_PASSES) n_passes = PREP_MAX_PASSES;      // the later ones gather themselves
+    PassPrepMultiArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t off = 0;
+    int wgs = 0;
+    for (int k = 0; k < n_passes; ++k) {
+        SplitData* d = split_of(c, h_domains[k], MAMDR_SPLIT_TRAIN);
+        if (!d || !d->bound) return fail(MAMDR_ESTATE, "pregather: train split of domain %d is not bound", h_domains[k]);
+        int64_t n = h_pass_rows ? h_pass_rows[k] : -1;
+        if (n < 0) n = d->n;
+        if (n > d->n) return fail(MAMDR_EINVAL, "pregather: pass of %lld rows exceeds the %lld rows of domain %d", (long long)n,
+                                  (long long)d->n, h_domains[k]);
+        PassPrepMultiArgs::Pass& p = a.p[k];
+        p.uid = d->uid;
+        p.pid = d->pid;
+        p.dom = d->dom;
+        p.label = d->label;
+        p.perm = h_d_perms ? h_d_perms[k] : nullptr;
+        p.n = n;
+        p.n_rows_split = d->n;
+        p.out_off = off;
+        p.pad_dom = h_domains[k];
+        const int64_t w = n > 0 ? (n + 16 + 3) / 4 : 0;      // (an empty pass has no steps: nothing to gather)
+        wgs += (int)w;
+        a.wg_end[k] = wgs;
+        c->pg.push_back(mamdr_ctx::PgEntry{h_domains[k], p.perm, n, off, batch});
+        off += 4 * w;
+    }
+    a.n_pass = n_passes;
+    if (wgs == 0) return MAMDR_OK;
+    {
+        std::vector<mamdr_ctx::PgEntry> keep = c->pg;      // (growing the buffer drops the entries of the OLD buffer)
+        if (int rc = grow_pass_buffer(c, off)) return rc;
+        c->pg = keep;
+    }
+    a.user_tab = c->user_tab;
+    a.item_tab = c->item_tab;
+    a.n_user = c->cfg.n_user;
+    a.n_item = c->cfg.n_item;
+    a.n_domain = c->cfg.n_domain;
+    a.xpre = c->xpre;
+    a.pdom = c->pdom;
+    a.plabel = c->plabel;
+    prof_break(c);
+    {
+        Prof p(c, MAMDR_KERNEL_AUX);
+        launch_pass_prep_multi(a, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }
 
@@ -1086,25 +1198,49 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     c->rows_ready = false;
     c->catchup_ready = false;
     prof_break(c);
-    DmStep dm_pending;                  // k_wgrad_adam path: the domain table's step of the previous step of THIS call
-    memset(&dm_pending, 0, sizeof(dm_pending));
     // one path per call (the pending domain-table step lives across the steps of a call): k_wgrad_adam for batches up
     // to fused_max_batch rows (measured: 27.3 vs 29.5 us / step at 1,024 rows, a tie at 4,096)
     const bool fused = c->fused && (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch;
+    // k_wgrad_adam path: the domain table's step of the previous step -- of this call or, between two Adam calls, of
+    // the previous call (c->dm_pending); every other kind of call starts from the materialised table
+    DmStep& dm_pending = c->dm_pending;
+    if (!(fused && optimizer == MAMDR_OPT_ADAM)) finish_dm(c);
     // ... and on that path the rows of the whole call are resolved and gathered once (frozen tables; 4-row tower)
     const int64_t pre_pos0 = first_step * batch;
     const int64_t pre_n = std::min<int64_t>((first_step + n_steps) * (int64_t)batch, pass_rows) - pre_pos0;
     const bool pre = fused && c->use_pre && n_steps > 0 && pre_n > 0;
+    // the transposed copies: built here unless the previous call's steps left them current (no sync_tables since).  On
+    // the k_wgrad_adam path with the W1 image (k_tower4<.., W1L, PRE>) only W2T is read, and only the call's FIRST tower
+    // can find it stale -- k_wgrad_adam rewrites every copy with the step -- so that tower reads W2 itself (w2_direct:
+    // 32 B runs of 128 rows, four loads per lane) and nothing is transposed at all
+    bool build_wT = need_wT && !c->wT_valid;
+    bool w2_direct = false;
+    if (build_wT && pre && c->w2_direct_ok && optimizer != MAMDR_OPT_ACCUMULATE && !c->t4_no_w1l && c->tower_tile != 16 &&
+        tower4_w1l_ready()) {
+        build_wT = false;
+        w2_direct = true;
+    }
+    // ... unless mamdr_pregather_passes gathered this pass ahead of the call: entries are consumed in order (an entry
+    // stays current while calls keep working on its pass); a call that matches none drops them all
+    int64_t pre_base = 0;              // position of row pre_pos0 inside the pass buffer
+    bool pre_cached = false;
     if (pre) {
-        if (pre_n > c->pre_cap) {
-            const int64_t cap = pre_n + pre_n / 4 + 1024;
-            if (c->xpre) { (void)hipFree(c->xpre); (void)hipFree(c->pdom); (void)hipFree(c->plabel); }
-            c->xpre = nullptr; c->pdom = nullptr; c->plabel = nullptr; c->pre_cap = 0;
-            HIP_TRY(hipMalloc((void**)&c->xpre, (size_t)cap * 2 * EMB * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&c->pdom, (size_t)cap * sizeof(int32_t)));
-            HIP_TRY(hipMalloc((void**)&c->plabel, (size_t)cap * sizeof(float)));
-            c->pre_cap = cap;
+        for (size_t k = c->pg_pos; k < c->pg.size(); ++k) {
+            const mamdr_ctx::PgEntry& e = c->pg[k];
+            if (e.domain == domain && e.perm == d_perm && e.n == pass_rows && e.batch == batch) {
+                c->pg_pos = k;
+                pre_base = e.off + pre_pos0;
+                pre_cached = true;
+                c->pg_hits += 1;
+                break;
+            }
         }
+        if (!pre_cached) c->pg.clear();
+    }
+    if (pre && pre_cached) {
+        if (build_wT) launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
+    } else if (pre) {
+        if (int rc = grow_pass_buffer(c, pre_n + 16)) return rc;
         PassPrepArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.user_tab = c->user_tab;
@@ -1124,16 +1260,20 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         pa.xpre = c->xpre;
         pa.pdom = c->pdom;
         pa.plabel = c->plabel;
-        if (need_wT) {                 // ... in k_pass_prep's launch (one launch less per call)
+        if (build_wT) {                // ... in k_pass_prep's launch (one launch less per call)
             pa.tw_dense = c->params + c->table_floats;
             pa.tw_L = c->L;
             pa.tw_wT = c->wT;
         }
         Prof p(c, MAMDR_KERNEL_AUX);
         launch_pass_prep(pa, c->stream);
-    } else if (need_wT) {
+    } else if (build_wT) {
         launch_transpose_w(c->params + c->table_floats, c->L, c->wT, c->stream);
     }
+    // (what the call's steps leave behind: k_wgrad_adam / k_update keep the copies of what they step current when the
+    // call uses them; steps without them make them stale; accumulate steps change no weight)
+    if (optimizer != MAMDR_OPT_ACCUMULATE) c->wT_valid = need_wT;
+    else if (build_wT) c->wT_valid = true;
     // Star tower: a batch carries one domain, so D - 1 of the D slices of every per-domain tensor see a zero gradient
     // and only decay -- TF1's dense Adam still moves them every step (star_kernels.hip).  Inside a call those steps are
     // postponed: k_star_update covers the live slice only and logs the step's alpha, k_star_catchup replays the
@@ -1251,14 +1391,15 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             ta.dms = dm_pending;                       // the previous step of this call (snap == null: none)
             ta.dm_hint = domain;
             if (pre) {
-                ta.xpre = c->xpre + (size_t)(row_base - pre_pos0) * 2 * EMB;
-                ta.pdom = c->pdom + (row_base - pre_pos0);
-                ta.plabel = c->plabel + (row_base - pre_pos0);
+                ta.xpre = c->xpre + (size_t)(pre_base + row_base - pre_pos0) * 2 * EMB;
+                ta.pdom = c->pdom + (pre_base + row_base - pre_pos0);
+                ta.plabel = c->plabel + (pre_base + row_base - pre_pos0);
             }
             ta.dm_live_p = c->params + c->table_floats + c->L.dm;
             ta.dm_live_m = dense_m + c->L.dm;
             ta.dm_live_v = c->adam_v + c->table_floats + c->L.dm;
             ta.dm_snap_out = c->dmsnap[c->dm_cur];
+            ta.w2_direct = (w2_direct && s == 0) ? 1 : 0;
         }
         {
             Prof p(c, MAMDR_KERNEL_FWD_BWD);
@@ -1315,12 +1456,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             dm_pending.omb2 = omb2;
             dm_pending.eps = c->cfg.adam_eps;
             dm_pending.two_l2 = 2.0f * c->cfg.l2_emb;
-            if (c->dm_finish_each || s + 1 == n_steps) {
-                Prof p(c, MAMDR_KERNEL_UPDATE);
-                launch_dm_finish(dm_pending, c->params + c->table_floats + c->L.dm, dense_m + c->L.dm,
-                                 c->adam_v + c->table_floats + c->L.dm, c->stream);
-                dm_pending.snap = nullptr;
-            }
+            // (an Adam call leaves its last step pending for the next call's first tower / the next sync_tables)
+            if (c->dm_finish_each || (s + 1 == n_steps && (optimizer != MAMDR_OPT_ADAM || c->dm_finish_call))) finish_dm(c);
             c->global_step += 1;
             continue;
         }
@@ -1628,6 +1765,35 @@ int mamdr_dr_advance(float* d_phi, float* d_w, float* d_merged, const float* d_t
     if (mode != MAMDR_MERGE_PLUS && mode != MAMDR_MERGE_TIMES) return fail(MAMDR_EINVAL, "unknown merge mode %d", mode);
     launch_dr_advance(d_phi, d_w, d_merged, d_theta, gamma, mode == MAMDR_MERGE_PLUS ? 0 : 1, assign_model != 0, n,
                       (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MAMDR_OK;
+}
+
+int mamdr_dr_advance_live(mamdr_ctx* c, float* d_phi, float* d_merged, const float* d_theta, float gamma, int32_t mode,
+                          int32_t assign_model, int64_t meta_off, int64_t n) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (ready(c)) return MAMDR_ESTATE;
+    CHECK_VEC(d_phi); CHECK_VEC(d_merged); CHECK_VEC(d_theta);
+    if (n < 0 || meta_off < 0 || (meta_off & 3) || meta_off + n > c->n_params)
+        return fail(MAMDR_EINVAL, "range [%lld, %lld) outside the %lld live parameters (or not 16-byte aligned)",
+                    (long long)meta_off, (long long)(meta_off + n), (long long)c->n_params);
+    if (n == 0) return MAMDR_OK;
+    if (mode != MAMDR_MERGE_PLUS && mode != MAMDR_MERGE_TIMES) return fail(MAMDR_EINVAL, "unknown merge mode %d", mode);
+    float* const w = c->params + meta_off;
+    const int64_t dm0 = c->table_floats + c->L.dm, dmn = (int64_t)c->cfg.n_domain * EMB;
+    if (c->dm_pending.snap && c->dm_pending.optimizer == MAMDR_OPT_ADAM && dm0 >= meta_off && dm0 + dmn <= meta_off + n &&
+        !c->tables_dirty && !c->dm_finish_call) {
+        // the pending domain-table step is materialised by the lanes that own its elements (no k_dm_finish launch)
+        prof_break(c);
+        launch_dr_advance_dm(d_phi, w, d_merged, d_theta, gamma, mode == MAMDR_MERGE_PLUS ? 0 : 1, assign_model != 0, n,
+                             c->dm_pending, c->adam_m + dm0, c->adam_v + dm0, (dm0 - meta_off) >> 2, (int)(dmn >> 2), c->stream);
+        c->dm_pending.snap = nullptr;
+        c->wT_valid = false;
+    } else {
+        sync_tables(c);
+        prof_break(c);
+        launch_dr_advance(d_phi, w, d_merged, d_theta, gamma, mode == MAMDR_MERGE_PLUS ? 0 : 1, assign_model != 0, n, c->stream);
+    }
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;
 }

@@ -156,6 +156,8 @@ struct TowerArgs {
     const int32_t* pdom;
     const float* plabel;
     int no_w1l;                // k_tower4: keep streaming W1 / W1^T (MAMDR_T4_NO_W1L=1, diagnostic)
+    int w2_direct;             // k_tower4<.., W1L, PRE>: the backward pass reads W2 itself instead of the copy W2T (the first
+                               // step of a call whose copies are stale)
     DmStep dms;
     int dm_hint;               // the domain the caller expects every row of the batch to carry (the pass's domain)
     float* dm_live_p;
@@ -514,6 +516,28 @@ struct PassPrepArgs {
     float* tw_wT;
     int n_prep_wgs;
 };
+// several passes in ONE launch (mamdr_pregather_passes): pass k owns workgroups [wg_end[k - 1], wg_end[k]) and the
+// rows [out_off, out_off + n + 16) of the pass buffer
+constexpr int PREP_MAX_PASSES = 16;
+struct PassPrepMultiArgs {
+    const float* user_tab;
+    const float* item_tab;
+    int n_user, n_item, n_domain, n_pass;
+    float* xpre;
+    int32_t* pdom;
+    float* plabel;
+    int wg_end[PREP_MAX_PASSES];
+    struct Pass {
+        const int32_t* uid;
+        const int32_t* pid;
+        const int32_t* dom;
+        const float* label;
+        const int32_t* perm;   // nullable
+        int64_t n, n_rows_split, out_off;
+        int pad_dom;
+    } p[PREP_MAX_PASSES];
+};
+void launch_pass_prep_multi(const PassPrepMultiArgs& a, hipStream_t s);
 // ---- W1 [256][128] as an LDS image (both towers, when a workgroup has its CU to itself).  LDS-DMA
 // (global_load_lds_dwordx4: 16 B per lane, two rows per wave instruction, no registers) writes a lane-linear image, so
 // the swizzle sits on the SOURCE address: the 16-B chunk q of row r lives at chunk position q ^ (r & 31) -- row reads
@@ -562,6 +586,8 @@ void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live
 void launch_tower_train(const TowerArgs& a, hipStream_t s);
 void launch_tower_eval(const TowerArgs& a, hipStream_t s);
 void launch_tower4_train(const TowerArgs& a, hipStream_t s);
+// the W1-image instance of the pre-gathered tower can run (its LDS limit was granted): grids of up to one tile per CU
+bool tower4_w1l_ready();
 void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s);
 struct EvalFinishArgs {
     const float* loss_part;
@@ -743,6 +769,8 @@ void launch_moving_average(float* unbiased, float* biased, const float* value, f
 void launch_merge(float* dst, const float* t, const float* p, int mode, int64_t n, hipStream_t s);
 void launch_dr_advance(float* phi, float* w, float* merged, const float* theta, float gamma, int mode, int assign, int64_t n,
                        hipStream_t s);
+void launch_dr_advance_dm(float* phi, float* w, float* merged, const float* theta, float gamma, int mode, int assign, int64_t n,
+                          const DmStep& q, float* live_m, float* live_v, int64_t dm_off4, int dm_n4, hipStream_t s);
 void launch_sub(float* dst, const float* a, const float* b, int64_t n, hipStream_t s);
 void launch_accumulate(float* acc, const float* a, const float* b, const float* shared, float divisor, int64_t n,
                        hipStream_t s);

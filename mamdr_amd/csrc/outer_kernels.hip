@@ -228,6 +228,36 @@ void launch_dr_advance(float* phi, float* w, float* merged, const float* theta, 
     else if (assign) hipLaunchKernelGGL((k_elementwise<DrAdvance<1, true>>), grid, block, 0, s, n, (DrAdvance<1, true>{phi, w, merged, theta, gamma}));
     else hipLaunchKernelGGL((k_elementwise<DrAdvance<1, false>>), grid, block, 0, s, n, (DrAdvance<1, false>{phi, w, merged, theta, gamma}));
 }
+// the same with a domain-table step of the k_wgrad_adam path still pending (DmStep): the lanes that own the table's
+// elements materialise it first -- live p / m / v := dm_step4, as k_dm_finish would have -- and go on with the value
+// they have just written (one launch instead of k_dm_finish + this one; the same bits)
+template <int MODE, bool ASSIGN>
+struct DrAdvanceDm {
+    DrAdvance<MODE, ASSIGN> op;
+    DmStep q;
+    float* live_m; float* live_v;      // the domain table's Adam slots
+    int64_t dm_off4; int dm_n4;        // its float4 range inside op.w
+    __device__ __forceinline__ void vec(int64_t i) const {
+        if (i >= dm_off4 && i < dm_off4 + dm_n4) {
+            const int k = (int)(i - dm_off4);
+            f32x4 p, m, v;
+            dm_step4(q, k / (EMB / 4), k % (EMB / 4), p, m, v);
+            reinterpret_cast<f32x4*>(op.w)[i] = p;
+            reinterpret_cast<f32x4*>(live_m)[k] = m;
+            reinterpret_cast<f32x4*>(live_v)[k] = v;
+        }
+        op.vec(i);
+    }
+    __device__ __forceinline__ void one(int64_t i) const { op.one(i); }
+};
+void launch_dr_advance_dm(float* phi, float* w, float* merged, const float* theta, float gamma, int mode, int assign, int64_t n,
+                          const DmStep& q, float* live_m, float* live_v, int64_t dm_off4, int dm_n4, hipStream_t s) {
+    const dim3 grid(grid_for(n >> 2)), block(BLOCK);
+    if (mode == 0 && assign) hipLaunchKernelGGL((k_elementwise<DrAdvanceDm<0, true>>), grid, block, 0, s, n, (DrAdvanceDm<0, true>{{phi, w, merged, theta, gamma}, q, live_m, live_v, dm_off4, dm_n4}));
+    else if (mode == 0) hipLaunchKernelGGL((k_elementwise<DrAdvanceDm<0, false>>), grid, block, 0, s, n, (DrAdvanceDm<0, false>{{phi, w, merged, theta, gamma}, q, live_m, live_v, dm_off4, dm_n4}));
+    else if (assign) hipLaunchKernelGGL((k_elementwise<DrAdvanceDm<1, true>>), grid, block, 0, s, n, (DrAdvanceDm<1, true>{{phi, w, merged, theta, gamma}, q, live_m, live_v, dm_off4, dm_n4}));
+    else hipLaunchKernelGGL((k_elementwise<DrAdvanceDm<1, false>>), grid, block, 0, s, n, (DrAdvanceDm<1, false>{{phi, w, merged, theta, gamma}, q, live_m, live_v, dm_off4, dm_n4}));
+}
 void launch_merge(float* dst, const float* t, const float* p, int mode, int64_t n, hipStream_t s) {
     if (mode == 0) run(n, Merge<0>{dst, t, p}, s);
     else run(n, Merge<1>{dst, t, p}, s);

@@ -121,6 +121,23 @@ struct T4W {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // the same ring from the UNtransposed matrix Wn [N][K] (W = Wn^T): b[u][t] = Wn[V lane + t][w KW + u] -- for each of
+    // the lane's V columns the wave's whole k range is one run of KW consecutive floats (the ring holds the wave's whole
+    // share: KW == PF)
+    __device__ __forceinline__ void prefetch_untransposed(const float* __restrict__ Wn) {
+        static_assert(KW == PF && KW % 4 == 0, "the wave's whole share in the ring");
+        const float* wp = Wn + (size_t)(V * (threadIdx.x & 63)) * K + (threadIdx.x >> 6) * KW;
+#pragma unroll
+        for (int t = 0; t < V; ++t) {
+#pragma unroll
+            for (int q = 0; q < KW; q += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(wp + (size_t)t * K + q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[q + j][t] = v[j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 };
 
 // Split-k partials of a wave -> LDS `red` as [slot][row][column].  D register r of lane l is row r; its column is
@@ -407,11 +424,14 @@ __device__ __forceinline__ int t4_clamp(int v, int lo, int hi) { return v < lo ?
 // -mllvm -amdgpu-kernarg-preload-count (mamdr_amd/build.py) they arrive in SGPRs with the wave, and those loads go out
 // without waiting for the argument block's own fetch (probe, tools/probes/kernarg_preload_probe.hip: entry -> first
 // load returned 840 -> 380 cycles).  `a` carries the same values; only the prologue reads the copies.
-template <bool DX, bool FM, bool W1L, bool PRE = false>
+// W2D (PRE + W1L only): the backward pass reads W2 itself instead of the transposed copy W2T -- the first tower of a call
+// whose copies are stale (an instance of its own: as a run-time branch around the ring's loads it cost every launch 0.3 us)
+template <bool DX, bool FM, bool W1L, bool PRE = false, bool W2D = false>
 __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__ k_xpre, const int32_t* __restrict__ k_pdom,
                                                        const float* __restrict__ k_plabel, const float* __restrict__ k_w0,
                                                        const float* __restrict__ k_w1, const int k_rows, const TowerArgs a) {
     static_assert(!PRE || (!DX && !FM), "pre-gathered passes serve the frozen-table mlp tower");
+    static_assert(!W2D || (PRE && W1L), "W2 read in place: the W1-image instance of the pre-gathered tower");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
@@ -657,7 +677,10 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
 
     T4STAMP(3);
     // ---- layer 1: 256 -> 128
-    if (W1L) t4_contract_w1f(w1s, smem + T4_H1, red, [&]() { v2.prefetch(a.wT + W2T_OFF); });
+    if (W1L) t4_contract_w1f(w1s, smem + T4_H1, red, [&]() {
+        if constexpr (W2D) v2.prefetch_untransposed(P + a.L.w2);     // W2T stale: the call's first tower
+        else v2.prefetch(a.wT + W2T_OFF);
+    });
     else t4_contract(w1, P + a.L.w1, smem + T4_H1, T4_H1LD, red, [&]() { w2.prefetch(P + a.L.w2); });
     __syncthreads();
     T4STAMP(4);
@@ -805,12 +828,33 @@ static void launch_tower4_inst(const TowerArgs& a, dim3 grid, bool w1l, hipStrea
     }
     const float* w0 = a.dense + a.L.w0;
     const float* w1 = a.dense + a.L.w1;
-    if (w1l && raised == 1)
+    if (w1l && raised == 1 && PRE && a.w2_direct) {
+        if constexpr (PRE) {
+            static int raised2 = 0;
+            if (raised2 == 0)
+                raised2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true, PRE, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess ? 1 : -1;
+            if (raised2 != 1) { fprintf(stderr, "mamdr: k_tower4<W2D> refused its LDS\n"); abort(); }
+            MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE, true>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a.xpre, a.pdom,
+                         a.plabel, w0, w1, a.rows, a);
+        }
+    } else if (w1l && raised == 1)
         MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a.xpre, a.pdom, a.plabel, w0, w1,
                      a.rows, a);
-    else
+    else {
+        if (a.w2_direct) { fprintf(stderr, "mamdr: w2_direct without the W1-image instance\n"); abort(); }
         MAMDR_LAUNCH((k_tower4<DX, FM, false, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a.xpre, a.pdom, a.plabel, w0,
                      w1, a.rows, a);
+    }
+}
+bool tower4_w1l_ready() {
+    static int ok = -1;
+    if (ok < 0)
+        ok = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<false, false, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<false, false, true, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess) ? 1 : 0;
+    return ok == 1;
 }
 static int t4_cu_count() {
     static int n = 0;

@@ -363,6 +363,25 @@ class TowerEngine(FlatVectorOps):
                                              _ptr(loss_out)))
         return n_steps
 
+    def dr_advance(self, phi, merged, theta, gamma, method="plus", assign_model=True):
+        """FlatVectorOps.dr_advance on the context's live weights (mamdr_dr_advance_live): the library synchronises them
+        itself, and a domain-table step the fused step path left pending is materialised inside the same launch."""
+        mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        L.check(self.lib.mamdr_dr_advance_live(self.ctx, _ptr(phi), _ptr(merged), _ptr(theta), float(gamma), mode,
+                                               1 if assign_model else 0, self.meta_off, phi.numel()))
+
+    def pregather(self, passes, batch_size=None):
+        """hint (mamdr_pregather_passes): the next train_steps calls run these passes -- [(domain, perm device tensor or
+        None[, pass_rows])] -- in this order; where a call would gather its pass's rows itself (frozen tables, fused
+        step path) the library gathers them all in one launch now.  Same rows, same bits; a no-op elsewhere."""
+        n = len(passes)
+        if n == 0:
+            return
+        doms = (C.c_int32 * n)(*[int(p[0]) for p in passes])
+        perms = (C.c_void_p * n)(*[(p[1].data_ptr() if p[1] is not None else None) for p in passes])
+        rows = (C.c_int64 * n)(*[(-1 if len(p) < 3 or p[2] is None else int(p[2])) for p in passes])
+        L.check(self.lib.mamdr_pregather_passes(self.ctx, n, doms, perms, rows, int(batch_size or self.batch_size)))
+
     def evaluate(self, domain, split, want_preds=False):
         """model.evaluate(data, steps=n_step) -> (loss, auc[, preds]); syncs to read back."""
         n = self.n_rows(domain, split)

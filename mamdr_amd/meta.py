@@ -27,6 +27,48 @@ def _upload_perm(eng, perm):
     return torch.from_numpy(perm).to(eng.device, non_blocking=True)
 
 
+class PassWindow(object):
+    """The passes a loop is about to run, announced ahead: where the engine would resolve and gather every pass's rows
+    at the start of its own call (frozen tables on the fused step path: one launch per call, 7 us of Taobao-10's
+    ~210 us passes) they are gathered for a whole window of passes in ONE launch (engine.pregather ->
+    mamdr_pregather_passes).  Needs a perm_fn that can show its next permutations without consuming them
+    (plan.EpochShuffles.peek); anything else -- and any engine without the hint -- runs as before.  A window holds at
+    most `max_passes` passes and `budget_rows` rows (1 KB each: the gathered rows should still sit in the 256 MB
+    infinity cache when their steps read them).  Results do not depend on it (same rows, same bits)."""
+
+    def __init__(self, eng, perm_fn, batch_size, budget_rows=96 * 1024, max_passes=16):
+        self.eng, self.perm_fn, self.batch_size = eng, perm_fn, batch_size
+        self.budget, self.max_passes = budget_rows, max_passes
+        import os
+        self.on = hasattr(perm_fn, "peek") and hasattr(eng, "pregather") and not os.environ.get("MAMDR_NO_PASS_WINDOW")
+        self.todo, self.left = [], 0
+
+    def announce(self, domains):
+        self.todo, self.left = list(domains), 0
+
+    def step(self):
+        """right before every announced pass"""
+        if not self.on:
+            return
+        if self.left == 0 and self.todo:
+            take, rows = 0, 0
+            while take < len(self.todo) and take < self.max_passes:
+                n = self.eng.n_rows(self.todo[take], "train")
+                if take and rows + n > self.budget:
+                    break
+                rows += n
+                take += 1
+            chunk, self.todo = self.todo[:take], self.todo[take:]
+            perms = self.perm_fn.peek(chunk)
+            if perms is None:          # the loop is not following the announced order: no hint
+                self.on = False
+                return
+            if take > 1:               # (a window of one pass is what the call does by itself)
+                self.eng.pregather(list(zip(chunk, perms)), self.batch_size)
+            self.left = take
+        self.left = max(self.left - 1, 0)
+
+
 def run_pass(eng, d, perm_fn, batch_size, lr, trace, phase, max_steps=0, optimizer="adam", window=None):
     """one pass over domain d's train split = re-initialised iterator + n_step x train_on_batch.
     window = (begin, end): the pass covers that file-order slice only (meta-train / meta-val split)."""
@@ -219,17 +261,22 @@ def pcgrad_epoch(eng, outer, cur, aux, seq, aux_plan, perm_fn, batch_size, lr, m
 
 
 def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, trace, merged,
-             merged_method="plus", domain_regulation_step=0, batch_variant=False, sample_num=None, acc=None):
+             merged_method="plus", domain_regulation_step=0, batch_variant=False, sample_num=None, acc=None, pw=None):
     """DR for one query domain (mamdr.py:60-108): phi is updated in place.  Reads theta
     (fixed during DR) and writes only phi -- the unit that shards across GPUs."""
     eng.merge(merged, theta, phi, merged_method)
     if batch_variant:
         acc.zero_()
     assigned = False
+    if pw is None:
+        pw = PassWindow(eng, perm_fn, batch_size)
+    pw.announce([x for j in support for x in (j, query)])
     for k, j in enumerate(support):
         if not assigned:
             eng.set_weights(merged)
+        pw.step()
         run_pass(eng, j, perm_fn, batch_size, lr, trace, "dr_support")
+        pw.step()
         run_pass(eng, query, perm_fn, batch_size, lr, trace, "dr_query", domain_regulation_step)
         if batch_variant:
             shared = theta if merged_method == "times" else None
@@ -257,9 +304,12 @@ def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged
                 finetune_every_epoch=False):
     """plan = {"seq": [...], "dr": [(query, [support...]), ...]}."""
     trace = []
+    pw = PassWindow(eng, perm_fn, batch_size)
     # DN phase (mamdr.py:48-57)
     eng.set_weights(theta)
+    pw.announce(plan["seq"])
     for d in plan["seq"]:
+        pw.step()
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
     eng.interp(theta, eng.meta_weights, theta, meta_lr)
     # DR phase (mamdr.py:59-108)
@@ -267,7 +317,7 @@ def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged
     acc = torch.zeros_like(theta) if batch_variant else None
     for query, support in plan["dr"]:
         dr_query(eng, theta, phis[query], query, support, perm_fn, batch_size, lr, meta_lr, trace, merged,
-                 merged_method, domain_regulation_step, batch_variant, sample_num, acc)
+                 merged_method, domain_regulation_step, batch_variant, sample_num, acc, pw)
         if finetune_every_epoch:
             finetune_query(eng, theta, phis[query], query, perm_fn, batch_size, lr, trace, merged, merged_method)
     return trace

@@ -422,7 +422,10 @@ class BalancedMAMDR(object):
             self.tail.sync()            # the previous epoch's DR displacements of the tail, before DN moves it again
             wire += self.tail.floats() * 4
         eng.set_weights(theta)
+        pw = meta.PassWindow(eng, perm_fn, batch_size)
+        pw.announce(local["seq"])
         for d in local["seq"]:
+            pw.step()
             meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn")
         if replicated:
             # one chain; rank 0's result is everybody's (bit-identical continuation on every rank)

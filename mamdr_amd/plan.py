@@ -192,6 +192,14 @@ class EpochShuffles(object):
             off += int(cnt)
         self.queue = q
 
+    def peek(self, domains):
+        """the permutations the next len(domains) calls will hand out, without consuming them (meta.PassWindow gathers
+        those passes' rows ahead of their calls); None if the epoch's next passes are not over these domains."""
+        nxt = self.queue[self.pos:self.pos + len(domains)]
+        if len(nxt) != len(domains) or any(dd != d for (dd, _), d in zip(nxt, domains)):
+            return None
+        return [perm for _, perm in nxt]
+
     def __call__(self, d, window=None):
         if window is not None:
             raise ValueError("EpochShuffles serves whole-split passes only")

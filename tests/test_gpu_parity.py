@@ -446,6 +446,66 @@ def test_pending_domain_table_step_is_bitwise(env, batch, mixed):
         assert same_bits(a, b), (name, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
 
 
+@pytest.mark.parametrize("batch", [256, 1000])
+def test_per_call_duties_across_calls_are_bitwise(env, batch):
+    """Round 4, k_wgrad_adam path: (1) an Adam call leaves its last domain-table step PENDING for the next call's first
+    tower (materialised by mamdr_sync_tables / mamdr_dr_advance_live / any other kind of call); (2) the call's first
+    tower reads W2 itself when the transposed copies are stale (no k_transpose_w); (3) the passes of a whole window of
+    calls are gathered in one launch (meta.PassWindow -> mamdr_pregather_passes: plan.EpochShuffles can show its next
+    permutations); (4) a DR support step materialises the pending step inside mamdr_dr_advance_live's launch.
+    Against the round-3 behaviour (MAMDR_DM_CALL=1: k_dm_finish closes every call; MAMDR_NO_W2_DIRECT=1: k_transpose_w
+    opens it; a perm_fn that cannot be peeked: every call gathers its own pass): two MAMDR epochs + SGD / accumulate /
+    one-step calls / an evaluation in between -> theta, every phi, the live weights, both Adam slots and a MAML
+    accumulator agree BITWISE."""
+    from mamdr_amd import meta, plan as mplan
+    res = {}
+    for mode in ("new", "old"):
+        if mode == "old":
+            os.environ["MAMDR_DM_CALL"] = "1"
+            os.environ["MAMDR_NO_W2_DIRECT"] = "1"
+        try:
+            g, eng, model = make_problem(env, scale=0.25, batch=batch, dropout=0.5)
+        finally:
+            os.environ.pop("MAMDR_DM_CALL", None)
+            os.environ.pop("MAMDR_NO_W2_DIRECT", None)
+        assert int(eng.lib.mamdr_step_path(eng.ctx, batch)) == 1
+        D = g["n_domain"]
+        sizes = [eng.n_rows(d, "train") for d in range(D)]
+        theta = eng.get_weights()
+        rs = np.random.RandomState(3)
+        phis = {d: torch.from_numpy((rs.standard_normal(eng.n_params) * 1e-3).astype(F32)).to(eng.device) for d in range(D)}
+        es = mplan.EpochShuffles(mplan.PassShuffler(sizes, 10000, 77), eng.device)
+        planner = mplan.EpochPlanner(range(D), 3, True, True, seed=5)
+        acc = eng.new_vector()
+        eng.bind_accumulator(acc)
+        for ep in range(2):
+            plan = planner.next_epoch()
+            es.prepare(mplan.epoch_passes(plan))
+            perm_fn = es if mode == "new" else (lambda d, es=es: es(d))
+            meta.mamdr_epoch(eng, theta, phis, plan, perm_fn, batch, lr=1e-3, meta_lr=0.1)
+            if ep == 0:
+                # other kinds of calls find the table materialised: an Adam call, then SGD, accumulate, a one-step Adam
+                # call, an evaluation, and Adam again
+                big = sorted(range(D), key=lambda d: -sizes[d])[:2]          # (at least two batches each)
+                assert sizes[big[1]] > batch
+                pm = torch.from_numpy(orng.shuffle_perm(sizes[big[0]], 10000, seed=9)).to(eng.device)
+                eng.train_steps(big[0], perm=pm, lr=1e-3)
+                eng.train_steps(big[0], perm=pm, first_step=0, n_steps=1, lr=1e-2, optimizer="sgd")
+                eng.train_steps(big[0], perm=pm, first_step=1, n_steps=1, lr=1e-3, optimizer="accumulate")
+                eng.train_steps(big[1], first_step=0, n_steps=1, lr=1e-3)
+                eng.evaluate(1, "val")
+                eng.train_steps(big[1], first_step=1, n_steps=1, lr=1e-3)
+        hits = int(eng.lib.mamdr_pregather_hits(eng.ctx))
+        assert (hits > 20) if mode == "new" else (hits == 0), hits
+        res[mode] = [theta.cpu().numpy().copy()] + [phis[d].cpu().numpy().copy() for d in range(D)] + \
+                    [eng.get_weights().cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(),
+                     eng.adam_v.cpu().numpy().copy(), acc.cpu().numpy().copy()]
+        eng.close()
+    for k, (a, b) in enumerate(zip(res["new"], res["old"])):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert same_bits(a, b), (k, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+
+
 def test_tower4_w1_image_is_bitwise(env):
     """k_tower4 with W1 as an LDS image (grids of up to one tile per CU) against the variant that streams W1 / W1^T
     (MAMDR_T4_NO_W1L=1): the same MFMA sequences per output element and the same split-k sums -- identical bits, on the
