@@ -1,4 +1,4 @@
-"""diagnostic (GPU): the Star / Amazon-13 full-table MAMDR epoch of tests/test_gpu_fullsize.py, compared with the oracle
+"""diagnostic (GPU; run by hand: python tests/diag_star13_phases.py -- it uses the oracle, so it lives under tests/): the Star / Amazon-13 full-table MAMDR epoch of tests/test_gpu_fullsize.py, compared with the oracle
 after EVERY phase (DN, then each DR query): per-domain val AUC of theta + phi_d on both sides and the relative L2
 distance of theta / phi / the live tail.  Localises where a per-domain AUC difference comes from."""
 import os
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mamdr_amd import engine, meta, synthetic          # noqa: E402

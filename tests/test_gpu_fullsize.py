@@ -277,7 +277,7 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
     # tests/test_gpu_parity.py::make_star_problem: with beta = 0 the normalised domain columns (constant over a
     # single-domain batch) are pure rounding residue, their kernel rows' gradients are noise that Adam normalises to
     # steps of +- lr -- a random walk that differs between any two fp32 evaluations (measured with this test: the tensors
-    # outside theta / phi 0.8 % apart after one epoch, one domain's AUC 2e-3 off, tools/diag/star13_phases.py)
+    # outside theta / phi 0.8 % apart after one epoch, one domain's AUC 2e-3 off, tests/diag_star13_phases.py)
     irs = np.random.RandomState(7)
     for n_ in ("pn_gamma_shared", "pn_gamma_spec"):
         params[n_] = (params[n_] + irs.standard_normal(params[n_].shape) * 0.2).astype(np.float32)
