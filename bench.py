@@ -661,6 +661,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-targets", action="store_true", help="skip the Taobao-30 record and the Amazon-6-sized gather")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="several ranks: skip the first-contact check of the communicator (all-reduce, send / recv ring, broadcast)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -678,17 +680,30 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # MAMDR_BENCH_SHARE_GPU=1 (testing on a 1-GPU box only): all ranks use device 0 and gloo
         share = os.environ.get("MAMDR_BENCH_SHARE_GPU") == "1"
+        import datetime
+        if not share and torch.cuda.device_count() < world:
+            # (one process per GPU: a rank without a device of its own must not fall back onto somebody else's)
+            print("rank %d: %d ranks but %d visible GPUs" % (rank, world, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(3)
         torch.cuda.set_device(0 if share else local_rank)
         backend = "gloo" if share else "nccl"
+        # a collective that hangs (first contact with RCCL on a new machine) ends the rank after this long, non-zero
+        limit = datetime.timedelta(seconds=int(os.environ.get("MAMDR_BENCH_COMM_TIMEOUT", "300")))
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
             except TypeError:
-                dist.init_process_group("nccl")
+                dist.init_process_group("nccl", timeout=limit)
     else:
         torch.cuda.set_device(0)
+    preflight = None
+    if world > 1 and not args.no_preflight:
+        from mamdr_amd import parallel as mpar
+        preflight = mpar.preflight(torch.device("cuda", torch.cuda.current_device()))
+        if rank == 0:
+            print("preflight: %s" % json.dumps(preflight), file=sys.stderr)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -734,6 +749,7 @@ def main():
         if world > 1:
             result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
             result["backend"] = backend
+            result["preflight"] = preflight
             for k in ("wire_bytes_per_epoch_rank0", "dn_mode"):
                 if k in r:
                     result[k] = r[k]

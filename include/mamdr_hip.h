@@ -366,6 +366,9 @@ int mamdr_graph_task_ranges(const mamdr_graph* g, int domain, int64_t* shared_of
                             int64_t* task_count);
 int mamdr_graph_bind_state(mamdr_graph* g, float* d_params, float* d_adam_m, float* d_adam_v);
 int mamdr_graph_optimizer_reset(mamdr_graph* g);
+/* epsilon of the following Adam steps: `compile(optimizer='adam')` of deep_mtl_ctr.py:147-148 builds a Keras Adam
+ * (epsilon = K.epsilon() = 1e-7) where the shared optimiser of :53-56 is tf.train.AdamOptimizer (1e-8) */
+int mamdr_graph_set_adam_eps(mamdr_graph* g, float eps);
 int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g);
 int64_t mamdr_graph_dropout_steps(const mamdr_graph* g);
 int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t n_rows);     /* deep_mtl_ctr.py:98-121 */

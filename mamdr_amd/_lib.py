@@ -119,6 +119,7 @@ SIGNATURES = {
     "mamdr_graph_task_ranges": (C.c_int, [_VP, C.c_int, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "mamdr_graph_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_graph_optimizer_reset": (C.c_int, [_VP]),
+    "mamdr_graph_set_adam_eps": (C.c_int, [_VP, _F]),
     "mamdr_graph_optimizer_steps": (_I64, [_VP]),
     "mamdr_graph_dropout_steps": (_I64, [_VP]),
     "mamdr_graph_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),

@@ -71,8 +71,15 @@ def init_distributed():
                 torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
+            if torch.cuda.device_count() < ws:
+                raise RuntimeError("%d ranks but %d visible GPUs (one process per GPU)" % (ws, torch.cuda.device_count()))
             torch.cuda.set_device(local)
             dist.init_process_group("nccl")
+        # first contact with the communicator: values of an all-reduce, a send / recv ring and a broadcast checked on
+        # every rank; a failing ring switches the phi hand-over to broadcasts (parallel.preflight)
+        from . import parallel
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        parallel.preflight(dev)
     return dist.get_rank(), dist.get_world_size()
 
 

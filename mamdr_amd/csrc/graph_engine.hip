@@ -1911,6 +1911,12 @@ int mamdr_graph_optimizer_reset(mamdr_graph* g) {
     g->b1p = g->b2p = 1.f;
     return MAMDR_OK;
 }
+int mamdr_graph_set_adam_eps(mamdr_graph* g, float eps) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (!(eps > 0.f)) return gfail(MAMDR_EINVAL, "adam epsilon %g", (double)eps);
+    g->cfg.adam_eps = eps;
+    return MAMDR_OK;
+}
 int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g) { return g ? g->adam_t : 0; }
 int64_t mamdr_graph_dropout_steps(const mamdr_graph* g) { return g ? (int64_t)g->global_step : 0; }
 

@@ -116,6 +116,20 @@ class FlatVectorOps(object):
                                           1e-8, float(beta1_power), float(beta2_power), p.numel(), self._s()))
 
 
+    def pcgrad_project(self, final, aux, tensors=None):
+        """PCGrad.PCGrad with final_grads is current_grads (pcgrad.py:107-124,152-160) on flat device vectors.
+        tensors: [(offset, rows, cols)], default = every segment inside the vectors."""
+        if tensors is None:
+            shapes = self.segment_shapes()
+            tensors = [(off, shapes[n][0], shapes[n][1]) for n, (off, cnt) in self.segments.items()
+                       if off + cnt <= final.numel()]
+        n = len(tensors)
+        offs = (C.c_int64 * n)(*[t[0] for t in tensors])
+        rows = (C.c_int64 * n)(*[t[1] for t in tensors])
+        cols = (C.c_int32 * n)(*[t[2] for t in tensors])
+        L.check(self.lib.mamdr_pcgrad_project(_ptr(final), _ptr(aux), offs, rows, cols, n, self._s()))
+
+
 class TowerEngine(FlatVectorOps):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False,
                  tower="mlp", emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None,
@@ -287,19 +301,6 @@ class TowerEngine(FlatVectorOps):
             else:                                  # 1-d biases and PartitionedNorm shared vectors
                 out[name] = (1, cnt)
         return out
-
-    def pcgrad_project(self, final, aux, tensors=None):
-        """PCGrad.PCGrad with final_grads is current_grads (pcgrad.py:107-124,152-160) on flat device vectors.
-        tensors: [(offset, rows, cols)], default = every segment inside the vectors."""
-        if tensors is None:
-            shapes = self.segment_shapes()
-            tensors = [(off, shapes[n][0], shapes[n][1]) for n, (off, cnt) in self.segments.items()
-                       if off + cnt <= final.numel()]
-        n = len(tensors)
-        offs = (C.c_int64 * n)(*[t[0] for t in tensors])
-        rows = (C.c_int64 * n)(*[t[1] for t in tensors])
-        cols = (C.c_int32 * n)(*[t[2] for t in tensors])
-        L.check(self.lib.mamdr_pcgrad_project(_ptr(final), _ptr(aux), offs, rows, cols, n, self._s()))
 
     # ------------------------------------------------------------ binding
     def bind_table(self, name, rows):

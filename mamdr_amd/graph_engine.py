@@ -129,6 +129,19 @@ class GraphEngine(FlatVectorOps):
         out.copy_(self._weights)
         return out
 
+    def segment_shapes(self):
+        """{tensor: (slices along the last axis, slice length)} of the Keras variables behind the tensors -- what numpy's
+        axis=-1 reductions in the reference's PCGrad see (model_zoo/pcgrad.py:152-160): rows of a kernel / table, a bias
+        as one slice, the Dense(1) head kernels and deepctr's 1-d linear tables ([n, 1]) as n slices of one element."""
+        out = {}
+        for name, (rows, cols) in self.shapes.items():
+            cnt = rows * cols
+            if name.startswith("lin_") or name.endswith("/w") or name in ("wo", "gb") or name.endswith("/gb"):
+                out[name] = (cnt, 1)
+            else:
+                out[name] = (rows, cols)
+        return out
+
     def task_ranges(self, domain):
         """[(offset, count)] of the flat vector a step on `domain` trains (Model(inputs, outputs[domain]).trainable_weights)."""
         v = [C.c_int64() for _ in range(4)]
@@ -214,3 +227,6 @@ class GraphEngine(FlatVectorOps):
 
     def optimizer_reset(self):
         L.check(self.lib.mamdr_graph_optimizer_reset(self.ctx), graph=True)
+
+    def set_adam_eps(self, eps):
+        L.check(self.lib.mamdr_graph_set_adam_eps(self.ctx, float(eps)), graph=True)

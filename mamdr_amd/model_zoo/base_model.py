@@ -78,7 +78,7 @@ class BaseModel(object):
             return self._summarise("test", dl, da)
         return self._finetune_domains(lambda d: weights, "adam" if init_parms else "sgd", self.learning_rate)
 
-    def _finetune_domains(self, start_weights, optimizer, lr, domains=None, summarise=True):
+    def _finetune_domains(self, start_weights, optimizer, lr, domains=None, summarise=True, per_domain_reset=False):
         domain_loss, domain_auc = {}, {}
         keep = self.model.get_weights()
         best = self.model.new_vector()
@@ -86,6 +86,8 @@ class BaseModel(object):
         hook = getattr(self, "finetune_epoch_hook", None)       # tests: hook(domain, epoch, engine) after every epoch's pass
         for d in (self.dataset.train_dataset if domains is None else domains):
             self.model.set_weights(start_weights(d))
+            if per_domain_reset:          # a freshly compiled optimiser per domain (deep_mtl_ctr.py:139-148)
+                self.model.optimizer_reset()
             print("Train on domain: {}".format(d))
             # Keras EarlyStopping(monitor=val_AUC, mode=max, min_delta=1e-4) + ModelCheckpoint(best only)
             es_best, wait, ck_best = -np.inf, 0, -np.inf

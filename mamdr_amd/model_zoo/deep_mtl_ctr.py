@@ -5,8 +5,9 @@ SharedBottom / MMOE / PLE, and, as the reference compiles `Model(inputs, outputs
 optimizer (:53-67), every step on domain d trains the variables on the path to output d only -- the multi-task engine
 (`GraphEngine`, csrc/graph_engine.hip) takes the domain with every call.  `train()` is the alternate loop of :69-96,
 `val_and_test` scores domain d with domain d's model (:189-222), `separate_train_val_test` restarts every domain from the
-same weights (:128-187: Adam-by-name when init_parms, plain SGD for the finetune stage, Keras EarlyStopping(val_AUC,
-min_delta=1e-4) + best-only checkpoint).  Initial tensors: deepctr's initialisers (glorot normal kernels, zero biases,
+same weights (:128-187): with init_parms every domain's model is compiled with the STRING 'adam' (:147-148) -- a fresh
+Keras Adam per domain, lr 1e-3 and epsilon 1e-7 whatever `learning_rate` says, zero slots -- and for the finetune stage
+with plain SGD at `learning_rate` (:143-146); Keras EarlyStopping(val_AUC, min_delta=1e-4) + best-only checkpoint.  Initial tensors: deepctr's initialisers (glorot normal kernels, zero biases,
 N(0, 1e-4^2) domain table, pretrained constants for the user / item tables) from a numpy stream seeded with dataset.seed.
 """
 import random
@@ -118,6 +119,24 @@ class DeepMTLCTR(BaseModel):
         if tc["loss"] != "binary_crossentropy":
             raise NotImplementedError("loss '%s': only binary_crossentropy is built" % tc["loss"])
         return eng
+
+    def separate_train_val_test(self, init_parms=True):
+        """deep_mtl_ctr.py:128-187.  init_parms: `compile(optimizer=self.train_config['optimizer'])` with the string
+        'adam' builds a NEW Keras Adam for every domain's model -- learning rate 1e-3 (not `learning_rate`), epsilon
+        K.epsilon() = 1e-7, empty slots; the shared tf.train.AdamOptimizer of the alternate loop is not involved.
+        Finetune (init_parms false): SGD at `learning_rate`, as BaseModel."""
+        if not init_parms:
+            return BaseModel.separate_train_val_test(self, init_parms=False)
+        from .. import parallel
+        if parallel.world()[1] > 1:
+            raise NotImplementedError("<%s>_separate under several processes" % self.tower_kind())
+        weights = self.model.get_weights()
+        self.model.set_adam_eps(1e-7)
+        try:
+            return self._finetune_domains(lambda d: weights, "adam", 1e-3, per_domain_reset=True)
+        finally:
+            self.model.set_adam_eps(1e-8)
+            self.model.optimizer_reset()
 
     def train(self):
         """deep_mtl_ctr.py:69-96: per epoch one full pass per domain through that domain's model, shuffled order."""

@@ -38,6 +38,66 @@ def world():
     return 0, 1
 
 
+# phi slots travel owner -> next owner point to point (BalancedMAMDR._transfer); False: one broadcast per slot instead
+# (what `preflight` switches to when the ring of sends / receives fails on this machine)
+P2P_ENABLED = True
+
+
+def p2p_possible(device):
+    """send / recv of a tensor on `device` exists on the initialised backend (gloo cannot send device tensors here)."""
+    return dist.get_backend() == "nccl" or torch.device(device).type == "cpu"
+
+
+def preflight(device, payload=4096):
+    """First contact with the communicator, before any epoch runs (bench.py / run.py under torch.distributed.run):
+    one tiny all-reduce, one ring of batch_isend_irecv (rank r -> r + 1: the pattern of the phi hand-over), one
+    broadcast -- each checked for its VALUES on every rank.  A hang is cut by the process group's timeout (the rank
+    exits non-zero); a send / recv that RAISES switches every rank to the per-slot broadcast path (P2P_ENABLED = False,
+    agreed by an all-reduce) with a warning.  Returns a record for the bench line."""
+    import time
+    import warnings
+    global P2P_ENABLED
+    rank, ws = world()
+    rec = {"ranks": ws, "backend": dist.get_backend() if ws > 1 else None, "all_reduce": None, "p2p": None, "broadcast": None}
+    if ws == 1:
+        return rec
+    t0 = time.perf_counter()
+    dev = torch.device(device)
+    x = torch.full((payload,), float(rank + 1), dtype=torch.float32, device=dev)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    want = ws * (ws + 1) / 2.0
+    if not bool((x == want).all().item()):
+        raise RuntimeError("preflight: all-reduce over %d ranks gave %r, not %r" % (ws, float(x[0].item()), want))
+    rec["all_reduce"] = True
+    ok = 1.0
+    if p2p_possible(dev):
+        try:
+            out = torch.arange(payload, dtype=torch.float32, device=dev) + 1000.0 * rank
+            got = torch.empty_like(out)
+            ops = [dist.P2POp(dist.isend, out, (rank + 1) % ws), dist.P2POp(dist.irecv, got, (rank - 1) % ws)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            src = (rank - 1) % ws
+            if not bool((got == torch.arange(payload, dtype=torch.float32, device=dev) + 1000.0 * src).all().item()):
+                raise RuntimeError("wrong payload from rank %d" % src)
+        except Exception as e:                       # (a hang is the timeout's business)
+            warnings.warn("preflight: point-to-point ring failed on rank %d (%s): phi slots will move by broadcast" % (rank, e))
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        P2P_ENABLED = bool(flag.item() > 0.5)
+        rec["p2p"] = P2P_ENABLED
+    else:
+        rec["p2p"] = "n/a (%s has no send / recv of device tensors)" % dist.get_backend()
+    y = torch.full((payload,), 7.0 if rank == ws - 1 else -1.0, dtype=torch.float32, device=dev)
+    dist.broadcast(y, src=ws - 1)
+    if not bool((y == 7.0).all().item()):
+        raise RuntimeError("preflight: broadcast from rank %d did not arrive on rank %d" % (ws - 1, rank))
+    rec["broadcast"] = True
+    rec["seconds"] = time.perf_counter() - t0
+    return rec
+
+
 def shard_plan(plan, owner, rank):
     """this rank's part of an epoch plan: its DN sub-sequence (order preserved) and the DR
     entries of the query domains it owns."""
@@ -338,7 +398,7 @@ class BalancedMAMDR(object):
         sent = 0
         if not moves:
             return sent
-        p2p = dist.get_backend() == "nccl" or self.pack.device.type == "cpu"
+        p2p = P2P_ENABLED and p2p_possible(self.pack.device)
         if p2p:
             ops = []
             for d, src, dst in moves:

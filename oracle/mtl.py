@@ -276,7 +276,7 @@ class OracleMTL(object):
                 m, v = self.m[n], self.v[n]
                 m += ((gr - m) * omb1).astype(F32)
                 v += ((gr * gr - v) * omb2).astype(F32)
-                self.params[n] -= ((m * alpha) / (np.sqrt(v, dtype=F32) + T.ADAM_EPS)).astype(F32)
+                self.params[n] -= ((m * alpha) / (np.sqrt(v, dtype=F32) + getattr(self, "adam_eps", T.ADAM_EPS))).astype(F32)
         self.step += 1
         return loss
 

@@ -258,6 +258,7 @@ class Optimizer(object):
         self.t = 0
         self.b1p = F32(1)
         self.b2p = F32(1)
+        self.eps = ADAM_EPS     # tf.train.AdamOptimizer's 1e-8 (a Keras Adam compiled by name has K.epsilon() = 1e-7)
 
     def adam(self, params, grads, lr):
         self.t += 1
@@ -270,11 +271,11 @@ class Optimizer(object):
             gr = grads[n]
             m, v = self.m[n], self.v[n]
             if isinstance(gr, bigtable.RowGrad):
-                bigtable.adam_rows(params[n], m, v, gr, alpha, omb1, omb2, ADAM_EPS)
+                bigtable.adam_rows(params[n], m, v, gr, alpha, omb1, omb2, self.eps)
                 continue
             m += ((gr - m) * omb1).astype(F32)
             v += ((gr * gr - v) * omb2).astype(F32)
-            params[n] -= ((m * alpha) / (np.sqrt(v, dtype=F32) + ADAM_EPS)).astype(F32)
+            params[n] -= ((m * alpha) / (np.sqrt(v, dtype=F32) + self.eps)).astype(F32)
 
     def sgd(self, params, grads, lr):
         for n in self.names:

@@ -272,6 +272,9 @@ class FakeGraphEngine(object):
         o.v = {n: np.zeros_like(o.params[n]) for n in o.names}
         o.b1p, o.b2p, o.t = F32(1), F32(1), 0
 
+    def set_adam_eps(self, eps):
+        self.oracle.adam_eps = F32(eps)
+
     def close(self):
         pass
 
