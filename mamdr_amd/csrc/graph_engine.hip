@@ -1989,7 +1989,19 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
     // DIAGNOSTIC (MAMDR_GRAPH_DIAG_REPLAY=1, wrong values, right timing): the second step of a call is captured into a
     // hipGraph and REPLAYED for the full-batch steps that follow -- what a step costs when the host issues one graph launch
     // instead of ~21 kernel launches (launch-rate sensitivity)
+    // Compiled in only with -DMAMDR_DIAG (tools/build_variant.sh): a production build that finds the variable set says so
+    // once and ignores it -- a replayed step reuses the captured batch, dropout position and Adam alpha.
+#ifdef MAMDR_DIAG
     static const bool diag_replay = getenv("MAMDR_GRAPH_DIAG_REPLAY") && atoi(getenv("MAMDR_GRAPH_DIAG_REPLAY")) != 0;
+#else
+    constexpr bool diag_replay = false;
+    static const bool diag_warned = []() {
+        if (getenv("MAMDR_GRAPH_DIAG_REPLAY") && atoi(getenv("MAMDR_GRAPH_DIAG_REPLAY")) != 0)
+            fprintf(stderr, "mamdr: MAMDR_GRAPH_DIAG_REPLAY is a diagnostic of -DMAMDR_DIAG builds (wrong values by design); ignored\n");
+        return true;
+    }();
+    (void)diag_warned;
+#endif
     hipGraph_t dgraph = nullptr;
     hipGraphExec_t dexec = nullptr;
     for (int64_t s = 0; s < n_steps; ++s) {

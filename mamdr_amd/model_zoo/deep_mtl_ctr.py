@@ -7,7 +7,7 @@ optimizer (:53-67), every step on domain d trains the variables on the path to o
 `val_and_test` scores domain d with domain d's model (:189-222), `separate_train_val_test` restarts every domain from the
 same weights (:128-187): with init_parms every domain's model is compiled with the STRING 'adam' (:147-148) -- a fresh
 Keras Adam per domain, lr 1e-3 and epsilon 1e-7 whatever `learning_rate` says, zero slots -- and for the finetune stage
-with plain SGD at `learning_rate` (:143-146); Keras EarlyStopping(val_AUC, min_delta=1e-4) + best-only checkpoint.  Initial tensors: deepctr's initialisers (glorot normal kernels, zero biases,
+with plain SGD at `learning_rate` (:143-146); Keras EarlyStopping(val_AUC, min_delta=1e-4) + best-only checkpoint.  Initial tensors: deepctr's initialisers (glorot normal DNN kernels, glorot uniform gate / head kernels, zero biases,
 N(0, 1e-4^2) domain table, pretrained constants for the user / item tables) from a numpy stream seeded with dataset.seed.
 """
 import random
@@ -56,8 +56,13 @@ def initial_tensors(rs, plan, emb_dim):
     for name, shape in plan:
         if name == "domain_emb":
             t[name] = (rs.standard_normal(shape) * 1e-4).astype(np.float32)        # deepctr SparseFeat default
+        elif name.endswith("/Wg") or (name.startswith("head_") and name.endswith("/w")):
+            # the gate's softmax kernel and the per-task output unit are plain `tf.keras.layers.Dense(..)` in deepctr
+            # 0.9.0's sharedbottom.py / mmoe.py / ple.py [dep]: Keras' default glorot_uniform, not the DNN's glorot_normal
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            t[name] = rs.uniform(-lim, lim, shape).astype(np.float32)
         elif len(shape) == 2:
-            t[name] = glorot_normal(rs, shape[0], shape[1], shape)                 # Dense kernels (DNN, gate, head)
+            t[name] = glorot_normal(rs, shape[0], shape[1], shape)                 # DNN kernels (experts, gate DNN, towers)
         else:
             t[name] = np.zeros(shape, np.float32)                                  # biases, PredictionLayer global_bias
     return t

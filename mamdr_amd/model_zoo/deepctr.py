@@ -41,10 +41,10 @@ def initial_tensors(rs, n_user, n_item, n_domain, emb_dim, hidden, user_emb=None
     t["item_emb"] = item_emb if item_emb is not None else (rs.standard_normal((n_item, emb_dim)) * 1e-4).astype(np.float32)
     t["domain_emb"] = (rs.standard_normal((n_domain, emb_dim)) * 1e-4).astype(np.float32)
     dims = (3 * emb_dim,) + tuple(hidden)
-    for l in range(3):
+    for l in range(len(hidden)):          # (the step kernels take exactly three layers; the generic-layer towers 1 - 4)
         t["W%d" % l] = glorot_normal(rs, dims[l], dims[l + 1], (dims[l], dims[l + 1]))
         t["b%d" % l] = np.zeros(dims[l + 1], np.float32)
-    t["wo"] = glorot_normal(rs, dims[3], 1, (dims[3], 1))
+    t["wo"] = glorot_normal(rs, dims[-1], 1, (dims[-1], 1))
     t["gb"] = np.zeros(1, np.float32)
     # DeepFM 1-d linear tables: Zeros initialiser (deepctr get_linear_logit); unused by the mlp tower
     t["lin_user"] = np.zeros(n_user, np.float32)
@@ -84,6 +84,12 @@ class DeepCTR(BaseModel):
         mc, tc = self.model_config, self.train_config
         if not (mc["user_dim"] == mc["item_dim"] == mc["domain_dim"]):
             raise ValueError("user_dim, item_dim and domain_dim must be equal")
+        n_hidden = len(mc["hidden_dim"])
+        if tower in GRAPH_TOWERS and not 1 <= n_hidden <= 4:
+            raise ValueError("hidden_dim %r: the '%s' tower takes 1 to 4 hidden layers" % (mc["hidden_dim"], tower))
+        if tower not in GRAPH_TOWERS and n_hidden != 3:
+            raise ValueError("hidden_dim %r: the '%s' tower's kernels are built for three hidden layers (the reference's "
+                             "configs all have [256, 128, 64])" % (mc["hidden_dim"], tower))
         factory = self.engine_factory
         if tower in GRAPH_TOWERS:         # generic-layer engine; an injected factory offers it as `.graph` (tests)
             if factory is not None:
