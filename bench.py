@@ -211,17 +211,35 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
     pinned, restore = _pin_to_one_socket()
     try:
         cap = len(pinned) if pinned else (cores // 2 if cores >= 16 else cores)
-        trials, best_nt, best_t, nt = [], None, None, min(8, cap)
-        while True:
+        # counts tried: 8, 16, 32, ... and 3/4 of the cap before the cap itself.  A count is STABLE when no step of its
+        # trial took more than 2.5 x the trial's median: near the pinned core count single steps stall for 0.1 - 1.6 s
+        # (tests/diag_cpu_cliff.py on the GPU host, profiles/r04_cpu_cliff.jsonl: 62 / 64 threads on 64 pinned cores,
+        # median 2.9 - 3.4 ms but outliers of 84 - 1,597 ms -- OpenMP's spinning workers lose a core to any other
+        # runnable thread of this shared host and the whole team waits at the next barrier; OMP_WAIT_POLICY=passive
+        # removes the outliers and costs 2 - 3 x on every step).  The baseline is the fastest STABLE count.
+        counts, nt = [], min(8, cap)
+        while nt < cap:
+            counts.append(nt)
+            nt *= 2
+        if cap >= 16 and (3 * cap) // 4 not in counts:
+            counts.append((3 * cap) // 4)
+        counts = sorted(set(counts + [cap]))
+        trials, unstable, best_nt, best_t = [], [], None, None
+        for nt in counts:
             torch.set_num_threads(nt)
             one(0)
-            t = float(np.median([one(k) for k in range(1, 6)]))
+            ts = [one(k) for k in range(1, 8)]
+            t, worst = float(np.median(ts)), float(max(ts))
             trials.append((nt, t))
+            if worst > 2.5 * t:
+                unstable.append((nt, worst))
+                continue
             if best_t is None or t < best_t:
                 best_nt, best_t = nt, t
-            if nt >= cap or t > 1.25 * best_t:
+            if best_t is not None and t > 1.25 * best_t:
                 break
-            nt = min(2 * nt, cap)
+        if best_nt is None:                  # (every count had an outlier: take the best median)
+            best_nt, best_t = min(trials, key=lambda x: x[1])
         torch.set_num_threads(best_nt)
         reps = []
         for _ in range(3):
@@ -235,6 +253,7 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
            "host_cores_visible": int(cores), "pinned_to": "%d physical cores of one socket" % len(pinned) if pinned else "not pinned",
            "repeats": [round(r[0], 2) for r in reps], "spread": [round(reps[0][0], 2), round(reps[-1][0], 2)],
            "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 2) for k, v in trials},
+           "thread_sweep_unstable": {str(k): round(v * 1e3, 1) for k, v in unstable},     # count -> slowest step of its trial, ms
            "sample": "median of 3 repeats of ~%d inner steps each (bs=%d, domain %d of the same synthetic workload, %.1f s per "
                      "repeat): torch-CPU fp32 restatement of the TF1.12 step (gather, tower forward, Keras BCE, autograd "
                      "backward, dense TF1 Adam, dropout masks from a pre-drawn pool; oracle/torch_ref.py) on %d threads "
@@ -573,6 +592,51 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows,
                                    tower_flops_per_row(384 if tower == "star" else (256 if trainable else 0)))
         roofline["rocprofv3_avg_us"] = rocprof_avg_us(kname, wl["shape"])
+        if kname == "k_tower4<false, false, true, true>":
+            # what this three-phase, 4-row-tile design can reach: the kernel's measured time minus
+            # what the diagnostic builds of round 2 showed each single remedy can return at most (DESIGN.md section 6:
+            # no W1 traffic at all 0.6 us, no split-k exchange through LDS 0.3 us, no cold paths 0.2 us)
+            roofline["latency_floor_us"] = max(roofline["avg_us"] - (0.6 + 0.3 + 0.2), 0.0)
+            roofline["latency_floor_note"] = ("avg_us minus the sum of the measured ablation bounds (no W1 stream, no split-k "
+                                              "exchange, no cold paths: diagnostic builds, DESIGN.md section 6); the MFMA "
+                                              "floor of a 4-row tile is 2.8 us, its weight stream at the L1 fill peak 3.8 us")
+        # ---- the other kernels of a step against the roof that bounds each of them
+        props = torch.cuda.get_device_properties(eng.device)
+        # parameters one k_update launch steps: the dense block (the tables and DeepFM's 1-d linear tables have kernels of
+        # their own); of the Star tower's per-domain tensors only the batch's slice (the others are replayed lazily)
+        per_domain = ("Wd0", "Wd1", "Wd2", "bd0", "bd1", "bd2", "pn_gamma_spec", "pn_beta_spec")
+        p_dense = sum((c // D if n in per_domain else c) for n, (_, c) in eng.segments.items()
+                      if n not in ("user_emb", "item_emb", "lin_user", "lin_item"))
+        rows_avg = prof_rows / max(cnt, 1)
+        rated = []
+        for key, kn in names.items():
+            if kn not in kernels or key == L.KERNEL_FWD_BWD:
+                continue
+            k_us, k_n = kernels[kn]["avg_us"], kernels[kn]["launches"]
+            if key == L.KERNEL_WGRAD:
+                # weight gradients: 2 x rows x 139,777 flop per launch; with k_wgrad_adam the optimiser step of
+                # the dense block rides in the same launch
+                ach = 2.0 * rows_avg * 139777 / (k_us * 1e-6) / 1e12
+                rated.append({"kernel": kn, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_us": k_us, "launches": k_n})
+            elif key == L.KERNEL_UPDATE and kn.startswith("k_update"):
+                # dense optimiser step: 28 B per parameter (read p, m, v, g; write p, m, v); the gradient arrives as G
+                # slabs (4 G P more bytes read: not algorithmic)
+                ach = 28.0 * p_dense / (k_us * 1e-6) / 1e9
+                rated.append({"kernel": kn, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": ach / PEAK_HBM_GBS, "avg_us": k_us, "launches": k_n, "bytes_per_launch": 28.0 * p_dense})
+            elif key == L.KERNEL_FLUSH:
+                # lazy table Adam's replay: every missed step of every element exactly once -> (steps between two
+                # flushes) x table elements per launch (rows a batch touched in between replay fewer: < 10 % of the
+                # rows), against the issue bound of its two quarter-rate instructions per element-step (v_sqrt_f32 +
+                # v_rcp_f32: 16 cycles each per 64-lane wave on a SIMD)
+                el_steps = (g["n_user"] + g["n_item"]) * 128.0 * (prof_steps / max(k_n, 1))
+                peak = props.multi_processor_count * 4 * getattr(props, "clock_rate", 2400000) * 1e3 * 64.0 / 32.0 / 1e12
+                ach = el_steps / (k_us * 1e-6) / 1e12
+                rated.append({"kernel": kn, "bound": "alu (quarter-rate v_sqrt_f32 + v_rcp_f32)", "achieved": ach, "peak": peak,
+                              "unit": "T element-steps/s", "frac": ach / peak, "avg_us": k_us, "launches": k_n,
+                              "element_steps_per_launch": el_steps})
+        kernels["_rated"] = rated
         if not trainable:
             # the workload's own gather: pass-sized, the frozen Taobao tables live in L2 / infinity cache
             dbig = max(range(D), key=lambda k: sizes[k])

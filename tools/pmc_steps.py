@@ -3,6 +3,9 @@ usage: python tools/pmc_steps.py [shape] [batch] [steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from mamdr_amd import _lib
+if os.environ.get("MAMDR_LIB_PATH"):          # a diagnostic build of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.environ["MAMDR_LIB_PATH"]
 from mamdr_amd import engine, synthetic
 shape = sys.argv[1] if len(sys.argv) > 1 else "taobao30"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
