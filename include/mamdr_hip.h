@@ -40,7 +40,11 @@ enum {
 /* tower kinds: run.py:37-47 + model_zoo/DeepCTR/deepctr.py:24-50 name registry */
 enum { MAMDR_TOWER_MLP = 0, MAMDR_TOWER_DEEPFM = 1, MAMDR_TOWER_STAR = 2,
        /* deepctr WDL (deepctr.py:29-32): linear tables + DNN = DeepFM without the FM term; same segments */
-       MAMDR_TOWER_WDL = 3 };
+       MAMDR_TOWER_WDL = 3,
+       /* deepctr PNN (deepctr.py:44-46; use_inner, no outer product): the mlp tower on [user | item | domain | <u,i> <u,d>
+          <i,d>] -- the three inner products feed three more rows of the first kernel (segment MAMDR_SEG_W0X).  Steps of
+          up to 2,048 rows (every reference config has batch_size 1,024); larger batches: the generic-layer engine */
+       MAMDR_TOWER_PNN = 4 };
 /* data splits: utils/dataset.py:79-92 */
 enum { MAMDR_SPLIT_TRAIN = 0, MAMDR_SPLIT_VAL = 1, MAMDR_SPLIT_TEST = 2 };
 /* optimisers: deepctr.py:55 (Adam) / specific_base_model.py:120, base_model.py:69 (SGD finetune) */
@@ -71,7 +75,9 @@ enum {
     MAMDR_SEG_STAR_BD0 = 27, MAMDR_SEG_STAR_BD1 = 28, MAMDR_SEG_STAR_BD2 = 29,
     /* uncertainty weighting: `log_var` [D] (model_zoo/uncertainty_weight/weighted_loss.py:23-28), last segment */
     MAMDR_SEG_LOG_VAR = 30,
-    MAMDR_SEG_COUNT = 31
+    /* PNN: rows 384..386 of deepctr's first DNN kernel [387, 256] (the inner products' rows), behind everything else */
+    MAMDR_SEG_W0X = 31,
+    MAMDR_SEG_COUNT = 32
 };
 /* kernels whose device time can be profiled (mamdr_profile_*) */
 enum { MAMDR_KERNEL_FWD_BWD = 0, MAMDR_KERNEL_WGRAD = 1, MAMDR_KERNEL_UPDATE = 2,
@@ -370,6 +376,8 @@ int mamdr_graph_optimizer_reset(mamdr_graph* g);
  * (epsilon = K.epsilon() = 1e-7) where the shared optimiser of :53-56 is tf.train.AdamOptimizer (1e-8) */
 int mamdr_graph_set_adam_eps(mamdr_graph* g, float eps);
 int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g);
+/* kernel launches this process has issued through mamdr_graph_* calls so far (measurement: launches per step) */
+int64_t mamdr_graph_launch_count(void);
 int64_t mamdr_graph_dropout_steps(const mamdr_graph* g);
 int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t n_rows);     /* deep_mtl_ctr.py:98-121 */
 int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const int32_t* d_uid, const int32_t* d_pid,

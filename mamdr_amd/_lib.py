@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
 ABI_VERSION = 14
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
-TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL = 0, 1, 2, 3
+TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN = 0, 1, 2, 3, 4
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
 OPT_ADAM, OPT_SGD, OPT_ACCUMULATE = 0, 1, 2
 MERGE_PLUS, MERGE_TIMES = 0, 1
@@ -22,7 +22,8 @@ SEG_NAMES = ("user_emb", "item_emb", "domain_emb", "W0", "W1", "W2", "b0", "b1",
              # Star tower
              "Ws0", "Ws1", "Ws2", "bs0", "bs1", "bs2", "pn_gamma_shared", "pn_beta_shared", "pn_gamma_spec",
              "pn_beta_spec", "Wd0", "Wd1", "Wd2", "bd0", "bd1", "bd2",
-             "log_var")
+             "log_var",
+             "W0x")          # PNN: the inner products' three rows of the first kernel
 KERNEL_FWD_BWD, KERNEL_WGRAD, KERNEL_UPDATE, KERNEL_EVAL, KERNEL_GATHER, KERNEL_EMB_SWEEP, KERNEL_AUX, KERNEL_FLUSH = range(8)
 KERNEL_NAMES = ("k_tower<train>", "k_wgrad", "k_update", "k_tower<eval>", "k_gather", "k_emb_sweep",
                 "other launches of a step (include/mamdr_hip.h: MAMDR_KERNEL_AUX)", "k_emb_flush")
@@ -120,6 +121,7 @@ SIGNATURES = {
     "mamdr_graph_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_graph_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_graph_set_adam_eps": (C.c_int, [_VP, _F]),
+    "mamdr_graph_launch_count": (_I64, []),
     "mamdr_graph_optimizer_steps": (_I64, [_VP]),
     "mamdr_graph_dropout_steps": (_I64, [_VP]),
     "mamdr_graph_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),

@@ -40,6 +40,14 @@
 #include "../../include/mamdr_hip.h"
 #include "mamdr_kernels.h"
 
+// every kernel launch of this engine goes through here: the count is what tools/graph_bench.py reports as launches per step
+static long long g_graph_launches = 0;
+#define GLAUNCH(...)                      \
+    do {                                  \
+        ++g_graph_launches;               \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
+
 using namespace mamdr;
 
 namespace {
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(256) void k_graph_dx_reduce(const float* part, int 
     *reinterpret_cast<f32x4*>(o) = v;
 }
 static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, float* out, int n_valid) {
-    hipLaunchKernelGGL(k_graph_colsum, dim3((n_valid + CS_COLS - 1) / CS_COLS), dim3(256), 0, s, dz, ld, rows, out, n_valid);
+    GLAUNCH(k_graph_colsum, dim3((n_valid + CS_COLS - 1) / CS_COLS), dim3(256), 0, s, dz, ld, rows, out, n_valid);
 }
 
 // out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1; the
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_
 }
 static void launch_small_tn(hipStream_t s, const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
                             float* out, float* sum_out = nullptr) {
-    hipLaunchKernelGGL(k_graph_small_tn, dim3((n_j * n_e + CS_COLS - 1) / CS_COLS + (sum_out ? 1 : 0)), dim3(256), 0, s, in, in_ld,
+    GLAUNCH(k_graph_small_tn, dim3((n_j * n_e + CS_COLS - 1) / CS_COLS + (sum_out ? 1 : 0)), dim3(256), 0, s, in, in_ld,
                        d, d_ld, rows, n_j, n_e, out, sum_out);
 }
 
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(256) void k_graph_lin_domain_grad(const float* dlog
 }
 static void launch_lin_domain_grad(hipStream_t s, const float* dlogit, const int32_t* domrow, int rows, const float* w, float two_l2,
                                    int n_domain, float* g) {
-    hipLaunchKernelGGL(k_graph_lin_domain_grad, dim3(n_domain), dim3(256), 0, s, dlogit, domrow, rows, w, two_l2, n_domain, g);
+    GLAUNCH(k_graph_lin_domain_grad, dim3(n_domain), dim3(256), 0, s, dlogit, domrow, rows, w, two_l2, n_domain, g);
 }
 
 // ------------------------------------------------------------------ CCPM: convolutions over the FIELD axis, one wave per row
@@ -1174,19 +1182,19 @@ void launch_wgrad(mamdr_graph* g, GemmArgs a, int M, int N, int rows, const floa
     a.K = rows / split;
     a.zstride = (size_t)M * N;
     if (split > 1) a.C = g->wpart;
-    hipLaunchKernelGGL(k_graph_gemm<2>, dim3(N / GT, M / GT, split), dim3(256), 0, g->stream, a);
+    GLAUNCH(k_graph_gemm<2>, dim3(N / GT, M / GT, split), dim3(256), 0, g->stream, a);
     const int64_t n4 = (int64_t)M * N / 4;
     const int nb_red = split > 1 ? (int)((n4 + 255) / 256) : 0, nb_cs = db ? (N + CS_COLS - 1) / CS_COLS : 0;
     if (nb_red + nb_cs)
-        hipLaunchKernelGGL(k_graph_wfinish, dim3(nb_red + nb_cs), dim3(256), 0, g->stream, g->wpart, split, a.zstride, n4, out,
+        GLAUNCH(k_graph_wfinish, dim3(nb_red + nb_cs), dim3(256), 0, g->stream, g->wpart, split, a.zstride, n4, out,
                            nb_red, dz, g->ld, rows, db, N);
 }
 
 void launch_gemm(int mode, const GemmArgs& a, int M, int N, hipStream_t s) {
     const dim3 grid(N / GT, M / GT), block(256);
-    if (mode == 0) hipLaunchKernelGGL(k_graph_gemm<0>, grid, block, 0, s, a);
-    else if (mode == 1) hipLaunchKernelGGL(k_graph_gemm<1>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(k_graph_gemm<2>, grid, block, 0, s, a);
+    if (mode == 0) GLAUNCH(k_graph_gemm<0>, grid, block, 0, s, a);
+    else if (mode == 1) GLAUNCH(k_graph_gemm<1>, grid, block, 0, s, a);
+    else GLAUNCH(k_graph_gemm<2>, grid, block, 0, s, a);
 }
 
 struct StepCtx {
@@ -1319,7 +1327,7 @@ void dnn_forward_group(mamdr_graph* g, const std::vector<int>& ids, const std::v
             t.bias_off[e] = L.b_off;
             t.drop_key[e] = dropout_layer_key(sc.seed, sc.step, L.id);
         }
-        hipLaunchKernelGGL(k_graph_gemm_group<0>, dim3(L0.out / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+        GLAUNCH(k_graph_gemm_group<0>, dim3(L0.out / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
     }
 }
 // backward of the group (every member's last-layer d z sits in the gradient workspace): weight / bias gradients and the
@@ -1361,10 +1369,10 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                 f.c_off[e] = L.w_off - g->table_floats;
                 f.bias_off[e] = L.b_off - g->table_floats;
             }
-            hipLaunchKernelGGL(k_graph_gemm_group<2>, dim3(N / GT, (M / GT) * n, split), dim3(256), 0, g->stream, a, t);
+            GLAUNCH(k_graph_gemm_group<2>, dim3(N / GT, (M / GT) * n, split), dim3(256), 0, g->stream, a, t);
             const int64_t n4 = (int64_t)M * N / 4;
             const int nb_red = split > 1 ? (int)((n4 + 255) / 256) : 0, nb_cs = (N + CS_COLS - 1) / CS_COLS;
-            hipLaunchKernelGGL(k_graph_wfinish_group, dim3(nb_red + nb_cs, n), dim3(256), 0, g->stream, g->wpart, split,
+            GLAUNCH(k_graph_wfinish_group, dim3(nb_red + nb_cs, n), dim3(256), 0, g->stream, g->wpart, split,
                                a.zstride, n4, g->grad, nb_red, g->dact, g->ld, sc.rp, g->grad, N, f);
         }
         if (l > 0) {    // d in_e = dz_e W_e^T through the producer's relu / dropout gate
@@ -1390,7 +1398,7 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                 t.c_off[e] = cols[e][l - 1];
                 t.gate_off[e] = cols[e][l - 1];
             }
-            hipLaunchKernelGGL(k_graph_gemm_group<1>, dim3(M / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+            GLAUNCH(k_graph_gemm_group<1>, dim3(M / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
         } else {
             // d x = sum_e dz_e W_e[first : first + nn]^T
             const int first = din_n > 0 ? din_first : 0, nn = din_n > 0 ? din_n : M;
@@ -1415,9 +1423,9 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                     t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
                     t.c_off[e] = (int64_t)e * stride;
                 }
-                hipLaunchKernelGGL(k_graph_gemm_group<1>, dim3(nn / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+                GLAUNCH(k_graph_gemm_group<1>, dim3(nn / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
                 const int64_t tot = (int64_t)sc.rp * (nn / 4);
-                hipLaunchKernelGGL(k_graph_dx_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g->stream, g->dxpart, n,
+                GLAUNCH(k_graph_dx_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g->stream, g->dxpart, n,
                                    stride, sc.rp, nn / 4, g->dact + in_col + first, g->ld, din_acc ? 1 : 0);
             } else {    // one contraction whose reduction index runs through all members
                 a.C = g->dact + in_col + first;
@@ -1427,7 +1435,7 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                     t.a_off[e] = cols[e][0];
                     t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
                 }
-                hipLaunchKernelGGL(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
+                GLAUNCH(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
             }
         }
     }
@@ -1505,7 +1513,7 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
                 aa.top = g->act + g->top_col;
                 aa.top_ld = g->ld;
             }
-            hipLaunchKernelGGL(k_graph_att_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, aa);
+            GLAUNCH(k_graph_att_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, aa);
         }
         dnn_forward(g, g->dnns[t.tower], t.col[0], 0, sc);
         return g->top_col;
@@ -1514,13 +1522,13 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
         if (g->cfg.kind == MAMDR_GRAPH_CCPM) {
             CcpmArgs ca;
             fill_ccpm(g, sc, ca);
-            hipLaunchKernelGGL(k_graph_ccpm_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
+            GLAUNCH(k_graph_ccpm_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
             dnn_forward(g, g->dnns[t.tower], t.col[0], g->f_col, sc);
             return t.col[0].back();
         }
         FeatArgs fa;
         fill_feat(g, t, sc, fa);
-        hipLaunchKernelGGL(k_graph_feat_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
+        GLAUNCH(k_graph_feat_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
         const bool nfm = g->cfg.kind == MAMDR_GRAPH_NFM;
         dnn_forward(g, g->dnns[t.tower], t.col[0], nfm ? g->f_col : 0, sc, nfm ? -1 : g->f_col);
         return t.col[0].back();
@@ -1537,7 +1545,7 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
         dnn_forward(g, g->dnns[t.gate], t.col[gi], 0, sc);
         GateArgs ga;
         fill_gate(g, t, sc, ga);
-        hipLaunchKernelGGL(k_graph_gate_fwd, dim3(sc.rp), dim3(256), 0, g->stream, ga);
+        GLAUNCH(k_graph_gate_fwd, dim3(sc.rp), dim3(256), 0, g->stream, ga);
         tower_in = t.m_col;
     } else {
         tower_in = t.col[0].back();
@@ -1917,6 +1925,7 @@ int mamdr_graph_set_adam_eps(mamdr_graph* g, float eps) {
     g->cfg.adam_eps = eps;
     return MAMDR_OK;
 }
+int64_t mamdr_graph_launch_count(void) { return (int64_t)g_graph_launches; }
 int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g) { return g ? g->adam_t : 0; }
 int64_t mamdr_graph_dropout_steps(const mamdr_graph* g) { return g ? (int64_t)g->global_step : 0; }
 
@@ -2040,7 +2049,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
         }
         GatherArgs ga;
         fill_gather(g, *d, d_perm, row_base, sc, ga);
-        hipLaunchKernelGGL(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
+        GLAUNCH(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
         const int t_col = task_forward(g, t, sc);
         const Dnn& tower = g->dnns[t.tower];
         HeadArgs ha;
@@ -2064,10 +2073,10 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
         ha.extra = g->extra;
         ha.train = 1;
         ha.gate_scale = sc.keep_scale;
-        hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
+        GLAUNCH(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
         if (d_loss_out && g->tables) refresh_sumsq(g);
         if (d_loss_out)
-            hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
+            GLAUNCH(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
                                g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out + s, 0,
                                g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear);
         // ---- backward
@@ -2096,7 +2105,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                     aa.dtop = g->dact + g->top_col;
                     aa.dtop_ld = g->ld;
                 }
-                hipLaunchKernelGGL(k_graph_att_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, aa);
+                GLAUNCH(k_graph_att_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, aa);
                 const float* xin = l == 0 ? g->xt : g->attY[l - 1];
                 if (l == 0) {
                     GemmArgs a;
@@ -2118,12 +2127,12 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                     a.K = ATT_P;
                     launch_gemm(1, a, 3 * sc.rp, d_in, g->stream);
                     const int first = g->tables ? 0 : 2 * EMB, n = g->tables ? XDIM : EMB;
-                    hipLaunchKernelGGL(k_graph_add_x, dim3((sc.rp * n + 255) / 256), dim3(256), 0, g->stream, g->dact, g->ld, g->dxt,
+                    GLAUNCH(k_graph_add_x, dim3((sc.rp * n + 255) / 256), dim3(256), 0, g->stream, g->dact, g->ld, g->dxt,
                                        sc.rp, first, n);
                 } else {
                     launch_small_tn(g->stream, xin, d_in,
                                        g->attdP[l], ATT_P, 3 * sc.rp, d_in, ATT_P, g->G(g->att_w[l]));
-                    hipLaunchKernelGGL(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
+                    GLAUNCH(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
                                        ATT_P, g->params + g->att_w[l], d_in, 3 * sc.rp, g->attdY[l - 1]);
                 }
             }
@@ -2135,7 +2144,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[0], g->f_col, g->f_col, -1, false, 0, 0, sc);
             CcpmArgs ca;
             fill_ccpm(g, sc, ca);
-            hipLaunchKernelGGL(k_graph_ccpm_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
+            GLAUNCH(k_graph_ccpm_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
             launch_colsum(g->stream, g->dact + g->cg_col, g->ld, sc.rp,
                                g->G(g->conv_off), 48);
             launch_lin_domain_grad(g->stream, g->dlogit,
@@ -2155,7 +2164,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                 launch_small_tn(g->stream, g->act + g->f_col, g->ld,
                                    g->dact + t.col[0][0], g->ld, sc.rp, 3, L0.out, g->G(L0.w_off + (int64_t)L0.in * L0.out));
             }
-            hipLaunchKernelGGL(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
+            GLAUNCH(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
             if (nfm)
                 launch_lin_domain_grad(g->stream, g->dlogit,
                                    g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
@@ -2164,7 +2173,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[ti], t.m_col, t.m_col, -1, false, 0, 0, sc);
             GateArgs gta;
             fill_gate(g, t, sc, gta);
-            hipLaunchKernelGGL(k_graph_gate_bwd, dim3(sc.rp), dim3(256), 0, g->stream, gta);
+            GLAUNCH(k_graph_gate_bwd, dim3(sc.rp), dim3(256), 0, g->stream, gta);
             const size_t gi = t.mix.size();
             const Dnn& gd = g->dnns[t.gate];
             launch_small_tn(g->stream, g->act + gta.q_col,
@@ -2186,7 +2195,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
             dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
-        hipLaunchKernelGGL(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
+        GLAUNCH(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
                            sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
         if (g->tables) {
             // TF1's dense step over both tables: g = 2 l2 p + scatter-add of d x[:, user | item columns]
@@ -2251,7 +2260,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             aa.omb2 = omb2;
             aa.eps = g->cfg.adam_eps;
             const int64_t n4 = aa.n4[0] + aa.n4[1];
-            if (n4 > 0) hipLaunchKernelGGL(k_graph_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, g->stream, aa);
+            if (n4 > 0) GLAUNCH(k_graph_adam, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, g->stream, aa);
         }
         g->global_step += 1;
     }
@@ -2291,7 +2300,7 @@ int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch
         sc.keep_scale = 1.0f;
         GatherArgs ga;
         fill_gather(g, *d, nullptr, row_base, sc, ga);
-        hipLaunchKernelGGL(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
+        GLAUNCH(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
         const int t_col = task_forward(g, t, sc);
         HeadArgs ha;
         memset(&ha, 0, sizeof(ha));
@@ -2312,12 +2321,12 @@ int mamdr_graph_eval_domain(mamdr_graph* g, int domain, int split, int32_t batch
         ha.thresholds = g->thresholds;
         ha.hist = d_hist;
         ha.pred_out = d_pred_out ? d_pred_out + row_base : nullptr;
-        hipLaunchKernelGGL(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
-        hipLaunchKernelGGL(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
+        GLAUNCH(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
+        GLAUNCH(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
                            g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, g->eval_acc, 1,
                            g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear);
     }
-    hipLaunchKernelGGL(k_graph_scale, dim3(1), dim3(1), 0, g->stream, g->eval_acc, 1.0f / (float)n_batches);
+    GLAUNCH(k_graph_scale, dim3(1), dim3(1), 0, g->stream, g->eval_acc, 1.0f / (float)n_batches);
     GHIP(hipMemcpyAsync(d_loss_out, g->eval_acc, sizeof(float), hipMemcpyDeviceToDevice, g->stream));
     GHIP(hipGetLastError());
     return MAMDR_OK;

@@ -65,6 +65,8 @@ struct mamdr_ctx {
     DenseLayout L;
     int64_t table_floats = 0;   // trainable user+item floats in front of the dense block
     bool deepfm = false;
+    bool pnn = false;           // the mlp tower + three inner-product inputs (MAMDR_TOWER_PNN): FM instances of the towers, mode 3
+    float* ipbuf = nullptr;     // PNN: [rows_pad][4] the batch's inner products (A operand of dW0x's tiles)
     bool star = false;
     StarLayout SL;
     StarAuxLayout AL;
@@ -211,7 +213,8 @@ struct mamdr_ctx {
 
 namespace {
 
-std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off, bool lin_w0dom, bool star) {
+std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off, bool lin_w0dom, bool star,
+                                  bool pnn = false) {
     std::vector<TileDesc> t;
     struct G { int a_off, M, b_off, N, dst; };
     // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
@@ -237,14 +240,18 @@ std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepf
             const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
             t.push_back(TileDesc{2, m0, 0, n0, L.alloc + m0 * H1 + n0, H1, mv, 32});
         }
-    if (deepfm)
+    if (deepfm || pnn)
         for (int m0 = 0; m0 < n_domain; m0 += 32) {
             const int mv = n_domain - m0 < 32 ? n_domain - m0 : 32;
-            // FM part of the domain-table gradient: S2 = onehot(domain)^T (dlogit * (u + i))
+            // per-row part of the domain-table gradient: S2 = onehot(domain)^T fmq (DeepFM: dlogit * (u + i); PNN: the
+            // inner products' chain rule, dip_ud * u + dip_id * i)
             for (int n0 = 0; n0 < EMB; n0 += 32) t.push_back(TileDesc{2, m0, 2, n0, s2_off + m0 * EMB + n0, EMB, mv, 32});
             // linear domain table: onehot(domain)^T dlogit
-            t.push_back(TileDesc{2, m0, 1, 0, L.ld + m0, 1, mv, 1});
+            if (deepfm) t.push_back(TileDesc{2, m0, 1, 0, L.ld + m0, 1, mv, 1});
         }
+    // PNN: the three extra rows of the first kernel, dW0x = ip^T dz1 (A = the batch's inner products, ipbuf [B][4])
+    if (pnn)
+        for (int n0 = 0; n0 < H1; n0 += 32) t.push_back(TileDesc{3, 0, 0, n0, L.wx + n0, H1, 3, 32});
     return t;
 }
 
@@ -314,7 +321,8 @@ void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
     a.label = d.label;
     a.n_rows_split = d.n;
     a.thresholds = c->thresholds;
-    a.deepfm = c->deepfm ? (c->cfg.tower == MAMDR_TOWER_WDL ? 2 : 1) : 0;
+    a.deepfm = c->deepfm ? (c->cfg.tower == MAMDR_TOWER_WDL ? 2 : 1) : (c->pnn ? 3 : 0);
+    a.ipbuf = c->ipbuf;
     a.uw_off = -1;
     if (c->deepfm && c->cfg.emb_trainable) {
         a.lin_user = c->params + c->lin_user_off;
@@ -694,7 +702,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (cfg->abi_version != MAMDR_ABI_VERSION)
         return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
     if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM && cfg->tower != MAMDR_TOWER_STAR &&
-        cfg->tower != MAMDR_TOWER_WDL)
+        cfg->tower != MAMDR_TOWER_WDL && cfg->tower != MAMDR_TOWER_PNN)
         return fail(MAMDR_EINVAL, "unknown tower kind %d", cfg->tower);
     if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
         return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
@@ -705,15 +713,19 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         return fail(MAMDR_EINVAL, "max_batch must be a positive multiple of %d", TILE_ROWS);
     if (cfg->max_batch > 16384) return fail(MAMDR_EINVAL, "max_batch %d exceeds 16384", cfg->max_batch);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
-    if (cfg->uncertainty_weight && cfg->tower == MAMDR_TOWER_STAR)
+    if (cfg->uncertainty_weight && (cfg->tower == MAMDR_TOWER_STAR || cfg->tower == MAMDR_TOWER_PNN))
         return fail(MAMDR_ENOTBUILT, "uncertainty weighting is built for the mlp / deepfm towers only");
+    if (cfg->tower == MAMDR_TOWER_PNN && cfg->max_batch > 2048)
+        return fail(MAMDR_ENOTBUILT, "the pnn tower's training step is built on the four-row tower: batches of up to 2,048 rows, "
+                                     "not %d (the generic-layer engine, mamdr_graph_*, takes any batch size)", cfg->max_batch);
 
     mamdr_ctx* c = new (std::nothrow) mamdr_ctx();
     if (!c) return fail(MAMDR_EINVAL, "out of host memory");
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
     c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM || cfg->tower == MAMDR_TOWER_WDL;   // linear tables (+ FM term)
-    c->L = DenseLayout::make(cfg->n_domain, c->deepfm, cfg->uncertainty_weight != 0);
+    c->pnn = cfg->tower == MAMDR_TOWER_PNN;
+    c->L = DenseLayout::make(cfg->n_domain, c->deepfm, cfg->uncertainty_weight != 0, c->pnn);
     c->table_floats = cfg->emb_trainable ? ((int64_t)cfg->n_user + cfg->n_item) * EMB : 0;
     if (c->deepfm && cfg->emb_trainable) {
         // each 1-d table padded to 4 floats so that the dense block stays 16-B aligned
@@ -730,7 +742,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     c->rows_pad_max = cfg->max_batch;
     if (const char* tt = getenv("MAMDR_TOWER_TILE")) c->tower_tile = atoi(tt);
     c->slab_ld = c->L.alloc + cfg->n_domain * H1;
-    if (c->deepfm) {
+    if (c->deepfm || c->pnn) {      // per-row terms of the domain-table gradient: S2 = onehot(domain)^T fmq
         c->s2_off = c->slab_ld;
         c->slab_ld += cfg->n_domain * EMB;
     }
@@ -739,7 +751,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     // dW0[256:384] without tiles: Dm^T . S in k_update, or (Star: one normalised domain row per batch) the
     // rank-1 form in k_star_update
     c->lin_w0dom = (c->star || cfg->n_domain <= 64) && !getenv("MAMDR_NO_W0LIN");
-    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom, c->star);
+    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom, c->star, c->pnn);
     c->n_tiles = (int)tiles.size();
     float thr[500];
     thr[0] = (float)(0.0 - 1e-7);
@@ -800,7 +812,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
             ALLOC(c->glin_i, rp * sizeof(float));
         }
     }
-    if (c->deepfm) ALLOC(c->fmq, rp * EMB * sizeof(float));
+    if (c->deepfm || c->pnn) ALLOC(c->fmq, rp * EMB * sizeof(float));
+    if (c->pnn) ALLOC(c->ipbuf, rp * 4 * sizeof(float));
     ALLOC(c->domrow, rp * sizeof(int32_t));
     ALLOC(c->loss_part, (rp / 4) * sizeof(float));
     ALLOC(c->wT, (size_t)WT_FLOATS * sizeof(float));
@@ -880,7 +893,7 @@ int mamdr_destroy(mamdr_ctx* c) {
             (void)hipEventDestroy(p.b);
         }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->star_alpha, c->pdm, c->dmsnap[0], c->dmsnap[1], c->xpre, c->pdom, c->plabel, c->fmq, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
+    void* ptrs[] = {c->urow_alt, c->irow_alt, c->map_u_alt, c->map_i_alt, c->acts, c->dz, c->dlogit, c->w0dom_copy, c->dm_copy, c->wT, c->dxe, c->urow, c->irow, c->map_u, c->map_i, c->gbuf_u, c->gbuf_i, c->hasdup_u, c->hasdup_i, c->last_u, c->last_i, c->alpha_log, c->star_alpha, c->pdm, c->dmsnap[0], c->dmsnap[1], c->xpre, c->pdom, c->plabel, c->fmq, c->ipbuf, c->glin_u, c->glin_i, c->eff, c->pn, c->star_part, c->star_sums, c->star_dmpart, c->domrow, c->loss_part, c->eval_part, c->slabs,
                     c->tiles, c->thresholds, c->frozen_sumsq, c->sumsq_partials};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -968,6 +981,7 @@ int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* c
             break;
         case MAMDR_SEG_LIN_DOMAIN: off = base + L.ld; cnt = L.ld_count; break;
         case MAMDR_SEG_LOG_VAR: off = base + L.lv; cnt = L.lv_count; break;
+        case MAMDR_SEG_W0X: off = base + L.wx; cnt = L.wx_count; break;
         default: return fail(MAMDR_EINVAL, "unknown segment %d", seg);
     }
     *offset = off;
@@ -1385,6 +1399,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.no_w1l = c->t4_no_w1l;
         float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= c->tower4_max_rows);
+        if (c->pnn && !use4)
+            return fail(MAMDR_ENOTBUILT, "pnn tower: a training step of %d rows needs the four-row tower (MAMDR_TOWER_TILE=16?)", rows);
         if (fused) {
             ta.w0dom_snap = c->w0dom_copy;
             c->dm_cur ^= 1;
@@ -1480,6 +1496,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         wa.dlogit = c->dlogit;
         wa.domrow = c->domrow;
         wa.fmq = c->fmq;
+        wa.ipbuf = c->ipbuf;
         wa.ld_off = c->L.ld;
         wa.ld_count = c->L.ld_count;
         wa.l2_lin = c->cfg.l2_linear;

@@ -28,9 +28,11 @@ constexpr int WT_FLOATS = H1 * H2 + H2 * H3 + 2 * EMB * H1;
 // dense block of the flat trainable vector, relative to the domain table start
 // (DeepFM appends its 1-d linear table of the domain feature, `ld`, behind the global bias)
 // (uncertainty weighting appends one trainable scalar per domain, `lv`, at the very end)
+// (PNN appends the three rows of its first kernel that the field pairs' inner products feed, `wx` [3][H1], at the end:
+// W0 itself keeps its [XDIM][H1] place, so every contraction of the mlp tower reads the same addresses)
 struct DenseLayout {
-    int dm, w0, w1, w2, b0, b1, b2, wo, gb, ld, ld_count, lv, lv_count, count, alloc;
-    __host__ __device__ static DenseLayout make(int n_domain, bool deepfm = false, bool uncertainty = false) {
+    int dm, w0, w1, w2, b0, b1, b2, wo, gb, ld, ld_count, lv, lv_count, wx, wx_count, count, alloc;
+    __host__ __device__ static DenseLayout make(int n_domain, bool deepfm = false, bool uncertainty = false, bool pnn = false) {
         DenseLayout L;
         L.dm = 0;
         L.w0 = n_domain * EMB;
@@ -45,7 +47,9 @@ struct DenseLayout {
         L.ld_count = deepfm ? n_domain : 0;
         L.lv = L.ld + L.ld_count;
         L.lv_count = uncertainty ? n_domain : 0;
-        L.count = L.lv + L.lv_count;
+        L.wx = (L.lv + L.lv_count + 3) & ~3;        // (16-B aligned rows)
+        L.wx_count = pnn ? 3 * H1 : 0;
+        L.count = pnn ? L.wx + L.wx_count : L.lv + L.lv_count;
         L.alloc = (L.count + 3) & ~3;
         return L;
     }

@@ -137,7 +137,8 @@ struct TowerArgs {
     int32_t* map_i;
     float* loss_part;          // [tiles] sum of per-row BCE of the tile
     // DeepFM: logit += FM second-order term + linear tables
-    int deepfm;
+    int deepfm;                // FM instances: 1 DeepFM, 2 WDL (linear tables only), 3 PNN (inner products of the field pairs)
+    float* ipbuf;              // PNN: [rows_pad][4] inner products <u,i> <u,d> <i,d> of the batch's rows (train)
     const float* lin_user;     // [n_user] / [n_item] 1-d tables; null = frozen at their zero initialisation
     const float* lin_item;
     float* fmq;                // train: [rows_pad][EMB] dlogit * (user + item embedding), for the domain-table gradient
@@ -175,7 +176,7 @@ struct TowerArgs {
 
 // weight-gradient GEMMs (K = batch rows) + bias / output-layer / domain-table sums
 struct TileDesc {
-    int a_kind, a_off;         // 0: acts column block, 1: ones (row 0), 2: one-hot(domain) rows a_off..
+    int a_kind, a_off;         // 0: acts column block, 1: ones (row 0), 2: one-hot(domain) rows a_off.., 3: ipbuf columns (PNN)
     int b_kind, b_off;         // 0: dz column block, 1: dlogit (col 0), 2: fmq column block
     int dst_off, dst_ld;       // destination in the dense-block gradient slab
     int m_valid, n_valid;      // valid rows / cols of the 32x32 tile
@@ -187,7 +188,8 @@ struct WgradArgs {
     const float* dz;
     const float* dlogit;
     const int32_t* domrow;
-    const float* fmq;          // DeepFM only
+    const float* fmq;          // DeepFM / PNN only
+    const float* ipbuf;        // PNN only: [rows_pad][4]
     const TileDesc* tiles;
     int n_tiles;
     int rows_pad;              // batch rows rounded up to TILE_ROWS

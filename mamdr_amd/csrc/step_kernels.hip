@@ -37,7 +37,7 @@ constexpr int H1S_OFF = XS_OFF + XREGION;                           // 6272
 constexpr int H2S_OFF = H1S_OFF + TILE_ROWS * H1_LD;                // 10432
 constexpr int H3S_OFF = H2S_OFF + TILE_ROWS * H2_LD;                // 12544
 constexpr int ROWI_OFF = H3S_OFF + TILE_ROWS * H3_LD;               // 13632
-constexpr int LDS_FLOATS = ROWI_OFF + 8 * TILE_ROWS;                // 13760 floats = 55,040 B
+constexpr int LDS_FLOATS = ROWI_OFF + 12 * TILE_ROWS;               // 13824 floats = 55,296 B (rowf [64, 112): PNN's inner products)
 static_assert(XREGION >= TILE_ROWS * XS_LD, "x tile must fit in its region");
 static_assert(LDS_FLOATS * 4 <= 65536, "stay under the 64 KiB dynamic-LDS default");
 
@@ -141,11 +141,26 @@ struct FwdW {
 // `mid()` runs between the K loop and the epilogue: the caller requests the NEXT layer's
 // weights there, so that those loads are older than this epilogue's global stores (vmcnt
 // retires in issue order: a load queued behind the stores would wait for all of them).
-template <int K, int N, int LDA, int LDO, bool TRAIN, int PF, int NW, typename Mid>
+// `extra(row, col)` (optional) is added to the pre-activation: PNN's three inner-product inputs times their rows of W0
+struct NoExtra {
+    static constexpr bool on = false;
+    __device__ __forceinline__ float operator()(int, int) const { return 0.f; }
+};
+struct PnnExtra {
+    static constexpr bool on = true;
+    const float* ip;           // LDS [TILE_ROWS][3]
+    const float* wx;           // global [3][H1]
+    bool act;                  // (uniform) this launch is a PNN tower
+    __device__ __forceinline__ float operator()(int row, int col) const {
+        if (!act) return 0.f;
+        return (ip[3 * row] * wx[col] + ip[3 * row + 1] * wx[H1 + col]) + ip[3 * row + 2] * wx[2 * H1 + col];
+    }
+};
+template <int K, int N, int LDA, int LDO, bool TRAIN, int PF, int NW, typename Mid, typename Extra = NoExtra>
 __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF, NW>& fw, const float* __restrict__ W, const float* As,
                                           float* Os, float* gout,
                                           uint32_t key, uint32_t thresh, float scale, bool use_dropout, int row0,
-                                          Mid mid) {
+                                          Mid mid, Extra extra = Extra()) {
     constexpr int TPW = FwdW<K, N, PF, NW>::TPW;
     constexpr int NC = K / 16;
     static_assert(NC % PF == 0, "chunk count must be a multiple of the ring depth");
@@ -199,7 +214,9 @@ __device__ __forceinline__ void fwd_layer(FwdW<K, N, PF, NW>& fw, const float* _
         float h[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            float z = fmaxf(acc[t][r], 0.0f);
+            float z = acc[t][r];
+            if constexpr (Extra::on) z += extra(row, ncol + t);
+            z = fmaxf(z, 0.0f);
 #ifndef MAMDR_ABLATE_HASH
             if (TRAIN && use_dropout) {
                 const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(row0 + row) * (uint32_t)N + (uint32_t)(ncol + t));
@@ -591,18 +608,37 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
         const f32x4 d = *reinterpret_cast<const f32x4*>(xr + 2 * EMB);
         const float fmw = a.deepfm == 1 ? 1.0f : 0.0f;    // 2 = WDL: linear tables only, no FM term
         fm_ui = fmw * (u + it);
-        const f32x4 t = u * it + (u + it) * d;
-        float s = fmw * ((t[0] + t[1]) + (t[2] + t[3]));
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 16);
-        if (part == 0) {
-            float lin = P[a.L.ld + rowi[2 * TILE_ROWS + i]];
-            if (a.lin_user) lin = (a.lin_user[rowi[i]] + a.lin_item[rowi[TILE_ROWS + i]]) + lin;
-            rowf[TILE_ROWS + i] = s + lin;
+        if (a.deepfm == 3) {
+            // PNN (forward only here: its training steps run on the four-row tower): ip = <u,i> <u,d> <i,d> of the row
+            const f32x4 p0 = u * it, p1 = u * d, p2 = it * d;
+            float s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]),
+                  s2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+            for (int o = 1; o < 32; o <<= 1) {
+                s0 += __shfl_xor(s0, o);
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            if (part == 0) {
+                rowf[4 * TILE_ROWS + 3 * i] = s0;
+                rowf[4 * TILE_ROWS + 3 * i + 1] = s1;
+                rowf[4 * TILE_ROWS + 3 * i + 2] = s2;
+                rowf[TILE_ROWS + i] = 0.f;             // no linear / FM logit in this tower
+            }
+        } else {
+            const f32x4 t = u * it + (u + it) * d;
+            float s = fmw * ((t[0] + t[1]) + (t[2] + t[3]));
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 16);
+            if (part == 0) {
+                float lin = P[a.L.ld + rowi[2 * TILE_ROWS + i]];
+                if (a.lin_user) lin = (a.lin_user[rowi[i]] + a.lin_item[rowi[TILE_ROWS + i]]) + lin;
+                rowf[TILE_ROWS + i] = s + lin;
+            }
         }
+        __syncthreads();       // (PNN: layer 0's epilogue reads every row's inner products)
     }
 
     const float scale = a.use_dropout ? a.keep_scale : 1.0f;
@@ -611,12 +647,17 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
     const uint32_t key1 = TRAIN ? dropout_layer_key(a.seed, a.step, 1) : 0u;
     const uint32_t key2 = TRAIN ? dropout_layer_key(a.seed, a.step, 2) : 0u;
 
-    fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(fw0, P + a.L.w0, smem + XS_OFF, smem + H1S_OFF, TRAIN ? acts_t + XDIM : nullptr,
-                                             key0, a.drop_thresh, scale, a.use_dropout != 0, row0,
-                                             [&]() {
-                                                 fw1.prefetch(P + a.L.w1, P + a.L.b1);
-                                                 if (EARLY2 || EARLY2S) fw2.prefetch(P + a.L.w2, P + a.L.b2);
-                                             });
+    auto mid0 = [&]() {
+        fw1.prefetch(P + a.L.w1, P + a.L.b1);
+        if (EARLY2 || EARLY2S) fw2.prefetch(P + a.L.w2, P + a.L.b2);
+    };
+    if constexpr (FM)
+        fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(fw0, P + a.L.w0, smem + XS_OFF, smem + H1S_OFF, TRAIN ? acts_t + XDIM : nullptr,
+                                                 key0, a.drop_thresh, scale, a.use_dropout != 0, row0, mid0,
+                                                 PnnExtra{rowf + 4 * TILE_ROWS, P + a.L.wx, a.deepfm == 3});
+    else
+        fwd_layer<XDIM, H1, XS_LD, H1_LD, TRAIN>(fw0, P + a.L.w0, smem + XS_OFF, smem + H1S_OFF, TRAIN ? acts_t + XDIM : nullptr,
+                                                 key0, a.drop_thresh, scale, a.use_dropout != 0, row0, mid0);
     STAMP(2);
     __syncthreads();
     fwd_layer<H1, H2, H1_LD, H2_LD, TRAIN>(fw1, P + a.L.w1, smem + H1S_OFF, smem + H2S_OFF,
@@ -933,6 +974,7 @@ template <int AK>
 __device__ __forceinline__ float fetch_a(const WgradArgs& g, const TileDesc& t, int b, int c) {
     if (AK == 0) return g.acts[(size_t)b * ACT_LD + t.a_off + c];
     if (AK == 1) return c == 0 ? 1.0f : 0.0f;
+    if (AK == 3) return c < 4 ? g.ipbuf[(size_t)b * 4 + c] : 0.0f;      // PNN: the rows' inner products (column 3 is zero)
     return (g.domrow[b] == t.a_off + c) ? 1.0f : 0.0f;
 }
 template <int BK>
@@ -1136,6 +1178,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& g, const int bid, fl
     else if (t.a_kind == 1 && t.b_kind == 0) wgrad_rows<1, 0>(g, t, b0, b1, acc);
     else if (t.a_kind == 0 && t.b_kind == 1) wgrad_rows<0, 1>(g, t, b0, b1, acc);
     else if (t.a_kind == 1 && t.b_kind == 1) wgrad_rows<1, 1>(g, t, b0, b1, acc);
+    else if (t.a_kind == 3) wgrad_rows<3, 0>(g, t, b0, b1, acc);      // PNN: dW0x = ip^T dz1
     else if (t.b_kind == 0) wgrad_rows<2, 0>(g, t, b0, b1, acc);
     else if (t.b_kind == 1) wgrad_rows<2, 1>(g, t, b0, b1, acc);    // DeepFM: linear domain table
     else wgrad_rows<2, 2>(g, t, b0, b1, acc);                        // DeepFM: S2 = onehot(domain)^T fmq

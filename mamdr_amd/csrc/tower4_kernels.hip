@@ -51,7 +51,9 @@ constexpr int T4_DZ1 = T4_H1;
 constexpr int T4_RED = T4_DZ3 + T4_ROWS * T4_H3LD;     // split-k partials: [8 waves][4][N <= 128] or [4 wave pairs][4][256]
 constexpr int T4_RED_FLOATS = 4 * T4_ROWS * H1;
 constexpr int T4_ROWI = T4_RED + T4_RED_FLOATS;
-constexpr int T4_W1S = T4_ROWI + 64;                   // W1L: [256][128] image of W1, 16-B chunks XOR-swizzled per row
+constexpr int T4_W1S = T4_ROWI + 96;                   // W1L: [256][128] image of W1, 16-B chunks XOR-swizzled per row
+// (row bookkeeping: 16 ints + 80 floats -- [0,4) label [4,8) loss [8,12) FM + linear term [12,16) dlogit [16,40) per-wave
+// partials of the FM term / of PNN's three inner products [48,64) PNN: ip[row][4] [64,80) PNN: d loss / d ip [row][4])
 constexpr int T4_LDS_FLOATS = T4_W1S;
 constexpr int T4_LDS_FLOATS_W1L = T4_W1S + H1 * H2;
 static_assert(T4_LDS_FLOATS_W1L * sizeof(float) <= 160 * 1024, "LDS of a gfx950 CU");
@@ -576,7 +578,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
     if (W1L && !pre) t4_w1_request<32>(k_w1, w1s, 32 * __builtin_amdgcn_readfirstlane(w));
     T4STAMP_W4(2);
     __syncthreads();
-    if (FM) {
+    const bool pnn = FM && a.deepfm == 3;              // (uniform) the inner products of the field pairs feed three more rows of W0
+    float wx0 = 0.f, wx1 = 0.f, wx2 = 0.f;             // ... rows a.L.wx + {0, 1, 2} H1, this thread's column
+    if (FM && !pnn) {
         // thread (row, k): FM second-order term sum_k (u i + (u + i) d), reduced over the row's two waves
         const int row = tid >> 7, k = tid & 127;
         const float* xr = smem + T4_XS + row * T4_XLD;
@@ -591,6 +595,36 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
             rowf[8 + tid] = (rowf[16 + 2 * tid] + rowf[17 + 2 * tid]) + lin;
         }
         // (read in the output-unit phase, several barriers later)
+    }
+    if (pnn) {
+        // PNN (deepctr InnerProductLayer, pairs (0,1) (0,2) (1,2)): ip = <u,i> <u,d> <i,d> per row, reduced over the row's
+        // two waves; kept in LDS for layer 0's epilogue and written out for the weight gradient of the three rows
+        const int row = tid >> 7, k = tid & 127;
+        const float* xr = smem + T4_XS + row * T4_XLD;
+        const float u = xr[k], it = xr[EMB + k], dd = xr[2 * EMB + k];
+        float s0 = u * it, s1 = u * dd, s2 = it * dd;
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o);
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (lane == 0) {
+            rowf[16 + 3 * w] = s0;
+            rowf[17 + 3 * w] = s1;
+            rowf[18 + 3 * w] = s2;
+        }
+        wx0 = P[a.L.wx + ecol];
+        wx1 = P[a.L.wx + H1 + ecol];
+        wx2 = P[a.L.wx + 2 * H1 + ecol];
+        __syncthreads();
+        if (tid < 4 * T4_ROWS) {
+            const int r = tid >> 2, j = tid & 3;
+            const float v = j < 3 ? rowf[16 + 6 * r + j] + rowf[19 + 6 * r + j] : 0.f;
+            rowf[48 + tid] = v;
+            a.ipbuf[(size_t)(r0 + r) * 4 + j] = v;
+            if (j == 0) rowf[8 + r] = 0.f;             // no linear / FM logit in this tower
+        }
+        // (read behind layer 0's barrier)
     }
 
     T4STAMP(1);
@@ -664,7 +698,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row = erow2 + 2 * rr;
-            float h = fmaxf(t4_sum<H1>(red, row, ecol) + b0r, 0.f);
+            float z = t4_sum<H1>(red, row, ecol) + b0r;
+            if (pnn) z += (rowf[48 + 4 * row] * wx0 + rowf[49 + 4 * row] * wx1) + rowf[50 + 4 * row] * wx2;
+            float h = fmaxf(z, 0.f);
             if (drop) {
                 const uint32_t u = mamdr_dropout_u32(key, (uint32_t)(r0 + row) * (uint32_t)H1 + (uint32_t)ecol);
                 h = (u >= a.drop_thresh) ? h * scale : 0.f;
@@ -762,7 +798,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
     }
     __syncthreads();
     if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
-    if (FM) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
+    if (FM && !pnn) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
         const int row = tid >> 7, k = tid & 127;
         const float* xr = smem + T4_XS + row * T4_XLD;
         a.fmq[(size_t)(r0 + row) * EMB + k] = a.deepfm == 1 ? rowf[12 + row] * (xr[k] + xr[EMB + k]) : 0.f;
@@ -785,6 +821,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
     if (W1L) t4_contract_w1b(w1s, smem + T4_DZ2, red, []() {});
     else t4_contract(v1, a.wT + W1T_OFF, smem + T4_DZ2, T4_H2LD, red, [&]() { if (DX) v0.prefetch(a.wT + W0T_OFF); });
     __syncthreads();
+    float dip[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};      // PNN: this thread's share of d loss / d ip of its two rows
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = erow2 + 2 * rr;
@@ -792,9 +829,48 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
         const float d = (smem[T4_H1 + row * T4_H1LD + ecol] > 0.f) ? v * scale : 0.f;
         T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + ecol], d);
         if (DX) smem[T4_DZ1 + row * T4_H1LD + ecol] = d;
+        dip[rr][0] = d * wx0;
+        dip[rr][1] = d * wx1;
+        dip[rr][2] = d * wx2;
     }
     T4STAMP(9);
     T4REAL(11);
+    if (pnn) {
+        // d loss / d ip[row][j] = sum_c dz1[row][c] W0x[j][c]: wave sums, then the row's four waves (rows erow2, erow2 + 2
+        // belong to waves 4 erow2 .. 4 erow2 + 3) through LDS in wave order; the inner products' chain rule then gives the
+        // per-row term of the domain-table gradient, fmq = dip_ud u + dip_id i (S2 tiles of k_wgrad), and with trainable
+        // tables the terms of the two table rows (added to the input gradient below)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                for (int o = 32; o > 0; o >>= 1) dip[rr][j] += __shfl_xor(dip[rr][j], o);
+        __syncthreads();           // (everybody is past the sums of `red`)
+        if (lane == 0) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) red[(w * 2 + rr) * 4 + j] = dip[rr][j];
+        }
+        __syncthreads();
+        if (tid < 4 * T4_ROWS) {
+            const int r = tid >> 2, j = tid & 3;
+            // row r = erow2 + 2 rr  ->  erow2 = r & 1, rr = r >> 1; its waves: 4 erow2 .. 4 erow2 + 3
+            float v = 0.f;
+            if (j < 3) {
+                const int w0_ = 4 * (r & 1), rr = r >> 1;
+                v = ((red[((w0_ + 0) * 2 + rr) * 4 + j] + red[((w0_ + 1) * 2 + rr) * 4 + j]) + red[((w0_ + 2) * 2 + rr) * 4 + j]) +
+                    red[((w0_ + 3) * 2 + rr) * 4 + j];
+            }
+            rowf[64 + tid] = v;
+        }
+        __syncthreads();
+        {
+            const int row = tid >> 7, k = tid & 127;
+            const float* xr = smem + T4_XS + row * T4_XLD;
+            a.fmq[(size_t)(r0 + row) * EMB + k] = rowf[65 + 4 * row] * xr[k] + rowf[66 + 4 * row] * xr[EMB + k];
+        }
+    }
     if (DX) {
         __syncthreads();           // dz1 complete, `red` free again
         t4_contract(v0, a.wT + W0T_OFF, smem + T4_DZ1, T4_H1LD, red, []() {});
@@ -809,6 +885,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
                 const int k = ecol & (EMB - 1);
                 const float other = (ecol < EMB ? xr[EMB + k] : xr[k]) + xr[2 * EMB + k];
                 if (a.deepfm == 1) v = fmaf(rowf[12 + row], other, v);
+                // PNN: d <u,i> / d u = i, d <u,d> / d u = d;  d <u,i> / d i = u, d <i,d> / d i = d
+                if (pnn) v += rowf[64 + 4 * row] * (ecol < EMB ? xr[EMB + k] : xr[k]) +
+                              rowf[(ecol < EMB ? 65 : 66) + 4 * row] * xr[2 * EMB + k];
             }
             dxe_t[(size_t)row * (2 * EMB) + ecol] = v;
         }

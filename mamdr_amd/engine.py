@@ -145,7 +145,8 @@ class TowerEngine(FlatVectorOps):
         self.dropout_seed = int(dropout_seed) & 0xFFFFFFFF
         self._acc = None
         self._ema = None            # set_moving_average
-        tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR, "wdl": L.TOWER_WDL}[tower]
+        tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR, "wdl": L.TOWER_WDL,
+                    "pnn": L.TOWER_PNN}[tower]
         max_batch = (self.batch_size + 15) // 16 * 16
         cfg = L.Config(L.ABI_VERSION, tower_id, self.n_user, self.n_item, self.n_domain, emb_dim,
                        (C.c_int32 * 3)(*hidden), max_batch, 1 if emb_trainable else 0, float(dropout),
@@ -251,8 +252,12 @@ class TowerEngine(FlatVectorOps):
                 "steps": h[4 * dx:4 * dx + self.n_domain].copy()}
 
     def pack(self, named):
-        """numpy dict {segment name: array} -> flat device vector (padding zero)."""
+        """numpy dict {segment name: array} -> flat device vector (padding zero).  PNN: deepctr's first kernel
+        [387, 256] is given as ONE tensor "W0"; its last three rows (the inner products') live in segment "W0x"."""
         host = np.zeros(self.n_params, np.float32)
+        if "W0x" in self.segments and "W0x" not in named:
+            w0 = np.asarray(named["W0"], np.float32).reshape(-1, 256)
+            named = dict(named, W0=w0[:384], W0x=w0[384:])
         for name, (off, cnt) in self.segments.items():
             a = np.asarray(named[name], np.float32).ravel()
             if a.size != cnt:
@@ -262,7 +267,10 @@ class TowerEngine(FlatVectorOps):
 
     def unpack(self, vec):
         host = vec.detach().cpu().numpy()
-        return {name: host[off:off + cnt].copy() for name, (off, cnt) in self.segments.items()}
+        out = {name: host[off:off + cnt].copy() for name, (off, cnt) in self.segments.items()}
+        if "W0x" in out:           # PNN: the caller's view is deepctr's one kernel [387, 256]
+            out["W0"] = np.concatenate([out["W0"], out.pop("W0x")])
+        return out
 
     def set_weights(self, vec):
         """SetVarOp.__call__ (utils/tool.py:36-45): device copy into the live weights.  A vector of
@@ -287,6 +295,8 @@ class TowerEngine(FlatVectorOps):
                 out[name] = (cnt // 128, 128)
             elif name in ("W0", "Ws0"):
                 out[name] = (384, 256)
+            elif name == "W0x":
+                out[name] = (3, 256)
             elif name in ("W1", "Ws1"):
                 out[name] = (256, 128)
             elif name in ("W2", "Ws2"):

@@ -91,7 +91,17 @@ class DeepCTR(BaseModel):
             raise ValueError("hidden_dim %r: the '%s' tower's kernels are built for three hidden layers (the reference's "
                              "configs all have [256, 128, 64])" % (mc["hidden_dim"], tower))
         factory = self.engine_factory
-        if tower in GRAPH_TOWERS:         # generic-layer engine; an injected factory offers it as `.graph` (tests)
+        # PNN on the step kernels (round 4: MAMDR_TOWER_PNN = the mlp tower + the inner products' three rows of the first
+        # kernel, k_tower4's FM instances): batches of up to 2,048 rows and three hidden layers -- every reference config;
+        # anything else, and MAMDR_PNN_ENGINE=graph (the parity twin), runs it on the generic-layer engine
+        import os
+        self.step_pnn = (tower == "pnn" and factory is None and self.batch_size <= 2048 and
+                         tuple(mc["hidden_dim"]) == (256, 128, 64) and mc["user_dim"] == 128 and
+                         "uncertainty_weight" not in mc["name"] and os.environ.get("MAMDR_PNN_ENGINE", "step") != "graph")
+        if self.step_pnn:
+            from ..engine import TowerEngine
+            factory = TowerEngine
+        elif tower in GRAPH_TOWERS:       # generic-layer engine; an injected factory offers it as `.graph` (tests)
             if factory is not None:
                 factory = getattr(factory, "graph", None)
                 if factory is None:
@@ -108,7 +118,7 @@ class DeepCTR(BaseModel):
         # deepctr.py:104-116: `trainable=emb_trainable` reaches SparseFeat only on the pretrained branch; without
         # pretrained tables the column is built with deepctr's default (trainable) WHATEVER emb_trainable says
         self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
-        if tower in GRAPH_TOWERS:
+        if tower in GRAPH_TOWERS and not self.step_pnn:
             if kw:
                 raise NotImplementedError("uncertainty weighting on the '%s' tower is not built" % tower)
             eng = factory(tower, self.n_uid, self.n_pid, self.n_domain, self.batch_size, expert_hidden=tuple(mc["hidden_dim"]),

@@ -22,9 +22,13 @@ HIDDEN = (256, 128, 64)
 
 
 def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable=False):
+    """kind "pnn@step": the PNN tower on the STEP kernels (mamdr_create, MAMDR_TOWER_PNN: k_tower4's FM instances with the
+    inner products' three rows of the first kernel; round 4) instead of the generic-layer engine -- the same oracle."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
-    from mamdr_amd import graph_engine, synthetic
+    from mamdr_amd import engine, graph_engine, synthetic
+    step = kind.endswith("@step")
+    kind = kind.split("@")[0]
     g = synthetic.generate("taobao10", batch_size=batch, seed=seed, scale=scale)
     D = g["n_domain"]
     rs = np.random.RandomState(seed)
@@ -46,8 +50,11 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
     if not emb_trainable:           # frozen linear tables stay at their zero initialisation (deepctr: same feature column)
         params["lin_user"][...] = 0
         params["lin_item"][...] = 0
-    eng = graph_engine.GraphEngine(kind, g["n_user"], g["n_item"], D, batch, HIDDEN, (), dropout=dropout,
-                                   emb_trainable=emb_trainable)
+    if step:
+        eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=dropout, emb_trainable=emb_trainable, tower=kind)
+    else:
+        eng = graph_engine.GraphEngine(kind, g["n_user"], g["n_item"], D, batch, HIDDEN, (), dropout=dropout,
+                                       emb_trainable=emb_trainable)
     if not emb_trainable:
         eng.bind_table("user_emb", params["user_emb"])
         eng.bind_table("item_emb", params["item_emb"])
@@ -57,14 +64,17 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
     names = list(ofm.ccpm_param_names(emb_trainable) if kind == "ccpm" else
                  (ofm.autoint_param_names(emb_trainable) if kind == "autoint" else ofm.param_names(kind, emb_trainable)))
-    assert list(eng.segments) == names, (list(eng.segments), names)
+    if step:            # (the step kernels keep the inner products' rows of W0 as a segment of their own, behind the rest)
+        assert sorted(set(eng.segments) - {"W0x"}) == sorted(names), (list(eng.segments), names)
+    else:
+        assert list(eng.segments) == names, (list(eng.segments), names)
     eng.set_weights(eng.pack(params))
     model = ofm.OracleNet({k: v.copy() for k, v in params.items()}, kind, emb_trainable=emb_trainable, dropout=dropout,
                           lr=1e-3, hidden=HIDDEN, dropout_seed=eng.dropout_seed)
     return g, eng, model
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
 @pytest.mark.parametrize("emb_trainable", [False, True])
 def test_one_step_gradients_match_oracle(kind, emb_trainable):
     g, eng, model = make_problem(kind, dropout=0.5, scale=0.1 if emb_trainable else 0.05, emb_trainable=emb_trainable)
@@ -80,7 +90,7 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable):
         idx = perm[step * 256:(step + 1) * 256]
         masks = otower.train_masks(model.seed, model.step, len(idx), HIDDEN, 0.5)
         fn = ofm.loss_and_grads_conv if kind in ("ccpm", "autoint") else ofm.loss_and_grads
-        loss, grads, _ = fn(model.params, kind, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+        loss, grads, _ = fn(model.params, kind.split("@")[0], cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
                             cols["label"][idx], masks, 0.5, emb_trainable, model.frozen_sumsq())
         loss_t = torch.zeros(1, device=eng.device)
         w0 = eng.get_weights()
@@ -97,7 +107,7 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
 def test_adam_pass_and_eval(kind):
     g, eng, model = make_problem(kind, dropout=0.5)
     d = 9
@@ -122,7 +132,7 @@ def test_adam_pass_and_eval(kind):
 
 
 def test_eval_predictions_at_equal_weights():
-    for kind in ("nfm", "pnn", "ccpm", "autoint"):
+    for kind in ("nfm", "pnn", "pnn@step", "ccpm", "autoint"):
         g, eng, model = make_problem(kind)
         for d in (1, 5):
             c = g["data"]["test"][d]
@@ -134,7 +144,7 @@ def test_eval_predictions_at_equal_weights():
         eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
 @pytest.mark.parametrize("emb_trainable", [False, True])
 def test_accumulate_steps_match_oracle(kind, emb_trainable):
     """MAMDR_OPT_ACCUMULATE on the generic-layer engine (the meta passes of MAML / MLDG / PCGrad, maml.py:107-109,196-229):
@@ -171,11 +181,11 @@ def test_accumulate_steps_match_oracle(kind, emb_trainable):
             assert bad.sum() <= max(2e-3 * bad.size, 4 * 128) and np.abs(gk - want[k]).max() <= 0.05 * scale + 1e-5, (k, bad.mean())
         else:
             np.testing.assert_allclose(gk, want[k], rtol=3e-4, atol=3e-4 * scale + 6e-8, err_msg=k)
-    assert flat_names == list(model.names)
+    assert flat_names == list(model.names) or kind.endswith("@step")
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
 def test_domain_negotiation_auc_parity(kind):
     """the meta wrappers run on these towers too (deepctr.py's registry is orthogonal to run.py's wrappers): five
     Domain Negotiation epochs (domain_negotiation.py:49-88) on 4 domains, same order / shuffles / masks on both sides.
@@ -205,7 +215,7 @@ def test_domain_negotiation_auc_parity(kind):
     params0 = {k: v.copy() for k, v in model.params.items()}
 
     def oracle_run(theta_start):
-        twin = ofm.OracleNet({k: v.copy() for k, v in params0.items()}, kind, dropout=0.5, lr=LR, hidden=HIDDEN,
+        twin = ofm.OracleNet({k: v.copy() for k, v in params0.items()}, kind.split("@")[0], dropout=0.5, lr=LR, hidden=HIDDEN,
                              dropout_seed=eng.dropout_seed)
         theta = theta_start.copy()
         pf, traces = make_perm_fn(), []

@@ -23,14 +23,23 @@ INPROC = len(sys.argv) > 3 and sys.argv[3] == "inproc"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def flops_per_row(model):
-    """2 x MACs of forward + backward (d input + d weights) of every dense layer on a step's path: 6 x the forward MACs."""
-    eng = model.model
-    macs = 0
-    for name, (rows, cols) in eng.shapes.items():
-        if "/W" in name or name in ("W0", "W1", "W2") or name.endswith("_w") and name.startswith("att"):
+def step_macs_per_row(eng, domain=0):
+    """forward multiply-adds per batch row of the dense layers on ONE step's path (a step of task d runs the shared
+    experts and task d's own experts / gate / tower); a training step costs 6 flop per such MAC (forward, d input,
+    d weights).  AutoInt's attention projections run on 3 token rows per batch row."""
+    if hasattr(eng, "shapes"):
+        ranges = eng.task_ranges(domain) if hasattr(eng, "task_ranges") else [(0, eng.n_params)]
+        macs = 0
+        for name, (rows, cols) in eng.shapes.items():
+            off = eng.segments[name][0]
+            if not any(o <= off < o + c for o, c in ranges) or rows <= 1 or name.endswith("_emb") or name.startswith("lin_"):
+                continue
             macs += rows * cols * (3 if name.startswith("att") else 1)
-    return macs
+        return macs
+    return sum(c for n, (_, c) in eng.segments.items() if n in ("W0", "W0x", "W1", "W2", "wo"))
+
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md (bench.py uses the same figure)
 
 
 TOWERS = ("shared_bottom", "mmoe", "ple", "nfm", "pnn", "ccpm", "autoint")
@@ -69,16 +78,27 @@ for cfg_name in TOWERS:
             eng.train_steps(d, perm=perms[d], lr=cfg["train"]["learning_rate"])
     epoch()
     torch.cuda.synchronize()
+    graph = hasattr(eng, "shapes")
+    l0 = int(eng.lib.mamdr_graph_launch_count())
     t0 = time.perf_counter()
     for _ in range(EPOCHS):
         epoch()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    launches = (int(eng.lib.mamdr_graph_launch_count()) - l0) / float(steps_per_epoch * EPOCHS) if graph else None
     n_path = 0
     if hasattr(eng, "task_ranges") and cfg_name in ("shared_bottom", "mmoe", "ple"):
         n_path = sum(c for _, c in eng.task_ranges(0))
-    print(json.dumps({"tower": cfg_name, "value": steps_per_epoch * EPOCHS / dt, "unit": "domain-steps/s",
-                      "us_per_domain_step": dt / (steps_per_epoch * EPOCHS) * 1e6, "batch": ds.batch_size,
+    rows = sum(sizes.values()) * EPOCHS
+    macs = step_macs_per_row(eng)
+    ach = 6.0 * macs * rows / dt / 1e12
+    roofline = {"bound": "mfma", "scope": "whole step (every launch of a domain-step; the engine has no single dominant kernel)"
+                if graph else "whole step (k_tower4<DX, FM> + k_wgrad + k_update)",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "flops_per_row": 6 * macs, "launches_per_step": launches if graph else 3}
+    print(json.dumps({"tower": cfg_name, "engine": "generic-layer (mamdr_graph_*)" if graph else "step kernels (mamdr_*)",
+                      "value": steps_per_epoch * EPOCHS / dt, "unit": "domain-steps/s",
+                      "us_per_domain_step": dt / (steps_per_epoch * EPOCHS) * 1e6, "batch": ds.batch_size, "roofline": roofline,
                       "params": int(eng.n_params), "params_on_a_step_path": int(n_path) or int(eng.n_params),
                       "model": {k: cfg["model"][k] for k in cfg["model"] if "hidden" in k or "expert" in k}}))
     eng.close()
