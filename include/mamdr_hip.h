@@ -44,7 +44,12 @@ enum { MAMDR_TOWER_MLP = 0, MAMDR_TOWER_DEEPFM = 1, MAMDR_TOWER_STAR = 2,
        /* deepctr PNN (deepctr.py:44-46; use_inner, no outer product): the mlp tower on [user | item | domain | <u,i> <u,d>
           <i,d>] -- the three inner products feed three more rows of the first kernel (segment MAMDR_SEG_W0X).  Steps of
           up to 2,048 rows (every reference config has batch_size 1,024); larger batches: the generic-layer engine */
-       MAMDR_TOWER_PNN = 4 };
+       MAMDR_TOWER_PNN = 4,
+       /* deepctr NFM (deepctr.py:33-35): linear tables (as WDL) + DNN over the 128 bi-interaction columns u i + (u + i) d.
+          Same segments as WDL, but segment W0 is deepctr's [128, 256] kernel: it occupies rows 256..383 of the mlp
+          tower's W0 (the bi-interaction takes the domain field's place in the input tile; rows 0..255 stay zero and
+          belong to no segment).  Steps of up to 2,048 rows, as PNN */
+       MAMDR_TOWER_NFM = 5 };
 /* data splits: utils/dataset.py:79-92 */
 enum { MAMDR_SPLIT_TRAIN = 0, MAMDR_SPLIT_VAL = 1, MAMDR_SPLIT_TEST = 2 };
 /* optimisers: deepctr.py:55 (Adam) / specific_base_model.py:120, base_model.py:69 (SGD finetune) */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
 ABI_VERSION = 14
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
-TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN = 0, 1, 2, 3, 4
+TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN, TOWER_NFM = 0, 1, 2, 3, 4, 5
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
 OPT_ADAM, OPT_SGD, OPT_ACCUMULATE = 0, 1, 2
 MERGE_PLUS, MERGE_TIMES = 0, 1

@@ -65,6 +65,7 @@ struct mamdr_ctx {
     DenseLayout L;
     int64_t table_floats = 0;   // trainable user+item floats in front of the dense block
     bool deepfm = false;
+    bool nfm = false;           // linear tables + DNN over the bi-interaction (MAMDR_TOWER_NFM): FM instances, mode 4
     bool pnn = false;           // the mlp tower + three inner-product inputs (MAMDR_TOWER_PNN): FM instances of the towers, mode 3
     float* ipbuf = nullptr;     // PNN: [rows_pad][4] the batch's inner products (A operand of dW0x's tiles)
     bool star = false;
@@ -214,15 +215,16 @@ struct mamdr_ctx {
 namespace {
 
 std::vector<TileDesc> build_tiles(const DenseLayout& L, int n_domain, bool deepfm, int s2_off, bool lin_w0dom, bool star,
-                                  bool pnn = false) {
+                                  bool pnn = false, bool nfm = false) {
     std::vector<TileDesc> t;
     struct G { int a_off, M, b_off, N, dst; };
     // dW0 = x^T dz1, dW1 = h1^T dz2, dW2 = h2^T dz3
     const G gemms[3] = {{0, XDIM, 0, H1, L.w0}, {XDIM, H1, H1, H2, L.w1}, {XDIM + H1, H2, H1 + H2, H3, L.w2}};
     // (64x64 tiles first: the kernel stages their operands through LDS)
     // (lin_w0dom: rows 256..383 of x are per-domain constants, their part of dW0 follows from S in k_update)
+    // (NFM: rows 0..255 of W0 meet the raw user / item rows of the tile but are no parameters -- they stay zero: no tiles)
     for (const G& g : gemms)
-        for (int m0 = 0; m0 < ((lin_w0dom && g.dst == L.w0) ? 2 * EMB : g.M); m0 += 64)
+        for (int m0 = (nfm && g.dst == L.w0) ? 2 * EMB : 0; m0 < ((lin_w0dom && g.dst == L.w0) ? 2 * EMB : g.M); m0 += 64)
             for (int n0 = 0; n0 < g.N; n0 += 64)
                 t.push_back(TileDesc{0, g.a_off + m0, 0, g.b_off + n0, g.dst + m0 * g.N + n0, g.N, 64, 64, 1});
     // biases = column sums of dz (A = ones in row 0)
@@ -321,7 +323,7 @@ void fill_tower_common(const mamdr_ctx* c, const SplitData& d, TowerArgs& a) {
     a.label = d.label;
     a.n_rows_split = d.n;
     a.thresholds = c->thresholds;
-    a.deepfm = c->deepfm ? (c->cfg.tower == MAMDR_TOWER_WDL ? 2 : 1) : (c->pnn ? 3 : 0);
+    a.deepfm = c->nfm ? 4 : (c->deepfm ? (c->cfg.tower == MAMDR_TOWER_WDL ? 2 : 1) : (c->pnn ? 3 : 0));
     a.ipbuf = c->ipbuf;
     a.uw_off = -1;
     if (c->deepfm && c->cfg.emb_trainable) {
@@ -702,7 +704,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (cfg->abi_version != MAMDR_ABI_VERSION)
         return fail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
     if (cfg->tower != MAMDR_TOWER_MLP && cfg->tower != MAMDR_TOWER_DEEPFM && cfg->tower != MAMDR_TOWER_STAR &&
-        cfg->tower != MAMDR_TOWER_WDL && cfg->tower != MAMDR_TOWER_PNN)
+        cfg->tower != MAMDR_TOWER_WDL && cfg->tower != MAMDR_TOWER_PNN && cfg->tower != MAMDR_TOWER_NFM)
         return fail(MAMDR_EINVAL, "unknown tower kind %d", cfg->tower);
     if (cfg->emb_dim != EMB || cfg->hidden[0] != H1 || cfg->hidden[1] != H2 || cfg->hidden[2] != H3)
         return fail(MAMDR_EINVAL, "kernels are specialised for emb_dim 128 and hidden (256,128,64); got %d (%d,%d,%d)",
@@ -713,17 +715,18 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         return fail(MAMDR_EINVAL, "max_batch must be a positive multiple of %d", TILE_ROWS);
     if (cfg->max_batch > 16384) return fail(MAMDR_EINVAL, "max_batch %d exceeds 16384", cfg->max_batch);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
-    if (cfg->uncertainty_weight && (cfg->tower == MAMDR_TOWER_STAR || cfg->tower == MAMDR_TOWER_PNN))
+    if (cfg->uncertainty_weight && (cfg->tower == MAMDR_TOWER_STAR || cfg->tower == MAMDR_TOWER_PNN || cfg->tower == MAMDR_TOWER_NFM))
         return fail(MAMDR_ENOTBUILT, "uncertainty weighting is built for the mlp / deepfm towers only");
-    if (cfg->tower == MAMDR_TOWER_PNN && cfg->max_batch > 2048)
-        return fail(MAMDR_ENOTBUILT, "the pnn tower's training step is built on the four-row tower: batches of up to 2,048 rows, "
+    if ((cfg->tower == MAMDR_TOWER_PNN || cfg->tower == MAMDR_TOWER_NFM) && cfg->max_batch > 2048)
+        return fail(MAMDR_ENOTBUILT, "the pnn / nfm towers' training step is built on the four-row tower: batches of up to 2,048 rows, "
                                      "not %d (the generic-layer engine, mamdr_graph_*, takes any batch size)", cfg->max_batch);
 
     mamdr_ctx* c = new (std::nothrow) mamdr_ctx();
     if (!c) return fail(MAMDR_EINVAL, "out of host memory");
     c->cfg = *cfg;
     c->stream = (hipStream_t)stream;
-    c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM || cfg->tower == MAMDR_TOWER_WDL;   // linear tables (+ FM term)
+    c->nfm = cfg->tower == MAMDR_TOWER_NFM;
+    c->deepfm = cfg->tower == MAMDR_TOWER_DEEPFM || cfg->tower == MAMDR_TOWER_WDL || c->nfm;   // linear tables (+ FM term)
     c->pnn = cfg->tower == MAMDR_TOWER_PNN;
     c->L = DenseLayout::make(cfg->n_domain, c->deepfm, cfg->uncertainty_weight != 0, c->pnn);
     c->table_floats = cfg->emb_trainable ? ((int64_t)cfg->n_user + cfg->n_item) * EMB : 0;
@@ -750,8 +753,9 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     const size_t rp = (size_t)c->rows_pad_max;
     // dW0[256:384] without tiles: Dm^T . S in k_update, or (Star: one normalised domain row per batch) the
     // rank-1 form in k_star_update
-    c->lin_w0dom = (c->star || cfg->n_domain <= 64) && !getenv("MAMDR_NO_W0LIN");
-    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom, c->star, c->pnn);
+    // (NFM: rows 256..383 of the input tile carry the bi-interaction, not the domain row: plain tiles)
+    c->lin_w0dom = (c->star || cfg->n_domain <= 64) && !getenv("MAMDR_NO_W0LIN") && !c->nfm;
+    std::vector<TileDesc> tiles = build_tiles(c->L, cfg->n_domain, c->deepfm, c->s2_off, c->lin_w0dom, c->star, c->pnn, c->nfm);
     c->n_tiles = (int)tiles.size();
     float thr[500];
     thr[0] = (float)(0.0 - 1e-7);
@@ -963,7 +967,10 @@ int mamdr_param_segment(const mamdr_ctx* c, int seg, int64_t* offset, int64_t* c
             cnt = c->cfg.emb_trainable ? (int64_t)c->cfg.n_item * EMB : 0;
             break;
         case MAMDR_SEG_DOMAIN_EMB: off = base + L.dm; cnt = (int64_t)c->cfg.n_domain * EMB; break;
-        case MAMDR_SEG_W0: off = base + L.w0; cnt = XDIM * H1; break;
+        case MAMDR_SEG_W0:
+            off = base + L.w0 + (c->nfm ? 2 * EMB * H1 : 0);
+            cnt = c->nfm ? EMB * H1 : XDIM * H1;
+            break;
         case MAMDR_SEG_W1: off = base + L.w1; cnt = H1 * H2; break;
         case MAMDR_SEG_W2: off = base + L.w2; cnt = H2 * H3; break;
         case MAMDR_SEG_B0: off = base + L.b0; cnt = H1; break;
@@ -1238,6 +1245,14 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     // stays current while calls keep working on its pass); a call that matches none drops them all
     int64_t pre_base = 0;              // position of row pre_pos0 inside the pass buffer
     bool pre_cached = false;
+    // ... and a call whose FIRST step runs the 16-row tower (which reads no copy) needs none built either: k_update
+    // rewrites the copy of every element it steps, so they are current from the call's second step on -- before the
+    // short last batch that runs the four-row tower (the rows of a pass's steps never grow)
+    if (build_wT && optimizer != MAMDR_OPT_ACCUMULATE && !fused && !c->star) {
+        const int64_t first_rows = std::min<int64_t>(batch, pass_rows - first_step * (int64_t)batch);
+        const int64_t first_pad = (first_rows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+        if (!(c->tower_tile == 4 || first_pad <= c->tower4_max_rows) && n_steps > 1) build_wT = false;
+    }
     if (pre) {
         for (size_t k = c->pg_pos; k < c->pg.size(); ++k) {
             const mamdr_ctx::PgEntry& e = c->pg[k];
@@ -1399,8 +1414,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ta.no_w1l = c->t4_no_w1l;
         float* const dense_m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
         const bool use4 = may_use4 && (c->tower_tile == 4 || rows_pad <= c->tower4_max_rows);
-        if (c->pnn && !use4)
-            return fail(MAMDR_ENOTBUILT, "pnn tower: a training step of %d rows needs the four-row tower (MAMDR_TOWER_TILE=16?)", rows);
+        if ((c->pnn || c->nfm) && !use4)
+            return fail(MAMDR_ENOTBUILT, "pnn / nfm tower: a training step of %d rows needs the four-row tower (MAMDR_TOWER_TILE=16?)", rows);
         if (fused) {
             ta.w0dom_snap = c->w0dom_copy;
             c->dm_cur ^= 1;
@@ -1596,7 +1611,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.w1_off = c->L.w1;
         ua.w2_off = c->L.w2;
         ua.w0_off = c->L.w0;
-        ua.w0t = c->cfg.emb_trainable ? 1 : 0;
+        ua.w0t = (c->cfg.emb_trainable && !c->nfm) ? 1 : 0;
+        ua.no_sdm = c->nfm ? 1 : 0;
         {
             Prof p(c, MAMDR_KERNEL_UPDATE);
             if (tail) {

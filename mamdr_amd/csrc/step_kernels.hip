@@ -608,6 +608,11 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
         const f32x4 d = *reinterpret_cast<const f32x4*>(xr + 2 * EMB);
         const float fmw = a.deepfm == 1 ? 1.0f : 0.0f;    // 2 = WDL: linear tables only, no FM term
         fm_ui = fmw * (u + it);
+        if (a.deepfm == 4) {
+            // NFM (forward only here, as PNN): the DNN's input is the bi-interaction u i + (u + i) d; it takes the domain
+            // field's place in the tile (rows 0..255 of W0 are zero), the linear tables' logit is formed below as WDL's
+            *reinterpret_cast<f32x4*>(smem + XS_OFF + i * XS_LD + 2 * EMB + 4 * part) = u * it + (u + it) * d;
+        }
         if (a.deepfm == 3) {
             // PNN (forward only here: its training steps run on the four-row tower): ip = <u,i> <u,d> <i,d> of the row
             const f32x4 p0 = u * it, p1 = u * d, p2 = it * d;
@@ -1442,6 +1447,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
         float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
         for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
         if (lane == 0) {
+            if (u.no_sdm) g = 0.f;
             if (u.s2_off) g += g2;
             g += u.two_l2 * p;
             optimizer_step(u, g, p, m, v);

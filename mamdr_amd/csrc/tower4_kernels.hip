@@ -51,7 +51,8 @@ constexpr int T4_DZ1 = T4_H1;
 constexpr int T4_RED = T4_DZ3 + T4_ROWS * T4_H3LD;     // split-k partials: [8 waves][4][N <= 128] or [4 wave pairs][4][256]
 constexpr int T4_RED_FLOATS = 4 * T4_ROWS * H1;
 constexpr int T4_ROWI = T4_RED + T4_RED_FLOATS;
-constexpr int T4_W1S = T4_ROWI + 96;                   // W1L: [256][128] image of W1, 16-B chunks XOR-swizzled per row
+constexpr int T4_DROW = T4_ROWI + 96;                  // NFM: [4][128] the rows' domain embedding (its tile columns carry the bi-interaction)
+constexpr int T4_W1S = T4_DROW + T4_ROWS * EMB;        // W1L: [256][128] image of W1, 16-B chunks XOR-swizzled per row
 // (row bookkeeping: 16 ints + 80 floats -- [0,4) label [4,8) loss [8,12) FM + linear term [12,16) dlogit [16,40) per-wave
 // partials of the FM term / of PNN's three inner products [48,64) PNN: ip[row][4] [64,80) PNN: d loss / d ip [row][4])
 constexpr int T4_LDS_FLOATS = T4_W1S;
@@ -596,6 +597,18 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
         }
         // (read in the output-unit phase, several barriers later)
     }
+    const bool nfm = FM && a.deepfm == 4;              // (uniform) the DNN reads the bi-interaction of the three fields
+    if (nfm) {
+        // NFM (deepctr BiInteractionPooling): f = u i + (u + i) d takes the domain field's place in the tile -- rows
+        // 256..383 of W0 are deepctr's [128, 256] kernel, rows 0..255 are zero -- and the domain row moves aside for the
+        // backward products.  (The linear tables' logit was formed above, as WDL's.)
+        const int row = tid >> 7, k = tid & 127;
+        float* xr = smem + T4_XS + row * T4_XLD;
+        const float u = xr[k], it = xr[EMB + k], dd = xr[2 * EMB + k];
+        smem[T4_DROW + row * EMB + k] = dd;
+        xr[2 * EMB + k] = u * it + (u + it) * dd;
+        __syncthreads();
+    }
     if (pnn) {
         // PNN (deepctr InnerProductLayer, pairs (0,1) (0,2) (1,2)): ip = <u,i> <u,d> <i,d> per row, reduced over the row's
         // two waves; kept in LDS for layer 0's epilogue and written out for the weight gradient of the three rows
@@ -798,7 +811,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
     }
     __syncthreads();
     if (tid == 0) a.loss_part[tile] = (rowf[4] + rowf[5]) + (rowf[6] + rowf[7]);
-    if (FM && !pnn) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
+    if (FM && !pnn && !nfm) {     // d fm / d domain embedding = u + i: per-row term of the domain-table gradient
         const int row = tid >> 7, k = tid & 127;
         const float* xr = smem + T4_XS + row * T4_XLD;
         a.fmq[(size_t)(r0 + row) * EMB + k] = a.deepfm == 1 ? rowf[12 + row] * (xr[k] + xr[EMB + k]) : 0.f;
@@ -828,7 +841,7 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
         const float v = t4_sum<H1>(red, row, ecol);
         const float d = (smem[T4_H1 + row * T4_H1LD + ecol] > 0.f) ? v * scale : 0.f;
         T4_WS_STORE(&dz_t[(size_t)row * DZ_LD + ecol], d);
-        if (DX) smem[T4_DZ1 + row * T4_H1LD + ecol] = d;
+        if (DX || nfm) smem[T4_DZ1 + row * T4_H1LD + ecol] = d;
         dip[rr][0] = d * wx0;
         dip[rr][1] = d * wx1;
         dip[rr][2] = d * wx2;
@@ -871,7 +884,51 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
             a.fmq[(size_t)(r0 + row) * EMB + k] = rowf[65 + 4 * row] * xr[k] + rowf[66 + 4 * row] * xr[EMB + k];
         }
     }
-    if (DX) {
+    if (nfm) {
+        // d loss / d f = dz1 . W0[256:384, :]^T (rows of the kernel read in place: lane l owns output columns 2 l, 2 l + 1,
+        // i.e. rows 256 + 2 l (+ 1) of W0, the wave's 32 k as two halves of 16); then the bi-interaction's chain rule:
+        // the per-row term of the domain-table gradient fmq = df (u + i) and, with trainable tables, the two table rows'
+        // gradients df (i + d), df (u + d)
+        __syncthreads();           // dz1 complete, `red` free again
+        {
+            const float* wn = P + a.L.w0 + (size_t)(2 * EMB + 2 * lane) * H1 + 32 * w;
+            const float* ap = smem + T4_DZ1 + (lane & 3) * T4_H1LD + 32 * w;
+            f32x4 acc[2];
+            acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 b0[4], b1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    b0[q] = *reinterpret_cast<const f32x4*>(wn + 16 * half + 4 * q);
+                    b1[q] = *reinterpret_cast<const f32x4*>(wn + H1 + 16 * half + 4 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 16 * half + 4 * q);
+#pragma unroll
+                    for (int u_ = 0; u_ < 4; ++u_) {
+                        acc[0] = MAMDR_MFMA4(a4[u_], b0[q][u_], acc[0]);
+                        acc[1] = MAMDR_MFMA4(a4[u_], b1[q][u_], acc[1]);
+                    }
+                }
+            }
+            t4_put<EMB, 2, false>(acc, red);
+        }
+        __syncthreads();
+        {
+            const int row = tid >> 7, k = tid & 127;
+            const float df = t4_sum<EMB>(red, row, k);
+            const float* xr = smem + T4_XS + row * T4_XLD;
+            const float u = xr[k], it = xr[EMB + k], dd = smem[T4_DROW + row * EMB + k];
+            a.fmq[(size_t)(r0 + row) * EMB + k] = df * (u + it);
+            if (DX) {
+                float* dxe_t = a.dxe + (size_t)(r0 + row) * (2 * EMB);
+                dxe_t[k] = df * (it + dd);
+                dxe_t[EMB + k] = df * (u + dd);
+            }
+        }
+    } else if (DX) {
         __syncthreads();           // dz1 complete, `red` free again
         t4_contract(v0, a.wT + W0T_OFF, smem + T4_DZ1, T4_H1LD, red, []() {});
         __syncthreads();

@@ -146,7 +146,7 @@ class TowerEngine(FlatVectorOps):
         self._acc = None
         self._ema = None            # set_moving_average
         tower_id = {"mlp": L.TOWER_MLP, "deepfm": L.TOWER_DEEPFM, "star": L.TOWER_STAR, "wdl": L.TOWER_WDL,
-                    "pnn": L.TOWER_PNN}[tower]
+                    "pnn": L.TOWER_PNN, "nfm": L.TOWER_NFM}[tower]
         max_batch = (self.batch_size + 15) // 16 * 16
         cfg = L.Config(L.ABI_VERSION, tower_id, self.n_user, self.n_item, self.n_domain, emb_dim,
                        (C.c_int32 * 3)(*hidden), max_batch, 1 if emb_trainable else 0, float(dropout),
@@ -294,7 +294,7 @@ class TowerEngine(FlatVectorOps):
             if name in ("user_emb", "item_emb", "domain_emb"):
                 out[name] = (cnt // 128, 128)
             elif name in ("W0", "Ws0"):
-                out[name] = (384, 256)
+                out[name] = (cnt // 256, 256)          # (NFM's first kernel has 128 rows)
             elif name == "W0x":
                 out[name] = (3, 256)
             elif name in ("W1", "Ws1"):

@@ -91,13 +91,16 @@ class DeepCTR(BaseModel):
             raise ValueError("hidden_dim %r: the '%s' tower's kernels are built for three hidden layers (the reference's "
                              "configs all have [256, 128, 64])" % (mc["hidden_dim"], tower))
         factory = self.engine_factory
-        # PNN on the step kernels (round 4: MAMDR_TOWER_PNN = the mlp tower + the inner products' three rows of the first
-        # kernel, k_tower4's FM instances): batches of up to 2,048 rows and three hidden layers -- every reference config;
-        # anything else, and MAMDR_PNN_ENGINE=graph (the parity twin), runs it on the generic-layer engine
+        # PNN and NFM on the step kernels (round 4: MAMDR_TOWER_PNN = the mlp tower + the inner products' three rows of the
+        # first kernel; MAMDR_TOWER_NFM = WDL's linear tables + the DNN on the bi-interaction in the domain field's place;
+        # both on k_tower4's FM instances): batches of up to 2,048 rows and hidden_dim [256, 128, 64] -- every reference
+        # config; anything else, and MAMDR_PNN_ENGINE / MAMDR_NFM_ENGINE=graph (the parity twins), runs them on the
+        # generic-layer engine
         import os
-        self.step_pnn = (tower == "pnn" and factory is None and self.batch_size <= 2048 and
+        self.step_pnn = (tower in ("pnn", "nfm") and factory is None and self.batch_size <= 2048 and
                          tuple(mc["hidden_dim"]) == (256, 128, 64) and mc["user_dim"] == 128 and
-                         "uncertainty_weight" not in mc["name"] and os.environ.get("MAMDR_PNN_ENGINE", "step") != "graph")
+                         "uncertainty_weight" not in mc["name"] and os.environ.get("MAMDR_PNN_ENGINE", "step") != "graph" and
+                         os.environ.get("MAMDR_%s_ENGINE" % tower.upper(), "step") != "graph")
         if self.step_pnn:
             from ..engine import TowerEngine
             factory = TowerEngine

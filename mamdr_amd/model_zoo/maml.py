@@ -49,8 +49,10 @@ class MAML(object):
         between = set()
         for n in chosen[1:]:
             off, cnt = segs[n]
-            if off - hi > 3:
-                between = set(k for k, (o, c) in segs.items() if hi <= o < off)
+            # (a gap that holds no other tensor is layout: alignment padding, or the rows of the step kernels' W0 that the
+            # NFM tower leaves unused -- zeros that the outer updates keep at zero)
+            between = set(k for k, (o, c) in segs.items() if hi <= o < off)
+            if off - hi > 3 and between:
                 raise NotImplementedError("meta_parms %s select tensors that are not neighbours in the flat vector (%s sit "
                                           "between them): scattered meta sets are not built"
                                           % (self.train_config["meta_parms"], sorted(between)))

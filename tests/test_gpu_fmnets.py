@@ -22,8 +22,8 @@ HIDDEN = (256, 128, 64)
 
 
 def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable=False):
-    """kind "pnn@step": the PNN tower on the STEP kernels (mamdr_create, MAMDR_TOWER_PNN: k_tower4's FM instances with the
-    inner products' three rows of the first kernel; round 4) instead of the generic-layer engine -- the same oracle."""
+    """kind "pnn@step" / "nfm@step": the tower on the STEP kernels (mamdr_create, MAMDR_TOWER_PNN / _NFM: k_tower4's FM
+    instances; round 4) instead of the generic-layer engine -- the same oracle."""
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     from mamdr_amd import engine, graph_engine, synthetic
@@ -74,7 +74,7 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
     return g, eng, model
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "nfm@step", "pnn", "pnn@step", "ccpm", "autoint"])
 @pytest.mark.parametrize("emb_trainable", [False, True])
 def test_one_step_gradients_match_oracle(kind, emb_trainable):
     g, eng, model = make_problem(kind, dropout=0.5, scale=0.1 if emb_trainable else 0.05, emb_trainable=emb_trainable)
@@ -107,7 +107,7 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "nfm@step", "pnn", "pnn@step", "ccpm", "autoint"])
 def test_adam_pass_and_eval(kind):
     g, eng, model = make_problem(kind, dropout=0.5)
     d = 9
@@ -132,7 +132,7 @@ def test_adam_pass_and_eval(kind):
 
 
 def test_eval_predictions_at_equal_weights():
-    for kind in ("nfm", "pnn", "pnn@step", "ccpm", "autoint"):
+    for kind in ("nfm", "nfm@step", "pnn", "pnn@step", "ccpm", "autoint"):
         g, eng, model = make_problem(kind)
         for d in (1, 5):
             c = g["data"]["test"][d]
@@ -144,7 +144,7 @@ def test_eval_predictions_at_equal_weights():
         eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "nfm@step", "pnn", "pnn@step", "ccpm", "autoint"])
 @pytest.mark.parametrize("emb_trainable", [False, True])
 def test_accumulate_steps_match_oracle(kind, emb_trainable):
     """MAMDR_OPT_ACCUMULATE on the generic-layer engine (the meta passes of MAML / MLDG / PCGrad, maml.py:107-109,196-229):
@@ -185,7 +185,7 @@ def test_accumulate_steps_match_oracle(kind, emb_trainable):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["nfm", "pnn", "pnn@step", "ccpm", "autoint"])
+@pytest.mark.parametrize("kind", ["nfm", "nfm@step", "pnn", "pnn@step", "ccpm", "autoint"])
 def test_domain_negotiation_auc_parity(kind):
     """the meta wrappers run on these towers too (deepctr.py's registry is orthogonal to run.py's wrappers): five
     Domain Negotiation epochs (domain_negotiation.py:49-88) on 4 domains, same order / shuffles / masks on both sides.
