@@ -243,8 +243,9 @@ struct T4L0 {
     static __device__ __forceinline__ const float* wptr2(const float* __restrict__ W) {
         return W + (size_t)(2 * EMB + (threadIdx.x >> 6) * 16) * H1 + 4 * (threadIdx.x & 63);
     }
-    __device__ __forceinline__ void prefetch(const float* __restrict__ W) {
-        const float* wp = wptr1(W);
+    // (skip1: the contraction starts at the domain segment -- NFM, whose kernel occupies rows 256..383 only)
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W, bool skip1 = false) {
+        const float* wp = skip1 ? wptr2(W) : wptr1(W);
 #pragma unroll
         for (int u = 0; u < T4_PF; ++u) t4_load<4>(b[u], wp + (size_t)u * H1);
         __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +254,7 @@ struct T4L0 {
 // (`acc`: zeroed by the caller -- see k_tower4, where the registers are claimed before the gather)
 template <typename MidSeg, typename Mid>
 __device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict__ W, const float* xs, float* red,
-                                               f32x4 (&acc)[4], MidSeg midseg, Mid mid) {
+                                               f32x4 (&acc)[4], MidSeg midseg, Mid mid, bool skip1 = false) {
     static_assert(T4_PF == 8, "two segments of 32 and 16 rows, 8-deep ring");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* wp1 = T4L0::wptr1(W);
@@ -274,9 +275,11 @@ __device__ __forceinline__ void t4_contract_l0(T4L0& tw, const float* __restrict
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    if (!skip1) {              // (uniform)
 #pragma unroll 1
-    for (int k0 = 0; k0 < 24; k0 += 8) chunk(ap1 + k0, wp1 + (size_t)(k0 + 8) * H1, true);
-    chunk(ap1 + 24, wp2, true);                    // ... and the domain segment's first 8 rows
+        for (int k0 = 0; k0 < 24; k0 += 8) chunk(ap1 + k0, wp1 + (size_t)(k0 + 8) * H1, true);
+        chunk(ap1 + 24, wp2, true);                    // ... and the domain segment's first 8 rows
+    }
     midseg();
     chunk(ap2, wp2 + (size_t)8 * H1, true);
     chunk(ap2 + 8, wp2, false);
@@ -488,7 +491,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
         perm_src = a.perm[pc];
     }
     __builtin_amdgcn_sched_barrier(0);
-    w0.prefetch(k_w0);
+    const bool l0_dom_only = FM && a.deepfm == 4;      // NFM: rows 0..255 of W0 are zero and meet nothing the DNN reads
+    w0.prefetch(k_w0, l0_dom_only);
     if (FUSED_OK) tower_snapshots(a, T4_THREADS, n_tiles);
     const bool dmw = FUSED_OK && a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
     // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
@@ -697,7 +701,8 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
                        } else {
                            w1.prefetch(P + a.L.w1);
                        }
-                   });
+                   },
+                   l0_dom_only);
     T4STAMP(2);
     if (!pre && tid < T4_ROWS * (XDIM / 4)) {     // x tile to the workspace, behind the weight stream (k_wgrad_adam reads
                                                   // a pre-gathered pass in place)
