@@ -189,7 +189,7 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
     copied into the oracle), the same shuffles and dropout masks; half of Taobao-10's rows at bs 256 (30 - 60 SGD steps
     per domain and epoch), up to 6 finetune epochs, patience 2.
     Compared after EVERY finetune epoch of every domain: (1) the WEIGHTS -- the displacement from the domain's start
-    weights, per tensor, relative L2 <= 2e-3 (+ the rounding of k SGD steps on the stored weights) and all but 1 % of
+    weights, per tensor, relative L2 <= 2e-3 per epoch run (+ the rounding of k SGD steps on the stored weights) and all but 1 % of
     the elements within 5e-3 of the oracle's displacement (+ 5e-3 of the tensor's RMS displacement); (2) the val AUC, within 1e-3 (north_star), measured far
     tighter (printed).  (3) Early stopping: SGD at 0.001 moves a trained model's val AUC by ~1e-4 per epoch, so the
     stop / keep decisions are comparisons between nearly equal numbers; they can only differ between two runs whose
@@ -267,7 +267,9 @@ def test_finetune_stage_matches_oracle_on_gpu(tmp_path, name):
                 floor = 6e-8 * np.sqrt(2.0 * steps * (e + 1)) * float(np.linalg.norm(ws)) + 1e-12
                 err = float(np.linalg.norm(dh_ - do_))
                 worst_rel = max(worst_rel, max(0.0, err - floor) / max(nrm, 1e-30))
-                assert err <= 2e-3 * nrm + floor, (d, e, nme, err, nrm, floor)
+                # (2e-3 per epoch run so far: every epoch starts from weights that already differ at that level -- at the
+                # DN variant's lr of 0.02 a hidden unit at the relu kink gates differently on the two sides now and then)
+                assert err <= 2e-3 * (e + 1) * nrm + floor, (d, e, nme, err, nrm, floor)
                 # elementwise (the distribution behind the norm): 5e-3 of the element's own displacement + 5e-3 of the
                 # tensor's RMS displacement (an element whose gradient nearly cancels is known to the summation order's
                 # rounding, not better; a hidden unit at the relu kink gates differently on the two sides and moves its
