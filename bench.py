@@ -236,8 +236,8 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
                 continue
             if best_t is None or t < best_t:
                 best_nt, best_t = nt, t
-            if best_t is not None and t > 1.25 * best_t:
-                break
+            if best_t is not None and t > 2.0 * best_t and nt >= 32:     # clearly past the optimum (one noisy trial at 16
+                break                                                      # threads once ended the sweep at 8)
         if best_nt is None:                  # (every count had an outlier: take the best median)
             best_nt, best_t = min(trials, key=lambda x: x[1])
         torch.set_num_threads(best_nt)

@@ -386,7 +386,8 @@ class TowerEngine(FlatVectorOps):
         None[, pass_rows])] -- in this order; where a call would gather its pass's rows itself (frozen tables, fused
         step path) the library gathers them all in one launch now.  Same rows, same bits; a no-op elsewhere."""
         n = len(passes)
-        if n == 0:
+        if n == 0:                 # forget an earlier hint
+            L.check(self.lib.mamdr_pregather_passes(self.ctx, 0, None, None, None, int(batch_size or self.batch_size)))
             return
         doms = (C.c_int32 * n)(*[int(p[0]) for p in passes])
         perms = (C.c_void_p * n)(*[(p[1].data_ptr() if p[1] is not None else None) for p in passes])

@@ -63,8 +63,9 @@ class PassWindow(object):
             if perms is None:          # the loop is not following the announced order: no hint
                 self.on = False
                 return
-            if take > 1:               # (a window of one pass is what the call does by itself)
-                self.eng.pregather(list(zip(chunk, perms)), self.batch_size)
+            # (a window of one pass is what the call does by itself: an empty hint, so that no entry of an earlier
+            # window -- same device buffer, other contents two epochs later -- can ever be taken for this pass)
+            self.eng.pregather(list(zip(chunk, perms)) if take > 1 else [], self.batch_size)
             self.left = take
         self.left = max(self.left - 1, 0)
 

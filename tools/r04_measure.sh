@@ -112,11 +112,13 @@ import json
 d = json.load(open("$OUT/bench_default.json"))
 print("taobao10", round(d["value"]), "steps/s", round(d["us_per_domain_step"], 2), "us/step; tower frac", round(d["roofline"]["frac"], 3),
       "| cpu", round(d["cpu_baseline"]["value"], 1), d["cpu_baseline"]["spread"], "x", round(d["gpu_over_cpu"], 1), "| gather", round(d["gather"]["frac"], 3), "host ms/epoch", d["host_ms_per_epoch"])
-print(d["kernels_avg_us"])
+print({k: v for k, v in d["kernels_avg_us"].items() if k != "_rated"})
+for r in d["kernels_avg_us"].get("_rated", []): print("   rated:", r["kernel"], r["bound"], round(r["frac"], 3))
 for w, t in d["targets"].items():
     print(w, round(t["value"]), round(t["us_per_domain_step"], 2), "us/step; tower frac", round(t["tower"]["frac"], 3), "cpu", round(t["cpu_baseline"]["value"], 2),
           "x", round(t["gpu_over_cpu"], 1), "host ms/epoch", t["host_ms_per_epoch"])
-    print("   ", {k: (round(v["us_per_domain_step"], 2) if isinstance(v, dict) else round(v, 2)) for k, v in t["kernels_avg_us"].items()})
+    print("   ", {k: (round(v["us_per_domain_step"], 2) if isinstance(v, dict) else round(v, 2)) for k, v in t["kernels_avg_us"].items() if k != "_rated"})
+    for r in t["kernels_avg_us"].get("_rated", []): print("    rated:", r["kernel"], r["bound"], round(r["frac"], 3))
 d2 = json.load(open("$OUT/bench_taobao10_2ranks_shared.json")); print("2 ranks shared:", round(d2["value"]), d2.get("partition_speedup_bound"), d2.get("host_ms_per_epoch"))
 PY
 fi
