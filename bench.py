@@ -580,8 +580,9 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
             # ... PRE (the instance for pre-gathered passes) on the k_wgrad_adam path
             pre4 = not trainable and tower == "mlp" and os.environ.get("MAMDR_NO_PREGATHER", "0") in ("", "0") and \
                 eng.step_kernel_names(batch)[L.KERNEL_WGRAD] == "k_wgrad_adam"
+            # (5th parameter W2D: the call's FIRST tower reads W2 in place -- 1 launch in 9; the steady-state instance is named)
             kname = ("k_tower4<true" if trainable else "k_tower4<false") + fm[:-1] + (", true" if w1l else ", false") + \
-                (", true>" if pre4 else ", false>")
+                (", true" if pre4 else ", false") + ", false>"
         else:
             # template <TRAIN, DXW, FM, FZ>; FZ (k_wgrad_adam's duties compiled in) only on that path
             fz = ", true>" if (not trainable and tower == "mlp" and eng.step_kernel_names(batch)[L.KERNEL_WGRAD] == "k_wgrad_adam") \
@@ -592,7 +593,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         roofline = finish_roofline(kname, roofline_ms, cnt, prof_rows,
                                    tower_flops_per_row(384 if tower == "star" else (256 if trainable else 0)))
         roofline["rocprofv3_avg_us"] = rocprof_avg_us(kname, wl["shape"])
-        if kname == "k_tower4<false, false, true, true>":
+        if kname == "k_tower4<false, false, true, true, false>":
             # what this three-phase, 4-row-tile design can reach: the kernel's measured time minus
             # what the diagnostic builds of round 2 showed each single remedy can return at most (DESIGN.md section 6:
             # no W1 traffic at all 0.6 us, no split-k exchange through LDS 0.3 us, no cold paths 0.2 us)
