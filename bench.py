@@ -211,12 +211,13 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
     pinned, restore = _pin_to_one_socket()
     try:
         cap = len(pinned) if pinned else (cores // 2 if cores >= 16 else cores)
-        # counts tried: 8, 16, 32, ... and 3/4 of the cap before the cap itself.  A count is STABLE when no step of its
-        # trial took more than 2.5 x the trial's median: near the pinned core count single steps stall for 0.1 - 1.6 s
-        # (tests/diag_cpu_cliff.py on the GPU host, profiles/r04_cpu_cliff.jsonl: 62 / 64 threads on 64 pinned cores,
-        # median 2.9 - 3.4 ms but outliers of 84 - 1,597 ms -- OpenMP's spinning workers lose a core to any other
-        # runnable thread of this shared host and the whole team waits at the next barrier; OMP_WAIT_POLICY=passive
-        # removes the outliers and costs 2 - 3 x on every step).  The baseline is the fastest STABLE count.
+        # counts tried: 8, 16, 32, ..., 3/4 of the cap, the cap.  Each trial = 1 warm + 9 timed steps, scored by the mean
+        # WITHOUT its two slowest steps: on this shared host single steps stall at any count (tests/diag_cpu_cliff.py,
+        # profiles/r04_cpu_cliff.jsonl: outliers of 8 - 1,600 ms; near the pinned core count OpenMP's spinning workers lose
+        # a core to any other runnable thread and the whole team waits at the next barrier -- 64 threads on 64 cores took
+        # 0.9 - 1.8 s per step in BENCH_r03 and in round 4's runs; OMP_WAIT_POLICY=passive removes that and costs 2 - 3 x
+        # everywhere).  The baseline runs at the SMALLEST count within 10 % of the best score: fewer threads = less
+        # exposure to the neighbours, and the counts near the optimum differ by less than the run-to-run spread.
         counts, nt = [], min(8, cap)
         while nt < cap:
             counts.append(nt)
@@ -224,22 +225,19 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
         if cap >= 16 and (3 * cap) // 4 not in counts:
             counts.append((3 * cap) // 4)
         counts = sorted(set(counts + [cap]))
-        trials, unstable, best_nt, best_t = [], [], None, None
+        trials, unstable = [], []
         for nt in counts:
             torch.set_num_threads(nt)
             one(0)
-            ts = [one(k) for k in range(1, 8)]
-            t, worst = float(np.median(ts)), float(max(ts))
-            trials.append((nt, t))
-            if worst > 2.5 * t:
-                unstable.append((nt, worst))
-                continue
-            if best_t is None or t < best_t:
-                best_nt, best_t = nt, t
-            if best_t is not None and t > 2.0 * best_t and nt >= 32:     # clearly past the optimum (one noisy trial at 16
-                break                                                      # threads once ended the sweep at 8)
-        if best_nt is None:                  # (every count had an outlier: take the best median)
-            best_nt, best_t = min(trials, key=lambda x: x[1])
+            ts = sorted(one(k) for k in range(1, 10))
+            score = float(np.mean(ts[:-2]))
+            trials.append((nt, score))
+            if ts[-1] > 2.5 * float(np.median(ts)):
+                unstable.append((nt, ts[-1]))
+            if score > 2.0 * min(t for _, t in trials) and nt >= 32:     # clearly past the optimum
+                break
+        best_t = min(t for _, t in trials)
+        best_nt = min(n for n, t in trials if t <= 1.10 * best_t)
         torch.set_num_threads(best_nt)
         reps = []
         for _ in range(3):
