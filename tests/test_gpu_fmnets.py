@@ -107,6 +107,50 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable):
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["pnn@step", "nfm@step"])
+@pytest.mark.parametrize("emb_trainable", [False, True])
+@pytest.mark.parametrize("batch", [1024, 2048])
+def test_step_kernel_towers_at_config_batch_sizes(kind, emb_trainable, batch):
+    """PNN / NFM on the step kernels at the reference configs' batch size (1,024: one four-row tile per CU, the W1 image
+    in LDS) and at the largest batch this path takes (2,048: two rounds of workgroups, the streaming instance with the
+    transposed W1 / W2 copies kept current by k_update): one-step gradients of every tensor and the loss against the
+    oracle, on a full and on the pass's last (partial) batch, then three Adam steps (copies stale after the first)."""
+    g, eng, model = make_problem(kind, batch=batch, dropout=0.5, scale=0.5, emb_trainable=emb_trainable)
+    base = kind.split("@")[0]
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    assert n > 2 * batch
+    perm = orng.shuffle_perm(n, 10000, seed=13)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_step = -(-n // batch)
+    for step in (0, n_step - 1):
+        idx = perm[step * batch:(step + 1) * batch]
+        masks = otower.train_masks(model.seed, model.step, len(idx), HIDDEN, 0.5)
+        loss, grads, _ = ofm.loss_and_grads(model.params, base, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                            cols["label"][idx], masks, 0.5, emb_trainable, model.frozen_sumsq())
+        loss_t = torch.zeros(1, device=eng.device)
+        w0 = eng.get_weights()
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = eng.unpack(w0 - eng.get_weights())
+        eng.set_weights(w0)
+        model.step += 1
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+        for name, want in grads.items():
+            want = want.ravel()
+            floor = 4e-8 if name in ("user_emb", "item_emb") else 1.5e-8
+            np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * max(np.abs(want).max(), 1e-3), floor),
+                                       err_msg=name)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=3, lr=1e-3)
+    want_losses = model.train_pass(cols, perm, batch, max_steps=3)
+    got = eng.unpack(eng.get_weights())
+    from test_gpu_parity import assert_adam_close      # (Adam normalises rounding-level gradients to steps of ~lr)
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], 3, 1e-3, name, max_frac=2e-3)
+    assert np.isfinite(np.array(want_losses, F32)).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("kind", ["nfm", "nfm@step", "pnn", "pnn@step", "ccpm", "autoint"])
 def test_adam_pass_and_eval(kind):
     g, eng, model = make_problem(kind, dropout=0.5)
