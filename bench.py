@@ -527,7 +527,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
             names[L.KERNEL_EMB_SWEEP] = "k_emb_reduce"
         names[L.KERNEL_AUX] = {"star": "k_star_stats+prep | k_star_pnb_* (PartitionedNorm backward) | k_emb_rows | "
                                        "k_emb_catchup | k_star_catchup (timed groups)",
-                               "deepfm": "k_emb_rows | k_emb_catchup | k_lin_sweep"}.get(tower, "k_pass_prep (once per call)")
+                               "deepfm": "k_emb_rows | k_emb_catchup | k_lin_sweep"}.get(tower, "k_pass_prep_multi (once per window of passes)")
         names[L.KERNEL_FLUSH] = "k_emb_flush"
         prof_steps = sum(n for (_, _, n) in prof_trace)
         accounted = 0.0

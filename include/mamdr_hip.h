@@ -115,7 +115,7 @@ typedef struct mamdr_config {
     float adam_beta1, adam_beta2, adam_eps; /* tf.train.AdamOptimizer defaults 0.9/0.999/1e-8 */
     int32_t uncertainty_weight; /* 1: training loss = mean(BCE) / var_d^2 + log var_d + regularisers with one trainable
                                    var per domain (model_zoo/uncertainty_weight/weighted_loss.py:30-43); evaluation is
-                                   unweighted, as the reference evaluates the base model.  mlp / deepfm towers only */
+                                   unweighted, as the reference evaluates the base model.  Every tower of mamdr_create but Star */
 } mamdr_config;
 
 const char* mamdr_last_error(void);

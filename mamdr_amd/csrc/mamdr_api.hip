@@ -715,8 +715,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         return fail(MAMDR_EINVAL, "max_batch must be a positive multiple of %d", TILE_ROWS);
     if (cfg->max_batch > 16384) return fail(MAMDR_EINVAL, "max_batch %d exceeds 16384", cfg->max_batch);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return fail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
-    if (cfg->uncertainty_weight && (cfg->tower == MAMDR_TOWER_STAR || cfg->tower == MAMDR_TOWER_PNN || cfg->tower == MAMDR_TOWER_NFM))
-        return fail(MAMDR_ENOTBUILT, "uncertainty weighting is built for the mlp / deepfm towers only");
+    if (cfg->uncertainty_weight && cfg->tower == MAMDR_TOWER_STAR)
+        return fail(MAMDR_ENOTBUILT, "uncertainty weighting is built for the deepctr towers of the step kernels (mlp / deepfm / wdl / pnn / nfm)");
     if ((cfg->tower == MAMDR_TOWER_PNN || cfg->tower == MAMDR_TOWER_NFM) && cfg->max_batch > 2048)
         return fail(MAMDR_ENOTBUILT, "the pnn / nfm towers' training step is built on the four-row tower: batches of up to 2,048 rows, "
                                      "not %d (the generic-layer engine, mamdr_graph_*, takes any batch size)", cfg->max_batch);

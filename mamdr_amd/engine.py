@@ -437,7 +437,7 @@ class TowerEngine(FlatVectorOps):
         """names of the kernels behind profile_read's FWD_BWD / WGRAD / UPDATE slots for a step of `batch` rows."""
         fused = int(self.lib.mamdr_step_path(self.ctx, int(batch or self.batch_size))) == 1
         return {L.KERNEL_FWD_BWD: "k_tower<train>", L.KERNEL_WGRAD: "k_wgrad_adam" if fused else "k_wgrad",
-                L.KERNEL_UPDATE: "k_dm_finish (once per call)" if fused else "k_update"}
+                L.KERNEL_UPDATE: "k_dm_finish (when the live table is read)" if fused else "k_update"}
 
     # ------------------------------------------------------------ profiling
     def profile(self, enable):

@@ -99,7 +99,7 @@ class DeepCTR(BaseModel):
         import os
         self.step_pnn = (tower in ("pnn", "nfm") and factory is None and self.batch_size <= 2048 and
                          tuple(mc["hidden_dim"]) == (256, 128, 64) and mc["user_dim"] == 128 and
-                         "uncertainty_weight" not in mc["name"] and os.environ.get("MAMDR_PNN_ENGINE", "step") != "graph" and
+                         os.environ.get("MAMDR_PNN_ENGINE", "step") != "graph" and
                          os.environ.get("MAMDR_%s_ENGINE" % tower.upper(), "step") != "graph")
         if self.step_pnn:
             from ..engine import TowerEngine

@@ -23,12 +23,14 @@ from . import tower as T
 F32 = np.float32
 
 
-def param_names(kind, emb_trainable):
+def param_names(kind, emb_trainable, uncertainty=False):
+    """(uncertainty: run.py:49-50 wraps ANY tower in the weighted loss -- one trainable `log_var` per domain, last)"""
     emb = ("user_emb", "item_emb") if emb_trainable else ()
+    uw = ("log_var",) if uncertainty else ()
     if kind == "nfm":
         lin = ("lin_user", "lin_item") if emb_trainable else ()
-        return emb + lin + ("domain_emb",) + T.DENSE_NAMES + ("lin_domain",)
-    return emb + ("domain_emb",) + T.DENSE_NAMES
+        return emb + lin + ("domain_emb",) + T.DENSE_NAMES + ("lin_domain",) + uw
+    return emb + ("domain_emb",) + T.DENSE_NAMES + uw
 
 
 def init_params(rs, kind, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64), pretrained=True):
@@ -73,16 +75,28 @@ def reg_loss(P, kind, frozen_sumsq=None):
     return F32(r)
 
 
-def loss_and_grads(P, kind, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None):
+def loss_and_grads(P, kind, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, uncertainty=False):
+    """uncertainty (model_zoo/uncertainty_weight/weighted_loss.py:30-43, as oracle/tower.loss_and_grads): loss =
+    mean(BCE) / var^2 + log var + regularisers, var = log_var[domain of the batch's first row]."""
     B = uid.shape[0]
     E = P["domain_emb"].shape[1]
     keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
     p, hs, x = forward(P, kind, uid, pid, dom, masks, keep_scale)
     y = label.astype(F32)
-    loss = F32(np.mean(T.bce_per_row(p, y), dtype=np.float64)) + reg_loss(P, kind, frozen_sumsq)
+    mean_bce = F32(np.mean(T.bce_per_row(p, y), dtype=np.float64))
     inside = ((p >= T.EPS_CLIP) & (p <= F32(1) - T.EPS_CLIP)).astype(F32)
     dlogit = ((p - y) * inside / F32(B)).astype(F32)
     g = {}
+    if uncertainty:
+        d0 = int(dom[0])
+        var = P["log_var"][d0]
+        w = F32(F32(1) / F32(var * var))
+        loss = F32(w * mean_bce) + F32(np.log(var, dtype=F32)) + reg_loss(P, kind, frozen_sumsq)
+        dlogit = (dlogit * w).astype(F32)
+        g["log_var"] = np.zeros_like(P["log_var"])
+        g["log_var"][d0] = F32(F32(-2) * mean_bce / F32(var * var * var)) + F32(F32(1) / var)
+    else:
+        loss = mean_bce + reg_loss(P, kind, frozen_sumsq)
     g["wo"] = (hs[3].T @ dlogit[:, None]).astype(F32)
     g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
     dh = (dlogit[:, None] * P["wo"][:, 0][None, :]).astype(F32)
@@ -125,19 +139,27 @@ def loss_and_grads(P, kind, uid, pid, dom, label, masks, rate, emb_trainable, fr
 class OracleNet(T.OracleModel):
     """OracleModel with the NFM / PNN forward and gradients (same optimiser, weights in / out, passes)."""
 
-    def __init__(self, params, kind, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64), dropout_seed=1024):
+    def __init__(self, params, kind, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64), dropout_seed=1024,
+                 uncertainty=False):
         T.OracleModel.__init__(self, params, emb_trainable, dropout, lr, hidden, dropout_seed, "mlp", False)
         self.kind = kind
         self.conv = kind in ("ccpm", "autoint")
+        if uncertainty and self.conv:
+            raise NotImplementedError("uncertainty weighting is restated for nfm / pnn only")
+        self.uncertainty = bool(uncertainty)
         self.names = (ccpm_param_names(emb_trainable) if kind == "ccpm" else autoint_param_names(emb_trainable)) if self.conv \
-            else param_names(kind, emb_trainable)
+            else param_names(kind, emb_trainable, uncertainty)
         self.opt = T.Optimizer(params, self.names)
 
     def train_on_batch(self, uid, pid, dom, label):
         B = uid.shape[0]
         masks = T.train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else None
-        fn = loss_and_grads_conv if self.conv else loss_and_grads
-        loss, g, _ = fn(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable, self.frozen_sumsq())
+        if self.conv:
+            loss, g, _ = loss_and_grads_conv(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
+                                             self.frozen_sumsq())
+        else:
+            loss, g, _ = loss_and_grads(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
+                                        self.frozen_sumsq(), self.uncertainty)
         if self.use_sgd:
             self.opt.sgd(self.params, g, self.lr)
         else:
@@ -148,8 +170,12 @@ class OracleNet(T.OracleModel):
     def accumulate_on_batch(self, acc, uid, pid, dom, label):
         """the meta pass of first-order MAML / MLDG / PCGrad on these towers (maml.py:107-109,196-229): gradient of the
         total loss at the current weights added to `acc`, learning phase 0 (dropout off), no update."""
-        fn = loss_and_grads_conv if self.conv else loss_and_grads
-        _, g, _ = fn(self.params, self.kind, uid, pid, dom, label, None, 0.0, self.emb_trainable, self.frozen_sumsq())
+        if self.conv:
+            _, g, _ = loss_and_grads_conv(self.params, self.kind, uid, pid, dom, label, None, 0.0, self.emb_trainable,
+                                          self.frozen_sumsq())
+        else:
+            _, g, _ = loss_and_grads(self.params, self.kind, uid, pid, dom, label, None, 0.0, self.emb_trainable,
+                                     self.frozen_sumsq(), self.uncertainty)
         if getattr(self, "moving_average", None) is not None:
             from . import outer
             ma = self.moving_average

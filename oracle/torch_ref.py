@@ -95,7 +95,8 @@ def star_forward(P, state, uid, pid, dom, training):
     return torch.sigmoid(logit), mean.detach(), var.detach()
 
 
-def fmnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64):
+def fmnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64,
+                         uncertainty=False):
     """deepctr NFM / PNN (deepctr.py:33-35,44-46), float64 autograd.  NFM: linear tables + DNN(BiInteractionPooling of the
     three fields); PNN: DNN([fields | inner products of the field pairs (0,1), (0,2), (1,2)]).  l2 1e-5 on the tables
     (+ the linear tables for NFM)."""
@@ -120,7 +121,12 @@ def fmnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, 
         logit = logit + P["lin_user"][ui] + P["lin_item"][pi] + P["lin_domain"][di]
         reg = reg + L2_LIN * (P["lin_user"].pow(2).sum() + P["lin_item"].pow(2).sum() + P["lin_domain"].pow(2).sum())
     p = torch.sigmoid(logit)
-    loss = keras_bce(p, y).mean() + reg
+    bce = keras_bce(p, y).mean()
+    if uncertainty:            # weighted_loss.py:30-43: mean(BCE) / var^2 + log var, var = log_var[dom[0]]
+        var = P["log_var"][int(dom[0])]
+        loss = bce / (var * var) + torch.log(var) + reg
+    else:
+        loss = bce + reg
     grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
     g = {n: (gr.numpy() if gr is not None else np.zeros(params[n].shape)) for n, gr in zip(names, grads)}
     return float(loss.detach()), g, p.detach().numpy()

@@ -21,7 +21,7 @@ F32 = np.float32
 HIDDEN = (256, 128, 64)
 
 
-def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable=False):
+def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable=False, uncertainty=False):
     """kind "pnn@step" / "nfm@step": the tower on the STEP kernels (mamdr_create, MAMDR_TOWER_PNN / _NFM: k_tower4's FM
     instances; round 4) instead of the generic-layer engine -- the same oracle."""
     if not torch.cuda.is_available():
@@ -50,8 +50,12 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
     if not emb_trainable:           # frozen linear tables stay at their zero initialisation (deepctr: same feature column)
         params["lin_user"][...] = 0
         params["lin_item"][...] = 0
+    if uncertainty:            # distinct per-domain scales around the initial value 1 (weighted_loss.py:23-28)
+        assert step
+        params["log_var"] = (1.0 + rs.uniform(-0.3, 0.3, D)).astype(F32)
     if step:
-        eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=dropout, emb_trainable=emb_trainable, tower=kind)
+        eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=dropout, emb_trainable=emb_trainable, tower=kind,
+                                 uncertainty_weight=uncertainty)
     else:
         eng = graph_engine.GraphEngine(kind, g["n_user"], g["n_item"], D, batch, HIDDEN, (), dropout=dropout,
                                        emb_trainable=emb_trainable)
@@ -63,14 +67,14 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
             c = g["data"][split][d]
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
     names = list(ofm.ccpm_param_names(emb_trainable) if kind == "ccpm" else
-                 (ofm.autoint_param_names(emb_trainable) if kind == "autoint" else ofm.param_names(kind, emb_trainable)))
+                 (ofm.autoint_param_names(emb_trainable) if kind == "autoint" else ofm.param_names(kind, emb_trainable, uncertainty)))
     if step:            # (the step kernels keep the inner products' rows of W0 as a segment of their own, behind the rest)
         assert sorted(set(eng.segments) - {"W0x"}) == sorted(names), (list(eng.segments), names)
     else:
         assert list(eng.segments) == names, (list(eng.segments), names)
     eng.set_weights(eng.pack(params))
     model = ofm.OracleNet({k: v.copy() for k, v in params.items()}, kind, emb_trainable=emb_trainable, dropout=dropout,
-                          lr=1e-3, hidden=HIDDEN, dropout_seed=eng.dropout_seed)
+                          lr=1e-3, hidden=HIDDEN, dropout_seed=eng.dropout_seed, **({"uncertainty": True} if uncertainty else {}))
     return g, eng, model
 
 
@@ -148,6 +152,51 @@ def test_step_kernel_towers_at_config_batch_sizes(kind, emb_trainable, batch):
     for name in model.names:
         assert_adam_close(got[name], model.params[name], 3, 1e-3, name, max_frac=2e-3)
     assert np.isfinite(np.array(want_losses, F32)).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["pnn@step", "nfm@step"])
+def test_uncertainty_weighted_step_on_the_step_kernel_towers(kind):
+    """run.py:49-50 wraps ANY tower in the weighted loss (weighted_loss.py:30-43); on the step kernels' PNN / NFM (round 4)
+    as on mlp / deepfm: every gradient scaled by 1 / var_d^2, d loss / d var_d, zero gradient for the other domains'
+    scalars, a few Adam steps, evaluation unweighted."""
+    g, eng, model = make_problem(kind, batch=256, dropout=0.5, uncertainty=True)
+    base = kind.split("@")[0]
+    assert eng.segments["log_var"][1] == 10 and model.names[-1] == "log_var"
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    perm = orng.shuffle_perm(n, 10000, seed=11)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    n_step = -(-n // 256)
+    for step in (0, n_step - 1):
+        idx = perm[step * 256:(step + 1) * 256]
+        masks = otower.train_masks(model.seed, model.step, len(idx), HIDDEN, 0.5)
+        loss, grads, _ = ofm.loss_and_grads(model.params, base, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                            cols["label"][idx], masks, 0.5, False, model.frozen_sumsq(), True)
+        loss_t = torch.zeros(1, device=eng.device)
+        w0 = eng.get_weights()
+        eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+        got = eng.unpack(w0 - eng.get_weights())
+        eng.set_weights(w0)
+        model.step += 1
+        assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+        for name, want in grads.items():
+            want = want.ravel()
+            np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * max(np.abs(want).max(), 1e-3), 1e-7),
+                                       err_msg=name)
+        lv = got["log_var"]
+        assert lv[d] != 0 and not np.delete(lv, d).any()
+    k = min(3, n_step)
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=k, lr=1e-3)
+    model.train_pass(cols, perm, 256, max_steps=k)
+    got = eng.unpack(eng.get_weights())
+    from test_gpu_parity import assert_adam_close
+    for name in model.names:
+        assert_adam_close(got[name], model.params[name], k, 1e-3, name, max_frac=2e-3)
+    loss_g, _ = eng.evaluate(d, "val")
+    loss_o, _ = model.evaluate(g["data"]["val"][d], eng.eval_batch)
+    assert abs(loss_g - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
     eng.close()
 
 
