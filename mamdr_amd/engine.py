@@ -74,6 +74,27 @@ class FlatVectorOps(object):
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
         L.check(self.lib.mamdr_merge(_ptr(dst), _ptr(theta), _ptr(phi), mode, dst.numel(), self._s()))
 
+    # ---- the COMPILED optimiser (deepctr.py:54-60: `model.compile(optimizer=opt)`): the wrappers' train_on_batch / fit calls
+    # -- train_steps(optimizer="adam") here -- run whatever the model was compiled with.  train.optimizer "adam" =
+    # tf.train.AdamOptimizer(learning_rate); any other value is handed to Keras as a STRING, i.e. the Keras optimiser of
+    # that name with ITS default hyper-parameters: "sgd" = SGD(lr 0.01, no momentum), whatever learning_rate says.
+    compiled = ("adam", None)
+
+    def compile(self, optimizer):
+        if optimizer == "adam":
+            self.compiled = ("adam", None)
+        elif optimizer == "sgd":
+            self.compiled = ("sgd", 0.01)
+        else:
+            raise NotImplementedError("train.optimizer '%s': Keras optimisers other than 'sgd' are not built (the reference's "
+                                      "configs all use adam: deepctr.py:54-57)" % optimizer)
+
+    def _compiled(self, optimizer, lr):
+        """(optimizer, lr) a train_steps call runs: "adam" names the compiled optimiser."""
+        if optimizer == "adam" and self.compiled[0] != "adam":
+            return self.compiled
+        return optimizer, lr
+
     # ---- meta parameters (MAML._get_model_meta_parms, maml.py:153-179): theta / phi vectors cover ONE contiguous range
     # [meta_off, meta_off + n_meta) of the flat vector -- the whole vector ("all"), the Star filter's prefix, or e.g.
     # "all_hidden" (everything behind the embedding tables)
@@ -352,6 +373,7 @@ class TowerEngine(FlatVectorOps):
         n = self.n_rows(domain, "train") if pass_rows is None else int(pass_rows)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
+        optimizer, lr = self._compiled(optimizer, lr)
         opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD, "accumulate": L.OPT_ACCUMULATE}[optimizer]
         if optimizer == "accumulate" and self._ema is not None:
             # average_meta_grad == "moving_mean": every meta batch updates the accumulator's moving average

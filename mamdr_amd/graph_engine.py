@@ -181,6 +181,7 @@ class GraphEngine(FlatVectorOps):
         n = self.n_rows(domain, "train") if pass_rows is None else int(pass_rows)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
+        optimizer, lr = self._compiled(optimizer, lr)
         opt = {"adam": L.OPT_ADAM, "sgd": L.OPT_SGD, "accumulate": L.OPT_ACCUMULATE}[optimizer]
         rows = -1 if pass_rows is None else n
         if optimizer == "accumulate" and self._ema is not None:       # average_meta_grad == "moving_mean" (maml.py:219-220)

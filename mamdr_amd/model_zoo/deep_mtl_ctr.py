@@ -119,8 +119,7 @@ class DeepMTLCTR(BaseModel):
                 c = v["data"]
                 eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
         eng.set_weights(eng.pack(tensors))
-        if tc["optimizer"] != "adam":
-            raise NotImplementedError("optimizer '%s': the reference configs all use adam (deep_mtl_ctr.py:53-56)" % tc["optimizer"])
+        eng.compile(tc["optimizer"])     # "adam" -> tf.train.AdamOptimizer(learning_rate); a Keras name otherwise (deep_mtl_ctr.py:53-56)
         if tc["loss"] != "binary_crossentropy":
             raise NotImplementedError("loss '%s': only binary_crossentropy is built" % tc["loss"])
         return eng

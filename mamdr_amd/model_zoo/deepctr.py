@@ -148,9 +148,7 @@ class DeepCTR(BaseModel):
                 eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
         eng.set_weights(eng.pack(tensors))
         self.optimizer = tc["optimizer"]
-        if self.optimizer != "adam":
-            raise NotImplementedError("optimizer '%s': the reference configs all use adam (deepctr.py:54-57)"
-                                      % self.optimizer)
+        eng.compile(self.optimizer)      # "adam" -> tf.train.AdamOptimizer(learning_rate); a Keras name otherwise (deepctr.py:54-57)
         if tc["loss"] != "binary_crossentropy":
             raise NotImplementedError("loss '%s': only binary_crossentropy is on the hot path" % tc["loss"])
         return eng

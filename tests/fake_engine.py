@@ -39,6 +39,10 @@ class FakeEngine(object):
         self.calls = []
         self._ema = None
 
+    def compile(self, optimizer):
+        from mamdr_amd.engine import FlatVectorOps
+        FlatVectorOps.compile(self, optimizer)
+
     # flat vectors
     def keras_name(self, segment):
         return segment
@@ -134,6 +138,8 @@ class FakeEngine(object):
         p = np.arange(n, dtype=np.int32) if perm is None else np.asarray(perm)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
+        if optimizer == "adam" and getattr(self, "compiled", ("adam", None))[0] != "adam":
+            optimizer, lr = self.compiled
         self.oracle.lr = lr
         self.oracle.use_sgd = optimizer == "sgd"
         for s in range(first_step, first_step + n_steps):
@@ -184,6 +190,11 @@ class FakeEngine(object):
 
 class FakeGraphEngine(object):
     """CPU stand-in for mamdr_amd.graph_engine.GraphEngine (multi-task towers), built on oracle/mtl.py (tests only)."""
+    compiled = ("adam", None)
+
+    def compile(self, optimizer):
+        from mamdr_amd.engine import FlatVectorOps
+        FlatVectorOps.compile(self, optimizer)
 
     def __init__(self, kind, n_user, n_item, n_domain, batch_size, expert_hidden, tower_hidden, gate_hidden=(),
                  num_experts=0, shared_expert_num=0, specific_expert_num=0, dropout=0.5, emb_trainable=False, emb_dim=128,
@@ -253,6 +264,8 @@ class FakeGraphEngine(object):
         p = np.arange(n, dtype=np.int32) if perm is None else np.asarray(perm)
         if n_steps is None:
             n_steps = -(-n // bs) - first_step
+        if optimizer == "adam" and self.compiled[0] != "adam":
+            optimizer, lr = self.compiled
         self.oracle.lr = lr
         self.oracle.use_sgd = optimizer == "sgd"
         for s in range(first_step, first_step + n_steps):

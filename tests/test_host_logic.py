@@ -687,3 +687,20 @@ def test_configs_mirror_the_reference():
     extra = {"Amazon_13/star_DN+DR.json", "Amazon_6/deepfm_DN.json", "Taobao_30/deepctr_DN+DR_bs4096.json"}
     have = {"%s/%s" % (s, f) for s in os.listdir(ours) for f in os.listdir(os.path.join(ours, s)) if f.endswith(".json")}
     assert extra <= have and len(have) == 43
+
+
+def test_compiled_optimizer_strings(tmp_path, monkeypatch):
+    """deepctr.py:54-57 / star.py:26-30 / deep_mtl_ctr.py:53-56: train.optimizer "adam" compiles tf.train.AdamOptimizer at
+    `learning_rate`; any other value reaches Keras as a STRING = that Keras optimiser at ITS defaults.  "sgd" (SGD, lr 0.01,
+    no momentum, whatever learning_rate says) is built: every step of the wrappers runs it; other names raise."""
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "mlp_meta_domain_negotiation", epochs=1)
+    cfg["train"].update(optimizer="sgd", learning_rate=0.5)
+    ds = mds.MultiDomainDataset(cfg["dataset"])
+    model = cli.build_model(cfg, ds, FakeEngine)
+    model.train()
+    calls = model.model.calls
+    assert calls and all(c[2] == "sgd" and c[3] == 0.01 for c in calls), calls[:3]
+    cfg["train"]["optimizer"] = "rmsprop"
+    with pytest.raises(NotImplementedError, match="rmsprop"):
+        cli.build_model(cfg, ds, FakeEngine)
