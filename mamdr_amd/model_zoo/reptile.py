@@ -22,9 +22,6 @@ class Reptile(MAML):
         batch_variant = "batch" in self.model_config["name"]
         rank, world = parallel.world()
         if world > 1:
-            if tc["target_domain"] >= 0:
-                raise NotImplementedError("multi-process Reptile with a target domain is not built (the target step "
-                                          "after every domain ties the domains' passes together)")
             sizes = [self.dataset.train_dataset[d]["n_data"] for d in range(self.n_domain)]
             owner = parallel.lpt_partition(sizes, world)
             acc = self.model.new_vector(meta=True)
@@ -37,13 +34,20 @@ class Reptile(MAML):
                 # one process per GPU: the batch variant's sum of displacements is a sum over ranks
                 self.trace += parallel.reptile_batch_epoch_sharded(
                     self.model, meta, meta_weights, [d for d in train_sequence if owner[d] == rank], self.shuffler,
-                    self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, tc["meta_train_step"])
+                    self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, tc["meta_train_step"],
+                    target=tc["target_domain"])
             elif world > 1:
                 # per-domain variant: every rank runs the recurrence over its domains, displacements summed
                 self.trace += parallel.reptile_epoch_sharded(
                     self.model, meta, meta_weights, [d for d in train_sequence if owner[d] == rank], self.shuffler,
-                    self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, zero, tc["meta_train_step"])
-            else:
+                    self.batch_size, self.learning_rate, tc["meta_learning_rate"], acc, zero, tc["meta_train_step"],
+                    target=tc["target_domain"])
+            if world > 1 and tc["target_domain"] >= 0:
+                # reptile.py:98-102: the epoch ends with a full pass of the model (theta, identical on every rank) over
+                # the target domain
+                meta.run_pass(self.model, tc["target_domain"], self.shuffler, self.batch_size, self.learning_rate, self.trace,
+                              "target")
+            if world == 1:
                 self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
                                                  self.batch_size, self.learning_rate, tc["meta_learning_rate"],
                                                  batch_variant, tc["meta_train_step"], target=tc["target_domain"])

@@ -135,16 +135,23 @@ def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_
 
 
 def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, delta_buf, zero_buf,
-                          meta_train_step=0):
+                          meta_train_step=0, target=-1):
     """Reptile, per-domain variant (reptile.py:45-99): the reference interpolates theta after EVERY domain, a
     sequential recurrence.  Sharded: every rank runs that recurrence over its own domains on a private copy
     starting from the epoch's theta, then the ranks' total displacements are summed (ONE all-reduce) and applied:
-    theta += sum_g (theta_g - theta).  One rank: exactly the reference's epoch."""
+    theta += sum_g (theta_g - theta).  One rank: exactly the reference's epoch.
+    target >= 0 (reptile.py:47-48,82-85,98-102): the target domain is no task; every domain's pass is followed by ONE
+    step on the target domain before its interpolation (on whichever rank runs that domain), and the caller closes the
+    epoch with a full pass of the updated model over the target domain (on every rank: the model is the same)."""
     trace = []
     local = theta.clone()
     for d in seq_local:
+        if target >= 0 and d == target:
+            continue
         eng.set_weights(local)
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
+        if target >= 0:
+            meta.run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
         eng.interp(local, eng.meta_weights, local, meta_lr)
     rank, ws = world()
     if ws == 1:
@@ -157,7 +164,8 @@ def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, 
     return trace
 
 
-def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, acc, meta_train_step=0):
+def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_lr, acc, meta_train_step=0,
+                                target=-1):
     """Reptile, batch variant (reptile.py:87-96,134-142): every domain starts from theta and adds its
     displacement theta~ - theta to `acc`; the epoch applies theta += beta * sum.  The sum over domains is a sum
     over ranks of per-rank sums: ONE all-reduce of `acc` per epoch, no other change to the algorithm.
@@ -165,8 +173,12 @@ def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size
     trace = []
     acc.zero_()
     for d in seq_local:
+        if target >= 0 and d == target:
+            continue
         eng.set_weights(theta)
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
+        if target >= 0:           # reptile.py:82-85: one step on the target domain after every domain's pass
+            meta.run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
         eng.accumulate(acc, eng.meta_weights, theta)
     rank, ws = world()
     if ws > 1:

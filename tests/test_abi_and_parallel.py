@@ -361,6 +361,8 @@ def test_run_entry_sharded_reptile_batch_gloo_world2(tmp_path):
     ("mlp_meta_mamdr", {"finetune_every_epoch": True}),             # mamdr.py:110-143
     ("mlp_meta_domain_negotiation", {"meta_train_step": 2, "target_domain": 1}),   # domain_negotiation.py:44-45,67,89-93
     ("mlp_meta_reptile", {}),                                       # reptile.py:45-99, per-domain interpolation
+    ("mlp_meta_reptile", {"target_domain": 1}),                     # reptile.py:47-48,82-85,98-102: target step + closing pass
+    ("mlp_meta_reptile_batch", {"target_domain": 2}),
     ("mlp_meta_mamdr_finetune", {"dn_mode": "replicated"}),         # SURVEY 8e fallback: one DN chain, DR sharded
     ("mlp_meta_domain_negotiation", {"meta_finetune_step": 1}),     # maml.py:245-287: fine-tune, then validate, per domain
     ("mlp_meta_mamdr", {"meta_finetune_step": 1}),
