@@ -89,6 +89,11 @@ def init_params(g, seed=1024):
     return p
 
 
+if os.environ.get("MAMDR_LIB_PATH"):          # a diagnostic build of the library (tools/build_variant.sh): A/B measurements
+    from mamdr_amd import _lib as _L
+    _L.LIB_PATH = os.environ["MAMDR_LIB_PATH"]
+
+
 def setup_engine(g, batch, emb_trainable=False, tower="mlp"):
     from mamdr_amd import engine
     eng = engine.TowerEngine(g["n_user"], g["n_item"], g["n_domain"], batch, dropout=TRAIN["dropout"],

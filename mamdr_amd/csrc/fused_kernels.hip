@@ -633,7 +633,11 @@ __device__ __forceinline__ void pass_prep_row(const P& a, const float* user_tab,
     it = it < 0 ? 0 : (it >= n_item ? n_item - 1 : it);
     const float* row = lane < 32 ? user_tab + (size_t)u * EMB + 4 * lane : item_tab + (size_t)it * EMB + 4 * (lane - 32);
     const f32x4 v = *reinterpret_cast<const f32x4*>(row);
+#ifdef MAMDR_PREP_PLAIN_STORES      // (A/B: plain stores, so that the rows may stay in the infinity cache for the towers)
+    *reinterpret_cast<f32x4*>(xpre + (size_t)i * (2 * EMB) + 4 * lane) = v;
+#else
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(xpre + (size_t)i * (2 * EMB) + 4 * lane));
+#endif
     if (lane == 0) {
         int d = a.dom[src];
         pdom[i] = d < 0 ? 0 : (d >= n_domain ? n_domain - 1 : d);

@@ -41,6 +41,8 @@ class PassWindow(object):
         self.budget, self.max_passes = budget_rows, max_passes
         import os
         self.on = hasattr(perm_fn, "peek") and hasattr(eng, "pregather") and not os.environ.get("MAMDR_NO_PASS_WINDOW")
+        if os.environ.get("MAMDR_PASS_WINDOW_ROWS"):          # (A/B measurements of the window size)
+            self.budget = int(os.environ["MAMDR_PASS_WINDOW_ROWS"])
         self.todo, self.left = [], 0
 
     def announce(self, domains):
