@@ -175,3 +175,56 @@ def test_largest_batch_of_the_context_with_a_one_row_remainder():
     for name in ("W0", "W1", "W2", "wo", "domain_emb"):
         assert_adam_close(got[name], model.params[name], 2, 1e-3, name, max_frac=2e-3)
     eng.close()
+
+
+def test_pregather_hint_edge_cases():
+    """mamdr_pregather_passes is a HINT (include/mamdr_hip.h): more than 16 passes (the later ones gather themselves),
+    calls that skip hinted passes, a call that was never hinted (drops the hint, gathers as before), a window of a
+    pass (`pass_rows`), step-at-a-time calls on a hinted pass, an empty hint, an unbound domain in the list (error,
+    nothing changed) -- weights and both Adam slots bit-identical to the same calls without any hint."""
+    out = {}
+    for mode in ("hint", "plain"):
+        g, eng, model, data = make(batch=256, scale=0.1)
+        assert int(eng.lib.mamdr_step_path(eng.ctx, 256)) == 1
+        D = g["n_domain"]
+        n = [eng.n_rows(d, "train") for d in range(D)]
+        perms = {}
+        for k in range(24):
+            d = k % D
+            perms[k] = (d, torch.from_numpy(orng.shuffle_perm(n[d], 10000, seed=100 + k)).to(eng.device))
+        hint = mode == "hint"
+        if hint:
+            eng.pregather([perms[k] for k in range(24)])             # 24 listed: the first 16 are gathered
+        for k in (0, 1, 3, 4, 15, 16, 20):                            # skips 2, 5..14; 16 and 20 gather themselves
+            eng.train_steps(perms[k][0], perm=perms[k][1], lr=1e-3)
+        hits0 = int(eng.lib.mamdr_pregather_hits(eng.ctx))
+        if hint:
+            assert hits0 == 5, hits0
+            eng.pregather([perms[k] for k in (21, 22, 23)])
+        eng.train_steps(perms[5][0], perm=perms[5][1], lr=1e-3)       # not in the hint: drops it
+        eng.train_steps(perms[21][0], perm=perms[21][1], lr=1e-3)     # ... so this one gathers itself too
+        if hint:
+            assert int(eng.lib.mamdr_pregather_hits(eng.ctx)) == hits0
+            w = 300                                                   # a window of the pass, then step-at-a-time calls
+            dbig = max(range(D), key=lambda d: n[d])
+            pw = torch.from_numpy(orng.shuffle_perm(w, 10000, seed=7)).to(eng.device)
+            pb = torch.from_numpy(orng.shuffle_perm(n[dbig], 10000, seed=8)).to(eng.device)
+            eng.pregather([(dbig, pw, w), (dbig, pb)])
+        else:
+            w = 300
+            dbig = max(range(D), key=lambda d: n[d])
+            pw = torch.from_numpy(orng.shuffle_perm(w, 10000, seed=7)).to(eng.device)
+            pb = torch.from_numpy(orng.shuffle_perm(n[dbig], 10000, seed=8)).to(eng.device)
+        eng.train_steps(dbig, perm=pw, lr=1e-3, pass_rows=w)
+        for s in range(min(3, -(-n[dbig] // 256))):
+            eng.train_steps(dbig, perm=pb, first_step=s, n_steps=1, lr=1e-3)
+        if hint:
+            assert int(eng.lib.mamdr_pregather_hits(eng.ctx)) == hits0 + 1 + min(3, -(-n[dbig] // 256))
+            eng.pregather([])                                         # forget it
+            with pytest.raises(Exception):
+                eng.pregather([(D + 3, None)])                        # unknown domain
+        eng.train_steps(0, lr=1e-3)                                   # file order, no permutation
+        out[mode] = (eng.weights.cpu().numpy().copy(), eng.adam_m.cpu().numpy().copy(), eng.adam_v.cpu().numpy().copy())
+        eng.close()
+    for a, b in zip(out["hint"], out["plain"]):
+        assert np.isfinite(a).all() and np.array_equal(bits(a), bits(b))
