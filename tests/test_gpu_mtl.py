@@ -27,11 +27,19 @@ SHAPES = {
 }
 
 
-def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, n_domain=4, emb_trainable=False):
+# the reference's own shapes: config/Taobao-10/{shared_bottom,mmoe,ple}.json (batch_size 1024, 10 domains)
+CONFIG_SHAPES = {
+    "shared_bottom": ((512, 256, 128), (64,), (), 0, 0, 0),
+    "mmoe": ((512, 256, 128), (64,), (64,), 2, 0, 0),
+    "ple": ((256,), (64,), (64,), 0, 2, 10),
+}
+
+
+def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, n_domain=4, emb_trainable=False, shapes=None):
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     from mamdr_amd import graph_engine, synthetic
-    eh, th, gh, ne, se, sp = SHAPES[kind]
+    eh, th, gh, ne, se, sp = (shapes or SHAPES)[kind]
     shape = dict(synthetic.SHAPES["taobao10"], n_domain=n_domain)
     g = synthetic.generate(shape, batch_size=batch, seed=seed, scale=scale)
     D = g["n_domain"]
@@ -104,6 +112,46 @@ def test_one_step_gradients_match_oracle(kind, dropout):
                 else:                         # not on task d's path: untouched, bit for bit
                     off, cnt = eng.segments[name]
                     assert np.array_equal(after[off:off + cnt], w0.cpu().numpy()[off:off + cnt]), name
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
+def test_config_shapes_at_batch_1024(kind):
+    """the reference's Taobao-10 multi-task configs as configured: their layer widths / expert counts, 10 domains, batch
+    size 1,024 (config/Taobao-10/*.json) -- one-step gradients of every tensor on task d's path and the loss against the
+    oracle on a full batch, everything off the path bit-unchanged, then three Adam steps."""
+    g, eng, model, spec = make_problem(kind, batch=1024, dropout=0.5, scale=0.5, n_domain=10, shapes=CONFIG_SHAPES)
+    d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
+    cols = g["data"]["train"][d]
+    n = cols["uid"].shape[0]
+    assert n >= 3 * 1024
+    perm = orng.shuffle_perm(n, 10000, seed=5)
+    perm_t = torch.from_numpy(perm).to(eng.device)
+    idx = perm[:1024]
+    masks = omtl.train_masks(spec, model.seed, model.step, 1024, 0.5)
+    loss, grads, _ = omtl.loss_and_grads(model.params, spec, d, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                                         cols["label"][idx], masks, 0.5, False, model.frozen_sumsq())
+    loss_t = torch.zeros(1, device=eng.device)
+    w0 = eng.get_weights()
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)
+    got = eng.unpack(w0 - eng.get_weights())
+    after = eng.get_weights().cpu().numpy()
+    eng.set_weights(w0)
+    model.step += 1
+    assert abs(float(loss_t.cpu()[0]) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    for name in eng.segments:
+        if name in grads:
+            want = grads[name].ravel()
+            scale = max(np.abs(want).max(), 1e-3)
+            np.testing.assert_allclose(got[name], want, rtol=2e-4, atol=max(2e-6 * scale, 1.5e-8), err_msg=name)
+        else:
+            off, cnt = eng.segments[name]
+            assert np.array_equal(after[off:off + cnt], w0.cpu().numpy()[off:off + cnt]), name
+    eng.train_steps(d, perm=perm_t, first_step=0, n_steps=3, lr=1e-3)
+    model.train_pass(d, cols, perm, 1024, max_steps=3)
+    got = eng.unpack(eng.get_weights())
+    for name in grads:
+        assert_adam_close(got[name], model.params[name], 3, 1e-3, name)
     eng.close()
 
 
