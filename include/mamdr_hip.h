@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 14
+#define MAMDR_ABI_VERSION 15
 
 enum {
     MAMDR_OK = 0,
@@ -361,6 +361,9 @@ typedef struct mamdr_graph_config {
     int32_t shared_expert_num, specific_expert_num;      /* ple (:40-41) */
     float dropout, l2_emb, adam_beta1, adam_beta2, adam_eps;
     float l2_linear;                                     /* NFM: deepctr l2_reg_linear (1e-5) on the 1-d linear tables */
+    int32_t uncertainty_weight;                          /* single-output towers: the weighted loss of uncertainty_weight/
+                                                          * weighted_loss.py:30-43 (one trainable `log_var` per domain, last
+                                                          * tensor of the flat vector); evaluation stays unweighted */
 } mamdr_graph_config;
 const char* mamdr_graph_last_error(void);
 int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph** out);   /* build_model, deep_mtl_ctr.py:21-67 */

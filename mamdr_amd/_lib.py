@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN, TOWER_NFM = 0, 1, 2, 3, 4, 5
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -61,7 +61,7 @@ class GraphConfig(C.Structure):
         ("n_gate_hidden", C.c_int32), ("gate_hidden", C.c_int32 * 4),
         ("num_experts", C.c_int32), ("shared_expert_num", C.c_int32), ("specific_expert_num", C.c_int32),
         ("dropout", C.c_float), ("l2_emb", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
-        ("adam_eps", C.c_float), ("l2_linear", C.c_float),
+        ("adam_eps", C.c_float), ("l2_linear", C.c_float), ("uncertainty_weight", C.c_int32),
     ]
 
 

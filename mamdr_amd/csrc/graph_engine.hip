@@ -902,6 +902,8 @@ struct HeadArgs {
     float* dlogit; float* rowloss;
     int train; float gate_scale;
     const float* thresholds; uint32_t* hist; float* pred_out;       // inference
+    const float* log_var; const int32_t* domrow;    // weighted loss (training only): d logit scaled by 1 / var^2, var =
+                                                    // log_var[domain of the batch's FIRST row] (weighted_loss.py:38-41)
 };
 __global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -926,7 +928,11 @@ __global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
     if (lane == 0) a.rowloss[r] = valid ? loss : 0.f;
     if (a.train) {
         const float inside = (p >= lo && p <= hi) ? 1.0f : 0.0f;
-        const float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.f;
+        float dl = valid ? ((p - y) * inside) / (float)a.rows : 0.f;
+        if (a.log_var) {
+            const float var = a.log_var[a.domrow[0]];
+            dl *= 1.0f / (var * var);
+        }
         if (lane == 0) a.dlogit[r] = dl;
         float* drow = a.dact + (size_t)r * a.ld;
         for (int cidx = lane; cidx < a.n_t; cidx += 64)
@@ -946,7 +952,9 @@ __global__ __launch_bounds__(256) void k_graph_head(const HeadArgs a) {
 // mode 0: out[0] = loss;  mode 1 (evaluation): out[0] += loss
 __global__ __launch_bounds__(256) void k_graph_loss(const float* rowloss, int rows, const float* dm, int dm_count, float l2,
                                                     const float* frozen_sumsq, float* out, int mode, const float* lin_d,
-                                                    int n_lin_d, float l2_lin) {
+                                                    int n_lin_d, float l2_lin, const float* log_var = nullptr,
+                                                    const int32_t* domrow = nullptr, float* g_log_var = nullptr,
+                                                    int n_domain = 0) {
     __shared__ float red[256];
     float s = 0.f, q = 0.f;
     for (int b = threadIdx.x; b < rows; b += 256) s += rowloss[b];
@@ -971,7 +979,14 @@ __global__ __launch_bounds__(256) void k_graph_loss(const float* rowloss, int ro
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float loss = tot / (float)rows + l2 * ((frozen_sumsq[0] + frozen_sumsq[1]) + red[0]) + ql;
+        float data = tot / (float)rows;
+        if (log_var) {      // weighted_loss.py:30-35: mean(BCE / var^2 + log var); d / d var = -2 mean(BCE) / var^3 + 1 / var
+            const int d0 = domrow[0];
+            const float var = log_var[d0];
+            for (int d = 0; d < n_domain; ++d) g_log_var[d] = d == d0 ? -2.0f * data / (var * var * var) + 1.0f / var : 0.f;
+            data = (1.0f / (var * var)) * data + logf(var);
+        }
+        const float loss = data + l2 * ((frozen_sumsq[0] + frozen_sumsq[1]) + red[0]) + ql;
         out[0] = mode ? out[0] + loss : loss;
     }
 }
@@ -1114,6 +1129,7 @@ struct mamdr_graph {
     float *attP[3] = {nullptr, nullptr, nullptr}, *attdP[3] = {nullptr, nullptr, nullptr};
     float *attA[3] = {nullptr, nullptr, nullptr}, *attY[3] = {nullptr, nullptr, nullptr}, *attdY[3] = {nullptr, nullptr, nullptr};
     int64_t lin_d_off = 0;      // NFM: 1-d linear table of the domain feature (behind the global bias)
+    int64_t lv_off = -1;        // weighted loss: `log_var` [n_domain], the last tensor (-1: plain loss)
     int64_t lin_u_off = 0, lin_i_off = 0;       // ... of the user / item features (trainable tables only)
     float *extra = nullptr, *glin_u = nullptr, *glin_i = nullptr;
     // bound state
@@ -1653,6 +1669,8 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (cfg->kind == MAMDR_GRAPH_PLE) { n_shared = cfg->shared_expert_num; n_specific = cfg->specific_expert_num; }
     if (!single && (n_shared < 0 || n_specific < 0 || n_shared + n_specific < 1 || n_shared + n_specific > MAX_MIX))
         return gfail(MAMDR_EINVAL, "a task must mix 1..%d experts", MAX_MIX);
+    if (!single && cfg->uncertainty_weight)     // uncertainty_weight.py:41-45 wraps model.inputs / outputs[0] of ONE Keras model
+        return gfail(MAMDR_ENOTBUILT, "the weighted loss wraps a single-output tower (the multi-task towers are a dict of models)");
 
     mamdr_graph* g = new (std::nothrow) mamdr_graph();
     if (!g) return gfail(MAMDR_EHIP, "out of host memory");
@@ -1724,6 +1742,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
         t.head_w = add_tensor(g, "wo", autoint ? 3 * ATT_OUT + in : in, 1);
         t.head_gb = add_tensor(g, "gb", 1, 1);
         if (has_lin) g->lin_d_off = add_tensor(g, "lin_domain", cfg->n_domain, 1);
+        if (cfg->uncertainty_weight) g->lv_off = add_tensor(g, "log_var", cfg->n_domain, 1);
         g->shared_end = g->n_params;
         t.blk_off = t.blk_end = g->n_params;
         int c = XDIM;
@@ -2073,12 +2092,19 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
         ha.extra = g->extra;
         ha.train = 1;
         ha.gate_scale = sc.keep_scale;
+        const bool weighted = g->lv_off >= 0;
+        if (weighted) {
+            ha.log_var = g->params + g->lv_off;
+            ha.domrow = g->domrow;
+        }
         GLAUNCH(k_graph_head, dim3(sc.rp / 4), dim3(256), 0, g->stream, ha);
         if (d_loss_out && g->tables) refresh_sumsq(g);
-        if (d_loss_out)
+        if (d_loss_out || weighted)     // the weighted loss takes d / d log_var from the batch's mean BCE: this launch, always
             GLAUNCH(k_graph_loss, dim3(1), dim3(256), 0, g->stream, g->rowloss, sc.rows, g->params + g->dm_off,
-                               g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out + s, 0,
-                               g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear);
+                               g->cfg.n_domain * EMB, g->cfg.l2_emb, g->frozen_sumsq, d_loss_out ? d_loss_out + s : g->eval_acc + 1, 0,
+                               g->extra ? g->params + g->lin_d_off : nullptr, g->cfg.n_domain, g->cfg.l2_linear,
+                               weighted ? g->params + g->lv_off : nullptr, g->domrow, weighted ? g->G(g->lv_off) : nullptr,
+                               g->cfg.n_domain);
         // ---- backward
         // head: dw = t^T dlogit, dgb = sum dlogit
         launch_small_tn(g->stream, g->act + t_col, g->ld, g->dlogit, 1,

@@ -29,7 +29,7 @@ def _arr4(values):
 class GraphEngine(FlatVectorOps):
     def __init__(self, kind, n_user, n_item, n_domain, batch_size, expert_hidden, tower_hidden, gate_hidden=(),
                  num_experts=0, shared_expert_num=0, specific_expert_num=0, dropout=0.5, emb_trainable=False, emb_dim=128,
-                 l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5):
+                 l2_emb=1e-5, device=None, dropout_seed=1024, l2_linear=1e-5, uncertainty_weight=False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("GraphEngine needs a HIP device (no CPU fallback)")
@@ -49,7 +49,7 @@ class GraphEngine(FlatVectorOps):
                             1 if emb_trainable else 0, len(expert_hidden), _arr4(expert_hidden), len(tower_hidden),
                             _arr4(tower_hidden), len(gate_hidden), _arr4(gate_hidden), int(num_experts),
                             int(shared_expert_num), int(specific_expert_num), float(dropout), float(l2_emb), 0.9, 0.999, 1e-8,
-                            float(l2_linear))
+                            float(l2_linear), 1 if uncertainty_weight else 0)
         handle = C.c_void_p()
         L.check(self.lib.mamdr_graph_create(C.byref(cfg), C.c_void_p(self.stream.cuda_stream), C.byref(handle)), graph=True)
         self.ctx = handle

@@ -122,11 +122,9 @@ class DeepCTR(BaseModel):
         # pretrained tables the column is built with deepctr's default (trainable) WHATEVER emb_trainable says
         self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
         if tower in GRAPH_TOWERS and not self.step_pnn:
-            if kw:
-                raise NotImplementedError("uncertainty weighting on the '%s' tower is not built" % tower)
             eng = factory(tower, self.n_uid, self.n_pid, self.n_domain, self.batch_size, expert_hidden=tuple(mc["hidden_dim"]),
                           tower_hidden=(), dropout=mc.get("dropout", 0.0), emb_trainable=self.tables_trainable,
-                          emb_dim=mc["user_dim"])
+                          emb_dim=mc["user_dim"], **kw)
         else:
             eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
                           emb_trainable=self.tables_trainable, tower=tower, emb_dim=mc["user_dim"],

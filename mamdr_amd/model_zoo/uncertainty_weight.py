@@ -14,6 +14,11 @@ class UncertaintyWeight(object):
     def __init__(self, base_model):
         self.base_model = base_model
         if "log_var" not in base_model.model.segments:
+            if hasattr(base_model.model, "task_ranges"):
+                # uncertainty_weight.py:41-45 takes `self.model.inputs` / `outputs[0]` of ONE compiled Keras model;
+                # DeepMTLCTR keeps a dict of per-domain models (deep_mtl_ctr.py:51-67): nothing to wrap
+                raise NotImplementedError("uncertainty weighting wraps a single-output tower; the multi-task towers are a "
+                                          "dict of per-domain models (deep_mtl_ctr.py:51-67)")
             raise ValueError("the tower was not built with the weighted loss (model name lacks 'uncertainty_weight')")
 
     def __getattr__(self, item):

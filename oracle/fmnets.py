@@ -144,10 +144,9 @@ class OracleNet(T.OracleModel):
         T.OracleModel.__init__(self, params, emb_trainable, dropout, lr, hidden, dropout_seed, "mlp", False)
         self.kind = kind
         self.conv = kind in ("ccpm", "autoint")
-        if uncertainty and self.conv:
-            raise NotImplementedError("uncertainty weighting is restated for nfm / pnn only")
         self.uncertainty = bool(uncertainty)
-        self.names = (ccpm_param_names(emb_trainable) if kind == "ccpm" else autoint_param_names(emb_trainable)) if self.conv \
+        self.names = (ccpm_param_names(emb_trainable, uncertainty) if kind == "ccpm"
+                      else autoint_param_names(emb_trainable, uncertainty)) if self.conv \
             else param_names(kind, emb_trainable, uncertainty)
         self.opt = T.Optimizer(params, self.names)
 
@@ -156,7 +155,7 @@ class OracleNet(T.OracleModel):
         masks = T.train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else None
         if self.conv:
             loss, g, _ = loss_and_grads_conv(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
-                                             self.frozen_sumsq())
+                                             self.frozen_sumsq(), self.uncertainty)
         else:
             loss, g, _ = loss_and_grads(self.params, self.kind, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
                                         self.frozen_sumsq(), self.uncertainty)
@@ -172,7 +171,7 @@ class OracleNet(T.OracleModel):
         total loss at the current weights added to `acc`, learning phase 0 (dropout off), no update."""
         if self.conv:
             _, g, _ = loss_and_grads_conv(self.params, self.kind, uid, pid, dom, label, None, 0.0, self.emb_trainable,
-                                          self.frozen_sumsq())
+                                          self.frozen_sumsq(), self.uncertainty)
         else:
             _, g, _ = loss_and_grads(self.params, self.kind, uid, pid, dom, label, None, 0.0, self.emb_trainable,
                                      self.frozen_sumsq(), self.uncertainty)
@@ -218,15 +217,16 @@ ATT_LAYERS, ATT_HEADS, ATT_DIM = 3, 4, 8
 ATT_OUT = ATT_HEADS * ATT_DIM          # 32
 
 
-def ccpm_param_names(emb_trainable):
+def ccpm_param_names(emb_trainable, uncertainty=False):
     emb = ("user_emb", "item_emb", "lin_user", "lin_item") if emb_trainable else ()
-    return emb + ("domain_emb", "conv1_w", "conv1_b", "conv2_w", "conv2_b") + T.DENSE_NAMES + ("lin_domain",)
+    return emb + ("domain_emb", "conv1_w", "conv1_b", "conv2_w", "conv2_b") + T.DENSE_NAMES + ("lin_domain",) + \
+        (("log_var",) if uncertainty else ())
 
 
-def autoint_param_names(emb_trainable):
+def autoint_param_names(emb_trainable, uncertainty=False):
     emb = ("user_emb", "item_emb", "lin_user", "lin_item") if emb_trainable else ()
     att = tuple("att%d_w" % l for l in range(ATT_LAYERS))
-    return emb + ("domain_emb",) + att + T.DENSE_NAMES + ("lin_domain",)
+    return emb + ("domain_emb",) + att + T.DENSE_NAMES + ("lin_domain",) + (("log_var",) if uncertainty else ())
 
 
 def init_params_conv(rs, kind, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64), pretrained=True):
@@ -354,16 +354,26 @@ def forward_conv(P, kind, uid, pid, dom, masks=None, keep_scale=F32(1)):
     return T.sigmoid(logit), c
 
 
-def loss_and_grads_conv(P, kind, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None):
+def loss_and_grads_conv(P, kind, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, uncertainty=False):
     B = uid.shape[0]
     E = P["domain_emb"].shape[1]
     keep_scale = F32(1.0 / (1.0 - rate)) if masks is not None else F32(1)
     p, c = forward_conv(P, kind, uid, pid, dom, masks, keep_scale)
     y = label.astype(F32)
-    loss = F32(np.mean(T.bce_per_row(p, y), dtype=np.float64)) + reg_loss(P, "nfm", frozen_sumsq)
+    mean_bce = F32(np.mean(T.bce_per_row(p, y), dtype=np.float64))
     inside = ((p >= T.EPS_CLIP) & (p <= F32(1) - T.EPS_CLIP)).astype(F32)
     dlogit = ((p - y) * inside / F32(B)).astype(F32)
     g = {}
+    if uncertainty:             # weighted_loss.py:30-43, as loss_and_grads above
+        d0 = int(dom[0])
+        var = P["log_var"][d0]
+        w = F32(F32(1) / F32(var * var))
+        loss = F32(w * mean_bce) + F32(np.log(var, dtype=F32)) + reg_loss(P, "nfm", frozen_sumsq)
+        dlogit = (dlogit * w).astype(F32)
+        g["log_var"] = np.zeros_like(P["log_var"])
+        g["log_var"][d0] = F32(F32(-2) * mean_bce / F32(var * var * var)) + F32(F32(1) / var)
+    else:
+        loss = mean_bce + reg_loss(P, "nfm", frozen_sumsq)
     g["wo"] = (c["top"].T @ dlogit[:, None]).astype(F32)
     g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
     dtop = (dlogit[:, None] * P["wo"][:, 0][None, :]).astype(F32)

@@ -132,7 +132,8 @@ def fmnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, 
     return float(loss.detach()), g, p.detach().numpy()
 
 
-def convnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64):
+def convnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None, rate=0.0, dtype=torch.float64,
+                           uncertainty=False):
     """deepctr CCPM / AutoInt (deepctr.py:37-43) in float64 autograd -- written with torch's own conv2d / softmax, not with
     the oracle's loops.  CCPM: Conv2D((6, 1), 'same', tanh) over the field axis (TF pads an even kernel 2 before / 3 after),
     max over the fields, Conv2D((5, 1)) on the remaining row = its centre tap, tanh, flatten [128 x 4], DNN, linear tables.
@@ -173,7 +174,11 @@ def convnet_loss_and_grads(params, names, kind, uid, pid, dom, label, masks=None
     reg = L2_EMB * (P["user_emb"].pow(2).sum() + P["item_emb"].pow(2).sum() + P["domain_emb"].pow(2).sum()) + \
         L2_LIN * (P["lin_user"].pow(2).sum() + P["lin_item"].pow(2).sum() + P["lin_domain"].pow(2).sum())
     p = torch.sigmoid(logit)
-    loss = keras_bce(p, y).mean() + reg
+    loss = keras_bce(p, y).mean()
+    if uncertainty:            # weighted_loss.py:30-43: mean(BCE) / var^2 + log var, var = log_var[dom[0]]
+        var = P["log_var"][int(dom[0])]
+        loss = loss / (var * var) + torch.log(var)
+    loss = loss + reg
     grads = torch.autograd.grad(loss, [P[n] for n in names], allow_unused=True)
     g = {n: (gr.numpy() if gr is not None else np.zeros(params[n].shape)) for n, gr in zip(names, grads)}
     return float(loss.detach()), g, p.detach().numpy()

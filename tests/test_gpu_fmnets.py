@@ -51,14 +51,13 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
         params["lin_user"][...] = 0
         params["lin_item"][...] = 0
     if uncertainty:            # distinct per-domain scales around the initial value 1 (weighted_loss.py:23-28)
-        assert step
         params["log_var"] = (1.0 + rs.uniform(-0.3, 0.3, D)).astype(F32)
     if step:
         eng = engine.TowerEngine(g["n_user"], g["n_item"], D, batch, dropout=dropout, emb_trainable=emb_trainable, tower=kind,
                                  uncertainty_weight=uncertainty)
     else:
         eng = graph_engine.GraphEngine(kind, g["n_user"], g["n_item"], D, batch, HIDDEN, (), dropout=dropout,
-                                       emb_trainable=emb_trainable)
+                                       emb_trainable=emb_trainable, uncertainty_weight=uncertainty)
     if not emb_trainable:
         eng.bind_table("user_emb", params["user_emb"])
         eng.bind_table("item_emb", params["item_emb"])
@@ -66,8 +65,9 @@ def make_problem(kind, batch=256, dropout=0.5, scale=0.05, seed=7, emb_trainable
         for d in range(D):
             c = g["data"][split][d]
             eng.bind_domain_data(d, split, c["uid"], c["pid"], c["domain"], c["label"])
-    names = list(ofm.ccpm_param_names(emb_trainable) if kind == "ccpm" else
-                 (ofm.autoint_param_names(emb_trainable) if kind == "autoint" else ofm.param_names(kind, emb_trainable, uncertainty)))
+    names = list(ofm.ccpm_param_names(emb_trainable, uncertainty) if kind == "ccpm" else
+                 (ofm.autoint_param_names(emb_trainable, uncertainty) if kind == "autoint"
+                  else ofm.param_names(kind, emb_trainable, uncertainty)))
     if step:            # (the step kernels keep the inner products' rows of W0 as a segment of their own, behind the rest)
         assert sorted(set(eng.segments) - {"W0x"}) == sorted(names), (list(eng.segments), names)
     else:
@@ -155,11 +155,12 @@ def test_step_kernel_towers_at_config_batch_sizes(kind, emb_trainable, batch):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["pnn@step", "nfm@step"])
+@pytest.mark.parametrize("kind", ["pnn@step", "nfm@step", "pnn", "nfm", "ccpm", "autoint"])
 def test_uncertainty_weighted_step_on_the_step_kernel_towers(kind):
     """run.py:49-50 wraps ANY tower in the weighted loss (weighted_loss.py:30-43); on the step kernels' PNN / NFM (round 4)
-    as on mlp / deepfm: every gradient scaled by 1 / var_d^2, d loss / d var_d, zero gradient for the other domains'
-    scalars, a few Adam steps, evaluation unweighted."""
+    as on mlp / deepfm, and on the generic-layer engine's single-output towers (CCPM, AutoInt, the PNN / NFM twins): every
+    gradient scaled by 1 / var_d^2, d loss / d var_d, zero gradient for the other domains' scalars, a few Adam steps
+    (without a loss output: the scalar's gradient must not depend on one), evaluation unweighted."""
     g, eng, model = make_problem(kind, batch=256, dropout=0.5, uncertainty=True)
     base = kind.split("@")[0]
     assert eng.segments["log_var"][1] == 10 and model.names[-1] == "log_var"
@@ -172,8 +173,9 @@ def test_uncertainty_weighted_step_on_the_step_kernel_towers(kind):
     for step in (0, n_step - 1):
         idx = perm[step * 256:(step + 1) * 256]
         masks = otower.train_masks(model.seed, model.step, len(idx), HIDDEN, 0.5)
-        loss, grads, _ = ofm.loss_and_grads(model.params, base, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
-                                            cols["label"][idx], masks, 0.5, False, model.frozen_sumsq(), True)
+        fn = ofm.loss_and_grads_conv if base in ("ccpm", "autoint") else ofm.loss_and_grads
+        loss, grads, _ = fn(model.params, base, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
+                            cols["label"][idx], masks, 0.5, False, model.frozen_sumsq(), True)
         loss_t = torch.zeros(1, device=eng.device)
         w0 = eng.get_weights()
         eng.train_steps(d, perm=perm_t, first_step=step, n_steps=1, lr=1.0, optimizer="sgd", loss_out=loss_t)

@@ -349,7 +349,7 @@ def test_run_multitask_configs_on_gpu(tmp_path, cfg_file):
 
 
 @pytest.mark.parametrize("name", ["wdl", "nfm_meta_mamdr_finetune", "pnn_meta_domain_negotiation", "ccpm_meta_reptile",
-                                  "autoint", "autoint_meta_maml"])
+                                  "autoint", "autoint_meta_maml", "ccpm_uncertainty_weight", "autoint_uncertainty_weight"])
 def test_run_other_deepctr_towers_on_gpu(tmp_path, name):
     """deepctr.py:24-50's registry beyond mlp / deepfm, under the wrappers of run.py:37-85 (the tower and the wrapper are
     orthogonal substrings of the model name)."""

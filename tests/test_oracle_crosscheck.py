@@ -244,9 +244,10 @@ def test_nfm_pnn_gradients_vs_float64_autograd(kind, emb_trainable, rate, uncert
     _check_grads(g, g64, names)
 
 
-@pytest.mark.parametrize("kind,emb_trainable,rate", [("ccpm", False, 0.5), ("ccpm", True, 0.0), ("autoint", False, 0.5),
-                                                      ("autoint", True, 0.5)])
-def test_ccpm_autoint_gradients_vs_float64_autograd(kind, emb_trainable, rate):
+@pytest.mark.parametrize("kind,emb_trainable,rate,uncertainty", [
+    ("ccpm", False, 0.5, False), ("ccpm", True, 0.0, False), ("autoint", False, 0.5, False), ("autoint", True, 0.5, False),
+    ("ccpm", False, 0.5, True), ("autoint", True, 0.5, True)])
+def test_ccpm_autoint_gradients_vs_float64_autograd(kind, emb_trainable, rate, uncertainty):
     """oracle/fmnets.py's CCPM (convolution over the field axis, max over the fields, tanh) and AutoInt (three multi-head
     self-attention layers with residuals) -- hand-derived fp32 backward passes -- against float64 autograd of a forward
     written with torch's own conv2d / softmax."""
@@ -266,11 +267,14 @@ def test_ccpm_autoint_gradients_vs_float64_autograd(kind, emb_trainable, rate):
         for l in range(3):                         # larger kernels: the softmax is off its uniform point
             p["att%d_w" % l] = (p["att%d_w" % l] * 8).astype(F32)
     p["gb"] = np.array([0.1], F32)
-    names = list(ofm.ccpm_param_names(emb_trainable) if kind == "ccpm" else ofm.autoint_param_names(emb_trainable))
-    uid, pid, dom, label = _batch(rs, n_user, n_item, D, B)
+    names = list(ofm.ccpm_param_names(emb_trainable, uncertainty) if kind == "ccpm"
+                 else ofm.autoint_param_names(emb_trainable, uncertainty))
+    if uncertainty:            # distinct per-domain scales around the initial value 1 (weighted_loss.py:23-28)
+        p["log_var"] = (1.0 + rs.uniform(-0.3, 0.3, D)).astype(F32)
+    uid, pid, dom, label = _batch(rs, n_user, n_item, D, B, single_domain=2 if uncertainty else None)
     masks = otower.train_masks(1024, 3, B, (16, 8, 4), rate) if rate > 0 else None
-    loss, g, pred = ofm.loss_and_grads_conv(p, kind, uid, pid, dom, label, masks, rate, emb_trainable)
-    loss64, g64, pred64 = tref.convnet_loss_and_grads(p, names, kind, uid, pid, dom, label, masks, rate)
+    loss, g, pred = ofm.loss_and_grads_conv(p, kind, uid, pid, dom, label, masks, rate, emb_trainable, None, uncertainty)
+    loss64, g64, pred64 = tref.convnet_loss_and_grads(p, names, kind, uid, pid, dom, label, masks, rate, uncertainty=uncertainty)
     assert abs(float(loss) - loss64) < 2e-6 * max(1.0, abs(loss64))
     np.testing.assert_allclose(pred, pred64, rtol=2e-5, atol=2e-7)
     assert sorted(g) == sorted(names)
