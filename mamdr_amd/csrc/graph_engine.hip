@@ -399,6 +399,90 @@ __global__ __launch_bounds__(256) void k_graph_wfinish_group(const float* part, 
         db[t.bias_off[gi] + col] = v;
     }
 }
+// ---- every weight gradient of a step in ONE launch.  dW_l = in_l^T dz_l needs nothing but the activations and the d z's,
+// which stay in the workspaces until the step ends: the backward pass runs its chain of d-input contractions first and
+// queues the weight gradients (host: queue_wgrad / flush_wgrads); here a flat grid walks the queue -- workgroup ->
+// (problem, tile, split of the batch rows) through the prefix table -- so that 90 tiles of four layers (shared_bottom) or of
+// an expert group + gate + tower share the 256 CUs instead of following one another in 2 launches per layer.
+constexpr int MAX_WQ = 40;
+struct WMulti {
+    int n;
+    int first[MAX_WQ + 1];          // first workgroup of problem p
+    const float* A[MAX_WQ]; const float* B[MAX_WQ]; float* C[MAX_WQ];       // C: the partial products' base, or dW itself (split 1)
+    int lda[MAX_WQ], ldb[MAX_WQ], N[MAX_WQ], tx[MAX_WQ], ty[MAX_WQ], K[MAX_WQ];     // K = batch rows per split
+    int mn[MAX_WQ];                 // M x N (stride between the splits' partial products)
+};
+__global__ __launch_bounds__(256) void k_graph_wgrad_multi(const WMulti t) {
+    int p = 0;
+    while (p + 1 < t.n && (int)blockIdx.x >= t.first[p + 1]) ++p;
+    int b = (int)blockIdx.x - t.first[p];
+    const int tiles = t.tx[p] * t.ty[p];
+    const int bz = b / tiles;
+    b -= bz * tiles;
+    const int by = b / t.tx[p], bx = b - by * t.tx[p];
+    GemmArgs a;
+    a.A = t.A[p];
+    a.lda = t.lda[p];
+    a.B = t.B[p];
+    a.ldb = t.ldb[p];
+    a.C = t.C[p];
+    a.ldc = t.N[p];
+    a.K = t.K[p];
+    a.zstride = (size_t)t.mn[p];
+    gemm_tile<2>(a, bx, by, bz);
+}
+// ... and their ends: per problem, the workgroups that add the splits' partial products in a fixed order, then the ones
+// that sum the columns of d z into the bias gradient (k_graph_wfinish's two halves, the queue's problems side by side)
+struct WFinish {
+    int n;
+    int first[MAX_WQ + 1];
+    const float* part[MAX_WQ]; float* out[MAX_WQ]; const float* dz[MAX_WQ]; float* db[MAX_WQ];
+    int split[MAX_WQ], nb_red[MAX_WQ], N[MAX_WQ], rows[MAX_WQ], ld[MAX_WQ], mn[MAX_WQ];
+};
+__global__ __launch_bounds__(256) void k_graph_wfinish_multi(const WFinish t) {
+    int p = 0;
+    while (p + 1 < t.n && (int)blockIdx.x >= t.first[p + 1]) ++p;
+    const int bi = (int)blockIdx.x - t.first[p];
+    if (bi < t.nb_red[p]) {
+        const int64_t i = (int64_t)bi * 256 + threadIdx.x;
+        if (i >= t.mn[p] / 4) return;
+        const float* part = t.part[p];
+        const size_t stride = (size_t)t.mn[p];
+        f32x4 v0 = reinterpret_cast<const f32x4*>(part)[i];
+        for (int z = 1; z < t.split[p]; ++z) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(part + z * stride)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v0[k] += v[k];
+        }
+        reinterpret_cast<f32x4*>(t.out[p])[i] = v0;
+        return;
+    }
+    __shared__ float red[CS_GROUPS][CS_COLS + 1];
+    const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
+    const int col = (bi - t.nb_red[p]) * CS_COLS + c;
+    const int rows = t.rows[p], ld = t.ld[p];
+    float s = 0.f;
+    if (col < t.N[p]) {
+        const float* q = t.dz[p] + col;
+        int b = g;
+        for (; b + 7 * CS_GROUPS < rows; b += 8 * CS_GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q[(size_t)(b + k * CS_GROUPS) * ld];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < rows; b += CS_GROUPS) s += q[(size_t)b * ld];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && col < t.N[p]) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_GROUPS; ++k) v += red[k][c];
+        t.db[p][col] = v;
+    }
+}
 // d x of a group's first layers: out[b][c] (+)= sum over the members of part[e][b][c], in member order
 __global__ __launch_bounds__(256) void k_graph_dx_reduce(const float* part, int n_part, size_t stride, int rows, int n4_row,
                                                          float* out, int ld, int accumulate) {
@@ -1148,6 +1232,12 @@ struct mamdr_graph {
     float* dxpart = nullptr;    // the members' products of a group's first-layer d x (dnn_backward_group)
     size_t dxpart_floats = 0;
     bool group_ok = true;       // MAMDR_GRAPH_NO_GROUP=1: one launch per expert and layer (A/B, parity of the grouped launches)
+    // the step's weight gradients, queued by the backward pass and run in ONE pair of launches at its end (flush_wgrads);
+    // MAMDR_GRAPH_NO_DEFER=1: a pair of launches per layer, where the backward pass meets it (A/B)
+    struct WProb { const float* A; int lda; const float* B; int ldb; float* out; int M, N, rows; const float* dz; float* db; };
+    std::vector<WProb> wq;
+    bool defer_w = true;
+    int wq_blocks = 512;        // the queue's launch splits the batch rows until it has about this many workgroups
     int32_t* domrow = nullptr;
     float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
     // trainable tables
@@ -1188,7 +1278,79 @@ int add_dnn(mamdr_graph* g, const std::string& name, int in_dim, const int32_t* 
 // dW[M x N] = A[rows x M]^T . B[rows x N], the rows split over up to 16 workgroups per tile when the tiles alone leave
 // most of the 256 CUs idle (a 384 x 512 kernel is 48 tiles); the partial products meet in k_graph_wfinish, which also
 // carries the layer's bias gradient (column sums of `dz` into `db`, skipped when db is null)
+void flush_wgrads(mamdr_graph* g) {
+    const int n = (int)g->wq.size();
+    if (!n) return;
+    int tiles = 0;
+    for (const auto& q : g->wq) tiles += (q.M / GT) * (q.N / GT);
+    int S = 1;
+    while (S < 16 && tiles * S < g->wq_blocks) S *= 2;
+    int split[MAX_WQ];
+    for (;; S /= 2) {       // per problem: the largest power of two <= S that leaves every split >= 4 k-tiles; all must fit
+        size_t need = 0;
+        for (int p = 0; p < n; ++p) {
+            const auto& q = g->wq[p];
+            const int nkt = q.rows / GK;
+            int sp = 1;
+            while (sp < S && nkt % (2 * sp) == 0 && nkt / (2 * sp) >= 4) sp *= 2;
+            split[p] = sp;
+            if (sp > 1) need += (size_t)sp * q.M * q.N;
+        }
+        if (need <= g->wpart_floats || S == 1) break;
+    }
+    WMulti m;
+    WFinish f;
+    memset(&m, 0, sizeof(m));
+    memset(&f, 0, sizeof(f));
+    m.n = f.n = n;
+    size_t used = 0;
+    int nb = 0, nf = 0;
+    for (int p = 0; p < n; ++p) {
+        const auto& q = g->wq[p];
+        const int sp = split[p];
+        float* part = g->wpart + used;
+        if (sp > 1) used += (size_t)sp * q.M * q.N;
+        m.first[p] = nb;
+        m.A[p] = q.A;
+        m.lda[p] = q.lda;
+        m.B[p] = q.B;
+        m.ldb[p] = q.ldb;
+        m.C[p] = sp > 1 ? part : q.out;
+        m.N[p] = q.N;
+        m.tx[p] = q.N / GT;
+        m.ty[p] = q.M / GT;
+        m.K[p] = q.rows / sp;
+        m.mn[p] = q.M * q.N;
+        nb += m.tx[p] * m.ty[p] * sp;
+        f.first[p] = nf;
+        f.part[p] = part;
+        f.out[p] = q.out;
+        f.dz[p] = q.dz;
+        f.db[p] = q.db;
+        f.split[p] = sp;
+        f.nb_red[p] = sp > 1 ? (q.M * q.N / 4 + 255) / 256 : 0;
+        f.N[p] = q.db ? q.N : 0;
+        f.rows[p] = q.rows;
+        f.ld[p] = g->ld;
+        f.mn[p] = q.M * q.N;
+        nf += f.nb_red[p] + (q.db ? (q.N + CS_COLS - 1) / CS_COLS : 0);
+    }
+    m.first[n] = nb;
+    f.first[n] = nf;
+    GLAUNCH(k_graph_wgrad_multi, dim3(nb), dim3(256), 0, g->stream, m);
+    if (nf) GLAUNCH(k_graph_wfinish_multi, dim3(nf), dim3(256), 0, g->stream, f);
+    g->wq.clear();
+}
+void queue_wgrad(mamdr_graph* g, const float* A, int lda, const float* B, int ldb, float* out, int M, int N, int rows,
+                 const float* dz, float* db) {
+    if ((int)g->wq.size() == MAX_WQ) flush_wgrads(g);
+    g->wq.push_back(mamdr_graph::WProb{A, lda, B, ldb, out, M, N, rows, dz, db});
+}
 void launch_wgrad(mamdr_graph* g, GemmArgs a, int M, int N, int rows, const float* dz, float* db) {
+    if (g->defer_w) {
+        queue_wgrad(g, a.A, a.lda, a.B, a.ldb, a.C, M, N, rows, dz, db);
+        return;
+    }
     const int tiles = (M / GT) * (N / GT), nkt = rows / GK;
     int split = 1;
     while (split < 16 && tiles * split < 256 && nkt % (2 * split) == 0 && nkt / (2 * split) >= 4 &&
@@ -1355,7 +1517,13 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
     for (int l = (int)d0.layers.size() - 1; l >= 0; --l) {
         const Layer& L0 = d0.layers[l];
         const int M = L0.in, N = L0.out;
-        {   // dW_e = in_e^T dz_e, db_e = column sums of dz_e
+        if (g->defer_w) {
+            for (int e = 0; e < n; ++e) {
+                const Layer& L = g->dnns[ids[e]].layers[l];
+                queue_wgrad(g, g->act + (l == 0 ? in_col : cols[e][l - 1]), g->ld, g->dact + cols[e][l], g->ld, g->G(L.w_off), M, N,
+                            sc.rp, g->dact + cols[e][l], g->G(L.b_off));
+            }
+        } else {    // dW_e = in_e^T dz_e, db_e = column sums of dz_e
             const int tiles = (M / GT) * (N / GT), nkt = sc.rp / GK;
             int split = 1;
             while (split < 16 && tiles * n * split < 256 && nkt % (2 * split) == 0 && nkt / (2 * split) >= 4 &&
@@ -1677,6 +1845,8 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     g->cfg = *cfg;
     g->stream = (hipStream_t)stream;
     if (const char* ev = getenv("MAMDR_GRAPH_NO_GROUP")) g->group_ok = atoi(ev) == 0;
+    if (const char* ev = getenv("MAMDR_GRAPH_NO_DEFER")) g->defer_w = atoi(ev) == 0;
+    if (const char* ev = getenv("MAMDR_GRAPH_WQ_BLOCKS")) g->wq_blocks = atoi(ev) > 0 ? atoi(ev) : g->wq_blocks;
     g->gated = gated;
     g->single = single;
     g->has_lin = has_lin;
@@ -1811,6 +1981,16 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     for (const Dnn& d : g->dnns)
         for (const Layer& L : d.layers) max_w = std::max(max_w, (size_t)L.in * L.out);
     g->wpart_floats = 16 * max_w;
+    if (g->defer_w) {       // the queue holds every problem's partial products at once: 8 splits of the widest step's kernels
+        size_t max_path = 3 * (size_t)EMB * ATT_P;
+        for (const Task& t : g->tasks) {
+            size_t w = cfg->kind == MAMDR_GRAPH_AUTOINT ? 3 * (size_t)EMB * ATT_P : 0;
+            for (int id : t.path)
+                for (const Layer& L : g->dnns[id].layers) w += (size_t)L.in * L.out;
+            max_path = std::max(max_path, w);
+        }
+        g->wpart_floats = std::max(g->wpart_floats, 8 * max_path);
+    }
     alloc((void**)&g->wpart, g->wpart_floats * sizeof(float));
     size_t max_mix = 0;
     for (const Task& t : g->tasks) max_mix = std::max(max_mix, t.mix.size());
@@ -2034,6 +2214,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
     hipGraphExec_t dexec = nullptr;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
+        g->wq.clear();          // (a step that failed half-way leaves its queue behind)
         if (diag_replay && dexec && pass_rows - row_base >= batch) {
             (void)hipGraphLaunch(dexec, g->stream);
             g->global_step += 1;
@@ -2221,6 +2402,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
             dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
+        flush_wgrads(g);        // every layer's dW / db of this step: one pair of launches
         GLAUNCH(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
                            sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
         if (g->tables) {
