@@ -100,10 +100,30 @@ class FlatVectorOps(object):
     # "all_hidden" (everything behind the embedding tables)
     meta_off = 0
 
-    def set_meta_range(self, off, count):
+    # tensors INSIDE the meta range that are not meta parameters (a `meta_parms` name list that selects tensors which are
+    # no neighbours in the flat vector, maml.py:167-177): [(offset within the range, count)].  theta / phi / merged span
+    # the whole range; the slots of these tensors carry no meaning and `assign_meta` never lets them reach the model.
+    meta_holes = ()
+
+    def set_meta_range(self, off, count, holes=()):
         if off < 0 or count <= 0 or off + count > self.n_params:
             raise ValueError("meta range [%d, %d) outside the flat vector of %d floats" % (off, off + count, self.n_params))
+        for o, c in holes:
+            if o < 0 or c <= 0 or o + c > count:
+                raise ValueError("hole [%d, %d) outside the meta range of %d floats" % (o, o + c, count))
         self.meta_off, self.n_meta = int(off), int(count)
+        self.meta_holes = tuple((int(o), int(c)) for o, c in holes)
+
+    def assign_meta(self, vec):
+        """MAML._set_model_meta_parms (maml.py:181-187; SetVarOp over `model_meta_parms`): the meta parameters of the live
+        model := vec.  Every other variable keeps training where it is -- the tensors between two selected ones first
+        take their live values into `vec`, then the range is assigned in one copy."""
+        if vec.numel() != self.n_meta:
+            raise ValueError("assign_meta: %d values for %d meta parameters" % (vec.numel(), self.n_meta))
+        live = self.meta_weights
+        for o, c in self.meta_holes:
+            L.check(self.lib.mamdr_copy(_ptr(vec[o:o + c]), _ptr(live[o:o + c]), c, self._s()))
+        L.check(self.lib.mamdr_copy(_ptr(live), _ptr(vec), self.n_meta, self._s()))
 
     @property
     def meta_weights(self):
@@ -114,10 +134,13 @@ class FlatVectorOps(object):
         """one DR support step in a single pass: phi += (live - merged) * gamma; merged = theta (+|*) phi; and, for
         the next support, model := merged (mamdr.py:103-105,74) -- bit-identical to interp + merge + set_weights."""
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        holes = bool(self.meta_holes) and assign_model      # (the kernel's assignment would overwrite the tensors in between)
         # self.weights (not _weights): the live table rows must be brought up to the current Adam step before they
         # are read into phi / replaced by merged (include/mamdr_hip.h: sync before reading or replacing the state)
         L.check(self.lib.mamdr_dr_advance(_ptr(phi), _ptr(self.meta_weights), _ptr(merged), _ptr(theta), float(gamma), mode,
-                                          1 if assign_model else 0, phi.numel(), self._s()))
+                                          1 if (assign_model and not holes) else 0, phi.numel(), self._s()))
+        if holes:
+            self.assign_meta(merged)
 
     def sub(self, dst, a, b):
         L.check(self.lib.mamdr_sub(_ptr(dst), _ptr(a), _ptr(b), dst.numel(), self._s()))
@@ -400,8 +423,11 @@ class TowerEngine(FlatVectorOps):
         """FlatVectorOps.dr_advance on the context's live weights (mamdr_dr_advance_live): the library synchronises them
         itself, and a domain-table step the fused step path left pending is materialised inside the same launch."""
         mode = {"plus": L.MERGE_PLUS, "times": L.MERGE_TIMES}[method]
+        holes = bool(self.meta_holes) and assign_model
         L.check(self.lib.mamdr_dr_advance_live(self.ctx, _ptr(phi), _ptr(merged), _ptr(theta), float(gamma), mode,
-                                               1 if assign_model else 0, self.meta_off, phi.numel()))
+                                               1 if (assign_model and not holes) else 0, self.meta_off, phi.numel()))
+        if holes:
+            self.assign_meta(merged)
 
     def pregather(self, passes, batch_size=None):
         """hint (mamdr_pregather_passes): the next train_steps calls run these passes -- [(domain, perm device tensor or

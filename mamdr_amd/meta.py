@@ -109,13 +109,13 @@ def dn_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, meta_train_step=
     """target >= 0 (domain_negotiation.py:44-45,67,89-93): the target domain closes the inner sequence with an
     uncapped pass, and after the outer update the model (not theta) takes one more full pass over it."""
     trace = []
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     for d in seq:
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
     if target >= 0:
         run_pass(eng, target, perm_fn, batch_size, lr, trace, "dn")
     eng.interp(theta, eng.meta_weights, theta, meta_lr)     # theta += (theta~ - theta) * beta
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     if target >= 0:
         run_pass(eng, target, perm_fn, batch_size, lr, trace, "target")
     return trace
@@ -132,7 +132,7 @@ def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_varia
     for d in seq:
         if target >= 0 and d == target:
             continue
-        eng.set_weights(theta)
+        eng.assign_meta(theta)
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
         if target >= 0:
             run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
@@ -142,7 +142,7 @@ def reptile_epoch(eng, theta, seq, perm_fn, batch_size, lr, meta_lr, batch_varia
             eng.interp(theta, eng.meta_weights, theta, meta_lr)
     if batch_variant:
         eng.apply_accumulated(theta, acc, 0.0, meta_lr)
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     if target >= 0:
         run_pass(eng, target, perm_fn, batch_size, lr, trace, "target")
     return trace
@@ -187,7 +187,7 @@ def maml_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
         dm = d
         if meta_domain >= 0:
             dm, wm = meta_domain, None
-        eng.set_weights(theta)
+        eng.assign_meta(theta)
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "maml_train", meta_train_step, window=wt)
         run_pass(eng, dm, perm_fn, batch_size, lr, trace, "maml_meta", meta_train_step, optimizer="accumulate",
                  window=wm)
@@ -195,7 +195,7 @@ def maml_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
             outer.apply(eng, theta, acc, meta_lr, grad_scale)
     if batch_variant:
         outer.apply(eng, theta, acc, meta_lr, grad_scale)
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     return trace
 
 
@@ -210,24 +210,24 @@ def mldg_epoch(eng, theta, outer, acc, seq, perm_fn, batch_size, lr, meta_lr, ba
     trace = []
     for d in seq:
         wt, wm = windows[d] if windows else (None, None)
-        eng.set_weights(theta)
+        eng.assign_meta(theta)
         run_pass(eng, d, perm_fn, batch_size, lr, trace, "mldg_train", meta_train_step, optimizer="accumulate",
                  window=wt)
         live = eng.meta_weights.clone()
         outer.apply(eng, live, acc, meta_lr, grad_scale, clear=False)
-        eng.set_weights(live)
+        eng.assign_meta(live)
         dm = d
         if meta_domain >= 0:            # train.target_domain (mldg.py:339-341): the meta pass runs over the target domain
             dm, wm = meta_domain, None
         run_pass(eng, dm, perm_fn, batch_size, lr, trace, "mldg_meta", meta_train_step, optimizer="accumulate",
                  window=wm)
         if not batch_variant:
-            eng.set_weights(theta)
+            eng.assign_meta(theta)
             outer.apply(eng, theta, acc, meta_lr, grad_scale)
     if batch_variant:
-        eng.set_weights(theta)
+        eng.assign_meta(theta)
         outer.apply(eng, theta, acc, meta_lr, grad_scale)
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     return trace
 
 
@@ -259,7 +259,7 @@ def pcgrad_epoch(eng, outer, cur, aux, seq, aux_plan, perm_fn, batch_size, lr, m
             eng.pcgrad_project(cur, aux, tensors)
         live = eng.meta_weights.clone()
         outer.apply(eng, live, cur, meta_lr, grad_scale)
-        eng.set_weights(live)
+        eng.assign_meta(live)
     return trace
 
 
@@ -276,7 +276,7 @@ def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, 
     pw.announce([x for j in support for x in (j, query)])
     for k, j in enumerate(support):
         if not assigned:
-            eng.set_weights(merged)
+            eng.assign_meta(merged)
         pw.step()
         run_pass(eng, j, perm_fn, batch_size, lr, trace, "dr_support")
         pw.step()
@@ -297,7 +297,7 @@ def finetune_query(eng, theta, phi, query, perm_fn, batch_size, lr, trace, merge
     """train.finetune_every_epoch (mamdr.py:110-143): after a query domain's DR the merged model takes one
     full pass over that domain and phi := theta~ - merged (`_update_domain_weights`, mamdr.py:168-171)."""
     eng.merge(merged, theta, phi, merged_method)
-    eng.set_weights(merged)
+    eng.assign_meta(merged)
     run_pass(eng, query, perm_fn, batch_size, lr, trace, "dr_finetune")
     eng.sub(phi, eng.meta_weights, merged)
 
@@ -309,7 +309,7 @@ def mamdr_epoch(eng, theta, phis, plan, perm_fn, batch_size, lr, meta_lr, merged
     trace = []
     pw = PassWindow(eng, perm_fn, batch_size)
     # DN phase (mamdr.py:48-57)
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     pw.announce(plan["seq"])
     for d in plan["seq"]:
         pw.step()

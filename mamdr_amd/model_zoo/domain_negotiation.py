@@ -47,7 +47,7 @@ class DomainNegotiation(MAML):
                 parallel.dn_phase_sharded(self.model, meta, meta_weights, [d for d in meta_sequence if owner[d] == rank],
                                           self.shuffler, self.batch_size, self.learning_rate, tc["meta_learning_rate"],
                                           self.trace, delta, zero, tc["meta_train_step"], target)
-                self.model.set_weights(meta_weights)
+                self.model.assign_meta(meta_weights)
                 if target >= 0:        # domain_negotiation.py:89-93: the model (not theta) takes one more pass over the target
                     meta.run_pass(self.model, target, self.shuffler, self.batch_size, self.learning_rate, self.trace,
                                   "target")

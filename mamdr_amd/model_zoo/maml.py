@@ -39,32 +39,38 @@ class MAML(object):
                     raise ValueError("meta parms: {} not found in the model".format(name))
                 chosen += hit
             self.model_meta_parms = chosen
-        # theta / phi cover ONE contiguous range of the flat vector (alignment padding between two selected tensors aside):
-        # everything ("all"), the reference's Star filter (tables, kernel_shared, bias_shared;
-        # config/Taobao-10/star_taobao.json:37-41: the prefix the Star block is laid out for), "all_hidden" (everything
-        # behind the embedding tables), or any name list that selects neighbouring tensors.  Scattered sets are not built.
+        # theta / phi cover ONE contiguous range of the flat vector, from the first selected tensor to the last: everything
+        # ("all"), the reference's Star filter (tables, kernel_shared, bias_shared; config/Taobao-10/star_taobao.json:37-41:
+        # the prefix the Star block is laid out for), "all_hidden" (everything behind the embedding tables), any name list
+        # of neighbouring tensors.  A list that skips tensors in between (maml.py:167-177 allows any) keeps them as HOLES
+        # of the range: the outer updates run over them too, `assign_meta` never lets those slots reach the model, so
+        # the skipped tensors train on undisturbed -- as variables outside `model_meta_parms` do in the reference.
         segs = self.model.segments
         chosen = sorted(self.model_meta_parms, key=lambda n: segs[n][0])
         lo, hi = segs[chosen[0]][0], segs[chosen[0]][0] + segs[chosen[0]][1]
-        between = set()
+        holes = []
         for n in chosen[1:]:
             off, cnt = segs[n]
             # (a gap that holds no other tensor is layout: alignment padding, or the rows of the step kernels' W0 that the
             # NFM tower leaves unused -- zeros that the outer updates keep at zero)
-            between = set(k for k, (o, c) in segs.items() if hi <= o < off)
-            if off - hi > 3 and between:
-                raise NotImplementedError("meta_parms %s select tensors that are not neighbours in the flat vector (%s sit "
-                                          "between them): scattered meta sets are not built"
-                                          % (self.train_config["meta_parms"], sorted(between)))
+            between = sorted((o, c) for k, (o, c) in segs.items() if hi <= o < off)
+            if between:
+                holes.append((between[0][0] - lo, between[-1][0] + between[-1][1] - between[0][0]))
             hi = off + cnt
         if lo == 0 and hi >= self.model.n_params - 3:
             hi = self.model.n_params
-        if lo == 0 and getattr(self.model, "tower", "") == "star" and hi == self.model.n_meta:
+        if lo == 0 and not holes and getattr(self.model, "tower", "") == "star" and hi == self.model.n_meta:
             return                                  # the engine's own prefix (its default)
-        self.model.set_meta_range(lo, hi - lo)
+        if holes and not hasattr(self.model, "assign_meta"):
+            raise NotImplementedError("meta_parms %s select tensors that are not neighbours in the flat vector; this engine "
+                                      "has no assign_meta" % (self.train_config["meta_parms"],))
+        if holes:
+            self.model.set_meta_range(lo, hi - lo, holes)
+        else:
+            self.model.set_meta_range(lo, hi - lo)
 
     def _set_model_meta_parms(self, meta_weights):
-        self.model.set_weights(meta_weights)
+        self.model.assign_meta(meta_weights)
 
     def _get_meta_weights(self):
         return self.model.meta_weights.clone()

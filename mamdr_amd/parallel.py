@@ -121,7 +121,7 @@ def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_
     meta_train_step caps every pass (domain_negotiation.py:67); a target domain (:44-45,89-93) closes EVERY rank's
     sub-sequence with an uncapped pass -- each displacement then ends adapted to the target, as the single
     sequence's does -- and the caller runs the closing target pass on the updated model (identical on every rank)."""
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     for d in seq_local:
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
     if target >= 0:
@@ -148,7 +148,7 @@ def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, 
     for d in seq_local:
         if target >= 0 and d == target:
             continue
-        eng.set_weights(local)
+        eng.assign_meta(local)
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
         if target >= 0:
             meta.run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
@@ -160,7 +160,7 @@ def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, 
         eng.sub(delta_buf, local, theta)
         dist.all_reduce(delta_buf, op=dist.ReduceOp.SUM)
         eng.interp(theta, delta_buf, zero_buf, 1.0)
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     return trace
 
 
@@ -175,7 +175,7 @@ def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size
     for d in seq_local:
         if target >= 0 and d == target:
             continue
-        eng.set_weights(theta)
+        eng.assign_meta(theta)
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "reptile", meta_train_step)
         if target >= 0:           # reptile.py:82-85: one step on the target domain after every domain's pass
             meta.run_pass(eng, target, perm_fn, batch_size, lr, trace, "target_step", 1)
@@ -184,7 +184,7 @@ def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size
     if ws > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     eng.apply_accumulated(theta, acc, 0.0, meta_lr)
-    eng.set_weights(theta)
+    eng.assign_meta(theta)
     return trace
 
 
@@ -246,6 +246,9 @@ class TailSync(object):
 
     def __init__(self, eng):
         self.eng = eng
+        if getattr(eng, "meta_holes", ()) and world()[1] > 1:
+            raise NotImplementedError("multi-process runs do not support scattered meta_parms lists (tensors that are no "
+                                      "neighbours in the flat vector)")
         if getattr(eng, "meta_off", 0) and eng.n_meta != eng.n_params and world()[1] > 1:
             raise NotImplementedError("multi-process runs support meta parameters that form a prefix of the flat vector "
                                       "(\"all\", the Star filter); got the range [%d, %d)" % (eng.meta_off, eng.meta_off + eng.n_meta))
@@ -493,7 +496,7 @@ class BalancedMAMDR(object):
         if replicated and self.tail.active:
             self.tail.sync()            # the previous epoch's DR displacements of the tail, before DN moves it again
             wire += self.tail.floats() * 4
-        eng.set_weights(theta)
+        eng.assign_meta(theta)
         pw = meta.PassWindow(eng, perm_fn, batch_size)
         pw.announce(local["seq"])
         for d in local["seq"]:

@@ -63,8 +63,20 @@ class FakeEngine(object):
 
     meta_off = 0
 
-    def set_meta_range(self, off, count):
+    meta_holes = ()
+
+    def set_meta_range(self, off, count, holes=()):
         self.meta_off, self.n_meta = int(off), int(count)
+        self.meta_holes = tuple((int(o), int(c)) for o, c in holes)
+
+    def assign_meta(self, vec):
+        assert vec.numel() == self.n_meta
+        live = self.meta_weights
+        for o, c in self.meta_holes:
+            vec[o:o + c] = live[o:o + c]
+        full = self.oracle.get_flat()
+        full[self.meta_off:self.meta_off + self.n_meta] = vec.numpy()
+        self.oracle.set_flat(full)
 
     @property
     def meta_weights(self):
@@ -98,7 +110,7 @@ class FakeEngine(object):
         self.interp(phi, self.meta_weights, merged, gamma)
         self.merge(merged, theta, phi, method)
         if assign_model:
-            self.set_weights(merged)
+            self.assign_meta(merged)
 
     def sub(self, dst, a, b):
         dst.copy_(torch.from_numpy(oouter.mamdr_domain_weights(a.numpy(), b.numpy())))
@@ -318,3 +330,25 @@ class FakeFmEngine(FakeEngine):
 
 
 FakeEngine.graph = FakeFmEngine
+
+
+def _otower():
+    from oracle import tower
+    return tower
+
+
+class MetaSubset(object):
+    """an oracle model whose flat vector covers the CHOSEN tensors only: `model_meta_parms` of maml.py:167-177 under the
+    oracle's loops (get_flat = _get_meta_weights, set_flat = _set_model_meta_parms)."""
+
+    def __init__(self, model, names):
+        self.model, self.meta = model, list(names)
+
+    def __getattr__(self, k):
+        return getattr(self.model, k)
+
+    def get_flat(self):
+        return _otower().flatten(self.model.params, self.meta)
+
+    def set_flat(self, vec):
+        _otower().unflatten(vec, self.model.params, self.meta)

@@ -849,6 +849,107 @@ def test_mamdr_epoch_auc_parity(env):
     eng.close()
 
 
+@pytest.mark.parametrize("loop", ["dn", "mamdr"])
+def test_scattered_meta_parms_epochs_match_oracle(env, loop):
+    """`meta_parms` lists whose tensors are no neighbours in the flat vector (maml.py:167-177): theta / phi span the range
+    from the first selected tensor to the last, `assign_meta` leaves the tensors in between (holes) to the inner steps.
+    One DN epoch / one DN + DR epoch against the oracle's loops on a model whose flat vector is the chosen tensors alone
+    (tests/test_host_logic.py checks the same bit for bit on the CPU stand-in): equal traces, theta and every LIVE tensor
+    within the Adam bar of the steps taken since its last reset, per-domain val AUC within 1e-3."""
+    engine, synthetic = env
+    from fake_engine import MetaSubset
+    from mamdr_amd import meta
+    shape = dict(synthetic.SHAPES["taobao10"], n_domain=4)
+    g, eng, model = make_problem(env, scale=0.1, batch=256, dropout=0.5, shape=shape)
+    D = g["n_domain"]
+    chosen = ["domain_emb", "W1", "b1", "gb"]
+    segs = eng.segments
+    order = sorted(segs, key=lambda n: segs[n][0])
+    lo, hi = segs[chosen[0]][0], segs[chosen[-1]][0] + segs[chosen[-1]][1]
+    holes, run = [], None
+    for n in order:
+        o, c = segs[n]
+        if n in chosen:
+            if run:
+                holes.append((run[0] - lo, run[1] - run[0]))
+            run = None
+        else:
+            run = (run[0] if run else o, o + c)
+    assert len(holes) == 3 and lo == 0
+    eng.set_meta_range(lo, hi - lo, holes)
+    sub = MetaSubset(model, chosen)
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+
+    def make_perm_fn():
+        counter = [0]
+
+        def perm_fn(d):
+            counter[0] += 1
+            return orng.shuffle_perm(sizes[d], 10000, seed=2000 + counter[0])
+        return perm_fn
+
+    def to_dev(flat):           # chosen tensors -> a vector over the whole range (holes zero)
+        t = torch.zeros(hi - lo, dtype=torch.float32)
+        o = 0
+        for n in chosen:
+            off, cnt = segs[n]
+            t[off - lo:off - lo + cnt] = torch.from_numpy(flat[o:o + cnt])
+            o += cnt
+        return t.to(eng.device)
+
+    def from_dev(t):
+        h = t.cpu().numpy()
+        return np.concatenate([h[segs[n][0] - lo:segs[n][0] - lo + segs[n][1]] for n in chosen])
+
+    init = {k: v.copy() for k, v in model.params.items()}
+    theta_o = sub.get_flat().copy()
+    theta_g = to_dev(theta_o)
+    META_LR = 0.5
+    seq = [2, 0, 3, 1]
+    if loop == "dn":
+        trace_o = oloops.dn_epoch(sub, theta_o, g["data"]["train"], seq, make_perm_fn(), 256, META_LR)
+        trace_g = meta.dn_epoch(eng, theta_g, seq, make_perm_fn(), 256, 1e-3, META_LR)
+    else:
+        plan = {"seq": seq, "dr": [(2, [0, 3]), (0, [1, 2]), (3, [2, 1]), (1, [3, 0])]}
+        rs = np.random.RandomState(5)
+        phis_o = [(rs.standard_normal(theta_o.size) * 0.001).astype(F32) for _ in range(D)]
+        phis_g = [to_dev(p) for p in phis_o]
+        trace_o = oloops.mamdr_epoch(sub, theta_o, phis_o, g["data"]["train"], plan, make_perm_fn(), 256, META_LR)
+        trace_g = meta.mamdr_epoch(eng, theta_g, phis_g, plan, make_perm_fn(), 256, lr=1e-3, meta_lr=META_LR)
+    assert trace_g == trace_o
+    n_steps = sum(t[2] for t in trace_o)
+    got = eng.unpack(eng.get_weights())
+    th = from_dev(theta_g)
+    o = 0
+    for n in chosen:
+        cnt = segs[n][1]
+        assert_adam_close(th[o:o + cnt], theta_o[o:o + cnt], n_steps, 1e-3, "theta " + n, max_frac=2e-3)
+        o += cnt
+    for n in order:
+        if n in chosen:
+            continue
+        # a hole tensor was never reset: it is where the inner steps of the whole epoch took it -- far from its start
+        # (had an assignment reached it, it would sit at the start value or at an interpolation of it)
+        moved = float(np.abs(model.params[n] - init[n]).mean())
+        diff = float(np.abs(got[n].ravel() - model.params[n].ravel()).mean())
+        assert moved > 0 and diff < 0.05 * moved, (n, diff, moved)
+    if loop == "mamdr":
+        for d in range(D):
+            ph = from_dev(phis_g[d])
+            assert float(np.abs(ph - phis_o[d]).mean()) < 0.05 * float(np.abs(phis_o[d]).mean()), d
+    merged = eng.new_vector(meta=True) if hasattr(eng, "new_vector") else None
+    for d in range(D):
+        if loop == "mamdr":
+            eng.merge(merged, theta_g, phis_g[d], "plus")
+            eng.assign_meta(merged)
+            sub.set_flat(oouter.merge(theta_o, phis_o[d], "plus"))
+        _, auc_g = eng.evaluate(d, "val")
+        _, preds = model.evaluate(g["data"]["val"][d], 256)
+        auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
+        assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)
+    eng.close()
+
+
 # ------------------------------------------------------------------ MAML: accumulate mode + outer Adam
 def test_maml_epoch_matches_oracle(env):
     """first-order MAML epoch (maml.py:62-116): inner Adam pass, meta pass accumulating gradients with

@@ -42,6 +42,26 @@ def test_run_config_on_gpu(tmp_path, name):
     assert z["weights"].shape[0] == (n_dense + 3) // 4 * 4 and np.isfinite(z["weights"]).all()
 
 
+@pytest.mark.parametrize("name", ["mlp_meta_mamdr_finetune", "mlp_meta_domain_negotiation", "mlp_meta_maml"])
+def test_run_scattered_meta_parms_on_gpu(tmp_path, name):
+    """a `meta_parms` name list that skips tensors in between (maml.py:167-177 takes any list of name substrings): the
+    range of theta / phi carries them as holes that the assignments skip (engine.assign_meta)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mamdr_amd import cli
+    with open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
+        cfg = copy.deepcopy(json.load(f))
+    cfg["model"]["name"] = name
+    cfg["train"].update(epoch=3, patience=1, sample_num=2, meta_learning_rate=0.5, meta_parms=["sparse_emb_domain", "W1", "dense/bias"],
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    if "maml" in name:
+        cfg["train"]["meta_learning_rate"] = 0.003
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
+    avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg)
+    assert len(domain_auc) == 10 and np.isfinite(avg_loss)
+    assert avg_auc > 0.6, (name, avg_auc)
+
+
 def test_run_amazon6_deepfm_config_trainable_tables(tmp_path):
     """BASELINE config 3 (deepfm_meta_domain_negotiation, trainable 128-d tables, no pretraining) through
     run.py's entry, on a small synthetic slice instead of the 79 M-parameter Amazon-6 tables."""

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from fake_engine import FakeEngine
+from fake_engine import FakeEngine, MetaSubset
 from mamdr_amd import cli, meta, plan as mplan, synthetic
 from mamdr_amd.utils import dataset as mds
 from oracle import loops as oloops
@@ -651,13 +651,96 @@ def test_all_hidden_through_the_run_entry(tmp_path, monkeypatch, name):
     assert sorted(da) == [0, 1, 2] and np.isfinite(avg_loss) and 0.3 < avg_auc < 1.0
 
 
-def test_scattered_meta_parms_say_so(tmp_path, monkeypatch):
+@pytest.mark.parametrize("loop", ["dn", "reptile", "mamdr"])
+def test_scattered_meta_parms_follow_the_reference_semantics(loop):
+    """a `meta_parms` list whose tensors are no neighbours in the flat vector (maml.py:167-177 takes any list): theta / phi
+    span the range from the first selected tensor to the last, the tensors in between are HOLES that `assign_meta` never
+    writes -- they train on undisturbed, as variables outside `model_meta_parms` do in the reference.  Against the oracle's
+    loops on a model whose flat vector is the chosen tensors alone: identical bits in every tensor."""
+    from oracle import loops as oloops
+    g = small_gen()
+    sizes = {d: g["data"]["train"][d]["uid"].shape[0] for d in range(3)}
+    eng = FakeEngine(g["n_user"], g["n_item"], 3, 64, emb_dim=8, hidden=(16, 8, 4))
+    eng.bind_table("user_emb", g["tables"]["user_emb"])
+    eng.bind_table("item_emb", g["tables"]["item_emb"])
+    for d in range(3):
+        c = g["data"]["train"][d]
+        eng.bind_domain_data(d, "train", c["uid"], c["pid"], c["domain"], c["label"])
+    chosen = ["domain_emb", "W1", "b1", "gb"]
+    segs = eng.segments
+    order = sorted(segs, key=lambda n: segs[n][0])
+    lo, hi = segs[chosen[0]][0], segs[chosen[-1]][0] + segs[chosen[-1]][1]
+    holes, run = [], None
+    for n in order:             # maximal runs of unselected tensors inside [lo, hi)
+        o, c = segs[n]
+        if n in chosen or o < lo or o >= hi:
+            if run:
+                holes.append((run[0] - lo, run[1] - run[0]))
+            run = None
+        else:
+            run = (run[0] if run else o, o + c)
+    assert len(holes) == 3
+    eng.set_meta_range(lo, hi - lo, holes)
+    ref = otower.OracleModel({k: v.copy() for k, v in eng.oracle.params.items()}, emb_trainable=False, dropout=eng.oracle.rate,
+                             lr=1e-3, hidden=(16, 8, 4), dropout_seed=eng.oracle.seed)
+    sub = MetaSubset(ref, chosen)
+    data = {d: g["data"]["train"][d] for d in range(3)}
+    sh = [mplan.PassShuffler(sizes, 10000, 9, shuffle_fn=orng.shuffle_perm) for _ in range(2)]
+    theta = eng.meta_weights.clone()
+    theta_o = sub.get_flat()
+    seq = [2, 0, 1]
+    if loop == "dn":
+        tr = meta.dn_epoch(eng, theta, seq, sh[0], 64, 1e-3, 0.5)
+        tr_o = oloops.dn_epoch(sub, theta_o, data, seq, sh[1], 64, 0.5)
+    elif loop == "reptile":
+        tr = meta.reptile_epoch(eng, theta, seq, sh[0], 64, 1e-3, 0.5)
+        tr_o = oloops.reptile_epoch(sub, theta_o, data, seq, sh[1], 64, 0.5)
+    else:
+        plan = {"seq": seq, "dr": [(0, [1, 2]), (2, [0, 1]), (1, [2, 0])]}
+        rs = np.random.RandomState(3)
+        phis_o = [(rs.standard_normal(theta_o.size) * 1e-3).astype(np.float32) for _ in range(3)]
+        phis = []
+        for p in phis_o:
+            t = torch.zeros_like(theta)
+            o = 0
+            for n in chosen:
+                off, cnt = segs[n]
+                t[off - lo:off - lo + cnt] = torch.from_numpy(p[o:o + cnt])
+                o += cnt
+            phis.append(t)
+        tr = meta.mamdr_epoch(eng, theta, phis, plan, sh[0], 64, 1e-3, 0.5)
+        tr_o = oloops.mamdr_epoch(sub, theta_o, phis_o, data, plan, sh[1], 64, 0.5)
+    assert tr == tr_o
+    live, want = eng.oracle.params, ref.params
+    for n in order:
+        np.testing.assert_array_equal(live[n], want[n], err_msg=n)
+    o = 0
+    for n in chosen:            # theta of the chosen tensors, bit for bit
+        off, cnt = segs[n]
+        np.testing.assert_array_equal(theta.numpy()[off - lo:off - lo + cnt], theta_o[o:o + cnt], err_msg=n)
+        o += cnt
+    if loop == "mamdr":
+        for k in range(3):
+            o = 0
+            for n in chosen:
+                off, cnt = segs[n]
+                np.testing.assert_array_equal(phis[k].numpy()[off - lo:off - lo + cnt], phis_o[k][o:o + cnt], err_msg=n)
+                o += cnt
+
+
+def test_scattered_meta_parms_through_the_run_entry(tmp_path, monkeypatch):
     patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "mlp_meta_domain_negotiation", epochs=2)
+    cfg["train"]["meta_parms"] = ["W0", "b2"]                 # W1, W2, b0, b1 sit between them: one hole
+    avg_loss, avg_auc, _, da = cli.main(cfg, FakeEngine)
+    assert np.isfinite(avg_loss) and sorted(da) == [0, 1, 2]
+    for name in ("mlp_meta_mamdr", "mlp_meta", "mlp_pcgrad"):
+        cfg = tiny_config(tmp_path, name, epochs=2)
+        cfg["train"]["meta_parms"] = ["domain_emb", "W1", "gb"]
+        avg_loss, avg_auc, _, da = cli.main(cfg, FakeEngine)
+        assert np.isfinite(avg_loss) and sorted(da) == [0, 1, 2]
     cfg = tiny_config(tmp_path, "mlp_meta_domain_negotiation", epochs=1)
-    cfg["train"]["meta_parms"] = ["W0", "b2"]                 # W1, W2, b0, b1 sit between them
-    with pytest.raises(NotImplementedError, match="neighbours"):
-        cli.main(cfg, FakeEngine)
-    cfg["train"]["meta_parms"] = ["W1", "W2"]                 # neighbours: fine
+    cfg["train"]["meta_parms"] = ["W1", "W2"]                 # neighbours: no hole
     avg_loss, avg_auc, _, da = cli.main(cfg, FakeEngine)
     assert np.isfinite(avg_loss) and sorted(da) == [0, 1, 2]
 
