@@ -285,6 +285,139 @@ __global__ __launch_bounds__(256) void k_graph_gemm_group(GemmArgs a, const Grou
     gemm_tile<MODE>(a, blockIdx.x, by, bz);
 }
 
+// ---- the same contractions (MODE 0 / 1) on 32 x 32 tiles with the reduction index split over the workgroup's four waves.
+// A 1,024-row layer of 512 / 256 / 128 / 64 units is 128 / 64 / 32 / 16 tiles of 64 x 64: half to a sixteenth of the 256
+// CUs, each walking a serial chain of K / 2 `32x32x2` MFMAs per wave behind one staged 16-deep tile per round trip
+// (12.6 us per launch on the Taobao-10 multi-task configs, profiles/r04g_*).  Here a workgroup owns a 32 x 32 tile
+// (4 x the workgroups), stages T32_K = 128 reduction indices per round trip (4 + 4 float4 loads in flight per thread, the
+// next stage requested before this one's MFMAs) and every wave contracts its own 32 of them into a full-tile accumulator:
+// the MFMA chain per wave is K / 8 long.  The four partial tiles meet in LDS in wave order (fixed: bit-stable), and the
+// epilogue runs on 4 neighbouring outputs per thread.  K needs no multiple of 128: the tail is staged as zeros.
+constexpr int T32 = 32, T32_K = 128, T32_LD = 36;
+template <int MODE, bool KCAT = false>
+__device__ __forceinline__ void gemm_tile32(const GemmArgs& a, const int bx, const int by, const GroupTab* tab = nullptr) {
+    __shared__ __attribute__((aligned(16))) float As[T32_K * T32_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[T32_K * T32_LD];
+    static_assert(MODE == 0 || MODE == 1, "weight gradients keep the 64 x 64 tiles");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = by * T32, n0 = bx * T32;
+    constexpr bool B_KC = MODE == 1;
+    const int r8 = tid >> 3, q8 = tid & 7;          // k-contiguous operand: tile row r8, float4s q8 + 8 j of its 128 k's
+    f32x4 ra[4], rb[4];
+    const float *A = a.A, *B = a.B;
+    const int nk = (a.K + T32_K - 1) / T32_K;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int kt) {
+        int k0 = kt * T32_K;
+        if (KCAT) {
+            const int e = kt / nk;
+            k0 = (kt - e * nk) * T32_K;
+            A = a.A + tab->a_off[e];
+            B = a.B + tab->b_off[e];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 4 * (q8 + 8 * j);
+            ra[j] = k < a.K ? *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + r8) * a.lda + k) : zero;
+            if (B_KC) {
+                rb[j] = k < a.K ? *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + r8) * a.ldb + k) : zero;
+            } else {            // B [K x N]: k row r8 + 32 j, float4 q8 of the tile's 32 columns
+                const int kr = k0 + r8 + 32 * j;
+                rb[j] = kr < a.K ? *reinterpret_cast<const f32x4*>(B + (size_t)kr * a.ldb + n0 + 4 * q8) : zero;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * (q8 + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[(k + i) * T32_LD + r8] = ra[j][i];
+            if (B_KC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[(k + i) * T32_LD + r8] = rb[j][i];
+            } else {
+                *reinterpret_cast<f32x4*>(&Bs[(r8 + 32 * j) * T32_LD + 4 * q8]) = rb[j];
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nkt = KCAT ? nk * tab->n : nk;
+    const int kk = lane >> 5, c = lane & 31;
+    gload(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nkt) gload(kt + 1);
+        const float* ap = &As[(32 * w + kk) * T32_LD + c];
+        const float* bp = &Bs[(32 * w + kk) * T32_LD + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = MAMDR_MFMA32(ap[2 * i * T32_LD], bp[2 * i * T32_LD], acc);
+        __syncthreads();
+    }
+    // the waves' partial tiles -> LDS (D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float* red = As;            // (the A stage is free after the loop's last barrier)
+    static_assert(4 * 32 * 33 <= T32_K * T32_LD, "the partial tiles fit the A stage");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(w * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 33 + c] = acc[r];
+    __syncthreads();
+    const int row = m0 + r8, col = n0 + 4 * q8;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = red[(0 * 32 + r8) * 33 + 4 * q8 + j];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) t += red[(ww * 32 + r8) * 33 + 4 * q8 + j];
+        v[j] = t;
+    }
+    float* cp = a.C + (size_t)row * a.ldc + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = v[j];
+        if (MODE == 0) {
+            for (int e = 0; e < a.n_xe; ++e) x = fmaf(a.xe[(size_t)row * a.xe_ld + e], a.we[(size_t)e * a.n_cols + col + j], x);
+            if (a.bias) x += a.bias[col + j];
+            if (a.relu) x = fmaxf(x, 0.f);
+            if (a.use_dropout) {
+                const uint32_t u = mamdr_dropout_u32(a.drop_key, (uint32_t)row * (uint32_t)a.n_cols + (uint32_t)(col + j));
+                x = u >= a.drop_thresh ? x * a.keep_scale : 0.f;
+            }
+        } else {
+            if (a.gate_y) x = a.gate_y[(size_t)row * a.gate_ld + col + j] > 0.f ? x * a.gate_scale : 0.f;
+            if (a.accumulate) x += cp[j];
+        }
+        v[j] = x;
+    }
+    if ((reinterpret_cast<uintptr_t>(cp) & 15) == 0) {
+        *reinterpret_cast<f32x4*>(cp) = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cp[j] = v[j];
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_graph_gemm32(const GemmArgs a) {
+    gemm_tile32<MODE>(a, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void k_graph_gemm32_kcat(const GemmArgs a, const GroupTab t) {
+    gemm_tile32<1, true>(a, blockIdx.x, blockIdx.y, &t);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_graph_gemm32_group(GemmArgs a, const GroupTab t) {
+    const int gi = blockIdx.z;
+    a.A += t.a_off[gi];
+    a.B += t.b_off[gi];
+    a.C += t.c_off[gi];
+    if (MODE == 0) {
+        a.bias += t.bias_off[gi];
+        a.drop_key = t.drop_key[gi];
+    }
+    if (MODE == 1 && a.gate_y) a.gate_y += t.gate_off[gi];
+    gemm_tile32<MODE>(a, blockIdx.x, blockIdx.y);
+}
+
 // db[n] = sum over the batch rows of dz[b][n]: 16 columns per workgroup, 16 row groups (8 loads in flight each) summed
 // through LDS in a fixed order
 constexpr int CS_COLS = 16, CS_GROUPS = 16;
@@ -1368,8 +1501,17 @@ void launch_wgrad(mamdr_graph* g, GemmArgs a, int M, int N, int rows, const floa
                            nb_red, dz, g->ld, rows, db, N);
 }
 
+// 32 x 32 tiles (gemm_tile32) while the 64 x 64 ones would leave CUs idle or nearly so; MAMDR_GRAPH_TILE32_BELOW=<tiles> (0: never)
+int g_tile32_below = 512;
+inline bool use_tile32(int M, int N, int n_group = 1) { return (M / GT) * (N / GT) * n_group < g_tile32_below && N % T32 == 0; }
 void launch_gemm(int mode, const GemmArgs& a, int M, int N, hipStream_t s) {
     const dim3 grid(N / GT, M / GT), block(256);
+    if (mode != 2 && use_tile32(M, N)) {
+        const dim3 g32(N / T32, M / T32);
+        if (mode == 0) GLAUNCH(k_graph_gemm32<0>, g32, block, 0, s, a);
+        else GLAUNCH(k_graph_gemm32<1>, g32, block, 0, s, a);
+        return;
+    }
     if (mode == 0) GLAUNCH(k_graph_gemm<0>, grid, block, 0, s, a);
     else if (mode == 1) GLAUNCH(k_graph_gemm<1>, grid, block, 0, s, a);
     else GLAUNCH(k_graph_gemm<2>, grid, block, 0, s, a);
@@ -1505,7 +1647,10 @@ void dnn_forward_group(mamdr_graph* g, const std::vector<int>& ids, const std::v
             t.bias_off[e] = L.b_off;
             t.drop_key[e] = dropout_layer_key(sc.seed, sc.step, L.id);
         }
-        GLAUNCH(k_graph_gemm_group<0>, dim3(L0.out / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+        if (use_tile32(sc.rp, L0.out, n))
+            GLAUNCH(k_graph_gemm32_group<0>, dim3(L0.out / T32, sc.rp / T32, n), dim3(256), 0, g->stream, a, t);
+        else
+            GLAUNCH(k_graph_gemm_group<0>, dim3(L0.out / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
     }
 }
 // backward of the group (every member's last-layer d z sits in the gradient workspace): weight / bias gradients and the
@@ -1582,7 +1727,10 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                 t.c_off[e] = cols[e][l - 1];
                 t.gate_off[e] = cols[e][l - 1];
             }
-            GLAUNCH(k_graph_gemm_group<1>, dim3(M / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+            if (use_tile32(sc.rp, M, n))
+                GLAUNCH(k_graph_gemm32_group<1>, dim3(M / T32, sc.rp / T32, n), dim3(256), 0, g->stream, a, t);
+            else
+                GLAUNCH(k_graph_gemm_group<1>, dim3(M / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
         } else {
             // d x = sum_e dz_e W_e[first : first + nn]^T
             const int first = din_n > 0 ? din_first : 0, nn = din_n > 0 ? din_n : M;
@@ -1607,7 +1755,10 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                     t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
                     t.c_off[e] = (int64_t)e * stride;
                 }
-                GLAUNCH(k_graph_gemm_group<1>, dim3(nn / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
+                if (use_tile32(sc.rp, nn, n))
+                    GLAUNCH(k_graph_gemm32_group<1>, dim3(nn / T32, sc.rp / T32, n), dim3(256), 0, g->stream, a, t);
+                else
+                    GLAUNCH(k_graph_gemm_group<1>, dim3(nn / GT, sc.rp / GT, n), dim3(256), 0, g->stream, a, t);
                 const int64_t tot = (int64_t)sc.rp * (nn / 4);
                 GLAUNCH(k_graph_dx_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g->stream, g->dxpart, n,
                                    stride, sc.rp, nn / 4, g->dact + in_col + first, g->ld, din_acc ? 1 : 0);
@@ -1619,7 +1770,10 @@ void dnn_backward_group(mamdr_graph* g, const std::vector<int>& ids, const std::
                     t.a_off[e] = cols[e][0];
                     t.b_off[e] = g->dnns[ids[e]].layers[0].w_off;
                 }
-                GLAUNCH(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
+                if (use_tile32(sc.rp, nn))
+                    GLAUNCH(k_graph_gemm32_kcat, dim3(nn / T32, sc.rp / T32), dim3(256), 0, g->stream, a, t);
+                else
+                    GLAUNCH(k_graph_gemm_kcat, dim3(nn / GT, sc.rp / GT), dim3(256), 0, g->stream, a, t);
             }
         }
     }
@@ -1846,6 +2000,7 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     g->stream = (hipStream_t)stream;
     if (const char* ev = getenv("MAMDR_GRAPH_NO_GROUP")) g->group_ok = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_GRAPH_NO_DEFER")) g->defer_w = atoi(ev) == 0;
+    if (const char* ev = getenv("MAMDR_GRAPH_TILE32_BELOW")) g_tile32_below = atoi(ev);
     if (const char* ev = getenv("MAMDR_GRAPH_WQ_BLOCKS")) g->wq_blocks = atoi(ev) > 0 ? atoi(ev) : g->wq_blocks;
     g->gated = gated;
     g->single = single;
