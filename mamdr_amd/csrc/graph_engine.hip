@@ -572,10 +572,10 @@ struct WFinish {
     const float* part[MAX_WQ]; float* out[MAX_WQ]; const float* dz[MAX_WQ]; float* db[MAX_WQ];
     int split[MAX_WQ], nb_red[MAX_WQ], N[MAX_WQ], rows[MAX_WQ], ld[MAX_WQ], mn[MAX_WQ];
 };
-__global__ __launch_bounds__(256) void k_graph_wfinish_multi(const WFinish t) {
+__device__ __forceinline__ void wfinish_multi_body(const WFinish& t, const int bid) {
     int p = 0;
-    while (p + 1 < t.n && (int)blockIdx.x >= t.first[p + 1]) ++p;
-    const int bi = (int)blockIdx.x - t.first[p];
+    while (p + 1 < t.n && bid >= t.first[p + 1]) ++p;
+    const int bi = bid - t.first[p];
     if (bi < t.nb_red[p]) {
         const int64_t i = (int64_t)bi * 256 + threadIdx.x;
         if (i >= t.mn[p] / 4) return;
@@ -616,6 +616,7 @@ __global__ __launch_bounds__(256) void k_graph_wfinish_multi(const WFinish t) {
         t.db[p][col] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_graph_wfinish_multi(const WFinish t) { wfinish_multi_body(t, blockIdx.x); }
 // d x of a group's first layers: out[b][c] (+)= sum over the members of part[e][b][c], in member order
 __global__ __launch_bounds__(256) void k_graph_dx_reduce(const float* part, int n_part, size_t stride, int rows, int n4_row,
                                                          float* out, int ld, int accumulate) {
@@ -642,10 +643,10 @@ static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, floa
 
 // out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1; the
 // attention projections: n_e = 128): 16 outputs per workgroup, the rows split over 16 groups summed through LDS in order
-__global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_ld, const float* d, int d_ld, int rows,
-                                                        int n_j, int n_e, float* out, float* sum_out) {
+__device__ __forceinline__ void small_tn_body(const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
+                                              float* out, float* sum_out, const int bid, const int nblk) {
     __shared__ float red[CS_GROUPS][CS_COLS + 1];
-    if (sum_out && blockIdx.x == gridDim.x - 1) {       // one more workgroup: sum_out[0] = sum over the rows of d[b][0], fixed order
+    if (sum_out && bid == nblk - 1) {       // one more workgroup: sum_out[0] = sum over the rows of d[b][0], fixed order
         float* r1 = &red[0][0];                         // (the head's d global bias beside its d kernel: one launch less)
         float s1 = 0.f;
         for (int b = threadIdx.x; b < rows; b += 256) s1 += d[(size_t)b * d_ld];
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_
         return;
     }
     const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
-    const int idx = blockIdx.x * CS_COLS + c;
+    const int idx = bid * CS_COLS + c;
     float s = 0.f;
     if (idx < n_j * n_e) {
         const int j = idx / n_e, e = idx - j * n_e;
@@ -685,6 +686,10 @@ __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_
         for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
         out[idx] = t;
     }
+}
+__global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_ld, const float* d, int d_ld, int rows,
+                                                        int n_j, int n_e, float* out, float* sum_out) {
+    small_tn_body(in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out, blockIdx.x, gridDim.x);
 }
 static void launch_small_tn(hipStream_t s, const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
                             float* out, float* sum_out = nullptr) {
@@ -1212,11 +1217,11 @@ __global__ void k_graph_scale(float* x, float s) { x[0] *= s; }
 // g[d][c] = sum over the batch rows of domain d of d x[b][256 + c]  +  2 l2 Dm[d][c]   (rows in batch order)
 // grid (8 column blocks, domains): 16 columns x 16 row groups per workgroup, 8 loads in flight, summed through LDS in a
 // fixed order; a domain with no row in the batch (all but one of them in a domain step) leaves after one look at the ids.
-__global__ __launch_bounds__(256) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
-                                                           const float* dm, float two_l2, float* g) {
+__device__ __forceinline__ void domain_grad_body(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
+                                                 const float* dm, float two_l2, float* g, const int bx, const int by) {
     __shared__ float red[CS_GROUPS][CS_COLS + 1];
-    const int d = blockIdx.y, c = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
-    const int col = blockIdx.x * CS_COLS + c;
+    const int d = by, c = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
+    const int col = bx * CS_COLS + c;
     int mine = 0;
     for (int b = threadIdx.x; b < rows; b += 256) mine |= domrow[b] == d;
     if (!__syncthreads_or(mine)) {
@@ -1246,6 +1251,42 @@ __global__ __launch_bounds__(256) void k_graph_domain_grad(const float* dx, int 
         for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
         g[d * EMB + col] = t + two_l2 * dm[d * EMB + col];
     }
+}
+__global__ __launch_bounds__(256) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
+                                                           const float* dm, float two_l2, float* g) {
+    domain_grad_body(dx, ld, x_col, domrow, rows, dm, two_l2, g, blockIdx.x, blockIdx.y);
+}
+// ---- the tail of a step's backward pass in ONE launch: the ends of the queued weight gradients (k_graph_wfinish_multi's
+// workgroups), the narrow contractions that were queued with them (head / gate kernels, PNN's inner-product rows, the
+// attention projections: k_graph_small_tn's workgroups) and the domain table's gradient (k_graph_domain_grad's) -- all of
+// them read what the backward pass left in the workspaces and write gradients nothing but the optimiser reads.
+constexpr int MAX_TQ = 6;
+struct TailJobs {
+    int n_tn;
+    int tn_first[MAX_TQ + 1];       // first workgroup (behind the weight gradients' ends) of narrow contraction q
+    const float* in[MAX_TQ]; const float* d[MAX_TQ]; float* out[MAX_TQ]; float* sum_out[MAX_TQ];
+    int in_ld[MAX_TQ], d_ld[MAX_TQ], rows[MAX_TQ], n_j[MAX_TQ], n_e[MAX_TQ];
+    int dg_first, dg_blocks;        // the domain table's gradient: 8 column blocks x n_domain (0 blocks: not in this launch)
+    const float* dx; int ld, x_col; const int32_t* domrow; int dg_rows; const float* dm; float two_l2; float* g_dm;
+};
+__global__ __launch_bounds__(256) void k_graph_tail(const WFinish f, const TailJobs j) {
+    const int nf = f.n ? f.first[f.n] : 0;
+    int bid = blockIdx.x;
+    if (bid < nf) {
+        wfinish_multi_body(f, bid);
+        return;
+    }
+    bid -= nf;
+    if (bid < j.dg_first) {
+        int q = 0;
+        while (q + 1 < j.n_tn && bid >= j.tn_first[q + 1]) ++q;
+        small_tn_body(j.in[q], j.in_ld[q], j.d[q], j.d_ld[q], j.rows[q], j.n_j[q], j.n_e[q], j.out[q], j.sum_out[q],
+                      bid - j.tn_first[q], j.tn_first[q + 1] - j.tn_first[q]);
+        return;
+    }
+    bid -= j.dg_first;
+    if (bid < j.dg_blocks) domain_grad_body(j.dx, j.ld, j.x_col, j.domrow, j.dg_rows, j.dm, j.two_l2, j.g_dm, bid % (EMB / CS_COLS),
+                                            bid / (EMB / CS_COLS));
 }
 
 // ------------------------------------------------------------------ optimiser on a range of the flat vector
@@ -1369,6 +1410,8 @@ struct mamdr_graph {
     // MAMDR_GRAPH_NO_DEFER=1: a pair of launches per layer, where the backward pass meets it (A/B)
     struct WProb { const float* A; int lda; const float* B; int ldb; float* out; int M, N, rows; const float* dz; float* db; };
     std::vector<WProb> wq;
+    struct TnProb { const float* in; int in_ld; const float* d; int d_ld; int rows, n_j, n_e; float* out; float* sum_out; };
+    std::vector<TnProb> tq;     // narrow contractions (k_graph_small_tn's problems) that ride in the queue's second launch
     bool defer_w = true;
     int wq_blocks = 512;        // the queue's launch splits the batch rows until it has about this many workgroups
     int32_t* domrow = nullptr;
@@ -1411,9 +1454,11 @@ int add_dnn(mamdr_graph* g, const std::string& name, int in_dim, const int32_t* 
 // dW[M x N] = A[rows x M]^T . B[rows x N], the rows split over up to 16 workgroups per tile when the tiles alone leave
 // most of the 256 CUs idle (a 384 x 512 kernel is 48 tiles); the partial products meet in k_graph_wfinish, which also
 // carries the layer's bias gradient (column sums of `dz` into `db`, skipped when db is null)
-void flush_wgrads(mamdr_graph* g) {
+struct DomainGradJob { const float* dx; int ld, x_col; const int32_t* domrow; int rows; const float* dm; float two_l2; float* g_dm;
+                       int n_domain; };
+void flush_wgrads(mamdr_graph* g, const DomainGradJob* dg = nullptr) {
     const int n = (int)g->wq.size();
-    if (!n) return;
+    if (!n && g->tq.empty() && !dg) return;
     int tiles = 0;
     for (const auto& q : g->wq) tiles += (q.M / GT) * (q.N / GT);
     int S = 1;
@@ -1470,9 +1515,51 @@ void flush_wgrads(mamdr_graph* g) {
     }
     m.first[n] = nb;
     f.first[n] = nf;
-    GLAUNCH(k_graph_wgrad_multi, dim3(nb), dim3(256), 0, g->stream, m);
-    if (nf) GLAUNCH(k_graph_wfinish_multi, dim3(nf), dim3(256), 0, g->stream, f);
+    if (nb) GLAUNCH(k_graph_wgrad_multi, dim3(nb), dim3(256), 0, g->stream, m);
+    TailJobs j;
+    memset(&j, 0, sizeof(j));
+    int nt = 0;
+    j.n_tn = (int)g->tq.size();
+    for (int q = 0; q < j.n_tn; ++q) {
+        const auto& t = g->tq[q];
+        j.tn_first[q] = nt;
+        j.in[q] = t.in;
+        j.in_ld[q] = t.in_ld;
+        j.d[q] = t.d;
+        j.d_ld[q] = t.d_ld;
+        j.rows[q] = t.rows;
+        j.n_j[q] = t.n_j;
+        j.n_e[q] = t.n_e;
+        j.out[q] = t.out;
+        j.sum_out[q] = t.sum_out;
+        nt += (t.n_j * t.n_e + CS_COLS - 1) / CS_COLS + (t.sum_out ? 1 : 0);
+    }
+    j.tn_first[j.n_tn] = nt;
+    j.dg_first = nt;
+    if (dg) {
+        j.dg_blocks = (EMB / CS_COLS) * dg->n_domain;
+        j.dx = dg->dx;
+        j.ld = dg->ld;
+        j.x_col = dg->x_col;
+        j.domrow = dg->domrow;
+        j.dg_rows = dg->rows;
+        j.dm = dg->dm;
+        j.two_l2 = dg->two_l2;
+        j.g_dm = dg->g_dm;
+    }
+    if (nf + nt + j.dg_blocks) GLAUNCH(k_graph_tail, dim3(nf + nt + j.dg_blocks), dim3(256), 0, g->stream, f, j);
     g->wq.clear();
+    g->tq.clear();
+}
+// a narrow contraction of the backward pass: queued beside the weight gradients (their outputs are gradients too)
+void small_tn(mamdr_graph* g, const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e, float* out,
+              float* sum_out = nullptr) {
+    if (!g->defer_w) {
+        launch_small_tn(g->stream, in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out);
+        return;
+    }
+    if ((int)g->tq.size() == MAX_TQ) flush_wgrads(g);
+    g->tq.push_back(mamdr_graph::TnProb{in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out});
 }
 void queue_wgrad(mamdr_graph* g, const float* A, int lda, const float* B, int ldb, float* out, int M, int N, int rows,
                  const float* dz, float* db) {
@@ -2369,7 +2456,8 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
     hipGraphExec_t dexec = nullptr;
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t row_base = (first_step + s) * batch;
-        g->wq.clear();          // (a step that failed half-way leaves its queue behind)
+        g->wq.clear();          // (a step that failed half-way leaves its queues behind)
+        g->tq.clear();
         if (diag_replay && dexec && pass_rows - row_base >= batch) {
             (void)hipGraphLaunch(dexec, g->stream);
             g->global_step += 1;
@@ -2443,7 +2531,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                                g->cfg.n_domain);
         // ---- backward
         // head: dw = t^T dlogit, dgb = sum dlogit
-        launch_small_tn(g->stream, g->act + t_col, g->ld, g->dlogit, 1,
+        small_tn(g, g->act + t_col, g->ld, g->dlogit, 1,
                            sc.rp, ha.n_t, 1, g->G(t.head_w), g->G(t.head_gb));
         const size_t ti = t.path.size() - 1;
         // the x columns of the gradient workspace collect d x from every first layer (the domain columns alone while the
@@ -2492,7 +2580,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                     GLAUNCH(k_graph_add_x, dim3((sc.rp * n + 255) / 256), dim3(256), 0, g->stream, g->dact, g->ld, g->dxt,
                                        sc.rp, first, n);
                 } else {
-                    launch_small_tn(g->stream, xin, d_in,
+                    small_tn(g, xin, d_in,
                                        g->attdP[l], ATT_P, 3 * sc.rp, d_in, ATT_P, g->G(g->att_w[l]));
                     GLAUNCH(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
                                        ATT_P, g->params + g->att_w[l], d_in, 3 * sc.rp, g->attdY[l - 1]);
@@ -2523,7 +2611,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                 // rows 0..383 of the first kernel as any first layer on x; rows 384..386 against the inner products
                 dnn_backward(g, tower, t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
                 const Layer& L0 = tower.layers[0];
-                launch_small_tn(g->stream, g->act + g->f_col, g->ld,
+                small_tn(g, g->act + g->f_col, g->ld,
                                    g->dact + t.col[0][0], g->ld, sc.rp, 3, L0.out, g->G(L0.w_off + (int64_t)L0.in * L0.out));
             }
             GLAUNCH(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
@@ -2538,7 +2626,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             GLAUNCH(k_graph_gate_bwd, dim3(sc.rp), dim3(256), 0, g->stream, gta);
             const size_t gi = t.mix.size();
             const Dnn& gd = g->dnns[t.gate];
-            launch_small_tn(g->stream, g->act + gta.q_col,
+            small_tn(g, g->act + gta.q_col,
                                g->ld, g->dact + t.g_col, g->ld, sc.rp, gta.n_q, gta.n_e, g->G(t.wg_off));
             dnn_backward(g, gd, t.col[gi], 0, 0, -1, dx_started, dx_first, dx_n, sc);
             dx_started = true;
@@ -2557,9 +2645,14 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, tower, t.col[ti], t.col[0].back(), t.col[0].back(), t.col[0].back(), false, 0, 0, sc);
             dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
-        flush_wgrads(g);        // every layer's dW / db of this step: one pair of launches
-        GLAUNCH(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB, g->domrow,
-                           sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
+        if (g->defer_w) {       // every layer's dW / db of this step, the narrow contractions, the domain table's gradient:
+            const DomainGradJob dg{g->dact, g->ld, 2 * EMB, g->domrow, sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb,
+                                   g->G(g->dm_off), g->cfg.n_domain};      // one pair of launches
+            flush_wgrads(g, &dg);
+        } else {
+            GLAUNCH(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB,
+                    g->domrow, sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb, g->G(g->dm_off));
+        }
         if (g->tables) {
             // TF1's dense step over both tables: g = 2 l2 p + scatter-add of d x[:, user | item columns]
             EmbStepArgs ea;
