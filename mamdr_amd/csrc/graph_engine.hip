@@ -779,10 +779,9 @@ __global__ __launch_bounds__(256) void k_graph_feat_bwd(const FeatArgs a) {
 }
 // NFM's linear domain table: g[d] = sum over the batch rows of domain d of d loss / d logit  +  2 l2_lin w[d]
 // one workgroup per domain: rows strided over the 256 threads, LDS tree in a fixed order
-__global__ __launch_bounds__(256) void k_graph_lin_domain_grad(const float* dlogit, const int32_t* domrow, int rows, const float* w,
-                                                               float two_l2, int n_domain, float* g) {
+__device__ __forceinline__ void lin_domain_grad_body(const float* dlogit, const int32_t* domrow, int rows, const float* w, float two_l2,
+                                                     float* g, const int d) {
     __shared__ float red[256];
-    const int d = blockIdx.x;
     float s = 0.f;
     for (int b = threadIdx.x; b < rows; b += 256) s += domrow[b] == d ? dlogit[b] : 0.f;
     red[threadIdx.x] = s;
@@ -793,6 +792,10 @@ __global__ __launch_bounds__(256) void k_graph_lin_domain_grad(const float* dlog
         __syncthreads();
     }
     if (threadIdx.x == 0) g[d] = red[0] + two_l2 * w[d];
+}
+__global__ __launch_bounds__(256) void k_graph_lin_domain_grad(const float* dlogit, const int32_t* domrow, int rows, const float* w,
+                                                               float two_l2, int n_domain, float* g) {
+    lin_domain_grad_body(dlogit, domrow, rows, w, two_l2, g, blockIdx.x);
 }
 static void launch_lin_domain_grad(hipStream_t s, const float* dlogit, const int32_t* domrow, int rows, const float* w, float two_l2,
                                    int n_domain, float* g) {
@@ -1268,6 +1271,8 @@ struct TailJobs {
     int in_ld[MAX_TQ], d_ld[MAX_TQ], rows[MAX_TQ], n_j[MAX_TQ], n_e[MAX_TQ];
     int dg_first, dg_blocks;        // the domain table's gradient: 8 column blocks x n_domain (0 blocks: not in this launch)
     const float* dx; int ld, x_col; const int32_t* domrow; int dg_rows; const float* dm; float two_l2; float* g_dm;
+    int lin_blocks;                 // the 1-d linear domain table's gradient (k_graph_lin_domain_grad's workgroups: one per domain)
+    const float* lin_dlogit; const float* lin_w; float lin_two_l2; float* lin_g;
 };
 __global__ __launch_bounds__(256) void k_graph_tail(const WFinish f, const TailJobs j) {
     const int nf = f.n ? f.first[f.n] : 0;
@@ -1285,8 +1290,12 @@ __global__ __launch_bounds__(256) void k_graph_tail(const WFinish f, const TailJ
         return;
     }
     bid -= j.dg_first;
-    if (bid < j.dg_blocks) domain_grad_body(j.dx, j.ld, j.x_col, j.domrow, j.dg_rows, j.dm, j.two_l2, j.g_dm, bid % (EMB / CS_COLS),
-                                            bid / (EMB / CS_COLS));
+    if (bid < j.dg_blocks) {
+        domain_grad_body(j.dx, j.ld, j.x_col, j.domrow, j.dg_rows, j.dm, j.two_l2, j.g_dm, bid % (EMB / CS_COLS), bid / (EMB / CS_COLS));
+        return;
+    }
+    bid -= j.dg_blocks;
+    if (bid < j.lin_blocks) lin_domain_grad_body(j.lin_dlogit, j.domrow, j.dg_rows, j.lin_w, j.lin_two_l2, j.lin_g, bid);
 }
 
 // ------------------------------------------------------------------ optimiser on a range of the flat vector
@@ -1455,7 +1464,8 @@ int add_dnn(mamdr_graph* g, const std::string& name, int in_dim, const int32_t* 
 // most of the 256 CUs idle (a 384 x 512 kernel is 48 tiles); the partial products meet in k_graph_wfinish, which also
 // carries the layer's bias gradient (column sums of `dz` into `db`, skipped when db is null)
 struct DomainGradJob { const float* dx; int ld, x_col; const int32_t* domrow; int rows; const float* dm; float two_l2; float* g_dm;
-                       int n_domain; };
+                       int n_domain;
+                       const float* lin_dlogit; const float* lin_w; float lin_two_l2; float* lin_g; };     // lin_g null: no linear table
 void flush_wgrads(mamdr_graph* g, const DomainGradJob* dg = nullptr) {
     const int n = (int)g->wq.size();
     if (!n && g->tq.empty() && !dg) return;
@@ -1546,8 +1556,16 @@ void flush_wgrads(mamdr_graph* g, const DomainGradJob* dg = nullptr) {
         j.dm = dg->dm;
         j.two_l2 = dg->two_l2;
         j.g_dm = dg->g_dm;
+        if (dg->lin_g) {
+            j.lin_blocks = dg->n_domain;
+            j.lin_dlogit = dg->lin_dlogit;
+            j.lin_w = dg->lin_w;
+            j.lin_two_l2 = dg->lin_two_l2;
+            j.lin_g = dg->lin_g;
+        }
     }
-    if (nf + nt + j.dg_blocks) GLAUNCH(k_graph_tail, dim3(nf + nt + j.dg_blocks), dim3(256), 0, g->stream, f, j);
+    const int nblk = nf + nt + j.dg_blocks + j.lin_blocks;
+    if (nblk) GLAUNCH(k_graph_tail, dim3(nblk), dim3(256), 0, g->stream, f, j);
     g->wq.clear();
     g->tq.clear();
 }
@@ -2582,11 +2600,24 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
                 } else {
                     small_tn(g, xin, d_in,
                                        g->attdP[l], ATT_P, 3 * sc.rp, d_in, ATT_P, g->G(g->att_w[l]));
-                    GLAUNCH(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
-                                       ATT_P, g->params + g->att_w[l], d_in, 3 * sc.rp, g->attdY[l - 1]);
+                    if (use_tile32(3 * sc.rp, d_in)) {      // d Y[l-1] = d P . W^T, [3 B x 128] x [32 x 128]^T
+                        GemmArgs a;
+                        memset(&a, 0, sizeof(a));
+                        a.A = g->attdP[l];
+                        a.lda = ATT_P;
+                        a.B = g->params + g->att_w[l];
+                        a.ldb = ATT_P;
+                        a.C = g->attdY[l - 1];
+                        a.ldc = d_in;
+                        a.K = ATT_P;
+                        launch_gemm(1, a, 3 * sc.rp, d_in, g->stream);
+                    } else {
+                        GLAUNCH(k_graph_small_nt, dim3((3 * sc.rp * d_in + 255) / 256), dim3(256), 0, g->stream, g->attdP[l],
+                                ATT_P, g->params + g->att_w[l], d_in, 3 * sc.rp, g->attdY[l - 1]);
+                    }
                 }
             }
-            launch_lin_domain_grad(g->stream, g->dlogit,
+            if (!g->defer_w) launch_lin_domain_grad(g->stream, g->dlogit,
                                g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                g->G(g->lin_d_off));
         } else if (g->single && g->cfg.kind == MAMDR_GRAPH_CCPM) {
@@ -2595,9 +2626,11 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             CcpmArgs ca;
             fill_ccpm(g, sc, ca);
             GLAUNCH(k_graph_ccpm_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, ca);
-            launch_colsum(g->stream, g->dact + g->cg_col, g->ld, sc.rp,
-                               g->G(g->conv_off), 48);
-            launch_lin_domain_grad(g->stream, g->dlogit,
+            if (g->defer_w)     // the 48 column sums as a queue entry without a contraction (its end = the bias-gradient workgroups)
+                queue_wgrad(g, nullptr, 0, nullptr, 0, nullptr, 0, 48, sc.rp, g->dact + g->cg_col, g->G(g->conv_off));
+            else
+                launch_colsum(g->stream, g->dact + g->cg_col, g->ld, sc.rp, g->G(g->conv_off), 48);
+            if (!g->defer_w) launch_lin_domain_grad(g->stream, g->dlogit,
                                g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                g->G(g->lin_d_off));
         } else if (g->single) {
@@ -2616,7 +2649,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             }
             GLAUNCH(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
             if (nfm)
-                launch_lin_domain_grad(g->stream, g->dlogit,
+                if (!g->defer_w) launch_lin_domain_grad(g->stream, g->dlogit,
                                    g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                    g->G(g->lin_d_off));
         } else if (g->gated) {
@@ -2646,8 +2679,10 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             dnn_backward(g, g->dnns[t.mix[0]], t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
         }
         if (g->defer_w) {       // every layer's dW / db of this step, the narrow contractions, the domain table's gradient:
+            const bool lin = g->single && g->has_lin;
             const DomainGradJob dg{g->dact, g->ld, 2 * EMB, g->domrow, sc.rows, g->params + g->dm_off, 2.0f * g->cfg.l2_emb,
-                                   g->G(g->dm_off), g->cfg.n_domain};      // one pair of launches
+                                   g->G(g->dm_off), g->cfg.n_domain, g->dlogit, lin ? g->params + g->lin_d_off : nullptr,
+                                   2.0f * g->cfg.l2_linear, lin ? g->G(g->lin_d_off) : nullptr};      // one pair of launches
             flush_wgrads(g, &dg);
         } else {
             GLAUNCH(k_graph_domain_grad, dim3(EMB / CS_COLS, g->cfg.n_domain), dim3(256), 0, g->stream, g->dact, g->ld, 2 * EMB,
