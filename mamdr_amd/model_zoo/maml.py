@@ -65,6 +65,10 @@ class MAML(object):
             raise NotImplementedError("meta_parms %s select tensors that are not neighbours in the flat vector; this engine "
                                       "has no assign_meta" % (self.train_config["meta_parms"],))
         if holes:
+            from .. import parallel
+            if parallel.world()[1] > 1:     # the skipped tensors would train apart on every rank (the all-reduce covers theta)
+                raise NotImplementedError("meta_parms %s skip tensors of the flat vector: not built for several processes"
+                                          % (self.train_config["meta_parms"],))
             self.model.set_meta_range(lo, hi - lo, holes)
         else:
             self.model.set_meta_range(lo, hi - lo)
