@@ -115,20 +115,32 @@ def test_one_step_gradients_match_oracle(kind, dropout):
     eng.close()
 
 
+# layer widths that are multiples of 64 but not of the 128-deep stages of the 32 x 32 tiles (their zero-filled tails), a
+# three-layer gate, three experts: nothing a reference config uses, everything mamdr_graph_create accepts
+ODD_SHAPES = {
+    "shared_bottom": ((192, 320), (192, 64), (), 0, 0, 0),
+    "mmoe": ((320, 192), (64,), (192, 64, 64), 3, 0, 0),
+    "ple": ((192,), (320, 64), (64,), 0, 1, 3),
+}
+
+
 @pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
-def test_config_shapes_at_batch_1024(kind):
+@pytest.mark.parametrize("shapes,batch", [("config", 1024), ("odd", 448)])
+def test_config_shapes_at_batch_1024(kind, shapes, batch):
     """the reference's Taobao-10 multi-task configs as configured: their layer widths / expert counts, 10 domains, batch
     size 1,024 (config/Taobao-10/*.json) -- one-step gradients of every tensor on task d's path and the loss against the
-    oracle on a full batch, everything off the path bit-unchanged, then three Adam steps."""
-    g, eng, model, spec = make_problem(kind, batch=1024, dropout=0.5, scale=0.5, n_domain=10, shapes=CONFIG_SHAPES)
+    oracle on a full batch, everything off the path bit-unchanged, then three Adam steps.  "odd": widths of 192 / 320
+    (reduction lengths that end inside a 128-deep stage) at a batch of 448 rows (7 tiles of 64)."""
+    g, eng, model, spec = make_problem(kind, batch=batch, dropout=0.5, scale=0.5, n_domain=10,
+                                       shapes=CONFIG_SHAPES if shapes == "config" else ODD_SHAPES)
     d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     cols = g["data"]["train"][d]
     n = cols["uid"].shape[0]
-    assert n >= 3 * 1024
+    assert n >= 3 * batch
     perm = orng.shuffle_perm(n, 10000, seed=5)
     perm_t = torch.from_numpy(perm).to(eng.device)
-    idx = perm[:1024]
-    masks = omtl.train_masks(spec, model.seed, model.step, 1024, 0.5)
+    idx = perm[:batch]
+    masks = omtl.train_masks(spec, model.seed, model.step, batch, 0.5)
     loss, grads, _ = omtl.loss_and_grads(model.params, spec, d, cols["uid"][idx], cols["pid"][idx], cols["domain"][idx],
                                          cols["label"][idx], masks, 0.5, False, model.frozen_sumsq())
     loss_t = torch.zeros(1, device=eng.device)
@@ -148,7 +160,7 @@ def test_config_shapes_at_batch_1024(kind):
             off, cnt = eng.segments[name]
             assert np.array_equal(after[off:off + cnt], w0.cpu().numpy()[off:off + cnt]), name
     eng.train_steps(d, perm=perm_t, first_step=0, n_steps=3, lr=1e-3)
-    model.train_pass(d, cols, perm, 1024, max_steps=3)
+    model.train_pass(d, cols, perm, batch, max_steps=3)
     got = eng.unpack(eng.get_weights())
     for name in grads:
         assert_adam_close(got[name], model.params[name], 3, 1e-3, name)
