@@ -566,13 +566,63 @@ __global__ __launch_bounds__(256) void k_graph_wgrad_multi(const WMulti t) {
 }
 // ... and their ends: per problem, the workgroups that add the splits' partial products in a fixed order, then the ones
 // that sum the columns of d z into the bias gradient (k_graph_wfinish's two halves, the queue's problems side by side)
+// where a finished gradient element goes: into the gradient vector (p null), or straight through the optimiser -- the
+// step's k_graph_adam launch folded into the launch that finishes the gradients (the same arithmetic per element: opt_elem)
+struct GradSink {
+    const float* g_base;        // base of the gradient vector (element 0 = flat-vector element `table_floats`)
+    float *p, *m, *v;           // parameters / slots addressed like g_base (m: the accumulator for MAMDR_OPT_ACCUMULATE)
+    int optimizer;
+    float alpha, omb1, omb2, eps;
+};
+__device__ __forceinline__ void opt_elem(const int optimizer, const float g, float& p, float& m, float& v, const float alpha,
+                                         const float omb1, const float omb2, const float eps) {
+    if (optimizer == MAMDR_OPT_SGD) {
+        p = p - g * alpha;
+    } else if (optimizer == MAMDR_OPT_ACCUMULATE) {
+        m = m + g;
+    } else {        // TF1 ApplyAdam: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p -= m alpha / (sqrt(v) + eps)
+        m = m + (g - m) * omb1;
+        v = v + (g * g - v) * omb2;
+        p = p - (m * alpha) / (sqrtf(v) + eps);
+    }
+}
+__device__ __forceinline__ void sink1(const GradSink& s, float* gptr, const float g) {
+    if (!s.p) {
+        *gptr = g;
+        return;
+    }
+    const size_t i = (size_t)(gptr - s.g_base);
+    float p = s.p[i], m = s.m[i], v = s.optimizer == MAMDR_OPT_ADAM ? s.v[i] : 0.f;
+    opt_elem(s.optimizer, g, p, m, v, s.alpha, s.omb1, s.omb2, s.eps);
+    if (s.optimizer != MAMDR_OPT_ACCUMULATE) s.p[i] = p;
+    if (s.optimizer != MAMDR_OPT_SGD) s.m[i] = m;
+    if (s.optimizer == MAMDR_OPT_ADAM) s.v[i] = v;
+}
+__device__ __forceinline__ void sink4(const GradSink& s, float* gptr, const f32x4 g) {
+    if (!s.p) {
+        *reinterpret_cast<f32x4*>(gptr) = g;
+        return;
+    }
+    const size_t i = (size_t)(gptr - s.g_base);
+    f32x4 p = *reinterpret_cast<const f32x4*>(s.p + i), m = *reinterpret_cast<const f32x4*>(s.m + i);
+    f32x4 v = s.optimizer == MAMDR_OPT_ADAM ? *reinterpret_cast<const f32x4*>(s.v + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float pk = p[k], mk = m[k], vk = v[k];
+        opt_elem(s.optimizer, g[k], pk, mk, vk, s.alpha, s.omb1, s.omb2, s.eps);
+        p[k] = pk; m[k] = mk; v[k] = vk;
+    }
+    if (s.optimizer != MAMDR_OPT_ACCUMULATE) *reinterpret_cast<f32x4*>(s.p + i) = p;
+    if (s.optimizer != MAMDR_OPT_SGD) *reinterpret_cast<f32x4*>(s.m + i) = m;
+    if (s.optimizer == MAMDR_OPT_ADAM) *reinterpret_cast<f32x4*>(s.v + i) = v;
+}
 struct WFinish {
     int n;
     int first[MAX_WQ + 1];
     const float* part[MAX_WQ]; float* out[MAX_WQ]; const float* dz[MAX_WQ]; float* db[MAX_WQ];
     int split[MAX_WQ], nb_red[MAX_WQ], N[MAX_WQ], rows[MAX_WQ], ld[MAX_WQ], mn[MAX_WQ];
 };
-__device__ __forceinline__ void wfinish_multi_body(const WFinish& t, const int bid) {
+__device__ __forceinline__ void wfinish_multi_body(const WFinish& t, const int bid, const GradSink& sk) {
     int p = 0;
     while (p + 1 < t.n && bid >= t.first[p + 1]) ++p;
     const int bi = bid - t.first[p];
@@ -587,7 +637,7 @@ __device__ __forceinline__ void wfinish_multi_body(const WFinish& t, const int b
 #pragma unroll
             for (int k = 0; k < 4; ++k) v0[k] += v[k];
         }
-        reinterpret_cast<f32x4*>(t.out[p])[i] = v0;
+        sink4(sk, t.out[p] + 4 * i, v0);
         return;
     }
     __shared__ float red[CS_GROUPS][CS_COLS + 1];
@@ -613,10 +663,14 @@ __device__ __forceinline__ void wfinish_multi_body(const WFinish& t, const int b
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < CS_GROUPS; ++k) v += red[k][c];
-        t.db[p][col] = v;
+        sink1(sk, t.db[p] + col, v);
     }
 }
-__global__ __launch_bounds__(256) void k_graph_wfinish_multi(const WFinish t) { wfinish_multi_body(t, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_graph_wfinish_multi(const WFinish t) {
+    GradSink none;
+    none.p = nullptr;
+    wfinish_multi_body(t, blockIdx.x, none);
+}
 // d x of a group's first layers: out[b][c] (+)= sum over the members of part[e][b][c], in member order
 __global__ __launch_bounds__(256) void k_graph_dx_reduce(const float* part, int n_part, size_t stride, int rows, int n4_row,
                                                          float* out, int ld, int accumulate) {
@@ -644,7 +698,7 @@ static void launch_colsum(hipStream_t s, const float* dz, int ld, int rows, floa
 // out[j][e] = sum_b in[b][j] * d[b][e]  for narrow right-hand sides (gate kernel Wg: e < n_e <= 32; head: n_e = 1; the
 // attention projections: n_e = 128): 16 outputs per workgroup, the rows split over 16 groups summed through LDS in order
 __device__ __forceinline__ void small_tn_body(const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
-                                              float* out, float* sum_out, const int bid, const int nblk) {
+                                              float* out, float* sum_out, const int bid, const int nblk, const GradSink& sk) {
     __shared__ float red[CS_GROUPS][CS_COLS + 1];
     if (sum_out && bid == nblk - 1) {       // one more workgroup: sum_out[0] = sum over the rows of d[b][0], fixed order
         float* r1 = &red[0][0];                         // (the head's d global bias beside its d kernel: one launch less)
@@ -656,7 +710,7 @@ __device__ __forceinline__ void small_tn_body(const float* in, int in_ld, const 
             if ((int)threadIdx.x < o) r1[threadIdx.x] += r1[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) sum_out[0] = r1[0];
+        if (threadIdx.x == 0) sink1(sk, sum_out, r1[0]);
         return;
     }
     const int c = threadIdx.x & (CS_COLS - 1), g = threadIdx.x / CS_COLS;
@@ -684,12 +738,14 @@ __device__ __forceinline__ void small_tn_body(const float* in, int in_ld, const 
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
-        out[idx] = t;
+        sink1(sk, out + idx, t);
     }
 }
 __global__ __launch_bounds__(256) void k_graph_small_tn(const float* in, int in_ld, const float* d, int d_ld, int rows,
                                                         int n_j, int n_e, float* out, float* sum_out) {
-    small_tn_body(in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out, blockIdx.x, gridDim.x);
+    GradSink none;
+    none.p = nullptr;
+    small_tn_body(in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out, blockIdx.x, gridDim.x, none);
 }
 static void launch_small_tn(hipStream_t s, const float* in, int in_ld, const float* d, int d_ld, int rows, int n_j, int n_e,
                             float* out, float* sum_out = nullptr) {
@@ -780,7 +836,7 @@ __global__ __launch_bounds__(256) void k_graph_feat_bwd(const FeatArgs a) {
 // NFM's linear domain table: g[d] = sum over the batch rows of domain d of d loss / d logit  +  2 l2_lin w[d]
 // one workgroup per domain: rows strided over the 256 threads, LDS tree in a fixed order
 __device__ __forceinline__ void lin_domain_grad_body(const float* dlogit, const int32_t* domrow, int rows, const float* w, float two_l2,
-                                                     float* g, const int d) {
+                                                     float* g, const int d, const GradSink& sk) {
     __shared__ float red[256];
     float s = 0.f;
     for (int b = threadIdx.x; b < rows; b += 256) s += domrow[b] == d ? dlogit[b] : 0.f;
@@ -791,11 +847,13 @@ __device__ __forceinline__ void lin_domain_grad_body(const float* dlogit, const 
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) g[d] = red[0] + two_l2 * w[d];
+    if (threadIdx.x == 0) sink1(sk, g + d, red[0] + two_l2 * w[d]);
 }
 __global__ __launch_bounds__(256) void k_graph_lin_domain_grad(const float* dlogit, const int32_t* domrow, int rows, const float* w,
                                                                float two_l2, int n_domain, float* g) {
-    lin_domain_grad_body(dlogit, domrow, rows, w, two_l2, g, blockIdx.x);
+    GradSink none;
+    none.p = nullptr;
+    lin_domain_grad_body(dlogit, domrow, rows, w, two_l2, g, blockIdx.x, none);
 }
 static void launch_lin_domain_grad(hipStream_t s, const float* dlogit, const int32_t* domrow, int rows, const float* w, float two_l2,
                                    int n_domain, float* g) {
@@ -1221,14 +1279,15 @@ __global__ void k_graph_scale(float* x, float s) { x[0] *= s; }
 // grid (8 column blocks, domains): 16 columns x 16 row groups per workgroup, 8 loads in flight, summed through LDS in a
 // fixed order; a domain with no row in the batch (all but one of them in a domain step) leaves after one look at the ids.
 __device__ __forceinline__ void domain_grad_body(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
-                                                 const float* dm, float two_l2, float* g, const int bx, const int by) {
+                                                 const float* dm, float two_l2, float* g, const int bx, const int by,
+                                                 const GradSink& sk) {
     __shared__ float red[CS_GROUPS][CS_COLS + 1];
     const int d = by, c = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
     const int col = bx * CS_COLS + c;
     int mine = 0;
     for (int b = threadIdx.x; b < rows; b += 256) mine |= domrow[b] == d;
     if (!__syncthreads_or(mine)) {
-        if (rg == 0) g[d * EMB + col] = two_l2 * dm[d * EMB + col];
+        if (rg == 0) sink1(sk, g + d * EMB + col, two_l2 * dm[d * EMB + col]);
         return;
     }
     const float* p = dx + x_col + col;
@@ -1252,12 +1311,14 @@ __device__ __forceinline__ void domain_grad_body(const float* dx, int ld, int x_
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < CS_GROUPS; ++k) t += red[k][c];
-        g[d * EMB + col] = t + two_l2 * dm[d * EMB + col];
+        sink1(sk, g + d * EMB + col, t + two_l2 * dm[d * EMB + col]);
     }
 }
 __global__ __launch_bounds__(256) void k_graph_domain_grad(const float* dx, int ld, int x_col, const int32_t* domrow, int rows,
                                                            const float* dm, float two_l2, float* g) {
-    domain_grad_body(dx, ld, x_col, domrow, rows, dm, two_l2, g, blockIdx.x, blockIdx.y);
+    GradSink none;
+    none.p = nullptr;
+    domain_grad_body(dx, ld, x_col, domrow, rows, dm, two_l2, g, blockIdx.x, blockIdx.y, none);
 }
 // ---- the tail of a step's backward pass in ONE launch: the ends of the queued weight gradients (k_graph_wfinish_multi's
 // workgroups), the narrow contractions that were queued with them (head / gate kernels, PNN's inner-product rows, the
@@ -1273,12 +1334,13 @@ struct TailJobs {
     const float* dx; int ld, x_col; const int32_t* domrow; int dg_rows; const float* dm; float two_l2; float* g_dm;
     int lin_blocks;                 // the 1-d linear domain table's gradient (k_graph_lin_domain_grad's workgroups: one per domain)
     const float* lin_dlogit; const float* lin_w; float lin_two_l2; float* lin_g;
+    GradSink sink;                  // p non-null: every finished gradient element steps its parameter right here
 };
 __global__ __launch_bounds__(256) void k_graph_tail(const WFinish f, const TailJobs j) {
     const int nf = f.n ? f.first[f.n] : 0;
     int bid = blockIdx.x;
     if (bid < nf) {
-        wfinish_multi_body(f, bid);
+        wfinish_multi_body(f, bid, j.sink);
         return;
     }
     bid -= nf;
@@ -1286,16 +1348,17 @@ __global__ __launch_bounds__(256) void k_graph_tail(const WFinish f, const TailJ
         int q = 0;
         while (q + 1 < j.n_tn && bid >= j.tn_first[q + 1]) ++q;
         small_tn_body(j.in[q], j.in_ld[q], j.d[q], j.d_ld[q], j.rows[q], j.n_j[q], j.n_e[q], j.out[q], j.sum_out[q],
-                      bid - j.tn_first[q], j.tn_first[q + 1] - j.tn_first[q]);
+                      bid - j.tn_first[q], j.tn_first[q + 1] - j.tn_first[q], j.sink);
         return;
     }
     bid -= j.dg_first;
     if (bid < j.dg_blocks) {
-        domain_grad_body(j.dx, j.ld, j.x_col, j.domrow, j.dg_rows, j.dm, j.two_l2, j.g_dm, bid % (EMB / CS_COLS), bid / (EMB / CS_COLS));
+        domain_grad_body(j.dx, j.ld, j.x_col, j.domrow, j.dg_rows, j.dm, j.two_l2, j.g_dm, bid % (EMB / CS_COLS), bid / (EMB / CS_COLS),
+                         j.sink);
         return;
     }
     bid -= j.dg_blocks;
-    if (bid < j.lin_blocks) lin_domain_grad_body(j.lin_dlogit, j.domrow, j.dg_rows, j.lin_w, j.lin_two_l2, j.lin_g, bid);
+    if (bid < j.lin_blocks) lin_domain_grad_body(j.lin_dlogit, j.domrow, j.dg_rows, j.lin_w, j.lin_two_l2, j.lin_g, bid, j.sink);
 }
 
 // ------------------------------------------------------------------ optimiser on a range of the flat vector
@@ -1313,29 +1376,17 @@ __global__ __launch_bounds__(256) void k_graph_adam(const AdamArgs a) {
     else return;
     f32x4 p = reinterpret_cast<const f32x4*>(a.p)[i];
     const f32x4 g = reinterpret_cast<const f32x4*>(a.g)[i];
-    if (a.optimizer == MAMDR_OPT_SGD) {
+    f32x4 m = a.optimizer != MAMDR_OPT_SGD ? reinterpret_cast<const f32x4*>(a.m)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 v = a.optimizer == MAMDR_OPT_ADAM ? reinterpret_cast<const f32x4*>(a.v)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p[k] = p[k] - g[k] * a.alpha;
-        reinterpret_cast<f32x4*>(a.p)[i] = p;
-        return;
+    for (int k = 0; k < 4; ++k) {
+        float pk = p[k], mk = m[k], vk = v[k];
+        opt_elem(a.optimizer, g[k], pk, mk, vk, a.alpha, a.omb1, a.omb2, a.eps);
+        p[k] = pk; m[k] = mk; v[k] = vk;
     }
-    if (a.optimizer == MAMDR_OPT_ACCUMULATE) {
-        f32x4 acc = reinterpret_cast<const f32x4*>(a.m)[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = acc[k] + g[k];
-        reinterpret_cast<f32x4*>(a.m)[i] = acc;
-        return;
-    }
-    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[i], v = reinterpret_cast<const f32x4*>(a.v)[i];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {       // TF1 ApplyAdam: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); p -= m alpha / (sqrt(v) + eps)
-        m[k] = m[k] + (g[k] - m[k]) * a.omb1;
-        v[k] = v[k] + (g[k] * g[k] - v[k]) * a.omb2;
-        p[k] = p[k] - (m[k] * a.alpha) / (sqrtf(v[k]) + a.eps);
-    }
-    reinterpret_cast<f32x4*>(a.p)[i] = p;
-    reinterpret_cast<f32x4*>(a.m)[i] = m;
-    reinterpret_cast<f32x4*>(a.v)[i] = v;
+    if (a.optimizer != MAMDR_OPT_ACCUMULATE) reinterpret_cast<f32x4*>(a.p)[i] = p;
+    if (a.optimizer != MAMDR_OPT_SGD) reinterpret_cast<f32x4*>(a.m)[i] = m;
+    if (a.optimizer == MAMDR_OPT_ADAM) reinterpret_cast<f32x4*>(a.v)[i] = v;
 }
 
 // ------------------------------------------------------------------ host side: structure of the tower
@@ -1422,6 +1473,10 @@ struct mamdr_graph {
     struct TnProb { const float* in; int in_ld; const float* d; int d_ld; int rows, n_j, n_e; float* out; float* sum_out; };
     std::vector<TnProb> tq;     // narrow contractions (k_graph_small_tn's problems) that ride in the queue's second launch
     bool defer_w = true;
+    // the optimiser step inside the tail launch (every gradient of a step's two ranges is finished there): no k_graph_adam.
+    // Off for the weighted loss (k_graph_loss writes d / d log_var) and under MAMDR_GRAPH_NO_TAIL_OPT=1 (A/B; same bits)
+    bool tail_opt = true;
+    GradSink sink;              // this step's sink (p null: gradients are stored, k_graph_adam follows)
     int wq_blocks = 512;        // the queue's launch splits the batch rows until it has about this many workgroups
     int32_t* domrow = nullptr;
     float *thresholds = nullptr, *frozen_sumsq = nullptr, *sumsq_partials = nullptr, *eval_acc = nullptr;
@@ -1511,12 +1566,13 @@ void flush_wgrads(mamdr_graph* g, const DomainGradJob* dg = nullptr) {
         m.mn[p] = q.M * q.N;
         nb += m.tx[p] * m.ty[p] * sp;
         f.first[p] = nf;
-        f.part[p] = part;
+        f.part[p] = sp > 1 ? part : q.out;
         f.out[p] = q.out;
         f.dz[p] = q.dz;
         f.db[p] = q.db;
         f.split[p] = sp;
-        f.nb_red[p] = sp > 1 ? (q.M * q.N / 4 + 255) / 256 : 0;
+        // (a gradient that the contraction wrote in place still has to pass through the optimiser when the sink steps)
+        f.nb_red[p] = (sp > 1 || g->sink.p) ? (q.M * q.N / 4 + 255) / 256 : 0;
         f.N[p] = q.db ? q.N : 0;
         f.rows[p] = q.rows;
         f.ld[p] = g->ld;
@@ -1564,6 +1620,7 @@ void flush_wgrads(mamdr_graph* g, const DomainGradJob* dg = nullptr) {
             j.lin_g = dg->lin_g;
         }
     }
+    j.sink = g->sink;
     const int nblk = nf + nt + j.dg_blocks + j.lin_blocks;
     if (nblk) GLAUNCH(k_graph_tail, dim3(nblk), dim3(256), 0, g->stream, f, j);
     g->wq.clear();
@@ -2106,6 +2163,8 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (const char* ev = getenv("MAMDR_GRAPH_NO_GROUP")) g->group_ok = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_GRAPH_NO_DEFER")) g->defer_w = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_GRAPH_TILE32_BELOW")) g_tile32_below = atoi(ev);
+    if (const char* ev = getenv("MAMDR_GRAPH_NO_TAIL_OPT")) g->tail_opt = atoi(ev) == 0;
+    g->sink.p = nullptr;
     if (const char* ev = getenv("MAMDR_GRAPH_WQ_BLOCKS")) g->wq_blocks = atoi(ev) > 0 ? atoi(ev) : g->wq_blocks;
     g->gated = gated;
     g->single = single;
@@ -2508,6 +2567,19 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             g->b2p *= g->cfg.adam_beta2;
             alpha = lr * sqrtf(1.0f - g->b2p) / (1.0f - g->b1p);
         }
+        const bool fuse_opt = g->defer_w && g->tail_opt && g->lv_off < 0;
+        g->sink.p = nullptr;
+        if (fuse_opt) {
+            g->sink.g_base = g->grad;
+            g->sink.p = g->params + g->table_floats;
+            g->sink.m = (optimizer == MAMDR_OPT_ACCUMULATE ? g->accum : g->adam_m) + g->table_floats;
+            g->sink.v = g->adam_v + g->table_floats;
+            g->sink.optimizer = optimizer;
+            g->sink.alpha = alpha;
+            g->sink.omb1 = omb1;
+            g->sink.omb2 = omb2;
+            g->sink.eps = g->cfg.adam_eps;
+        }
         GatherArgs ga;
         fill_gather(g, *d, d_perm, row_base, sc, ga);
         GLAUNCH(k_graph_gather, dim3(sc.rp / 4), dim3(256), 0, g->stream, ga);
@@ -2733,8 +2805,8 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             launch_emb_sweep(ea, g->stream);
             if (g->has_lin) launch_lin_sweep(ea, g->stream);      // (reads the row maps, then resets them)
         }
-        // ---- optimiser on the two ranges this task's model trains (one launch)
-        {
+        // ---- optimiser on the two ranges this task's model trains (one launch; none when the tail launch stepped them)
+        if (!fuse_opt) {
             const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
             AdamArgs aa;
             aa.p = g->params;

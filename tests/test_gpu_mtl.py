@@ -283,6 +283,47 @@ def test_alternate_training_auc_parity(kind):
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
+@pytest.mark.parametrize("emb_trainable", [False, True])
+def test_launch_plans_are_bitwise_twins(kind, emb_trainable, monkeypatch):
+    """the engine's launch plans of round 4 against the plans they replaced, same seeds: the optimiser step inside the tail
+    launch vs a k_graph_adam launch of its own (MAMDR_GRAPH_NO_TAIL_OPT=1) must leave identical bits (the same arithmetic per
+    element); a pair of weight-gradient launches per layer (MAMDR_GRAPH_NO_DEFER=1: other splits of the batch rows) and
+    64 x 64 tiles everywhere (MAMDR_GRAPH_TILE32_BELOW=0: another summation order) agree to rounding.  Adam and SGD steps
+    on three domains, then accumulate-only steps (the meta passes)."""
+    def run(env):
+        for k in ("MAMDR_GRAPH_NO_TAIL_OPT", "MAMDR_GRAPH_NO_DEFER", "MAMDR_GRAPH_TILE32_BELOW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g, eng, model, spec = make_problem(kind, batch=256, dropout=0.5, scale=0.1, emb_trainable=emb_trainable)
+        acc = eng.new_vector()
+        eng.bind_accumulator(acc)
+        for d, opt, lr in ((0, "adam", 1e-3), (2, "adam", 1e-3), (1, "sgd", 0.01), (0, "adam", 1e-3)):
+            n = g["data"]["train"][d]["uid"].shape[0]
+            perm = torch.from_numpy(orng.shuffle_perm(n, 10000, seed=3 + d)).to(eng.device)
+            eng.train_steps(d, perm=perm, first_step=0, n_steps=min(3, -(-n // 256)), lr=lr, optimizer=opt)
+        n = g["data"]["train"][3]["uid"].shape[0]
+        perm = torch.from_numpy(orng.shuffle_perm(n, 10000, seed=9)).to(eng.device)
+        eng.train_steps(3, perm=perm, first_step=0, n_steps=2, lr=1e-3, optimizer="accumulate")
+        out = (eng.get_weights().cpu().numpy().copy(), acc.cpu().numpy().copy(), eng._adam_m.cpu().numpy().copy(),
+               eng._adam_v.cpu().numpy().copy())
+        eng.close()
+        return out
+
+    base = run({})
+    twin = run({"MAMDR_GRAPH_NO_TAIL_OPT": "1"})
+    for a, b, what in zip(base, twin, ("weights", "accumulator", "adam m", "adam v")):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), what
+    assert np.abs(base[1]).max() > 0
+    for env in ({"MAMDR_GRAPH_NO_DEFER": "1"}, {"MAMDR_GRAPH_TILE32_BELOW": "0"}):
+        other = run(env)
+        from test_gpu_parity import assert_adam_close
+        assert_adam_close(other[0], base[0], 11, 1e-3, str(env), max_frac=2e-3)
+        # (gradients taken at weights that differ by the Adam noise above: compared in the L2 norm)
+        assert np.linalg.norm(other[1] - base[1]) < 5e-2 * np.linalg.norm(base[1]), env
+
+
 def test_invalid_configurations_say_so():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
