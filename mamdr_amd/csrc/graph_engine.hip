@@ -1633,12 +1633,18 @@ void small_tn(mamdr_graph* g, const float* in, int in_ld, const float* d, int d_
         launch_small_tn(g->stream, in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out);
         return;
     }
-    if ((int)g->tq.size() == MAX_TQ) flush_wgrads(g);
+    if ((int)g->tq.size() == MAX_TQ) {
+        g->sink.p = nullptr;
+        flush_wgrads(g);
+    }
     g->tq.push_back(mamdr_graph::TnProb{in, in_ld, d, d_ld, rows, n_j, n_e, out, sum_out});
 }
 void queue_wgrad(mamdr_graph* g, const float* A, int lda, const float* B, int ldb, float* out, int M, int N, int rows,
                  const float* dz, float* db) {
-    if ((int)g->wq.size() == MAX_WQ) flush_wgrads(g);
+    if ((int)g->wq.size() == MAX_WQ) {      // a flush in mid-step must not step parameters the backward pass still reads:
+        g->sink.p = nullptr;                // this step's gradients are stored and k_graph_adam runs at its end
+        flush_wgrads(g);
+    }
     g->wq.push_back(mamdr_graph::WProb{A, lda, B, ldb, out, M, N, rows, dz, db});
 }
 void launch_wgrad(mamdr_graph* g, GemmArgs a, int M, int N, int rows, const float* dz, float* db) {
@@ -2806,7 +2812,7 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             if (g->has_lin) launch_lin_sweep(ea, g->stream);      // (reads the row maps, then resets them)
         }
         // ---- optimiser on the two ranges this task's model trains (one launch; none when the tail launch stepped them)
-        if (!fuse_opt) {
+        if (!fuse_opt || !g->sink.p) {      // (sink dropped: a queue overflowed in mid-step)
             const int64_t off[2] = {g->dm_off, t.blk_off}, cnt[2] = {g->shared_end - g->dm_off, t.blk_end - t.blk_off};
             AdamArgs aa;
             aa.p = g->params;

@@ -124,15 +124,22 @@ ODD_SHAPES = {
 }
 
 
+# 16 experts of three layers per task: 48 weight gradients + gate + tower, more than one queue of the backward pass holds
+# (MAX_WQ = 40): the queue is flushed in mid-step and the optimiser step falls back to its own launch for that step
+MANY_SHAPES = {"ple": ((64, 64, 64), (64,), (64,), 0, 2, 14)}
+
+
 @pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
-@pytest.mark.parametrize("shapes,batch", [("config", 1024), ("odd", 448)])
+@pytest.mark.parametrize("shapes,batch", [("config", 1024), ("odd", 448), ("many", 256)])
 def test_config_shapes_at_batch_1024(kind, shapes, batch):
     """the reference's Taobao-10 multi-task configs as configured: their layer widths / expert counts, 10 domains, batch
     size 1,024 (config/Taobao-10/*.json) -- one-step gradients of every tensor on task d's path and the loss against the
     oracle on a full batch, everything off the path bit-unchanged, then three Adam steps.  "odd": widths of 192 / 320
     (reduction lengths that end inside a 128-deep stage) at a batch of 448 rows (7 tiles of 64)."""
+    if shapes == "many" and kind != "ple":
+        pytest.skip("the many-experts case is a PLE")
     g, eng, model, spec = make_problem(kind, batch=batch, dropout=0.5, scale=0.5, n_domain=10,
-                                       shapes=CONFIG_SHAPES if shapes == "config" else ODD_SHAPES)
+                                       shapes={"config": CONFIG_SHAPES, "odd": ODD_SHAPES, "many": MANY_SHAPES}[shapes])
     d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     cols = g["data"]["train"][d]
     n = cols["uid"].shape[0]
