@@ -129,15 +129,13 @@ ODD_SHAPES = {
 MANY_SHAPES = {"ple": ((64, 64, 64), (64,), (64,), 0, 2, 14)}
 
 
-@pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
-@pytest.mark.parametrize("shapes,batch", [("config", 1024), ("odd", 448), ("many", 256)])
+@pytest.mark.parametrize("kind,shapes,batch", [(k, sh, b) for sh, b in (("config", 1024), ("odd", 448))
+                                               for k in ("shared_bottom", "mmoe", "ple")] + [("ple", "many", 256)])
 def test_config_shapes_at_batch_1024(kind, shapes, batch):
     """the reference's Taobao-10 multi-task configs as configured: their layer widths / expert counts, 10 domains, batch
     size 1,024 (config/Taobao-10/*.json) -- one-step gradients of every tensor on task d's path and the loss against the
     oracle on a full batch, everything off the path bit-unchanged, then three Adam steps.  "odd": widths of 192 / 320
     (reduction lengths that end inside a 128-deep stage) at a batch of 448 rows (7 tiles of 64)."""
-    if shapes == "many" and kind != "ple":
-        pytest.skip("the many-experts case is a PLE")
     g, eng, model, spec = make_problem(kind, batch=batch, dropout=0.5, scale=0.5, n_domain=10,
                                        shapes={"config": CONFIG_SHAPES, "odd": ODD_SHAPES, "many": MANY_SHAPES}[shapes])
     d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
