@@ -16,6 +16,14 @@
 //   domain table: segment sum of d x over the batch's domain ids + 2 l2 Dm    k_graph_domain_grad
 //   TF1 Adam (or SGD) on the two ranges of the flat vector task d's model trains: the shared block (domain table +
 //   shared experts) and task d's block (its experts, gate, tower, head)       k_graph_adam     (hbm)
+// Launch plan since round 4 (the per-layer launches above remain under MAMDR_GRAPH_NO_DEFER=1):
+//   * forward / d-input contractions of fewer than 512 tiles of 64 x 64 run on 32 x 32 tiles with the reduction index
+//     split over the workgroup's four waves (gemm_tile32, k_graph_gemm32*: 4 x the workgroups, 128-deep stages);
+//   * the weight gradients are QUEUED by the backward pass and contracted in one flat grid at its end
+//     (queue_wgrad / flush_wgrads, k_graph_wgrad_multi);
+//   * one tail launch (k_graph_tail) finishes them (split sums, bias column sums), runs the narrow contractions
+//     (head / gate kernels, PNN's rows, attention projections), the domain table's and the linear table's gradients --
+//     and steps every parameter where its gradient is finished (GradSink; k_graph_adam only for the weighted loss).
 // All fp32 (`v_mfma_f32_32x32x2_f32`: exact fp32 products), every reduction in a fixed order (no float atomics).
 // Trainable user / item tables (the Amazon configs: no pretraining) sit at the head of the flat vector; their step is
 // TF1's dense Adam over every row -- regulariser gradient 2 l2 p + the scatter-add of the batch's row gradients --
