@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 15
+#define MAMDR_ABI_VERSION 16
 
 enum {
     MAMDR_OK = 0,
@@ -308,10 +308,12 @@ int mamdr_profile_enable(mamdr_ctx* ctx, int32_t enable);
  * none (that call then gathers as before).  The permutations and the bound columns must not change in between.  At
  * most 16 passes per hint (more: the first 16); everywhere else this is a no-op.  Same rows, same bits.  No reference
  * counterpart: the reference's tf.data iterator re-reads the csv files on every pass (utils/dataset.py:20-38).
- * mamdr_pregather_hits: how many calls found their pass gathered (tests). */
+ * mamdr_pregather_hits: how many calls found their pass gathered; mamdr_pregather_launches: how many hints led to a
+ * gather launch (k_pass_prep_multi) -- both for tests and reports. */
 int mamdr_pregather_passes(mamdr_ctx* ctx, int32_t n_passes, const int32_t* h_domains, const int32_t* const* h_d_perms,
                            const int64_t* h_pass_rows, int32_t batch);
 int64_t mamdr_pregather_hits(const mamdr_ctx* ctx);
+int64_t mamdr_pregather_launches(const mamdr_ctx* ctx);
 /* which kernels a training step of `batch` rows launches (for reports; no reference counterpart):
  *   0  tower -> k_wgrad (split-K slabs) -> k_update
  *   1  [k_pass_prep once per call] tower -> k_wgrad_adam (weight gradients + optimiser step in one launch;

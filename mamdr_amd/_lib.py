@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN, TOWER_NFM = 0, 1, 2, 3, 4, 5
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -84,6 +84,7 @@ SIGNATURES = {
     "mamdr_table_flushes": (_I64, [_VP, _I32]),
     "mamdr_pregather_passes": (_I32, [_VP, _I32, _VP, _VP, _VP, _I32]),
     "mamdr_pregather_hits": (_I64, [_VP]),
+    "mamdr_pregather_launches": (_I64, [_VP]),
     "mamdr_sync_tables": (C.c_int, [_VP]),
     "mamdr_bind_accumulator": (C.c_int, [_VP, _VP]),
     "mamdr_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),

@@ -83,7 +83,9 @@ def init_distributed():
     return dist.get_rank(), dist.get_world_size()
 
 
-def main(config, engine_factory=None):
+def main(config, engine_factory=None, on_model=None):
+    """run.py:71-89.  on_model(model) (optional) sees the built, wrapped model before training starts (tests attach
+    their recorders there)."""
     from .utils import MultiDomainDataset
     rank, world = init_distributed()
     name = config["model"]["name"]
@@ -92,6 +94,8 @@ def main(config, engine_factory=None):
                                   "wrappers only; got '%s'" % name)
     dataset = MultiDomainDataset(config["dataset"])
     model = build_model(config, dataset, engine_factory)
+    if on_model is not None:
+        on_model(model)
     if "separate" in name:
         avg_loss, avg_auc, domain_loss, domain_auc = model.separate_train_val_test()
     else:

@@ -132,6 +132,7 @@ struct mamdr_ctx {
     std::vector<PgEntry> pg;
     size_t pg_pos = 0;
     int64_t pg_hits = 0;            // calls served from an entry (mamdr_pregather_hits)
+    int64_t pg_launches = 0;        // hints that launched k_pass_prep_multi (mamdr_pregather_launches)
     bool gather_pf = true;          // MAMDR_NO_GATHER_PF=1: no riders in k_update's launch touching the next step's gather
     bool use_pre = true;            // MAMDR_NO_PREGATHER=1: the towers gather through perm / uid / pid every step
     float* dmsnap[2] = {nullptr, nullptr};
@@ -1104,6 +1105,7 @@ static int grow_pass_buffer(mamdr_ctx* c, int64_t rows) {
 }
 
 int64_t mamdr_pregather_hits(const mamdr_ctx* c) { return c ? c->pg_hits : 0; }
+int64_t mamdr_pregather_launches(const mamdr_ctx* c) { return c ? c->pg_launches : 0; }
 
 int mamdr_pregather_passes(mamdr_ctx* c, int32_t n_passes, const int32_t* h_domains, const int32_t* const* h_d_perms,
                            const int64_t* h_pass_rows, int32_t batch) {
@@ -1163,6 +1165,7 @@ int mamdr_pregather_passes(mamdr_ctx* c, int32_t n_passes, const int32_t* h_doma
     {
         Prof p(c, MAMDR_KERNEL_AUX);
         launch_pass_prep_multi(a, c->stream);
+        c->pg_launches++;
     }
     HIP_TRY(hipGetLastError());
     return MAMDR_OK;

@@ -51,6 +51,8 @@ class DomainNegotiation(MAML):
                 if target >= 0:        # domain_negotiation.py:89-93: the model (not theta) takes one more pass over the target
                     meta.run_pass(self.model, target, self.shuffler, self.batch_size, self.learning_rate, self.trace,
                                   "target")
+                    # (per-rank shuffle streams and Adam slots: rank 0's model is everybody's from here on)
+                    parallel.broadcast_live(self.model, src=0)
             else:
                 self.trace += meta.dn_epoch(self.model, meta_weights, list(meta_sequence), self.shuffler,
                                             self.batch_size, self.learning_rate, tc["meta_learning_rate"],

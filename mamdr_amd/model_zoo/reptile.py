@@ -47,6 +47,8 @@ class Reptile(MAML):
                 # the target domain
                 meta.run_pass(self.model, tc["target_domain"], self.shuffler, self.batch_size, self.learning_rate, self.trace,
                               "target")
+                # ... whose result differs per rank (own shuffle stream, own Adam slots): rank 0's is everybody's
+                parallel.broadcast_live(self.model, src=0)
             if world == 1:
                 self.trace += meta.reptile_epoch(self.model, meta_weights, list(train_sequence), self.shuffler,
                                                  self.batch_size, self.learning_rate, tc["meta_learning_rate"],

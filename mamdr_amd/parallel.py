@@ -541,6 +541,26 @@ class BalancedMAMDR(object):
         return trace
 
 
+def broadcast_live(eng, src=0):
+    """every rank continues from rank `src`'s LIVE model (weights + Star's moving statistics).  Needed wherever the ranks
+    trained their live models separately after the last collective and the loop goes on as if there were one model --
+    the closing pass over the target domain of Reptile / Domain Negotiation (reptile.py:98-102,
+    domain_negotiation.py:89-93): the ranks' shuffle streams and Adam slots differ by then (each drew a shuffle and
+    stepped its optimiser per OWNED domain), so the same pass from the same theta ends in different weights per rank,
+    while validation deals the domains round-robin on the premise of one model and rank 0 alone writes the checkpoint
+    (ADVICE r04).  The Adam slots stay per rank, as every optimiser slot does."""
+    rank, ws = world()
+    if ws <= 1:
+        return
+    w = eng.weights
+    dist.broadcast(w, src=src)
+    if w.data_ptr() != eng.weights.data_ptr():      # (an engine that hands out copies of its weights: the tests' CPU stand-in)
+        eng.set_weights(w)
+    aux = getattr(eng, "aux", None)
+    if aux is not None:
+        dist.broadcast(aux, src=src)
+
+
 def gather_domain_scalars(local, n_domain, device):
     """local: dict domain -> (loss, auc) for owned domains; returns full dicts on every rank."""
     rank, ws = world()

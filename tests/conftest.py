@@ -4,12 +4,52 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+# The numpy oracle's GEMMs are small (1,024 .. 8,192 rows x 384 .. 64 columns): on the GPU box (256 hardware threads,
+# OpenBLAS default 64) they ran 4 - 6x SLOWER than on 8 threads -- 14 / 72 ms per oracle step at bs 1,024 / 4,096 against
+# 3.8 / 12.7 ms (profiles/r05_oracle_threads.txt, tests/diag_oracle_threads.py).  Results do not depend on it beyond
+# BLAS' own blocking (the bars of the parity tests are ~1e-3, rounding ~1e-7).
+BLAS_THREADS = int(os.environ.get("MAMDR_TEST_BLAS_THREADS", "8"))
+try:
+    from threadpoolctl import threadpool_limits
+    _blas_limit = threadpool_limits(limits=BLAS_THREADS, user_api="blas")      # kept for the whole session
+except Exception:                                                              # pragma: no cover
+    _blas_limit = None
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "oracle_job(name, **kwargs): the test reads the result of tests/oracle_jobs.py's "
+                                       "job `name`; selected jobs start in worker processes when the session starts")
+
+
+def pytest_collection_finish(session):
+    """start the heavy oracle runs of the SELECTED tests in worker processes, all at once, so that they compute
+    while the HIP side of the suite runs (tests/oracle_jobs.py).  Only where a GPU is visible: without one the tests
+    that would read them skip.  (device_count() does not initialise the GPU; the workers are spawned, not forked.)"""
+    keys = []
+    for item in session.items:
+        for m in item.iter_markers("oracle_job"):
+            keys.append((m.args[0], dict(m.kwargs)))
+    if not keys or os.environ.get("MAMDR_TEST_NO_ORACLE_POOL"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() == 0:
+            return
+    except Exception:
+        return
+    import oracle_jobs      # (tests/ is on sys.path: rootdir conftest)
+    oracle_jobs.start(keys, BLAS_THREADS)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    mod = sys.modules.get("oracle_jobs")
+    if mod is not None:
+        mod.shutdown()
 
 
 @pytest.fixture(scope="session")

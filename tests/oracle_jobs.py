@@ -1,0 +1,368 @@
+"""The heavy runs of the numpy oracle that the GPU parity tests compare with, as jobs of a worker-process pool
+(test infrastructure; nothing under mamdr_amd/ imports this).
+
+Round 4's GPU suite spent ~500 of its 606 s inside the oracle, one case after the other, while the GPU idled.  The jobs
+below are pure functions of their arguments (seeded inputs, no GPU): `conftest.pytest_collection_finish` starts the
+jobs of every SELECTED test (marker `oracle_job(name, **kwargs)`) in spawned worker processes when the session starts,
+and a test collects its result with `result(name, **kwargs)` after its HIP side has run.  The oracle still runs LIVE in
+every session -- no stored outputs that could go stale -- only concurrently.  `problem_*` helpers build the seeded
+inputs; the tests call the same helpers for the HIP side, so both sides see the same tensors by construction.
+"""
+import os
+import time
+
+import numpy as np
+
+F32 = np.float32
+SHUFFLE_SEED = 0x5eed
+DROPOUT_SEED = 1024          # mamdr_amd.engine.TowerEngine's default (asserted by the tests)
+
+_pool = None
+_futures = {}
+
+
+def _key(name, kwargs):
+    return (name,) + tuple(sorted(kwargs.items()))
+
+
+def _init_worker(blas_threads):
+    try:
+        from threadpoolctl import threadpool_limits
+        globals()["_limit"] = threadpool_limits(limits=blas_threads, user_api="blas")
+    except Exception:
+        pass
+
+
+def start(keys, blas_threads=8):
+    """keys: [(job name, kwargs)].  One worker per job (they all start at once; the GPU box has 256 hardware threads)."""
+    global _pool
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    uniq = []
+    for name, kw in keys:
+        if _key(name, kw) not in [_key(*u) for u in uniq]:
+            uniq.append((name, kw))
+    todo = [u for u in uniq if _key(*u) not in _futures]
+    if not todo:
+        return
+    if _pool is None:
+        n = min(len(uniq), max(1, (os.cpu_count() or 8) // max(1, blas_threads)), 16)
+        _pool = ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn"), initializer=_init_worker,
+                                    initargs=(blas_threads,))
+    # longest first (matters only when there are more jobs than workers)
+    todo.sort(key=lambda u: -COST.get(u[0], 1.0) * float(u[1].get("epochs", 1)))
+    for name, kw in todo:
+        _futures[_key(name, kw)] = _pool.submit(_run, name, kw)
+
+
+def _run(name, kw):
+    t0 = time.time()
+    out = JOBS[name](**kw)
+    out["job_seconds"] = time.time() - t0
+    return out
+
+
+def result(name, **kw):
+    """the job's result: from the pool if the session started it, else computed here."""
+    f = _futures.get(_key(name, kw))
+    if f is None:
+        return _run(name, kw)
+    t0 = time.time()
+    out = f.result(timeout=1500)
+    out["waited_seconds"] = time.time() - t0
+    return out
+
+
+def shutdown():
+    global _pool
+    if _pool is not None:
+        for f in _futures.values():
+            f.cancel()
+        procs = list(getattr(_pool, "_processes", {}).values())
+        _pool.shutdown(wait=False, cancel_futures=True)
+        for p in procs:                  # a job still running when the session ends (a failed -x run) is not waited for
+            if p.is_alive():
+                p.terminate()
+        _pool = None
+    _futures.clear()
+
+
+# ---------------------------------------------------------------------------------------------- MAMDR epochs, frozen tables
+def problem_fullsize(shape, batch, epochs, seed=123):
+    """BASELINE.json configs[1] / configs[3]: every domain, full tables, full splits, the config's sample_num 5 +
+    add_query_domain + shuffled sequence (config/Taobao-10/deepctr_DN+DR.json), phi_d = a second random initialisation of
+    the whole model (mamdr.py:31-33)."""
+    from mamdr_amd import plan as mplan
+    from mamdr_amd import synthetic
+    from oracle import tower as otower
+    g = synthetic.generate(shape, batch_size=batch, seed=seed)
+    params = otower.init_params(np.random.RandomState(1024), g["n_user"], g["n_item"], g["n_domain"])
+    params["user_emb"], params["item_emb"] = g["tables"]["user_emb"], g["tables"]["item_emb"]
+    D = g["n_domain"]
+    planner = mplan.EpochPlanner(range(D), 5, True, True, seed=123)
+    plans = [planner.next_epoch() for _ in range(epochs)]
+    names = otower.param_names(False)
+    phis0 = [otower.flatten(otower.init_params(np.random.RandomState(2000 + d), 8, 8, D), names) for d in range(D)]
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    return dict(g=g, params=params, plans=plans, names=names, phis0=phis0, sizes=sizes, D=D)
+
+
+def job_fullsize_mamdr(shape, batch, meta_lr, epochs):
+    """oracle/loops.mamdr_epoch (model_zoo/mamdr.py:41-108) x epochs, then every domain's validation AUC with the merged
+    weights theta + phi_d (specific_base_model.py:64-97).  The per-pass shuffles are plan.PassShuffler's stream -- the
+    one plan.EpochShuffles hands the HIP side."""
+    from mamdr_amd import plan as mplan
+    from oracle import auc as oauc
+    from oracle import loops as oloops
+    from oracle import outer as oouter
+    from oracle import tower as otower
+    pb = problem_fullsize(shape, batch, epochs)
+    g, params = pb["g"], pb["params"]
+    model = otower.OracleModel({k: (v if k in ("user_emb", "item_emb") else v.copy()) for k, v in params.items()},
+                               dropout=0.5, lr=1e-3, dropout_seed=DROPOUT_SEED)
+    theta = model.get_flat().copy()
+    phis = [p.copy() for p in pb["phis0"]]
+    shuf = mplan.PassShuffler(pb["sizes"], 10000, SHUFFLE_SEED)
+    t0 = time.time()
+    trace = []
+    for plan in pb["plans"]:
+        trace += oloops.mamdr_epoch(model, theta, phis, g["data"]["train"], plan, shuf, batch, meta_lr)
+    secs = time.time() - t0
+    aucs = []
+    for d in range(pb["D"]):
+        model.set_flat(oouter.merge(theta, phis[d], "plus"))
+        _, preds = model.evaluate(g["data"]["val"][d], batch)
+        aucs.append(float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch)))
+    return dict(trace=trace, aucs=aucs, secs=secs, theta=theta)
+
+
+# ---------------------------------------------------------------------------------------------- configs[2]: DeepFM + DN
+def perm_stream(sizes, base):
+    from mamdr_amd import engine
+    k = [0]
+
+    def perm_fn(d):
+        k[0] += 1
+        return engine.shuffle_perm(sizes[d], 10000, base + k[0])
+    return perm_fn
+
+
+def problem_amazon6(batch=1024, steps=160):
+    from mamdr_amd import synthetic
+    from oracle import tower as otower
+    shape = synthetic.SHAPES["amazon6"]
+    g = synthetic.generate("amazon6", batch_size=batch, seed=123, row_scale=steps * batch / shape["n_train"],
+                           splits=("train", "val"), hot=dict(users=2000, items=1000, share=0.7))
+    D = g["n_domain"]
+    params = otower.init_params(np.random.RandomState(1024), g["n_user"], g["n_item"], D, pretrained=False)
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    seq = [int(d) for d in np.random.RandomState(5).permutation(D)]
+    return dict(g=g, params=params, sizes=sizes, seq=seq, D=D)
+
+
+def job_amazon6_dn(batch=1024):
+    from oracle import auc as oauc
+    from oracle import loops as oloops
+    from oracle import tower as otower
+    pb = problem_amazon6(batch)
+    g = pb["g"]
+    model = otower.OracleModel(pb["params"], emb_trainable=True, dropout=0.5, lr=1e-3, dropout_seed=DROPOUT_SEED,
+                               tower="deepfm")
+    theta = model.get_flat().copy()
+    t0 = time.time()
+    trace = oloops.dn_epoch(model, theta, g["data"]["train"], pb["seq"], perm_stream(pb["sizes"], 500), batch, 0.5)
+    secs = time.time() - t0
+    model.set_flat(theta)
+    aucs = []
+    for d in range(pb["D"]):
+        _, preds = model.evaluate(g["data"]["val"][d], batch)
+        aucs.append(float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch)))
+    from oracle import bigtable
+    return dict(trace=trace, aucs=aucs, secs=secs,
+                tables={n: np.ascontiguousarray(bigtable.densify(model.params[n]), F32) for n in ("user_emb", "item_emb")})
+
+
+# ---------------------------------------------------------------------------------------------- configs[4]: Star + MAMDR
+class StarMeta(object):
+    """oracle Star model seen through its meta parameters (what the MAMDR loop reads and assigns, maml.py:153-194)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def get_flat(self):
+        return self.m.get_flat(meta_only=True)
+
+    def set_flat(self, vec):
+        self.m.set_flat(vec, meta_only=True)
+
+    def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
+        assert accumulate_into is None
+        return self.m.train_pass(data, perm, batch_size, max_steps)
+
+
+def problem_amazon13(batch=8192, keras_init=False):
+    """keras_init: PartitionedNorm gamma = 1 / beta = 0 (Star/partitioned_norm.py:19-22), zero biases (star_fcn.py:24-25)
+    and phi_d = a second random initialisation (mamdr.py:31-33) -- the state `star_meta_mamdr` really starts from.
+    Otherwise (round 4's conditioning): PN / biases moved off their special values, phi_d = 0."""
+    from mamdr_amd import synthetic
+    from oracle import star as ostar
+    shape = synthetic.SHAPES["amazon13"]
+    g = synthetic.generate("amazon13", batch_size=batch, seed=123, row_scale=90000 * 13 / shape["n_train"] / 3,
+                           splits=("train", "val"), hot=dict(users=3000, items=1500, share=0.8))
+    D = g["n_domain"]
+    all_sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    doms = sorted(range(D), key=lambda d: -all_sizes[d])[:4]
+    params = ostar.init_params(np.random.RandomState(1024), g["n_user"], g["n_item"], D)
+    if not keras_init:
+        irs = np.random.RandomState(7)
+        for n_ in ("pn_gamma_shared", "pn_gamma_spec"):
+            params[n_] = (params[n_] + irs.standard_normal(params[n_].shape) * 0.2).astype(F32)
+        for n_ in ("pn_beta_shared", "pn_beta_spec", "bs0", "bs1", "bs2", "bd0", "bd1", "bd2", "gb"):
+            params[n_] = (irs.standard_normal(params[n_].shape) * 0.05).astype(F32)
+    prs = np.random.RandomState(3)
+    plan = {"seq": [doms[i] for i in prs.permutation(4)], "dr": []}
+    for q in [doms[i] for i in prs.permutation(4)]:
+        plan["dr"].append((q, [doms[i] for i in prs.permutation(4) if doms[i] != q][:2] + [q]))
+    return dict(g=g, params=params, plan=plan, doms=doms, all_sizes=all_sizes, D=D)
+
+
+def star_phi0(pb, d, n_meta, names_meta=None):
+    """phi_d of the keras_init variant: the meta part of a second random initialisation of the model, seed 2000 + d
+    (mamdr.py:31-33).  The two big tables are drawn in place of a full second model (2 x 92 M normals per domain)."""
+    from oracle import star as ostar
+    g = pb["g"]
+    p2 = ostar.init_params(np.random.RandomState(2000 + d), g["n_user"], g["n_item"], pb["D"])
+    m2 = ostar.OracleStar(p2, emb_trainable=True, lr=1e-3)
+    v = m2.get_flat(meta_only=True).copy()
+    assert v.size == n_meta
+    return v
+
+
+def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0):
+    """oracle/loops.mamdr_epoch on oracle/star.OracleStar (dense Adam over every table row and every per-domain slice
+    each step).  perturb > 0: every initial tensor multiplied by (1 + perturb * N(0, 1)) elementwise in fp32 -- a second
+    oracle run whose distance from the first measures the oracle's own sensitivity to rounding-level input changes
+    (the instrument of tests/test_gpu_parity.py's miniature Star test, here at the full table size)."""
+    from oracle import auc as oauc
+    from oracle import loops as oloops
+    from oracle import outer as oouter
+    from oracle import star as ostar
+    pb = problem_amazon13(batch, keras_init)
+    g, doms, plan = pb["g"], pb["doms"], pb["plan"]
+    params = pb["params"]
+    if perturb > 0:
+        prs = np.random.RandomState(99)
+        for n_ in sorted(params):
+            a = params[n_]
+            if a.dtype == F32:
+                params[n_] = (a * (F32(1) + F32(perturb) * prs.standard_normal(a.shape).astype(F32))).astype(F32)
+    model = ostar.OracleStar(params, emb_trainable=True, lr=1e-3)
+    wrapped = StarMeta(model)
+    theta = wrapped.get_flat().copy()
+    if keras_init:
+        phis = {d: star_phi0(pb, d, theta.size) for d in doms}
+    else:
+        phis = {d: np.zeros_like(theta) for d in doms}
+    t0 = time.time()
+    trace = oloops.mamdr_epoch(wrapped, theta, phis, g["data"]["train"], plan, perm_stream(pb["all_sizes"], 900), batch, 0.5)
+    secs = time.time() - t0
+    aucs = {}
+    for d in doms:
+        wrapped.set_flat(oouter.merge(theta, phis[d], "plus"))
+        _, preds = model.evaluate(g["data"]["val"][d], batch)
+        aucs[d] = float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch))
+    tail = {n: np.array(model.params[n], F32).ravel() for n in ostar.param_names(True)[1]}
+    return dict(trace=trace, aucs=aucs, secs=secs, tail=tail, n_meta=theta.size,
+                mov_mean={d: model.state["mov_mean"][d].copy() for d in doms},
+                mov_var={d: model.state["mov_var"][d].copy() for d in doms}, steps=model.state["steps"].copy())
+
+
+# ---------------------------------------------------------------------------------------------- run.py end to end
+class Recorder(object):
+    """what the run.py pipeline decided, epoch by epoch: attached to a built model (cli.main's `on_model`), it wraps
+    `val_and_test` and `early_stop_step` of the outermost wrapper and reads the traces / finetune log afterwards.
+    Everything it keeps is plain python (it travels back from the worker process)."""
+
+    def __init__(self):
+        self.events = []
+        self.model = None
+
+    def attach(self, model):
+        self.model = model
+        rec = self.events
+        vt, es = model.val_and_test, model.early_stop_step
+        base = getattr(model, "base_model", model)
+
+        def val_and_test(mode):
+            out = vt(mode)
+            rec.append(("eval", mode, float(out[0]), float(out[1]), {int(k): float(v) for k, v in out[2].items()},
+                        {int(k): float(v) for k, v in out[3].items()}))
+            return out
+
+        def early_stop_step(metric):
+            stop = es(metric)
+            rec.append(("early_stop", float(metric), float(base.best_metric), int(base.counter), bool(stop)))
+            return stop
+        model.val_and_test = val_and_test
+        model.early_stop_step = early_stop_step
+
+    def summary(self, result):
+        model = self.model
+        base = getattr(model, "base_model", model)
+        return dict(events=self.events, trace=[tuple(t) for t in getattr(model, "trace", [])],
+                    finetune_log={int(d): dict(v) for d, v in getattr(base, "finetune_log", {}).items()},
+                    result=(float(result[0]), float(result[1]), {int(k): float(v) for k, v in result[2].items()},
+                            {int(k): float(v) for k, v in result[3].items()}))
+
+
+def pipeline_config(cfg_file, name, tmp, train=None, dataset=None):
+    import copy
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "config", cfg_file)) as f:
+        cfg = copy.deepcopy(json.load(f))
+    if name:
+        cfg["model"]["name"] = name
+    cfg["train"].update(result_save_path=os.path.join(tmp, "result"), checkpoint_path=os.path.join(tmp, "ckpt"))
+    cfg["train"].update(train or {})
+    cfg["dataset"].update(dataset or {})
+    return cfg
+
+
+def run_pipeline(cfg, engine_factory=None):
+    """mamdr_amd.cli.main (= the reference's run.py:71-89: train -> val / early stop -> best state -> test -> finetune ->
+    save_result) with a Recorder attached.  -> the Recorder's summary + result.json as written."""
+    import json
+    from mamdr_amd import cli
+    rec = Recorder()
+    out = cli.main(cfg, engine_factory, on_model=rec.attach)
+    s = rec.summary(out)
+    rdir = cfg["train"]["result_save_path"]
+    found = [os.path.join(r, "result.json") for r, _, fs in os.walk(rdir) if "result.json" in fs]
+    with open(found[0]) as f:
+        s["result_json"] = json.load(f)
+    return s
+
+
+def job_pipeline(cfg_file, name, train, dataset):
+    """the oracle twin of a whole run: the SAME host code (cli.main, model_zoo/*, meta.py) on tests/fake_engine.FakeEngine,
+    i.e. every numeric call answered by the numpy oracle.  train / dataset: tuples of (key, value) overrides."""
+    import contextlib
+    import io
+    import tempfile
+    from fake_engine import FakeEngine
+    tmp = tempfile.mkdtemp(prefix="mamdr_twin_")
+    cfg = pipeline_config(cfg_file, name, tmp, dict(train), dict(dataset))
+    buf = io.StringIO()
+    t0 = time.time()
+    with contextlib.redirect_stdout(buf):
+        s = run_pipeline(cfg, FakeEngine)
+    s["secs"] = time.time() - t0
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return s
+
+
+JOBS = {"fullsize_mamdr": job_fullsize_mamdr, "amazon6_dn": job_amazon6_dn, "amazon13_star": job_amazon13_star,
+        "pipeline": job_pipeline}
+COST = {"fullsize_mamdr": 1.0, "amazon6_dn": 1.5, "amazon13_star": 2.0, "pipeline": 6.0}

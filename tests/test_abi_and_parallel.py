@@ -330,10 +330,13 @@ from mamdr_amd import cli, synthetic
 real = synthetic.generate
 synthetic.generate = lambda *a, **k: real(*a, **dict(k, emb_dim=8))          # tiny tables for CPU speed
 cfg = json.load(open({cfg!r}))
-res = cli.main(cfg, FakeEngine)                  # run.py's entry; init_distributed() reads RANK / WORLD_SIZE
+built = []
+res = cli.main(cfg, FakeEngine, on_model=built.append)   # run.py's entry; init_distributed() reads RANK / WORLD_SIZE
 rank = int(os.environ.get("RANK", "0"))
-json.dump({{"avg_loss": res[0], "avg_auc": res[1], "domain_auc": {{str(k): v for k, v in res[3].items()}}}},
-          open({out!r} % rank, "w"))
+import hashlib
+sha = hashlib.sha1(built[0].model.weights.numpy().tobytes()).hexdigest()      # the LIVE model this rank ends with
+json.dump({{"avg_loss": res[0], "avg_auc": res[1], "domain_auc": {{str(k): v for k, v in res[3].items()}},
+           "weights_sha": sha}}, open({out!r} % rank, "w"))
 print("rank", rank, "ok")
 '''
 
@@ -399,6 +402,12 @@ def _run_entry_worlds(tmp_path, name, extra=None):
             assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
         results[world] = [json.load(open(str(tmp_path / ("res_%d.json" % r)))) for r in range(world)]
     a, b = results[2]
+    sha = [r.pop("weights_sha") for r in (a, b)]
+    if (extra or {}).get("target_domain", -1) >= 0 and "mamdr" not in name:
+        # the closing pass over the target domain ran on every rank with its own shuffle stream and Adam slots: the ranks
+        # must still END with one live model (parallel.broadcast_live) -- validation deals the domains
+        # round-robin on that premise and rank 0 alone writes the checkpoint
+        assert sha[0] == sha[1], sha
     assert a == b and sorted(a["domain_auc"]) == ["0", "1", "2"]          # every rank holds every domain's result
     assert np.isfinite(a["avg_loss"]) and abs(a["avg_auc"] - results[1][0]["avg_auc"]) < 0.1
 

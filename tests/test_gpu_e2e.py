@@ -1,0 +1,186 @@
+"""The reference's deliverable, compared end to end on the GPU: `run.py --config` = train() (meta epochs -> val() with merged
+weights -> early_stop_step -> best theta / phi copies) -> val_and_test("test") from the best state -> finetune ->
+save_result (/root/reference/run.py:71-89, model_zoo/mamdr.py:145-159, specific_base_model.py:44-162,
+base_model.py:41-109,183-224).
+
+Both sides run THE SAME host code -- mamdr_amd.cli.main, model_zoo/*, meta.py -- once on the HIP engine (the product) and
+once, in a worker process (tests/oracle_jobs.py), on tests/fake_engine.FakeEngine, where every numeric call is answered
+by the numpy oracle.  Plans, shuffles, dropout masks and initial tensors are functions of the config's seed on both
+sides.  What is compared is everything the pipeline decides and reports:
+  * the trace of (phase, domain, steps) of the whole training;
+  * per epoch: every domain's validation AUC (<= 1e-3, north_star's bar) and loss, the early-stopping metric, counter and
+    decision, the per-epoch test AUC from the best state;
+  * the finetune stage: per domain the epochs run, the kept checkpoint's epoch, every epoch's val AUC;
+  * the returned per-domain test AUC / loss and result.json.
+Decisions are comparisons of nearly equal numbers; two runs whose metrics differ by delta can only decide differently
+where the oracle's own comparison was closer than 2 delta (the tie logic of tests/test_gpu_run.py's finetune test): every
+decision with a larger margin MUST be identical, asserted; a run all of whose meta-level decisions are clear-cut must
+stop in the same epoch and keep the same best epoch.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_jobs
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+# (config file, model name or None = the file's, train overrides, dataset overrides, expectations)
+CASES = {
+    # BASELINE.json configs[1] AS CONFIGURED: full rows, bs 1,024, sample_num 5, meta lr 0.1, patience 3; only `epoch` capped
+    "taobao10_mamdr_finetune_as_configured": dict(
+        cfg_file="Taobao-10/deepctr_DN+DR.json", name=None, train=(("epoch", 6),), dataset=(), min_auc=0.75,
+        want_early_stop=False),
+    # the same pipeline where early stopping DOES fire (the counter, the stop and the restore of an EARLIER best state are
+    # exercised; the oracle stops after 4 epochs and keeps epoch 1, its comparisons >= 5e-4 apart): half of the rows, bs 512,
+    # larger steps, patience 2
+    "taobao10_mamdr_finetune_early_stop": dict(
+        cfg_file="Taobao-10/deepctr_DN+DR.json", name=None,
+        train=(("epoch", 12), ("patience", 2), ("meta_learning_rate", 0.3), ("learning_rate", 0.005)),
+        dataset=(("batch_size", 512), ("synthetic_scale", 0.5)), min_auc=0.6, want_early_stop=True),
+    # BASELINE.json configs[2]'s name and file (DeepFM + Domain Negotiation, trainable tables, no pretraining) on a row /
+    # table sample of the Amazon-6 shape
+    "amazon6_deepfm_dn": dict(
+        cfg_file="Amazon_6/deepfm_DN.json", name=None, train=(("epoch", 4), ("meta_learning_rate", 0.5)),
+        dataset=(("synthetic_scale", 0.01),), min_auc=0.5, want_early_stop=False),
+}
+
+
+def _job_kwargs(case):
+    c = CASES[case]
+    return dict(cfg_file=c["cfg_file"], name=c["name"], train=c["train"], dataset=c["dataset"])
+
+
+def _evals(s, mode):
+    return [e for e in s["events"] if e[0] == "eval" and e[1] == mode]
+
+
+def _finetune_margin(v):
+    """how close the oracle's own Keras EarlyStopping(min_delta 1e-4) / ModelCheckpoint(best only) comparisons came to a
+    tie (base_model.py:75-83)."""
+    margins, best = [], -np.inf
+    for a in v:
+        margins.append(abs(a - 1e-4 - best))
+        if a - 1e-4 > best:
+            best = a
+    ck = min([abs(a - b) for i, a in enumerate(v) for b in v[:i]] or [1.0])
+    return min(min(margins), ck)
+
+
+def compare(case, s_h, s_o):
+    c = CASES[case]
+    # --- meta-level: validation per epoch, early stopping, the test score from the best state
+    val_h, val_o = _evals(s_h, "val"), _evals(s_o, "val")
+    es_h = [e for e in s_h["events"] if e[0] == "early_stop"]
+    es_o = [e for e in s_o["events"] if e[0] == "early_stop"]
+    k = min(len(val_h), len(val_o))
+    assert k >= 2
+    worst_val, worst_loss, delta = 0.0, 0.0, 1e-7
+    for e in range(k):
+        _, _, loss_h, auc_h, dl_h, da_h = val_h[e]
+        _, _, loss_o, auc_o, dl_o, da_o = val_o[e]
+        assert sorted(da_h) == sorted(da_o)
+        for d in da_o:
+            worst_val = max(worst_val, abs(da_h[d] - da_o[d]))
+            worst_loss = max(worst_loss, abs(dl_h[d] - dl_o[d]))
+            assert abs(da_h[d] - da_o[d]) <= 1e-3, ("val AUC", case, e, d, da_h[d], da_o[d])
+            assert abs(dl_h[d] - dl_o[d]) <= 2e-3 * max(1.0, abs(dl_o[d])), ("val loss", case, e, d, dl_h[d], dl_o[d])
+        assert abs(es_h[e][1] - es_o[e][1]) <= 1e-3
+        delta = max(delta, abs(es_h[e][1] - es_o[e][1]) + 1e-7)
+    # the oracle's own early-stopping comparisons (`metric <= best`: base_model.py:202-224): margin of each
+    margins, best = [], None
+    for e, ev in enumerate(es_o):
+        if best is not None:
+            margins.append(abs(ev[1] - best))
+        best = ev[1] if best is None or ev[1] > best else best
+    clear = all(m > 2 * delta for m in margins)
+    stopped_o = bool(es_o[-1][4])
+    print("%s: %d / %d epochs (hip / oracle), early stop %s / %s, closest early-stop comparison %.1e vs delta %.1e%s" % (
+        case, len(val_h), len(val_o), bool(es_h[-1][4]), stopped_o, min(margins) if margins else float("nan"), delta,
+        "" if clear else " (a tie within 2 delta)"))
+    print("  worst per-domain |d val AUC| %.1e, |d val loss| %.1e over %d epochs x %d domains" % (
+        worst_val, worst_loss, k, len(val_o[0][5])))
+    for e in range(k):                              # every decision the oracle made with a margin: identical
+        if e == 0 or margins[e - 1] > 2 * delta:
+            assert es_h[e][3:] == es_o[e][3:], ("early-stop decision", case, e, es_h[e], es_o[e])
+        else:
+            break                                   # (after a tie the two runs may hold different best states)
+    if c["want_early_stop"]:
+        assert stopped_o and len(val_o) < dict(c["train"])["epoch"], "the case is meant to stop early: %r" % (es_o,)
+    if clear:
+        assert len(val_h) == len(val_o) and [e[3:] for e in es_h] == [e[3:] for e in es_o]
+        assert s_h["trace"] == s_o["trace"]
+        best_h = int(np.argmax([e[1] for e in es_h]))
+        best_o = int(np.argmax([e[1] for e in es_o]))
+        assert best_h == best_o
+        # val_and_test("test") after every non-stopping epoch + the one after training: all from the best state so far
+        t_h, t_o = _evals(s_h, "test"), _evals(s_o, "test")
+        assert len(t_h) == len(t_o)
+        worst_test = 0.0
+        for a, b in zip(t_h, t_o):
+            for d in b[5]:
+                worst_test = max(worst_test, abs(a[5][d] - b[5][d]))
+                assert abs(a[5][d] - b[5][d]) <= 1e-3, ("test AUC", case, d, a[5][d], b[5][d])
+        print("  best epoch %d on both sides; worst per-domain |d test AUC| from the best state %.1e over %d evaluations" % (
+            best_o, worst_test, len(t_o)))
+    else:
+        n = min(len(s_h["trace"]), len(s_o["trace"]))
+        assert s_h["trace"][:n // 2] == s_o["trace"][:n // 2]
+    # --- finetune stage (names with `finetune`): per domain, Keras EarlyStopping + best-only checkpoint
+    fl_h, fl_o = s_h["finetune_log"], s_o["finetune_log"]
+    assert sorted(fl_h) == sorted(fl_o)
+    decided = 0
+    for d in sorted(fl_o):
+        o, h = fl_o[d], fl_h[d]
+        kk = min(o["epochs"], h["epochs"])
+        dv = np.abs(np.array(o["val_auc"][:kk]) - np.array(h["val_auc"][:kk]))
+        assert dv.max() <= 1e-3, ("finetune val AUC", case, d, o, h)
+        d_ft = float(dv.max()) + 1e-7
+        if clear and _finetune_margin(o["val_auc"]) > 2 * d_ft:
+            decided += 1
+            assert (h["epochs"], h["best_epoch"]) == (o["epochs"], o["best_epoch"]), ("finetune decisions", case, d, o, h)
+    if fl_o:
+        print("  finetune: %d of %d domains clear-cut and identical (epochs run, kept checkpoint)" % (decided, len(fl_o)))
+        if clear:
+            assert decided >= len(fl_o) // 2
+    # --- what run.py returns and writes
+    (loss_h, auc_h, dl_h, da_h), (loss_o, auc_o, dl_o, da_o) = s_h["result"], s_o["result"]
+    worst = max(abs(da_h[d] - da_o[d]) for d in da_o)
+    print("  returned: avg test AUC hip %.5f oracle %.5f, worst per-domain |d| %.1e; avg loss %.5f / %.5f" % (
+        auc_h, auc_o, worst, loss_h, loss_o))
+    assert worst <= 1e-3 and abs(auc_h - auc_o) <= 1e-3
+    assert abs(loss_h - loss_o) <= 2e-3 * max(1.0, abs(loss_o))
+    assert auc_o > c["min_auc"], auc_o                          # a model that has learnt
+    for s, (lo, au, dl, da) in ((s_h, s_h["result"]), (s_o, s_o["result"])):
+        rj = s["result_json"]
+        assert abs(rj["avg_auc"] - au) < 1e-12 and abs(rj["avg_loss"] - lo) < 1e-12
+        assert {int(k_): v for k_, v in rj["domain_auc"].items()} == da
+    rh, ro = s_h["result_json"], s_o["result_json"]
+    assert abs(rh["avg_auc"] - ro["avg_auc"]) <= 1e-3
+    for d in ro["domain_auc"]:
+        assert abs(rh["domain_auc"][d] - ro["domain_auc"][d]) <= 1e-3
+
+
+def _case_param(case):
+    return pytest.param(case, marks=pytest.mark.oracle_job("pipeline", **_job_kwargs(case)), id=case)
+
+
+@pytest.mark.parametrize("case", [_case_param(c) for c in CASES])
+def test_run_pipeline_matches_oracle_twin(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    kw = _job_kwargs(case)
+    tmp = tempfile.mkdtemp(prefix="mamdr_e2e_")
+    cfg = oracle_jobs.pipeline_config(kw["cfg_file"], kw["name"], tmp, dict(kw["train"]), dict(kw["dataset"]))
+    import time
+    t0 = time.time()
+    s_h = oracle_jobs.run_pipeline(cfg)                         # the product: HIP engine behind cli.main
+    t_h = time.time() - t0
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    s_o = oracle_jobs.result("pipeline", **kw)                  # the oracle twin (worker process)
+    print("%s: hip %.1f s, oracle twin %.1f s (waited %.1f s)" % (case, t_h, s_o["secs"], s_o.get("waited_seconds", 0.0)))
+    compare(case, s_h, s_o)
