@@ -66,15 +66,23 @@ def init_distributed():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        # an explicit timeout: a rank that hangs in the preflight's ring or in a collective is cut after
+        # minutes, not after the backend's default of 10 - 30; MAMDR_COMM_TIMEOUT (seconds) overrides
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("MAMDR_COMM_TIMEOUT", "300")))
         if os.environ.get("MAMDR_SHARE_GPU") == "1":
             if torch.cuda.is_available():
                 torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timeout)
         else:
-            if torch.cuda.device_count() < ws:
-                raise RuntimeError("%d ranks but %d visible GPUs (one process per GPU)" % (ws, torch.cuda.device_count()))
+            # one process per GPU OF THIS NODE: LOCAL_WORLD_SIZE ranks share the node's devices (WORLD_SIZE counts the
+            # ranks of every node)
+            local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", str(local + 1)))
+            if torch.cuda.device_count() < max(local_ws, local + 1):
+                raise RuntimeError("%d local ranks but %d visible GPUs (one process per GPU)" % (
+                    max(local_ws, local + 1), torch.cuda.device_count()))
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl")
+            dist.init_process_group("nccl", timeout=timeout)
         # first contact with the communicator: values of an all-reduce, a send / recv ring and a broadcast checked on
         # every rank; a failing ring switches the phi hand-over to broadcasts (parallel.preflight)
         from . import parallel

@@ -1240,7 +1240,8 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     bool build_wT = need_wT && !c->wT_valid;
     bool w2_direct = false;
     if (build_wT && pre && c->w2_direct_ok && optimizer != MAMDR_OPT_ACCUMULATE && !c->t4_no_w1l && c->tower_tile != 16 &&
-        tower4_w1l_ready()) {
+        tower4_w1l_ready() &&
+        tower4_takes_w1l(std::min<int64_t>(batch, pass_rows - first_step * (int64_t)batch), c->t4_no_w1l)) {
         build_wT = false;
         w2_direct = true;
     }

@@ -591,6 +591,7 @@ void launch_tower_eval(const TowerArgs& a, hipStream_t s);
 void launch_tower4_train(const TowerArgs& a, hipStream_t s);
 // the W1-image instance of the pre-gathered tower can run (its LDS limit was granted): grids of up to one tile per CU
 bool tower4_w1l_ready();
+bool tower4_takes_w1l(int64_t rows, int no_w1l);      // launch_tower4_train's choice of the W1-image instance for a batch
 void launch_transpose_w(const float* dense, const DenseLayout& L, float* wT, hipStream_t s);
 struct EvalFinishArgs {
     const float* loss_part;

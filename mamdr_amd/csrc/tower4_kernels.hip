@@ -1006,11 +1006,17 @@ static int t4_cu_count() {
     }
     return n;
 }
+// the predicate BOTH the launcher and the caller's w2_direct decision use (they disagreed on devices with
+// fewer CUs than a batch has four-row tiles -- a CPX partition -- and the launcher aborted)
+bool tower4_takes_w1l(int64_t rows, int no_w1l) {
+    const int64_t tiles = ((rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);
+    return !no_w1l && tiles <= t4_cu_count();
+}
 void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
     const dim3 grid(tiles);
     const bool dx = a.dxe != nullptr;
-    const bool w1l = !a.no_w1l && tiles <= t4_cu_count();
+    const bool w1l = tower4_takes_w1l(a.rows, a.no_w1l);
     if (a.deepfm) {
         if (dx) launch_tower4_inst<true, true, false>(a, grid, w1l, s);
         else launch_tower4_inst<false, true, false>(a, grid, w1l, s);

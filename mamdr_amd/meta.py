@@ -273,7 +273,11 @@ def dr_query(eng, theta, phi, query, support, perm_fn, batch_size, lr, meta_lr, 
     assigned = False
     if pw is None:
         pw = PassWindow(eng, perm_fn, batch_size)
-    pw.announce([x for j in support for x in (j, query)])
+    # (a query pass capped to `domain_regulation_step` steps runs over the first few batches of its shuffle only: announced,
+    # ALL of the query domain's rows would be gathered once per support domain and evict useful rows from the window --
+    # ADVICE r04; no hint then, every call gathers exactly the rows its steps read)
+    capped = bool(domain_regulation_step and domain_regulation_step > 0)
+    pw.announce([] if capped else [x for j in support for x in (j, query)])
     for k, j in enumerate(support):
         if not assigned:
             eng.assign_meta(merged)

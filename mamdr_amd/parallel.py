@@ -51,9 +51,12 @@ def p2p_possible(device):
 def preflight(device, payload=4096):
     """First contact with the communicator, before any epoch runs (bench.py / run.py under torch.distributed.run):
     one tiny all-reduce, one ring of batch_isend_irecv (rank r -> r + 1: the pattern of the phi hand-over), one
-    broadcast -- each checked for its VALUES on every rank.  A hang is cut by the process group's timeout (the rank
-    exits non-zero); a send / recv that RAISES switches every rank to the per-slot broadcast path (P2P_ENABLED = False,
-    agreed by an all-reduce) with a warning.  Returns a record for the bench line."""
+    broadcast -- each checked for its VALUES on every rank.  A hang is cut by the process group's timeout (bench.py and
+    cli.init_distributed both create the group with an explicit one, 300 s by default; the rank exits non-zero).  A send /
+    recv that RAISES PROMPTLY ON EVERY RANK (a backend without the operation, a symmetric failure) switches every rank to
+    the per-slot broadcast path (P2P_ENABLED = False, agreed by an all-reduce) with a warning; a failure on ONE rank leaves
+    its peers waiting in `req.wait()`, which the timeout ends -- that case is a failed run, not a fallback.  Returns a
+    record for the bench line."""
     import time
     import warnings
     global P2P_ENABLED

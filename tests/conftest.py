@@ -26,6 +26,11 @@ def pytest_configure(config):
                                        "job `name`; selected jobs start in worker processes when the session starts")
 
 
+def pytest_collection_modifyitems(config, items):
+    """tests that wait for an oracle job run LAST (stable otherwise): the jobs compute while the rest of the suite runs."""
+    items.sort(key=lambda it: 1 if any(True for _ in it.iter_markers("oracle_job")) else 0)
+
+
 def pytest_collection_finish(session):
     """start the heavy oracle runs of the SELECTED tests in worker processes, all at once, so that they compute
     while the HIP side of the suite runs (tests/oracle_jobs.py).  Only where a GPU is visible: without one the tests

@@ -25,7 +25,21 @@ def _key(name, kwargs):
     return (name,) + tuple(sorted(kwargs.items()))
 
 
-def _init_worker(blas_threads):
+def _init_worker(blas_threads, counter, n_workers):
+    """a worker keeps to its own block of hardware threads (BLAS pool, oracle/bigtable.py's row-block pool -- sized from
+    the affinity mask -- and the kernel's migrations all stay inside it): 15 concurrent jobs on one 256-thread host
+    otherwise slow each other 2 - 3x (measured in round 5: the Star job 50 s alone, 165 s in a crowd)."""
+    try:
+        with counter.get_lock():
+            idx = counter.value
+            counter.value += 1
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(blas_threads, min(16, len(cpus) // max(1, n_workers)))
+        if len(cpus) >= 2 * per:
+            lo = (idx * per) % (len(cpus) - per + 1)
+            os.sched_setaffinity(0, cpus[lo:lo + per])
+    except Exception:
+        pass
     try:
         from threadpoolctl import threadpool_limits
         globals()["_limit"] = threadpool_limits(limits=blas_threads, user_api="blas")
@@ -47,8 +61,9 @@ def start(keys, blas_threads=8):
         return
     if _pool is None:
         n = min(len(uniq), max(1, (os.cpu_count() or 8) // max(1, blas_threads)), 16)
-        _pool = ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn"), initializer=_init_worker,
-                                    initargs=(blas_threads,))
+        ctx = mp.get_context("spawn")
+        _pool = ProcessPoolExecutor(max_workers=n, mp_context=ctx, initializer=_init_worker,
+                                    initargs=(blas_threads, ctx.Value("i", 0), n))
     # longest first (matters only when there are more jobs than workers)
     todo.sort(key=lambda u: -COST.get(u[0], 1.0) * float(u[1].get("epochs", 1)))
     for name, kw in todo:
@@ -62,11 +77,11 @@ def _run(name, kw):
     return out
 
 
-def result(name, **kw):
+def result(job, **kw):
     """the job's result: from the pool if the session started it, else computed here."""
-    f = _futures.get(_key(name, kw))
+    f = _futures.get(_key(job, kw))
     if f is None:
-        return _run(name, kw)
+        return _run(job, kw)
     t0 = time.time()
     out = f.result(timeout=1500)
     out["waited_seconds"] = time.time() - t0
@@ -107,10 +122,16 @@ def problem_fullsize(shape, batch, epochs, seed=123):
     return dict(g=g, params=params, plans=plans, names=names, phis0=phis0, sizes=sizes, D=D)
 
 
-def job_fullsize_mamdr(shape, batch, meta_lr, epochs):
+def perturbed(a, prs, rel):
+    """a * (1 + rel * N(0, 1)) elementwise in fp32: rel = 2e-7 is a rounding-level change of every element."""
+    return (a * (F32(1) + F32(rel) * prs.standard_normal(a.shape).astype(F32))).astype(F32)
+
+
+def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0):
     """oracle/loops.mamdr_epoch (model_zoo/mamdr.py:41-108) x epochs, then every domain's validation AUC with the merged
     weights theta + phi_d (specific_base_model.py:64-97).  The per-pass shuffles are plan.PassShuffler's stream -- the
-    one plan.EpochShuffles hands the HIP side."""
+    one plan.EpochShuffles hands the HIP side.  perturb > 0: the SECOND oracle run of the self-divergence instrument --
+    every trainable initial tensor (theta's and the phi_d's; not the frozen tables) changed at rounding level."""
     from mamdr_amd import plan as mplan
     from oracle import auc as oauc
     from oracle import loops as oloops
@@ -122,6 +143,10 @@ def job_fullsize_mamdr(shape, batch, meta_lr, epochs):
                                dropout=0.5, lr=1e-3, dropout_seed=DROPOUT_SEED)
     theta = model.get_flat().copy()
     phis = [p.copy() for p in pb["phis0"]]
+    if perturb > 0:
+        prs = np.random.RandomState(99)
+        theta = perturbed(theta, prs, perturb)
+        phis = [perturbed(p, prs, perturb) for p in phis]
     shuf = mplan.PassShuffler(pb["sizes"], 10000, SHUFFLE_SEED)
     t0 = time.time()
     trace = []
@@ -255,7 +280,7 @@ def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0):
         for n_ in sorted(params):
             a = params[n_]
             if a.dtype == F32:
-                params[n_] = (a * (F32(1) + F32(perturb) * prs.standard_normal(a.shape).astype(F32))).astype(F32)
+                params[n_] = perturbed(a, prs, perturb)
     model = ostar.OracleStar(params, emb_trainable=True, lr=1e-3)
     wrapped = StarMeta(model)
     theta = wrapped.get_flat().copy()
@@ -329,13 +354,24 @@ def pipeline_config(cfg_file, name, tmp, train=None, dataset=None):
     return cfg
 
 
-def run_pipeline(cfg, engine_factory=None):
+def run_pipeline(cfg, engine_factory=None, perturb=0.0):
     """mamdr_amd.cli.main (= the reference's run.py:71-89: train -> val / early stop -> best state -> test -> finetune ->
-    save_result) with a Recorder attached.  -> the Recorder's summary + result.json as written."""
+    save_result) with a Recorder attached.  -> the Recorder's summary + result.json as written.
+    perturb > 0: the built model's initial weights (what theta starts from) are changed at rounding level before
+    training starts -- the second run of the self-divergence instrument."""
     import json
     from mamdr_amd import cli
     rec = Recorder()
-    out = cli.main(cfg, engine_factory, on_model=rec.attach)
+
+    def on_model(model):
+        rec.attach(model)
+        if perturb > 0:
+            import torch
+            eng = model.model
+            w = eng.get_weights().clone()
+            noise = np.random.RandomState(99).standard_normal(w.numel()).astype(F32)
+            eng.set_weights(w * (1 + perturb * torch.from_numpy(noise).to(w.device)))
+    out = cli.main(cfg, engine_factory, on_model=on_model)
     s = rec.summary(out)
     rdir = cfg["train"]["result_save_path"]
     found = [os.path.join(r, "result.json") for r, _, fs in os.walk(rdir) if "result.json" in fs]
@@ -344,7 +380,7 @@ def run_pipeline(cfg, engine_factory=None):
     return s
 
 
-def job_pipeline(cfg_file, name, train, dataset):
+def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0):
     """the oracle twin of a whole run: the SAME host code (cli.main, model_zoo/*, meta.py) on tests/fake_engine.FakeEngine,
     i.e. every numeric call answered by the numpy oracle.  train / dataset: tuples of (key, value) overrides."""
     import contextlib
@@ -352,11 +388,11 @@ def job_pipeline(cfg_file, name, train, dataset):
     import tempfile
     from fake_engine import FakeEngine
     tmp = tempfile.mkdtemp(prefix="mamdr_twin_")
-    cfg = pipeline_config(cfg_file, name, tmp, dict(train), dict(dataset))
+    cfg = pipeline_config(cfg_file, model_name, tmp, dict(train), dict(dataset))
     buf = io.StringIO()
     t0 = time.time()
     with contextlib.redirect_stdout(buf):
-        s = run_pipeline(cfg, FakeEngine)
+        s = run_pipeline(cfg, FakeEngine, perturb)
     s["secs"] = time.time() - t0
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
