@@ -630,8 +630,23 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
                 # weight gradients: 2 x rows x 139,777 flop per launch; with k_wgrad_adam the optimiser step of
                 # the dense block rides in the same launch
                 ach = 2.0 * rows_avg * 139777 / (k_us * 1e-6) / 1e12
-                rated.append({"kernel": kn, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_us": k_us, "launches": k_n})
+                ent = {"kernel": kn, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_us": k_us, "launches": k_n}
+                if not kn.startswith("k_wgrad_adam"):
+                    # the split-K form is as much a memory kernel: it reads the tower's activations /
+                    # gradients [rows][832 + 448] once and writes one partial slab of the dense block per row group
+                    # (mamdr_api.hip: 256-row groups up to 4,096 rows, 512 beyond, at most 16) -- rated against HBM too, on
+                    # these algorithmic bytes and on the PMC counter bytes of the committed passes
+                    rpg = 256 if batch <= 4096 else 512
+                    groups = min(16, -(-batch // rpg))
+                    alg = rows_avg * (832 + 448) * 4.0 + groups * p_dense * 4.0
+                    ent.update({"hbm_bytes_algorithmic": alg, "hbm_frac_algorithmic": alg / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                                "row_groups": groups})
+                    tr = pmc_traffic(kn + "@" + wl["shape"]) or pmc_traffic(kn)
+                    if tr:
+                        ent.update({"hbm_bytes_pmc": tr, "hbm_frac": tr / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                                    "hbm_note": "counter bytes per launch (profiles/pmc_hbm_latest.json) / this run's avg_us / 8 TB/s"})
+                rated.append(ent)
             elif key == L.KERNEL_UPDATE and kn.startswith("k_update"):
                 # dense optimiser step: 28 B per parameter (read p, m, v, g; write p, m, v); the gradient arrives as G
                 # slabs (4 G P more bytes read: not algorithmic)

@@ -8,6 +8,12 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# On the GPU box (256 hardware threads) the main process keeps to a block of cores of its own and the oracle workers to
+# theirs (tests/oracle_pool.py) -- decided BEFORE numpy / torch create their thread pools.
+import oracle_pool  # noqa: E402
+if (os.cpu_count() or 1) >= 64 and not os.environ.get("MAMDR_TEST_NO_PINNING"):
+    oracle_pool.pin_main()
+
 # The numpy oracle's GEMMs are small (1,024 .. 8,192 rows x 384 .. 64 columns): on the GPU box (256 hardware threads,
 # OpenBLAS default 64) they ran 4 - 6x SLOWER than on 8 threads -- 14 / 72 ms per oracle step at bs 1,024 / 4,096 against
 # 3.8 / 12.7 ms (profiles/r05_oracle_threads.txt, tests/diag_oracle_threads.py).  Results do not depend on it beyond
@@ -48,13 +54,11 @@ def pytest_collection_finish(session):
     except Exception:
         return
     import oracle_jobs      # (tests/ is on sys.path: rootdir conftest)
-    oracle_jobs.start(keys, BLAS_THREADS)
+    oracle_jobs.start(keys)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    mod = sys.modules.get("oracle_jobs")
-    if mod is not None:
-        mod.shutdown()
+    oracle_pool.shutdown()
 
 
 @pytest.fixture(scope="session")

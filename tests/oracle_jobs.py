@@ -5,7 +5,8 @@ Round 4's GPU suite spent ~500 of its 606 s inside the oracle, one case after th
 below are pure functions of their arguments (seeded inputs, no GPU): `conftest.pytest_collection_finish` starts the
 jobs of every SELECTED test (marker `oracle_job(name, **kwargs)`) in spawned worker processes when the session starts,
 and a test collects its result with `result(name, **kwargs)` after its HIP side has run.  The oracle still runs LIVE in
-every session -- no stored outputs that could go stale -- only concurrently.  `problem_*` helpers build the seeded
+every session -- no stored outputs that could go stale -- only concurrently (tests/oracle_pool.py: one worker per job,
+each on its own block of physical cores).  `problem_*` helpers build the seeded
 inputs; the tests call the same helpers for the HIP side, so both sides see the same tensors by construction.
 """
 import os
@@ -17,89 +18,12 @@ F32 = np.float32
 SHUFFLE_SEED = 0x5eed
 DROPOUT_SEED = 1024          # mamdr_amd.engine.TowerEngine's default (asserted by the tests)
 
-_pool = None
-_futures = {}
+from oracle_pool import result, shutdown  # noqa: E402,F401  (the pool itself: tests/oracle_pool.py)
 
 
-def _key(name, kwargs):
-    return (name,) + tuple(sorted(kwargs.items()))
-
-
-def _init_worker(blas_threads, counter, n_workers):
-    """a worker keeps to its own block of hardware threads (BLAS pool, oracle/bigtable.py's row-block pool -- sized from
-    the affinity mask -- and the kernel's migrations all stay inside it): 15 concurrent jobs on one 256-thread host
-    otherwise slow each other 2 - 3x (measured in round 5: the Star job 50 s alone, 165 s in a crowd)."""
-    try:
-        with counter.get_lock():
-            idx = counter.value
-            counter.value += 1
-        cpus = sorted(os.sched_getaffinity(0))
-        per = max(blas_threads, min(16, len(cpus) // max(1, n_workers)))
-        if len(cpus) >= 2 * per:
-            lo = (idx * per) % (len(cpus) - per + 1)
-            os.sched_setaffinity(0, cpus[lo:lo + per])
-    except Exception:
-        pass
-    try:
-        from threadpoolctl import threadpool_limits
-        globals()["_limit"] = threadpool_limits(limits=blas_threads, user_api="blas")
-    except Exception:
-        pass
-
-
-def start(keys, blas_threads=8):
-    """keys: [(job name, kwargs)].  One worker per job (they all start at once; the GPU box has 256 hardware threads)."""
-    global _pool
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
-    uniq = []
-    for name, kw in keys:
-        if _key(name, kw) not in [_key(*u) for u in uniq]:
-            uniq.append((name, kw))
-    todo = [u for u in uniq if _key(*u) not in _futures]
-    if not todo:
-        return
-    if _pool is None:
-        n = min(len(uniq), max(1, (os.cpu_count() or 8) // max(1, blas_threads)), 16)
-        ctx = mp.get_context("spawn")
-        _pool = ProcessPoolExecutor(max_workers=n, mp_context=ctx, initializer=_init_worker,
-                                    initargs=(blas_threads, ctx.Value("i", 0), n))
-    # longest first (matters only when there are more jobs than workers)
-    todo.sort(key=lambda u: -COST.get(u[0], 1.0) * float(u[1].get("epochs", 1)))
-    for name, kw in todo:
-        _futures[_key(name, kw)] = _pool.submit(_run, name, kw)
-
-
-def _run(name, kw):
-    t0 = time.time()
-    out = JOBS[name](**kw)
-    out["job_seconds"] = time.time() - t0
-    return out
-
-
-def result(job, **kw):
-    """the job's result: from the pool if the session started it, else computed here."""
-    f = _futures.get(_key(job, kw))
-    if f is None:
-        return _run(job, kw)
-    t0 = time.time()
-    out = f.result(timeout=1500)
-    out["waited_seconds"] = time.time() - t0
-    return out
-
-
-def shutdown():
-    global _pool
-    if _pool is not None:
-        for f in _futures.values():
-            f.cancel()
-        procs = list(getattr(_pool, "_processes", {}).values())
-        _pool.shutdown(wait=False, cancel_futures=True)
-        for p in procs:                  # a job still running when the session ends (a failed -x run) is not waited for
-            if p.is_alive():
-                p.terminate()
-        _pool = None
-    _futures.clear()
+def start(keys):
+    import oracle_pool
+    oracle_pool.start(keys, COST)
 
 
 # ---------------------------------------------------------------------------------------------- MAMDR epochs, frozen tables

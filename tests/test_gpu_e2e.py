@@ -48,7 +48,12 @@ CASES = {
     # table sample of the Amazon-6 shape
     "amazon6_deepfm_dn": dict(
         cfg_file="Amazon_6/deepfm_DN.json", name=None, train=(("epoch", 4), ("meta_learning_rate", 0.5)),
-        dataset=(("synthetic_scale", 0.03),), min_auc=0.5, want_early_stop=False),
+        dataset=(("synthetic_scale", 0.03),), min_auc=0.5, want_early_stop=False,
+        # tables that start at N(0, 1e-4^2) under Adam: the first steps of a rarely seen row are +- lr whatever the
+        # gradient's size, so rounding-level differences move single domains by ~1e-3 (the oracle against its own
+        # perturbed twin: 6e-4 .. 1e-3 per domain, profiles/r05_e2e_variants.txt) -- up to a quarter of the comparisons may
+        # need the self-divergence term here (the frozen-table cases: none did)
+        beyond_share=0.25),
 }
 
 
@@ -107,7 +112,8 @@ def compare(case, s_h, s_o, s_p):
             assert abs(dl_h[d] - dl_o[d]) <= 5e-3 * max(1.0, abs(dl_o[d])), ("val loss", case, e, d, dl_h[d], dl_o[d])
         assert abs(es_h[e][1] - es_o[e][1]) <= 1e-3
         delta = max(delta, abs(es_h[e][1] - es_o[e][1]) + 1e-7)
-    assert beyond <= max(1, n_cmp // 20), (beyond, n_cmp)       # the plain 1e-3 holds on >= 95 % of the comparisons
+    share = c.get("beyond_share", 0.05)                          # the plain 1e-3 holds on >= 95 % of the comparisons
+    assert beyond <= max(1, int(n_cmp * share)), (beyond, n_cmp)
     # the oracle's own early-stopping comparisons (`metric <= best`: base_model.py:202-224): margin of each
     margins, best = [], None
     for e, ev in enumerate(es_o):
@@ -146,7 +152,7 @@ def compare(case, s_h, s_o, s_p):
                 worst_test = max(worst_test, diff)
                 beyond_t += diff > 1e-3
                 assert diff <= 1e-3 + 2 * sd_test.get((i, d), 0.0), ("test AUC", case, i, d, a[5][d], b[5][d])
-        assert beyond_t <= max(1, len(t_o) * len(t_o[0][5]) // 20)
+        assert beyond_t <= max(1, int(len(t_o) * len(t_o[0][5]) * share))
         print("  best epoch %d on both sides; test from the best state: worst per-domain |d AUC| %.1e over %d evaluations "
               "(%d beyond the plain 1e-3; oracle vs its twin up to %.1e)" % (
                   best_o, worst_test, len(t_o), beyond_t, max(sd_test.values()) if sd_test else 0.0))

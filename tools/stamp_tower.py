@@ -9,7 +9,10 @@ from mamdr_amd import build as B
 so = os.path.join(ROOT, "mamdr_amd", "build", "libmamdr_hip_stamps.so")
 srcs = [os.path.join(B.CSRC, s) for s, _ in B.SOURCES]
 extra = os.environ.get("MAMDR_DIAG_FLAGS", "").split()
-subprocess.check_call([B._hipcc()] + B.COMMON + ["-DMAMDR_STAMPS"] + extra + ["-shared", "-o", so] + srcs)
+if not (os.environ.get("MAMDR_STAMPS_PREBUILT") and os.path.exists(so)):       # (prebuilt in the build container: `--build-only`)
+    subprocess.check_call([B._hipcc()] + B.COMMON + ["-DMAMDR_STAMPS"] + extra + ["-shared", "-o", so] + srcs)
+if "--build-only" in sys.argv:
+    sys.exit(0)
 from mamdr_amd import _lib
 _lib.LIB_PATH = so
 from mamdr_amd import engine, synthetic
