@@ -350,7 +350,13 @@ enum { MAMDR_GRAPH_SHARED_BOTTOM = 0,   /* deep_mtl_ctr.py:25-30  models.SharedB
        /* deepctr.py:37-40  models.AutoInt(att_head_num=4): three InteractingLayers (4 heads x 8, residual, relu) over the three
           fields beside the DNN, Dense(1) on [attention output 96 | DNN output] + linear tables; att<l>_w = [W_query | W_key |
           W_value | W_res] ([128][128], then [32][128] twice) precede W0, wo has 96 + hidden[-1] rows */
-       MAMDR_GRAPH_AUTOINT = 6 };
+       MAMDR_GRAPH_AUTOINT = 6,
+       /* round 5: the towers of the step kernels with ANY hidden_dim of 1..4 layers (widths multiples of 64) -- the step
+        * kernels are built for [256, 128, 64]; deepctr.py:26-32,36-38 pass hidden_dim through as dnn_hidden_units.
+        * Flat layout = oracle/tower.param_names: [tables | 1-d linear tables] domain_emb | W0.. | b0.. | wo | gb | lin_domain */
+       MAMDR_GRAPH_MLP = 7,             /* deepctr.py:118-136 build_mlp: DNN(x) -> Dense(1) -> sigmoid */
+       MAMDR_GRAPH_WDL = 8,             /* deepctr.py:29-32  models.WDL: linear tables + DNN(x) */
+       MAMDR_GRAPH_DEEPFM = 9 };        /* deepctr.py:36-38  models.DeepFM: linear tables + FM second-order term + DNN(x) */
 typedef struct mamdr_graph mamdr_graph;
 typedef struct mamdr_graph_config {
     int32_t abi_version;        /* MAMDR_ABI_VERSION */

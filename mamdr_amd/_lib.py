@@ -50,6 +50,7 @@ class Config(C.Structure):
 
 
 GRAPH_SHARED_BOTTOM, GRAPH_MMOE, GRAPH_PLE, GRAPH_NFM, GRAPH_PNN, GRAPH_CCPM, GRAPH_AUTOINT = 0, 1, 2, 3, 4, 5, 6
+GRAPH_MLP, GRAPH_WDL, GRAPH_DEEPFM = 7, 8, 9       # the step kernels' towers with any hidden_dim of 1..4 layers
 
 
 class GraphConfig(C.Structure):

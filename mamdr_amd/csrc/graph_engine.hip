@@ -769,10 +769,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------ NFM / PNN: interactions of the three fields, one wave per row
 // kind 0 (NFM): f[c] = u i + u d + i d (= 1/2 ((u+i+d)^2 - u^2 - i^2 - d^2), BiInteractionPooling), 128 columns
 // kind 1 (PNN): f[0..2] = <u,i>, <u,d>, <i,d> (InnerProductLayer over the pairs (0,1), (0,2), (1,2))
+// kind 2 (DeepFM): the FM second-order term  sum_k (u i + u d + i d)_k  joins the linear logit of the row (`extra`); no columns
 struct FeatArgs {
     float* act; float* dact; int ld; int f_col; int rows_pad; int kind; int dx_all;
     const float* w_ip;      // PNN: rows 384..386 of the first kernel [3][n_out]
     int z_col, n_out;       // PNN: d z of the first layer
+    float* extra;           // DeepFM: the per-row logit terms outside the DNN (linear part; the FM term is added here)
+    const float* dlogit;    // DeepFM: d loss / d logit of the row
 };
 __global__ __launch_bounds__(256) void k_graph_feat_fwd(const FeatArgs a) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -785,6 +788,12 @@ __global__ __launch_bounds__(256) void k_graph_feat_fwd(const FeatArgs a) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) f[k] = fmaf(it[k], d[k], fmaf(u[k], d[k], u[k] * it[k]));
         *reinterpret_cast<f32x2*>(row + a.f_col + 2 * lane) = f;
+    } else if (a.kind == 2) {
+        float f = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) f += fmaf(it[k], d[k], fmaf(u[k], d[k], u[k] * it[k]));
+        f = wave_sum(f);
+        if (lane == 0) a.extra[r] += f;
     } else {
         const float ui = wave_sum(fmaf(u[1], it[1], u[0] * it[0])), ud = wave_sum(fmaf(u[1], d[1], u[0] * d[0])),
                     id = wave_sum(fmaf(it[1], d[1], it[0] * d[0]));
@@ -814,6 +823,17 @@ __global__ __launch_bounds__(256) void k_graph_feat_bwd(const FeatArgs a) {
             du[k] = df[k] * (it[k] + d[k]);
             di[k] = df[k] * (u[k] + d[k]);
             dd[k] = df[k] * (u[k] + it[k]);
+        }
+    } else if (a.kind == 2) {
+        // DeepFM: d fm / d e_f = the sum of the other two fields' rows, ADDED to what the DNN's first layer left in d x
+        const float dl = a.dlogit[r];
+        const f32x2 du0 = *reinterpret_cast<const f32x2*>(drow + 2 * lane), di0 = *reinterpret_cast<const f32x2*>(drow + EMB + 2 * lane),
+                    dd0 = *reinterpret_cast<const f32x2*>(drow + 2 * EMB + 2 * lane);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            du[k] = du0[k] + dl * (it[k] + d[k]);
+            di[k] = di0[k] + dl * (u[k] + d[k]);
+            dd[k] = dd0[k] + dl * (u[k] + it[k]);
         }
     } else {
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -1982,7 +2002,9 @@ void fill_feat(const mamdr_graph* g, const Task& t, const StepCtx& sc, FeatArgs&
     fa.ld = g->ld;
     fa.f_col = g->f_col;
     fa.rows_pad = sc.rp;
-    fa.kind = g->cfg.kind == MAMDR_GRAPH_NFM ? 0 : 1;
+    fa.kind = g->cfg.kind == MAMDR_GRAPH_NFM ? 0 : (g->cfg.kind == MAMDR_GRAPH_DEEPFM ? 2 : 1);
+    fa.extra = g->extra;
+    fa.dlogit = g->dlogit;
     fa.dx_all = g->tables ? 1 : 0;
     const Layer& L0 = g->dnns[t.tower].layers[0];
     fa.w_ip = g->params + L0.w_off + (size_t)L0.in * L0.out;
@@ -2040,11 +2062,16 @@ int task_forward(mamdr_graph* g, const Task& t, const StepCtx& sc) {
             dnn_forward(g, g->dnns[t.tower], t.col[0], g->f_col, sc);
             return t.col[0].back();
         }
+        const int kind = g->cfg.kind;
+        if (kind == MAMDR_GRAPH_MLP || kind == MAMDR_GRAPH_WDL) {       // the plain DNN on x (WDL's linear part rides in `extra`)
+            dnn_forward(g, g->dnns[t.tower], t.col[0], 0, sc);
+            return t.col[0].back();
+        }
         FeatArgs fa;
         fill_feat(g, t, sc, fa);
         GLAUNCH(k_graph_feat_fwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
-        const bool nfm = g->cfg.kind == MAMDR_GRAPH_NFM;
-        dnn_forward(g, g->dnns[t.tower], t.col[0], nfm ? g->f_col : 0, sc, nfm ? -1 : g->f_col);
+        const bool nfm = kind == MAMDR_GRAPH_NFM;
+        dnn_forward(g, g->dnns[t.tower], t.col[0], nfm ? g->f_col : 0, sc, kind == MAMDR_GRAPH_PNN ? g->f_col : -1);
         return t.col[0].back();
     }
     if (g->group_ok && same_shape(g, t.mix)) {
@@ -2144,11 +2171,12 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
     if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");
     if (cfg->emb_trainable && cfg->max_batch > 16384) return gfail(MAMDR_EINVAL, "trainable tables: max_batch <= 16384");
-    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_AUTOINT)
+    if (cfg->kind < MAMDR_GRAPH_SHARED_BOTTOM || cfg->kind > MAMDR_GRAPH_DEEPFM)
         return gfail(MAMDR_EINVAL, "unknown graph tower kind %d", cfg->kind);
     if (!(cfg->dropout >= 0.f && cfg->dropout < 1.f)) return gfail(MAMDR_EINVAL, "dropout rate must be in [0,1)");
     const bool single = cfg->kind >= MAMDR_GRAPH_NFM;
-    const bool has_lin = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_CCPM || cfg->kind == MAMDR_GRAPH_AUTOINT;
+    const bool has_lin = cfg->kind == MAMDR_GRAPH_NFM || cfg->kind == MAMDR_GRAPH_CCPM || cfg->kind == MAMDR_GRAPH_AUTOINT ||
+                         cfg->kind == MAMDR_GRAPH_WDL || cfg->kind == MAMDR_GRAPH_DEEPFM;
     const bool gated = cfg->kind == MAMDR_GRAPH_MMOE || cfg->kind == MAMDR_GRAPH_PLE;
     if (cfg->n_expert_hidden < 1 || cfg->n_expert_hidden > 4 || (!single && (cfg->n_tower_hidden < 1 || cfg->n_tower_hidden > 4)) ||
         (gated && (cfg->n_gate_hidden < 1 || cfg->n_gate_hidden > 4)))
@@ -2719,6 +2747,18 @@ int mamdr_graph_train_steps_n(mamdr_graph* g, int domain, const int32_t* d_perm,
             if (!g->defer_w) launch_lin_domain_grad(g->stream, g->dlogit,
                                g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear, g->cfg.n_domain,
                                g->G(g->lin_d_off));
+        } else if (g->single && (g->cfg.kind == MAMDR_GRAPH_MLP || g->cfg.kind == MAMDR_GRAPH_WDL ||
+                                 g->cfg.kind == MAMDR_GRAPH_DEEPFM)) {
+            // the DNN on x as any first layer (deepctr.py:26-32,36-38 with any hidden_dim); DeepFM: + the FM term's d x
+            dnn_backward(g, tower, t.col[0], 0, 0, -1, false, dx_first, dx_n, sc);
+            if (g->cfg.kind == MAMDR_GRAPH_DEEPFM) {
+                FeatArgs fa;
+                fill_feat(g, t, sc, fa);
+                GLAUNCH(k_graph_feat_bwd, dim3(sc.rp / 4), dim3(256), 0, g->stream, fa);
+            }
+            if (g->has_lin && !g->defer_w)
+                launch_lin_domain_grad(g->stream, g->dlogit, g->domrow, sc.rows, g->params + g->lin_d_off, 2.0f * g->cfg.l2_linear,
+                                       g->cfg.n_domain, g->G(g->lin_d_off));
         } else if (g->single) {
             const bool nfm = g->cfg.kind == MAMDR_GRAPH_NFM;
             FeatArgs fa;

@@ -18,7 +18,7 @@ from . import _lib as L
 from .engine import FlatVectorOps, _ptr, auc_from_histogram
 
 KINDS = {"shared_bottom": L.GRAPH_SHARED_BOTTOM, "mmoe": L.GRAPH_MMOE, "ple": L.GRAPH_PLE, "nfm": L.GRAPH_NFM, "pnn": L.GRAPH_PNN,
-         "ccpm": L.GRAPH_CCPM, "autoint": L.GRAPH_AUTOINT}
+         "ccpm": L.GRAPH_CCPM, "autoint": L.GRAPH_AUTOINT, "mlp": L.GRAPH_MLP, "wdl": L.GRAPH_WDL, "deepfm": L.GRAPH_DEEPFM}
 
 
 def _arr4(values):

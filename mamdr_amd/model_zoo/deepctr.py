@@ -85,11 +85,15 @@ class DeepCTR(BaseModel):
         if not (mc["user_dim"] == mc["item_dim"] == mc["domain_dim"]):
             raise ValueError("user_dim, item_dim and domain_dim must be equal")
         n_hidden = len(mc["hidden_dim"])
-        if tower in GRAPH_TOWERS and not 1 <= n_hidden <= 4:
+        if not 1 <= n_hidden <= 4:
             raise ValueError("hidden_dim %r: the '%s' tower takes 1 to 4 hidden layers" % (mc["hidden_dim"], tower))
-        if tower not in GRAPH_TOWERS and n_hidden != 3:
-            raise ValueError("hidden_dim %r: the '%s' tower's kernels are built for three hidden layers (the reference's "
-                             "configs all have [256, 128, 64])" % (mc["hidden_dim"], tower))
+        # mlp / wdl / deepfm with a hidden_dim other than the reference configs' [256, 128, 64] (deepctr.py:26-49 passes any
+        # list through as dnn_hidden_units): the step kernels are built for that one shape, the generic-layer engine takes
+        # 1 - 4 layers of widths that are multiples of 64 (MAMDR_GRAPH_MLP / WDL / DEEPFM, round 5)
+        if tower == "star" and n_hidden != 3:
+            raise ValueError("hidden_dim %r: the Star tower's kernels are built for three hidden layers (the reference's "
+                             "configs all have [256, 128, 64])" % (mc["hidden_dim"],))
+        self.graph_dnn = (tower not in GRAPH_TOWERS and tower != "star" and tuple(mc["hidden_dim"]) != (256, 128, 64))
         factory = self.engine_factory
         # PNN and NFM on the step kernels (round 4: MAMDR_TOWER_PNN = the mlp tower + the inner products' three rows of the
         # first kernel; MAMDR_TOWER_NFM = WDL's linear tables + the DNN on the bi-interaction in the domain field's place;
@@ -104,6 +108,14 @@ class DeepCTR(BaseModel):
         if self.step_pnn:
             from ..engine import TowerEngine
             factory = TowerEngine
+        elif self.graph_dnn:
+            if factory is None:       # (an injected factory -- the tests' CPU stand-in -- takes `hidden` itself)
+                if any(h <= 0 or h % 64 for h in mc["hidden_dim"]):
+                    raise ValueError("hidden_dim %r: layer widths must be multiples of 64" % (mc["hidden_dim"],))
+                from ..graph_engine import GraphEngine
+                factory = GraphEngine
+            else:
+                self.graph_dnn = False
         elif tower in GRAPH_TOWERS:       # generic-layer engine; an injected factory offers it as `.graph` (tests)
             if factory is not None:
                 factory = getattr(factory, "graph", None)
@@ -121,7 +133,7 @@ class DeepCTR(BaseModel):
         # deepctr.py:104-116: `trainable=emb_trainable` reaches SparseFeat only on the pretrained branch; without
         # pretrained tables the column is built with deepctr's default (trainable) WHATEVER emb_trainable says
         self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
-        if tower in GRAPH_TOWERS and not self.step_pnn:
+        if (tower in GRAPH_TOWERS and not self.step_pnn) or self.graph_dnn:
             eng = factory(tower, self.n_uid, self.n_pid, self.n_domain, self.batch_size, expert_hidden=tuple(mc["hidden_dim"]),
                           tower_hidden=(), dropout=mc.get("dropout", 0.0), emb_trainable=self.tables_trainable,
                           emb_dim=mc["user_dim"], **kw)

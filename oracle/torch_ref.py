@@ -42,10 +42,12 @@ def deepctr_forward(P, uid, pid, dom, masks, keep_scale, tower):
     second-order term over the three 128-d fields, WDL the linear tables only (deepctr.py:29-32)."""
     u, i, d = _rows(P["user_emb"], uid), _rows(P["item_emb"], pid), _rows(P["domain_emb"], dom)
     h = torch.cat([u, i, d], dim=1)
-    for l in range(3):
+    l = 0
+    while "W%d" % l in P:          # hidden_dim of any length (deepctr.py:26-49 passes it through as dnn_hidden_units)
         h = torch.relu(torch.addmm(P["b%d" % l], h, P["W%d" % l]))
         if masks is not None:
             h = h * keep_scale * masks[l]
+        l += 1
 
     logit = (h @ P["wo"])[:, 0] + P["gb"][0]
     if tower in ("deepfm", "wdl"):

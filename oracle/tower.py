@@ -30,10 +30,24 @@ ADAM_EPS = F32(1e-8)
 L2_EMB = F32(1e-5)          # deepctr.py:118 l2_reg_embedding
 L2_LIN = F32(1e-5)          # deepctr DeepFM l2_reg_linear default
 
-DENSE_NAMES = ("W0", "W1", "W2", "b0", "b1", "b2", "wo", "gb")
+def dense_names(n_layers=3):
+    """DNN kernels, DNN biases, final dense kernel, global bias -- deepctr's `DNN(hidden_units)` creates ALL kernels
+    before ALL biases (layers/core.py build()), for any number of hidden layers (deepctr.py:26-49 passes
+    `hidden_dim` through as `dnn_hidden_units`)."""
+    return tuple("W%d" % l for l in range(n_layers)) + tuple("b%d" % l for l in range(n_layers)) + ("wo", "gb")
 
 
-def param_names(emb_trainable, deepfm=False, uncertainty=False):
+DENSE_NAMES = dense_names(3)      # the reference's configs: hidden_dim [256, 128, 64]
+
+
+def n_layers(params):
+    n = 0
+    while "W%d" % n in params:
+        n += 1
+    return n
+
+
+def param_names(emb_trainable, deepfm=False, uncertainty=False, n_layers=3):
     """Flat meta-vector order = Keras `trainable_weights` order:
     trainable embeddings in feature order (deepctr.py:102), DNN kernels, DNN
     biases, final dense kernel, global bias.  DeepFM (A.8) adds the 1-d linear
@@ -46,7 +60,7 @@ def param_names(emb_trainable, deepfm=False, uncertainty=False):
     tail = ("lin_domain",) if deepfm else ()
     # uncertainty weighting (model_zoo/uncertainty_weight/weighted_loss.py:23-28): one trainable scalar per domain
     tail = tail + (("log_var",) if uncertainty else ())
-    return emb + lin + ("domain_emb",) + DENSE_NAMES + tail
+    return emb + lin + ("domain_emb",) + dense_names(n_layers) + tail
 
 
 def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64),
@@ -60,12 +74,12 @@ def init_params(rs, n_user, n_item, n_domain, emb_dim=128, hidden=(256, 128, 64)
     p["item_emb"] = (rs.standard_normal((n_item, emb_dim)) * sd).astype(F32)
     p["domain_emb"] = (rs.standard_normal((n_domain, emb_dim)) * 1e-4).astype(F32)
     dims = (3 * emb_dim,) + tuple(hidden)
-    for l in range(3):
+    for l in range(len(hidden)):
         s = np.sqrt(2.0 / (dims[l] + dims[l + 1]))
         p["W%d" % l] = (np.clip(rs.standard_normal((dims[l], dims[l + 1])), -2, 2) * s).astype(F32)
         p["b%d" % l] = np.zeros(dims[l + 1], F32)
-    s = np.sqrt(2.0 / (dims[3] + 1))
-    p["wo"] = (np.clip(rs.standard_normal((dims[3], 1)), -2, 2) * s).astype(F32)
+    s = np.sqrt(2.0 / (dims[-1] + 1))
+    p["wo"] = (np.clip(rs.standard_normal((dims[-1], 1)), -2, 2) * s).astype(F32)
     p["gb"] = np.zeros(1, F32)
     # DeepFM linear tables: Zeros initialiser (deepctr get_linear_logit)
     p["lin_user"] = np.zeros(n_user, F32)
@@ -151,7 +165,7 @@ def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1), deepfm=False):
     x = gather(params, uid, pid, dom)
     hs = [x]
     h = x
-    for l in range(3):
+    for l in range(n_layers(params)):
         z = (h @ params["W%d" % l] + params["b%d" % l]).astype(F32)
         a = np.maximum(z, F32(0))
         if masks is not None:
@@ -166,7 +180,7 @@ def forward(params, uid, pid, dom, masks=None, keep_scale=F32(1), deepfm=False):
 
 
 def train_masks(seed, step, n_rows, hidden, rate):
-    return [rng.dropout_mask(seed, step, l, n_rows, hidden[l], rate) for l in range(3)]
+    return [rng.dropout_mask(seed, step, l, n_rows, hidden[l], rate) for l in range(len(hidden))]
 
 
 def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, deepfm=False,
@@ -192,10 +206,11 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
         g["log_var"][d0] = F32(F32(-2) * mean_bce / F32(var * var * var)) + F32(F32(1) / var)
     else:
         loss = mean_bce + reg_loss(params, frozen_sumsq, deepfm)
-    g["wo"] = (hs[3].T @ dlogit[:, None]).astype(F32)
+    L = len(hs) - 1
+    g["wo"] = (hs[L].T @ dlogit[:, None]).astype(F32)
     g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
     dh = (dlogit[:, None] * params["wo"][:, 0][None, :]).astype(F32)
-    for l in (2, 1, 0):
+    for l in range(L - 1, -1, -1):
         gate = (hs[l + 1] > 0).astype(F32) * keep_scale     # relu' * dropout mask * 1/keep
         dz = (dh * gate).astype(F32)
         g["W%d" % l] = (hs[l].T @ dz).astype(F32)
@@ -294,7 +309,7 @@ class OracleModel(object):
         self.emb_trainable = emb_trainable
         self.deepfm = {"deepfm": 1, "wdl": 2}.get(tower, 0)      # tower with linear tables (+ FM term for 1)
         self.uncertainty = bool(uncertainty)
-        self.names = param_names(emb_trainable, self.deepfm, self.uncertainty)
+        self.names = param_names(emb_trainable, self.deepfm, self.uncertainty, len(hidden))
         self.opt = Optimizer(params, self.names)
         self.rate = float(dropout)
         self.lr = lr

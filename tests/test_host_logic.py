@@ -383,6 +383,28 @@ def test_run_main_end_to_end(tmp_path, monkeypatch, name):
     assert info["total_train"] == sum(info[str(d)]["n_train"] for d in range(3))
 
 
+@pytest.mark.parametrize("name,hidden", [("mlp_meta_mamdr_finetune", [16, 8]), ("deepfm_meta_domain_negotiation", [16, 8, 8, 4]),
+                                         ("wdl", [8])])
+def test_run_main_other_hidden_dims(tmp_path, monkeypatch, name, hidden):
+    """deepctr.py:26-49 passes ANY hidden_dim list on as dnn_hidden_units: 1 .. 4 hidden layers run (round 4 raised for
+    everything but three), theta / phi / checkpoints carry 2 n + 2 dense tensors in Keras order, five layers raise."""
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, name)
+    cfg["model"]["hidden_dim"] = hidden
+    built = []
+    avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg, FakeEngine, on_model=built.append)
+    assert set(domain_auc) == {0, 1, 2} and np.isfinite(avg_loss)
+    eng = built[0].model
+    n = len(hidden)
+    dense = [k for k in eng.segments if k[0] in "Wb" and k[1:].isdigit() or k in ("wo", "gb")]
+    assert dense == ["W%d" % l for l in range(n)] + ["b%d" % l for l in range(n)] + ["wo", "gb"]
+    dims = [24] + hidden
+    assert [eng.segments["W%d" % l][1] for l in range(n)] == [dims[l] * dims[l + 1] for l in range(n)]
+    cfg["model"]["hidden_dim"] = [8, 8, 8, 8, 8]
+    with pytest.raises(ValueError):
+        cli.main(cfg, FakeEngine)
+
+
 def test_mamdr_wrapper_quirks(tmp_path, monkeypatch):
     """phi_d = fresh random init of the whole model; finetune = SGD lr 0.001 from best merged weights."""
     patch_emb_dim(monkeypatch)

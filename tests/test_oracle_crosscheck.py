@@ -28,10 +28,10 @@ def _batch(rs, n_user, n_item, n_domain, B, single_domain=None):
     return uid, pid, dom, label
 
 
-def _params(rs, n_user, n_item, n_domain, tower, uncertainty):
-    p = otower.init_params(rs, n_user, n_item, n_domain)
+def _params(rs, n_user, n_item, n_domain, tower, uncertainty, hidden=(256, 128, 64)):
+    p = otower.init_params(rs, n_user, n_item, n_domain, hidden=hidden)
     p["domain_emb"] = (rs.standard_normal(p["domain_emb"].shape) * 0.05).astype(F32)
-    for l in range(3):
+    for l in range(len(hidden)):
         p["b%d" % l] = (rs.standard_normal(p["b%d" % l].shape) * 0.05).astype(F32)
     p["gb"] = np.array([0.1], F32)
     if tower in ("deepfm", "wdl"):
@@ -72,6 +72,38 @@ def test_deepctr_towers_gradients_vs_float64_autograd(tower, emb_trainable, rate
     assert abs(float(loss32) - loss64) < 2e-6 * max(1.0, abs(loss64))
     np.testing.assert_allclose(p32, p64, rtol=2e-5, atol=2e-7)
     _check_grads(g32, g64, names)
+
+
+@pytest.mark.parametrize("tower,emb_trainable,hidden", [("mlp", False, (128, 64)), ("deepfm", True, (256, 128, 64, 64)),
+                                                        ("wdl", True, (64,)), ("deepfm", False, (128, 128, 64))])
+def test_deepctr_towers_other_hidden_dims_vs_float64_autograd(tower, emb_trainable, hidden):
+    """oracle/tower.py with 1, 2 and 4 hidden layers (round 5: `hidden_dim` lists other than the reference configs'
+    [256, 128, 64] run on the generic-layer engine; deepctr.py:26-49 passes any list through): the hand-derived gradients
+    against float64 autograd of the independently written forward, tensor order = kernels, biases, wo, gb."""
+    rs = np.random.RandomState(21)
+    n_user, n_item, n_domain, B = 300, 200, 5, 192
+    p = _params(rs, n_user, n_item, n_domain, tower, False, hidden)
+    uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B)
+    deepfm = {"deepfm": 1, "wdl": 2}.get(tower, 0)
+    names = otower.param_names(emb_trainable, deepfm, False, len(hidden))
+    L = len(hidden)
+    assert names[-(2 * L + 2 + (1 if deepfm else 0)):][:2 * L + 2] == tuple("W%d" % l for l in range(L)) + \
+        tuple("b%d" % l for l in range(L)) + ("wo", "gb")
+    masks = otower.train_masks(1024, 3, B, hidden, 0.5)
+    assert len(masks) == L and [m.shape[1] for m in masks] == list(hidden)
+    loss32, g32, p32 = otower.loss_and_grads(p, uid, pid, dom, label, masks, 0.5, emb_trainable, None, deepfm)
+    loss64, g64, p64, _ = tref.loss_and_grads(p, names, uid, pid, dom, label, masks, 0.5, tower, False)
+    assert abs(float(loss32) - loss64) < 2e-6 * max(1.0, abs(loss64))
+    np.testing.assert_allclose(p32, p64, rtol=2e-5, atol=2e-7)
+    assert sorted(g32) == sorted(names)
+    _check_grads(g32, g64, names)
+    # ... and a whole OracleModel of that shape steps (TF1 Adam over every named tensor) and evaluates
+    model = otower.OracleModel({k: v.copy() for k, v in p.items()}, emb_trainable=emb_trainable, dropout=0.5, hidden=hidden,
+                               tower=tower)
+    assert model.names == names
+    w0 = model.get_flat().copy()
+    model.train_on_batch(uid, pid, dom, label)
+    assert model.get_flat().shape == w0.shape and np.all(np.isfinite(model.get_flat())) and np.any(model.get_flat() != w0)
 
 
 @pytest.mark.parametrize("emb_trainable", [True, False])
