@@ -96,7 +96,7 @@ def test_one_step_gradients_match_oracle(kind, emb_trainable, hidden):
 def test_adam_pass_and_evaluation_match_oracle(kind, hidden):
     """one pass of TF1 Adam steps (dropout on) over the largest domain, then evaluation of another domain's val split: the
     displacement of every tensor against the oracle's, loss and AUC-500."""
-    g, eng, model = make_problem(kind, hidden, scale=0.1)
+    g, eng, model = make_problem(kind, hidden, scale=0.2)
     d = max(range(10), key=lambda k: g["data"]["train"][k]["uid"].shape[0])
     c = g["data"]["train"][d]
     n = c["uid"].shape[0]
