@@ -187,7 +187,7 @@ def star_phi0(pb, d, n_meta, names_meta=None):
     return v
 
 
-def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0):
+def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0, phi0="init"):
     """oracle/loops.mamdr_epoch on oracle/star.OracleStar (dense Adam over every table row and every per-domain slice
     each step).  perturb > 0: every initial tensor multiplied by (1 + perturb * N(0, 1)) elementwise in fp32 -- a second
     oracle run whose distance from the first measures the oracle's own sensitivity to rounding-level input changes
@@ -208,9 +208,9 @@ def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0):
     model = ostar.OracleStar(params, emb_trainable=True, lr=1e-3)
     wrapped = StarMeta(model)
     theta = wrapped.get_flat().copy()
-    if keras_init:
+    if keras_init and phi0 == "init":
         phis = {d: star_phi0(pb, d, theta.size) for d in doms}
-    else:
+    else:           # (keras_init with phi0 == "zero": round 4's diagnostic, profiles/r04_star13_phases_keras_init.txt)
         phis = {d: np.zeros_like(theta) for d in doms}
     t0 = time.time()
     trace = oloops.mamdr_epoch(wrapped, theta, phis, g["data"]["train"], plan, perm_stream(pb["all_sizes"], 900), batch, 0.5)

@@ -225,7 +225,7 @@ def test_amazon6_deepfm_dn_epoch_trainable_full_tables():
     eng.close()
 
 
-def _star_case(keras_init):
+def _star_case(keras_init, phi0="init"):
     from mamdr_amd import engine, meta
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
@@ -239,7 +239,7 @@ def _star_case(keras_init):
     eng.set_weights(full)
     theta_g = full[:eng.n_meta].clone()
     assert eng.n_meta < eng.n_params
-    if keras_init:
+    if keras_init and phi0 == "init":
         phis_g = {d: torch.from_numpy(oracle_jobs.star_phi0(pb, d, eng.n_meta)).to(eng.device) for d in doms}
     else:
         phis_g = {d: eng.new_vector(meta=True) for d in doms}
@@ -267,7 +267,7 @@ def _star_case(keras_init):
     return dict(trace=trace_g, aucs=auc_g, tail=tail_g, aux=aux, n_steps=n_steps, flushes=flushes, secs=gsecs, doms=doms)
 
 
-@pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=False, perturb=0.0)
+@pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=False, perturb=0.0, phi0="init")
 def test_amazon13_star_mamdr_epoch_trainable_full_tables():
     """BASELINE.json configs[4] on its own kernel path: star_meta_mamdr, Amazon-13's FULL tables (502,222 + 215,403
     rows x 128, trainable: 91.9 M parameters inside theta / phi_d), bs 8,192 -> k_star_stats / k_star_prep +
@@ -283,7 +283,7 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
     traces, the table replays between the passes, per-domain val AUC of theta + phi_d within the plain 1e-3, oracle mean
     AUC > 0.6, PartitionedNorm's moving statistics."""
     h = _star_case(False)
-    ora = oracle_jobs.result("amazon13_star", batch=8192, keras_init=False, perturb=0.0)
+    ora = oracle_jobs.result("amazon13_star", batch=8192, keras_init=False, perturb=0.0, phi0="init")
     assert h["trace"] == ora["trace"]
     print("amazon13 star MAMDR bs 8192: %d domain-steps in %d passes (%d table flushes); oracle %.1f s (waited %.1f s), hip %.2f s" % (
         h["n_steps"], len(h["trace"]), h["flushes"], ora["secs"], ora.get("waited_seconds", 0.0), h["secs"]))
@@ -308,9 +308,12 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
 KERAS_PERTURB = 2e-7
 
 
-@pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=True, perturb=0.0)
-@pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=True, perturb=KERAS_PERTURB)
-def test_amazon13_star_mamdr_epoch_at_keras_initial_values():
+def _keras_jobs(phi0):
+    return [pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=True, perturb=pt, phi0=phi0) for pt in (0.0, KERAS_PERTURB)]
+
+
+@pytest.mark.parametrize("phi0", [pytest.param("init", marks=_keras_jobs("init")), pytest.param("zero", marks=_keras_jobs("zero"))])
+def test_amazon13_star_mamdr_epoch_at_keras_initial_values(phi0):
     """configs[4] from the state the reference really starts from: PartitionedNorm gamma = 1, beta = 0
     (Star/partitioned_norm.py:19-22), zero biases (star_fcn.py:24-25), phi_d = a second random initialisation of the
     model (mamdr.py:31-33).  At beta = 0 the normalised domain columns of a single-domain batch are rounding residue
@@ -319,13 +322,15 @@ def test_amazon13_star_mamdr_epoch_at_keras_initial_values():
     whose initial tensors are perturbed by 2e-7 relative (one fp32 rounding) -- its distance from the first oracle run
     is the oracle's self-divergence.  Bar per domain: |AUC_hip - AUC_oracle| <= 1e-3 + 2 x |AUC_oracle - AUC_oracle'|;
     a HIP side beyond it would be a kernel bug, not conditioning.  The tail tensors (outside theta / phi) are reported
-    the same way: relative L2 distance hip-oracle next to oracle-oracle'."""
-    h = _star_case(True)
-    ora = oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=0.0)
-    orb = oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=KERAS_PERTURB)
+    the same way: relative L2 distance hip-oracle next to oracle-oracle'.
+    phi0 "init": phi_d as the reference draws it.  phi0 "zero": the starting point of round 4's diagnostic
+    (profiles/r04_star13_phases_keras_init.txt: one domain 2.0e-3 off, then unexplained) under the same instrument."""
+    h = _star_case(True, phi0)
+    ora = oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=0.0, phi0=phi0)
+    orb = oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=KERAS_PERTURB, phi0=phi0)
     assert h["trace"] == ora["trace"] == orb["trace"]
-    print("amazon13 star MAMDR at Keras init, bs 8192: %d domain-steps; oracle %.1f s + perturbed oracle %.1f s, hip %.2f s" % (
-        h["n_steps"], ora["secs"], orb["secs"], h["secs"]))
+    print("amazon13 star MAMDR at Keras init (phi0 %s), bs 8192: %d domain-steps; oracle %.1f s + perturbed oracle %.1f s, hip %.2f s" % (
+        phi0, h["n_steps"], ora["secs"], orb["secs"], h["secs"]))
     worst_excess, aucs = 0.0, []
     for d in h["doms"]:
         a_h, a_o, a_p = h["aucs"][d], ora["aucs"][d], orb["aucs"][d]
