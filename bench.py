@@ -642,7 +642,9 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
                     alg = rows_avg * (832 + 448) * 4.0 + groups * p_dense * 4.0
                     ent.update({"hbm_bytes_algorithmic": alg, "hbm_frac_algorithmic": alg / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                                 "row_groups": groups})
-                    tr = pmc_traffic(kn + "@" + wl["shape"]) or pmc_traffic(kn)
+                    # (with trainable tables the launch is k_wgrad_reduce: the table reduce's workgroups ride in it and
+                    # its counter bytes are theirs too)
+                    tr = pmc_traffic(kn + "@" + wl["shape"]) or pmc_traffic(kn + "_reduce@" + wl["shape"]) or pmc_traffic(kn)
                     if tr:
                         ent.update({"hbm_bytes_pmc": tr, "hbm_frac": tr / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                                     "hbm_note": "counter bytes per launch (profiles/pmc_hbm_latest.json) / this run's avg_us / 8 TB/s"})
