@@ -93,7 +93,7 @@ def _key(name, kwargs):
 
 
 def start(keys, cost=None):
-    """keys: [(job name, kwargs)].  One worker per job, up to 24 (they all start at once)."""
+    """keys: [(job name, kwargs)].  One worker per job, up to 32 (they all start at once)."""
     global _pool
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
@@ -109,7 +109,7 @@ def start(keys, cost=None):
         allc = os.environ.get("MAMDR_TEST_ALL_CPUS")
         if allc:
             n_cores = max(n_cores, len(allc.split(",")) // 2)
-        n = max(1, min(len(uniq), 24, max(1, (n_cores - MAIN_CORES) // WORKER_BLAS_THREADS)))
+        n = max(1, min(len(uniq), 32, max(1, (n_cores - MAIN_CORES) // WORKER_BLAS_THREADS)))
         ctx = mp.get_context("spawn")
         _pool = ProcessPoolExecutor(max_workers=n, mp_context=ctx, initializer=_init_worker,
                                     initargs=(ctx.Value("i", 0), n, WORKER_BLAS_THREADS))

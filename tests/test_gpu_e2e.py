@@ -44,6 +44,21 @@ CASES = {
         cfg_file="Taobao-10/deepctr_DN+DR.json", name=None,
         train=(("epoch", 12), ("patience", 2), ("meta_learning_rate", 0.5)), dataset=(), min_auc=0.75,
         want_early_stop=True),
+    # BASELINE.json configs[0]: the plain `mlp` tower, joint (alternate) training of deepctr.py:63-93 on Taobao-10 bs 1,024 --
+    # the reference's own CPU-runnable case -- full rows, early stopping on the average val AUC (base_model.py:202-224)
+    "taobao10_mlp_joint_train": dict(
+        cfg_file="Taobao-10/deepctr_DN+DR.json", name="mlp", train=(("epoch", 6), ("patience", 2)), dataset=(), min_auc=0.7,
+        want_early_stop=False),
+    # the other wrappers of run.py:37-85 over the same tower and data, each through its whole pipeline: Domain Negotiation
+    # + finetune (base_model.py:41-109: SGD with `learning_rate`), Reptile.  (First-order MAML is left to the per-epoch
+    # tests of tests/test_gpu_parity.py: with the outer Adam at 0.003 its second epoch drops to AUC 0.36 and the oracle differs
+    # from its own perturbed twin by 1e-2 there -- no setting for an end-to-end bar.)
+    "taobao10_dn_finetune": dict(
+        cfg_file="Taobao-10/deepctr_DN+DR.json", name="mlp_meta_domain_negotiation_finetune",
+        train=(("epoch", 6), ("meta_learning_rate", 0.5)), dataset=(), min_auc=0.7, want_early_stop=False),
+    "taobao10_reptile": dict(
+        cfg_file="Taobao-10/deepctr_DN+DR.json", name="mlp_meta_reptile", train=(("epoch", 6), ("meta_learning_rate", 0.5)),
+        dataset=(), min_auc=0.7, want_early_stop=False),
     # BASELINE.json configs[2]'s name and file (DeepFM + Domain Negotiation, trainable tables, no pretraining) on a row /
     # table sample of the Amazon-6 shape
     "amazon6_deepfm_dn": dict(
