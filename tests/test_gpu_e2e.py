@@ -93,16 +93,24 @@ def _finetune_margin(v):
     return min(min(margins), ck)
 
 
-def _self_div(ev_o, ev_p):
-    """{(k-th evaluation, domain): |AUC_oracle - AUC_oracle'|} over the evaluations both oracle runs made."""
-    return {(k, d): abs(a[5][d] - b[5][d]) for k, (a, b) in enumerate(zip(ev_o, ev_p)) for d in a[5]}
+def _self_div(ev_o, ev_p, field=5):
+    """{(k-th evaluation, domain): s} with s = the LARGEST |AUC_oracle - AUC_oracle'| over the domains of that evaluation
+    (field 4: the per-domain losses).  One perturbed twin is one draw of the rounding noise per domain; the HIP side is
+    another draw, so the scale it is held to is the evaluation's, not the single domain's draw (the rule of the
+    chaos-aware bars of tests/test_gpu_fmnets.py)."""
+    out = {}
+    for k, (a, b) in enumerate(zip(ev_o, ev_p)):
+        s = max(abs(a[field][d] - b[field][d]) for d in a[field])
+        for d in a[field]:
+            out[(k, d)] = s
+    return out
 
 
 def compare(case, s_h, s_o, s_p):
     """s_h: the HIP run, s_o: the oracle twin, s_p: the oracle twin from rounding-level perturbed initial weights (its
     distance from s_o = what any two fp32 evaluations of this training differ by).  Bars on AUCs: north_star's 1e-3 plus
-    twice the oracle's own self-divergence for that domain and evaluation; how many comparisons needed that term is
-    printed and bounded."""
+    twice the oracle's own self-divergence at that evaluation (its largest over the domains); how many comparisons needed
+    that term is printed and bounded."""
     c = CASES[case]
     # --- meta-level: validation per epoch, early stopping, the test score from the best state
     val_h, val_o, val_p = _evals(s_h, "val"), _evals(s_o, "val"), _evals(s_p, "val")
@@ -111,6 +119,7 @@ def compare(case, s_h, s_o, s_p):
     k = min(len(val_h), len(val_o))
     assert k >= 2
     sd_val = _self_div(val_o, val_p)
+    sd_loss = _self_div(val_o, val_p, 4)
     worst_val, worst_loss, worst_sd, beyond, n_cmp, delta = 0.0, 0.0, 0.0, 0, 0, 1e-7
     for e in range(k):
         _, _, loss_h, auc_h, dl_h, da_h = val_h[e]
@@ -124,7 +133,9 @@ def compare(case, s_h, s_o, s_p):
             beyond += diff > 1e-3
             n_cmp += 1
             assert diff <= 1e-3 + 2 * sd, ("val AUC", case, e, d, da_h[d], da_o[d], sd)
-            assert abs(dl_h[d] - dl_o[d]) <= 5e-3 * max(1.0, abs(dl_o[d])), ("val loss", case, e, d, dl_h[d], dl_o[d])
+            # (the loss is not north_star's bar; held to 5e-3 relative + twice the oracle's own self-divergence of it)
+            assert abs(dl_h[d] - dl_o[d]) <= 5e-3 * max(1.0, abs(dl_o[d])) + 2 * sd_loss.get((e, d), 0.0), \
+                ("val loss", case, e, d, dl_h[d], dl_o[d], sd_loss.get((e, d)))
         assert abs(es_h[e][1] - es_o[e][1]) <= 1e-3
         delta = max(delta, abs(es_h[e][1] - es_o[e][1]) + 1e-7)
     share = c.get("beyond_share", 0.05)                          # the plain 1e-3 holds on >= 95 % of the comparisons
@@ -202,10 +213,11 @@ def compare(case, s_h, s_o, s_p):
     worst = max(abs(da_h[d] - da_o[d]) for d in da_o)
     print("  returned: avg test AUC hip %.5f oracle %.5f, worst per-domain |d| %.1e (oracle vs its twin %.1e); avg loss "
           "%.5f / %.5f" % (auc_h, auc_o, worst, max(abs(da_p[d] - da_o[d]) for d in da_o), loss_h, loss_o))
+    sd_ret = max(abs(da_p[d] - da_o[d]) for d in da_o)
     for d in da_o:
-        assert abs(da_h[d] - da_o[d]) <= 1e-3 + 2 * abs(da_p[d] - da_o[d]), ("returned AUC", case, d, da_h[d], da_o[d], da_p[d])
+        assert abs(da_h[d] - da_o[d]) <= 1e-3 + 2 * sd_ret, ("returned AUC", case, d, da_h[d], da_o[d], da_p[d])
     assert abs(auc_h - auc_o) <= 1e-3
-    assert abs(loss_h - loss_o) <= 5e-3 * max(1.0, abs(loss_o))
+    assert abs(loss_h - loss_o) <= 5e-3 * max(1.0, abs(loss_o)) + 2 * abs(s_p["result"][0] - loss_o)
     assert auc_o > c["min_auc"], auc_o                          # a model that has learnt
     for s_, (lo, au, dl, da) in ((s_h, s_h["result"]), (s_o, s_o["result"])):
         rj = s_["result_json"]                                  # result.json = what was returned (base_model.py:183-200)
