@@ -561,21 +561,48 @@ __device__ __forceinline__ void fz_loss_body(const FusedArgs& a, float* lds) {
     }
 }
 
-// grid: [0, 32) S workgroups (the longest chains first), [32, 240) tiles, 240 / 241 output unit, 242 loss (optional)
+// rider block: its 8 waves touch the rows of 8 four-row tiles of the NEXT tower launch, all of them tiles whose workgroup
+// will run on THIS block's XCD (tile t -> XCD t mod 8).  One word per 128-B line of a tile's 4 KB, the tile's first domain /
+// label words; nothing is written (the sink keeps the loads alive).
+__device__ __forceinline__ void fz_prefetch_body(const FusedArgs& a, const int b, const int first_rider) {
+    if (b < first_rider) return;            // (the blocks that pad the grid to a multiple of 8 in front of the riders)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int xcd = b & 7, round = (b - first_rider) >> 3;
+    const int tile = xcd + 8 * (FZ_WAVES * round + w);
+    if (tile >= a.pf_tiles) return;
+    const float* base = a.pf_x + (size_t)tile * 4 * (2 * EMB);
+    float t = 0.f;
+    if (lane < 32) t = base[lane * 32];
+    else if (lane == 32) t = (float)a.pf_dom[4 * tile];
+    else if (lane == 33) t = a.pf_lab[4 * tile];
+    if (t == 1.2345678e30f) a.pf_sink[0] = t;
+}
+
+// grid: [0, 32) S workgroups (the longest chains first), [32, 240) tiles, 240 / 241 output unit, 242 loss (optional),
+// then the prefetch riders
 __global__ __launch_bounds__(FZ_THREADS) void k_wgrad_adam(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = (int)blockIdx.x;
     FZSTAMP(0);
     FZREAL(5);
+    const int n_main = FZ_SBLK + FZ_TILES + FZ_OUTB + (a.loss_out ? 1 : 0);
     if (b < FZ_SBLK) fz_s_body(a, b, lds);
     else if (b < FZ_SBLK + FZ_TILES) fz_tile_body(a, b - FZ_SBLK, lds);
     else if (b < FZ_SBLK + FZ_TILES + FZ_OUTB) fz_out_body(a, b - FZ_SBLK - FZ_TILES, lds);
-    else fz_loss_body(a, lds);
+    else if (b < n_main) fz_loss_body(a, lds);
+    else fz_prefetch_body(a, b, (n_main + 7) & ~7);
     FZREAL(6);
 }
 
 void launch_wgrad_adam(const FusedArgs& a, hipStream_t s) {
-    const int grid = FZ_SBLK + FZ_TILES + FZ_OUTB + (a.loss_out ? 1 : 0);
+    int grid = FZ_SBLK + FZ_TILES + FZ_OUTB + (a.loss_out ? 1 : 0);
+    if (a.pf_tiles > 0) {
+        // riders start at the next multiple of 8 (block b runs on XCD b mod 8: `round` counts whole rounds over the XCDs)
+        const int first = (grid + 7) & ~7;
+        const int per_xcd = (a.pf_tiles + 7) / 8;                      // tiles per XCD
+        const int rounds = (per_xcd + FZ_WAVES - 1) / FZ_WAVES;        // 8 tiles (one per wave) per block and XCD
+        grid = first + 8 * rounds;
+    }
     const size_t lds = (size_t)fz_lds_floats(a.n_domain) * sizeof(float);
     static bool big_lds_set = false;
     if (lds > 65536 && !big_lds_set) {          // 49..64 domains: 72 KB of partial S tiles

@@ -134,6 +134,9 @@ struct mamdr_ctx {
     int64_t pg_hits = 0;            // calls served from an entry (mamdr_pregather_hits)
     int64_t pg_launches = 0;        // hints that launched k_pass_prep_multi (mamdr_pregather_launches)
     bool gather_pf = true;          // MAMDR_NO_GATHER_PF=1: no riders in k_update's launch touching the next step's gather
+    bool fused_pf = false;          // MAMDR_FUSED_PF=1: riders in k_wgrad_adam's launch touch the next tower launch's pre-gathered rows (round 5:
+                                    // measured and left off -- the tower gains 0.08 us, k_wgrad_adam's second round of blocks costs 0.8;
+                                    // profiles/r05_ab_fused_pf.txt)
     bool use_pre = true;            // MAMDR_NO_PREGATHER=1: the towers gather through perm / uid / pid every step
     float* dmsnap[2] = {nullptr, nullptr};
     int dm_cur = 0;
@@ -859,6 +862,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     if (const char* ev = getenv("MAMDR_NO_GATHER_PF")) c->gather_pf = atoi(ev) == 0;
+    if (const char* ev = getenv("MAMDR_FUSED_PF")) c->fused_pf = atoi(ev) != 0;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
@@ -1475,6 +1479,27 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
 #ifdef MAMDR_STAMPS
             fa.stamps = c->stamps ? c->stamps + 65536 + (c->global_step & 1) * 4096 : nullptr;
 #endif
+            // prefetch riders: the next tower launch's pre-gathered rows -- the next step of this call, or (last step) the
+            // first step of the pass the pregather hint says the next call will run
+            if (pre && c->fused_pf && ta.xpre) {
+                const int64_t here = pre_base + row_base - pre_pos0;         // this step's first row in the pass buffer
+                int64_t next_off = -1, next_rows = 0;
+                if (s + 1 < n_steps) {
+                    next_off = here + batch;
+                    next_rows = std::min<int64_t>(batch, pass_rows - (row_base + batch));
+                } else if (pre_cached && c->pg_pos + 1 < c->pg.size() && c->pg[c->pg_pos + 1].batch == batch) {
+                    const mamdr_ctx::PgEntry& e = c->pg[c->pg_pos + 1];
+                    next_off = e.off;
+                    next_rows = std::min<int64_t>(batch, e.n);
+                }
+                if (next_off >= 0 && next_rows > 0) {
+                    fa.pf_x = c->xpre + (size_t)next_off * 2 * EMB;
+                    fa.pf_dom = c->pdom + next_off;
+                    fa.pf_lab = c->plabel + next_off;
+                    fa.pf_tiles = (int)((next_rows + 3) / 4);
+                    fa.pf_sink = c->loss_part;
+                }
+            }
             {
                 Prof p(c, MAMDR_KERNEL_WGRAD);
                 launch_wgrad_adam(fa, c->stream);

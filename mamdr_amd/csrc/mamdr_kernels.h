@@ -491,6 +491,15 @@ struct FusedArgs {
     const float* frozen_sumsq;
     float l2_emb;
     float* loss_out;
+    // rider workgroups (round 5): the NEXT tower launch's pre-gathered rows, touched ahead of time from the XCD whose
+    // workgroup will read them (workgroup b of a 1-d grid runs on XCD b mod 8; what a kernel leaves in an XCD's L2
+    // survives the kernel boundary: 240 cycles instead of 1,400 cold -- see GatherPf).  The tower's prologue waits
+    // 5.3 K cycles for its first data (profiles/r05_stamps_tower4_taobao10_bs1024.txt); pf_tiles = 0: no rider
+    const float* pf_x;         // next step's rows in the pass buffer [pf_rows][2 EMB]
+    const int32_t* pf_dom;
+    const float* pf_lab;
+    int pf_tiles;              // four-row tiles of the next step
+    float* pf_sink;
 #ifdef MAMDR_STAMPS
     unsigned long long* stamps; // diagnostic build only: [workgroups][8] s_memtime stamps of wave 0
 #endif
