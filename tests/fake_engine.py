@@ -332,6 +332,59 @@ class FakeFmEngine(FakeEngine):
 FakeEngine.graph = FakeFmEngine
 
 
+class FakeStarEngine(FakeEngine):
+    """CPU stand-in for TowerEngine(tower="star"), built on oracle/star.OracleStar (tests only): the flat vector = the meta
+    prefix [tables if trainable | domain_emb | shared kernels | shared biases] followed by the tensors that stay outside
+    theta / phi; `aux` = PartitionedNorm's moving statistics in the HIP engine's layout, aliased to the oracle's state."""
+
+    def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.0, emb_trainable=False, tower="star", emb_dim=128,
+                 hidden=(256, 128, 64), device=None, dropout_seed=1024, **kw):
+        from mamdr_amd.engine import TowerEngine
+        from oracle import star as ostar
+        assert tower == "star" and tuple(hidden) == (256, 128, 64) and emb_dim == 128
+        self.tower = "star"
+        self.KERAS_NAMES = TowerEngine.KERAS_NAMES
+        self.n_user, self.n_item, self.n_domain = n_user, n_item, n_domain
+        self.batch_size = batch_size
+        self.device = torch.device("cpu")
+        self.dropout_seed = dropout_seed
+        params = ostar.init_params(np.random.RandomState(0), n_user, n_item, n_domain)
+        self.oracle = ostar.OracleStar(params, emb_trainable=emb_trainable, lr=1e-3)
+        self.segments, off = {}, 0
+        for name in self.oracle.names:
+            self.segments[name] = (off, params[name].size)
+            off += params[name].size
+        self.n_params = off
+        self.n_meta = sum(params[n].size for n in self.oracle.meta_names)
+        # aux = [mov_mean | mov_var | biased_mean | biased_var] (D x 384 each) | steps (D), padded to 4 floats
+        D, X = n_domain, 3 * emb_dim
+        self._aux_np = np.zeros((4 * D * X + D + 3) // 4 * 4, F32)
+        st = self.oracle.state
+        for k, key in enumerate(("mov_mean", "mov_var", "biased_mean", "biased_var")):
+            view = self._aux_np[k * D * X:(k + 1) * D * X].reshape(D, X)
+            view[...] = st[key]
+            st[key] = view
+        view = self._aux_np[4 * D * X:4 * D * X + D]
+        view[...] = st["steps"]
+        st["steps"] = view
+        self.aux = torch.from_numpy(self._aux_np)       # shares memory with the oracle's state
+        self.data, self.calls = {}, []
+        self._ema = None
+
+    def keras_name(self, segment):
+        return self.KERAS_NAMES.get(segment, segment)
+
+
+def fake_factory(*args, **kw):
+    """engine factory that also serves the Star tower (cli.main(engine_factory=fake_factory))."""
+    if kw.get("tower") == "star":
+        return FakeStarEngine(*args, **kw)
+    return FakeEngine(*args, **kw)
+
+
+fake_factory.graph = FakeFmEngine
+
+
 def _otower():
     from oracle import tower
     return tower

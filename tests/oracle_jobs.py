@@ -310,7 +310,7 @@ def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0):
     import contextlib
     import io
     import tempfile
-    from fake_engine import FakeEngine
+    from fake_engine import fake_factory as FakeEngine      # (FakeEngine, or FakeStarEngine for the Star tower)
     tmp = tempfile.mkdtemp(prefix="mamdr_twin_")
     cfg = pipeline_config(cfg_file, model_name, tmp, dict(train), dict(dataset))
     buf = io.StringIO()

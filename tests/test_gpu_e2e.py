@@ -59,6 +59,16 @@ CASES = {
     "taobao10_reptile": dict(
         cfg_file="Taobao-10/deepctr_DN+DR.json", name="mlp_meta_reptile", train=(("epoch", 6), ("meta_learning_rate", 0.5)),
         dataset=(), min_auc=0.7, want_early_stop=False),
+    # BASELINE.json configs[4]'s name (star_meta_mamdr: PartitionedNorm + StarFCN, theta / phi over the name-filtered meta
+    # parameters ["emb", "kernel_shared", "bias_shared"], maml.py:153-179) on the reference's Taobao-10 Star config
+    # (config/Taobao-10/star_taobao.json: frozen pretrained tables), from the Keras initial values, full rows.  The oracle twin
+    # runs on tests/fake_engine.FakeStarEngine (oracle/star.py).  This tower is the least reproducible one: at Keras init the
+    # oracle differs from its own perturbed twin by 1 - 2e-3 per domain and by 5e-2 in the loss (the noise-gradient walk of
+    # DESIGN.md section 2), the average val AUC by <= 5e-4 -- while the pipeline's decisions are 3e-3 apart: validation peaks
+    # after the FIRST epoch, the counter runs to patience 3 and the best state of epoch 0 is what the test score comes from.
+    "taobao10_star_mamdr": dict(
+        cfg_file="Taobao-10/star_taobao.json", name="star_meta_mamdr", train=(("epoch", 8),), dataset=(), min_auc=0.75,
+        want_early_stop=True, beyond_share=0.25),
     # BASELINE.json configs[2]'s name and file (DeepFM + Domain Negotiation, trainable tables, no pretraining) on a row /
     # table sample of the Amazon-6 shape
     "amazon6_deepfm_dn": dict(
