@@ -214,8 +214,15 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
     # timed steps (median), stopped once a trial is clearly slower than the best so far; the timed sample then runs
     # at the best count in THREE repeats: value = the median repeat, spread = [min, max].
     pinned, restore = _pin_to_one_socket()
+    quota = _cpu_quota()
     try:
         cap = len(pinned) if pinned else (cores // 2 if cores >= 16 else cores)
+        # (round 5: the container's cgroup may grant fewer CPUs of TIME than it shows cores -- the GPU box: 256 hardware
+        # threads, cpu.max = 16 CPUs.  More runnable threads than that are throttled for whole 100 ms periods: that is the
+        # "cliff" rounds 3 - 4 measured -- single steps of 84 - 1,597 ms at 62 - 64 threads -- not OpenMP's spinning.  The
+        # sweep stops at the quota: what lies beyond measures the throttle, not the CPU path.)
+        if quota is not None:
+            cap = max(1, min(cap, int(quota)))
         # counts tried: 8, 16, 32, ..., 3/4 of the cap, the cap.  Each trial = 1 warm + 9 timed steps, scored by the mean
         # WITHOUT its two slowest steps: on this shared host single steps stall at any count (tests/diag_cpu_cliff.py,
         # profiles/r04_cpu_cliff.jsonl: outliers of 8 - 1,600 ms; near the pinned core count OpenMP's spinning workers lose
@@ -254,12 +261,13 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
     reps.sort()
     value, steps, dt = reps[1]
     out = {"value": value, "unit": "domain-steps/s", "cores": int(best_nt), "kind": "port",
-           "host_cores_visible": int(cores), "pinned_to": "%d physical cores of one socket" % len(pinned) if pinned else "not pinned",
+           "host_cores_visible": int(cores), "cpu_quota_cpus": quota, "pinned_to": "%d physical cores of one socket" % len(pinned) if pinned else "not pinned",
            "repeats": [round(r[0], 2) for r in reps], "spread": [round(reps[0][0], 2), round(reps[-1][0], 2)],
            # scoring rule of this record (ratios across rounds are comparable only under the same rule).
            # v1 (r01-r02) unpinned, fastest of a doubling sweep; v2 (r03) pinned to one socket, new sample + initialiser;
            # v3 (r04-) trimmed-mean trials (a trial's two slowest steps dropped), smallest thread count within 10 % of the best
-           "method": "v3: pinned to one socket, trimmed-mean thread sweep, smallest count within 10 % of the best, median of 3",
+           # v4 (r05): as v3, the sweep capped at the container's CPU quota (cpu_quota_cpus)
+           "method": "v4: pinned to one socket, trimmed-mean thread sweep up to the cgroup CPU quota, smallest count within 10 % of the best, median of 3",
            "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 2) for k, v in trials},
            "thread_sweep_unstable": {str(k): round(v * 1e3, 1) for k, v in unstable},     # count -> slowest step of its trial, ms
            "sample": "median of 3 repeats of ~%d inner steps each (bs=%d, domain %d of the same synthetic workload, %.1f s per "
@@ -282,6 +290,27 @@ def cpu_baseline(g, batch, budget_s=15.0, params=None, emb_trainable=False, towe
 
 
 # ---------------------------------------------------------------------------------------------- committed profiles
+def _cpu_quota():
+    """CPUs of time the container's cgroup grants (cgroup v2 cpu.max / v1 cfs quota); None = unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            return max(1.0, float(q) / float(per))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        if q > 0:
+            return max(1.0, q / per)
+    except Exception:
+        pass
+    return None
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (tools/rocpd_summary.py pmc, gfx950 corrections applied); None if no summary is committed."""

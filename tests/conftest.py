@@ -16,9 +16,11 @@ if (os.cpu_count() or 1) >= 64 and not os.environ.get("MAMDR_TEST_NO_PINNING"):
 
 # The numpy oracle's GEMMs are small (1,024 .. 8,192 rows x 384 .. 64 columns): on the GPU box (256 hardware threads,
 # OpenBLAS default 64) they ran 4 - 6x SLOWER than on 8 threads -- 14 / 72 ms per oracle step at bs 1,024 / 4,096 against
-# 3.8 / 12.7 ms (profiles/r05_oracle_threads.txt, tests/diag_oracle_threads.py).  Results do not depend on it beyond
-# BLAS' own blocking (the bars of the parity tests are ~1e-3, rounding ~1e-7).
-BLAS_THREADS = int(os.environ.get("MAMDR_TEST_BLAS_THREADS", "8"))
+# 3.8 / 12.7 ms (profiles/r05_oracle_threads.txt, tests/diag_oracle_threads.py) -- the container's CPU quota of 16 CPUs
+# throttles what runs beyond it (oracle_pool.cpu_quota).  4 threads where the quota is <= 16 CPUs (the workers take the
+# rest), 8 otherwise.  Results do not depend on it beyond BLAS' own blocking (the bars of the parity tests are ~1e-3,
+# rounding ~1e-7).
+BLAS_THREADS = int(os.environ.get("MAMDR_TEST_BLAS_THREADS", str(oracle_pool.budget()[0])))
 try:
     from threadpoolctl import threadpool_limits
     _blas_limit = threadpool_limits(limits=BLAS_THREADS, user_api="blas")      # kept for the whole session

@@ -3,17 +3,60 @@ for the jobs).  This module imports nothing heavy at load time ON PURPOSE: a spa
 by importing this module, and the worker must choose its CPUs BEFORE numpy is imported -- OpenBLAS creates its threads at
 import and they keep the affinity mask of that moment.
 
-CPU layout (measured in round 5 on the 256-thread GPU box): 18 oracle jobs started at once slowed each other 3 - 6x (the
-whole-pipeline twin 67 s alone, 395 s in the crowd) and slowed the main process's own in-test oracle runs with them.
-So the pool is topology-aware: the main pytest process keeps the first MAIN_CORES physical cores (both hardware threads
-of each), every worker gets its own block of physical cores (one hardware thread per core) and caps BLAS at 4 threads
-(4 threads: 4.1 / 15.5 ms per oracle step at bs 1,024 / 4,096; 8 threads: 3.8 / 12.7 ms -- profiles/r05_oracle_threads.txt).
+CPU budget (measured in round 5 on the GPU box): 256 hardware threads are visible, but the container's cgroup grants 16
+CPUs of time (`cpu_quota`); 18 - 30 oracle jobs started at once slowed each other 3 - 6x (the whole-pipeline twin 44 s
+with 6 jobs, 244 s with 30) and the main process's own in-test oracle runs with them -- throttling, not cache or
+memory traffic.  So the pool runs as many workers AT A TIME as the quota pays for (2 BLAS threads each, the main process
+4: 6 workers on that box), longest jobs first, the rest queue; workers still take their own physical cores (no migrations,
+no SMT sharing with the main process).
 """
 import os
 import time
 
 MAIN_CORES = 16
-WORKER_BLAS_THREADS = 4
+WORKER_BLAS_THREADS = 2
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 `cpu.max` / v1 cfs quota), None if unlimited.  The GPU box
+    shows 256 hardware threads and grants 16 CPUs of time (`cpu.max` = 1600000 100000): more runnable threads than that
+    are THROTTLED -- whole 100 ms periods without a time slice -- however they are pinned.  Measured in round 5
+    (tests/diag_oracle_crowd.py): the oracle step of one worker 2.1 ms, of 8 / 16 / 28 concurrent workers of 4 threads
+    5.6 / 11.1 / 22.3 ms -- total throughput constant.  (It is also what rounds 3 - 4 called the "CPU cliff".)"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            return max(1.0, float(q) / float(per))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        if q > 0:
+            return max(1.0, q / per)
+    except Exception:
+        pass
+    return None
+
+
+def budget():
+    """(BLAS threads of the main process, worker count limit): the main process and the workers together stay inside the
+    CPU quota (or the visible cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    allc = os.environ.get("MAMDR_TEST_ALL_CPUS")
+    if allc:
+        n = max(n, len(allc.split(",")))
+    q = cpu_quota()
+    cpus = n if q is None else min(float(n), q)
+    main = 4 if cpus <= 16 else 8
+    workers = max(1, int((cpus - main) // WORKER_BLAS_THREADS))
+    return main, workers
 
 _pool = None
 _futures = {}
@@ -73,7 +116,7 @@ def _init_worker(counter, n_workers, blas_threads):
         cores = physical_cores()
         if len(cores) >= 4 * MAIN_CORES:
             free = cores[MAIN_CORES:]
-            per = max(blas_threads, min(8, len(free) // max(1, n_workers)))
+            per = max(blas_threads, min(4, len(free) // max(1, n_workers)))
             lo = (idx * per) % max(1, len(free) - per + 1)
             os.sched_setaffinity(0, [g[0] for g in free[lo:lo + per]])
     except Exception:
@@ -93,7 +136,7 @@ def _key(name, kwargs):
 
 
 def start(keys, cost=None):
-    """keys: [(job name, kwargs)].  One worker per job, up to 32 (they all start at once)."""
+    """keys: [(job name, kwargs)].  As many workers as the CPU budget pays for; the jobs queue, longest first."""
     global _pool
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
@@ -105,11 +148,7 @@ def start(keys, cost=None):
     if not todo:
         return
     if _pool is None:
-        n_cores = len(physical_cores())
-        allc = os.environ.get("MAMDR_TEST_ALL_CPUS")
-        if allc:
-            n_cores = max(n_cores, len(allc.split(",")) // 2)
-        n = max(1, min(len(uniq), 32, max(1, (n_cores - MAIN_CORES) // WORKER_BLAS_THREADS)))
+        n = max(1, min(len(uniq), budget()[1]))
         ctx = mp.get_context("spawn")
         _pool = ProcessPoolExecutor(max_workers=n, mp_context=ctx, initializer=_init_worker,
                                     initargs=(ctx.Value("i", 0), n, WORKER_BLAS_THREADS))
