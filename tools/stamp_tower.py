@@ -35,8 +35,16 @@ stamps = torch.zeros(65536 + 8192, dtype=torch.int64, device=eng.device)
 eng.lib.mamdr_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 eng.lib.mamdr_debug_set_stamps(eng.ctx, C.c_void_p(stamps.data_ptr()))
 perm = torch.from_numpy(engine.shuffle_perm(n, 10000, 1)).to(eng.device)
+# STAMP_OPT=accumulate (round 5): the meta pass's steps -- gradients added to an accumulator, the weights NOT rewritten, so
+# the next tower finds them where the previous one left them (its own XCD's L2) instead of fetching what k_wgrad_adam wrote
+# on other XCDs a moment ago: the difference of the two timelines is the price of reading freshly updated weights
+opt = os.environ.get("STAMP_OPT", "adam")
+if opt == "accumulate":
+    acc = eng.new_vector()
+    eng.bind_accumulator(acc)
 for _ in range(5):
-    eng.train_steps(d, perm=perm, first_step=0, n_steps=3)
+    eng.train_steps(d, perm=perm, first_step=0, n_steps=3, optimizer=opt)
+print("optimizer of the stamped steps: %s" % opt)
 torch.cuda.synchronize()
 allst = stamps.cpu().numpy()
 st = allst[:tiles * 16].reshape(tiles, 16)[:, :10].astype(np.float64)
