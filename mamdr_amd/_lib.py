@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmamdr_hip.so")
+LIB_PATH = os.environ.get("MAMDR_LIB_PATH") or os.path.join(HERE, "libmamdr_hip.so")      # (MAMDR_LIB_PATH: A/B of diagnostic builds, tools/build_variant.sh)
 
 ABI_VERSION = 16
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4

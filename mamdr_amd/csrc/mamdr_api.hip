@@ -1442,6 +1442,12 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         }
         {
             Prof p(c, MAMDR_KERNEL_FWD_BWD);
+#ifdef MAMDR_TOWER_TWICE
+            // diagnostic build (tools/stamp_tower.py with MAMDR_DIAG_FLAGS=-DMAMDR_TOWER_TWICE): the same tower launch twice in a
+            // row -- idempotent (the pending domain-table step is formed from its snapshot, every output is overwritten) -- so that
+            // the stamps of the SECOND launch show the kernel with its own code and data still where the first left them
+            if (use4) launch_tower4_train(ta, c->stream);
+#endif
             if (use4) launch_tower4_train(ta, c->stream);
             else launch_tower_train(ta, c->stream);
         }

@@ -493,7 +493,13 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
     __builtin_amdgcn_sched_barrier(0);
     const bool l0_dom_only = FM && a.deepfm == 4;      // NFM: rows 0..255 of W0 are zero and meet nothing the DNN reads
     w0.prefetch(k_w0, l0_dom_only);
+    // (the snapshot of W0[256:384] for k_wgrad_adam is taken at the END of the kernel since round 5: here, its load -> store
+    // dependency put an `s_waitcnt vmcnt(0)` into the last wave's prologue -- one full round trip for everything that wave
+    // had requested, in front of its bias loads and W1-image requests -- and the whole workgroup waited for that wave at the
+    // bookkeeping barrier)
+#ifdef MAMDR_T4_SNAP_EARLY
     if (FUSED_OK) tower_snapshots(a, T4_THREADS, n_tiles);
+#endif
     const bool dmw = FUSED_OK && a.dm_snap_out != nullptr;       // k_wgrad_adam path: domain-table duty (DmStep)
     // (the pending domain row is requested AFTER the bookkeeping, also with a pre-gathered pass: asked for here, from
     // the caller's expected domain, its loads -- misses to HBM -- delayed the x rows by 1.5 K cycles; measured)
@@ -853,6 +859,9 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
     }
     T4STAMP(9);
     T4REAL(11);
+#ifndef MAMDR_T4_SNAP_EARLY
+    if (FUSED_OK) tower_snapshots(a, T4_THREADS, n_tiles);      // (W0's rows are L2-resident by now: layer 0 streamed them)
+#endif
     if (pnn) {
         // d loss / d ip[row][j] = sum_c dz1[row][c] W0x[j][c]: wave sums, then the row's four waves (rows erow2, erow2 + 2
         // belong to waves 4 erow2 .. 4 erow2 + 3) through LDS in wave order; the inner products' chain rule then gives the

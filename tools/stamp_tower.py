@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from mamdr_amd import build as B
-so = os.path.join(ROOT, "mamdr_amd", "build", "libmamdr_hip_stamps.so")
+so = os.path.join(ROOT, "mamdr_amd", "build", "libmamdr_hip_stamps%s.so" % os.environ.get("STAMP_SO_SUFFIX", ""))
 srcs = [os.path.join(B.CSRC, s) for s, _ in B.SOURCES]
 extra = os.environ.get("MAMDR_DIAG_FLAGS", "").split()
 if not (os.environ.get("MAMDR_STAMPS_PREBUILT") and os.path.exists(so)):       # (prebuilt in the build container: `--build-only`)
