@@ -1625,6 +1625,9 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.v = c->adam_v + c->table_floats;
         ua.slabs = c->slabs;
         ua.n_groups = groups;
+#ifdef MAMDR_STAMPS
+        ua.stamps = c->stamps ? c->stamps + 65536 + 8192 : nullptr;
+#endif
         ua.slab_ld = c->slab_ld;
         ua.s_off = c->L.alloc;
         ua.w0dom_copy = c->w0dom_copy;

@@ -241,6 +241,9 @@ struct UpdateArgs {
     int w1_off, w2_off;        // offsets of W1 / W2 in the dense block
     int w0_off, w0t;           // W0 offset; w0t: also keep W0T (trainable tables)
     int no_sdm;                // NFM: rows 256..383 of W0 do not meet the domain row -- no S . W0dom^T term in the table's gradient
+#ifdef MAMDR_STAMPS
+    unsigned long long* stamps; // diagnostic build only: [workgroups][4] s_memtime stamps (entry, operands summed, exit)
+#endif
 };
 
 // pre-update snapshot of W0[256:384, :] for k_wgrad_adam, by the LAST wave of every tower workgroup (it is not on

@@ -1268,31 +1268,30 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
     MAMDR_LAUNCH(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a);
 }
 
-// sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
-// loop paid one dependent round trip per slab: 4 at 1024 rows, 16 at 4096)
+// sum of one float4 / float over the gradient slabs IN SLAB ORDER.  Round 5: ALL of up to 16 slabs' loads in flight at once (the
+// slabs were written a moment ago by k_wgrad on other XCDs: every dependent batch of loads is a ~2 K-cycle trip to the
+// infinity cache -- the timeline of k_update showed 5 K cycles for the two batches of eight; round 2's rolled loop paid one
+// trip per slab); the additions run in slab order as before (bit-identical)
 __device__ __forceinline__ f32x4 slab_sum4(const float* slabs, int n_groups, int slab_ld, size_t e) {
-    f32x4 g = *reinterpret_cast<const f32x4*>(slabs + e);
-    for (int s0 = 1; s0 < n_groups; s0 += 8) {
-        f32x4 t[8];
+    f32x4 t[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            t[k] = *reinterpret_cast<const f32x4*>(slabs + (size_t)min(s0 + k, n_groups - 1) * slab_ld + e);
+    for (int k = 0; k < 16; ++k) t[k] = *reinterpret_cast<const f32x4*>(slabs + (size_t)min(k, n_groups - 1) * slab_ld + e);
+    f32x4 g = t[0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (s0 + k < n_groups) g += t[k];
-    }
+    for (int k = 1; k < 16; ++k)
+        if (k < n_groups) g += t[k];
+    for (int s0 = 16; s0 < n_groups; ++s0) g += *reinterpret_cast<const f32x4*>(slabs + (size_t)s0 * slab_ld + e);      // (MAMDR_MAX_GROUPS > 16)
     return g;
 }
 __device__ __forceinline__ float slab_sum1(const float* slabs, int n_groups, int slab_ld, size_t e) {
-    float g = slabs[e];
-    for (int s0 = 1; s0 < n_groups; s0 += 8) {
-        float t[8];
+    float t[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = slabs[(size_t)min(s0 + k, n_groups - 1) * slab_ld + e];
+    for (int k = 0; k < 16; ++k) t[k] = slabs[(size_t)min(k, n_groups - 1) * slab_ld + e];
+    float g = t[0];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (s0 + k < n_groups) g += t[k];
-    }
+    for (int k = 1; k < 16; ++k)
+        if (k < n_groups) g += t[k];
+    for (int s0 = 16; s0 < n_groups; ++s0) g += slabs[(size_t)s0 * slab_ld + e];
     return g;
 }
 
@@ -1373,40 +1372,56 @@ __device__ __forceinline__ void update_w0dom_linear(const UpdateArgs& u, int wg,
     const f32x4 p0 = *reinterpret_cast<const f32x4*>(u.p + e);
     const f32x4 m0 = *reinterpret_cast<const f32x4*>(u.m + e);
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(u.v + e);
-    float x[8];
+    // (round 5: the first 32 domains' values of this thread's table column are requested up front, beside the S block's slab
+    // loads -- the 8-at-a-time prefetch paid one trip to the infinity cache per eight domains: 12.2 K cycles per workgroup)
+    float x[32];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = u.dm_copy[min(k, u.n_domain - 1) * EMB + r];
+    for (int k = 0; k < 32; ++k) x[k] = u.dm_copy[min(k, u.n_domain - 1) * EMB + r];
     for (int idx = tid; idx < u.n_domain * W0LIN_COLS; idx += 256) {
         const int d = idx / W0LIN_COLS, cc = idx - d * W0LIN_COLS;
         s_l[idx] = slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + c0 + cc);
     }
     __syncthreads();
     f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int d0 = 0; d0 < u.n_domain; d0 += 8) {
-        float xn[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xn[k] = u.dm_copy[min(d0 + 8 + k, u.n_domain - 1) * EMB + r];   // next eight
+    for (int k = 0; k < 32; ++k) {
+        if (k < u.n_domain) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + k * W0LIN_COLS + 4 * half);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (d0 + k < u.n_domain) {
-                const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + (d0 + k) * W0LIN_COLS + 4 * half);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = fmaf(x[k], sv[q], g[q]);
-            }
+            for (int q = 0; q < 4; ++q) g[q] = fmaf(x[k], sv[q], g[q]);
         }
+    }
+    for (int d = 32; d < u.n_domain; ++d) {              // (33 .. 64 domains)
+        const float xd = u.dm_copy[d * EMB + r];
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + d * W0LIN_COLS + 4 * half);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = xn[k];
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(xd, sv[q], g[q]);
     }
     apply_vec4(u, e, g, p0, m0, v0);
 }
 
+#ifdef MAMDR_STAMPS
+#define USTAMP(k)                                                                             \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (u.stamps && threadIdx.x == 0 && bx < 1024) u.stamps[bx * 4 + (k)] = t_;            \
+    } while (0)
+#else
+#define USTAMP(k) do { } while (0)
+#endif
+
 constexpr int DM_CBLOCKS = 8;       // column blocks of the domain table's update: 16 columns per workgroup
 __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, float* s_l) {
+    USTAMP(0);
     const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
     // the workgroups with the longest dependent chain come first in the grid
     const int n_lin_wgs = u.dm_copy ? W0LIN_WGS : 0;
     if (bx < n_lin_wgs) {
         update_w0dom_linear(u, bx, s_l);
+        USTAMP(2);
         return;
     }
     const int bid = bx - n_lin_wgs;
@@ -1421,7 +1436,10 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(u.p + e);
         const f32x4 m0 = *reinterpret_cast<const f32x4*>(u.m + e);
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(u.v + e);
-        apply_vec4(u, e, slab_sum4(u.slabs, u.n_groups, u.slab_ld, e), p0, m0, v0);
+        const f32x4 gs = slab_sum4(u.slabs, u.n_groups, u.slab_ld, e);
+        USTAMP(1);
+        apply_vec4(u, e, gs, p0, m0, v0);
+        USTAMP(2);
         return;
     }
     // domain table, one workgroup per (domain d, 16 columns c):
@@ -1434,16 +1452,31 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
     const int d = blk / DM_CBLOCKS, c0 = (blk - d * DM_CBLOCKS) * (EMB / DM_CBLOCKS);
     if (d >= u.dm_count / EMB) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    s_l[threadIdx.x] = slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + threadIdx.x);
-    __syncthreads();
-    const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + 4 * lane);
     constexpr int PER_WAVE = EMB / DM_CBLOCKS / 4;
+    // (round 5: the wave's four elements' parameters, slots, W0 snapshot rows and S2 sums are requested BEFORE the S row's slab
+    // sums are waited for -- one trip instead of five; round 4 tried the same while the 32 linearity workgroups were the
+    // kernel's long pole and saw no change)
+    float pe[PER_WAVE], me[PER_WAVE], ve[PER_WAVE], g2e[PER_WAVE];
+    f32x4 wve[PER_WAVE];
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int c = c0 + w * PER_WAVE + i, el = d * EMB + c;
-        float p = u.p[el], m = u.m[el], v = u.v[el];
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
-        const float g2 = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
+        pe[i] = u.p[el];
+        me[i] = u.m[el];
+        ve[i] = u.v[el];
+        wve[i] = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
+        g2e[i] = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
+    }
+    s_l[threadIdx.x] = slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + threadIdx.x);
+    __syncthreads();
+    USTAMP(1);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int c = c0 + w * PER_WAVE + i, el = d * EMB + c;
+        float p = pe[i], m = me[i], v = ve[i];
+        const f32x4 wv = wve[i];
+        const float g2 = g2e[i];
         float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
         for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
         if (lane == 0) {
@@ -1462,6 +1495,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
             u.p[el] = p;
         }
     }
+    USTAMP(2);
 }
 #define UPDATE_EARLY_PARAMS                                                                                            \
     float *__restrict__ k_p, float *__restrict__ k_m, float *__restrict__ k_v, const float *__restrict__ k_slabs,      \

@@ -31,7 +31,7 @@ w = (rs.standard_normal(eng.n_params) * 0.05).astype(np.float32); eng.set_weight
 # stamp the eval launch (forward phases) and, for train, rely on a debug env hook.
 n = eng.n_rows(d, "train")
 tiles = bs // (4 if os.environ.get('MAMDR_TOWER_TILE') != '16' else 16)
-stamps = torch.zeros(65536 + 8192, dtype=torch.int64, device=eng.device)
+stamps = torch.zeros(65536 + 8192 + 4096, dtype=torch.int64, device=eng.device)
 eng.lib.mamdr_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 eng.lib.mamdr_debug_set_stamps(eng.ctx, C.c_void_p(stamps.data_ptr()))
 perm = torch.from_numpy(engine.shuffle_perm(n, 10000, 1)).to(eng.device)
@@ -78,3 +78,26 @@ print("k_wgrad: %d tile workgroups stamped; lifetime median %.0f cycles" % (len(
 for i, nme in enumerate(["tile descriptor load", "row loads + MFMAs (wave 0)", "LDS write + barrier", "reduce + slab store"]):
     print("  %-28s %8.0f" % (nme, np.median(wd[:, i])))
 print("  first start -> last end: %.0f cycles; start spread %.0f" % (ws[:, 4].max() - ws[:, 0].min(), ws[:, 0].max() - ws[:, 0].min()))
+
+# ---- k_update (slab path): [workgroups][4] stamps (entry, operands summed, exit); workgroup kinds by index: the first 32
+#      step W0[256:384] by linearity (frozen-table mlp tower), then the float4 workgroups, then the domain table's (D x 8)
+us = allst[65536 + 8192:65536 + 8192 + 4096].reshape(1024, 4)[:, :3].astype(np.float64)
+live = us[:, 0] > 0
+if live.any():
+    idx = np.nonzero(live)[0]
+    t0 = us[live, 0].min()
+    n_lin = 32
+    n_vec = (139777 + 3) // 4 // 256 + 1          # float4 workgroups behind the domain table's elements (update_blocks)
+    kinds = [("W0[256:384] by linearity", idx[idx < n_lin]), ("float4 elements", idx[(idx >= n_lin) & (idx < n_lin + n_vec)]),
+             ("domain table", idx[idx >= n_lin + n_vec])]
+    print("k_update: %d workgroups stamped; first start -> last exit %.0f cycles; start spread %.0f" % (
+        len(idx), us[live, 2].max() - t0, us[live, 0].max() - t0))
+    for nme, ii in kinds:
+        if len(ii) == 0:
+            continue
+        a = us[ii]
+        ok = a[:, 2] > 0
+        mid = np.where(a[:, 1] > 0, a[:, 1], a[:, 0])
+        print("  %-26s %4d workgroups: start %6.0f .. %6.0f after the first; operands summed after %6.0f (median); lifetime median "
+              "%6.0f max %6.0f; last exit %6.0f" % (nme, len(ii), (a[:, 0] - t0).min(), (a[:, 0] - t0).max(), np.median(mid - a[:, 0]),
+                                                  np.median(a[ok, 2] - a[ok, 0]), (a[ok, 2] - a[ok, 0]).max(), (a[ok, 2] - t0).max()))
