@@ -1273,20 +1273,25 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s) {
 // infinity cache -- the timeline of k_update showed 5 K cycles for the two batches of eight; round 2's rolled loop paid one
 // trip per slab); the additions run in slab order as before (bit-identical)
 __device__ __forceinline__ f32x4 slab_sum4(const float* slabs, int n_groups, int slab_ld, size_t e) {
-    f32x4 t[16];
+    // (float4: eight slabs' loads in flight -- sixteen would cost the kernel half its occupancy: 113 instead of 62 VGPRs, and the
+    // kernel is bound by how many requests the chip keeps in flight, not by this thread's trips: measured on Amazon-6)
+    f32x4 g = *reinterpret_cast<const f32x4*>(slabs + e);
+    for (int s0 = 1; s0 < n_groups; s0 += 8) {
+        f32x4 t[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = *reinterpret_cast<const f32x4*>(slabs + (size_t)min(k, n_groups - 1) * slab_ld + e);
-    f32x4 g = t[0];
+        for (int k = 0; k < 8; ++k)
+            t[k] = *reinterpret_cast<const f32x4*>(slabs + (size_t)min(s0 + k, n_groups - 1) * slab_ld + e);
 #pragma unroll
-    for (int k = 1; k < 16; ++k)
-        if (k < n_groups) g += t[k];
-    for (int s0 = 16; s0 < n_groups; ++s0) g += *reinterpret_cast<const f32x4*>(slabs + (size_t)s0 * slab_ld + e);      // (MAMDR_MAX_GROUPS > 16)
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < n_groups) g += t[k];
+    }
     return g;
 }
 __device__ __forceinline__ float slab_sum1(const float* slabs, int n_groups, int slab_ld, size_t e) {
     float t[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = slabs[(size_t)min(k, n_groups - 1) * slab_ld + e];
+    for (int k = 0; k < 16; ++k)
+        if (k < n_groups) t[k] = slabs[(size_t)k * slab_ld + e];
     float g = t[0];
 #pragma unroll
     for (int k = 1; k < 16; ++k)
@@ -1456,7 +1461,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
     // (round 5: the wave's four elements' parameters, slots, W0 snapshot rows and S2 sums are requested BEFORE the S row's slab
     // sums are waited for -- one trip instead of five; round 4 tried the same while the 32 linearity workgroups were the
     // kernel's long pole and saw no change)
-    float pe[PER_WAVE], me[PER_WAVE], ve[PER_WAVE], g2e[PER_WAVE];
+    float pe[PER_WAVE], me[PER_WAVE], ve[PER_WAVE];
     f32x4 wve[PER_WAVE];
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
@@ -1465,7 +1470,6 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
         me[i] = u.m[el];
         ve[i] = u.v[el];
         wve[i] = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
-        g2e[i] = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
     }
     s_l[threadIdx.x] = slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + threadIdx.x);
     __syncthreads();
@@ -1476,7 +1480,8 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
         const int c = c0 + w * PER_WAVE + i, el = d * EMB + c;
         float p = pe[i], m = me[i], v = ve[i];
         const f32x4 wv = wve[i];
-        const float g2 = g2e[i];
+        // (DeepFM's S2 sums stay in the loop: hoisted with the rest they made k_update_lin slower on Amazon-6, 7.55 -> 8.05 us)
+        const float g2 = u.s2_off ? slab_sum1(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
         float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
         for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
         if (lane == 0) {
@@ -1497,6 +1502,138 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
     }
     USTAMP(2);
 }
+
+// ---- the NARROW forms (rounds 2 - 4; 62 VGPRs, eight waves per SIMD): up to 8 row groups, k_update_lin.  Sum of one float4 / float over the gradient slabs IN SLAB ORDER, eight slabs' loads in flight (the rolled
+// loop paid one dependent round trip per slab: 4 at 1024 rows, 16 at 4096)
+__device__ __forceinline__ f32x4 slab_sum4_n(const float* slabs, int n_groups, int slab_ld, size_t e) {
+    f32x4 g = *reinterpret_cast<const f32x4*>(slabs + e);
+    for (int s0 = 1; s0 < n_groups; s0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            t[k] = *reinterpret_cast<const f32x4*>(slabs + (size_t)min(s0 + k, n_groups - 1) * slab_ld + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < n_groups) g += t[k];
+    }
+    return g;
+}
+__device__ __forceinline__ float slab_sum1_n(const float* slabs, int n_groups, int slab_ld, size_t e) {
+    float g = slabs[e];
+    for (int s0 = 1; s0 < n_groups; s0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = slabs[(size_t)min(s0 + k, n_groups - 1) * slab_ld + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < n_groups) g += t[k];
+    }
+    return g;
+}
+
+// dW0[256:384, :] by linearity.  Those rows of x are the domain-embedding row of the sample's domain, the same
+// vector for every sample of a domain, so  sum_b x[b][256 + r] dz1[b][c] = sum_d Dm[d][r] S[d][c]  with
+// S = onehot(domain)^T dz1 -- which k_wgrad computes anyway for the domain-table gradient.  8 of the 34 64x64
+// tiles of k_wgrad (24 % of its MFMA work) become D fmas per element here.  One workgroup per 8 columns:
+// S[:, 8 columns] is summed over the slabs into LDS once, thread (r, half) then owns W0[256 + r][c0 + 4 half .. +3].
+__device__ __forceinline__ void update_w0dom_linear_n(const UpdateArgs& u, int wg, float* s_l) {
+    const int tid = threadIdx.x, c0 = wg * W0LIN_COLS;
+    const int r = tid >> 1, half = tid & 1;
+    // this thread's parameters and slots, and the first eight domains' embedding values of row r, are requested
+    // before the S block is reduced
+    const size_t e = (size_t)u.w0_off + (size_t)(2 * EMB + r) * H1 + c0 + 4 * half;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(u.p + e);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(u.m + e);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(u.v + e);
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = u.dm_copy[min(k, u.n_domain - 1) * EMB + r];
+    for (int idx = tid; idx < u.n_domain * W0LIN_COLS; idx += 256) {
+        const int d = idx / W0LIN_COLS, cc = idx - d * W0LIN_COLS;
+        s_l[idx] = slab_sum1_n(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + c0 + cc);
+    }
+    __syncthreads();
+    f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < u.n_domain; d0 += 8) {
+        float xn[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xn[k] = u.dm_copy[min(d0 + 8 + k, u.n_domain - 1) * EMB + r];   // next eight
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (d0 + k < u.n_domain) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + (d0 + k) * W0LIN_COLS + 4 * half);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = fmaf(x[k], sv[q], g[q]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = xn[k];
+    }
+    apply_vec4(u, e, g, p0, m0, v0);
+}
+
+__device__ __forceinline__ void update_body_n(const UpdateArgs& u, const int bx, float* s_l) {
+    const int n_vec_wgs = (u.count4 - u.dm_count / 4 + 255) / 256;
+    // the workgroups with the longest dependent chain come first in the grid
+    const int n_lin_wgs = u.dm_copy ? W0LIN_WGS : 0;
+    if (bx < n_lin_wgs) {
+        update_w0dom_linear_n(u, bx, s_l);
+        return;
+    }
+    const int bid = bx - n_lin_wgs;
+    if (bid < n_vec_wgs) {
+        // dense weights behind the domain table: float4 per thread
+        const int e4 = u.dm_count / 4 + bid * 256 + threadIdx.x;
+        if (e4 >= u.count4) return;
+        const size_t e = (size_t)e4 * 4;
+        // (rows 256..383 of W0 have no tiles when their gradient comes from S: update_w0dom_linear_n)
+        if (u.dm_copy && (int)e >= u.w0_off + 2 * EMB * H1 && (int)e < u.w0_off + XDIM * H1) return;
+        // (parameters and slots are requested before the slab sum is waited for: one round of misses, not two)
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(u.p + e);
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(u.m + e);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(u.v + e);
+        apply_vec4(u, e, slab_sum4_n(u.slabs, u.n_groups, u.slab_ld, e), p0, m0, v0);
+        return;
+    }
+    // domain table, one workgroup per (domain d, 16 columns c):
+    //   g[d][c] = sum_k S[d][k] * W0[256 + c][k] + 2 l2 p,   S = onehot(domain)^T dz1 summed over the slabs
+    // S[d][:] is summed over the slabs ONCE per workgroup (thread k owns element k; LDS), then every wave contracts it with
+    // four rows of the W0 snapshot.  (One wave per element re-summed the 16 slabs of S[d][:] for each of its 128 columns:
+    // 960 workgroups x 16 KB on Taobao-30.)  Same orders as that form -- slabs in sequence, four fmas per lane, the
+    // xor tree over the lanes: bit-identical.
+    const int blk = bid - n_vec_wgs;
+    const int d = blk / DM_CBLOCKS, c0 = (blk - d * DM_CBLOCKS) * (EMB / DM_CBLOCKS);
+    if (d >= u.dm_count / EMB) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    s_l[threadIdx.x] = slab_sum1_n(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s_off + (size_t)d * H1 + threadIdx.x);
+    __syncthreads();
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s_l + 4 * lane);
+    constexpr int PER_WAVE = EMB / DM_CBLOCKS / 4;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int c = c0 + w * PER_WAVE + i, el = d * EMB + c;
+        float p = u.p[el], m = u.m[el], v = u.v[el];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(u.w0dom_copy + (size_t)c * H1 + 4 * lane);
+        const float g2 = u.s2_off ? slab_sum1_n(u.slabs, u.n_groups, u.slab_ld, (size_t)u.s2_off + el) : 0.f;
+        float g = fmaf(sv[3], wv[3], fmaf(sv[2], wv[2], fmaf(sv[1], wv[1], sv[0] * wv[0])));
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+        if (lane == 0) {
+            if (u.no_sdm) g = 0.f;
+            if (u.s2_off) g += g2;
+            g += u.two_l2 * p;
+            optimizer_step(u, g, p, m, v);
+            if (u.optimizer == 2) {
+                u.m[el] = m;
+                continue;
+            }
+            if (u.optimizer == 0) {
+                u.m[el] = m;
+                u.v[el] = v;
+            }
+            u.p[el] = p;
+        }
+    }
+}
 #define UPDATE_EARLY_PARAMS                                                                                            \
     float *__restrict__ k_p, float *__restrict__ k_m, float *__restrict__ k_v, const float *__restrict__ k_slabs,      \
         const int k_n_groups, const int k_slab_ld, const int k_count4, const int k_dm_count, const int k_optimizer
@@ -1505,10 +1642,15 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bx, f
     UpdateArgs u = u0;                                                                                                 \
     u.p = k_p; u.m = k_m; u.v = k_v; u.slabs = k_slabs; u.n_groups = k_n_groups; u.slab_ld = k_slab_ld;               \
     u.count4 = k_count4; u.dm_count = k_dm_count; u.optimizer = k_optimizer
+// WIDE (round 5): the forms that keep every operand of a workgroup in flight at once -- 113 VGPRs, four waves per SIMD; they
+// pay where a step has more than 8 row groups (4,096-row batches: k_update 7.5 -> 7.0 us) and cost where it has 4 and the
+// launch hosts many other workgroups (Amazon-6's k_update_lin: 7.55 -> 8.0+ us with them) -- an instance of its own
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_update(UPDATE_EARLY_PARAMS, const UpdateArgs u0) {
     __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];     // n_domain <= 64
     UPDATE_EARLY_APPLY(u, u0);
-    update_body(u, (int)blockIdx.x, s_l);
+    if constexpr (WIDE) update_body(u, (int)blockIdx.x, s_l);
+    else update_body_n(u, (int)blockIdx.x, s_l);
 }
 // rider workgroup rb (4 waves = 4 tiles of the next step's tower, all = rb mod 8): see GatherPf
 __device__ __forceinline__ void gather_prefetch_body(const GatherPf& p, const int rb) {
@@ -1526,12 +1668,16 @@ __device__ __forceinline__ void gather_prefetch_body(const GatherPf& p, const in
     const float t1 = base[0] + base[32];                          // one word per 128-B line
     if (t0 + t1 == 1.2345678e30f) p.sink[0] = t1;                 // (keeps the loads)
 }
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_update_pf(UPDATE_EARLY_PARAMS, const UpdateArgs u0, const GatherPf pf, const int n_update,
                                                    const int n_pad) {
     __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
     UPDATE_EARLY_APPLY(u, u0);
     const int bid = (int)blockIdx.x;
-    if (bid < n_update) update_body(u, bid, s_l);
+    if (bid < n_update) {
+        if constexpr (WIDE) update_body(u, bid, s_l);
+        else update_body_n(u, bid, s_l);
+    }
     else if (bid >= n_pad) gather_prefetch_body(pf, bid - n_pad);
 }
 // k_update and DeepFM's k_lin_sweep touch disjoint state: one launch
@@ -1543,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_update_lin(UPDATE_EARLY_PARAMS, const U
     UPDATE_EARLY_APPLY(u, u0);
     const int bid = (int)blockIdx.x;
     if (bid < 2 * n_cu) emb_catchup_body(nc, bid % n_cu, bid / n_cu);
-    else if (bid < 2 * n_cu + n_update) update_body(u, bid - 2 * n_cu, s_l);
+    else if (bid < 2 * n_cu + n_update) update_body_n(u, bid - 2 * n_cu, s_l);
     else lin_sweep_body(e, bid - 2 * n_cu - n_update, n_lin);
 }
 static int update_blocks(const UpdateArgs& a) {
@@ -1555,10 +1701,14 @@ void launch_update(const UpdateArgs& a, hipStream_t s, const GatherPf* pf) {
     if (pf && pf->n_tiles > 0) {
         // riders behind the update's workgroups, at block ids that are = their tiles mod 8 (the XCD of block b is b mod 8)
         const int n_pad = (n_update + 7) / 8 * 8, n_riders = ((pf->n_tiles + 7) / 8 + 3) / 4 * 8;
-        MAMDR_LAUNCH(k_update_pf, dim3(n_pad + n_riders), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a, *pf, n_update, n_pad);
+        if (a.n_groups > 8)
+            MAMDR_LAUNCH(k_update_pf<true>, dim3(n_pad + n_riders), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a, *pf, n_update, n_pad);
+        else
+            MAMDR_LAUNCH(k_update_pf<false>, dim3(n_pad + n_riders), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a, *pf, n_update, n_pad);
         return;
     }
-    MAMDR_LAUNCH(k_update, dim3(n_update), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a);
+    if (a.n_groups > 8) MAMDR_LAUNCH(k_update<true>, dim3(n_update), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a);
+    else MAMDR_LAUNCH(k_update<false>, dim3(n_update), dim3(256), 0, s, UPDATE_EARLY_ARGS(a), a);
 }
 void launch_update_lin(const UpdateArgs& a, const EmbStepArgs& e, bool lin, const EmbStepArgs* next_catchup, hipStream_t s) {
     const int64_t n_all = e.t[0].n_rows + e.t[1].n_rows;
