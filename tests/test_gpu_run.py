@@ -137,6 +137,67 @@ def test_bench_gpus2_starts_two_ranks(tmp_path):
     assert rec["config"]["domain_steps_per_epoch"] > 1000 and 1.0 < rec["partition_speedup_bound"] <= 2.0
 
 
+SHARDED_WORKER = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, {root!r})
+from mamdr_amd import cli
+cfg = json.load(open({cfg!r}))
+built = []
+res = cli.main(cfg, on_model=built.append)           # init_distributed(): gloo over the shared GPU (MAMDR_SHARE_GPU=1)
+eng = built[0].model
+sha = hashlib.sha1(eng.get_weights().cpu().numpy().tobytes()).hexdigest()
+rank = int(os.environ["RANK"])
+json.dump({{"avg_auc": res[1], "domain_auc": {{str(k): v for k, v in res[3].items()}}, "weights_sha": sha}},
+          open({out!r} % rank, "w"))
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("name,extra", [("mlp_meta_reptile", {"target_domain": 1}),
+                                        ("mlp_meta_domain_negotiation", {"target_domain": 2, "meta_train_step": 2}),
+                                        ("mlp_meta_mamdr_finetune", {})])
+def test_run_entry_two_ranks_on_the_hip_engine(tmp_path, name, extra):
+    """run.py's entry under two processes ON THE HIP ENGINE (both ranks on this GPU, gloo carrying device tensors): the
+    sharded wrappers' collectives -- the all-reduce of the displacement, the phi hand-over, the broadcast of the live model
+    after a target-domain pass (parallel.broadcast_live, ADVICE r04) -- on device memory.  Every rank ends with the same
+    per-domain results; with a target domain every rank ends with the SAME live weights (hash)."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    with open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
+        cfg = copy.deepcopy(json.load(f))
+    cfg["model"]["name"] = name
+    cfg["train"].update(epoch=2, patience=2, sample_num=2, meta_learning_rate=0.5,
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    cfg["train"].update(extra)
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
+    cfg_path = tmp_path / "cfg.json"
+    cfg_path.write_text(json.dumps(cfg))
+    script = tmp_path / "worker.py"
+    script.write_text(SHARDED_WORKER.format(root=ROOT, cfg=str(cfg_path), out=str(tmp_path / "res_%d.json")))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", MAMDR_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
+    a, b = (json.load(open(str(tmp_path / ("res_%d.json" % r)))) for r in range(2))
+    assert a["domain_auc"] == b["domain_auc"] and len(a["domain_auc"]) == 10 and a["avg_auc"] > 0.6
+    if extra.get("target_domain", -1) >= 0:
+        assert a["weights_sha"] == b["weights_sha"]
+
+
 def test_rccl_communicator_on_this_gpu():
     """backend "nccl" is RCCL here: a one-rank communicator on the MI355X reduces device memory (float32 and the
     float64 timings bench.py reduces) and passes a barrier.  The N > 1 code paths themselves are covered by the gloo
