@@ -134,6 +134,9 @@ struct mamdr_ctx {
     int64_t pg_hits = 0;            // calls served from an entry (mamdr_pregather_hits)
     int64_t pg_launches = 0;        // hints that launched k_pass_prep_multi (mamdr_pregather_launches)
     bool gather_pf = true;          // MAMDR_NO_GATHER_PF=1: no riders in k_update's launch touching the next step's gather
+    bool gather_pf_in_wgrad = true;    // the riders of the next step's gather sit in k_wgrad's launch (round 5: k_update, bound by what it pulls over
+                                       // the fabric, loses 0.42 us without them, k_wgrad gains 0.13; profiles/r05_ab_riders_place.txt);
+                                       // MAMDR_GATHER_PF_IN=update: in k_update's launch as in rounds 3 - 4
     bool fused_pf = false;          // MAMDR_FUSED_PF=1: riders in k_wgrad_adam's launch touch the next tower launch's pre-gathered rows (round 5:
                                     // measured and left off -- the tower gains 0.08 us, k_wgrad_adam's second round of blocks costs 0.8;
                                     // profiles/r05_ab_fused_pf.txt)
@@ -863,6 +866,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     if (const char* ev = getenv("MAMDR_NO_GATHER_PF")) c->gather_pf = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_FUSED_PF")) c->fused_pf = atoi(ev) != 0;
+    if (const char* ev = getenv("MAMDR_GATHER_PF_IN")) c->gather_pf_in_wgrad = strcmp(ev, "update") != 0;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
     ALLOC(c->thresholds, sizeof(thr));
@@ -1612,10 +1616,36 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             nea.t[1].brow = c->irow_alt;
             nea.t[1].map = c->map_i_alt;
         }
+        // frozen tables, another step of this call follows on the 16-row tower: its gather is touched by riders (GatherPf,
+        // mamdr_kernels.h) -- in k_wgrad's launch (default since round 5), or (MAMDR_GATHER_PF_IN=update) in k_update's
+        GatherPf pf;
+        memset(&pf, 0, sizeof(pf));
+        if (!tail && c->gather_pf && !c->cfg.emb_trainable && !c->star && s + 1 < n_steps) {
+            const int64_t nb = row_base + batch;
+            const int nrows = (int)std::min<int64_t>(batch, pass_rows - nb);
+            const int npad = (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+            const bool next4 = may_use4 && (c->tower_tile == 4 || npad <= c->tower4_max_rows);
+            if (nrows > 0 && !next4) {
+                pf.perm = d_perm;
+                pf.uid = d->uid;
+                pf.pid = d->pid;
+                pf.dom = d->dom;
+                pf.label = d->label;
+                pf.user_tab = c->user_tab;
+                pf.item_tab = c->item_tab;
+                pf.row_base = nb;
+                pf.n_rows_split = d->n;
+                pf.rows = nrows;
+                pf.n_user = c->cfg.n_user;
+                pf.n_item = c->cfg.n_item;
+                pf.n_tiles = npad / TILE_ROWS;
+                pf.sink = c->loss_part;
+            }
+        }
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
             if (tail) launch_wgrad_reduce(wa, tea, pre ? &nr : nullptr, nullptr, c->stream);
-            else launch_wgrad(wa, c->stream);
+            else launch_wgrad(wa, c->stream, c->gather_pf_in_wgrad ? &pf : nullptr);
         }
 
         UpdateArgs ua;
@@ -1667,31 +1697,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             } else {
                 // frozen tables, another step of this call follows on the 16-row tower: its gather is touched by riders
                 // (GatherPf, mamdr_kernels.h)
-                GatherPf pf;
-                memset(&pf, 0, sizeof(pf));
-                if (c->gather_pf && !c->cfg.emb_trainable && !c->star && s + 1 < n_steps) {
-                    const int64_t nb = row_base + batch;
-                    const int nrows = (int)std::min<int64_t>(batch, pass_rows - nb);
-                    const int npad = (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
-                    const bool next4 = may_use4 && (c->tower_tile == 4 || npad <= c->tower4_max_rows);
-                    if (nrows > 0 && !next4) {
-                        pf.perm = d_perm;
-                        pf.uid = d->uid;
-                        pf.pid = d->pid;
-                        pf.dom = d->dom;
-                        pf.label = d->label;
-                        pf.user_tab = c->user_tab;
-                        pf.item_tab = c->item_tab;
-                        pf.row_base = nb;
-                        pf.n_rows_split = d->n;
-                        pf.rows = nrows;
-                        pf.n_user = c->cfg.n_user;
-                        pf.n_item = c->cfg.n_item;
-                        pf.n_tiles = npad / TILE_ROWS;
-                        pf.sink = c->loss_part;
-                    }
-                }
-                launch_update(ua, c->stream, &pf);
+                launch_update(ua, c->stream, c->gather_pf_in_wgrad ? nullptr : &pf);
             }
         }
         if (c->cfg.emb_trainable && !tail) emb_post_step(c, optimizer, ua.alpha, omb1, omb2, rows);

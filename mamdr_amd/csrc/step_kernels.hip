@@ -1264,7 +1264,14 @@ void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRows
     MAMDR_LAUNCH(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a, e, n_wgrad,
                        nr, n_rows, sd, n_dm);
 }
-void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+__global__ void k_wgrad_pf(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad);
+void launch_wgrad(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
+    if (pf && pf->n_tiles > 0) {        // (the riders of the next step's gather in THIS launch: default since round 5)
+        const int n_wgrad = wgrad_blocks(a);
+        const int n_pad = (n_wgrad + 7) / 8 * 8, n_riders = ((pf->n_tiles + 7) / 8 + 3) / 4 * 8;
+        MAMDR_LAUNCH(k_wgrad_pf, dim3(n_pad + n_riders), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a, *pf, n_wgrad, n_pad);
+        return;
+    }
     MAMDR_LAUNCH(k_wgrad, dim3(wgrad_blocks(a)), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a);
 }
 
@@ -1667,6 +1674,13 @@ __device__ __forceinline__ void gather_prefetch_body(const GatherPf& p, const in
     const float* base = (part < 2 ? p.user_tab + (size_t)u * EMB : p.item_tab + (size_t)it * EMB) + (part & 1) * (EMB / 2);
     const float t1 = base[0] + base[32];                          // one word per 128-B line
     if (t0 + t1 == 1.2345678e30f) p.sink[0] = t1;                 // (keeps the loads)
+}
+__global__ __launch_bounds__(256) void k_wgrad_pf(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad) {
+    __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
+    WGRAD_EARLY_APPLY(g, g0);
+    const int bid = (int)blockIdx.x;
+    if (bid < n_wgrad) wgrad_body(g, bid, red);
+    else if (bid >= n_pad) gather_prefetch_body(pf, bid - n_pad);
 }
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_update_pf(UPDATE_EARLY_PARAMS, const UpdateArgs u0, const GatherPf pf, const int n_update,
