@@ -134,6 +134,7 @@ struct mamdr_ctx {
     int64_t pg_hits = 0;            // calls served from an entry (mamdr_pregather_hits)
     int64_t pg_launches = 0;        // hints that launched k_pass_prep_multi (mamdr_pregather_launches)
     bool gather_pf = true;          // MAMDR_NO_GATHER_PF=1: no riders in k_update's launch touching the next step's gather
+    bool wgrad_pairs = false;          // MAMDR_WGRAD_PAIRS=1: k_wgrad8 (eight waves, one slab per pair of row groups) where a step has > 8 groups
     bool gather_pf_in_wgrad = true;    // the riders of the next step's gather sit in k_wgrad's launch (round 5: k_update, bound by what it pulls over
                                        // the fabric, loses 0.42 us without them, k_wgrad gains 0.13; profiles/r05_ab_riders_place.txt);
                                        // MAMDR_GATHER_PF_IN=update: in k_update's launch as in rounds 3 - 4
@@ -866,6 +867,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     if (const char* ev = getenv("MAMDR_NO_GATHER_PF")) c->gather_pf = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_FUSED_PF")) c->fused_pf = atoi(ev) != 0;
+    if (const char* ev = getenv("MAMDR_WGRAD_PAIRS")) c->wgrad_pairs = atoi(ev) != 0;
     if (const char* ev = getenv("MAMDR_GATHER_PF_IN")) c->gather_pf_in_wgrad = strcmp(ev, "update") != 0;
     ALLOC(c->slabs, (size_t)c->max_groups * c->slab_ld * sizeof(float));
     ALLOC(c->tiles, tiles.size() * sizeof(TileDesc));
@@ -1642,10 +1644,15 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
                 pf.sink = c->loss_part;
             }
         }
+        bool paired = false;        // k_wgrad8: one slab per PAIR of row groups (MAMDR_WGRAD_PAIRS; steps of more than 8 groups)
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
             if (tail) launch_wgrad_reduce(wa, tea, pre ? &nr : nullptr, nullptr, c->stream);
-            else launch_wgrad(wa, c->stream, c->gather_pf_in_wgrad ? &pf : nullptr);
+            else {
+                if (c->wgrad_pairs && !c->star && !c->cfg.emb_trainable && groups > 8)
+                    paired = launch_wgrad_pairs(wa, c->stream, c->gather_pf_in_wgrad ? &pf : nullptr);
+                if (!paired) launch_wgrad(wa, c->stream, c->gather_pf_in_wgrad ? &pf : nullptr);
+            }
         }
 
         UpdateArgs ua;
@@ -1654,7 +1661,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         ua.m = (optimizer == MAMDR_OPT_ACCUMULATE ? c->accum : c->adam_m) + c->table_floats;
         ua.v = c->adam_v + c->table_floats;
         ua.slabs = c->slabs;
-        ua.n_groups = groups;
+        ua.n_groups = paired ? (groups + 1) / 2 : groups;
 #ifdef MAMDR_STAMPS
         ua.stamps = c->stamps ? c->stamps + 65536 + 8192 : nullptr;
 #endif

@@ -620,6 +620,7 @@ struct EvalFinishArgs {
 void launch_eval_finish(const EvalFinishArgs& a, hipStream_t s);
 struct GatherPf;
 void launch_wgrad(const WgradArgs& a, hipStream_t s, const GatherPf* pf = nullptr);
+bool launch_wgrad_pairs(const WgradArgs& a, hipStream_t s, const GatherPf* pf);      // false: the 96 KB of LDS were refused
 // the NEXT step's gather, touched ahead of time by rider workgroups in k_update's launch.  What one kernel leaves in an
 // XCD's L2 survives the kernel boundary (tools/probes/l2_survive_probe.hip: 240 cycles for a line the same workgroup id
 // touched in the kernel before, 1,400 cold, 600 when another XCD touched it), and workgroup b of any 1-d grid runs on XCD

@@ -1246,6 +1246,132 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WGRAD_EARLY_PARAMS, const 
     if (idx < 2 * nb) emb_reduce_body(e, idx % nb, idx / nb, reinterpret_cast<uint16_t(*)[RED_CAP]>(red));
     else emb_rows_body(nr, idx - 2 * nb);
 }
+// ---- k_wgrad8 (round 5): one workgroup of EIGHT waves = one tile x TWO adjacent row groups.  Waves 0..3 run row group
+// 2 q, waves 4..7 row group 2 q + 1, each half with its own staging buffers; the two partial tiles are added through LDS
+// (group 2 q first) and ONE slab per pair is written: half the slab bytes for k_update -- which is bound by what it pulls
+// over the fabric -- with the same eight waves per CU that two co-resident four-wave workgroups give.  (Fewer, longer
+// four-wave workgroups lose that: profiles/r05_ab_groups_taobao30.txt.)  Frozen-table slab path only.
+__device__ __forceinline__ void wgrad8_big(const WgradArgs& g, const TileDesc& t, int gb0, int gb1, int n_chunks, float* lds,
+                                            float* xch, int pair, int half) {
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int c = lane & 31, kk = lane >> 5;
+    const int lr = tid >> 4, lc4 = (tid & 15) * 4;
+    f32x4 ra[WG_PF][2], rb[WG_PF][2];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](int slot, int ch) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = gb0 + ch * WG_KC + lr + 16 * h;
+            const bool ok = ch < n_chunks && b < gb1;
+            ra[slot][h] = ok ? *reinterpret_cast<const f32x4*>(g.acts + (size_t)b * ACT_LD + t.a_off + lc4) : zero4;
+            rb[slot][h] = ok ? *reinterpret_cast<const f32x4*>(g.dz + (size_t)b * DZ_LD + t.b_off + lc4) : zero4;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < WG_PF; ++s) issue(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // (n_chunks is the same for both halves -- a short or missing last group stages zeros -- so that the barriers pair up)
+    for (int ch0 = 0; ch0 < n_chunks; ch0 += WG_PF) {
+#pragma unroll
+        for (int u = 0; u < WG_PF; ++u) {
+            const int ch = ch0 + u;
+            if (ch >= n_chunks) break;                 // uniform
+            float* As = lds + (ch & 1) * 2 * WG_BUF;
+            float* Bs = As + WG_BUF;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<f32x4*>(As + (lr + 16 * h) * WG_LD + lc4) = ra[u][h];
+                *reinterpret_cast<f32x4*>(Bs + (lr + 16 * h) * WG_LD + lc4) = rb[u][h];
+            }
+            __syncthreads();
+            issue(u, ch + WG_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* ap = As + kk * WG_LD + wm * 32 + c;
+            const float* bp = Bs + kk * WG_LD + wn * 32 + c;
+#pragma unroll
+            for (int i = 0; i < WG_KC / 2; ++i) acc = MAMDR_MFMA32(ap[2 * i * WG_LD], bp[2 * i * WG_LD], acc);
+        }
+    }
+    __syncthreads();                // every wave is past its last staged chunk: the exchange area may be written
+    if (half == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[r * 256 + tid] = acc[r];
+    }
+    __syncthreads();
+    if (half == 0) {
+        float* dst = g.slabs + (size_t)pair * g.slab_ld + t.dst_off + (size_t)(wm * 32) * t.dst_ld + wn * 32;
+        const int rb4 = 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            WS_STORE1(&dst[(size_t)((r & 3) + 8 * (r >> 2) + rb4) * t.dst_ld + c], acc[r] + xch[r * 256 + tid]);
+    }
+}
+
+// lds: 2 x 4 WG_BUF floats (96 KB, dynamic)
+__device__ __forceinline__ void wgrad8_body(const WgradArgs& g, const int bid, float* lds) {
+    const int n_pairs = (g.n_groups + 1) / 2;
+    const int n_work = g.n_tiles * n_pairs;
+    if (bid >= n_work) {
+        // the loss workgroup and the snapshot workgroups: the first four waves, as in k_wgrad (same indices behind n_work)
+        if (threadIdx.x >= 256) return;
+        WgradArgs g1 = g;
+        g1.n_groups = n_pairs;       // (wgrad_body derives n_work = n_tiles * n_groups: the same boundary)
+        wgrad_body(g1, bid, lds);
+        return;
+    }
+    const int half = (int)threadIdx.x >> 8;
+    const int pair = bid % n_pairs, tile = bid / n_pairs;
+    const TileDesc t = g.tiles[tile];
+    const int grp = 2 * pair + half;
+    const int gb0 = min(grp * g.rows_per_group, g.rows_pad);
+    const int gb1 = grp < g.n_groups ? min(gb0 + g.rows_per_group, g.rows_pad) : gb0;
+    float* xch = lds + 4 * WG_BUF;          // (the second half's staging area, free once its chunks are consumed)
+    if (t.big) {
+        wgrad8_big(g, t, gb0, gb1, (g.rows_per_group + WG_KC - 1) / WG_KC, lds + half * 4 * WG_BUF, xch, pair, half);
+        return;
+    }
+    // small tiles: the pair's rows [first group's start, second group's end) over the 8 waves in multiples of 2
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int p0 = min(2 * pair * g.rows_per_group, g.rows_pad), p1 = min(p0 + 2 * g.rows_per_group, g.rows_pad);
+    const int span = p1 > p0 ? p1 - p0 : 0;
+    const int per = ((span + 15) / 16) * 2;
+    const int b0 = min(p0 + w * per, p1), b1 = min(b0 + per, p1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (t.a_kind == 0 && t.b_kind == 0) wgrad_rows<0, 0>(g, t, b0, b1, acc);
+    else if (t.a_kind == 1 && t.b_kind == 0) wgrad_rows<1, 0>(g, t, b0, b1, acc);
+    else if (t.a_kind == 0 && t.b_kind == 1) wgrad_rows<0, 1>(g, t, b0, b1, acc);
+    else if (t.a_kind == 1 && t.b_kind == 1) wgrad_rows<1, 1>(g, t, b0, b1, acc);
+    else if (t.a_kind == 3) wgrad_rows<3, 0>(g, t, b0, b1, acc);
+    else if (t.b_kind == 0) wgrad_rows<2, 0>(g, t, b0, b1, acc);
+    else if (t.b_kind == 1) wgrad_rows<2, 1>(g, t, b0, b1, acc);
+    else wgrad_rows<2, 2>(g, t, b0, b1, acc);
+    {
+        const int col = lane & 31, rb = 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[w * 1024 + ((r & 3) + 8 * (r >> 2) + rb) * 32 + col] = acc[r];
+    }
+    __syncthreads();
+    float* slab = g.slabs + (size_t)pair * g.slab_ld;
+    for (int e = tid; e < 1024; e += 512) {
+        const int row = e >> 5, col = e & 31;
+        if (row < t.m_valid && col < t.n_valid) {
+            float v = lds[e];
+#pragma unroll
+            for (int ww = 1; ww < 8; ++ww) v += lds[ww * 1024 + e];
+            WS_STORE1(&slab[t.dst_off + row * t.dst_ld + col], v);
+        }
+    }
+}
+static int wgrad8_blocks(const WgradArgs& a) {
+    const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
+    return a.n_tiles * ((a.n_groups + 1) / 2) + 1 + W0DOM_COPY_WGS + dm_wgs;
+}
 static int wgrad_blocks(const WgradArgs& a) {
     const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
     return a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs;
@@ -1265,6 +1391,23 @@ void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRows
                        nr, n_rows, sd, n_dm);
 }
 __global__ void k_wgrad_pf(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad);
+__global__ void k_wgrad8(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad);
+// pairs of row groups per workgroup: ONE slab per pair (k_update then sums (n_groups + 1) / 2 slabs)
+bool launch_wgrad_pairs(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
+    static int raised = 0;
+    const size_t lds = (size_t)8 * WG_BUF * sizeof(float);
+    if (raised == 0)
+        raised = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
+                         hipSuccess ? 1 : -1;
+    if (raised != 1) return false;
+    GatherPf none;
+    memset(&none, 0, sizeof(none));
+    const GatherPf& p = (pf && pf->n_tiles > 0) ? *pf : none;
+    const int n_wgrad = wgrad8_blocks(a);
+    const int n_pad = (n_wgrad + 7) / 8 * 8, n_riders = p.n_tiles > 0 ? ((p.n_tiles + 7) / 8 + 3) / 4 * 8 : 0;
+    MAMDR_LAUNCH(k_wgrad8, dim3(n_riders ? n_pad + n_riders : n_wgrad), dim3(512), lds, s, WGRAD_EARLY_ARGS(a), a, p, n_wgrad, n_pad);
+    return true;
+}
 void launch_wgrad(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
     if (pf && pf->n_tiles > 0) {        // (the riders of the next step's gather in THIS launch: default since round 5)
         const int n_wgrad = wgrad_blocks(a);
@@ -1681,6 +1824,13 @@ __global__ __launch_bounds__(256) void k_wgrad_pf(WGRAD_EARLY_PARAMS, const Wgra
     const int bid = (int)blockIdx.x;
     if (bid < n_wgrad) wgrad_body(g, bid, red);
     else if (bid >= n_pad) gather_prefetch_body(pf, bid - n_pad);
+}
+__global__ __launch_bounds__(512) void k_wgrad8(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds8[];
+    WGRAD_EARLY_APPLY(g, g0);
+    const int bid = (int)blockIdx.x;
+    if (bid < n_wgrad) wgrad8_body(g, bid, lds8);
+    else if (bid >= n_pad && threadIdx.x < 256) gather_prefetch_body(pf, bid - n_pad);
 }
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_update_pf(UPDATE_EARLY_PARAMS, const UpdateArgs u0, const GatherPf pf, const int n_update,
