@@ -516,7 +516,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            parallel.barrier()          # (ranks of a process group, or the lanes of this process)
         torch.cuda.synchronize()
 
     for _ in range(warmup):
@@ -539,8 +539,8 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     if world > 1:
         t = torch.tensor([dt, float(local_steps), float(local_passes), host_s], dtype=torch.float64, device=eng.device)
         tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        parallel.all_reduce(tmax, "max")
+        parallel.all_reduce(t)
         dt = float(tmax[0])
         assert int(round(float(t[1]))) == global_steps, (float(t[1]), global_steps)
         local_passes = int(round(float(t[2])))
@@ -750,6 +750,23 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     return rec
 
 
+def run_lanes(wl_name, steps, warmup, lanes):
+    """the same epochs by `lanes` LANES of this process (mamdr_amd/parallel.LaneGroup): the sharded epoch of SURVEY 8e -- per-epoch
+    LPT of the DR query domains and DN passes, one sum of the DN displacements -- with the ranks as host threads, one engine
+    and one HIP stream each, on ONE GPU.  Same timed region as the ranks' (barrier + device synchronise on both sides,
+    max over lanes).  NOT the reference's single sequential chain (its Adam slots and shuffle streams are per lane, its
+    DN update sums per-lane displacements): reported beside `value`, never as `value`."""
+    from mamdr_amd import parallel
+    recs = parallel.LaneGroup(lanes).run(lambda lane: run_workload(wl_name, steps, warmup, lane, lanes, False, 0.0))
+    r = recs[0]
+    out = {k: r[k] for k in ("value", "unit", "ms_per_step", "us_per_domain_step", "workload", "domain_steps_per_epoch",
+                             "partition_speedup_bound", "host_ms_per_epoch", "dn_mode") if k in r}
+    out.update({"lanes": lanes, "semantics": "the %d-rank sharded epoch (SURVEY 8e) on one GPU: lanes = host threads, one engine + "
+                                             "one HIP stream each; not the single chain `value` times" % lanes,
+                "us_per_domain_step": r["ms_per_step"] * 1e3 / r["domain_steps_per_epoch"]})
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- launcher
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a rendezvous: start N ranks through torch.distributed.run as a CHILD
@@ -784,6 +801,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-targets", action="store_true", help="skip the Taobao-30 record and the Amazon-6-sized gather")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="single GPU: also time the same epochs sharded over this many lanes of one process (0 = skip)")
     ap.add_argument("--no-preflight", action="store_true",
                     help="several ranks: skip the first-contact check of the communicator (all-reduce, send / recv ring, broadcast)")
     args = ap.parse_args()
@@ -796,6 +815,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.lanes > 1:
+        # every lane's stream on a hardware queue of its own (the runtime's default of 4 is shared with torch's other
+        # streams): 4 lanes 67 K instead of 46 K domain-steps/s, the single chain unchanged (profiles/r05_lanes_bench.txt).
+        # Read by the HIP runtime when it initialises, i.e. at the first device call below.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
     if world > 1:
@@ -848,6 +872,9 @@ def main():
             targets[wname] = {k: rec[k] for k in TARGET_KEYS if k in rec}
     if not args.no_targets and rank == 0 and world == 1 and not args.no_profile:
         gather = gather_hbm_record(torch.device("cuda", torch.cuda.current_device()))
+    lanes_rec = None
+    if world == 1 and args.lanes > 1:
+        lanes_rec = run_lanes(args.workload, args.steps, args.warmup, args.lanes)
     if rank == 0:
         r = main_rec
         result = {
@@ -869,6 +896,9 @@ def main():
             "cpu_baseline": r["cpu_baseline"], "host_ms_per_epoch": r["host_ms_per_epoch"],
             "host_prep_ms_per_epoch": r["host_prep_ms_per_epoch"], "targets": targets,
         }
+        if lanes_rec is not None:
+            lanes_rec["over_single_chain"] = lanes_rec["value"] / r["value"]
+            result["lanes"] = lanes_rec
         if world > 1:
             result["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0
             result["backend"] = backend

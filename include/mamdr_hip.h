@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 16
+#define MAMDR_ABI_VERSION 17
 
 enum {
     MAMDR_OK = 0,
@@ -320,6 +320,14 @@ int64_t mamdr_pregather_launches(const mamdr_ctx* ctx);
  *      MAMDR_KERNEL_WGRAD times it), the domain table's step applied by the next tower, k_dm_finish once per call
  *      (MAMDR_KERNEL_UPDATE times it) */
 int mamdr_step_path(const mamdr_ctx* ctx, int32_t batch);
+/* rows per tower workgroup from the next call on: 0 = the library's choice (4-row tiles while the grid fits the CUs in one
+ * round: ONE chain of steps then has every CU busy), 4 or 16 forced.  16 is the choice of a context that SHARES the
+ * device with other contexts on other streams (the lanes of mamdr_amd/parallel.py: 64 workgroups per 1,024-row step
+ * leave the other CUs to the other lanes' launches; 4 lanes: 72 K instead of 59 K domain-steps/s,
+ * profiles/r05_lanes_probe.txt).  Same arithmetic per element either way; the two tiles add the split-K partials of a
+ * layer in different orders (rounding-level differences, each inside the parity bars).  No reference counterpart.
+ * (ABI 17; the environment's MAMDR_TOWER_TILE sets the initial value.) */
+int mamdr_set_tower_tile(mamdr_ctx* ctx, int32_t rows);
 /* training steps taken so far (any optimiser): the position of the counter-based dropout stream, which the mask of
  * step s is keyed on (dropout_seed, s).  A caller that replays the run elsewhere continues the stream from here. */
 int64_t mamdr_dropout_steps(const mamdr_ctx* ctx);

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAMDR_LIB_PATH") or os.path.join(HERE, "libmamdr_hip.so")      # (MAMDR_LIB_PATH: A/B of diagnostic builds, tools/build_variant.sh)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN, TOWER_NFM = 0, 1, 2, 3, 4, 5
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -109,6 +109,7 @@ SIGNATURES = {
     "mamdr_shuffle_perms": (C.c_int, [_I32, _VP, _I64, _VP, _VP]),
     "mamdr_step_path": (C.c_int, [_VP, _I32]),
     "mamdr_dropout_steps": (_I64, [_VP]),
+    "mamdr_set_tower_tile": (C.c_int, [_VP, _I32]),
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
     "mamdr_profile_reset": (C.c_int, [_VP]),
     "mamdr_profile_read": (C.c_int, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64)]),

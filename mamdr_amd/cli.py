@@ -91,16 +91,42 @@ def init_distributed():
     return dist.get_rank(), dist.get_world_size()
 
 
+def n_lanes(config):
+    """train.lanes (not a key of the reference's configs; MAMDR_LANES overrides; default 1 = the reference's one
+    sequential chain): the sharded epoch of SURVEY 8e run by that many LANES of this process on one GPU
+    (parallel.LaneGroup) -- a lane run is the run of as many ranks, with the lanes' kernels overlapping on the device."""
+    import os
+    return max(1, int(os.environ.get("MAMDR_LANES") or config["train"].get("lanes", 1) or 1))
+
+
 def main(config, engine_factory=None, on_model=None):
     """run.py:71-89.  on_model(model) (optional) sees the built, wrapped model before training starts (tests attach
     their recorders there)."""
     from .utils import MultiDomainDataset
     rank, world = init_distributed()
     name = config["model"]["name"]
-    if world > 1 and not ("meta" in name and ("mamdr" in name or "domain_negotiation" in name or "reptile" in name)):
-        raise NotImplementedError("multi-process runs shard the MAMDR (DN + DR), Domain Negotiation and Reptile "
+    lanes = n_lanes(config)
+    if (world > 1 or lanes > 1) and not ("meta" in name and ("mamdr" in name or "domain_negotiation" in name or "reptile" in name)):
+        raise NotImplementedError("multi-process / multi-lane runs shard the MAMDR (DN + DR), Domain Negotiation and Reptile "
                                   "wrappers only; got '%s'" % name)
     dataset = MultiDomainDataset(config["dataset"])
+    if lanes > 1:
+        if world > 1:
+            raise NotImplementedError("train.lanes = %d under %d processes: lanes stand in for ranks inside ONE process" % (lanes, world))
+        from . import parallel
+        import os
+        import torch
+        if not torch.cuda.is_initialized():
+            # every lane's stream on a hardware queue of its own (the HIP runtime reads this when it initialises; its
+            # default of 4 queues is shared with torch's other streams: profiles/r05_lanes_bench.txt)
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * lanes)))
+        # (the dataset is read-only: one copy for all lanes; every lane builds its own model = its own engine and stream)
+        return parallel.LaneGroup(lanes).run(lambda lane: _run(config, dataset, engine_factory, on_model, lane))[0]
+    return _run(config, dataset, engine_factory, on_model, rank)
+
+
+def _run(config, dataset, engine_factory, on_model, rank):
+    name = config["model"]["name"]
     model = build_model(config, dataset, engine_factory)
     if on_model is not None:
         on_model(model)

@@ -2004,6 +2004,15 @@ int mamdr_step_path(const mamdr_ctx* c, int32_t batch) {
     return (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch ? 1 : 0;
 }
 
+int mamdr_set_tower_tile(mamdr_ctx* c, int32_t rows) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (rows != 0 && rows != 4 && rows != 16) return fail(MAMDR_EINVAL, "tower tile of %d rows (0 = automatic, 4, 16)", rows);
+    if (rows != c->tower_tile) {
+        c->tower_tile = rows;
+        c->pg.clear();          // (passes gathered ahead were laid out for the step path of the old choice)
+    }
+    return MAMDR_OK;
+}
 int mamdr_profile_enable(mamdr_ctx* c, int32_t enable) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     c->profile = enable != 0;

@@ -177,7 +177,10 @@ class FlatVectorOps(object):
 class TowerEngine(FlatVectorOps):
     def __init__(self, n_user, n_item, n_domain, batch_size, dropout=0.5, emb_trainable=False,
                  tower="mlp", emb_dim=128, hidden=(256, 128, 64), l2_emb=1e-5, device=None,
-                 dropout_seed=1024, l2_linear=1e-5, uncertainty_weight=False):
+                 dropout_seed=1024, l2_linear=1e-5, uncertainty_weight=False, tower_tile=None):
+        """tower_tile: rows per tower workgroup (mamdr_set_tower_tile: 0 automatic, 4, 16); None = automatic, except for an
+        engine built on a lane of a parallel.LaneGroup of four or more lanes, which takes 16 (it shares the CUs with the
+        other lanes' launches)."""
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("TowerEngine needs a HIP device (no CPU fallback for the MAMDR hot path)")
@@ -199,6 +202,12 @@ class TowerEngine(FlatVectorOps):
         handle = C.c_void_p()
         L.check(self.lib.mamdr_create(C.byref(cfg), C.c_void_p(self.stream.cuda_stream), C.byref(handle)))
         self.ctx = handle
+        if tower_tile is None:
+            from . import parallel
+            group = parallel.lanes()
+            tower_tile = 16 if (group is not None and group.n >= 4) else 0
+        if tower_tile:
+            self.set_tower_tile(tower_tile)
         self.emb_trainable = bool(emb_trainable)
         self.tower = tower
         self.n_params = int(self.lib.mamdr_param_count(self.ctx))
@@ -355,6 +364,9 @@ class TowerEngine(FlatVectorOps):
             else:                                  # 1-d biases and PartitionedNorm shared vectors
                 out[name] = (1, cnt)
         return out
+
+    def set_tower_tile(self, rows):
+        L.check(self.lib.mamdr_set_tower_tile(self.ctx, int(rows)))
 
     # ------------------------------------------------------------ binding
     def bind_table(self, name, rows):

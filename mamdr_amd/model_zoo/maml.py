@@ -97,8 +97,7 @@ class MAML(object):
             # several processes: every rank starts from the SAME weights -- the ones the single-process loop would hold
             # here: theta for the wrappers that leave theta in the model, the model of the rank that ran the plan's last
             # pass otherwise (`live_src`, set by the sharded MAMDR loop) -- and the domains are dealt round-robin
-            import torch.distributed as dist
-            dist.broadcast(weights, src=int(getattr(self, "live_src", 0)))
+            parallel.broadcast(weights, int(getattr(self, "live_src", 0)))
         aux = getattr(self.model, "aux", None)      # Star: PartitionedNorm moving statistics move while training
         aux = aux.clone() if aux is not None else None
         domain_loss, domain_auc = {}, {}

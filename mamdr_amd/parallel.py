@@ -15,9 +15,193 @@ scheme (slides p.22) sums per-worker displacements.  Here
 * eval is per domain: owners evaluate, scalars are all-gathered.
 
 torch.distributed (backend nccl = RCCL on ROCm, gloo in CPU tests) is plumbing.
+
+LANES (round 5): the same sharding inside ONE process.  One dependent chain of 1,024-row steps cannot fill 256 CUs
+(each step is two launches whose workgroups wait for each other's results), but the units that shard
+over ranks are just as independent on one GPU: `LaneGroup(L).run(fn)` runs `fn(lane)` on L host threads, each lane with
+its own engine on its own HIP stream, and inside those threads `world()` answers (lane, L) and the collectives of this
+module (`all_reduce`, `broadcast`, the phi hand-over) become stream-ordered copies / sums between the lanes' buffers --
+every function below runs unchanged, and a lane run IS the L-rank run (same assignment, same arithmetic, same sums in
+rank order), with the kernels of different lanes overlapping on the device.
 """
+import threading
+
 import torch
 import torch.distributed as dist
+
+_lane = threading.local()
+
+
+class LaneGroup(object):
+    """L lanes = L host threads of one process standing in for L ranks (module docstring).  Collectives between lanes:
+    every lane publishes its tensor and an event recorded on ITS stream, a host barrier, every lane makes its stream wait
+    for the publishers' events and reads; a second round of events keeps a publisher from overwriting what a reader has
+    not read yet.  No host synchronisation with the device anywhere: the lanes' streams stay asynchronous."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self.barrier = threading.Barrier(self.n)
+        self.slots = [None] * self.n
+        self.ev = [None] * self.n
+        self.ev2 = [None] * self.n
+        self.adders = [None] * self.n
+
+    def run(self, fn):
+        """fn(lane) on every lane (lane 0 on the calling thread's device); returns the list of results.  The first
+        exception of any lane is re-raised after every lane has ended (a failing lane breaks the barrier: no lane waits
+        for it for ever)."""
+        results, errors = [None] * self.n, [None] * self.n
+        device = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def body(lane):
+            _lane.group, _lane.rank = self, lane
+            try:
+                if device is not None:
+                    torch.cuda.set_device(device)
+                    with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                        results[lane] = fn(lane)
+                        torch.cuda.current_stream().synchronize()
+                else:
+                    results[lane] = fn(lane)
+            except BaseException as e:      # noqa: B902 -- reported below, on the caller's thread
+                errors[lane] = e
+                self.barrier.abort()
+            finally:
+                _lane.group, _lane.rank = None, 0
+        threads = [threading.Thread(target=body, args=(l,), name="mamdr-lane-%d" % l) for l in range(self.n)]
+        import sys
+        out = sys.stdout
+        sys.stdout = _Lane0Stdout(out)      # every lane prints the same progress lines: lane 0's are the run's
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.stdout = out
+        first = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)] or \
+                [e for e in errors if e is not None]
+        if first:
+            raise first[0]
+        return results
+
+    # -- the collectives (called through the module functions below, from lane threads only)
+    def wait(self):
+        self.barrier.wait()
+
+    def _publish(self, rank, obj, cuda):
+        self.slots[rank] = obj
+        if cuda:
+            e = torch.cuda.Event()
+            e.record()
+            self.ev[rank] = e
+        self.wait()
+
+    def _read_done(self, rank, cuda, publishers):
+        """readers have ENQUEUED their reads: publishers make their streams wait for them before going on."""
+        if cuda:
+            e = torch.cuda.Event()
+            e.record()
+            self.ev2[rank] = e
+        self.wait()
+        if cuda and rank in publishers:
+            s = torch.cuda.current_stream()
+            for k in range(self.n):
+                if k != rank:
+                    s.wait_event(self.ev2[k])
+        self.wait()             # (the slots and events may be reused from here on)
+
+    def all_reduce(self, rank, t, op):
+        cuda = t.is_cuda
+        self._publish(rank, t, cuda)
+        if cuda:
+            s = torch.cuda.current_stream()
+            for k in range(self.n):
+                if k != rank:
+                    s.wait_event(self.ev[k])
+        acc = self.slots[0].clone()
+        add = self.adders[rank] if (op == "sum" and t.dtype == torch.float32 and t.dim() == 1) else None
+        for k in range(1, self.n):          # rank order on every lane: the same bits everywhere
+            if add is not None:
+                add(acc, self.slots[k])
+            elif op == "sum":
+                torch.add(acc, self.slots[k], out=acc)
+            elif op == "max":
+                torch.maximum(acc, self.slots[k], out=acc)
+            else:
+                torch.minimum(acc, self.slots[k], out=acc)
+        self._read_done(rank, cuda, range(self.n))
+        t.copy_(acc)
+
+    def broadcast(self, rank, t, src):
+        cuda = t.is_cuda
+        self._publish(rank, t, cuda)
+        if rank != src:
+            if cuda:
+                torch.cuda.current_stream().wait_event(self.ev[src])
+            t.copy_(self.slots[src])
+        self._read_done(rank, cuda, (src,))
+
+    def transfer(self, rank, vectors, moves):
+        """moves [(key, src lane, dst lane)]: vectors[key] of lane src -> vectors[key] of lane dst."""
+        cuda = any(v.is_cuda for v in vectors.values())
+        self._publish(rank, vectors, cuda)
+        for key, src, dst in moves:
+            if rank == dst and src != dst:
+                if cuda:
+                    torch.cuda.current_stream().wait_event(self.ev[src])
+                vectors[key].copy_(self.slots[src][key])
+        self._read_done(rank, cuda, set(src for _, src, _ in moves))
+
+
+class _Lane0Stdout(object):
+    def __init__(self, out):
+        self._out = out
+
+    def write(self, text):
+        if getattr(_lane, "rank", 0) == 0:
+            return self._out.write(text)
+        return len(text)
+
+    def __getattr__(self, name):
+        return getattr(self._out, name)
+
+
+def lanes():
+    """the LaneGroup this thread is a lane of, or None."""
+    return getattr(_lane, "group", None)
+
+
+def lane_adder(eng):
+    """the lanes' all-reduce of fp32 vectors sums with this engine's elementwise kernel (mamdr_merge, mode plus) on the
+    lane's stream instead of a torch op.  No-op outside a lane."""
+    g = lanes()
+    if g is not None and hasattr(eng, "merge"):
+        g.adders[_lane.rank] = lambda dst, src: eng.merge(dst, dst, src, "plus")
+
+
+def all_reduce(t, op="sum"):
+    g = lanes()
+    if g is not None:
+        g.all_reduce(_lane.rank, t, op)
+    else:
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+
+
+def broadcast(t, src):
+    g = lanes()
+    if g is not None:
+        g.broadcast(_lane.rank, t, src)
+    else:
+        dist.broadcast(t, src=src)
+
+
+def barrier():
+    g = lanes()
+    if g is not None:
+        g.wait()
+    elif dist.is_available() and dist.is_initialized():
+        dist.barrier()
 
 
 def lpt_partition(costs, n_parts):
@@ -33,6 +217,9 @@ def lpt_partition(costs, n_parts):
 
 
 def world():
+    g = lanes()
+    if g is not None:
+        return _lane.rank, g.n
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
@@ -61,8 +248,8 @@ def preflight(device, payload=4096):
     import warnings
     global P2P_ENABLED
     rank, ws = world()
-    rec = {"ranks": ws, "backend": dist.get_backend() if ws > 1 else None, "all_reduce": None, "p2p": None, "broadcast": None}
-    if ws == 1:
+    rec = {"ranks": ws, "backend": ("lanes" if lanes() is not None else dist.get_backend()) if ws > 1 else None, "all_reduce": None, "p2p": None, "broadcast": None}
+    if ws == 1 or lanes() is not None:
         return rec
     t0 = time.perf_counter()
     dev = torch.device(device)
@@ -113,7 +300,7 @@ def allreduce_delta(eng, theta, delta_buf):
     eng.sub(delta_buf, eng.meta_weights, theta)
     rank, ws = world()
     if ws > 1:
-        dist.all_reduce(delta_buf, op=dist.ReduceOp.SUM)
+        all_reduce(delta_buf)
     return delta_buf
 
 
@@ -124,6 +311,7 @@ def dn_phase_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, meta_
     meta_train_step caps every pass (domain_negotiation.py:67); a target domain (:44-45,89-93) closes EVERY rank's
     sub-sequence with an uncapped pass -- each displacement then ends adapted to the target, as the single
     sequence's does -- and the caller runs the closing target pass on the updated model (identical on every rank)."""
+    lane_adder(eng)
     eng.assign_meta(theta)
     for d in seq_local:
         meta.run_pass(eng, d, perm_fn, batch_size, lr, trace, "dn", meta_train_step)
@@ -146,6 +334,7 @@ def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, 
     target >= 0 (reptile.py:47-48,82-85,98-102): the target domain is no task; every domain's pass is followed by ONE
     step on the target domain before its interpolation (on whichever rank runs that domain), and the caller closes the
     epoch with a full pass of the updated model over the target domain (on every rank: the model is the same)."""
+    lane_adder(eng)
     trace = []
     local = theta.clone()
     for d in seq_local:
@@ -161,7 +350,7 @@ def reptile_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size, lr, 
         theta.copy_(local)
     else:
         eng.sub(delta_buf, local, theta)
-        dist.all_reduce(delta_buf, op=dist.ReduceOp.SUM)
+        all_reduce(delta_buf)
         eng.interp(theta, delta_buf, zero_buf, 1.0)
     eng.assign_meta(theta)
     return trace
@@ -173,6 +362,7 @@ def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size
     displacement theta~ - theta to `acc`; the epoch applies theta += beta * sum.  The sum over domains is a sum
     over ranks of per-rank sums: ONE all-reduce of `acc` per epoch, no other change to the algorithm.
     Only the optimiser slots differ from the single-process run: each rank's Adam moments see its own domains."""
+    lane_adder(eng)
     trace = []
     acc.zero_()
     for d in seq_local:
@@ -185,7 +375,7 @@ def reptile_batch_epoch_sharded(eng, meta, theta, seq_local, perm_fn, batch_size
         eng.accumulate(acc, eng.meta_weights, theta)
     rank, ws = world()
     if ws > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        all_reduce(acc)
     eng.apply_accumulated(theta, acc, 0.0, meta_lr)
     eng.assign_meta(theta)
     return trace
@@ -354,7 +544,7 @@ class TailSync(object):
             return
         buf = torch.empty(self.floats(), dtype=torch.float32, device=self.common.device)
         self.fill(buf)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        all_reduce(buf)
         self.apply(buf)
 
 
@@ -380,6 +570,7 @@ class BalancedMAMDR(object):
         if dn_mode not in ("sharded", "replicated"):
             raise ValueError("dn_mode must be 'sharded' or 'replicated', not: {}".format(dn_mode))
         self.eng, self.meta, self.theta = eng, meta, theta
+        lane_adder(eng)
         self.dn_mode = dn_mode
         self.steps = list(steps_per_domain)
         self.domains = sorted(phis)
@@ -416,6 +607,9 @@ class BalancedMAMDR(object):
         sent = 0
         if not moves:
             return sent
+        if lanes() is not None:     # lane to lane inside the process: a stream-ordered device copy
+            lanes().transfer(rank, self.phis, moves)
+            return sum(self.P * 4 for _, src, _ in moves if src == rank)
         p2p = P2P_ENABLED and p2p_possible(self.pack.device)
         if p2p:
             ops = []
@@ -430,7 +624,7 @@ class BalancedMAMDR(object):
                     req.wait()
         else:                       # gloo with device tensors (ranks sharing one GPU in tests): no send / recv there
             for d, src, dst in moves:
-                dist.broadcast(self.phis[d], src=src)
+                broadcast(self.phis[d], src)
                 sent += self.P * 4 if rank == src else 0
         return sent
 
@@ -439,7 +633,7 @@ class BalancedMAMDR(object):
         if ws > 1:
             for d in self.domains:
                 if self.where[d] is not None:
-                    dist.broadcast(self.phis[d], src=self.where[d])
+                    broadcast(self.phis[d], self.where[d])
         self.where = {d: None for d in self.domains}
 
     def sync_tail(self):
@@ -509,26 +703,26 @@ class BalancedMAMDR(object):
             # one chain; rank 0's result is everybody's (bit-identical continuation on every rank)
             live = eng.weights
             if self.tail.active:
-                dist.broadcast(live, src=0)
+                broadcast(live, 0)
                 if self.tail.aux is not None:
-                    dist.broadcast(self.tail.aux, src=0)
+                    broadcast(self.tail.aux, 0)
                 self.tail.rebase()
                 wire += live.numel() * 4 if rank == 0 else 0
                 eng.sub(self.delta, live[:self.P], theta)
             else:
                 eng.sub(self.delta, live, theta)
-                dist.broadcast(self.delta, src=0)
+                broadcast(self.delta, 0)
                 wire += self.P * 4 if rank == 0 else 0
         else:
             eng.sub(self.delta, eng.meta_weights, theta)
             if self.tail.active:
                 # [delta | tail displacement | statistics] in ONE collective
                 self.tail.fill(self.tail_buf)
-                dist.all_reduce(self.pack[:self.P + self.tail_buf.numel()], op=dist.ReduceOp.SUM)
+                all_reduce(self.pack[:self.P + self.tail_buf.numel()])
                 self.tail.apply(self.tail_buf)
                 wire += (self.P + self.tail_buf.numel()) * 4
             else:
-                dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+                all_reduce(self.delta)
                 wire += self.P * 4
         eng.interp(theta, self.delta, self.zero, meta_lr)
         for query, support in local["dr"]:
@@ -556,12 +750,12 @@ def broadcast_live(eng, src=0):
     if ws <= 1:
         return
     w = eng.weights
-    dist.broadcast(w, src=src)
+    broadcast(w, src)
     if w.data_ptr() != eng.weights.data_ptr():      # (an engine that hands out copies of its weights: the tests' CPU stand-in)
         eng.set_weights(w)
     aux = getattr(eng, "aux", None)
     if aux is not None:
-        dist.broadcast(aux, src=src)
+        broadcast(aux, src)
 
 
 def gather_domain_scalars(local, n_domain, device):
@@ -571,7 +765,7 @@ def gather_domain_scalars(local, n_domain, device):
     for d, (loss, auc) in local.items():
         t[d, 0], t[d, 1], t[d, 2] = loss, auc, 1.0
     if ws > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        all_reduce(t)
     t = t.cpu()
     return ({d: float(t[d, 0]) for d in range(n_domain) if t[d, 2] > 0},
             {d: float(t[d, 1]) for d in range(n_domain) if t[d, 2] > 0})

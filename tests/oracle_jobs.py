@@ -285,10 +285,14 @@ def run_pipeline(cfg, engine_factory=None, perturb=0.0):
     training starts -- the second run of the self-divergence instrument."""
     import json
     from mamdr_amd import cli
-    rec = Recorder()
+    from mamdr_amd import parallel
+    recs = {}
 
     def on_model(model):
-        rec.attach(model)
+        # (train.lanes > 1: called once per lane, on the lane's thread; every lane sees the same gathered results and
+        # takes the same decisions -- lane 0's record is the run's, the lanes' traces are kept beside it)
+        recs[parallel.world()[0]] = r = Recorder()
+        r.attach(model)
         if perturb > 0:
             import torch
             eng = model.model
@@ -296,7 +300,9 @@ def run_pipeline(cfg, engine_factory=None, perturb=0.0):
             noise = np.random.RandomState(99).standard_normal(w.numel()).astype(F32)
             eng.set_weights(w * (1 + perturb * torch.from_numpy(noise).to(w.device)))
     out = cli.main(cfg, engine_factory, on_model=on_model)
-    s = rec.summary(out)
+    s = recs[0].summary(out)
+    s["lane_traces"] = {r: [tuple(t) for t in getattr(rec.model, "trace", [])] for r, rec in sorted(recs.items())}
+    s["lane_events"] = {r: rec.events for r, rec in sorted(recs.items())}
     rdir = cfg["train"]["result_save_path"]
     found = [os.path.join(r, "result.json") for r, _, fs in os.walk(rdir) if "result.json" in fs]
     with open(found[0]) as f:

@@ -410,6 +410,28 @@ def _run_entry_worlds(tmp_path, name, extra=None):
         assert sha[0] == sha[1], sha
     assert a == b and sorted(a["domain_auc"]) == ["0", "1", "2"]          # every rank holds every domain's result
     assert np.isfinite(a["avg_loss"]) and abs(a["avg_auc"] - results[1][0]["avg_auc"]) < 0.1
+    # the same two ranks as LANES of this process (train.lanes = 2, parallel.LaneGroup): the 2-process run bit for bit --
+    # the returned results and the live model every lane ends with
+    import hashlib
+    import shutil
+    from fake_engine import FakeEngine
+    from mamdr_amd import cli, synthetic
+    for d in ("result", "checkpoint"):
+        shutil.rmtree(str(tmp_path / d), ignore_errors=True)
+    real = synthetic.generate
+    synthetic.generate = lambda *a_, **k: real(*a_, **dict(k, emb_dim=8))
+    try:
+        built = []
+        lane_cfg = json.loads(json.dumps(cfg))
+        lane_cfg["train"]["lanes"] = 2
+        res = cli.main(lane_cfg, FakeEngine, on_model=built.append)
+    finally:
+        synthetic.generate = real
+    assert len(built) == 2
+    got = {"avg_loss": res[0], "avg_auc": res[1], "domain_auc": {str(k): v for k, v in res[3].items()}}
+    assert got == a, (got, a)
+    lane_sha = sorted(hashlib.sha1(m.model.weights.numpy().tobytes()).hexdigest() for m in built)
+    assert lane_sha == sorted(sha), (lane_sha, sha)
 
 
 TAIL_WORKER = r"""
