@@ -328,6 +328,8 @@ int mamdr_step_path(const mamdr_ctx* ctx, int32_t batch);
  * layer in different orders (rounding-level differences, each inside the parity bars).  No reference counterpart.
  * (ABI 17; the environment's MAMDR_TOWER_TILE sets the initial value.) */
 int mamdr_set_tower_tile(mamdr_ctx* ctx, int32_t rows);
+/* rows per tower workgroup of a training step of `batch` rows under the present choice: 4 or 16 (for reports and tests) */
+int mamdr_tower_tile(const mamdr_ctx* ctx, int32_t batch);
 /* training steps taken so far (any optimiser): the position of the counter-based dropout stream, which the mask of
  * step s is keyed on (dropout_seed, s).  A caller that replays the run elsewhere continues the stream from here. */
 int64_t mamdr_dropout_steps(const mamdr_ctx* ctx);

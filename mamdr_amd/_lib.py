@@ -110,6 +110,7 @@ SIGNATURES = {
     "mamdr_step_path": (C.c_int, [_VP, _I32]),
     "mamdr_dropout_steps": (_I64, [_VP]),
     "mamdr_set_tower_tile": (C.c_int, [_VP, _I32]),
+    "mamdr_tower_tile": (C.c_int, [_VP, _I32]),
     "mamdr_profile_enable": (C.c_int, [_VP, _I32]),
     "mamdr_profile_reset": (C.c_int, [_VP]),
     "mamdr_profile_read": (C.c_int, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64)]),

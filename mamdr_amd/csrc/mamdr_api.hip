@@ -2013,6 +2013,12 @@ int mamdr_set_tower_tile(mamdr_ctx* c, int32_t rows) {
     }
     return MAMDR_OK;
 }
+int mamdr_tower_tile(const mamdr_ctx* c, int32_t batch) {
+    if (!c || batch <= 0) return MAMDR_EINVAL;
+    const int64_t pad = ((int64_t)batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    const bool may_use4 = !c->star && c->tower_tile != 16;
+    return may_use4 && (c->tower_tile == 4 || pad <= c->tower4_max_rows) ? 4 : 16;
+}
 int mamdr_profile_enable(mamdr_ctx* c, int32_t enable) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     c->profile = enable != 0;

@@ -368,6 +368,10 @@ class TowerEngine(FlatVectorOps):
     def set_tower_tile(self, rows):
         L.check(self.lib.mamdr_set_tower_tile(self.ctx, int(rows)))
 
+    def tower_tile(self, batch=None):
+        """rows per tower workgroup of a training step of `batch` rows (4: k_tower4, 16: k_tower)."""
+        return int(self.lib.mamdr_tower_tile(self.ctx, int(batch or self.batch_size)))
+
     # ------------------------------------------------------------ binding
     def bind_table(self, name, rows):
         """frozen pretrained table (deepctr.py:104-116), numpy [n, 128] fp32."""

@@ -647,3 +647,78 @@ def test_taobao30_partition_bound_at_8_ranks():
         dr_owner, dn_owner, load = parallel.epoch_assignment(plan, spd, 8)
         assert sum(load) == mplan.plan_steps(plan, spd) and min(load) > 0
         assert sum(load) / max(load) >= 6.5, (ep, load)
+
+
+# ------------------------------------------------------------------ lanes (parallel.LaneGroup): ranks as threads of one process
+def test_lane_group_collectives_cpu():
+    """world() / all_reduce / broadcast / barrier / the phi hand-over inside a LaneGroup: the values every rank of a process
+    group would see, sums taken in rank order on every lane (bit-identical everywhere)."""
+    import torch
+    from mamdr_amd import parallel
+    L = 3
+    rs = np.random.RandomState(3)
+    base = [torch.from_numpy(rs.standard_normal(1000).astype(np.float32)) for _ in range(L)]
+
+    def fn(lane):
+        assert parallel.world() == (lane, L) and parallel.lanes().n == L
+        out = {}
+        t = base[lane].clone()
+        parallel.all_reduce(t)
+        out["sum"] = t
+        m = base[lane].clone()
+        parallel.all_reduce(m, "max")
+        out["max"] = m
+        b = base[lane].clone()
+        parallel.broadcast(b, 1)
+        out["bcast"] = b
+        vecs = {d: torch.full((4,), float(10 * lane + d)) for d in range(3)}
+        parallel.lanes().transfer(lane, vecs, [(0, 0, 2), (1, 2, 1), (2, 1, 1)])
+        out["vecs"] = vecs
+        parallel.barrier()
+        s = torch.tensor([float(lane)], dtype=torch.float64)
+        parallel.all_reduce(s)
+        out["scalar"] = float(s[0])
+        return out
+    outs = parallel.LaneGroup(L).run(fn)
+    want = (base[0] + base[1]) + base[2]
+    for lane, o in enumerate(outs):
+        assert torch.equal(o["sum"], want) and torch.equal(o["bcast"], base[1])
+        assert torch.equal(o["max"], torch.maximum(torch.maximum(base[0], base[1]), base[2]))
+        assert o["scalar"] == 3.0
+    assert float(outs[2]["vecs"][0][0]) == 0.0 and float(outs[1]["vecs"][1][0]) == 21.0 and float(outs[1]["vecs"][2][0]) == 12.0
+    assert float(outs[0]["vecs"][0][0]) == 0.0 and float(outs[0]["vecs"][1][0]) == 1.0       # the senders keep theirs
+    assert parallel.world() == (0, 1) and parallel.lanes() is None                        # nothing leaks to the caller's thread
+
+
+def test_lane_group_error_ends_every_lane():
+    """a lane that raises breaks the barrier: the others do not wait for it for ever, and the caller sees ITS exception."""
+    import torch
+    from mamdr_amd import parallel
+
+    def fn(lane):
+        if lane == 1:
+            raise KeyError("lane 1 failed")
+        t = torch.zeros(4)
+        for _ in range(3):
+            parallel.all_reduce(t)
+        return lane
+    with pytest.raises(KeyError, match="lane 1 failed"):
+        parallel.LaneGroup(3).run(fn)
+
+
+def test_run_entry_lanes_need_a_sharded_wrapper_and_one_process(tmp_path, monkeypatch):
+    sys.path.insert(0, HERE)
+    from fake_engine import FakeEngine
+    from test_host_logic import patch_emb_dim, tiny_config
+    from mamdr_amd import cli
+    patch_emb_dim(monkeypatch)
+    cfg = tiny_config(tmp_path, "mlp", epochs=1)
+    cfg["train"]["lanes"] = 2
+    with pytest.raises(NotImplementedError, match="multi-lane"):
+        cli.main(cfg, FakeEngine)
+    # MAMDR_LANES overrides the config's key; three lanes over three domains
+    cfg = tiny_config(tmp_path, "mlp_meta_mamdr", epochs=1)
+    monkeypatch.setenv("MAMDR_LANES", "3")
+    built = []
+    res = cli.main(cfg, FakeEngine, on_model=built.append)
+    assert len(built) == 3 and sorted(res[3]) == [0, 1, 2] and np.isfinite(res[0])
