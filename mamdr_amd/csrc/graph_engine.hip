@@ -38,6 +38,7 @@
 //            over 3 B token rows, the 3 x 3 attention core in k_graph_att_fwd/bwd), beside the DNN; head over [96 | DNN]
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +50,7 @@
 #include "mamdr_kernels.h"
 
 // every kernel launch of this engine goes through here: the count is what tools/graph_bench.py reports as launches per step
-static long long g_graph_launches = 0;
+static std::atomic<long long> g_graph_launches{0};      // (contexts may be driven from several host threads: lanes)
 #define GLAUNCH(...)                      \
     do {                                  \
         ++g_graph_launches;               \
@@ -2485,7 +2486,7 @@ int mamdr_graph_set_adam_eps(mamdr_graph* g, float eps) {
     g->cfg.adam_eps = eps;
     return MAMDR_OK;
 }
-int64_t mamdr_graph_launch_count(void) { return (int64_t)g_graph_launches; }
+int64_t mamdr_graph_launch_count(void) { return (int64_t)g_graph_launches.load(); }
 int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g) { return g ? g->adam_t : 0; }
 int64_t mamdr_graph_dropout_steps(const mamdr_graph* g) { return g ? (int64_t)g->global_step : 0; }
 
