@@ -500,16 +500,20 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
                 host_prep_s[0] += time.perf_counter() - th1
             return tr, mplan.plan_steps(p, steps_per_domain)
         p = next_plan[0] if next_plan[0] is not None else planner.next_epoch()    # same seed on every rank -> same global plan
+        next_plan[0] = None
         host_prep_s[0] += time.perf_counter() - th0
-        tr = balanced.epoch(p, shuffles.prepare, shuffles, batch, TRAIN["learning_rate"], TRAIN["meta_learning_rate"],
-                            TRAIN["merged_method"])
-        # the NEXT epoch's plan is a function of the seed alone: its shuffles are drawn on a worker thread while the
-        # stream runs this epoch (plan.EpochShuffles.prefetch; the work stays inside the timed region, off the critical path)
-        if prefetch:
+
+        # the NEXT epoch's plan is a function of the seed alone: its shuffles are drawn on a worker thread while this epoch is
+        # enqueued and run (plan.EpochShuffles.lookahead: a few passes in; the work stays inside the timed region, off the
+        # critical path of the epoch boundary, whose run-ahead margin is 2 - 3 ms of queued launches)
+        def look():
             th1 = time.perf_counter()
             next_plan[0] = planner.next_epoch()
             shuffles.prefetch(balanced.local_passes(next_plan[0]))
             host_prep_s[0] += time.perf_counter() - th1
+        shuffles.lookahead = look if prefetch else None
+        tr = balanced.epoch(p, shuffles.prepare, shuffles, batch, TRAIN["learning_rate"], TRAIN["meta_learning_rate"],
+                            TRAIN["merged_method"])
         if balanced.last_load is not None:
             loads.append(balanced.last_load)
         return tr, mplan.plan_steps(p, steps_per_domain)
@@ -745,6 +749,8 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         rec["partition_speedup_bound"] = float(np.mean([sum(l) / max(l) for l in loads]))
     if cpu:
         rec["gpu_over_cpu"] = rec["value"] / cpu["value"]
+    if os.environ.get("MAMDR_BENCH_PREP_TIMING"):
+        print("prep timing (ms summed over %d epochs): %s" % (steps + warmup, {k: round(v * 1e3, 2) for k, v in shuffles.timing.items()}), file=sys.stderr)
     shuffles.cancel()           # the prefetch of an epoch that will not run
     eng.close()
     return rec

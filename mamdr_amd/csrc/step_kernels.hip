@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WGRAD_EARLY_PARAMS, const 
     if (idx < 2 * nb) emb_reduce_body(e, idx % nb, idx / nb, reinterpret_cast<uint16_t(*)[RED_CAP]>(red));
     else emb_rows_body(nr, idx - 2 * nb);
 }
+#ifdef MAMDR_WGRAD8     // (a rejected experiment, profiles/r05_ab_wgrad_pairs.txt: in diagnostic builds only, tools/build_variant.sh x -DMAMDR_WGRAD8)
 // ---- k_wgrad8 (round 5): one workgroup of EIGHT waves = one tile x TWO adjacent row groups.  Waves 0..3 run row group
 // 2 q, waves 4..7 row group 2 q + 1, each half with its own staging buffers; the two partial tiles are added through LDS
 // (group 2 q first) and ONE slab per pair is written: half the slab bytes for k_update -- which is bound by what it pulls
@@ -1372,6 +1373,7 @@ static int wgrad8_blocks(const WgradArgs& a) {
     const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
     return a.n_tiles * ((a.n_groups + 1) / 2) + 1 + W0DOM_COPY_WGS + dm_wgs;
 }
+#endif
 static int wgrad_blocks(const WgradArgs& a) {
     const int dm_wgs = a.dm_copy ? (a.dm_count / 4 + 255) / 256 : 0;
     return a.n_tiles * a.n_groups + 1 + W0DOM_COPY_WGS + dm_wgs;
@@ -1391,6 +1393,7 @@ void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRows
                        nr, n_rows, sd, n_dm);
 }
 __global__ void k_wgrad_pf(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad);
+#ifdef MAMDR_WGRAD8
 __global__ void k_wgrad8(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad);
 // pairs of row groups per workgroup: ONE slab per pair (k_update then sums (n_groups + 1) / 2 slabs)
 bool launch_wgrad_pairs(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
@@ -1408,6 +1411,9 @@ bool launch_wgrad_pairs(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
     MAMDR_LAUNCH(k_wgrad8, dim3(n_riders ? n_pad + n_riders : n_wgrad), dim3(512), lds, s, WGRAD_EARLY_ARGS(a), a, p, n_wgrad, n_pad);
     return true;
 }
+#else
+bool launch_wgrad_pairs(const WgradArgs&, hipStream_t, const GatherPf*) { return false; }
+#endif
 void launch_wgrad(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
     if (pf && pf->n_tiles > 0) {        // (the riders of the next step's gather in THIS launch: default since round 5)
         const int n_wgrad = wgrad_blocks(a);
@@ -1825,6 +1831,7 @@ __global__ __launch_bounds__(256) void k_wgrad_pf(WGRAD_EARLY_PARAMS, const Wgra
     if (bid < n_wgrad) wgrad_body(g, bid, red);
     else if (bid >= n_pad) gather_prefetch_body(pf, bid - n_pad);
 }
+#ifdef MAMDR_WGRAD8
 __global__ __launch_bounds__(512) void k_wgrad8(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad) {
     extern __shared__ __attribute__((aligned(16))) float lds8[];
     WGRAD_EARLY_APPLY(g, g0);
@@ -1832,6 +1839,7 @@ __global__ __launch_bounds__(512) void k_wgrad8(WGRAD_EARLY_PARAMS, const WgradA
     if (bid < n_wgrad) wgrad8_body(g, bid, lds8);
     else if (bid >= n_pad && threadIdx.x < 256) gather_prefetch_body(pf, bid - n_pad);
 }
+#endif
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_update_pf(UPDATE_EARLY_PARAMS, const UpdateArgs u0, const GatherPf pf, const int n_update,
                                                    const int n_pad) {

@@ -111,9 +111,13 @@ class EpochShuffles(object):
         self.k = 0
         self.queue = []
         self.pending = None         # (passes, job, thread) of a prefetch in flight
+        self.lookahead = None       # callable: invoked once per epoch, a few passes in (see __call__)
+        self.timing = {"stage": 0.0, "stage_sync": 0.0, "draw": 0.0, "join": 0.0, "upload": 0.0, "queue": 0.0}   # seconds, summed
 
     def _stage(self, passes):
         """seeds (consumed from the shuffler's stream, in pass order) and the staging buffer of one epoch."""
+        import time
+        t0 = time.perf_counter()
         torch, sh = self.torch, self.sh
         n = np.array([sh.sizes[d] for d, _ in passes], np.int64)
         seeds = np.empty(len(passes), np.uint64)
@@ -128,18 +132,31 @@ class EpochShuffles(object):
             self.dev[k] = torch.empty(cap, dtype=torch.int32, device=self.device)
             self.done[k] = None
         if self.done[k] is not None:
+            t1 = time.perf_counter()
             self.done[k].synchronize()          # the previous upload from this staging buffer has been read
-        return {"k": k, "n": n, "seeds": seeds, "total": total, "error": None}
+            self.timing["stage_sync"] += time.perf_counter() - t1
+        self.timing["stage"] += time.perf_counter() - t0
+        return {"k": k, "n": n, "seeds": seeds, "total": total, "error": None, "passes": passes, "queue": None}
 
     def _draw(self, job):
         import ctypes as C
+        import time
+        t0 = time.perf_counter()
         try:
             lib = _engine.L.load()
             _engine.L.check(lib.mamdr_shuffle_perms(len(job["n"]), job["n"].ctypes.data_as(C.c_void_p), self.sh.buffer_size,
                                                     job["seeds"].ctypes.data_as(C.c_void_p),
                                                     C.c_void_p(self.host[job["k"]].data_ptr())))
+            # the passes' device slices (views of the device buffer the upload will fill): built here, off the caller's
+            # critical path -- 250 slices cost 1.8 ms of an epoch boundary whose run-ahead margin is 2 - 3 ms
+            k, off, q = job["k"], 0, []
+            for (d, _), cnt in zip(job["passes"], job["n"]):
+                q.append((d, self.dev[k][off:off + int(cnt)]))
+                off += int(cnt)
+            job["queue"] = q
         except Exception as e:      # surfaces in prepare(), on the caller's thread
             job["error"] = e
+        self.timing["draw"] += time.perf_counter() - t0
 
     def prefetch(self, passes):
         """start drawing the permutations of the epoch whose passes these are; `prepare` of the SAME passes then only
@@ -175,7 +192,10 @@ class EpochShuffles(object):
         if self.pending is not None and self.pending[0] == passes:
             _, job, t = self.pending
             self.pending = None
+            import time
+            t0 = time.perf_counter()
             t.join()
+            self.timing["join"] += time.perf_counter() - t0
         else:
             self.cancel()
             job = self._stage(passes)
@@ -183,14 +203,15 @@ class EpochShuffles(object):
         if job["error"] is not None:
             raise job["error"]
         k, n, total = job["k"], job["n"], job["total"]
+        import time
+        t0 = time.perf_counter()
         self.dev[k][:total].copy_(self.host[k][:total], non_blocking=True)
         self.done[k] = torch.cuda.Event()
         self.done[k].record(torch.cuda.current_stream(self.device))
-        off, q = 0, []
-        for (d, _), cnt in zip(passes, n):
-            q.append((d, self.dev[k][off:off + int(cnt)]))
-            off += int(cnt)
-        self.queue = q
+        t1 = time.perf_counter()
+        self.queue = job["queue"]
+        self.timing["upload"] += t1 - t0
+        self.timing["queue"] += time.perf_counter() - t1
 
     def peek(self, domains):
         """the permutations the next len(domains) calls will hand out, without consuming them (meta.PassWindow gathers
@@ -207,6 +228,10 @@ class EpochShuffles(object):
         if dd != d:
             raise RuntimeError("pass %d of the epoch is over domain %d, not %d" % (self.pos, dd, d))
         self.pos += 1
+        if self.lookahead is not None and self.pos == min(8, len(self.queue)):
+            # a few passes of this epoch are enqueued (the stream has fresh work): the caller's hook plans the NEXT epoch and
+            # calls prefetch() now, so that its draw runs beside the whole of this epoch's enqueueing instead of after it
+            self.lookahead()
         return perm
 
 
