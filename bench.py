@@ -523,6 +523,19 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
             parallel.barrier()          # (ranks of a process group, or the lanes of this process)
         torch.cuda.synchronize()
 
+    # device warm-up before the W warm-up epochs the contract asks for: the first process on a box that has just come up runs
+    # its first second at lower clocks (measured: 43.3 K on such a run against 44.6 K on every later one, kernel times of the
+    # later profile pass identical) -- W = 3 epochs are 85 ms.  Untimed, reported as `prewarm_s`.
+    prewarm_s = float(os.environ.get("MAMDR_BENCH_PREWARM_S", "0.75"))
+    tw = time.perf_counter()
+    while prewarm_s > 0:
+        epoch()
+        torch.cuda.synchronize()
+        go_on = torch.tensor([1.0 if time.perf_counter() - tw < prewarm_s else 0.0], device=eng.device)
+        if world > 1:
+            parallel.all_reduce(go_on, "min")        # (ranks / lanes leave the loop together)
+        if float(go_on.item()) == 0.0:
+            break
     for _ in range(warmup):
         epoch()
     barrier()
@@ -736,7 +749,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         # bound -- the HIP queue blocks the host once it is a few hundred launches ahead, so at N = 1 this tracks the
         # device time.  host_prep_ms_per_epoch = the part that does not shrink with the rank count (drawing the epoch's
         # plan, the per-epoch assignment, drawing + uploading this rank's shuffles), timed on its own.
-        "host_ms_per_epoch": host_ms,
+        "host_ms_per_epoch": host_ms, "prewarm_s": prewarm_s, "prewarm_note": "untimed epochs before the W warm-up epochs (device clocks)",
         "host_prep_ms_per_epoch": (host_prep_s[0] + (balanced.host_prep_s if balanced is not None else 0.0) - host_prep0) / steps * 1e3,
     }
     if balanced is not None and balanced.wire_bytes:
@@ -882,7 +895,7 @@ def main():
     if world == 1 and args.lanes > 1:
         lanes_rec = run_lanes(args.workload, args.steps, args.warmup, args.lanes)
         if "taobao30" in targets:
-            t30l = run_lanes("taobao30", max(3, args.steps // 4), min(args.warmup, 2), args.lanes)
+            t30l = run_lanes("taobao30", max(3, args.steps // 2), min(args.warmup, 2), args.lanes)
             t30l["over_single_chain"] = t30l["value"] / targets["taobao30"]["value"]
             targets["taobao30"]["lanes"] = t30l
     if rank == 0:
@@ -904,7 +917,7 @@ def main():
             "roofline": r["roofline"], "tower": r["tower"], "table_update": r["table_update"],
             "gather": gather, "gather_l2": r["gather_l2"], "kernels_avg_us": r["kernels_avg_us"],
             "cpu_baseline": r["cpu_baseline"], "host_ms_per_epoch": r["host_ms_per_epoch"],
-            "host_prep_ms_per_epoch": r["host_prep_ms_per_epoch"], "targets": targets,
+            "host_prep_ms_per_epoch": r["host_prep_ms_per_epoch"], "prewarm_s": r["prewarm_s"], "targets": targets,
         }
         if lanes_rec is not None:
             lanes_rec["over_single_chain"] = lanes_rec["value"] / r["value"]

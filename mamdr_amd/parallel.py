@@ -58,7 +58,7 @@ class LaneGroup(object):
             try:
                 if device is not None:
                     torch.cuda.set_device(device)
-                    with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                    with torch.cuda.stream(_lane_stream(device, lane)):
                         results[lane] = fn(lane)
                         torch.cuda.current_stream().synchronize()
                 else:
@@ -152,6 +152,19 @@ class LaneGroup(object):
                     torch.cuda.current_stream().wait_event(self.ev[src])
                 vectors[key].copy_(self.slots[src][key])
         self._read_done(rank, cuda, set(src for _, src, _ in moves))
+
+
+_lane_streams = {}
+
+
+def _lane_stream(device, lane):
+    """lane k of every LaneGroup of this process runs on the SAME stream: streams map to hardware queues in creation order, and
+    a second group on fresh streams can land two lanes on one queue (Taobao-30, 4 lanes: 28 K instead of 33 K domain-steps/s
+    for the second group of a process)."""
+    key = (device, lane)
+    if key not in _lane_streams:
+        _lane_streams[key] = torch.cuda.Stream(device=device)
+    return _lane_streams[key]
 
 
 class _Lane0Stdout(object):
