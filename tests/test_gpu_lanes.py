@@ -88,14 +88,18 @@ def test_lanes_running_side_by_side_end_in_the_bits_of_their_solo_runs(tile):
             parallel.barrier()                    # (start together)
         for _ in range(3):
             eng.train_steps(d, perm=perm, lr=1e-3)
+        # ... the finetune stage's steps (SGD: the slab path's k_update) and an evaluation (AUC histogram, loss) as well
+        eng.train_steps(d, perm=perm, lr=1e-3, optimizer="sgd")
+        ev = eng.evaluate(d, "train")
         w = eng.get_weights().cpu().numpy().copy()
         eng.close()
-        return w
+        return w, ev
     together = parallel.LaneGroup(L).run(lambda lane: one(lane, False))
     for lane in range(L):
-        alone = one(lane, True)
-        assert np.array_equal(together[lane].view(np.uint32), alone.view(np.uint32)), (tile, lane)
-        assert not np.array_equal(together[lane], together[(lane + 1) % L])
+        alone, ev = one(lane, True)
+        assert np.array_equal(together[lane][0].view(np.uint32), alone.view(np.uint32)), (tile, lane)
+        assert together[lane][1] == ev, (tile, lane, together[lane][1], ev)
+        assert not np.array_equal(together[lane][0], together[(lane + 1) % L][0])
 
 
 def test_tower_tile_of_an_engine():

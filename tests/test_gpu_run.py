@@ -196,6 +196,24 @@ def test_run_entry_two_ranks_on_the_hip_engine(tmp_path, name, extra):
     assert a["domain_auc"] == b["domain_auc"] and len(a["domain_auc"]) == 10 and a["avg_auc"] > 0.6
     if extra.get("target_domain", -1) >= 0:
         assert a["weights_sha"] == b["weights_sha"]
+    # the same two ranks as LANES of this process (train.lanes = 2: host threads, one engine + HIP stream each, their kernels
+    # overlapping on the device): the two-process run BIT FOR BIT on the HIP engine -- returned per-domain AUCs and the live
+    # weights every lane ends with -- as on the CPU stand-in (tests/test_abi_and_parallel.py)
+    import hashlib
+    import shutil
+    from mamdr_amd import cli
+    for d in ("result", "ckpt"):
+        shutil.rmtree(str(tmp_path / d), ignore_errors=True)
+    lane_cfg = copy.deepcopy(cfg)
+    lane_cfg["train"]["lanes"] = 2
+    built = []
+    res = cli.main(lane_cfg, on_model=built.append)
+    assert len(built) == 2
+    assert {str(k): v for k, v in res[3].items()} == a["domain_auc"] and res[1] == a["avg_auc"]
+    lane_w = [m.model.get_weights() for m in built]      # (materialises what a lane's stream still holds pending, ON that stream)
+    torch.cuda.synchronize()                             # ... which this thread's stream does not wait for by itself
+    lane_sha = sorted(hashlib.sha1(w.cpu().numpy().tobytes()).hexdigest() for w in lane_w)
+    assert lane_sha == sorted([a["weights_sha"], b["weights_sha"]]), (lane_sha, a["weights_sha"], b["weights_sha"])
 
 
 def test_rccl_communicator_on_this_gpu():
