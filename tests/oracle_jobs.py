@@ -239,21 +239,38 @@ class Recorder(object):
     def attach(self, model):
         self.model = model
         rec = self.events
-        vt, es = model.val_and_test, model.early_stop_step
         base = getattr(model, "base_model", model)
+        depth = [0]
+        # the outermost wrapper AND the tower below it: a wrapper that leaves the training loop to the tower (uncertainty
+        # weighting: train() = the base model's alternate loop) validates through the tower's methods.  Only the outermost of
+        # nested calls is recorded.
+        for target in ([model] if base is model else [model, base]):
+            def wrap(target=target):
+                vt, es = target.val_and_test, target.early_stop_step
 
-        def val_and_test(mode):
-            out = vt(mode)
-            rec.append(("eval", mode, float(out[0]), float(out[1]), {int(k): float(v) for k, v in out[2].items()},
-                        {int(k): float(v) for k, v in out[3].items()}))
-            return out
+                def val_and_test(mode):
+                    depth[0] += 1
+                    try:
+                        out = vt(mode)
+                    finally:
+                        depth[0] -= 1
+                    if depth[0] == 0:
+                        rec.append(("eval", mode, float(out[0]), float(out[1]), {int(k): float(v) for k, v in out[2].items()},
+                                    {int(k): float(v) for k, v in out[3].items()}))
+                    return out
 
-        def early_stop_step(metric):
-            stop = es(metric)
-            rec.append(("early_stop", float(metric), float(base.best_metric), int(base.counter), bool(stop)))
-            return stop
-        model.val_and_test = val_and_test
-        model.early_stop_step = early_stop_step
+                def early_stop_step(metric):
+                    depth[0] += 1
+                    try:
+                        stop = es(metric)
+                    finally:
+                        depth[0] -= 1
+                    if depth[0] == 0:
+                        rec.append(("early_stop", float(metric), float(base.best_metric), int(base.counter), bool(stop)))
+                    return stop
+                target.val_and_test = val_and_test
+                target.early_stop_step = early_stop_step
+            wrap()
 
     def summary(self, result):
         model = self.model

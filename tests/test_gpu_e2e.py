@@ -71,6 +71,23 @@ CASES = {
     "taobao10_reptile": dict(
         cfg_file="Taobao-10/deepctr_DN+DR.json", name="mlp_meta_reptile", train=(("epoch", 6), ("meta_learning_rate", 0.5)),
         dataset=(), min_auc=0.7, want_early_stop=False),
+    # the reference's remaining Taobao-10 config files AS CONFIGURED (only `epoch` capped), each through run.py's whole pipeline:
+    # MLDG (mldg.py:62-125: meta-train / meta-val split of every domain, first-order gradients of both, outer Adam at 1e-4),
+    # PCGrad (pcgrad.py:62-160: per-domain gradients projected against the sampled auxiliary domains' -- bit-exact projection,
+    # tests/test_gpu_parity.py), uncertainty weighting (weighted_loss.py:29-42: one trainable log-variance per domain in the
+    # loss), and the plain Star tower trained jointly (star.py:34-68: alternate batches over the domains)
+    "taobao10_mldg_as_configured": dict(
+        cfg_file="Taobao-10/deepctr_mldg_taobao_10.json", name=None, train=(("epoch", 6),), dataset=(), min_auc=0.58,
+        want_early_stop=False),
+    "taobao10_pcgrad_as_configured": dict(
+        cfg_file="Taobao-10/deepctr_pcgrad_taobao_10.json", name=None, train=(("epoch", 5),), dataset=(), min_auc=0.7,
+        want_early_stop=False),
+    "taobao10_uncertainty_weight_as_configured": dict(
+        cfg_file="Taobao-10/deepctr_uncertainty_weight_taobao_10.json", name=None, train=(("epoch", 6),), dataset=(),
+        min_auc=0.7, want_early_stop=False),
+    "taobao10_star_joint_as_configured": dict(
+        cfg_file="Taobao-10/star_taobao.json", name=None, train=(("epoch", 5),), dataset=(), min_auc=0.6,
+        want_early_stop=False, beyond_share=0.25),
     # BASELINE.json configs[4]'s name (star_meta_mamdr: PartitionedNorm + StarFCN, theta / phi over the name-filtered meta
     # parameters ["emb", "kernel_shared", "bias_shared"], maml.py:153-179) on the reference's Taobao-10 Star config
     # (config/Taobao-10/star_taobao.json: frozen pretrained tables), from the Keras initial values, full rows.  The oracle twin
