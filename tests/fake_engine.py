@@ -375,14 +375,22 @@ class FakeStarEngine(FakeEngine):
         return self.KERAS_NAMES.get(segment, segment)
 
 
+def fake_graph(kind, *args, **kw):
+    """the generic-layer engine's stand-ins by kind: nfm / pnn (oracle/fmnets.py), shared_bottom / mmoe / ple (oracle/mtl.py)."""
+    return (FakeFmEngine if kind in ("nfm", "pnn") else FakeGraphEngine)(kind, *args, **kw)
+
+
 def fake_factory(*args, **kw):
-    """engine factory that also serves the Star tower (cli.main(engine_factory=fake_factory))."""
+    """engine factory that also serves the Star tower and -- called with a kind name first, as DeepMTLCTR calls its factory --
+    the multi-task towers (cli.main(engine_factory=fake_factory))."""
+    if args and isinstance(args[0], str):
+        return fake_graph(*args, **kw)
     if kw.get("tower") == "star":
         return FakeStarEngine(*args, **kw)
     return FakeEngine(*args, **kw)
 
 
-fake_factory.graph = FakeFmEngine
+fake_factory.graph = fake_graph
 
 
 def _otower():
