@@ -133,3 +133,30 @@ def test_tower_tile_of_an_engine():
         eng.close()
         return t
     assert parallel.LaneGroup(4).run(fn) == [16] * 4 and parallel.LaneGroup(2).run(fn) == [4] * 2
+
+
+@pytest.mark.parametrize("cfg_file,name,lanes", [
+    ("Taobao-10/deepctr_DN+DR.json", "ccpm_meta_reptile", 2),                            # generic-layer engine on lanes
+    ("Taobao-10/star_taobao.json", "star_meta_mamdr", 2),                                # Star: TailSync through the lanes' collectives
+    ("Taobao-10/deepctr_DN+DR.json", "deepfm_meta_domain_negotiation_finetune", 3),
+])
+def test_run_entry_on_lanes_with_the_other_towers(tmp_path, cfg_file, name, lanes):
+    """run.py's entry with train.lanes for towers beyond the frozen-table mlp: every lane builds its own engine of that kind
+    on its own stream, the sharded wrappers' collectives (and, for the Star tower, the step-weighted combination of the
+    tensors outside theta / phi) run between the lanes, every domain is reported and the model has learnt."""
+    _need_gpu()
+    import copy
+    import json
+    import os
+    from mamdr_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "config", cfg_file)) as f:
+        cfg = copy.deepcopy(json.load(f))
+    cfg["model"]["name"] = name
+    cfg["train"].update(epoch=3, patience=2, sample_num=2, meta_learning_rate=0.5, lanes=lanes,
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
+    built = []
+    avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg, on_model=built.append)
+    assert len(built) == lanes and len(domain_auc) == 10 and np.isfinite(avg_loss)
+    assert avg_auc > 0.52, (name, avg_auc)
