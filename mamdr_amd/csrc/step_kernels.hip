@@ -383,25 +383,27 @@ __device__ __forceinline__ void early_pre(const TowerArgs& a, int r0, PreTile& t
     t.dom = a.pdom[rb];
     t.lab = a.plabel[rb];
 }
-__device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int r0, float* gx, int gx_ld,
-                                            const bool dmw = false, const int* perm_src = nullptr,
-                                            const PreTile* pt = nullptr) {
+// (PRE, the pre-gathered tile and the early permutation entry travel as a template flag / reference / value: handed over as
+// `pre ? &pt : nullptr` and `&perm_src` they lived in scratch -- 96 B per lane in the one instance that used them, round 5)
+template <bool PRE = false>
+__device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int r0, float* gx, int gx_ld, const bool dmw,
+                                            const bool has_perm_src, const int perm_src_v, const PreTile& pt) {
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
     float* rowf = smem + ROWI_OFF + 4 * TILE_ROWS;
     const int tid = threadIdx.x;
-    const bool pre = pt != nullptr;
+    constexpr bool pre = PRE;
     if (pre) {
         if (tid < TILE_ROWS) {
             rowi[tid] = 0;
             rowi[TILE_ROWS + tid] = 0;
-            rowi[2 * TILE_ROWS + tid] = pt->dom;
+            rowi[2 * TILE_ROWS + tid] = pt.dom;
             rowi[3 * TILE_ROWS + tid] = (r0 + tid) < a.rows ? 1 : 0;
-            rowf[tid] = pt->lab;
+            rowf[tid] = pt.lab;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + TOWER_THREADS * u, row = e >> 6;
-            f32x4 v = pt->x[u];
+            f32x4 v = pt.x[u];
             if (r0 + row >= a.rows) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(smem + XS_OFF + row * XS_LD + 4 * (e & 63)) = v;
         }
@@ -410,7 +412,7 @@ __device__ __forceinline__ void gather_tile(const TowerArgs& a, float* smem, int
         int64_t pos = a.row_base + r0 + tid;
         int64_t src = 0;
         if (valid) {
-            src = a.perm ? (perm_src ? (int64_t)*perm_src : (int64_t)a.perm[pos]) : pos;
+            src = a.perm ? (has_perm_src ? (int64_t)perm_src_v : (int64_t)a.perm[pos]) : pos;
             if (src < 0) src = 0;
             if (src >= a.n_rows_split) src = a.n_rows_split - 1;
         }
@@ -595,7 +597,8 @@ __global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restri
     const f32x2 wo_reg = *reinterpret_cast<const f32x2*>(P + a.L.wo + (tid & 31) * 2);
     const float gb_reg = P[a.L.gb];
 
-    gather_tile(a, smem, r0, acts_t, ACT_LD, dmw, &perm_src, pre ? &pt : nullptr);
+    if (FUSED_OK && pre) gather_tile<true>(a, smem, r0, acts_t, ACT_LD, dmw, false, 0, pt);
+    else gather_tile<false>(a, smem, r0, acts_t, ACT_LD, dmw, true, perm_src, pt);
     STAMP(1);
     // DeepFM: thread (i, part) owns columns 4 part .. +3 of row i's three fields.  u + i stays in
     // registers for the domain-table gradient (the x tile is overwritten by the backward chain).
@@ -879,7 +882,10 @@ void launch_tower_eval(const TowerArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(TOWER_THREADS) void k_gather(const TowerArgs a, float* out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r0 = blockIdx.x * TILE_ROWS;
-    gather_tile(a, smem, r0, nullptr, 0);
+    {
+        PreTile none;
+        gather_tile<false>(a, smem, r0, nullptr, 0, false, false, 0, none);
+    }
     const float* xs = smem + XS_OFF;
     for (int e = threadIdx.x; e < TILE_ROWS * (XDIM / 4); e += TOWER_THREADS) {
         const int row = e / (XDIM / 4), c4 = e - row * (XDIM / 4);
