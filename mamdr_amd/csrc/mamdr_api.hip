@@ -2007,6 +2007,7 @@ int mamdr_step_path(const mamdr_ctx* c, int32_t batch) {
 int mamdr_set_tower_tile(mamdr_ctx* c, int32_t rows) {
     if (check_ctx(c)) return MAMDR_EINVAL;
     if (rows != 0 && rows != 4 && rows != 16) return fail(MAMDR_EINVAL, "tower tile of %d rows (0 = automatic, 4, 16)", rows);
+    if (rows == 16 && (c->pnn || c->nfm)) return fail(MAMDR_EINVAL, "the pnn / nfm towers exist as four-row tiles only");
     if (rows != c->tower_tile) {
         c->tower_tile = rows;
         c->pg.clear();          // (passes gathered ahead were laid out for the step path of the old choice)

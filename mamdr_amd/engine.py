@@ -205,7 +205,8 @@ class TowerEngine(FlatVectorOps):
         if tower_tile is None:
             from . import parallel
             group = parallel.lanes()
-            tower_tile = 16 if (group is not None and group.n >= 4) else 0
+            # (the PNN / NFM modes exist in the four-row tower only)
+            tower_tile = 16 if (group is not None and group.n >= 4 and tower in ("mlp", "deepfm", "wdl")) else 0
         if tower_tile:
             self.set_tower_tile(tower_tile)
         self.emb_trainable = bool(emb_trainable)

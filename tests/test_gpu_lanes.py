@@ -139,6 +139,8 @@ def test_tower_tile_of_an_engine():
     ("Taobao-10/deepctr_DN+DR.json", "ccpm_meta_reptile", 2),                            # generic-layer engine on lanes
     ("Taobao-10/star_taobao.json", "star_meta_mamdr", 2),                                # Star: TailSync through the lanes' collectives
     ("Taobao-10/deepctr_DN+DR.json", "deepfm_meta_domain_negotiation_finetune", 3),
+    ("Taobao-10/deepctr_DN+DR.json", "nfm_meta_mamdr", 4),                               # (four lanes: the nfm tower keeps its four-row tile)
+    ("Taobao-10/deepctr_DN+DR.json", "wdl_meta_mamdr", 4),                               # (... wdl takes the 16-row tower)
 ])
 def test_run_entry_on_lanes_with_the_other_towers(tmp_path, cfg_file, name, lanes):
     """run.py's entry with train.lanes for towers beyond the frozen-table mlp: every lane builds its own engine of that kind
