@@ -29,7 +29,10 @@ namespace mamdr {
 
 constexpr int FZ_THREADS = 512;
 constexpr int FZ_WAVES = 8;
-constexpr int FZ_RING = 32;                   // slots (of 4 batch rows) in flight per wave
+#ifndef MAMDR_FZ_RING
+#define MAMDR_FZ_RING 32
+#endif
+constexpr int FZ_RING = MAMDR_FZ_RING;       // slots (of 4 batch rows) in flight per wave (diagnostic builds may override)
 constexpr int FZ_SBLK = DM_PARTS;                   // S workgroups = 8-column blocks of dz1 (the optimiser step of their
                                               // 128 x 8 block of W0[256:384] is the long part: 2 elements per thread)
 constexpr int FZ_SC = 8;                      // columns per S workgroup
