@@ -8,7 +8,7 @@ Dispatch is by substring of config.model.name, in the reference's order (run.py:
   modes    'separate' -> per-domain training; otherwise train() + val_and_test("test");
            'finetune' -> load best + separate_train_val_test(init_parms=False)
 Every tower name of the reference's registries is built (run.py:37-47; deepctr.py:24-50: mlp wdl nfm autoint ccpm pnn
-deepfm; deep_mtl_ctr.py:25-49: shared_bottom mmoe ple; star); what is not (Star's auxiliary net, ple with more than one
+deepfm; deep_mtl_ctr.py:25-49: shared_bottom mmoe ple; star); what is not (Star's auxiliary net and BatchNormalization form, ple with more than one
 level, uncertainty weighting on the multi-task towers) raises NotImplementedError naming why.
 """
 import argparse

@@ -127,7 +127,7 @@ class DeepCTR(BaseModel):
         elif factory is None:
             from ..engine import TowerEngine
             factory = TowerEngine
-        kw = {}
+        kw = dict(self.engine_kwargs())
         if "uncertainty_weight" in mc["name"]:     # run.py:49-50: the weighted loss joins the compiled model
             kw["uncertainty_weight"] = True
         # deepctr.py:104-116: `trainable=emb_trainable` reaches SparseFeat only on the pretrained branch; without
@@ -135,10 +135,10 @@ class DeepCTR(BaseModel):
         self.tables_trainable = bool(tc["emb_trainable"]) or not bool(tc["load_pretrain_emb"])
         if (tower in GRAPH_TOWERS and not self.step_pnn) or self.graph_dnn:
             eng = factory(tower, self.n_uid, self.n_pid, self.n_domain, self.batch_size, expert_hidden=tuple(mc["hidden_dim"]),
-                          tower_hidden=(), dropout=mc.get("dropout", 0.0), emb_trainable=self.tables_trainable,
+                          tower_hidden=(), dropout=self.dropout_rate(), emb_trainable=self.tables_trainable,
                           emb_dim=mc["user_dim"], **kw)
         else:
-            eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=mc.get("dropout", 0.0),
+            eng = factory(self.n_uid, self.n_pid, self.n_domain, self.batch_size, dropout=self.dropout_rate(),
                           emb_trainable=self.tables_trainable, tower=tower, emb_dim=mc["user_dim"],
                           hidden=tuple(mc["hidden_dim"]), **kw)
         self.tower = tower
@@ -162,6 +162,13 @@ class DeepCTR(BaseModel):
         if tc["loss"] != "binary_crossentropy":
             raise NotImplementedError("loss '%s': only binary_crossentropy is on the hot path" % tc["loss"])
         return eng
+
+    def engine_kwargs(self):
+        """extra keyword arguments of the engine (subclasses: Star's plain-DNN form has no regularisers)."""
+        return {}
+
+    def dropout_rate(self):
+        return self.model_config.get("dropout", 0.0)
 
     def draw_initial_tensors(self):
         mc = self.model_config

@@ -127,17 +127,18 @@ def table_sumsq(table):
     return bigtable.table_sumsq(table)
 
 
-def reg_loss(params, frozen_sumsq=None, deepfm=False):
+def reg_loss(params, frozen_sumsq=None, deepfm=False, l2=None):
     """deepctr l2_reg_embedding * sum(W^2) on every table, frozen or not (A.3); DeepFM adds
     l2_reg_linear * sum(w^2) on its three linear tables (A.8).
     frozen_sumsq: optional {name: sum of squares} of tables that never change (computed once)."""
+    l2_emb, l2_lin = (L2_EMB, L2_LIN) if l2 is None else (F32(l2[0]), F32(l2[1]))    # (l2: Star's plain-DNN form has none)
     r = F32(0)
     for n in ("user_emb", "item_emb", "domain_emb"):
         ss = frozen_sumsq[n] if frozen_sumsq and n in frozen_sumsq else table_sumsq(params[n])
-        r = F32(r + L2_EMB * ss)
+        r = F32(r + l2_emb * ss)
     if deepfm:
         for n in ("lin_user", "lin_item", "lin_domain"):
-            r = F32(r + L2_LIN * table_sumsq(params[n]))
+            r = F32(r + l2_lin * table_sumsq(params[n]))
     return F32(r)
 
 
@@ -184,7 +185,7 @@ def train_masks(seed, step, n_rows, hidden, rate):
 
 
 def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, frozen_sumsq=None, deepfm=False,
-                   uncertainty=False):
+                   uncertainty=False, l2=None):
     """one batch: total loss (BCE mean + regularisers) and dense gradients.
     uncertainty (weighted_loss.py:30-43): loss = mean(BCE / var^2 + log var) + regularisers with
     var = log_var[domain of the batch's first row]."""
@@ -200,12 +201,12 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
         d0 = int(dom[0])
         var = params["log_var"][d0]
         w = F32(F32(1) / F32(var * var))
-        loss = F32(w * mean_bce) + F32(np.log(var, dtype=F32)) + reg_loss(params, frozen_sumsq, deepfm)
+        loss = F32(w * mean_bce) + F32(np.log(var, dtype=F32)) + reg_loss(params, frozen_sumsq, deepfm, l2)
         dlogit = (dlogit * w).astype(F32)
         g["log_var"] = np.zeros_like(params["log_var"])
         g["log_var"][d0] = F32(F32(-2) * mean_bce / F32(var * var * var)) + F32(F32(1) / var)
     else:
-        loss = mean_bce + reg_loss(params, frozen_sumsq, deepfm)
+        loss = mean_bce + reg_loss(params, frozen_sumsq, deepfm, l2)
     L = len(hs) - 1
     g["wo"] = (hs[L].T @ dlogit[:, None]).astype(F32)
     g["gb"] = np.array([np.sum(dlogit, dtype=np.float64)], F32)
@@ -217,7 +218,7 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
         g["b%d" % l] = np.sum(dz, axis=0, dtype=np.float64).astype(F32)
         dh = (dz @ params["W%d" % l].T).astype(F32)
     E = params["domain_emb"].shape[1]
-    two_l2 = F32(2) * L2_EMB
+    two_l2 = F32(2) * (L2_EMB if l2 is None else F32(l2[0]))
     if deepfm:
         # d fm / d e_f = sum of the other two fields' embeddings; d linear / d w_f[id] = 1
         x = hs[0]
@@ -227,7 +228,7 @@ def loss_and_grads(params, uid, pid, dom, label, masks, rate, emb_trainable, fro
             dh[:, :E] += dlogit[:, None] * (it + d)
             dh[:, E:2 * E] += dlogit[:, None] * (u + d)
             dh[:, 2 * E:] += dlogit[:, None] * (u + it)
-        two_l2_lin = F32(2) * L2_LIN
+        two_l2_lin = F32(2) * (L2_LIN if l2 is None else F32(l2[1]))
         nd = params["lin_domain"].shape[0]
         gl = np.bincount(dom, weights=dlogit.astype(np.float64), minlength=nd)
         g["lin_domain"] = (gl.astype(F32) + two_l2_lin * params["lin_domain"]).astype(F32)
@@ -304,8 +305,13 @@ class OracleModel(object):
     """Stand-in for the compiled Keras model: train_on_batch / evaluate."""
 
     def __init__(self, params, emb_trainable=False, dropout=0.5, lr=1e-3, hidden=(256, 128, 64),
-                 dropout_seed=1024, tower="mlp", uncertainty=False):
+                 dropout_seed=1024, tower="mlp", uncertainty=False, l2_emb=None, l2_linear=None):
         self.params = params
+        # regularisers (deepctr's defaults; Star's plain-DNN form passes 0 / 0)
+        self.l2_emb = float(L2_EMB if l2_emb is None else l2_emb)
+        self.l2_linear = float(L2_LIN if l2_linear is None else l2_linear)
+        self.l2 = None if (l2_emb is None and l2_linear is None) else (F32(self.l2_emb), F32(self.l2_linear))
+        self.dropout = float(dropout)
         self.emb_trainable = emb_trainable
         self.deepfm = {"deepfm": 1, "wdl": 2}.get(tower, 0)      # tower with linear tables (+ FM term for 1)
         self.uncertainty = bool(uncertainty)
@@ -331,7 +337,7 @@ class OracleModel(object):
         masks = train_masks(self.seed, self.step, B, self.hidden, self.rate) if self.rate > 0 else \
             [np.ones((B, h), F32) for h in self.hidden]
         loss, g, _ = loss_and_grads(self.params, uid, pid, dom, label, masks, self.rate, self.emb_trainable,
-                                    self.frozen_sumsq(), self.deepfm, self.uncertainty)
+                                    self.frozen_sumsq(), self.deepfm, self.uncertainty, self.l2)
         if self.use_sgd:
             self.opt.sgd(self.params, g, self.lr)
         else:
@@ -353,7 +359,7 @@ class OracleModel(object):
         d total_loss / d theta at the current weights to `acc` (a flat vector); no update,
         learning phase 0 = dropout off.  The dropout counter still advances (one per step)."""
         _, g, _ = loss_and_grads(self.params, uid, pid, dom, label, None, 0.0, self.emb_trainable,
-                                 self.frozen_sumsq(), self.deepfm, self.uncertainty)
+                                 self.frozen_sumsq(), self.deepfm, self.uncertainty, self.l2)
         if getattr(self, "moving_average", None) is not None:       # average_meta_grad == "moving_mean" (maml.py:219-220)
             from . import outer
             ma = self.moving_average
@@ -390,7 +396,7 @@ class OracleModel(object):
         """Keras evaluate (A.6): loss = mean over batches of batch-mean loss (+reg),
         predictions for the AUC over all rows in file order."""
         n = data["uid"].shape[0]
-        reg = reg_loss(self.params, self.frozen_sumsq(), self.deepfm)
+        reg = reg_loss(self.params, self.frozen_sumsq(), self.deepfm, self.l2)
         batch_losses = []
         preds = np.empty(n, F32)
         for s in range(0, n, batch_size):

@@ -26,8 +26,9 @@ class FakeEngine(object):
         self.dropout_seed = dropout_seed
         rs = np.random.RandomState(0)
         params = otower.init_params(rs, n_user, n_item, n_domain, emb_dim, hidden)
+        l2 = {} if (l2_emb == 1e-5 and l2_linear == 1e-5) else dict(l2_emb=l2_emb, l2_linear=l2_linear)
         self.oracle = otower.OracleModel(params, emb_trainable=emb_trainable, dropout=dropout, hidden=hidden,
-                                         dropout_seed=dropout_seed, tower=tower, uncertainty=uncertainty_weight)
+                                         dropout_seed=dropout_seed, tower=tower, uncertainty=uncertainty_weight, **l2)
         self.segments = {}
         off = 0
         for name in self.oracle.names:

@@ -281,7 +281,7 @@ class Recorder(object):
                             {int(k): float(v) for k, v in result[3].items()}))
 
 
-def pipeline_config(cfg_file, name, tmp, train=None, dataset=None):
+def pipeline_config(cfg_file, name, tmp, train=None, dataset=None, model=None):
     import copy
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -290,8 +290,10 @@ def pipeline_config(cfg_file, name, tmp, train=None, dataset=None):
     if name:
         cfg["model"]["name"] = name
     cfg["train"].update(result_save_path=os.path.join(tmp, "result"), checkpoint_path=os.path.join(tmp, "ckpt"))
-    cfg["train"].update(train or {})
+    # (job keys are hashable: list-valued settings travel as tuples)
+    cfg["train"].update({k: (list(v) if isinstance(v, tuple) else v) for k, v in (train or {}).items()})
     cfg["dataset"].update(dataset or {})
+    cfg["model"].update(model or {})
     return cfg
 
 
@@ -327,7 +329,7 @@ def run_pipeline(cfg, engine_factory=None, perturb=0.0):
     return s
 
 
-def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0):
+def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0, model=()):
     """the oracle twin of a whole run: the SAME host code (cli.main, model_zoo/*, meta.py) on tests/fake_engine.FakeEngine,
     i.e. every numeric call answered by the numpy oracle.  train / dataset: tuples of (key, value) overrides."""
     import contextlib
@@ -335,7 +337,7 @@ def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0):
     import tempfile
     from fake_engine import fake_factory as FakeEngine      # (FakeEngine, or FakeStarEngine for the Star tower)
     tmp = tempfile.mkdtemp(prefix="mamdr_twin_")
-    cfg = pipeline_config(cfg_file, model_name, tmp, dict(train), dict(dataset))
+    cfg = pipeline_config(cfg_file, model_name, tmp, dict(train), dict(dataset), dict(model))
     buf = io.StringIO()
     t0 = time.time()
     with contextlib.redirect_stdout(buf):

@@ -99,6 +99,15 @@ CASES = {
     "taobao10_ple_as_configured": dict(
         cfg_file="Taobao-10/ple.json", name=None, train=(("epoch", 2),), dataset=(), min_auc=0.55,
         want_early_stop=False, beyond_share=0.25),
+    # Star's OTHER form (star.py:74-87 with `norm: "none"`, `dense: "dense"`: no PartitionedNorm, plain Keras Dense layers, no
+    # dropout, no regularisers, Keras initial values) under MAMDR with a name filter that takes the embeddings and the kernels
+    # but not the biases (holes in the meta range): runs on the mlp step kernels; oracle twin = FakeEngine(tower "mlp")
+    "taobao10_star_plain_dnn_mamdr": dict(
+        cfg_file="Taobao-10/star_taobao.json", name="star_meta_mamdr", model=(("norm", "none"), ("dense", "dense")),
+        train=(("epoch", 5), ("meta_parms", ("emb", "kernel"))), dataset=(), min_auc=0.7, want_early_stop=False,
+        # (no dropout, no regulariser, Keras initial values: the oracle differs from its own perturbed twin by up to 1.7e-3
+        # per domain in the first epochs)
+        beyond_share=0.25),
     # BASELINE.json configs[4]'s name (star_meta_mamdr: PartitionedNorm + StarFCN, theta / phi over the name-filtered meta
     # parameters ["emb", "kernel_shared", "bias_shared"], maml.py:153-179) on the reference's Taobao-10 Star config
     # (config/Taobao-10/star_taobao.json: frozen pretrained tables), from the Keras initial values, full rows.  The oracle twin
@@ -124,7 +133,10 @@ CASES = {
 
 def _job_kwargs(case):
     c = CASES[case]
-    return dict(cfg_file=c["cfg_file"], model_name=c["name"], train=c["train"], dataset=c["dataset"])
+    kw = dict(cfg_file=c["cfg_file"], model_name=c["name"], train=c["train"], dataset=c["dataset"])
+    if c.get("model"):
+        kw["model"] = c["model"]
+    return kw
 
 
 def _evals(s, mode):
@@ -299,7 +311,8 @@ def test_run_pipeline_matches_oracle_twin(case):
         pytest.skip("no HIP device")
     kw = _job_kwargs(case)
     tmp = tempfile.mkdtemp(prefix="mamdr_e2e_")
-    cfg = oracle_jobs.pipeline_config(kw["cfg_file"], kw["model_name"], tmp, dict(kw["train"]), dict(kw["dataset"]))
+    cfg = oracle_jobs.pipeline_config(kw["cfg_file"], kw["model_name"], tmp, dict(kw["train"]), dict(kw["dataset"]),
+                                      dict(kw.get("model", ())))
     import time
     t0 = time.time()
     s_h = oracle_jobs.run_pipeline(cfg)                         # the product: HIP engine behind cli.main
