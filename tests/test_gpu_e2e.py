@@ -77,24 +77,24 @@ CASES = {
     # tests/test_gpu_parity.py), uncertainty weighting (weighted_loss.py:29-42: one trainable log-variance per domain in the
     # loss), and the plain Star tower trained jointly (star.py:34-68: alternate batches over the domains)
     "taobao10_mldg_as_configured": dict(
-        cfg_file="Taobao-10/deepctr_mldg_taobao_10.json", name=None, train=(("epoch", 6),), dataset=(), min_auc=0.58,
+        cfg_file="Taobao-10/deepctr_mldg_taobao_10.json", name=None, train=(("epoch", 4),), dataset=(), min_auc=0.55,
         want_early_stop=False),
     "taobao10_pcgrad_as_configured": dict(
-        cfg_file="Taobao-10/deepctr_pcgrad_taobao_10.json", name=None, train=(("epoch", 5),), dataset=(), min_auc=0.7,
+        cfg_file="Taobao-10/deepctr_pcgrad_taobao_10.json", name=None, train=(("epoch", 4),), dataset=(), min_auc=0.7,
         want_early_stop=False),
     "taobao10_uncertainty_weight_as_configured": dict(
-        cfg_file="Taobao-10/deepctr_uncertainty_weight_taobao_10.json", name=None, train=(("epoch", 6),), dataset=(),
+        cfg_file="Taobao-10/deepctr_uncertainty_weight_taobao_10.json", name=None, train=(("epoch", 4),), dataset=(),
         min_auc=0.7, want_early_stop=False),
     "taobao10_star_joint_as_configured": dict(
-        cfg_file="Taobao-10/star_taobao.json", name=None, train=(("epoch", 5),), dataset=(), min_auc=0.6,
+        cfg_file="Taobao-10/star_taobao.json", name=None, train=(("epoch", 4),), dataset=(), min_auc=0.6,
         want_early_stop=False, beyond_share=0.25),
     # ... and the multi-task comparison baselines' config files (deep_mtl_ctr.py:21-96 on the generic-layer engine; the oracle
     # twin on tests/fake_engine.FakeGraphEngine = oracle/mtl.py), as configured with `epoch` capped
     "taobao10_shared_bottom_as_configured": dict(
-        cfg_file="Taobao-10/shared_bottom.json", name=None, train=(("epoch", 4),), dataset=(), min_auc=0.6,
+        cfg_file="Taobao-10/shared_bottom.json", name=None, train=(("epoch", 3),), dataset=(), min_auc=0.6,
         want_early_stop=False, beyond_share=0.25),
     "taobao10_mmoe_as_configured": dict(
-        cfg_file="Taobao-10/mmoe.json", name=None, train=(("epoch", 4),), dataset=(), min_auc=0.6,
+        cfg_file="Taobao-10/mmoe.json", name=None, train=(("epoch", 3),), dataset=(), min_auc=0.6,
         want_early_stop=False, beyond_share=0.25),
     "taobao10_ple_as_configured": dict(
         cfg_file="Taobao-10/ple.json", name=None, train=(("epoch", 2),), dataset=(), min_auc=0.55,
@@ -104,7 +104,7 @@ CASES = {
     # but not the biases (holes in the meta range): runs on the mlp step kernels; oracle twin = FakeEngine(tower "mlp")
     "taobao10_star_plain_dnn_mamdr": dict(
         cfg_file="Taobao-10/star_taobao.json", name="star_meta_mamdr", model=(("norm", "none"), ("dense", "dense")),
-        train=(("epoch", 5), ("meta_parms", ("emb", "kernel"))), dataset=(), min_auc=0.7, want_early_stop=False,
+        train=(("epoch", 4), ("meta_parms", ("emb", "kernel"))), dataset=(), min_auc=0.7, want_early_stop=False,
         # (no dropout, no regulariser, Keras initial values: the oracle differs from its own perturbed twin by up to 1.7e-3
         # per domain in the first epochs)
         beyond_share=0.25),
