@@ -6,7 +6,6 @@ MAMDR_T4 (0/1) etc. select the tower as for any run.  No oracle, no parity: a ra
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, ".")
