@@ -887,10 +887,18 @@ def main():
         for wname in ("amazon6", "amazon13"):
             if os.environ.get("MAMDR_BENCH_SKIP_" + wname.upper()):
                 continue
-            rec = run_workload(wname, 2, 1, rank, world, not args.no_profile, min(args.cpu_budget * 0.3, 8.0))
-            targets[wname] = {k: rec[k] for k in TARGET_KEYS if k in rec}
+            try:        # (single process: an extra workload that fails is reported, the headline above stands)
+                rec = run_workload(wname, 2, 1, rank, world, not args.no_profile, min(args.cpu_budget * 0.3, 8.0))
+                targets[wname] = {k: rec[k] for k in TARGET_KEYS if k in rec}
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                targets[wname] = {"error": "%s: %s" % (type(e).__name__, e)}
     if not args.no_targets and rank == 0 and world == 1 and not args.no_profile:
-        gather = gather_hbm_record(torch.device("cuda", torch.cuda.current_device()))
+        try:
+            gather = gather_hbm_record(torch.device("cuda", torch.cuda.current_device()))
+        except Exception as e:      # noqa: BLE001
+            gather = {"error": "%s: %s" % (type(e).__name__, e)}
     lanes_rec = None
     if world == 1 and args.lanes > 1:
         # (an extra beside `value`: a failure here is reported in the line, it does not cost the run its headline)
