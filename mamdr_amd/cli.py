@@ -148,7 +148,11 @@ def _run(config, dataset, engine_factory, on_model, rank):
 def cli(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--config", type=str, help="Train config file", required=True)
+    # (not an option of the reference's run.py: the sharded epoch on one GPU, see n_lanes)
+    parser.add_argument("--lanes", type=int, default=None, help="run the sharded epoch on this many lanes of one process (train.lanes)")
     args = parser.parse_args(argv)
     with open(args.config, "r") as f:
         config = json.load(f)
+    if args.lanes is not None:
+        config["train"]["lanes"] = args.lanes
     return main(config)
