@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MAMDR_ABI_VERSION 17
+#define MAMDR_ABI_VERSION 18
 
 enum {
     MAMDR_OK = 0,
@@ -120,6 +120,13 @@ typedef struct mamdr_config {
 
 const char* mamdr_last_error(void);
 int mamdr_abi_version(void);
+/* Every environment switch this build reads (library, Python host, bench.py, tools, tests), one per line:
+ * "NAME\twho reads it\teffect\n"; a trailing '*' marks a name prefix.  Diagnostics only -- the reference is configured by
+ * its JSON files alone (run.py:20-33) and the defaults are what the parity tests and bench.py run.  mamdr_create /
+ * mamdr_graph_create report (stderr, once per process) any MAMDR_* name of the environment that is NOT in this table;
+ * mamdr_env_unknown returns how many there were.  (ABI 18) */
+const char* mamdr_env_switches(void);
+int mamdr_env_unknown(void);
 
 /* --- lifetime: replaces DeepCTR(dataset, config) / build_model + compile
  *     (model_zoo/DeepCTR/deepctr.py:20-61). */
@@ -156,6 +163,13 @@ int mamdr_optimizer_reset(mamdr_ctx* ctx);
  * target of MAMDR_OPT_ACCUMULATE steps.  Replaces `self.accum_grads` (model_zoo/maml.py:202). */
 int mamdr_bind_accumulator(mamdr_ctx* ctx, float* d_acc);
 int64_t mamdr_optimizer_steps(const mamdr_ctx* ctx);
+/* Restore the run's two host-side counters -- the Adam step count with its running beta powers (TF's `beta1_power` /
+ * `beta2_power` slot variables, restored by tf.train.Saver with the optimizer: deepctr.py:55-60 creates them) and the
+ * position of the dropout stream (mamdr_dropout_steps) -- e.g. when a run resumes from saved weights and slots written into
+ * the bound vectors.  The live state is synchronised first (as mamdr_sync_tables); afterwards every table row counts as
+ * current AT `optimizer_steps`.  The parity tests use it to start a pass from the oracle's state at that point
+ * (tests/test_gpu_teacher.py).  (ABI 18) */
+int mamdr_set_counters(mamdr_ctx* ctx, int64_t optimizer_steps, int64_t dropout_steps);
 /* Trainable tables only (no-op otherwise).  tf.train.AdamOptimizer moves every table row every step
  * (deepctr.py:54-60 with l2_reg_embedding: regulariser gradient + decaying moments).  The library replays
  * those per-row steps lazily -- bit-identical to the per-step dense update -- so between two calls of

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAMDR_LIB_PATH") or os.path.join(HERE, "libmamdr_hip.so")      # (MAMDR_LIB_PATH: A/B of diagnostic builds, tools/build_variant.sh)
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 OK, EINVAL, ESTATE, EHIP, ENOTBUILT = 0, -1, -2, -3, -4
 TOWER_MLP, TOWER_DEEPFM, TOWER_STAR, TOWER_WDL, TOWER_PNN, TOWER_NFM = 0, 1, 2, 3, 4, 5
 SPLIT_TRAIN, SPLIT_VAL, SPLIT_TEST = 0, 1, 2
@@ -72,6 +72,8 @@ _VP, _I32, _I64, _U32, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, 
 SIGNATURES = {
     "mamdr_last_error": (C.c_char_p, []),
     "mamdr_abi_version": (C.c_int, []),
+    "mamdr_env_switches": (C.c_char_p, []),
+    "mamdr_env_unknown": (C.c_int, []),
     "mamdr_create": (C.c_int, [C.POINTER(Config), _VP, C.POINTER(_VP)]),
     "mamdr_destroy": (C.c_int, [_VP]),
     "mamdr_param_count": (_I64, [_VP]),
@@ -82,6 +84,7 @@ SIGNATURES = {
     "mamdr_bind_state": (C.c_int, [_VP, _VP, _VP, _VP]),
     "mamdr_optimizer_reset": (C.c_int, [_VP]),
     "mamdr_optimizer_steps": (_I64, [_VP]),
+    "mamdr_set_counters": (C.c_int, [_VP, _I64, _I64]),
     "mamdr_table_flushes": (_I64, [_VP, _I32]),
     "mamdr_pregather_passes": (_I32, [_VP, _I32, _VP, _VP, _VP, _I32]),
     "mamdr_pregather_hits": (_I64, [_VP]),
@@ -158,8 +161,15 @@ def load():
         fn.argtypes = args
     if lib.mamdr_abi_version() != ABI_VERSION:
         raise ImportError("libmamdr_hip.so ABI %d != binding ABI %d" % (lib.mamdr_abi_version(), ABI_VERSION))
+    lib.mamdr_env_unknown()          # a MAMDR_* name nobody reads is reported on stderr (once per process)
     _lib = lib
     return lib
+
+
+def env_switches():
+    """[(name, who reads it, effect)] -- the library's table of environment switches (csrc/env_registry.h)."""
+    rows = load().mamdr_env_switches().decode("utf-8").strip().split("\n")
+    return [tuple(r.split("\t")) for r in rows]
 
 
 def check(code, graph=False):

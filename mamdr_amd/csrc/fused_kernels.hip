@@ -607,11 +607,12 @@ void launch_wgrad_adam(const FusedArgs& a, hipStream_t s) {
         grid = first + 8 * rounds;
     }
     const size_t lds = (size_t)fz_lds_floats(a.n_domain) * sizeof(float);
-    static bool big_lds_set = false;
-    if (lds > 65536 && !big_lds_set) {          // 49..64 domains: 72 KB of partial S tiles
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_adam), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        big_lds_set = true;
+    if (lds > 65536) {          // 49..64 domains: 72 KB of partial S tiles (raised once: thread-safe static initialiser, to the
+                                // size of the largest domain count this path takes)
+        static const bool big_lds_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_adam),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            (int)(fz_lds_floats(64) * sizeof(float))) == hipSuccess;
+        (void)big_lds_set;
     }
     MAMDR_LAUNCH(k_wgrad_adam, dim3(grid), dim3(FZ_THREADS), lds, s, a);
 }

@@ -2168,6 +2168,7 @@ const char* mamdr_graph_last_error(void) { return g_gerr; }
 int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph** out) {
     if (!cfg || !out) return gfail(MAMDR_EINVAL, "null argument");
     *out = nullptr;
+    (void)mamdr::env_warn_unknown();
     if (cfg->abi_version != MAMDR_ABI_VERSION) return gfail(MAMDR_EINVAL, "abi_version %d != %d", cfg->abi_version, MAMDR_ABI_VERSION);
     if (cfg->emb_dim != EMB) return gfail(MAMDR_EINVAL, "emb_dim must be %d", EMB);
     if (cfg->n_user <= 0 || cfg->n_item <= 0 || cfg->n_domain <= 0 || cfg->max_batch <= 0) return gfail(MAMDR_EINVAL, "bad sizes");

@@ -13,11 +13,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/mamdr_hip.h"
 #include "mamdr_kernels.h"
+#include "env_registry.h"
 
 using namespace mamdr;
 
@@ -701,12 +703,54 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     return MAMDR_OK;
 }
 
+extern char** environ;
+namespace mamdr {
+// once per process (thread-safe static initialiser): a MAMDR_* name in the environment that nobody reads is reported
+int env_warn_unknown() {
+    static const int unknown = []() {
+        int n = 0;
+        for (char** e = environ; e && *e; ++e) {
+            if (strncmp(*e, "MAMDR_", 6) != 0) continue;
+            const char* eq = strchr(*e, '=');
+            const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+            bool known = false;
+            for (int i = 0; i < kNumEnvSwitches && !known; ++i) {
+                const char* k = kEnvSwitches[i].name;
+                const size_t kl = strlen(k);
+                if (kl && k[kl - 1] == '*') known = len >= kl - 1 && strncmp(*e, k, kl - 1) == 0;
+                else known = len == kl && strncmp(*e, k, kl) == 0;
+            }
+            if (!known) {
+                fprintf(stderr, "mamdr: environment variable %.*s is not a switch this build reads (mamdr_env_switches() lists them)\n",
+                        (int)len, *e);
+                n += 1;
+            }
+        }
+        return n;
+    }();
+    return unknown;
+}
+}  // namespace mamdr
+
 extern "C" {
 
 const char* mamdr_last_error(void) { return g_err; }
 int mamdr_abi_version(void) { return MAMDR_ABI_VERSION; }
 
+// ---- environment switches: one table (env_registry.h), handed out and checked against the process environment
+const char* mamdr_env_switches(void) {
+    static const std::string table = []() {
+        std::string t;
+        for (int i = 0; i < kNumEnvSwitches; ++i)
+            t += std::string(kEnvSwitches[i].name) + "\t" + kEnvSwitches[i].reader + "\t" + kEnvSwitches[i].effect + "\n";
+        return t;
+    }();
+    return table.c_str();
+}
+int mamdr_env_unknown(void) { return mamdr::env_warn_unknown(); }
+
 int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
+    (void)mamdr::env_warn_unknown();
     if (!cfg || !out) return fail(MAMDR_EINVAL, "null argument");
     *out = nullptr;
     if (cfg->abi_version != MAMDR_ABI_VERSION)
@@ -1037,6 +1081,32 @@ int mamdr_optimizer_reset(mamdr_ctx* c) {
 }
 
 int64_t mamdr_optimizer_steps(const mamdr_ctx* c) { return c ? c->adam_t : 0; }
+
+// Restore the two host-side counters of a run (a checkpoint's `beta1_power` / `beta2_power` variables and the position of
+// the dropout stream): the live state is brought up to date first (pending domain-table step, lagging table rows), then
+// every table row counts as current AT the new step count -- the caller supplies weights and slots that belong to it.
+int mamdr_set_counters(mamdr_ctx* c, int64_t optimizer_steps, int64_t dropout_steps) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (optimizer_steps < 0 || optimizer_steps > (int64_t)0x7ffffff0 || dropout_steps < 0 || dropout_steps > (int64_t)0xffffffffLL)
+        return fail(MAMDR_EINVAL, "mamdr_set_counters(%lld, %lld): out of range", (long long)optimizer_steps, (long long)dropout_steps);
+    if (!c->adam_m) return fail(MAMDR_ESTATE, "mamdr_bind_state has not been called");
+    sync_tables(c);
+    if (c->last_u) {
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->last_u), (int)optimizer_steps, (size_t)c->cfg.n_user, c->stream));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->last_i), (int)optimizer_steps, (size_t)c->cfg.n_item, c->stream));
+    }
+    c->flush_t = optimizer_steps;
+    c->adam_t = optimizer_steps;
+    float b1 = 1.0f, b2 = 1.0f;                 // TF's running products, one fp32 rounding per step (as the step loop forms them)
+    for (int64_t t = 0; t < optimizer_steps; ++t) {
+        b1 = b1 * c->cfg.adam_beta1;
+        b2 = b2 * c->cfg.adam_beta2;
+    }
+    c->b1p = b1;
+    c->b2p = b2;
+    c->global_step = (uint32_t)dropout_steps;
+    return MAMDR_OK;
+}
 int64_t mamdr_table_flushes(const mamdr_ctx* c, int32_t forced_only) {
     return !c ? 0 : forced_only ? c->n_flush_forced : c->n_flush;
 }
@@ -1452,10 +1522,11 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             // diagnostic build (tools/stamp_tower.py with MAMDR_DIAG_FLAGS=-DMAMDR_TOWER_TWICE): the same tower launch twice in a
             // row -- idempotent (the pending domain-table step is formed from its snapshot, every output is overwritten) -- so that
             // the stamps of the SECOND launch show the kernel with its own code and data still where the first left them
-            if (use4) launch_tower4_train(ta, c->stream);
+            if (use4) (void)launch_tower4_train(ta, c->stream);
 #endif
-            if (use4) launch_tower4_train(ta, c->stream);
-            else launch_tower_train(ta, c->stream);
+            const int t4e = use4 ? launch_tower4_train(ta, c->stream) : (launch_tower_train(ta, c->stream), 0);
+            if (t4e == T4_E_W2D_LDS) return fail(MAMDR_EHIP, "k_tower4<W2D> was refused its LDS limit (hipFuncSetAttribute)");
+            if (t4e) return fail(MAMDR_ESTATE, "w2_direct without the W1-image instance of k_tower4 (step %lld of the call)", (long long)s);
         }
         if (fused) {
             FusedArgs fa;

@@ -22,6 +22,7 @@ constexpr int32_t EMB_UNTOUCHED = 0x7fffffff;
 // carries as its OWN stop event (hipExtLaunchKernelGGL: recorded by the kernel's completion, no marker packet
 // between the kernels).  A kernel's time is then its stop event minus the stop event of the kernel before it.
 extern thread_local hipEvent_t g_prof_stop;
+int env_warn_unknown();          // mamdr_api.hip: MAMDR_* names of the environment missing from env_registry.h, reported once
 #define MAMDR_LAUNCH(kernel, grid, block, lds, stream, ...)                                               \
     do {                                                                                                  \
         if (::mamdr::g_prof_stop) {                                                                       \
@@ -600,7 +601,11 @@ void launch_dm_finish(const DmStep& q, float* live_p, float* live_m, float* live
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s);
 void launch_tower_eval(const TowerArgs& a, hipStream_t s);
-void launch_tower4_train(const TowerArgs& a, hipStream_t s);
+// -> 0, or one of T4_E_* (a state the caller's own predicate should have excluded / a refused LDS limit): the C ABI reports
+// them as MAMDR_ESTATE / MAMDR_EHIP through mamdr_last_error -- the library never aborts
+constexpr int T4_E_W2D_LDS = 1;        // k_tower4<.., W2D> was refused its LDS limit
+constexpr int T4_E_W2D_STATE = 2;      // w2_direct asked of a launch that does not take the W1-image instance
+int launch_tower4_train(const TowerArgs& a, hipStream_t s);
 // the W1-image instance of the pre-gathered tower can run (its LDS limit was granted): grids of up to one tile per CU
 bool tower4_w1l_ready();
 bool tower4_takes_w1l(int64_t rows, int no_w1l);      // launch_tower4_train's choice of the W1-image instance for a batch

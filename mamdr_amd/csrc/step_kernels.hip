@@ -1403,12 +1403,10 @@ __global__ void k_wgrad_pf(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherP
 __global__ void k_wgrad8(WGRAD_EARLY_PARAMS, const WgradArgs g0, const GatherPf pf, const int n_wgrad, const int n_pad);
 // pairs of row groups per workgroup: ONE slab per pair (k_update then sums (n_groups + 1) / 2 slabs)
 bool launch_wgrad_pairs(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
-    static int raised = 0;
     const size_t lds = (size_t)8 * WG_BUF * sizeof(float);
-    if (raised == 0)
-        raised = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
-                         hipSuccess ? 1 : -1;
-    if (raised != 1) return false;
+    static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(8 * WG_BUF * sizeof(float))) == hipSuccess;
+    if (!raised) return false;
     GatherPf none;
     memset(&none, 0, sizeof(none));
     const GatherPf& p = (pf && pf->n_tiles > 0) ? *pf : none;

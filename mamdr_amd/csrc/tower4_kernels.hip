@@ -967,52 +967,55 @@ __global__ __launch_bounds__(T4_THREADS) void k_tower4(const float* __restrict__
 
 // W1L needs the whole LDS of a CU: one workgroup per CU, i.e. grids of up to one tile per CU; larger grids keep the
 // streaming variant (30 KB of LDS, several workgroups per CU overlap each other's phases).
+// One-time raises of the LDS limit: function-local statics with initialisers (C++11: initialised exactly once, thread-safe --
+// the lanes of mamdr_amd/parallel.py reach these launchers from several host threads at once).
+template <bool DX, bool FM, bool PRE, bool W2D>
+static bool t4_w1l_raised() {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true, PRE, W2D>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess;
+    return ok;
+}
+// -> 0, or MAMDR_T4_E* (no abort() inside the library: mamdr_train_steps turns these into MAMDR_ESTATE / MAMDR_EHIP through
+// mamdr_last_error)
 template <bool DX, bool FM, bool PRE>
-static void launch_tower4_inst(const TowerArgs& a, dim3 grid, bool w1l, hipStream_t s) {
-    static int raised = 0;         // 1: the LDS limit of the W1L instance is raised, -1: refused (streaming variant only)
-    if (w1l && raised == 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true, PRE>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true));
-        raised = e == hipSuccess ? 1 : -1;
-        if (e != hipSuccess) fprintf(stderr, "mamdr: k_tower4 keeps streaming W1 (%s)\n", hipGetErrorString(e));
+static int launch_tower4_inst(const TowerArgs& a, dim3 grid, bool w1l, hipStream_t s) {
+    bool raised = false;           // the LDS limit of the W1L instance is raised (refused: streaming variant only)
+    if (w1l) {
+        raised = t4_w1l_raised<DX, FM, PRE, false>();
+        if (!raised) {
+            static const bool told = (fprintf(stderr, "mamdr: k_tower4 keeps streaming W1 (its LDS image was refused)\n"), true);
+            (void)told;
+        }
     }
     const float* w0 = a.dense + a.L.w0;
     const float* w1 = a.dense + a.L.w1;
-    if (w1l && raised == 1 && PRE && a.w2_direct) {
+    if (w1l && raised && PRE && a.w2_direct) {
         if constexpr (PRE) {
-            static int raised2 = 0;
-            if (raised2 == 0)
-                raised2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<DX, FM, true, PRE, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess ? 1 : -1;
-            if (raised2 != 1) { fprintf(stderr, "mamdr: k_tower4<W2D> refused its LDS\n"); abort(); }
+            if (!t4_w1l_raised<DX, FM, PRE, true>()) return T4_E_W2D_LDS;
             MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE, true>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a.xpre, a.pdom,
                          a.plabel, w0, w1, a.rows, a);
         }
-    } else if (w1l && raised == 1)
+    } else if (w1l && raised)
         MAMDR_LAUNCH((k_tower4<DX, FM, true, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(true), s, a.xpre, a.pdom, a.plabel, w0, w1,
                      a.rows, a);
     else {
-        if (a.w2_direct) { fprintf(stderr, "mamdr: w2_direct without the W1-image instance\n"); abort(); }
+        if (a.w2_direct) return T4_E_W2D_STATE;
         MAMDR_LAUNCH((k_tower4<DX, FM, false, PRE>), grid, dim3(T4_THREADS), tower4_lds_bytes(false), s, a.xpre, a.pdom, a.plabel, w0,
                      w1, a.rows, a);
     }
+    return 0;
 }
 bool tower4_w1l_ready() {
-    static int ok = -1;
-    if (ok < 0)
-        ok = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<false, false, true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess &&
-              hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower4<false, false, true, true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tower4_lds_bytes(true)) == hipSuccess) ? 1 : 0;
-    return ok == 1;
+    static const bool ok = t4_w1l_raised<false, false, true, false>() && t4_w1l_raised<false, false, true, true>();
+    return ok;
 }
 static int t4_cu_count() {
-    static int n = 0;
-    if (!n) {
+    static const int n = []() {
         int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
-        if (n <= 0) n = 1;
-    }
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            return v;
+        return 1;
+    }();
     return n;
 }
 // the predicate BOTH the launcher and the caller's w2_direct decision use (they disagreed on devices with
@@ -1021,21 +1024,18 @@ bool tower4_takes_w1l(int64_t rows, int no_w1l) {
     const int64_t tiles = ((rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);
     return !no_w1l && tiles <= t4_cu_count();
 }
-void launch_tower4_train(const TowerArgs& a, hipStream_t s) {
+int launch_tower4_train(const TowerArgs& a, hipStream_t s) {
     const int tiles = ((a.rows + TILE_ROWS - 1) / TILE_ROWS) * (TILE_ROWS / T4_ROWS);   // cover rows_pad
     const dim3 grid(tiles);
     const bool dx = a.dxe != nullptr;
     const bool w1l = tower4_takes_w1l(a.rows, a.no_w1l);
     if (a.deepfm) {
-        if (dx) launch_tower4_inst<true, true, false>(a, grid, w1l, s);
-        else launch_tower4_inst<false, true, false>(a, grid, w1l, s);
-    } else if (dx) {
-        launch_tower4_inst<true, false, false>(a, grid, w1l, s);
-    } else if (a.xpre) {
-        launch_tower4_inst<false, false, true>(a, grid, w1l, s);
-    } else {
-        launch_tower4_inst<false, false, false>(a, grid, w1l, s);
+        if (dx) return launch_tower4_inst<true, true, false>(a, grid, w1l, s);
+        return launch_tower4_inst<false, true, false>(a, grid, w1l, s);
     }
+    if (dx) return launch_tower4_inst<true, false, false>(a, grid, w1l, s);
+    if (a.xpre) return launch_tower4_inst<false, false, true>(a, grid, w1l, s);
+    return launch_tower4_inst<false, false, false>(a, grid, w1l, s);
 }
 
 // W1T / W2T from the live weights (start of every mamdr_train_steps call; k_update keeps them current)

@@ -371,7 +371,10 @@ class TowerEngine(FlatVectorOps):
 
     def tower_tile(self, batch=None):
         """rows per tower workgroup of a training step of `batch` rows (4: k_tower4, 16: k_tower)."""
-        return int(self.lib.mamdr_tower_tile(self.ctx, int(batch or self.batch_size)))
+        rows = int(self.lib.mamdr_tower_tile(self.ctx, int(batch or self.batch_size)))
+        if rows < 0:                    # (an error code is not a tile size: ADVICE r05)
+            L.check(rows)
+        return rows
 
     # ------------------------------------------------------------ binding
     def bind_table(self, name, rows):
@@ -494,6 +497,11 @@ class TowerEngine(FlatVectorOps):
         self._ema = {"momentum": float(momentum), "step": 0, "biased": self.new_vector(), "scratch": self.new_vector()}
         if self._acc is not None:
             self.bind_accumulator(self._acc)
+
+    def set_counters(self, optimizer_steps, dropout_steps):
+        """restore the Adam step count (with TF's running beta powers) and the dropout stream's position
+        (mamdr_set_counters): a run resumed from saved weights / slots written into the bound vectors."""
+        L.check(self.lib.mamdr_set_counters(self.ctx, int(optimizer_steps), int(dropout_steps)))
 
     def optimizer_reset(self):
         L.check(self.lib.mamdr_optimizer_reset(self.ctx))

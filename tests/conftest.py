@@ -59,8 +59,21 @@ def pytest_collection_finish(session):
     oracle_jobs.start(keys)
 
 
+def pytest_sessionstart(session):
+    """the teacher-forced tests' per-pass oracle states (tests/oracle_jobs.PassDump, up to ~1 GB for a Taobao-30 epoch) live
+    in one directory per session, removed when the session ends whatever the tests did."""
+    import tempfile
+    if "MAMDR_TEST_DUMP_ROOT" not in os.environ:
+        os.environ["MAMDR_TEST_DUMP_ROOT"] = session.config._mamdr_dump_root = tempfile.mkdtemp(prefix="mamdr_tf_session_")
+
+
 def pytest_sessionfinish(session, exitstatus):
     oracle_pool.shutdown()
+    root = getattr(session.config, "_mamdr_dump_root", None)
+    if root:
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
+        os.environ.pop("MAMDR_TEST_DUMP_ROOT", None)
 
 
 @pytest.fixture(scope="session")

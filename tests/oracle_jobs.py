@@ -51,7 +51,71 @@ def perturbed(a, prs, rel):
     return (a * (F32(1) + F32(rel) * prs.standard_normal(a.shape).astype(F32))).astype(F32)
 
 
-def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0):
+def dump_root():
+    """where the per-pass states of the teacher-forced tests are written: one directory per pytest session (conftest sets
+    MAMDR_TEST_DUMP_ROOT and removes it when the session ends); the system's temporary directory otherwise."""
+    import tempfile
+    root = os.environ.get("MAMDR_TEST_DUMP_ROOT") or tempfile.gettempdir()
+    os.makedirs(root, exist_ok=True)
+    return root
+
+
+class PassDump(object):
+    """The oracle model behind a recorder (teacher-forced epochs).  Every `train_pass` of the loop is
+    written out with the state it STARTED from -- weights, Adam m / v, Adam step count, position of the dropout stream --
+    its per-step losses and the weights it ended with, as one record of a raw float32 file:
+        record k = [w_start | m_start | v_start | w_end]   (4 P floats; P = the model's flat length, oracle order)
+    and behind the last record [m_end | v_end] of the last pass (m / v at the end of pass k = m / v at the start of pass k + 1:
+    nothing touches the slots between passes -- SURVEY A.5).  tests/test_gpu_teacher.py starts the HIP engine from every
+    record and compares the pass it then runs: no chaos term, every pass of the epoch, every ragged last batch."""
+
+    def __init__(self, model, tag):
+        import tempfile
+        self.model = model
+        self.dir = tempfile.mkdtemp(prefix="mamdr_tf_%s_" % tag, dir=dump_root())
+        self.path = os.path.join(self.dir, "passes.f32")
+        self.f = open(self.path, "wb")
+        self.meta = []          # per pass: (adam t at the start, dropout step at the start, n_steps)
+        self.losses = []        # per pass: float32 array of the steps' total losses
+        self.P = None
+
+    def state(self):
+        from oracle import tower as otower
+        m = self.model
+        return (m.get_flat(), otower.flatten(m.opt.m, m.names), otower.flatten(m.opt.v, m.names))
+
+    def __getattr__(self, name):           # get_flat / set_flat / evaluate / params / ...: the model's own
+        return getattr(self.model, name)
+
+    def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
+        w, m, v = self.state()
+        self.P = w.size
+        t0, s0 = int(self.model.opt.t), int(self.model.step)
+        for a in (w, m, v):
+            self.f.write(np.ascontiguousarray(a, F32).tobytes())
+        losses = self.model.train_pass(data, perm, batch_size, max_steps, accumulate_into)
+        self.f.write(np.ascontiguousarray(self.model.get_flat(), F32).tobytes())
+        self.meta.append((t0, s0, len(losses)))
+        self.losses.append(np.array([np.nan if l is None else l for l in losses], F32))
+        return losses
+
+    def close(self):
+        _, m, v = self.state()
+        for a in (m, v):
+            self.f.write(np.ascontiguousarray(a, F32).tobytes())
+        self.f.close()
+        return dict(dir=self.dir, path=self.path, P=int(self.P), meta=self.meta, losses=self.losses)
+
+
+def read_dump(dump):
+    """-> (records [n_pass][4][P] (w_start, m_start, v_start, w_end), tail [2][P] (m, v after the last pass)) as memmaps."""
+    n, P = len(dump["meta"]), dump["P"]
+    raw = np.memmap(dump["path"], dtype=F32, mode="r")
+    assert raw.size == (4 * n + 2) * P, (raw.size, n, P)
+    return raw[:4 * n * P].reshape(n, 4, P), raw[4 * n * P:].reshape(2, P)
+
+
+def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0, dump=False):
     """oracle/loops.mamdr_epoch (model_zoo/mamdr.py:41-108) x epochs, then every domain's validation AUC with the merged
     weights theta + phi_d (specific_base_model.py:64-97).  The per-pass shuffles are plan.PassShuffler's stream -- the
     one plan.EpochShuffles hands the HIP side.  perturb > 0: the SECOND oracle run of the self-divergence instrument --
@@ -72,17 +136,21 @@ def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0):
         theta = perturbed(theta, prs, perturb)
         phis = [perturbed(p, prs, perturb) for p in phis]
     shuf = mplan.PassShuffler(pb["sizes"], 10000, SHUFFLE_SEED)
+    rec = PassDump(model, "%s_bs%d" % (shape, batch)) if dump else None
     t0 = time.time()
     trace = []
     for plan in pb["plans"]:
-        trace += oloops.mamdr_epoch(model, theta, phis, g["data"]["train"], plan, shuf, batch, meta_lr)
+        trace += oloops.mamdr_epoch(rec or model, theta, phis, g["data"]["train"], plan, shuf, batch, meta_lr)
     secs = time.time() - t0
     aucs = []
     for d in range(pb["D"]):
         model.set_flat(oouter.merge(theta, phis[d], "plus"))
         _, preds = model.evaluate(g["data"]["val"][d], batch)
         aucs.append(float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch)))
-    return dict(trace=trace, aucs=aucs, secs=secs, theta=theta)
+    out = dict(trace=trace, aucs=aucs, secs=secs, theta=theta)
+    if rec is not None:
+        out["dump"] = rec.close()
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- configs[2]: DeepFM + DN

@@ -36,6 +36,45 @@ def test_library_exports_every_declared_symbol():
         _lib.check(_lib.ENOTBUILT)
 
 
+def test_environment_switch_registry_is_complete():
+    """ONE table of environment switches (csrc/env_registry.h, mamdr_env_switches): every MAMDR_* name that any source file
+    reads from the environment is listed, a name nobody reads is reported (mamdr_env_unknown), and the library never
+    aborts the process (VERDICT r05 weak #11)."""
+    from mamdr_amd import _lib
+    table = _lib.env_switches()
+    names = [t[0] for t in table]
+    assert len(names) == len(set(names)) and all(len(t) == 3 and t[2] for t in table)
+    exact = {n for n in names if not n.endswith("*")}
+    prefixes = tuple(n[:-1] for n in names if n.endswith("*"))
+    read = set()
+    pats = (r'getenv\(\s*"(MAMDR_[A-Z0-9_]+)"', r'environ(?:\.get|\.setdefault)?[\(\[]\s*"(MAMDR_[A-Z0-9_]+)"',
+            r'\$\{?(MAMDR_[A-Z0-9_]+)')
+    for top in ("mamdr_amd", "tools", "tests", "bench.py", "run.py", "__graft_entry__.py"):
+        path = os.path.join(ROOT, top)
+        files = [path] if os.path.isfile(path) else [os.path.join(b, f) for b, _, fs in os.walk(path) for f in fs
+                                                      if f.endswith((".py", ".hip", ".h", ".sh"))]
+        for f in files:
+            if os.path.basename(f) == "test_abi_and_parallel.py":
+                continue
+            src = open(f, errors="replace").read()
+            for pat in pats:
+                read.update(re.findall(pat, src))
+    read = {n for n in read if not n.endswith("_")} | {"MAMDR_NFM_ENGINE"}     # ("MAMDR_%s_ENGINE" % tower: pnn, nfm)
+    missing = sorted(n for n in read if n not in exact and not n.startswith(prefixes))
+    assert not missing, "environment switches read but not in csrc/env_registry.h: %s" % missing
+    # an unknown name is counted (and reported on stderr) by a fresh process; a known one and a prefixed one are not
+    code = "from mamdr_amd import _lib; print('unknown', _lib.load().mamdr_env_unknown())"
+    env = dict(os.environ, MAMDR_NO_SUCH_SWITCH="1", MAMDR_TOWER_TILE="0", MAMDR_BENCH_SKIP_AMAZON6="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "unknown 1" in out.stdout and "MAMDR_NO_SUCH_SWITCH" in out.stderr and "MAMDR_TOWER_TILE" not in out.stderr
+    # no abort() / exit() in the library, no unsynchronised one-time flags (function-local statics carry initialisers)
+    for f in os.listdir(os.path.join(ROOT, "mamdr_amd", "csrc")):
+        src = re.sub(r"//.*", "", open(os.path.join(ROOT, "mamdr_amd", "csrc", f)).read())
+        assert not re.search(r"\babort\s*\(|\bexit\s*\(", src), f
+        assert not re.search(r"^\s+static\s+(int|bool)\s+\w+\s*=\s*(0|-1|false)\s*;", src, flags=re.M), f
+
+
 def test_product_path_does_not_import_oracle():
     """the oracle is test infrastructure: nothing under mamdr_amd/ or tools/, nor run.py, may import it;
     bench.py only inside its cpu_baseline leg, __graft_entry__ only inside smoke()."""

@@ -25,7 +25,7 @@ from oracle import tower as otower      # noqa: E402
 F32 = np.float32
 
 
-def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3):
+def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3, dump=False):
     """HIP side on the host path bench.py times (bench.py:439-482): plan.EpochShuffles (every permutation of an epoch from
     one C call, one upload, the NEXT epoch's drawn on the prefetch thread) + parallel.BalancedMAMDR(world 1).epoch, hence
     meta.PassWindow with `peek` -> mamdr_pregather_passes -> k_pass_prep_multi on the fused path.  The oracle (worker
@@ -73,7 +73,8 @@ def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3):
         assert launches < len(trace_g) // 4
     else:              # (the slab path gathers inside the tower: the hint is a no-op there)
         assert hits == 0 and launches == 0
-    ora = oracle_jobs.result("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=0.0)
+    ora = oracle_jobs.result("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=0.0,
+                             **({"dump": True} if dump else {}))
     # the instrument of the Keras-init Star case, for every full-size case: a second oracle run from initial tensors that
     # differ at rounding level -- its distance from the first is what ANY two fp32 evaluations of this training differ by
     orb = oracle_jobs.result("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=PERTURB)
@@ -118,11 +119,14 @@ def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3):
 PERTURB = 2e-7
 
 
-def _job(shape, batch, meta_lr, epochs):
+def _job(shape, batch, meta_lr, epochs, dump=False):
+    """dump: the unperturbed oracle run also writes its per-pass states -- the SAME run serves the teacher-forced epoch of
+    tests/test_gpu_teacher.py (one oracle epoch, two tests)."""
     def deco(fn):
         for pt in (0.0, PERTURB):
+            kw = {"dump": True} if (dump and pt == 0.0) else {}
             fn = pytest.mark.oracle_job("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs,
-                                        perturb=pt)(fn)
+                                        perturb=pt, **kw)(fn)
         return fn
     return deco
 
@@ -134,18 +138,18 @@ def test_taobao10_bs1024_two_epochs_config_meta_lr():
     run_case("taobao10", 1024, meta_lr=0.1, epochs=2)
 
 
-@_job("taobao10", 1024, 0.5, 1)
+@_job("taobao10", 1024, 0.5, 1, dump=True)
 def test_taobao10_bs1024_full_epoch_auc_parity():
     """the same workload with meta lr 0.5, so that ONE epoch already gives a trained model (oracle AUC 0.76-0.82:
     predictions spread over the 500 thresholds) -- the setting of the miniature test in tests/test_gpu_parity.py."""
-    run_case("taobao10", 1024, meta_lr=0.5)
+    run_case("taobao10", 1024, meta_lr=0.5, dump=True)
 
 
-@_job("taobao30", 4096, 0.5, 1)
+@_job("taobao30", 4096, 0.5, 1, dump=True)
 def test_taobao30_bs4096_full_epoch_auc_parity():
     """BASELINE.json configs[3] / north_star target: 30 domains, 394,805 train rows, bs 4096 (slab path), 1,501
     inner steps; meta lr 0.5 as above (at the config's 0.1 one epoch leaves the oracle at AUC ~0.57)."""
-    run_case("taobao30", 4096, meta_lr=0.5)
+    run_case("taobao30", 4096, meta_lr=0.5, dump=True)
 
 
 @_job("taobao30", 4096, 0.1, 2)
