@@ -365,11 +365,12 @@ def pipeline_config(cfg_file, name, tmp, train=None, dataset=None, model=None):
     return cfg
 
 
-def run_pipeline(cfg, engine_factory=None, perturb=0.0):
+def run_pipeline(cfg, engine_factory=None, perturb=0.0, pseed=99):
     """mamdr_amd.cli.main (= the reference's run.py:71-89: train -> val / early stop -> best state -> test -> finetune ->
     save_result) with a Recorder attached.  -> the Recorder's summary + result.json as written.
     perturb > 0: the built model's initial weights (what theta starts from) are changed at rounding level before
-    training starts -- the second run of the self-divergence instrument."""
+    training starts -- a run of the self-divergence instrument; `pseed` draws the perturbation (the K twins of an ensemble
+    differ in it)."""
     import json
     from mamdr_amd import cli
     from mamdr_amd import parallel
@@ -384,7 +385,7 @@ def run_pipeline(cfg, engine_factory=None, perturb=0.0):
             import torch
             eng = model.model
             w = eng.get_weights().clone()
-            noise = np.random.RandomState(99).standard_normal(w.numel()).astype(F32)
+            noise = np.random.RandomState(pseed).standard_normal(w.numel()).astype(F32)
             eng.set_weights(w * (1 + perturb * torch.from_numpy(noise).to(w.device)))
     out = cli.main(cfg, engine_factory, on_model=on_model)
     s = recs[0].summary(out)
@@ -397,7 +398,7 @@ def run_pipeline(cfg, engine_factory=None, perturb=0.0):
     return s
 
 
-def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0, model=()):
+def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0, model=(), pseed=99):
     """the oracle twin of a whole run: the SAME host code (cli.main, model_zoo/*, meta.py) on tests/fake_engine.FakeEngine,
     i.e. every numeric call answered by the numpy oracle.  train / dataset: tuples of (key, value) overrides."""
     import contextlib
@@ -409,7 +410,7 @@ def job_pipeline(cfg_file, model_name, train, dataset, perturb=0.0, model=()):
     buf = io.StringIO()
     t0 = time.time()
     with contextlib.redirect_stdout(buf):
-        s = run_pipeline(cfg, FakeEngine, perturb)
+        s = run_pipeline(cfg, FakeEngine, perturb, pseed)
     s["secs"] = time.time() - t0
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)

@@ -75,10 +75,9 @@ class HipSide(object):
         """variant 0: the bench's path -- the pass announced by mamdr_pregather_passes (k_pass_prep_multi), no loss output;
         variant 1: no hint (k_pass_prep inside the call), per-step losses written."""
         torch, eng = self.torch, self.eng
-        key = (d, perm.ctypes.data, perm.shape[0])
-        if key not in self.perms:
-            self.perms = {key: torch.from_numpy(perm).to(eng.device)}
-        pd = self.perms[key]
+        if self.perms.get("host") is not perm:          # (the host array is kept alive with its device copy)
+            self.perms = {"host": perm, "dev": torch.from_numpy(perm).to(eng.device)}
+        pd = self.perms["dev"]
         n_steps = -(-perm.shape[0] // batch)
         if variant == 0:
             eng.pregather([(d, pd)], batch)
@@ -111,14 +110,23 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def run_teacher_forced(side, dump, trace, perm_fn, batch, lr, bars, variants=(0, 1), report=None, exact=False):
+def run_teacher_forced(side, dump, trace, perm_fn, batch, lr, bars, variants=(0, 1), report=None, exact=False, segments=None):
     """every pass of `trace` ((phase, domain, n_steps) tuples, the oracle's) on `side` from the dumped start state.
-    bars: dict(loss_first, loss_rel, frac, max_klr, med_klr, mv_rel) -- see tests/test_gpu_teacher.py.  -> summary dict."""
+    bars: dict(loss_first, loss_rel, frac, max_klr, med_klr, m_rel, v_rel) -- see tests/test_gpu_teacher.py.  Violations are
+    collected over the WHOLE epoch and raised together (a GPU run is too dear to stop at the first one); `segments`
+    ([(name, offset, count)] in the oracle's flat order) adds a per-tensor breakdown to a violation's record.
+    -> summary dict."""
     import oracle_jobs
     recs, tail = oracle_jobs.read_dump(dump)
     assert len(trace) == len(dump["meta"]) == recs.shape[0]
     worst = dict(loss_first=0.0, loss_rel=0.0, frac=0.0, max_klr=0.0, med_klr=0.0, m_rel=0.0, v_rel=0.0)
-    n_steps_total, ragged = 0, 0
+    n_steps_total, ragged, bad = 0, 0, []
+
+    def breakdown(got, want):
+        if not segments:
+            return ""
+        rows = [(rel_l2(got[o:o + c], want[o:o + c]), n) for n, o, c in segments]
+        return " ".join("%s %.1e" % (n, r) for r, n in sorted(rows, reverse=True)[:4])
     for k, ((phase, d, n_tr), (t0, s0, n_st)) in enumerate(zip(trace, dump["meta"])):
         assert n_tr == n_st
         perm = perm_fn(d)
@@ -138,8 +146,10 @@ def run_teacher_forced(side, dump, trace, perm_fn, batch, lr, bars, variants=(0,
                 rel = np.abs(losses - lo) / np.maximum(np.abs(lo), 1e-6)
                 worst["loss_first"] = max(worst["loss_first"], float(rel[0]))
                 worst["loss_rel"] = max(worst["loss_rel"], float(rel.max()))
-                assert rel[0] <= bars["loss_first"], ("first step's loss (identical weights)", k, phase, d, losses[0], lo[0])
-                assert rel.max() <= bars["loss_rel"], ("loss", k, phase, d, int(rel.argmax()), losses, lo)
+                if rel[0] > bars["loss_first"]:
+                    bad.append(("first step's loss (identical weights)", k, phase, d, float(losses[0]), float(lo[0])))
+                if rel.max() > bars["loss_rel"]:
+                    bad.append(("loss", k, phase, d, int(rel.argmax()), float(rel.max())))
         for e in ends[1:]:          # the two launch paths of a pass give the same bits
             for a, b in zip(ends[0], e):
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), ("variants differ", k, phase, d)
@@ -151,9 +161,117 @@ def run_teacher_forced(side, dump, trace, perm_fn, batch, lr, bars, variants=(0,
         mr, vr = rel_l2(mg, m1), rel_l2(vg, v1)
         for key, val in (("frac", frac), ("max_klr", mx), ("med_klr", med), ("m_rel", mr), ("v_rel", vr)):
             worst[key] = max(worst[key], val)
-        assert frac <= bars["frac"] and mx <= bars["max_klr"] and med <= bars["med_klr"], ("end weights", k, phase, d, n_st, frac, mx, med)
-        assert mr <= bars["mv_rel"] and vr <= bars["mv_rel"], ("Adam slots", k, phase, d, mr, vr)
+        if not (frac <= bars["frac"] and mx <= bars["max_klr"] and med <= bars["med_klr"]):
+            bad.append(("end weights", k, phase, d, n_st, perm.shape[0], frac, mx, med, breakdown(wg, w1)))
+        if not (mr <= bars["m_rel"] and vr <= bars["v_rel"]):
+            bad.append(("Adam slots", k, phase, d, n_st, perm.shape[0], mr, vr, "m: " + breakdown(mg, m1), "v: " + breakdown(vg, v1)))
         n_steps_total += n_st
         if report is not None:
             report(k, phase, d, n_st, frac, mx, med, mr, vr)
-    return dict(worst, passes=len(trace), steps=n_steps_total, ragged_passes=int(ragged))
+    out = dict(worst, passes=len(trace), steps=n_steps_total, ragged_passes=int(ragged), violations=bad)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- trainable FULL-size tables
+class LockStep(object):
+    """Teacher forcing without a dump: the oracle model runs INSIDE the test process and every `train_pass` of the loop is
+    mirrored on the HIP engine from the oracle's state at that moment (configs[2] / configs[4]: the state is 1 - 1.1 GB per
+    pass with the trainable tables' Adam slots -- uploaded, not stored).  Per pass:
+        oracle state (every tensor, Adam m / v, counters, Star: PartitionedNorm's moving statistics) -> HIP engine
+        HIP pass queued (per-step losses into a device buffer)  ||  oracle pass on the CPU
+        oracle end state -> device, compared tensor by tensor with the HIP engine's (mamdr_sync_tables first: lagging rows
+        of the lazy table Adam are replayed, which is part of what is being checked).
+    `inner`: the object the loop calls (the model, or its meta view for Star); `model`: the oracle model itself."""
+
+    def __init__(self, inner, model, eng, data, lr, bars, aux_of=None):
+        import torch
+        self.torch = torch
+        self.inner, self.model, self.eng, self.lr, self.bars, self.aux_of = inner, model, eng, lr, bars, aux_of
+        self.dom_of = {id(cols): d for d, cols in data.items()}
+        self.rows, self.bad = [], []
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def _dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, F32).ravel()).to(self.eng.device)
+
+    def _load(self):
+        eng, m = self.eng, self.model
+        eng.sync()
+        for n in m.names:
+            off, cnt = eng.segments[n]
+            assert cnt == m.params[n].size, (n, cnt, m.params[n].size)
+            eng._weights[off:off + cnt].copy_(self._dev(m.params[n]))
+            eng._adam_m[off:off + cnt].copy_(self._dev(m.opt.m[n]))
+            eng._adam_v[off:off + cnt].copy_(self._dev(m.opt.v[n]))
+        if self.aux_of is not None:
+            eng.aux.copy_(self._dev(self.aux_of(m)))
+        eng.set_counters(int(m.opt.t), int(m.step))
+
+    def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
+        assert accumulate_into is None
+        torch, eng, m = self.torch, self.eng, self.model
+        d = self.dom_of[id(data)]
+        n_steps = -(-perm.shape[0] // batch_size)
+        if max_steps > 0:
+            n_steps = min(n_steps, max_steps)
+        t0, s0 = int(m.opt.t), int(m.step)
+        perm_d = torch.from_numpy(perm).to(eng.device)
+        # launch path A -- what a training run executes: no loss output, i.e. with trainable tables the LAZY table Adam (a
+        # non-null loss buffer makes every step synchronise the tables first: include/mamdr_hip.h)
+        self._load()
+        eng.train_steps(d, perm_d, n_steps=n_steps, batch_size=batch_size)
+        eng.sync()
+        snap = [x.clone() for x in (eng._weights, eng._adam_m, eng._adam_v)] + ([eng.aux.clone()] if eng.aux is not None else [])
+        # launch path B -- the same pass again from the same state with the per-step losses written: same bits at the end
+        self._load()
+        loss_g = torch.zeros(n_steps, dtype=torch.float32, device=eng.device)
+        eng.train_steps(d, perm_d, n_steps=n_steps, batch_size=batch_size, loss_out=loss_g)
+        eng.sync()
+        live = [eng._weights, eng._adam_m, eng._adam_v] + ([eng.aux] if eng.aux is not None else [])
+        for a, b in zip(snap, live):
+            if not torch.equal(a.view(torch.int32), b.view(torch.int32)):
+                self.bad.append(("launch paths differ", len(self.rows), d, n_steps, int((a.view(torch.int32) != b.view(torch.int32)).sum())))
+        del snap
+        losses = self.inner.train_pass(data, perm, batch_size, max_steps)          # the oracle's pass
+        assert len(losses) == n_steps
+        lib = eng.lib
+        assert (int(lib.mamdr_optimizer_steps(eng.ctx)), int(lib.mamdr_dropout_steps(eng.ctx))) == (t0 + n_steps, s0 + n_steps) == \
+            (int(m.opt.t), int(m.step))
+        lg, lo = loss_g.cpu().numpy(), np.array(losses, F32)
+        rel = np.abs(lg - lo) / np.maximum(np.abs(lo), 1e-6)
+        k = len(self.rows)
+        if rel[0] > self.bars["loss_first"] or rel.max() > self.bars["loss_rel"]:
+            self.bad.append(("loss", k, d, n_steps, float(rel[0]), float(rel.max())))
+        eng.sync()
+        klr = n_steps * self.lr
+        worst = dict(frac=0.0, max_klr=0.0, med_klr=0.0, m_rel=0.0, v_rel=0.0)
+        for n in m.names:
+            off, cnt = eng.segments[n]
+            diff = (eng._weights[off:off + cnt] - self._dev(m.params[n])).abs_()
+            frac, mx = float((diff > 0.05 * klr).float().mean()), float(diff.max()) / klr
+            med = float(diff.median()) / klr
+            rels = []
+            for got, want in ((eng._adam_m, m.opt.m[n]), (eng._adam_v, m.opt.v[n])):
+                w = self._dev(want)
+                rels.append(float((got[off:off + cnt] - w).double().norm() / max(float(w.double().norm()), 1e-30)))
+            del diff
+            if not (frac <= self.bars["frac"] and mx <= self.bars["max_klr"] and med <= self.bars["med_klr"]):
+                self.bad.append(("end weights", k, d, n_steps, n, frac, mx, med))
+            if not (rels[0] <= self.bars["m_rel"] and rels[1] <= self.bars["v_rel"]):
+                self.bad.append(("Adam slots", k, d, n_steps, n, rels[0], rels[1]))
+            for key, val in (("frac", frac), ("max_klr", mx), ("med_klr", med), ("m_rel", rels[0]), ("v_rel", rels[1])):
+                worst[key] = max(worst[key], val)
+        if self.aux_of is not None:
+            a_o = self._dev(self.aux_of(m))
+            worst["aux_rel"] = float((eng.aux - a_o).double().norm() / max(float(a_o.double().norm()), 1e-30))
+            if worst["aux_rel"] > self.bars.get("aux_rel", 1e-4):
+                self.bad.append(("moving statistics", k, d, n_steps, worst["aux_rel"]))
+        self.rows.append(dict(worst, k=k, d=d, n=n_steps, rows=int(perm.shape[0]), loss_first=float(rel[0]), loss_rel=float(rel.max())))
+        return losses
+
+    def summary(self):
+        keys = ("loss_first", "loss_rel", "frac", "max_klr", "med_klr", "m_rel", "v_rel") + (("aux_rel",) if self.aux_of else ())
+        return dict({key: max(r[key] for r in self.rows) for key in keys}, passes=len(self.rows),
+                    steps=sum(r["n"] for r in self.rows), ragged_passes=sum(1 for r in self.rows if r["rows"] % self.eng.batch_size))

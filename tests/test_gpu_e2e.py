@@ -48,7 +48,9 @@ CASES = {
     # the reference's own CPU-runnable case -- full rows, early stopping on the average val AUC (base_model.py:202-224)
     "taobao10_mlp_joint_train": dict(
         cfg_file="Taobao-10/deepctr_DN+DR.json", name="mlp", train=(("epoch", 6), ("patience", 2)), dataset=(), min_auc=0.7,
-        want_early_stop=False),
+        # (the least damped loop: one model, no meta interpolation -- per-domain AUC 1.7e-3 from the oracle in round 5 next to
+        # 9.6e-4 for ONE perturbed twin)
+        want_early_stop=False, ensemble=True),
     # train.lanes = 2 (round 5; not a key of the reference's configs): the same pipeline as the 2-RANK sharded run of
     # SURVEY 8e -- DN sub-sequences + one sum of displacements, DR by query owner, owners evaluate / finetune -- with the
     # ranks as two lanes of one process, two engines on two HIP streams whose kernels overlap (parallel.LaneGroup).  The
@@ -87,18 +89,18 @@ CASES = {
         min_auc=0.7, want_early_stop=False),
     "taobao10_star_joint_as_configured": dict(
         cfg_file="Taobao-10/star_taobao.json", name=None, train=(("epoch", 4),), dataset=(), min_auc=0.6,
-        want_early_stop=False, beyond_share=0.25),
+        want_early_stop=False, ensemble=True),
     # ... and the multi-task comparison baselines' config files (deep_mtl_ctr.py:21-96 on the generic-layer engine; the oracle
     # twin on tests/fake_engine.FakeGraphEngine = oracle/mtl.py), as configured with `epoch` capped
     "taobao10_shared_bottom_as_configured": dict(
         cfg_file="Taobao-10/shared_bottom.json", name=None, train=(("epoch", 3),), dataset=(), min_auc=0.6,
-        want_early_stop=False, beyond_share=0.25),
+        want_early_stop=False, ensemble=True),
     "taobao10_mmoe_as_configured": dict(
         cfg_file="Taobao-10/mmoe.json", name=None, train=(("epoch", 3),), dataset=(), min_auc=0.6,
-        want_early_stop=False, beyond_share=0.25),
+        want_early_stop=False, ensemble=True),
     "taobao10_ple_as_configured": dict(
         cfg_file="Taobao-10/ple.json", name=None, train=(("epoch", 2),), dataset=(), min_auc=0.55,
-        want_early_stop=False, beyond_share=0.25),
+        want_early_stop=False, ensemble=True),
     # Star's OTHER form (star.py:74-87 with `norm: "none"`, `dense: "dense"`: no PartitionedNorm, plain Keras Dense layers, no
     # dropout, no regularisers, Keras initial values) under MAMDR with a name filter that takes the embeddings and the kernels
     # but not the biases (holes in the meta range): runs on the mlp step kernels; oracle twin = FakeEngine(tower "mlp")
@@ -107,7 +109,7 @@ CASES = {
         train=(("epoch", 4), ("meta_parms", ("emb", "kernel"))), dataset=(), min_auc=0.7, want_early_stop=False,
         # (no dropout, no regulariser, Keras initial values: the oracle differs from its own perturbed twin by up to 1.7e-3
         # per domain in the first epochs)
-        beyond_share=0.25),
+        ensemble=True),
     # BASELINE.json configs[4]'s name (star_meta_mamdr: PartitionedNorm + StarFCN, theta / phi over the name-filtered meta
     # parameters ["emb", "kernel_shared", "bias_shared"], maml.py:153-179) on the reference's Taobao-10 Star config
     # (config/Taobao-10/star_taobao.json: frozen pretrained tables), from the Keras initial values, full rows.  The oracle twin
@@ -117,7 +119,7 @@ CASES = {
     # after the FIRST epoch, the counter runs to patience 3 and the best state of epoch 0 is what the test score comes from.
     "taobao10_star_mamdr": dict(
         cfg_file="Taobao-10/star_taobao.json", name="star_meta_mamdr", train=(("epoch", 8),), dataset=(), min_auc=0.75,
-        want_early_stop=True, beyond_share=0.25),
+        want_early_stop=True, ensemble=True),
     # BASELINE.json configs[2]'s name and file (DeepFM + Domain Negotiation, trainable tables, no pretraining) on a row /
     # table sample of the Amazon-6 shape
     "amazon6_deepfm_dn": dict(
@@ -126,8 +128,8 @@ CASES = {
         # tables that start at N(0, 1e-4^2) under Adam: the first steps of a rarely seen row are +- lr whatever the
         # gradient's size, so rounding-level differences move single domains by ~1e-3 (the oracle against its own
         # perturbed twin: 6e-4 .. 1e-3 per domain, profiles/r05_e2e_variants.txt) -- up to a quarter of the comparisons may
-        # need the self-divergence term here (the frozen-table cases: none did)
-        beyond_share=0.25),
+        # need the ensemble's range here (the frozen-table cases: none did)
+        ensemble=True),
 }
 
 
@@ -156,10 +158,8 @@ def _finetune_margin(v):
 
 
 def _self_div(ev_o, ev_p, field=5):
-    """{(k-th evaluation, domain): s} with s = the LARGEST |AUC_oracle - AUC_oracle'| over the domains of that evaluation
-    (field 4: the per-domain losses).  One perturbed twin is one draw of the rounding noise per domain; the HIP side is
-    another draw, so the scale it is held to is the evaluation's, not the single domain's draw (the rule of the
-    chaos-aware bars of tests/test_gpu_fmnets.py)."""
+    """{(k-th evaluation, domain): s} with s = the LARGEST |x_oracle - x_oracle'| over the domains of that evaluation -- used for
+    the LOSS bars only (not north_star's metric); the AUC bars are the plain 1e-3 or the ensemble's range (`Ensemble`)."""
     out = {}
     for k, (a, b) in enumerate(zip(ev_o, ev_p)):
         s = max(abs(a[field][d] - b[field][d]) for d in a[field])
@@ -168,40 +168,98 @@ def _self_div(ev_o, ev_p, field=5):
     return out
 
 
-def compare(case, s_h, s_o, s_p):
-    """s_h: the HIP run, s_o: the oracle twin, s_p: the oracle twin from rounding-level perturbed initial weights (its
-    distance from s_o = what any two fp32 evaluations of this training differ by).  Bars on AUCs: north_star's 1e-3 plus
-    twice the oracle's own self-divergence at that evaluation (its largest over the domains); how many comparisons needed
-    that term is printed and bounded."""
+class Ensemble(object):
+    """K + 1 oracle runs of one case -- the unperturbed twin and K twins whose initial weights differ by one fp32 rounding
+    (relative 2e-7, K different draws): what ANY fp32 evaluation of this training is distributed like.
+    For every comparison c = (evaluation, domain) -- an epoch's validation, a test evaluation, the returned scores --
+        mean_c  = mean of the K + 1 members' AUC
+        loo_k,c = |member k - mean of the OTHER members|          (a member's distance from the ensemble without it)
+        hip_c   = |hip - mean_c|
+    and per run two statistics over all comparisons of the case: S = the MEAN distance (a systematic offset shows here) and
+    M = the LARGEST distance (a single outlying domain shows here).  The HIP run must not be an outlier of the ensemble in
+    either: S_hip <= mean_k S_k + 3 sd_k S_k and M_hip <= mean_k M_k + 3 sd_k M_k (sample sd over the K + 1 members).
+    (Any rank criterion -- "no further out than the furthest member" -- fails a run that IS a member with probability
+    1 / (K + 2) by symmetry, whatever K is affordable; tests/test_teacher_harness.py checks these bars on synthetic draws.)
+    Where north_star's plain |hip - oracle| <= 1e-3 holds nothing else is needed; the count of comparisons beyond it is
+    printed next to each twin's own count against the same oracle run.  No factor on a single draw, no allowed share of misses."""
+
+    def __init__(self, members):
+        self.members = members            # summaries: oracle first, then the twins
+        self.h_dist, self.m_dist = [], [[] for _ in members]
+        self.n_cmp = self.beyond = 0
+        self.m_beyond = [0] * (len(members) - 1)
+        self.worst = 0.0
+
+    def check(self, what, vals_h, vals_members):
+        """vals_h: {d: AUC} of the HIP run; vals_members: the same per member."""
+        K1 = len(vals_members)
+        doms = sorted(vals_members[0])
+        arr = np.array([[vm[d] for d in doms] for vm in vals_members], np.float64)          # [K + 1][D]
+        mean = arr.mean(axis=0)
+        loo = np.abs(arr - (arr.sum(axis=0, keepdims=True) - arr) / (K1 - 1))
+        for j, d in enumerate(doms):
+            diff = abs(vals_h[d] - vals_members[0][d])
+            self.h_dist.append(abs(vals_h[d] - mean[j]))
+            for k in range(K1):
+                self.m_dist[k].append(loo[k, j])
+            for k in range(1, K1):
+                self.m_beyond[k - 1] += int(abs(arr[k, j] - arr[0, j]) > 1e-3)
+            self.n_cmp += 1
+            self.worst = max(self.worst, diff)
+            self.beyond += int(diff > 1e-3)
+
+    def aggregate(self, case):
+        out = {}
+        for name, f in (("mean", np.mean), ("largest", np.max)):
+            s_h = float(f(self.h_dist))
+            s_k = np.array([float(f(m)) for m in self.m_dist])
+            out[name] = (s_h, s_k, float(s_k.mean() + 3 * s_k.std(ddof=1)))
+        print("  ensemble of %d oracle runs, %d comparisons: |hip - oracle| worst %.1e, %d beyond the plain 1e-3 (the twins against the "
+              "same oracle run: %s)" % (len(self.members), self.n_cmp, self.worst, self.beyond, self.m_beyond))
+        for name in ("mean", "largest"):
+            s_h, s_k, bar = out[name]
+            print("    %s distance from the ensemble mean: hip %.2e | members (leave-one-out) %s | bar mean + 3 sd = %.2e" % (
+                name, s_h, " ".join("%.2e" % v for v in s_k), bar))
+        for name in ("mean", "largest"):
+            s_h, s_k, bar = out[name]
+            assert s_h <= bar, ("the HIP run is an outlier of the oracle ensemble: %s distance" % name, case, s_h, list(s_k), bar)
+
+
+def compare(case, s_h, s_o, twins):
+    """s_h: the HIP run, s_o: the oracle twin, twins: oracle twins from rounding-level perturbed initial weights (one for the
+    cases that hold north_star's plain 1e-3 -- it scales the LOSS bars only --, K = 5 for the `ensemble` cases).
+    AUC bars: the plain 1e-3 per domain and evaluation; `ensemble` cases: not an outlier of the ensemble (`Ensemble`)."""
     c = CASES[case]
+    s_p = twins[0]
+    ens = Ensemble([s_o] + list(twins)) if c.get("ensemble") else None
     # --- meta-level: validation per epoch, early stopping, the test score from the best state
     val_h, val_o, val_p = _evals(s_h, "val"), _evals(s_o, "val"), _evals(s_p, "val")
+    val_m = [_evals(m, "val") for m in ([s_o] + list(twins))]
     es_h = [e for e in s_h["events"] if e[0] == "early_stop"]
     es_o = [e for e in s_o["events"] if e[0] == "early_stop"]
     k = min(len(val_h), len(val_o))
     assert k >= 2
-    sd_val = _self_div(val_o, val_p)
     sd_loss = _self_div(val_o, val_p, 4)
-    worst_val, worst_loss, worst_sd, beyond, n_cmp, delta = 0.0, 0.0, 0.0, 0, 0, 1e-7
+    worst_val, worst_loss, beyond, n_cmp, delta = 0.0, 0.0, 0, 0, 1e-7
     for e in range(k):
         _, _, loss_h, auc_h, dl_h, da_h = val_h[e]
         _, _, loss_o, auc_o, dl_o, da_o = val_o[e]
         assert sorted(da_h) == sorted(da_o)
+        if ens is not None and all(len(vm) > e for vm in val_m):
+            ens.check(("val AUC", case, e), da_h, [vm[e][5] for vm in val_m])
         for d in da_o:
-            sd = sd_val.get((e, d), 0.0)
             diff = abs(da_h[d] - da_o[d])
-            worst_val, worst_sd = max(worst_val, diff), max(worst_sd, sd)
+            worst_val = max(worst_val, diff)
             worst_loss = max(worst_loss, abs(dl_h[d] - dl_o[d]))
             beyond += diff > 1e-3
             n_cmp += 1
-            assert diff <= 1e-3 + 2 * sd, ("val AUC", case, e, d, da_h[d], da_o[d], sd)
+            if ens is None:
+                assert diff <= 1e-3, ("val AUC", case, e, d, da_h[d], da_o[d])        # north_star's plain bar
             # (the loss is not north_star's bar; held to 5e-3 relative + twice the oracle's own self-divergence of it)
             assert abs(dl_h[d] - dl_o[d]) <= 5e-3 * max(1.0, abs(dl_o[d])) + 2 * sd_loss.get((e, d), 0.0), \
                 ("val loss", case, e, d, dl_h[d], dl_o[d], sd_loss.get((e, d)))
         assert abs(es_h[e][1] - es_o[e][1]) <= 1e-3
         delta = max(delta, abs(es_h[e][1] - es_o[e][1]) + 1e-7)
-    share = c.get("beyond_share", 0.05)                          # the plain 1e-3 holds on >= 95 % of the comparisons
-    assert beyond <= max(1, int(n_cmp * share)), (beyond, n_cmp)
     # the oracle's own early-stopping comparisons (`metric <= best`: base_model.py:202-224): margin of each
     margins, best = [], None
     for e, ev in enumerate(es_o):
@@ -213,8 +271,8 @@ def compare(case, s_h, s_o, s_p):
     print("%s: %d / %d epochs (hip / oracle), early stop %s / %s, closest early-stop comparison %.1e vs delta %.1e%s" % (
         case, len(val_h), len(val_o), bool(es_h[-1][4]), stopped_o, min(margins) if margins else float("nan"), delta,
         "" if clear else " (a tie within 2 delta)"))
-    print("  val: worst per-domain |d AUC| %.1e (oracle vs its perturbed twin %.1e; %d of %d comparisons beyond the plain 1e-3), "
-          "|d loss| %.1e" % (worst_val, worst_sd, beyond, n_cmp, worst_loss))
+    print("  val: worst per-domain |d AUC| %.1e (%d of %d comparisons beyond the plain 1e-3), |d loss| %.1e" % (
+        worst_val, beyond, n_cmp, worst_loss))
     for e in range(k):                              # every decision the oracle made with a margin: identical
         if e == 0 or margins[e - 1] > 2 * delta:
             assert es_h[e][3:] == es_o[e][3:], ("early-stop decision", case, e, es_h[e], es_o[e])
@@ -230,31 +288,32 @@ def compare(case, s_h, s_o, s_p):
         best_o = int(np.argmax([e[1] for e in es_o]))
         assert best_h == best_o
         # val_and_test("test") after every non-stopping epoch + the one after training: all from the best state so far
-        t_h, t_o, t_p = _evals(s_h, "test"), _evals(s_o, "test"), _evals(s_p, "test")
+        t_h, t_o = _evals(s_h, "test"), _evals(s_o, "test")
+        t_m = [_evals(m, "test") for m in ([s_o] + list(twins))]
         assert len(t_h) == len(t_o)
-        sd_test = _self_div(t_o, t_p)
         worst_test, beyond_t = 0.0, 0
         for i, (a, b) in enumerate(zip(t_h, t_o)):
+            # (a twin whose best state comes from another epoch -- a tie of ITS early-stop comparisons -- is another draw of
+            # the pipeline's answer, which is what the ensemble is for; a twin that ran fewer evaluations drops out of this one)
+            if ens is not None and all(len(tm) > i for tm in t_m):
+                ens.check(("test AUC", case, i), a[5], [tm[i][5] for tm in t_m])
             for d in b[5]:
                 diff = abs(a[5][d] - b[5][d])
                 worst_test = max(worst_test, diff)
                 beyond_t += diff > 1e-3
-                # (the scale of the oracle's own divergence at this point of the training: this test evaluation's, or -- one
-                # perturbed twin is ONE draw -- that of the validation pass of the same epoch, run on the same weights while
-                # the metric still improves)
-                sd = max(sd_test.get((i, d), 0.0), sd_val.get((min(i, k - 1), d), 0.0))
-                assert diff <= 1e-3 + 2 * sd, ("test AUC", case, i, d, a[5][d], b[5][d], sd)
-        assert beyond_t <= max(1, int(len(t_o) * len(t_o[0][5]) * share))
+                if ens is None:
+                    assert diff <= 1e-3, ("test AUC", case, i, d, a[5][d], b[5][d])
         print("  best epoch %d on both sides; test from the best state: worst per-domain |d AUC| %.1e over %d evaluations "
-              "(%d beyond the plain 1e-3; oracle vs its twin up to %.1e)" % (
-                  best_o, worst_test, len(t_o), beyond_t, max(sd_test.values()) if sd_test else 0.0))
+              "(%d beyond the plain 1e-3)" % (best_o, worst_test, len(t_o), beyond_t))
     else:
         n = min(len(s_h["trace"]), len(s_o["trace"]))
         assert s_h["trace"][:n // 2] == s_o["trace"][:n // 2]
     # --- finetune stage (names with `finetune`): per domain, Keras EarlyStopping + best-only checkpoint.  The two sides
     # START it from weights whose val AUC already differs by the training's delta, far more than SGD at 0.001 moves it per
     # epoch; the decisions, though, depend on the trajectory RELATIVE to its first epoch (differences between epochs of
-    # one run), so that is what is compared: delta_ft = the largest difference of the relative trajectories
+    # one run), so that is what is compared: delta_ft = the largest difference of the relative trajectories.  (The stage's
+    # DECISIONS are compared from identical starting weights in tests/test_gpu_run.py -- inside the pipeline every domain is a
+    # tie within 2 delta_ft)
     fl_h, fl_o = s_h["finetune_log"], s_o["finetune_log"]
     assert sorted(fl_h) == sorted(fl_o)
     decided, worst_rel, sd_rel = 0, 0.0, 0.0
@@ -267,8 +326,7 @@ def compare(case, s_h, s_o, s_p):
             sd_rel = max(sd_rel, float(np.abs((vo_ - vo_[0]) - (vp_ - vp_[0])).max()))
         kk = min(o["epochs"], h["epochs"])
         vo, vh = np.array(o["val_auc"][:kk]), np.array(h["val_auc"][:kk])
-        assert np.abs(vo - vh).max() <= 1e-3 + 2 * max([v for (i, dd), v in sd_val.items() if dd == d] or [0.0]), \
-            ("finetune val AUC", case, d, o, h)
+        assert np.abs(vo - vh).max() <= 1e-3, ("finetune val AUC", case, d, o, h)
         d_ft = float(np.abs((vo - vo[0]) - (vh - vh[0])).max()) + 1e-7
         worst_rel = max(worst_rel, d_ft)
         if clear and _finetune_margin(o["val_auc"]) > 2 * d_ft:
@@ -280,13 +338,15 @@ def compare(case, s_h, s_o, s_p):
         assert worst_rel <= 2e-4 + 2 * sd_rel
     # --- what run.py returns and writes
     (loss_h, auc_h, dl_h, da_h), (loss_o, auc_o, dl_o, da_o) = s_h["result"], s_o["result"]
-    da_p = s_p["result"][3]
     worst = max(abs(da_h[d] - da_o[d]) for d in da_o)
-    print("  returned: avg test AUC hip %.5f oracle %.5f, worst per-domain |d| %.1e (oracle vs its twin %.1e); avg loss "
-          "%.5f / %.5f" % (auc_h, auc_o, worst, max(abs(da_p[d] - da_o[d]) for d in da_o), loss_h, loss_o))
-    sd_ret = max(abs(da_p[d] - da_o[d]) for d in da_o)
-    for d in da_o:
-        assert abs(da_h[d] - da_o[d]) <= 1e-3 + 2 * sd_ret, ("returned AUC", case, d, da_h[d], da_o[d], da_p[d])
+    print("  returned: avg test AUC hip %.5f oracle %.5f, worst per-domain |d| %.1e; avg loss %.5f / %.5f" % (
+        auc_h, auc_o, worst, loss_h, loss_o))
+    if ens is not None:
+        ens.check(("returned AUC", case), da_h, [m["result"][3] for m in ([s_o] + list(twins))])
+        ens.aggregate(case)
+    else:
+        for d in da_o:
+            assert abs(da_h[d] - da_o[d]) <= 1e-3, ("returned AUC", case, d, da_h[d], da_o[d])
     assert abs(auc_h - auc_o) <= 1e-3
     assert abs(loss_h - loss_o) <= 5e-3 * max(1.0, abs(loss_o)) + 2 * abs(s_p["result"][0] - loss_o)
     assert auc_o > c["min_auc"], auc_o                          # a model that has learnt
@@ -298,11 +358,17 @@ def compare(case, s_h, s_o, s_p):
 
 
 PERTURB = 2e-7
+TWIN_SEEDS = (99, 100, 101, 102, 103)          # K = 5 perturbed oracle twins of an `ensemble` case (the first one: every case)
+
+
+def _twin_seeds(case):
+    return TWIN_SEEDS if CASES[case].get("ensemble") else TWIN_SEEDS[:1]
 
 
 def _case_param(case):
-    return pytest.param(case, marks=[pytest.mark.oracle_job("pipeline", perturb=pt, **_job_kwargs(case))
-                                     for pt in (0.0, PERTURB)], id=case)
+    marks = [pytest.mark.oracle_job("pipeline", perturb=0.0, **_job_kwargs(case))]
+    marks += [pytest.mark.oracle_job("pipeline", perturb=PERTURB, pseed=ps, **_job_kwargs(case)) for ps in _twin_seeds(case)]
+    return pytest.param(case, marks=marks, id=case)
 
 
 @pytest.mark.parametrize("case", [_case_param(c) for c in CASES])
@@ -320,9 +386,11 @@ def test_run_pipeline_matches_oracle_twin(case):
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     s_o = oracle_jobs.result("pipeline", perturb=0.0, **kw)     # the oracle twin (worker process)
-    s_p = oracle_jobs.result("pipeline", perturb=PERTURB, **kw)     # ... and its rounding-level perturbed second run
-    print("%s: hip %.1f s, oracle twin %.1f s (waited %.1f s)" % (case, t_h, s_o["secs"], s_o.get("waited_seconds", 0.0)))
-    compare(case, s_h, s_o, s_p)
+    # ... and its rounding-level perturbed runs (one; K = 5 for the `ensemble` cases)
+    twins = [oracle_jobs.result("pipeline", perturb=PERTURB, pseed=ps, **kw) for ps in _twin_seeds(case)]
+    print("%s: hip %.1f s, oracle twin %.1f s (waited %.1f s), %d perturbed twin(s) %s s" % (
+        case, t_h, s_o["secs"], s_o.get("waited_seconds", 0.0), len(twins), " ".join("%.0f" % t["secs"] for t in twins)))
+    compare(case, s_h, s_o, twins)
     lanes = dict(kw["train"]).get("lanes", 1)
     assert sorted(s_h["lane_traces"]) == sorted(s_o["lane_traces"]) == list(range(lanes))
     if lanes > 1:
