@@ -65,7 +65,7 @@ WORKLOADS = {
 }
 TARGET_KEYS = ("workload", "value", "unit", "us_per_domain_step", "ms_per_step", "epochs_timed", "domain_steps_per_epoch",
                "roofline", "tower", "table_update", "kernels_avg_us", "cpu_baseline", "gpu_over_cpu",
-               "partition_speedup_bound", "host_ms_per_epoch", "host_prep_ms_per_epoch")
+               "partition_speedup_bound", "host_ms_per_epoch", "host_prep_ms_per_epoch", "gather_in_step")
 TRAIN = dict(learning_rate=1e-3, meta_learning_rate=0.1, sample_num=5, add_query_domain=True, dropout=0.5,
              merged_method="plus", shuffle_buffer_size=10000, seed=123)
 
@@ -322,6 +322,41 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def pmc_sq(kernel_key):
+    """SQ / TCP counters per launch of `kernel_key` from the committed rocprofv3 --pmc passes (tools/r06_measure.sh stage `sq`,
+    profiles/pmc_sq_latest.json), turned into the two figures DESIGN.md section 5 argues with: the share of the kernel's
+    cycles its MFMA pipes were busy, and the bytes its workgroups pulled from L2 into their L1s (TCP_TCC_READ_REQ x 128 B).
+    None if no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_sq_latest.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)[kernel_key]
+    except Exception:
+        return None
+    out = {"source": "profiles/pmc_sq_latest.json (separate rocprofv3 --pmc passes, counters per launch)"}
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("SQ_BUSY_CYCLES"):
+        # SQ_BUSY_CYCLES sums the shader engines' busy clocks (32 on this part); MFMA-busy sums over the 1,024 SIMDs
+        kernel_cycles = c["SQ_BUSY_CYCLES"] / 32.0
+        out.update({"mfma_busy_cycles_per_simd": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, "kernel_cycles": kernel_cycles,
+                    "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / max(kernel_cycles, 1.0)})
+    if c.get("TCP_TCC_READ_REQ"):
+        out.update({"tcp_tcc_read_req": c["TCP_TCC_READ_REQ"], "l2_to_l1_bytes": c["TCP_TCC_READ_REQ"] * 128.0,
+                    "l1_fill_cycles_per_cu_at_64B_clk": c["TCP_TCC_READ_REQ"] * 128.0 / 256.0 / 64.0})
+    if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES"):
+        out["wave_cycles_in_waitcnt_frac"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+    return out
+
+
+def stamped_gather(shape):
+    """the gather PHASE of a tower kernel as s_memtime stamps of a -DMAMDR_STAMPS build measured it (tools/r06_gather_in_step.py,
+    profiles/gather_in_step_latest.json): cycles from kernel start to `rows in LDS`, median over the workgroups."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gather_in_step_latest.json")) as f:
+            return json.load(f)[shape]
+    except Exception:
+        return None
+
+
 def rocprof_avg_us(kernel, shape):
     """average duration of `kernel` in the newest committed rocprofv3 summary of this workload
     (profiles/r*_kernel_stats_<shape>.csv), for comparison with the HIP-event average measured live;
@@ -565,7 +600,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
 
     # ---- per-kernel device time (HIP events on the launch stream) over one more epoch of
     #      the same workload; reported for the dominant kernel, k_tower<train>
-    roofline, kernels, sweep_info, table_info, l2_gather = None, {}, None, None, None
+    roofline, kernels, sweep_info, table_info, l2_gather, gather_in_step = None, {}, None, None, None, None
     if profile:
         eng.profile(True)
         eng.profile_reset()
@@ -712,6 +747,44 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
                 rated.append({"kernel": kn, "bound": "alu (quarter-rate v_sqrt_f32 + v_rcp_f32)", "achieved": ach, "peak": peak,
                               "unit": "T element-steps/s", "frac": ach / peak, "avg_us": k_us, "launches": k_n,
                               "element_steps_per_launch": el_steps})
+        # ---- the gather WHERE IT RUNS.  k_wgrad_adam path: k_pass_prep_multi resolves and gathers a window
+        # of <= 16 passes per launch -- per row it reads the permutation entry, uid / pid / domain / label (20 B), the two
+        # 512-B table rows, and writes them with the domain and label (1,032 B): 2,076 algorithmic bytes -- timed live by the
+        # HIP events above.  Everywhere else the gather is the first phase of the tower kernel: its duration comes from the
+        # stamps of a diagnostic build (profiles/gather_in_step_latest.json), the rows per launch from this run.
+        gather_in_step = None
+        aux_name = names.get(L.KERNEL_AUX, "")
+        if aux_name.startswith("k_pass_prep_multi") and aux_name in kernels:
+            k_us, k_n = kernels[aux_name]["avg_us"], kernels[aux_name]["launches"]
+            by = prof_rows / max(k_n, 1) * 2076.0
+            ach = by / (k_us * 1e-6) / 1e9
+            gather_in_step = {"kernel": "k_pass_prep_multi", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": ach / PEAK_HBM_GBS, "avg_us": k_us, "launches": k_n, "rows_per_launch": prof_rows / max(k_n, 1),
+                              "bytes_per_row": 2076, "traffic": pmc_traffic("k_pass_prep_multi"),
+                              "served_from": "tables of %.1f MB: L2 / infinity cache reads, HBM writes" % ((g["n_user"] + g["n_item"]) * 512 / 1e6),
+                              "share_of_step_us": kernels[aux_name]["us_per_domain_step"]}
+            rated.append(dict(gather_in_step))
+        else:
+            st = stamped_gather(wl["shape"])
+            if st and st.get("kernel") == roofline["kernel"]:
+                secs = st["gather_phase_cycles"] / (st["clock_ghz"] * 1e9)
+                by = rows_avg * GATHER_BYTES_PER_ROW
+                ach = by / secs / 1e9
+                gather_in_step = {"kernel": roofline["kernel"] + " (gather phase)", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "phase_us": secs * 1e6, "phase_cycles": st["gather_phase_cycles"],
+                                  "rows_per_launch": rows_avg, "bytes_per_row": GATHER_BYTES_PER_ROW,
+                                  "share_of_kernel": secs * 1e6 / max(roofline["avg_us"], 1e-9),
+                                  "source": "profiles/gather_in_step_latest.json (s_memtime stamps of a -DMAMDR_STAMPS build, median "
+                                            "over the workgroups: %s)" % st.get("note", ""),
+                                  "table_bytes": (g["n_user"] + g["n_item"]) * 512}
+        # counter-backed reading of the two headline kernels: MFMA-busy share and L2 -> L1 traffic
+        sq = pmc_sq(roofline["kernel"] + "@" + wl["shape"]) or pmc_sq(roofline["kernel"])
+        if sq:
+            roofline["counters"] = sq
+        for ent in rated:
+            sq = pmc_sq(ent["kernel"] + "@" + wl["shape"]) or pmc_sq(ent["kernel"])
+            if sq:
+                ent["counters"] = sq
         kernels["_rated"] = rated
         if not trainable:
             # the workload's own gather: pass-sized, the frozen Taobao tables live in L2 / infinity cache
@@ -743,7 +816,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
         "domain_passes_per_sec": local_passes / dt,
         "roofline": sweep_info if (sweep_info and sweep_info["avg_us"] * 2 > (roofline or {}).get("avg_us", 0)) else roofline,
         "tower": roofline, "table_update": table_info or sweep_info, "gather_l2": l2_gather,
-        "kernels_avg_us": kernels, "cpu_baseline": cpu,
+        "kernels_avg_us": kernels, "cpu_baseline": cpu, "gather_in_step": gather_in_step if profile else None,
         # host side of an epoch.  host_ms_per_epoch = wall time spent inside the epoch call before any synchronisation
         # (plan + LPT + shuffle generation / upload + every launch; [mean, max] over ranks when world > 1): an UPPER
         # bound -- the HIP queue blocks the host once it is a few hundred launches ahead, so at N = 1 this tracks the
@@ -809,6 +882,37 @@ def spawn_ranks(args):
         print(line)
     sys.stdout.flush()
     return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+def summary_block(result, targets, lanes_rec):
+    """compact per-workload digest: value, us per domain-step, the dominant kernel with its roofline fraction (and, where the
+    counters are committed, its MFMA-busy share), the in-step gather, the CPU baseline of the same run, lanes."""
+    def brief(rec, lanes=None):
+        if "error" in rec:
+            return {"error": rec["error"][:120]}
+        roof = rec.get("roofline") or {}
+        out = {"value": round(rec["value"], 1), "us_per_step": round(rec["us_per_domain_step"], 2),
+               "kernel": roof.get("kernel"), "bound": roof.get("bound"), "frac": round(roof.get("frac", 0.0), 4),
+               "kernel_us": round(roof.get("avg_us", 0.0), 2)}
+        if (roof.get("counters") or {}).get("mfma_busy_frac") is not None:
+            out["mfma_busy"] = round(roof["counters"]["mfma_busy_frac"], 3)
+        gi = rec.get("gather_in_step")
+        if gi:
+            out["gather_in_step"] = {"kernel": gi["kernel"].split("<")[0], "GBps": round(gi["achieved"], 1), "frac": round(gi["frac"], 3)}
+        cpu = rec.get("cpu_baseline")
+        if cpu:
+            out["cpu"] = {"value": round(cpu["value"], 2), "cores": cpu["cores"], "kind": cpu["kind"]}
+        lanes = lanes if lanes is not None else rec.get("lanes")
+        if lanes:
+            out["lanes"] = {"n": lanes.get("lanes"), "value": round(lanes["value"], 1)} if "value" in lanes else {"error": lanes.get("error", "")[:80]}
+        return out
+    out = {"taobao10": brief(dict(result, us_per_domain_step=result["us_per_domain_step"]), lanes_rec)}
+    for name, rec in targets.items():
+        out[name] = brief(rec)
+    g_ = result.get("gather")
+    if g_ and "frac" in g_:
+        out["gather_hbm_microbench"] = {"GBps": round(g_["achieved"], 1), "frac": round(g_["frac"], 3)}
+    return out
 
 
 def main():
@@ -932,10 +1036,14 @@ def main():
             # cap) and the epoch time (= ms_per_step: a bench step is one meta-epoch)
             "domain_passes_per_sec": r["domain_passes_per_sec"], "epoch_time_ms": r["ms_per_step"],
             "roofline": r["roofline"], "tower": r["tower"], "table_update": r["table_update"],
-            "gather": gather, "gather_l2": r["gather_l2"], "kernels_avg_us": r["kernels_avg_us"],
+            "gather": gather, "gather_l2": r["gather_l2"], "gather_in_step": r.get("gather_in_step"),
+            "kernels_avg_us": r["kernels_avg_us"],
             "cpu_baseline": r["cpu_baseline"], "host_ms_per_epoch": r["host_ms_per_epoch"],
             "host_prep_ms_per_epoch": r["host_prep_ms_per_epoch"], "prewarm_s": r["prewarm_s"], "targets": targets,
         }
+        for rec_ in [result] + [t for t in targets.values() if isinstance(t, dict)]:
+            if rec_.get("tower") is rec_.get("roofline") or rec_.get("tower") == rec_.get("roofline"):
+                rec_["tower"] = "= roofline"
         if lanes_rec is not None:
             if "value" in lanes_rec:
                 lanes_rec["over_single_chain"] = lanes_rec["value"] / r["value"]
@@ -952,6 +1060,9 @@ def main():
                 result["partition_speedup_bound"] = r["partition_speedup_bound"]
         if r.get("gpu_over_cpu") is not None:
             result["gpu_over_cpu"] = r["gpu_over_cpu"]
+        # LAST key of the line: every workload of the run in a few hundred bytes each, so that a record which keeps only the
+        # tail of stdout still carries all of them (round 5's record lost `targets.taobao30`); the bulky blocks sit above
+        result["summary"] = summary_block(result, targets, lanes_rec)
         print(json.dumps(result))
         sys.stdout.flush()
     if world > 1:
