@@ -842,19 +842,22 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     return rec
 
 
-def run_lanes(wl_name, steps, warmup, lanes):
+def run_lanes(wl_name, steps, warmup, lanes, outer=(0, 1)):
     """the same epochs by `lanes` LANES of this process (mamdr_amd/parallel.LaneGroup): the sharded epoch of SURVEY 8e -- per-epoch
     LPT of the DR query domains and DN passes, one sum of the DN displacements -- with the ranks as host threads, one engine
     and one HIP stream each, on ONE GPU.  Same timed region as the ranks' (barrier + device synchronise on both sides,
     max over lanes).  NOT the reference's single sequential chain (its Adam slots and shuffle streams are per lane, its
     DN update sums per-lane displacements): reported beside `value`, never as `value`."""
     from mamdr_amd import parallel
-    recs = parallel.LaneGroup(lanes).run(lambda lane: run_workload(wl_name, steps, warmup, lane, lanes, False, 0.0))
+    # (outer = (rank, world) of a multi-process run: RANKS x LANES, one world of world * lanes participants -- parallel.py)
+    recs = parallel.LaneGroup(lanes, outer=outer).run(
+        lambda lane: run_workload(wl_name, steps, warmup, outer[0] * lanes + lane, outer[1] * lanes, False, 0.0))
     r = recs[0]
     out = {k: r[k] for k in ("value", "unit", "ms_per_step", "us_per_domain_step", "workload", "domain_steps_per_epoch",
                              "partition_speedup_bound", "host_ms_per_epoch", "dn_mode") if k in r}
-    out.update({"lanes": lanes, "semantics": "the %d-rank sharded epoch (SURVEY 8e) on one GPU: lanes = host threads, one engine + "
-                                             "one HIP stream each; not the single chain `value` times" % lanes,
+    out.update({"lanes": lanes, "participants": outer[1] * lanes,
+                "semantics": "the %d-participant sharded epoch (SURVEY 8e), %d lane(s) per GPU: lanes = host threads, one engine + "
+                             "one HIP stream each; not the single chain `value` times" % (outer[1] * lanes, lanes),
                 "us_per_domain_step": r["ms_per_step"] * 1e3 / r["domain_steps_per_epoch"]})
     return out
 
@@ -926,6 +929,9 @@ def main():
     ap.add_argument("--no-targets", action="store_true", help="skip the Taobao-30 record and the Amazon-6-sized gather")
     ap.add_argument("--lanes", type=int, default=4,
                     help="single GPU: also time the same epochs sharded over this many lanes of one process (0 = skip)")
+    ap.add_argument("--rank-lanes", type=int, default=0,
+                    help="several ranks: also time the epochs with this many lanes PER RANK (ranks x lanes: one world of "
+                         "gpus * rank-lanes participants; 0 = skip)")
     ap.add_argument("--no-preflight", action="store_true",
                     help="several ranks: skip the first-contact check of the communicator (all-reduce, send / recv ring, broadcast)")
     args = ap.parse_args()
@@ -1004,6 +1010,9 @@ def main():
         except Exception as e:      # noqa: BLE001
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
     lanes_rec = None
+    if world > 1 and args.rank_lanes > 1:
+        # ranks x lanes (every rank takes part; a failure here fails the run: the ranks must stay in step)
+        lanes_rec = run_lanes(args.workload, args.steps, args.warmup, args.rank_lanes, outer=(rank, world))
     if world == 1 and args.lanes > 1:
         # (an extra beside `value`: a failure here is reported in the line, it does not cost the run its headline)
         try:

@@ -111,8 +111,9 @@ def main(config, engine_factory=None, on_model=None):
                                   "wrappers only; got '%s'" % name)
     dataset = MultiDomainDataset(config["dataset"])
     if lanes > 1:
-        if world > 1:
-            raise NotImplementedError("train.lanes = %d under %d processes: lanes stand in for ranks inside ONE process" % (lanes, world))
+        # (under N processes the lanes of every rank are a slice of ONE world of N * lanes participants: a rank's DR queries
+        # and DN sub-sequence are dealt on to its lanes, collectives = lane step + one inter-rank collective per process --
+        # parallel.py, "RANKS x LANES")
         from . import parallel
         import os
         import torch
@@ -121,7 +122,10 @@ def main(config, engine_factory=None, on_model=None):
             # default of 4 queues is shared with torch's other streams: profiles/r05_lanes_bench.txt)
             os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * lanes)))
         # (the dataset is read-only: one copy for all lanes; every lane builds its own model = its own engine and stream)
-        return parallel.LaneGroup(lanes).run(lambda lane: _run(config, dataset, engine_factory, on_model, lane))[0]
+        # (train.lane_sum_block: a test knob -- a one-process run of N * L lanes that adds up in the order of N processes of L
+        # lanes, the bit-for-bit reference of the composed run: tests/test_abi_and_parallel.py)
+        return parallel.LaneGroup(lanes, outer=(rank, world), sum_block=config["train"].get("lane_sum_block")).run(
+            lambda lane: _run(config, dataset, engine_factory, on_model, rank * lanes + lane))[0]
     return _run(config, dataset, engine_factory, on_model, rank)
 
 

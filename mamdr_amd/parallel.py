@@ -23,6 +23,15 @@ its own engine on its own HIP stream, and inside those threads `world()` answers
 module (`all_reduce`, `broadcast`, the phi hand-over) become stream-ordered copies / sums between the lanes' buffers --
 every function below runs unchanged, and a lane run IS the L-rank run (same assignment, same arithmetic, same sums in
 rank order), with the kernels of different lanes overlapping on the device.
+
+RANKS x LANES (round 6): the two compose.  Under N processes each LaneGroup of L lanes is a slice of ONE world of N * L
+participants -- `world()` answers (rank * L + lane, N * L) -- so a rank's share of an epoch (its DR queries, its DN
+sub-sequence) is dealt on to its lanes by the same assignment code, and a collective is the lane step on the device
+followed by ONE inter-rank collective per process: all_reduce = sum over the process's lanes in lane order, lane 0's
+`dist.all_reduce` of that sum, lane 0's result copied to the other lanes; broadcast = the source lane's thread broadcasts
+between the processes, then between the lanes; a phi slot that changes hands travels lane to lane inside a process and
+through lane 0's batched send / recv between processes.  Exactly one thread of a process is inside torch.distributed at
+any time (the lanes meet at a host barrier around every collective) and every process issues the same sequence.
 """
 import threading
 
@@ -38,8 +47,17 @@ class LaneGroup(object):
     for the publishers' events and reads; a second round of events keeps a publisher from overwriting what a reader has
     not read yet.  No host synchronisation with the device anywhere: the lanes' streams stay asynchronous."""
 
-    def __init__(self, n):
+    def __init__(self, n, outer=None, sum_block=None):
+        """outer = (rank, world size) of the process group this process is a rank of (default: read from
+        torch.distributed; (0, 1) without one).  sum_block (tests): the all-reduce adds the lanes in blocks of that many --
+        the order in which `sum_block` lanes x n / sum_block processes add up -- instead of one run in lane order."""
         self.n = int(n)
+        if outer is None:
+            outer = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+        self.outer_rank, self.outer_ws = int(outer[0]), int(outer[1])
+        self.sum_block = int(sum_block) if sum_block else self.n
+        if self.n % self.sum_block:
+            raise ValueError("sum_block %d does not divide %d lanes" % (self.sum_block, self.n))
         self.barrier = threading.Barrier(self.n)
         self.slots = [None] * self.n
         self.ev = [None] * self.n
@@ -52,6 +70,7 @@ class LaneGroup(object):
         for it for ever)."""
         results, errors = [None] * self.n, [None] * self.n
         device = torch.cuda.current_device() if torch.cuda.is_available() else None
+        self.barrier = threading.Barrier(self.n)        # (a barrier broken by a failed run stays broken: ADVICE r05)
 
         def body(lane):
             _lane.group, _lane.rank = self, lane
@@ -119,22 +138,50 @@ class LaneGroup(object):
             for k in range(self.n):
                 if k != rank:
                     s.wait_event(self.ev[k])
-        acc = self.slots[0].clone()
         add = self.adders[rank] if (op == "sum" and t.dtype == torch.float32 and t.dim() == 1) else None
-        for k in range(1, self.n):          # rank order on every lane: the same bits everywhere
+
+        def fold(acc, other):
             if add is not None:
-                add(acc, self.slots[k])
+                add(acc, other)
             elif op == "sum":
-                torch.add(acc, self.slots[k], out=acc)
+                torch.add(acc, other, out=acc)
             elif op == "max":
-                torch.maximum(acc, self.slots[k], out=acc)
+                torch.maximum(acc, other, out=acc)
             else:
-                torch.minimum(acc, self.slots[k], out=acc)
+                torch.minimum(acc, other, out=acc)
+        # lane order on every lane: the same bits everywhere.  (sum_block < n: block sums first, then the blocks in order --
+        # what n / sum_block processes of sum_block lanes each compute; one block = one run in lane order)
+        acc = None
+        for b0 in range(0, self.n, self.sum_block):
+            blk = self.slots[b0].clone()
+            for k in range(b0 + 1, b0 + self.sum_block):
+                fold(blk, self.slots[k])
+            if acc is None:
+                acc = blk
+            else:
+                fold(acc, blk)
         self._read_done(rank, cuda, range(self.n))
+        if self.outer_ws > 1:
+            # ONE inter-rank collective per process: lane 0 reduces the lanes' sum over the ranks, the others take its result
+            if rank == 0:
+                dist.all_reduce(acc, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+            self._publish(rank, acc, cuda)
+            if rank != 0:
+                if cuda:
+                    torch.cuda.current_stream().wait_event(self.ev[0])
+                acc.copy_(self.slots[0])
+            self._read_done(rank, cuda, (0,))
         t.copy_(acc)
 
     def broadcast(self, rank, t, src):
+        """src: a participant of the whole world (process src // n, lane src % n)."""
         cuda = t.is_cuda
+        src_proc, src = divmod(int(src), self.n)
+        if self.outer_ws > 1:
+            if rank == src:             # the source lane's thread moves it between the processes (one thread inside dist)
+                dist.broadcast(t, src=src_proc)
+        elif src_proc != 0:
+            raise ValueError("broadcast from participant %d of a world of %d" % (src_proc * self.n + src, self.n))
         self._publish(rank, t, cuda)
         if rank != src:
             if cuda:
@@ -143,15 +190,46 @@ class LaneGroup(object):
         self._read_done(rank, cuda, (src,))
 
     def transfer(self, rank, vectors, moves):
-        """moves [(key, src lane, dst lane)]: vectors[key] of lane src -> vectors[key] of lane dst."""
+        """moves [(key, src, dst)] between participants of the whole world (process p = x // n, lane x % n): vectors[key] of
+        src -> vectors[key] of dst.  Inside this process a stream-ordered device copy; between processes lane 0 sends /
+        receives all of this process's slots in ONE batch (the tensors are the lanes' own: lane 0's stream waits for the
+        source lanes' events first, the destination lanes wait for lane 0's before they go on).  -> bytes this lane's
+        slots put on the wire."""
         cuda = any(v.is_cuda for v in vectors.values())
+        me = self.outer_rank
         self._publish(rank, vectors, cuda)
+        touched, sent = set(), 0
+        remote = []
         for key, src, dst in moves:
-            if rank == dst and src != dst:
-                if cuda:
-                    torch.cuda.current_stream().wait_event(self.ev[src])
-                vectors[key].copy_(self.slots[src][key])
-        self._read_done(rank, cuda, set(src for _, src, _ in moves))
+            (sp, sl), (dp, dl) = divmod(int(src), self.n), divmod(int(dst), self.n)
+            if sp == me and dp == me:
+                touched.add(sl)
+                if rank == dl and sl != dl:
+                    if cuda:
+                        torch.cuda.current_stream().wait_event(self.ev[sl])
+                    vectors[key].copy_(self.slots[sl][key])
+            elif sp == me or dp == me:
+                remote.append((key, sp, sl, dp, dl))
+                touched.add(sl if sp == me else dl)
+                if sp == me and rank == sl:
+                    sent += vectors[key].numel() * vectors[key].element_size()
+        if remote and self.outer_ws > 1:
+            touched.add(0)
+            if rank == 0:
+                ops = []
+                for key, sp, sl, dp, dl in remote:
+                    if sp == me:
+                        if cuda and sl != 0:
+                            torch.cuda.current_stream().wait_event(self.ev[sl])
+                        ops.append(dist.P2POp(dist.isend, self.slots[sl][key], dp))
+                    else:
+                        if cuda and dl != 0:
+                            torch.cuda.current_stream().wait_event(self.ev[dl])
+                        ops.append(dist.P2POp(dist.irecv, self.slots[dl][key], sp))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        self._read_done(rank, cuda, touched)
+        return sent
 
 
 _lane_streams = {}
@@ -163,8 +241,33 @@ def _lane_stream(device, lane):
     for the second group of a process)."""
     key = (device, lane)
     if key not in _lane_streams:
-        _lane_streams[key] = torch.cuda.Stream(device=device)
+        _lane_streams[key] = _masked_stream(device, lane) or torch.cuda.Stream(device=device)
     return _lane_streams[key]
+
+
+def _masked_stream(device, lane):
+    """MAMDR_LANE_CUS=<n> (a measurement switch, default off): lane k's stream is confined to n of the device's CUs
+    (mamdr_stream_create_masked = hipExtStreamCreateWithCUMask) -- `n` consecutive CU numbers from k * n, or with
+    MAMDR_LANE_CUS=<n>i every (CUs / n)-th CU from k: the lanes' launches then run side by side on partitions of the
+    device instead of interleaving their workgroups on all CUs."""
+    import os
+    spec = os.environ.get("MAMDR_LANE_CUS", "")
+    if not spec or spec == "0":
+        return None
+    import ctypes as C
+    from . import _lib as L
+    inter = spec.endswith("i")
+    n = int(spec.rstrip("i"))
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    parts = max(1, total // n)
+    cus = [(lane % parts) + parts * j for j in range(n)] if inter else [((lane % parts) * n + j) for j in range(n)]
+    words = [0] * ((total + 31) // 32)
+    for c in cus:
+        words[c // 32] |= 1 << (c % 32)
+    out = C.c_void_p()
+    with torch.cuda.device(device):
+        L.check(L.load().mamdr_stream_create_masked(len(words), (C.c_uint32 * len(words))(*words), C.byref(out)))
+    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 class _Lane0Stdout(object):
@@ -213,6 +316,10 @@ def barrier():
     g = lanes()
     if g is not None:
         g.wait()
+        if g.outer_ws > 1:
+            if _lane.rank == 0:
+                dist.barrier()
+            g.wait()
     elif dist.is_available() and dist.is_initialized():
         dist.barrier()
 
@@ -230,9 +337,10 @@ def lpt_partition(costs, n_parts):
 
 
 def world():
+    """(this participant, participants): a lane of a LaneGroup under N processes is participant rank * L + lane of N * L."""
     g = lanes()
     if g is not None:
-        return _lane.rank, g.n
+        return g.outer_rank * g.n + _lane.rank, g.outer_ws * g.n
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
@@ -620,10 +728,12 @@ class BalancedMAMDR(object):
         sent = 0
         if not moves:
             return sent
-        if lanes() is not None:     # lane to lane inside the process: a stream-ordered device copy
-            lanes().transfer(rank, self.phis, moves)
+        g = lanes()
+        if g is not None and (g.outer_ws == 1 or (P2P_ENABLED and p2p_possible(self.pack.device))):
+            # lane to lane inside the process: a stream-ordered device copy; between processes: lane 0's batched send / recv
+            g.transfer(_lane.rank, self.phis, moves)
             return sum(self.P * 4 for _, src, _ in moves if src == rank)
-        p2p = P2P_ENABLED and p2p_possible(self.pack.device)
+        p2p = g is None and P2P_ENABLED and p2p_possible(self.pack.device)
         if p2p:
             ops = []
             for d, src, dst in moves:

@@ -473,6 +473,89 @@ def _run_entry_worlds(tmp_path, name, extra=None):
     assert lane_sha == sorted(sha), (lane_sha, sha)
 
 
+COMPOSED_WORKER = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+import numpy as np
+from fake_engine import FakeEngine
+from mamdr_amd import cli, synthetic
+real = synthetic.generate
+synthetic.generate = lambda *a, **k: real(*a, **dict(k, emb_dim=8))
+cfg = json.load(open({cfg!r}))
+built = []
+res = cli.main(cfg, FakeEngine, on_model=built.append)
+rank = int(os.environ.get("RANK", "0"))
+json.dump({{"avg_loss": res[0], "avg_auc": res[1], "domain_auc": {{str(k): v for k, v in res[3].items()}},
+           "weights_sha": sorted(hashlib.sha1(m.model.weights.numpy().tobytes()).hexdigest() for m in built),
+           "traces": sorted([list(map(list, getattr(m, "trace", []))) for m in built])}}, open({out!r} % rank, "w"))
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("name,extra", [
+    ("mlp_meta_mamdr_finetune", {}),
+    ("mlp_meta_mamdr_finetune", {"dn_mode": "replicated"}),
+    ("mlp_meta_domain_negotiation_finetune", {}),
+    ("mlp_meta_reptile_batch", {"target_domain": 2}),
+    ("mlp_meta_mamdr_batch", {}),
+])
+def test_run_entry_ranks_x_lanes_gloo_world2(tmp_path, name, extra):
+    """RANKS x LANES (VERDICT r05 item 4): run.py's entry under 2 gloo processes with train.lanes = 2 -- ONE world of 4
+    participants (rank * 2 + lane): a rank's DR queries and DN sub-sequence are dealt on to its lanes, a collective is the
+    lanes' step followed by one inter-rank collective per process, a phi slot that changes hands between processes travels
+    through lane 0's batched send / recv.  It must equal, bit for bit -- returned results, every participant's live model and
+    trace --, the ONE-process run of 4 lanes whose all-reduce adds up in the same order (lanes 0 + 1, lanes 2 + 3, then the
+    two sums: train.lane_sum_block = 2).  (A flat world of 4 gloo ranks adds in gloo's ring order, chunk by chunk: no
+    hierarchical sum can equal that bit for bit; the flat 2-lane run equals the 2-process run, test above.)"""
+    import json
+    sys.path.insert(0, HERE)
+    from test_host_logic import tiny_config
+    cfg = tiny_config(tmp_path, name, epochs=2)
+    cfg["dataset"]["synthetic"].update(n_domain=5, n_train=1500, n_val=500, n_test=500)
+    cfg["train"].update(extra or {}, lanes=2)
+    cfg_path = tmp_path / "cfg.json"
+    cfg_path.write_text(json.dumps(cfg))
+    script = tmp_path / "composed_worker.py"
+    script.write_text(COMPOSED_WORKER.format(root=ROOT, here=HERE, cfg=str(cfg_path), out=str(tmp_path / "res_%d.json")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", MAMDR_SHARE_GPU="1", OMP_NUM_THREADS="2")
+    env.pop("MAMDR_LANES", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
+    a, b = [json.load(open(str(tmp_path / ("res_%d.json" % r)))) for r in range(2)]
+    sha, traces = a.pop("weights_sha") + b.pop("weights_sha"), a.pop("traces") + b.pop("traces")
+    assert a == b and sorted(a["domain_auc"]) == ["0", "1", "2", "3", "4"]
+    assert sum(1 for t in traces if t) >= 3                  # the work really was dealt over the four participants
+    # the reference: 4 lanes of ONE process, sums in blocks of 2
+    import hashlib
+    import shutil
+    from fake_engine import FakeEngine
+    from mamdr_amd import cli, synthetic
+    for d in ("result", "checkpoint"):
+        shutil.rmtree(str(tmp_path / d), ignore_errors=True)
+    real = synthetic.generate
+    synthetic.generate = lambda *a_, **k: real(*a_, **dict(k, emb_dim=8))
+    try:
+        built = []
+        lane_cfg = json.loads(json.dumps(cfg))
+        lane_cfg["train"].update(lanes=4, lane_sum_block=2)
+        res = cli.main(lane_cfg, FakeEngine, on_model=built.append)
+    finally:
+        synthetic.generate = real
+    assert len(built) == 4
+    got = {"avg_loss": res[0], "avg_auc": res[1], "domain_auc": {str(k): v for k, v in res[3].items()}}
+    assert got == a, (got, a)
+    assert sorted(hashlib.sha1(m.model.weights.numpy().tobytes()).hexdigest() for m in built) == sorted(sha)
+    assert sorted([list(map(list, getattr(m, "trace", []))) for m in built]) == sorted(traces)
+
+
 TAIL_WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r})
@@ -745,7 +828,7 @@ def test_lane_group_error_ends_every_lane():
         parallel.LaneGroup(3).run(fn)
 
 
-def test_run_entry_lanes_need_a_sharded_wrapper_and_one_process(tmp_path, monkeypatch):
+def test_run_entry_lanes_need_a_sharded_wrapper(tmp_path, monkeypatch):
     sys.path.insert(0, HERE)
     from fake_engine import FakeEngine
     from test_host_logic import patch_emb_dim, tiny_config

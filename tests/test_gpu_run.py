@@ -216,6 +216,85 @@ def test_run_entry_two_ranks_on_the_hip_engine(tmp_path, name, extra):
     assert lane_sha == sorted([a["weights_sha"], b["weights_sha"]]), (lane_sha, a["weights_sha"], b["weights_sha"])
 
 
+COMPOSED_WORKER = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+from mamdr_amd import cli
+cfg = json.load(open({cfg!r}))
+built = []
+res = cli.main(cfg, on_model=built.append)           # 2 gloo ranks on the shared GPU x train.lanes = 2
+ws = [m.model.get_weights() for m in built]
+torch.cuda.synchronize()
+rank = int(os.environ["RANK"])
+json.dump({{"avg_auc": res[1], "domain_auc": {{str(k): v for k, v in res[3].items()}},
+           "weights_sha": sorted(hashlib.sha1(w.cpu().numpy().tobytes()).hexdigest() for w in ws),
+           "passes": [len(getattr(m, "trace", [])) for m in built]}}, open({out!r} % rank, "w"))
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("name,extra", [("mlp_meta_mamdr_finetune", {}),
+                                        ("mlp_meta_domain_negotiation", {"target_domain": 2, "meta_train_step": 2})])
+def test_run_entry_ranks_x_lanes_on_the_hip_engine(tmp_path, name, extra, monkeypatch):
+    """RANKS x LANES on the HIP engine (VERDICT r05 item 4): two gloo processes on this GPU, each with train.lanes = 2 -- one
+    world of 4 participants, collectives = the lanes' device step + one inter-rank collective per process -- against the
+    ONE-process run of 4 lanes that adds up in the same order (train.lane_sum_block = 2): the same per-domain AUCs and the
+    same four live models, bit for bit.  (Both sides on the 16-row tower: engines of a 4-lane group choose it by themselves,
+    MAMDR_TOWER_TILE gives it to the 2-lane groups -- the two tiles differ in rounding.)"""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    with open(os.path.join(ROOT, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
+        cfg = copy.deepcopy(json.load(f))
+    cfg["model"]["name"] = name
+    cfg["train"].update(epoch=2, patience=2, sample_num=2, meta_learning_rate=0.5, lanes=2,
+                        result_save_path=str(tmp_path / "result"), checkpoint_path=str(tmp_path / "ckpt"))
+    cfg["train"].update(extra)
+    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
+    cfg_path = tmp_path / "cfg.json"
+    cfg_path.write_text(json.dumps(cfg))
+    script = tmp_path / "worker.py"
+    script.write_text(COMPOSED_WORKER.format(root=ROOT, cfg=str(cfg_path), out=str(tmp_path / "res_%d.json")))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", MAMDR_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", MAMDR_TOWER_TILE="16")
+    env.pop("MAMDR_LANES", None)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0 and ("rank %d ok" % r) in out.decode(), out.decode()[-3000:]
+    a, b = (json.load(open(str(tmp_path / ("res_%d.json" % r)))) for r in range(2))
+    assert a["domain_auc"] == b["domain_auc"] and len(a["domain_auc"]) == 10 and a["avg_auc"] > 0.6
+    assert all(n > 0 for n in a["passes"] + b["passes"])          # every one of the four participants ran passes
+    import hashlib
+    import shutil
+    from mamdr_amd import cli
+    for d in ("result", "ckpt"):
+        shutil.rmtree(str(tmp_path / d), ignore_errors=True)
+    lane_cfg = copy.deepcopy(cfg)
+    lane_cfg["train"].update(lanes=4, lane_sum_block=2)
+    monkeypatch.setenv("MAMDR_TOWER_TILE", "16")
+    built = []
+    res = cli.main(lane_cfg, on_model=built.append)
+    assert len(built) == 4
+    assert {str(k): v for k, v in res[3].items()} == a["domain_auc"] and res[1] == a["avg_auc"]
+    lane_w = [m.model.get_weights() for m in built]
+    torch.cuda.synchronize()
+    lane_sha = sorted(hashlib.sha1(w.cpu().numpy().tobytes()).hexdigest() for w in lane_w)
+    assert lane_sha == sorted(a["weights_sha"] + b["weights_sha"]), (lane_sha, a["weights_sha"], b["weights_sha"])
+
+
 def test_rccl_communicator_on_this_gpu():
     """backend "nccl" is RCCL here: a one-rank communicator on the MI355X reduces device memory (float32 and the
     float64 timings bench.py reduces) and passes a barrier.  The N > 1 code paths themselves are covered by the gloo
