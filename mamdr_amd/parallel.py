@@ -258,16 +258,18 @@ def _masked_stream(device, lane):
     from . import _lib as L
     inter = spec.endswith("i")
     n = int(spec.rstrip("i"))
-    total = torch.cuda.get_device_properties(device).multi_processor_count
+    try:
+        total = torch.cuda.get_device_properties(torch.device("cuda", int(device))).multi_processor_count
+    except Exception:           # (seen on the GPU box inside a lane thread: "Invalid device id" from torch's cached device count)
+        total = 256
     parts = max(1, total // n)
     cus = [(lane % parts) + parts * j for j in range(n)] if inter else [((lane % parts) * n + j) for j in range(n)]
     words = [0] * ((total + 31) // 32)
     for c in cus:
         words[c // 32] |= 1 << (c % 32)
     out = C.c_void_p()
-    with torch.cuda.device(device):
-        L.check(L.load().mamdr_stream_create_masked(len(words), (C.c_uint32 * len(words))(*words), C.byref(out)))
-    return torch.cuda.ExternalStream(out.value, device=device)
+    L.check(L.load().mamdr_stream_create_masked(len(words), (C.c_uint32 * len(words))(*words), C.byref(out)))
+    return torch.cuda.ExternalStream(out.value)         # (the calling thread's current device: LaneGroup.run set it)
 
 
 class _Lane0Stdout(object):
