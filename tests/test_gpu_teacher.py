@@ -145,10 +145,17 @@ def test_amazon6_deepfm_dn_epoch_teacher_forced():
                                tower="deepfm")
     assert sorted(model.names) == sorted(eng.segments)
     theta = model.get_flat().copy()
-    ls = teacher.LockStep(model, model, eng, g["data"]["train"], 1e-3, BARS, chunk=8)
+    # 8-step chunks (teacher.LockStep.train_pass: this configuration amplifies a rounding-level difference ~1.15x per step).
+    # Even so single chunks show EVENTS: Adam is sign-like on elements whose second moment is tiny (the tables start at
+    # N(0, 1e-4^2), so do the rows of W0 they feed), and an element whose gradient is rounding residue moves +- lr whichever way
+    # the residue points.  The oracle against copies of its own state perturbed by one rounding, same chunks: up to 7.8e-3 of
+    # W0's elements beyond 5 % of k lr (profiles/r06_teacher_probe.txt) -- hence 1e-2 here instead of 1e-3; the other bars
+    # are the frozen-table cases'.
+    bars = dict(BARS, frac=1e-2)
+    ls = teacher.LockStep(model, model, eng, g["data"]["train"], 1e-3, bars, chunk=8)
     t0 = time.time()
     trace = oloops.dn_epoch(ls, theta, g["data"]["train"], seq, oracle_jobs.perm_stream(sizes, 500), batch, 0.5)
-    out = _report_lockstep("amazon6 deepfm DN bs 1024, full tables", ls, time.time() - t0, BARS)
+    out = _report_lockstep("amazon6 deepfm DN bs 1024, full tables", ls, time.time() - t0, bars)
     assert out["passes"] == len(trace) == D and out["steps"] >= 150
     # (8-step chunks never reach the lazy table Adam's forced flush -- 32 steps; the free-running epoch of
     # tests/test_gpu_fullsize.py asserts >= 4 of them -- every chunk END replays every lagging row of both tables, which is
