@@ -43,7 +43,7 @@ CASES = {
     # shape: (tower, trainable, batch, row_scale, kernel as bench.py names it, rows per tile)
     "amazon6": ("deepfm", True, 1024, 0.01, "k_tower4<true, true, true, false, false>", 4),
     "taobao30": ("mlp", False, 4096, 1.0, "k_tower<true, 0, false, false>", 16),
-    "amazon13": ("star", True, 8192, 0.01, "k_tower<true, 384, false, false>", 16),
+    "amazon13": ("star", True, 8192, 0.04, "k_tower<true, 384, false, false>", 16),
 }
 
 
