@@ -209,6 +209,7 @@ class TowerEngine(FlatVectorOps):
             tower_tile = 16 if (group is not None and group.n >= 4 and tower in ("mlp", "deepfm", "wdl")) else 0
         if tower_tile:
             self.set_tower_tile(tower_tile)
+        self._group = None
         self.emb_trainable = bool(emb_trainable)
         self.tower = tower
         self.n_params = int(self.lib.mamdr_param_count(self.ctx))
@@ -237,6 +238,10 @@ class TowerEngine(FlatVectorOps):
         self.data = {}          # (domain, split) -> dict of device columns
         self._hist = torch.zeros(2 * 501, dtype=torch.int32, device=self.device)
         self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # a lane of a LaneGroup in batch mode: the step launches are shared with the other lanes' (mamdr_group_join)
+        from . import parallel as _parallel
+        if _parallel.lanes() is not None:
+            _parallel.lanes().join_step_group(self)
 
     # The live state is only handed out synchronised: with trainable tables the library advances rows that
     # no batch touched lazily (mamdr_sync_tables in include/mamdr_hip.h); every read or replacement of the
@@ -497,6 +502,12 @@ class TowerEngine(FlatVectorOps):
         self._ema = {"momentum": float(momentum), "step": 0, "biased": self.new_vector(), "scratch": self.new_vector()}
         if self._acc is not None:
             self.bind_accumulator(self._acc)
+
+    def join_group(self, group, member):
+        """mamdr_group_join: this context's slab-path step launches are issued together with those of the group's other
+        members that are stepping at the same moment (all members on one stream, each driven by its own host thread)."""
+        L.check(self.lib.mamdr_group_join(group, self.ctx, int(member)))
+        self._group = group
 
     def set_counters(self, optimizer_steps, dropout_steps):
         """restore the Adam step count (with TF's running beta powers) and the dropout stream's position

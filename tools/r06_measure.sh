@@ -162,7 +162,7 @@ print("taobao10", round(d["value"]), "steps/s", round(d["us_per_domain_step"], 2
 print({k: v for k, v in d["kernels_avg_us"].items() if k != "_rated"})
 for r in d["kernels_avg_us"].get("_rated", []): print("   rated:", r["kernel"], r["bound"], round(r["frac"], 3))
 for w, t in d["targets"].items():
-    print(w, round(t["value"]), round(t["us_per_domain_step"], 2), "us/step; tower frac", round(t["tower"]["frac"], 3), "cpu", round(t["cpu_baseline"]["value"], 2),
+    print(w, round(t["value"]), round(t["us_per_domain_step"], 2), "us/step; tower frac", round(t["roofline"]["frac"], 3), "cpu", round(t["cpu_baseline"]["value"], 2),
           "x", round(t["gpu_over_cpu"], 1), "host ms/epoch", t["host_ms_per_epoch"])
     print("   ", {k: (round(v["us_per_domain_step"], 2) if isinstance(v, dict) else round(v, 2)) for k, v in t["kernels_avg_us"].items() if k != "_rated"})
     for r in t["kernels_avg_us"].get("_rated", []): print("    rated:", r["kernel"], r["bound"], round(r["frac"], 3))
