@@ -150,6 +150,10 @@ int mamdr_group_create(int32_t n_members, void* stream, mamdr_group** out);
 int mamdr_group_destroy(mamdr_group* g);
 int mamdr_group_join(mamdr_group* g, mamdr_ctx* ctx, int32_t member);
 int mamdr_group_leave(mamdr_ctx* ctx);
+/* on != 0: the member counts as stepping -- the others wait for its next step launch -- from now on, BETWEEN its training
+ * calls as well (a caller that knows the member is about to step again: the passes of one phase of an epoch); on == 0: only
+ * while it is inside a training call again.  A held member must be released before it blocks on the other members. */
+int mamdr_group_hold(mamdr_ctx* ctx, int32_t on);
 int64_t mamdr_group_launches(const mamdr_group* g, int32_t carried);
 
 /* --- lifetime: replaces DeepCTR(dataset, config) / build_model + compile

@@ -80,6 +80,7 @@ SIGNATURES = {
     "mamdr_group_destroy": (C.c_int, [_VP]),
     "mamdr_group_join": (C.c_int, [_VP, _VP, _I32]),
     "mamdr_group_leave": (C.c_int, [_VP]),
+    "mamdr_group_hold": (C.c_int, [_VP, _I32]),
     "mamdr_group_launches": (_I64, [_VP, _I32]),
     "mamdr_create": (C.c_int, [C.POINTER(Config), _VP, C.POINTER(_VP)]),
     "mamdr_destroy": (C.c_int, [_VP]),

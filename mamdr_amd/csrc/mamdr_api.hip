@@ -78,6 +78,7 @@ static void group_release(mamdr_group* g) {
 struct mamdr_ctx {
     mamdr_group* group = nullptr;   // mamdr_group_join
     int member = -1;
+    bool group_held = false;        // mamdr_group_hold: active (waited for) between training calls as well
     mamdr_config cfg;
     hipStream_t stream = nullptr;
     DenseLayout L;
@@ -767,7 +768,7 @@ namespace {
 struct GroupScope {
     mamdr_ctx* c;
     bool on;
-    GroupScope(mamdr_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->group->comb.enter(c->member); }
+    GroupScope(mamdr_ctx* c_, bool on_) : c(c_), on(on_ && !c_->group_held) { if (on) c->group->comb.enter(c->member); }
     ~GroupScope() { if (on) c->group->comb.leave(c->member); }
 };
 }  // namespace
@@ -1056,10 +1057,23 @@ int mamdr_group_join(mamdr_group* g, mamdr_ctx* c, int32_t member) {
 }
 int mamdr_group_leave(mamdr_ctx* c) {
     if (check_ctx(c)) return MAMDR_EINVAL;
+    if (c->group_held) (void)mamdr_group_hold(c, 0);
     mamdr_group* g = c->group;
     c->group = nullptr;
     c->member = -1;
     group_release(g);
+    return MAMDR_OK;
+}
+int mamdr_group_hold(mamdr_ctx* c, int32_t on) {
+    if (check_ctx(c)) return MAMDR_EINVAL;
+    if (!c->group) return MAMDR_OK;
+    if (on && !c->group_held) {
+        c->group->comb.enter(c->member);
+        c->group_held = true;
+    } else if (!on && c->group_held) {
+        c->group_held = false;
+        c->group->comb.leave(c->member);
+    }
     return MAMDR_OK;
 }
 int64_t mamdr_group_launches(const mamdr_group* g, int32_t carried) {

@@ -472,10 +472,14 @@ class TowerEngine(FlatVectorOps):
         n = self.n_rows(domain, split)
         preds = torch.empty(n, dtype=torch.float32, device=self.device) if want_preds else None
         split_id = {"train": L.SPLIT_TRAIN, "val": L.SPLIT_VAL, "test": L.SPLIT_TEST}[split]
+        held = self._group is not None and getattr(self, "_held", False)
+        L.check(self.lib.mamdr_group_hold(self.ctx, 0))       # (an evaluation blocks on the device: nobody waits for this member)
         L.check(self.lib.mamdr_eval_domain(self.ctx, domain, split_id, self.eval_batch, _ptr(self._loss1),
                                            _ptr(self._hist), _ptr(preds)))
         hist = self._hist.cpu().numpy().astype(np.int64)
         loss = float(self._loss1.cpu().numpy()[0])
+        if held:
+            L.check(self.lib.mamdr_group_hold(self.ctx, 1))
         auc, _ = auc_from_histogram(hist)
         if want_preds:
             return loss, auc, hist.reshape(2, 501), preds.cpu().numpy()
@@ -508,6 +512,10 @@ class TowerEngine(FlatVectorOps):
         members that are stepping at the same moment (all members on one stream, each driven by its own host thread)."""
         L.check(self.lib.mamdr_group_join(group, self.ctx, int(member)))
         self._group = group
+
+    def group_hold(self, on):
+        self._held = bool(on)
+        L.check(self.lib.mamdr_group_hold(self.ctx, 1 if on else 0))
 
     def set_counters(self, optimizer_steps, dropout_steps):
         """restore the Adam step count (with TF's running beta powers) and the dropout stream's position

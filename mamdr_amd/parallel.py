@@ -95,6 +95,13 @@ class LaneGroup(object):
                 errors[lane] = e
                 self.barrier.abort()
             finally:
+                held = getattr(_lane, "held", None)
+                if held is not None:
+                    try:
+                        held.group_hold(False)
+                    except Exception:
+                        pass
+                    _lane.held = None
                 _lane.group, _lane.rank = None, 0
         threads = [threading.Thread(target=body, args=(l,), name="mamdr-lane-%d" % l) for l in range(self.n)]
         import sys
@@ -119,6 +126,7 @@ class LaneGroup(object):
         if not self.batch or not hasattr(eng, "join_group"):
             return
         import ctypes as C
+        import os
         from . import _lib as L
         with self._step_lock:
             if self._step_group is None:
@@ -126,6 +134,11 @@ class LaneGroup(object):
                 L.check(L.load().mamdr_group_create(self.n, C.c_void_p(eng.stream.cuda_stream), C.byref(h)))
                 self._step_group = h
         eng.join_group(self._step_group, _lane.rank)
+        # MAMDR_LANES_HOLD=1 (measurement switch): the lane counts as stepping between its training calls too -- released
+        # around every host barrier of the lanes (every collective passes one) and around evaluations
+        if os.environ.get("MAMDR_LANES_HOLD", "0") not in ("", "0"):
+            _lane.held = eng
+            eng.group_hold(True)
 
     def step_group_launches(self):
         """(launches issued, step launches they carried) of the lanes' mamdr_group so far, or None."""
@@ -146,7 +159,14 @@ class LaneGroup(object):
 
     # -- the collectives (called through the module functions below, from lane threads only)
     def wait(self):
-        self.barrier.wait()
+        held = getattr(_lane, "held", None)
+        if held is not None:
+            held.group_hold(False)
+        try:
+            self.barrier.wait()
+        finally:
+            if held is not None:
+                held.group_hold(True)
 
     def _publish(self, rank, obj, cuda):
         self.slots[rank] = obj
