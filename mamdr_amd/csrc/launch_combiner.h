@@ -16,6 +16,7 @@
 // make the host the bottleneck of a 40 us batched step); after a few thousand spins the waiter yields its time slice.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <mutex>
 #include <thread>
@@ -73,8 +74,19 @@ class LaunchCombiner {
             if (released_[member].load(std::memory_order_relaxed) != g) return;
         }
         int spins = 0;
+        auto t0 = std::chrono::steady_clock::now();
         while (released_[member].load(std::memory_order_acquire) == g) {
-            if (++spins > 4096) {
+            if ((++spins & 63) == 0 && wait_ns_ > 0) {
+                // a bounded wait: members that are held active between their calls (hold) but busy elsewhere for longer than
+                // this are not waited for -- whoever is here goes (earliest stage first), the late member joins the next launch
+                const auto now = std::chrono::steady_clock::now();
+                if (std::chrono::duration_cast<std::chrono::nanoseconds>(now - t0).count() > wait_ns_) {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    if (released_[member].load(std::memory_order_relaxed) == g) flush_kind_locked(-1, -1);
+                    t0 = now;
+                }
+            }
+            if (spins > 4096) {
                 std::this_thread::yield();
                 spins = 0;
             } else {
@@ -84,6 +96,7 @@ class LaunchCombiner {
             }
         }
     }
+    void set_wait_ns(int64_t ns) { wait_ns_ = ns; }
     // launches issued / descriptors carried so far (reports and tests)
     uint64_t launches() const { return launches_.load(); }
     uint64_t carried() const { return carried_.load(); }
@@ -131,6 +144,7 @@ class LaunchCombiner {
     const void* desc_[MAX_MEMBERS];
     std::atomic<uint64_t> released_[MAX_MEMBERS];
     std::atomic<uint64_t> launches_{0}, carried_{0};
+    int64_t wait_ns_ = 0;           // 0: wait for every active member however long
 };
 
 }  // namespace mamdr

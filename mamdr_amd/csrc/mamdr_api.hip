@@ -1037,6 +1037,7 @@ int mamdr_group_create(int32_t n_members, void* stream, mamdr_group** out) {
         return fail(MAMDR_EINVAL, "a group has 1 .. %d members, not %d", LaunchCombiner::MAX_MEMBERS, n_members);
     mamdr_group* g = new (std::nothrow) mamdr_group(n_members, static_cast<hipStream_t>(stream));
     if (!g) return fail(MAMDR_EHIP, "out of host memory");
+    if (const char* ev = getenv("MAMDR_GROUP_WAIT_US")) g->comb.set_wait_ns((int64_t)(atof(ev) * 1000.0));
     *out = g;
     return MAMDR_OK;
 }

@@ -24,14 +24,11 @@ PY
     tail -1 "$RES"
 }
 for rep in 1 2; do
-  run "streams of their own (r05)"   taobao10 4 MAMDR_LANES_BATCH=0
-  run "batched step launches"        taobao10 4 MAMDR_LANES_BATCH=1
-  run "batched + held between calls"  taobao10 4 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1
-  run "batched + held, 3 lanes"       taobao10 3 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1
-  run "batched + held, 8 lanes"       taobao10 8 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1
-  run "batched, 8 lanes"             taobao10 8 MAMDR_LANES_BATCH=1
+  run "streams of their own (r05)"    taobao10 4 MAMDR_LANES_BATCH=0
+  run "batched + held"                taobao10 4 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1
+  run "batched + held, wait 10 us"    taobao10 4 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1 MAMDR_GROUP_WAIT_US=10
+  run "batched + held, wait 25 us"    taobao10 4 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1 MAMDR_GROUP_WAIT_US=25
+  run "batched + held, wait 60 us"    taobao10 4 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1 MAMDR_GROUP_WAIT_US=60
+  run "batched, wait 10 us (no hold)" taobao10 4 MAMDR_LANES_BATCH=1 MAMDR_GROUP_WAIT_US=10
 done
-run "streams of their own (r05)"   taobao30 4 MAMDR_LANES_BATCH=0
-run "batched step launches"        taobao30 4 MAMDR_LANES_BATCH=1
-run "batched + held"               taobao30 4 MAMDR_LANES_BATCH=1 MAMDR_LANES_HOLD=1
 cat "$RES"
