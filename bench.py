@@ -842,7 +842,7 @@ def run_workload(wl_name, steps, warmup, rank, world, profile=True, cpu_budget=0
     return rec
 
 
-def run_lanes(wl_name, steps, warmup, lanes, outer=(0, 1), batch=None):
+def run_lanes(wl_name, steps, warmup, lanes, outer=(0, 1)):
     """the same epochs by `lanes` LANES of this process (mamdr_amd/parallel.LaneGroup): the sharded epoch of SURVEY 8e -- per-epoch
     LPT of the DR query domains and DN passes, one sum of the DN displacements -- with the ranks as host threads, one engine
     and one HIP stream each, on ONE GPU.  Same timed region as the ranks' (barrier + device synchronise on both sides,
@@ -850,8 +850,8 @@ def run_lanes(wl_name, steps, warmup, lanes, outer=(0, 1), batch=None):
     DN update sums per-lane displacements): reported beside `value`, never as `value`."""
     from mamdr_amd import parallel
     # (outer = (rank, world) of a multi-process run: RANKS x LANES, one world of world * lanes participants -- parallel.py)
-    group = parallel.LaneGroup(lanes, outer=outer, batch=batch)
-    recs = group.run(lambda lane: run_workload(wl_name, steps, warmup, outer[0] * lanes + lane, outer[1] * lanes, False, 0.0))
+    recs = parallel.LaneGroup(lanes, outer=outer).run(
+        lambda lane: run_workload(wl_name, steps, warmup, outer[0] * lanes + lane, outer[1] * lanes, False, 0.0))
     r = recs[0]
     out = {k: r[k] for k in ("value", "unit", "ms_per_step", "us_per_domain_step", "workload", "domain_steps_per_epoch",
                              "partition_speedup_bound", "host_ms_per_epoch", "dn_mode") if k in r}
@@ -859,10 +859,6 @@ def run_lanes(wl_name, steps, warmup, lanes, outer=(0, 1), batch=None):
                 "semantics": "the %d-participant sharded epoch (SURVEY 8e), %d lane(s) per GPU: lanes = host threads, one engine + "
                              "one HIP stream each; not the single chain `value` times" % (outer[1] * lanes, lanes),
                 "us_per_domain_step": r["ms_per_step"] * 1e3 / r["domain_steps_per_epoch"]})
-    out["batched"] = bool(group.batch)
-    st = group.step_group_launches()
-    if st:          # (mamdr_group_*: step launches of the lanes issued together)
-        out["step_launches"] = {"issued": st[0], "carried": st[1], "lanes_per_launch": st[1] / max(st[0], 1)}
     return out
 
 

@@ -134,28 +134,6 @@ int mamdr_env_unknown(void);
 int mamdr_stream_create_masked(uint32_t n_words, const uint32_t* cu_mask, void** out_stream);
 int mamdr_stream_destroy(void* stream);
 
-/* --- several contexts stepping side by side: ONE launch for their steps (ABI 18).
- * A 1,024-row step of the mlp tower fills a quarter of the device; contexts that step independently -- the query domains of
- * a DR phase, the sub-sequences of a DN phase: model_zoo/mamdr.py:48-57,60-108 read theta and write only their own phi /
- * displacement -- can share launches.  Contexts created on ONE stream join a group; while a member is inside
- * mamdr_train_steps(_n), each of the three launches of its step (tower, weight gradients, update: the path of
- * mamdr_step_path 0, 16-row tower tiles, for every batch size) is issued together with the same launch of every other
- * member that is stepping at that moment (k_tower_multi / k_wgrad_multi / k_update_multi: workgroup ranges of one grid,
- * each running its member's arguments through the bodies of the single launches -- a member's results do not depend on
- * whom it shared a launch with).  Members are driven from host threads of their own; a member that is not inside a
- * training call is not waited for.  Frozen-table mlp / wdl-less towers only (other contexts may join and launch as before).
- * mamdr_group_launches: launches issued (carried != 0: step launches they carried) -- for reports and tests. */
-typedef struct mamdr_group mamdr_group;
-int mamdr_group_create(int32_t n_members, void* stream, mamdr_group** out);
-int mamdr_group_destroy(mamdr_group* g);
-int mamdr_group_join(mamdr_group* g, mamdr_ctx* ctx, int32_t member);
-int mamdr_group_leave(mamdr_ctx* ctx);
-/* on != 0: the member counts as stepping -- the others wait for its next step launch -- from now on, BETWEEN its training
- * calls as well (a caller that knows the member is about to step again: the passes of one phase of an epoch); on == 0: only
- * while it is inside a training call again.  A held member must be released before it blocks on the other members. */
-int mamdr_group_hold(mamdr_ctx* ctx, int32_t on);
-int64_t mamdr_group_launches(const mamdr_group* g, int32_t carried);
-
 /* --- lifetime: replaces DeepCTR(dataset, config) / build_model + compile
  *     (model_zoo/DeepCTR/deepctr.py:20-61). */
 int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out);

@@ -76,12 +76,6 @@ SIGNATURES = {
     "mamdr_env_unknown": (C.c_int, []),
     "mamdr_stream_create_masked": (C.c_int, [_U32, _VP, C.POINTER(_VP)]),
     "mamdr_stream_destroy": (C.c_int, [_VP]),
-    "mamdr_group_create": (C.c_int, [_I32, _VP, C.POINTER(_VP)]),
-    "mamdr_group_destroy": (C.c_int, [_VP]),
-    "mamdr_group_join": (C.c_int, [_VP, _VP, _I32]),
-    "mamdr_group_leave": (C.c_int, [_VP]),
-    "mamdr_group_hold": (C.c_int, [_VP, _I32]),
-    "mamdr_group_launches": (_I64, [_VP, _I32]),
     "mamdr_create": (C.c_int, [C.POINTER(Config), _VP, C.POINTER(_VP)]),
     "mamdr_destroy": (C.c_int, [_VP]),
     "mamdr_param_count": (_I64, [_VP]),

@@ -124,8 +124,7 @@ def main(config, engine_factory=None, on_model=None):
         # (the dataset is read-only: one copy for all lanes; every lane builds its own model = its own engine and stream)
         # (train.lane_sum_block: a test knob -- a one-process run of N * L lanes that adds up in the order of N processes of L
         # lanes, the bit-for-bit reference of the composed run: tests/test_abi_and_parallel.py)
-        return parallel.LaneGroup(lanes, outer=(rank, world), sum_block=config["train"].get("lane_sum_block"),
-                                  batch=config["train"].get("lanes_batch")).run(
+        return parallel.LaneGroup(lanes, outer=(rank, world), sum_block=config["train"].get("lane_sum_block")).run(
             lambda lane: _run(config, dataset, engine_factory, on_model, rank * lanes + lane))[0]
     return _run(config, dataset, engine_factory, on_model, rank)
 

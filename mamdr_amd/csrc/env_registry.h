@@ -49,9 +49,6 @@ static const EnvSwitch kEnvSwitches[] = {
     // ---- Python host (mamdr_amd/*.py)
     {"MAMDR_LIB_PATH", "host,bench", "load this build of the library instead of mamdr_amd/libmamdr_hip.so (tools/build_variant.sh)"},
     {"MAMDR_LANES", "host", "lanes per process (overrides train.lanes)"},
-    {"MAMDR_LANES_BATCH", "host", "1: the lanes share one stream and their step launches (mamdr_group_*, overrides train.lanes_batch)"},
-    {"MAMDR_LANES_HOLD", "host", "1 (with MAMDR_LANES_BATCH): a lane is waited for between its training calls as well (measurement switch)"},
-    {"MAMDR_GROUP_WAIT_US", "lib", "mamdr_group_create: microseconds a member waits for the others before the launches present go (0 = for ever)"},
     {"MAMDR_LANE_CUS", "host", "<n> / <n>i: every lane's stream confined to n CUs, consecutive / interleaved (measurement switch, default off)"},
     {"MAMDR_SHARE_GPU", "host", "1: every rank of run.py on device 0 over gloo (testing on a 1-GPU box)"},
     {"MAMDR_COMM_TIMEOUT", "host", "seconds: process-group timeout of run.py"},

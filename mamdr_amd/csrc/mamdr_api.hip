@@ -12,7 +12,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <atomic>
 #include <new>
 #include <string>
 #include <utility>
@@ -21,7 +20,6 @@
 #include "../../include/mamdr_hip.h"
 #include "mamdr_kernels.h"
 #include "env_registry.h"
-#include "launch_combiner.h"
 
 using namespace mamdr;
 
@@ -63,22 +61,7 @@ struct EventPair {
 
 }  // namespace
 
-// ---- a group of contexts whose slab-path step launches are issued together (launch_combiner.h): the lanes of
-//      mamdr_amd/parallel.py in batch mode.  All members share ONE stream; reference counted (creator + members).
-struct mamdr_group {
-    mamdr::LaunchCombiner comb;
-    hipStream_t stream;
-    std::atomic<int> refs{1};
-    mamdr_group(int n, hipStream_t s);
-};
-static void group_release(mamdr_group* g) {
-    if (g && g->refs.fetch_sub(1) == 1) delete g;
-}
-
 struct mamdr_ctx {
-    mamdr_group* group = nullptr;   // mamdr_group_join
-    int member = -1;
-    bool group_held = false;        // mamdr_group_hold: active (waited for) between training calls as well
     mamdr_config cfg;
     hipStream_t stream = nullptr;
     DenseLayout L;
@@ -720,59 +703,6 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     return MAMDR_OK;
 }
 
-// the combined launches of a group (called by the member that completes a rendezvous, with the group locked): up to
-// MULTI_MAX descriptors of one kind per launch; a single descriptor takes the single-context launcher (same bodies)
-static void group_flush(void* user, int kind, int n, const int* /*members*/, const void* const* descs) {
-    mamdr_group* g = static_cast<mamdr_group*>(user);
-    for (int i0 = 0; i0 < n; i0 += MULTI_MAX) {
-        const int k = n - i0 < MULTI_MAX ? n - i0 : MULTI_MAX;
-        if (kind == COMB_TOWER) {
-            if (k == 1) { launch_tower_train(*static_cast<const TowerArgs*>(descs[i0]), g->stream); continue; }
-            MultiTowerArgs m;
-            m.n = k;
-            m.first[0] = 0;
-            for (int j = 0; j < k; ++j) {
-                m.a[j] = *static_cast<const TowerArgs*>(descs[i0 + j]);
-                m.first[j + 1] = m.first[j] + (m.a[j].rows + TILE_ROWS - 1) / TILE_ROWS;
-            }
-            for (int j = k; j < MULTI_MAX; ++j) m.first[j + 1] = m.first[k];
-            launch_tower_multi(m, g->stream);
-        } else if (kind == COMB_WGRAD) {
-            if (k == 1) { launch_wgrad(*static_cast<const WgradArgs*>(descs[i0]), g->stream, nullptr); continue; }
-            MultiWgradArgs m;
-            m.n = k;
-            m.first[0] = 0;
-            for (int j = 0; j < k; ++j) {
-                m.a[j] = *static_cast<const WgradArgs*>(descs[i0 + j]);
-                m.first[j + 1] = m.first[j] + wgrad_block_count(m.a[j]);
-            }
-            for (int j = k; j < MULTI_MAX; ++j) m.first[j + 1] = m.first[k];
-            launch_wgrad_multi(m, g->stream);
-        } else {
-            if (k == 1) { launch_update(*static_cast<const UpdateArgs*>(descs[i0]), g->stream, nullptr); continue; }
-            MultiUpdateArgs m;
-            m.n = k;
-            m.first[0] = 0;
-            for (int j = 0; j < k; ++j) {
-                m.a[j] = *static_cast<const UpdateArgs*>(descs[i0 + j]);
-                m.first[j + 1] = m.first[j] + update_block_count(m.a[j]);
-            }
-            for (int j = k; j < MULTI_MAX; ++j) m.first[j + 1] = m.first[k];
-            launch_update_multi(m, g->stream);
-        }
-    }
-}
-mamdr_group::mamdr_group(int n, hipStream_t s) : comb(n, group_flush, this), stream(s) {}
-namespace {
-// a member is ACTIVE (waited for by the others) exactly while this object lives: every return path of a training call
-struct GroupScope {
-    mamdr_ctx* c;
-    bool on;
-    GroupScope(mamdr_ctx* c_, bool on_) : c(c_), on(on_ && !c_->group_held) { if (on) c->group->comb.enter(c->member); }
-    ~GroupScope() { if (on) c->group->comb.leave(c->member); }
-};
-}  // namespace
-
 extern char** environ;
 namespace mamdr {
 // once per process (thread-safe static initialiser): a MAMDR_* name in the environment that nobody reads is reported
@@ -1030,60 +960,8 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     return MAMDR_OK;
 }
 
-int mamdr_group_create(int32_t n_members, void* stream, mamdr_group** out) {
-    if (!out) return fail(MAMDR_EINVAL, "null argument");
-    *out = nullptr;
-    if (n_members < 1 || n_members > LaunchCombiner::MAX_MEMBERS)
-        return fail(MAMDR_EINVAL, "a group has 1 .. %d members, not %d", LaunchCombiner::MAX_MEMBERS, n_members);
-    mamdr_group* g = new (std::nothrow) mamdr_group(n_members, static_cast<hipStream_t>(stream));
-    if (!g) return fail(MAMDR_EHIP, "out of host memory");
-    if (const char* ev = getenv("MAMDR_GROUP_WAIT_US")) g->comb.set_wait_ns((int64_t)(atof(ev) * 1000.0));
-    *out = g;
-    return MAMDR_OK;
-}
-int mamdr_group_destroy(mamdr_group* g) {
-    group_release(g);           // (freed when the last member has left as well)
-    return MAMDR_OK;
-}
-int mamdr_group_join(mamdr_group* g, mamdr_ctx* c, int32_t member) {
-    if (check_ctx(c)) return MAMDR_EINVAL;
-    if (!g) return fail(MAMDR_EINVAL, "null group");
-    if (member < 0 || member >= g->comb.members()) return fail(MAMDR_EINVAL, "member %d of a group of %d", member, g->comb.members());
-    if (c->stream != g->stream) return fail(MAMDR_ESTATE, "a context joins the group of ITS stream (all members on one stream)");
-    if (c->group) return fail(MAMDR_ESTATE, "the context is a member of a group already");
-    g->refs.fetch_add(1);
-    c->group = g;
-    c->member = member;
-    return MAMDR_OK;
-}
-int mamdr_group_leave(mamdr_ctx* c) {
-    if (check_ctx(c)) return MAMDR_EINVAL;
-    if (c->group_held) (void)mamdr_group_hold(c, 0);
-    mamdr_group* g = c->group;
-    c->group = nullptr;
-    c->member = -1;
-    group_release(g);
-    return MAMDR_OK;
-}
-int mamdr_group_hold(mamdr_ctx* c, int32_t on) {
-    if (check_ctx(c)) return MAMDR_EINVAL;
-    if (!c->group) return MAMDR_OK;
-    if (on && !c->group_held) {
-        c->group->comb.enter(c->member);
-        c->group_held = true;
-    } else if (!on && c->group_held) {
-        c->group_held = false;
-        c->group->comb.leave(c->member);
-    }
-    return MAMDR_OK;
-}
-int64_t mamdr_group_launches(const mamdr_group* g, int32_t carried) {
-    return !g ? 0 : (int64_t)(carried ? g->comb.carried() : g->comb.launches());
-}
-
 int mamdr_destroy(mamdr_ctx* c) {
     if (!c) return MAMDR_OK;
-    if (c->group) (void)mamdr_group_leave(c);
     for (int k = 0; k < MAMDR_KERNEL_COUNT; ++k)
         for (EventPair& p : c->ev[k]) {
             if (p.own_a) (void)hipEventDestroy(p.a);
@@ -1426,12 +1304,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
 
     // small batches run the 4-row-tile tower (all CUs busy); it needs transposed W1 / W2 copies:
     // refreshed here because the caller may have assigned new weights, kept current by k_update
-    // member of a group (mamdr_group_join): the three launches of a slab-path step of the frozen-table mlp tower are issued
-    // TOGETHER with those of the other members that are stepping right now (k_tower_multi / k_wgrad_multi / k_update_multi:
-    // the same bodies) -- that path for every batch size, the 16-row tower for every batch, no rider workgroups
-    const bool grp = c->group != nullptr && !c->profile && !c->cfg.emb_trainable && !c->star && !c->deepfm && !c->pnn && !c->nfm;
-    GroupScope group_scope(c, grp);
-    const bool may_use4 = !c->star && c->tower_tile != 16 && !grp;
+    const bool may_use4 = !c->star && c->tower_tile != 16;
     // ... only when a step of THIS call is small enough for that tower (the rows of a pass's steps never grow: the
     // last one is the smallest) -- a 4,096-row call over a domain without a short last batch needs no copies at all
     bool need_wT = false;
@@ -1447,7 +1320,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
     prof_break(c);
     // one path per call (the pending domain-table step lives across the steps of a call): k_wgrad_adam for batches up
     // to fused_max_batch rows (measured: 27.3 vs 29.5 us / step at 1,024 rows, a tie at 4,096)
-    const bool fused = !grp && c->fused && (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch;
+    const bool fused = c->fused && (batch + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS <= c->fused_max_batch;
     // k_wgrad_adam path: the domain table's step of the previous step -- of this call or, between two Adam calls, of
     // the previous call (c->dm_pending); every other kind of call starts from the materialised table
     DmStep& dm_pending = c->dm_pending;
@@ -1667,9 +1540,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             // the stamps of the SECOND launch show the kernel with its own code and data still where the first left them
             if (use4) (void)launch_tower4_train(ta, c->stream);
 #endif
-            int t4e = 0;
-            if (grp && !use4 && tower_multi_ok(ta)) c->group->comb.submit(c->member, COMB_TOWER, &ta);
-            else t4e = use4 ? launch_tower4_train(ta, c->stream) : (launch_tower_train(ta, c->stream), 0);
+            const int t4e = use4 ? launch_tower4_train(ta, c->stream) : (launch_tower_train(ta, c->stream), 0);
             if (t4e == T4_E_W2D_LDS) return fail(MAMDR_EHIP, "k_tower4<W2D> was refused its LDS limit (hipFuncSetAttribute)");
             if (t4e) return fail(MAMDR_ESTATE, "w2_direct without the W1-image instance of k_tower4 (step %lld of the call)", (long long)s);
         }
@@ -1838,7 +1709,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         // mamdr_kernels.h) -- in k_wgrad's launch (default since round 5), or (MAMDR_GATHER_PF_IN=update) in k_update's
         GatherPf pf;
         memset(&pf, 0, sizeof(pf));
-        if (!tail && !grp && c->gather_pf && !c->cfg.emb_trainable && !c->star && s + 1 < n_steps) {
+        if (!tail && c->gather_pf && !c->cfg.emb_trainable && !c->star && s + 1 < n_steps) {
             const int64_t nb = row_base + batch;
             const int nrows = (int)std::min<int64_t>(batch, pass_rows - nb);
             const int npad = (nrows + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
@@ -1864,7 +1735,6 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
             if (tail) launch_wgrad_reduce(wa, tea, pre ? &nr : nullptr, nullptr, c->stream);
-            else if (grp) c->group->comb.submit(c->member, COMB_WGRAD, &wa);
             else {
                 if (c->wgrad_pairs && !c->star && !c->cfg.emb_trainable && groups > 8)
                     paired = launch_wgrad_pairs(wa, c->stream, c->gather_pf_in_wgrad ? &pf : nullptr);
@@ -1921,8 +1791,7 @@ int mamdr_train_steps_n(mamdr_ctx* c, int domain, const int32_t* d_perm, int64_t
             } else {
                 // frozen tables, another step of this call follows on the 16-row tower: its gather is touched by riders
                 // (GatherPf, mamdr_kernels.h)
-                if (grp) c->group->comb.submit(c->member, COMB_UPDATE, &ua);
-                else launch_update(ua, c->stream, c->gather_pf_in_wgrad ? nullptr : &pf);
+                launch_update(ua, c->stream, c->gather_pf_in_wgrad ? nullptr : &pf);
             }
         }
         if (c->cfg.emb_trainable && !tail) emb_post_step(c, optimizer, ua.alpha, omb1, omb2, rows);

@@ -247,15 +247,6 @@ struct UpdateArgs {
 #endif
 };
 
-// ---- the step kernels of up to MULTI_MAX contexts in one launch (k_tower_multi / k_wgrad_multi / k_update_multi):
-// lane l owns workgroups [first[l], first[l + 1]) and runs a[l]
-constexpr int MULTI_MAX = 4;
-struct MultiTowerArgs { int n; int first[MULTI_MAX + 1]; TowerArgs a[MULTI_MAX]; };
-struct MultiWgradArgs { int n; int first[MULTI_MAX + 1]; WgradArgs a[MULTI_MAX]; };
-struct MultiUpdateArgs { int n; int first[MULTI_MAX + 1]; UpdateArgs a[MULTI_MAX]; };
-static_assert(sizeof(MultiTowerArgs) <= 4096 && sizeof(MultiWgradArgs) <= 4096 && sizeof(MultiUpdateArgs) <= 4096,
-              "kernel arguments travel by value (4 KB)");
-
 // pre-update snapshot of W0[256:384, :] for k_wgrad_adam, by the LAST wave of every tower workgroup (it is not on
 // the row bookkeeping's critical path): float4 i for i in this workgroup's share
 __device__ __forceinline__ void tower_snapshots(const TowerArgs& a, int n_threads, int n_tiles) {
@@ -615,12 +606,6 @@ void launch_tower_eval(const TowerArgs& a, hipStream_t s);
 constexpr int T4_E_W2D_LDS = 1;        // k_tower4<.., W2D> was refused its LDS limit
 constexpr int T4_E_W2D_STATE = 2;      // w2_direct asked of a launch that does not take the W1-image instance
 int launch_tower4_train(const TowerArgs& a, hipStream_t s);
-void launch_tower_multi(const MultiTowerArgs& m, hipStream_t s);
-bool tower_multi_ok(const TowerArgs& a);               // the instance launch_tower_train would run is k_tower_multi's
-void launch_wgrad_multi(const MultiWgradArgs& m, hipStream_t s);
-int wgrad_block_count(const WgradArgs& a);
-void launch_update_multi(const MultiUpdateArgs& m, hipStream_t s);
-int update_block_count(const UpdateArgs& a);
 // the W1-image instance of the pre-gathered tower can run (its LDS limit was granted): grids of up to one tile per CU
 bool tower4_w1l_ready();
 bool tower4_takes_w1l(int64_t rows, int no_w1l);      // launch_tower4_train's choice of the W1-image instance for a batch

@@ -541,12 +541,10 @@ constexpr int PFB2 = 2, PFB1 = MAMDR_PFB1, PFB0 = 4;
 // DXW: width of the input gradient written to a.dxe: 0 none, 256 = [user | item] (trainable tables),
 // 384 = all three fields (Star: PartitionedNorm's backward needs d loss / d normalised input).
 // FZ: the k_wgrad_adam path's duties compiled in (pre-gathered passes, the pending domain-table step, the W0 snapshot)
-// (the kernel's body as a device function of (arguments, tile, tiles of the launch): k_tower runs it for its own grid,
-// k_tower_multi -- the towers of several contexts in ONE launch, round 6 -- for the slice of the grid that belongs to a lane)
 template <bool TRAIN, int DXW, bool FM, bool FZ = false>
-__device__ __forceinline__ void tower_body(const int32_t* __restrict__ k_perm, const int64_t k_row_base,
-                                           const float* __restrict__ k_w0, const float* __restrict__ k_b0,
-                                           const int k_rows, const TowerArgs& a, const int tile, const int n_tiles) {
+__global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restrict__ k_perm, const int64_t k_row_base,
+                                                        const float* __restrict__ k_w0, const float* __restrict__ k_b0,
+                                                        const int k_rows, const TowerArgs a) {
     // (leading scalar arguments = what the prologue's first loads need, preloaded into SGPRs with the wave -- see
     // k_tower4 -- `a` carries the same values)
     static_assert(!FZ || (TRAIN && DXW == 0 && !FM), "k_wgrad_adam serves the frozen-table mlp tower");
@@ -554,6 +552,8 @@ __device__ __forceinline__ void tower_body(const int32_t* __restrict__ k_perm, c
     constexpr int DXN = DX ? DXW : 2 * EMB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int n_tiles = (int)gridDim.x;
     const int r0 = tile * TILE_ROWS;
     int* rowi = reinterpret_cast<int*>(smem + ROWI_OFF);
     // [0,16) label, [16,32) DeepFM fm + linear term, [32,40) per-wave loss, [48,64) DeepFM dlogit
@@ -849,34 +849,6 @@ __device__ __forceinline__ void tower_body(const int32_t* __restrict__ k_perm, c
         }
     }
     STAMP(9);
-}
-template <bool TRAIN, int DXW, bool FM, bool FZ = false>
-__global__ __launch_bounds__(TOWER_THREADS) void k_tower(const int32_t* __restrict__ k_perm, const int64_t k_row_base,
-                                                        const float* __restrict__ k_w0, const float* __restrict__ k_b0,
-                                                        const int k_rows, const TowerArgs a) {
-    tower_body<TRAIN, DXW, FM, FZ>(k_perm, k_row_base, k_w0, k_b0, k_rows, a, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// ---- the step kernels of SEVERAL contexts in one launch (round 6: mamdr_group_*, the lanes of mamdr_amd/parallel.py).
-// One 1,024-row step fills a quarter of the device with its 16-row tower (64 workgroups) and spreads 34 x 4 weight-gradient
-// workgroups over it; four independent contexts launched one after the other on streams of their own reach the packing
-// bound of those launches.  Launched TOGETHER -- workgroup b belongs to the lane whose block range
-// holds b and runs that lane's arguments, the same bodies, hence the same bits -- four 1,024-row steps have the shapes of
-// one 4,096-row step.  Frozen-table mlp tower on the slab path (tower -> k_wgrad -> k_update).
-__global__ __launch_bounds__(TOWER_THREADS) void k_tower_multi(const MultiTowerArgs m) {
-    int lane = 0;
-#pragma unroll
-    for (int l = 1; l < MULTI_MAX; ++l) lane += (l < m.n && (int)blockIdx.x >= m.first[l]) ? 1 : 0;
-    const TowerArgs& a = m.a[lane];
-    tower_body<true, 0, false, false>(a.perm, a.row_base, a.dense + a.L.w0, a.dense + a.L.b0, a.rows, a,
-                                      (int)blockIdx.x - m.first[lane], m.first[lane + 1] - m.first[lane]);
-}
-void launch_tower_multi(const MultiTowerArgs& m, hipStream_t s) {
-    MAMDR_LAUNCH(k_tower_multi, dim3(m.first[m.n]), dim3(TOWER_THREADS), tower_lds_bytes(), s, m);
-}
-// the instance launch_tower_train would choose is the one k_tower_multi runs
-bool tower_multi_ok(const TowerArgs& a) {
-    return !a.deepfm && !a.dxe && !(a.xpre || a.dm_snap_out || a.dms.snap || a.w0dom_snap) && !a.pn_aff;
 }
 
 void launch_tower_train(const TowerArgs& a, hipStream_t s) {
@@ -1256,13 +1228,6 @@ __global__ __launch_bounds__(256) void k_wgrad(WGRAD_EARLY_PARAMS, const WgradAr
     WGRAD_EARLY_APPLY(g, g0);
     wgrad_body(g, (int)blockIdx.x, red);
 }
-__global__ __launch_bounds__(256) void k_wgrad_multi(const MultiWgradArgs m) {
-    __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
-    int lane = 0;
-#pragma unroll
-    for (int l = 1; l < MULTI_MAX; ++l) lane += (l < m.n && (int)blockIdx.x >= m.first[l]) ? 1 : 0;
-    wgrad_body(m.a[lane], (int)blockIdx.x - m.first[lane], red);
-}
 // k_wgrad and k_emb_reduce only need the tower's outputs and write disjoint state: one launch, the table
 // workgroups behind the weight-gradient ones (they share CUs instead of queueing behind each other)
 // ... and the NEXT step's k_emb_rows (n_rows workgroups): it writes the other half of the row-id / map double
@@ -1453,10 +1418,6 @@ bool launch_wgrad_pairs(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
 #else
 bool launch_wgrad_pairs(const WgradArgs&, hipStream_t, const GatherPf*) { return false; }
 #endif
-int wgrad_block_count(const WgradArgs& a) { return wgrad_blocks(a); }
-void launch_wgrad_multi(const MultiWgradArgs& m, hipStream_t s) {
-    MAMDR_LAUNCH(k_wgrad_multi, dim3(m.first[m.n]), dim3(256), 0, s, m);
-}
 void launch_wgrad(const WgradArgs& a, hipStream_t s, const GatherPf* pf) {
     if (pf && pf->n_tiles > 0) {        // (the riders of the next step's gather in THIS launch: default since round 5)
         const int n_wgrad = wgrad_blocks(a);
@@ -1910,22 +1871,6 @@ __global__ __launch_bounds__(256) void k_update_lin(UPDATE_EARLY_PARAMS, const U
 static int update_blocks(const UpdateArgs& a) {
     const int n_vec_wgs = (a.count4 - a.dm_count / 4 + 255) / 256;
     return n_vec_wgs + (a.dm_count / EMB) * DM_CBLOCKS + (a.dm_copy ? W0LIN_WGS : 0);
-}
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_update_multi(const MultiUpdateArgs m) {
-    __shared__ __attribute__((aligned(16))) float s_l[64 * W0LIN_COLS];
-    int lane = 0;
-#pragma unroll
-    for (int l = 1; l < MULTI_MAX; ++l) lane += (l < m.n && (int)blockIdx.x >= m.first[l]) ? 1 : 0;
-    if constexpr (WIDE) update_body(m.a[lane], (int)blockIdx.x - m.first[lane], s_l);
-    else update_body_n(m.a[lane], (int)blockIdx.x - m.first[lane], s_l);
-}
-int update_block_count(const UpdateArgs& a) { return update_blocks(a); }
-void launch_update_multi(const MultiUpdateArgs& m, hipStream_t s) {
-    bool wide = false;          // (the two forms add the slabs in the same order: same bits; the wide one pays above 8 row groups)
-    for (int l = 0; l < m.n; ++l) wide = wide || m.a[l].n_groups > 8;
-    if (wide) MAMDR_LAUNCH(k_update_multi<true>, dim3(m.first[m.n]), dim3(256), 0, s, m);
-    else MAMDR_LAUNCH(k_update_multi<false>, dim3(m.first[m.n]), dim3(256), 0, s, m);
 }
 void launch_update(const UpdateArgs& a, hipStream_t s, const GatherPf* pf) {
     const int n_update = update_blocks(a);

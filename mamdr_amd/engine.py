@@ -209,7 +209,6 @@ class TowerEngine(FlatVectorOps):
             tower_tile = 16 if (group is not None and group.n >= 4 and tower in ("mlp", "deepfm", "wdl")) else 0
         if tower_tile:
             self.set_tower_tile(tower_tile)
-        self._group = None
         self.emb_trainable = bool(emb_trainable)
         self.tower = tower
         self.n_params = int(self.lib.mamdr_param_count(self.ctx))
@@ -238,10 +237,6 @@ class TowerEngine(FlatVectorOps):
         self.data = {}          # (domain, split) -> dict of device columns
         self._hist = torch.zeros(2 * 501, dtype=torch.int32, device=self.device)
         self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
-        # a lane of a LaneGroup in batch mode: the step launches are shared with the other lanes' (mamdr_group_join)
-        from . import parallel as _parallel
-        if _parallel.lanes() is not None:
-            _parallel.lanes().join_step_group(self)
 
     # The live state is only handed out synchronised: with trainable tables the library advances rows that
     # no batch touched lazily (mamdr_sync_tables in include/mamdr_hip.h); every read or replacement of the
@@ -472,14 +467,10 @@ class TowerEngine(FlatVectorOps):
         n = self.n_rows(domain, split)
         preds = torch.empty(n, dtype=torch.float32, device=self.device) if want_preds else None
         split_id = {"train": L.SPLIT_TRAIN, "val": L.SPLIT_VAL, "test": L.SPLIT_TEST}[split]
-        held = self._group is not None and getattr(self, "_held", False)
-        L.check(self.lib.mamdr_group_hold(self.ctx, 0))       # (an evaluation blocks on the device: nobody waits for this member)
         L.check(self.lib.mamdr_eval_domain(self.ctx, domain, split_id, self.eval_batch, _ptr(self._loss1),
                                            _ptr(self._hist), _ptr(preds)))
         hist = self._hist.cpu().numpy().astype(np.int64)
         loss = float(self._loss1.cpu().numpy()[0])
-        if held:
-            L.check(self.lib.mamdr_group_hold(self.ctx, 1))
         auc, _ = auc_from_histogram(hist)
         if want_preds:
             return loss, auc, hist.reshape(2, 501), preds.cpu().numpy()
@@ -506,16 +497,6 @@ class TowerEngine(FlatVectorOps):
         self._ema = {"momentum": float(momentum), "step": 0, "biased": self.new_vector(), "scratch": self.new_vector()}
         if self._acc is not None:
             self.bind_accumulator(self._acc)
-
-    def join_group(self, group, member):
-        """mamdr_group_join: this context's slab-path step launches are issued together with those of the group's other
-        members that are stepping at the same moment (all members on one stream, each driven by its own host thread)."""
-        L.check(self.lib.mamdr_group_join(group, self.ctx, int(member)))
-        self._group = group
-
-    def group_hold(self, on):
-        self._held = bool(on)
-        L.check(self.lib.mamdr_group_hold(self.ctx, 1 if on else 0))
 
     def set_counters(self, optimizer_steps, dropout_steps):
         """restore the Adam step count (with TF's running beta powers) and the dropout stream's position

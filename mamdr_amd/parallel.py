@@ -47,7 +47,7 @@ class LaneGroup(object):
     for the publishers' events and reads; a second round of events keeps a publisher from overwriting what a reader has
     not read yet.  No host synchronisation with the device anywhere: the lanes' streams stay asynchronous."""
 
-    def __init__(self, n, outer=None, sum_block=None, batch=None):
+    def __init__(self, n, outer=None, sum_block=None):
         """outer = (rank, world size) of the process group this process is a rank of (default: read from
         torch.distributed; (0, 1) without one).  sum_block (tests): the all-reduce adds the lanes in blocks of that many --
         the order in which `sum_block` lanes x n / sum_block processes add up -- instead of one run in lane order."""
@@ -58,15 +58,6 @@ class LaneGroup(object):
         self.sum_block = int(sum_block) if sum_block else self.n
         if self.n % self.sum_block:
             raise ValueError("sum_block %d does not divide %d lanes" % (self.sum_block, self.n))
-        # batch (train.lanes_batch / MAMDR_LANES_BATCH=1; round 6): the lanes share ONE stream and their engines join a
-        # mamdr_group -- the step launches of the lanes that are stepping at the same moment are issued as one launch each
-        # (include/mamdr_hip.h, "several contexts stepping side by side")
-        import os
-        if batch is None:
-            batch = os.environ.get("MAMDR_LANES_BATCH", "0") not in ("", "0")
-        self.batch = bool(batch) and self.n > 1
-        self._step_group = None
-        self._step_lock = threading.Lock()
         self.barrier = threading.Barrier(self.n)
         self.slots = [None] * self.n
         self.ev = [None] * self.n
@@ -86,7 +77,7 @@ class LaneGroup(object):
             try:
                 if device is not None:
                     torch.cuda.set_device(device)
-                    with torch.cuda.stream(_lane_stream(device, 0 if self.batch else lane)):
+                    with torch.cuda.stream(_lane_stream(device, lane)):
                         results[lane] = fn(lane)
                         torch.cuda.current_stream().synchronize()
                 else:
@@ -95,13 +86,6 @@ class LaneGroup(object):
                 errors[lane] = e
                 self.barrier.abort()
             finally:
-                held = getattr(_lane, "held", None)
-                if held is not None:
-                    try:
-                        held.group_hold(False)
-                    except Exception:
-                        pass
-                    _lane.held = None
                 _lane.group, _lane.rank = None, 0
         threads = [threading.Thread(target=body, args=(l,), name="mamdr-lane-%d" % l) for l in range(self.n)]
         import sys
@@ -120,53 +104,9 @@ class LaneGroup(object):
             raise first[0]
         return results
 
-    def join_step_group(self, eng):
-        """batch mode: the engine of the calling lane joins the lanes' mamdr_group (created by the first lane that asks, on
-        the lanes' common stream).  Engines without step kernels to share (the generic-layer engine) are left alone."""
-        if not self.batch or not hasattr(eng, "join_group"):
-            return
-        import ctypes as C
-        import os
-        from . import _lib as L
-        with self._step_lock:
-            if self._step_group is None:
-                h = C.c_void_p()
-                L.check(L.load().mamdr_group_create(self.n, C.c_void_p(eng.stream.cuda_stream), C.byref(h)))
-                self._step_group = h
-        eng.join_group(self._step_group, _lane.rank)
-        # MAMDR_LANES_HOLD=1 (measurement switch): the lane counts as stepping between its training calls too -- released
-        # around every host barrier of the lanes (every collective passes one) and around evaluations
-        if os.environ.get("MAMDR_LANES_HOLD", "0") not in ("", "0"):
-            _lane.held = eng
-            eng.group_hold(True)
-
-    def step_group_launches(self):
-        """(launches issued, step launches they carried) of the lanes' mamdr_group so far, or None."""
-        if self._step_group is None:
-            return None
-        from . import _lib as L
-        lib = L.load()
-        return int(lib.mamdr_group_launches(self._step_group, 0)), int(lib.mamdr_group_launches(self._step_group, 1))
-
-    def __del__(self):
-        try:
-            if self._step_group is not None:
-                from . import _lib as L
-                L.load().mamdr_group_destroy(self._step_group)
-                self._step_group = None
-        except Exception:
-            pass
-
     # -- the collectives (called through the module functions below, from lane threads only)
     def wait(self):
-        held = getattr(_lane, "held", None)
-        if held is not None:
-            held.group_hold(False)
-        try:
-            self.barrier.wait()
-        finally:
-            if held is not None:
-                held.group_hold(True)
+        self.barrier.wait()
 
     def _publish(self, rank, obj, cuda):
         self.slots[rank] = obj

@@ -162,71 +162,3 @@ def test_run_entry_on_lanes_with_the_other_towers(tmp_path, cfg_file, name, lane
     avg_loss, avg_auc, domain_loss, domain_auc = cli.main(cfg, on_model=built.append)
     assert len(built) == lanes and len(domain_auc) == 10 and np.isfinite(avg_loss)
     assert avg_auc > 0.52, (name, avg_auc)
-
-
-def _lane_pipeline(tmp_path, tag, lanes, batch_mode, name="mlp_meta_mamdr_finetune"):
-    """cli.main of a small Taobao-10 config on `lanes` lanes -> (per-domain AUC, sorted hashes of the lanes' live models,
-    step-launch statistics of the lanes' mamdr_group or None)."""
-    import copy
-    import hashlib
-    import json
-    import os
-    from mamdr_amd import cli, parallel
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "config", "Taobao-10", "deepctr_DN+DR.json")) as f:
-        cfg = copy.deepcopy(json.load(f))
-    cfg["model"]["name"] = name
-    cfg["train"].update(epoch=2, patience=2, sample_num=2, meta_learning_rate=0.5, lanes=lanes, lanes_batch=bool(batch_mode),
-                        result_save_path=str(tmp_path / (tag + "_result")), checkpoint_path=str(tmp_path / (tag + "_ckpt")))
-    cfg["dataset"].update(batch_size=256, synthetic="taobao10", synthetic_scale=0.1)
-    built, groups = [], []
-
-    def on_model(m):
-        built.append(m)
-        if parallel.lanes() is not None and parallel.lanes() not in groups:
-            groups.append(parallel.lanes())
-    res = cli.main(cfg, on_model=on_model)
-    ws = [m.model.get_weights() for m in built]
-    torch.cuda.synchronize()
-    sha = sorted(hashlib.sha1(w.cpu().numpy().tobytes()).hexdigest() for w in ws)
-    stats = groups[0].step_group_launches() if groups else None
-    return {int(k): float(v) for k, v in res[3].items()}, sha, stats
-
-
-def test_batched_lane_steps_equal_the_unbatched_slab_path_bit_for_bit(tmp_path, monkeypatch):
-    """mamdr_group_* (round 6): four lanes on ONE stream whose step launches are issued together (k_tower_multi /
-    k_wgrad_multi / k_update_multi behind csrc/launch_combiner.h) run the bodies of the single launches on each lane's own
-    arguments -- so a batched run must equal, bit for bit, the same four lanes launching for themselves on the same step
-    path (slab path, 16-row tower, no rider workgroups: MAMDR_FUSED=0 MAMDR_TOWER_TILE=16 MAMDR_NO_GATHER_PF=1): per-domain
-    AUCs of the whole run.py pipeline (train -> validate -> test -> finetune) and every lane's live model.  And launches
-    really were shared (more step launches carried than launches issued)."""
-    _need_gpu()
-    for k in ("MAMDR_FUSED", "MAMDR_TOWER_TILE", "MAMDR_NO_GATHER_PF", "MAMDR_LANES_BATCH", "MAMDR_LANES"):
-        monkeypatch.delenv(k, raising=False)
-    auc_b, sha_b, stats = _lane_pipeline(tmp_path, "batched", 4, True)
-    assert stats is not None and stats[0] > 0 and stats[1] > stats[0], stats          # launches really were shared
-    monkeypatch.setenv("MAMDR_FUSED", "0")
-    monkeypatch.setenv("MAMDR_TOWER_TILE", "16")
-    monkeypatch.setenv("MAMDR_NO_GATHER_PF", "1")
-    auc_u, sha_u, stats_u = _lane_pipeline(tmp_path, "unbatched", 4, False)
-    assert stats_u is None
-    assert auc_b == auc_u, (auc_b, auc_u)
-    assert sha_b == sha_u
-    assert len(auc_b) == 10 and np.mean(list(auc_b.values())) > 0.6
-    print("batched lanes: %d launches carried %d step launches (%.2f per launch); equal to the unbatched slab path bit for bit" % (
-        stats[0], stats[1], stats[1] / stats[0]))
-
-
-def test_batched_lanes_survive_ragged_calls_and_one_lane_groups(tmp_path, monkeypatch):
-    """the rendezvous under lanes that step unequal numbers of passes (Domain Negotiation: 10 domains over 3 lanes, one closing
-    target pass on every lane) and a group of ONE lane (every launch carries one step: the single launchers)."""
-    _need_gpu()
-    for k in ("MAMDR_FUSED", "MAMDR_TOWER_TILE", "MAMDR_NO_GATHER_PF", "MAMDR_LANES_BATCH", "MAMDR_LANES"):
-        monkeypatch.delenv(k, raising=False)
-    auc3, sha3, st3 = _lane_pipeline(tmp_path, "dn3", 3, True, name="mlp_meta_domain_negotiation_finetune")
-    assert st3 is not None and st3[1] >= st3[0] > 0 and len(auc3) == 10
-    monkeypatch.setenv("MAMDR_FUSED", "0")
-    monkeypatch.setenv("MAMDR_TOWER_TILE", "16")
-    monkeypatch.setenv("MAMDR_NO_GATHER_PF", "1")
-    auc3u, sha3u, _ = _lane_pipeline(tmp_path, "dn3u", 3, False, name="mlp_meta_domain_negotiation_finetune")
-    assert auc3 == auc3u and sha3 == sha3u
