@@ -127,12 +127,6 @@ int mamdr_abi_version(void);
  * mamdr_env_unknown returns how many there were.  (ABI 18) */
 const char* mamdr_env_switches(void);
 int mamdr_env_unknown(void);
-/* A HIP stream whose kernels run on the given compute units only (hipExtStreamCreateWithCUMask; n_words x 32 bits, bit i = CU
- * i), and its release.  For callers that drive several contexts side by side on one device (the lanes of
- * mamdr_amd/parallel.py): a context created on such a stream keeps to its partition.  No reference counterpart (the
- * reference is one TF session on one device, run.py:71-89).  (ABI 18) */
-int mamdr_stream_create_masked(uint32_t n_words, const uint32_t* cu_mask, void** out_stream);
-int mamdr_stream_destroy(void* stream);
 
 /* --- lifetime: replaces DeepCTR(dataset, config) / build_model + compile
  *     (model_zoo/DeepCTR/deepctr.py:20-61). */

@@ -74,8 +74,6 @@ SIGNATURES = {
     "mamdr_abi_version": (C.c_int, []),
     "mamdr_env_switches": (C.c_char_p, []),
     "mamdr_env_unknown": (C.c_int, []),
-    "mamdr_stream_create_masked": (C.c_int, [_U32, _VP, C.POINTER(_VP)]),
-    "mamdr_stream_destroy": (C.c_int, [_VP]),
     "mamdr_create": (C.c_int, [C.POINTER(Config), _VP, C.POINTER(_VP)]),
     "mamdr_destroy": (C.c_int, [_VP]),
     "mamdr_param_count": (_I64, [_VP]),

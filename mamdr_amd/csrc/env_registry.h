@@ -49,7 +49,6 @@ static const EnvSwitch kEnvSwitches[] = {
     // ---- Python host (mamdr_amd/*.py)
     {"MAMDR_LIB_PATH", "host,bench", "load this build of the library instead of mamdr_amd/libmamdr_hip.so (tools/build_variant.sh)"},
     {"MAMDR_LANES", "host", "lanes per process (overrides train.lanes)"},
-    {"MAMDR_LANE_CUS", "host", "<n> / <n>i: every lane's stream confined to n CUs, consecutive / interleaved (measurement switch, default off)"},
     {"MAMDR_SHARE_GPU", "host", "1: every rank of run.py on device 0 over gloo (testing on a 1-GPU box)"},
     {"MAMDR_COMM_TIMEOUT", "host", "seconds: process-group timeout of run.py"},
     {"MAMDR_TAIL_SYNC", "host", "sum: tensors outside theta / phi combined by sum instead of the step-weighted mean"},

@@ -749,21 +749,6 @@ const char* mamdr_env_switches(void) {
 }
 int mamdr_env_unknown(void) { return mamdr::env_warn_unknown(); }
 
-// ---- a stream confined to a set of CUs (hipExtStreamCreateWithCUMask): the lanes of mamdr_amd/parallel.py can each be given a
-//      partition of the device, so that the launches of different lanes run side by side on their own CUs instead of
-//      interleaving workgroups on all of them.  n_words x 32 bits, bit i = CU i as the runtime numbers them.
-int mamdr_stream_create_masked(uint32_t n_words, const uint32_t* cu_mask, void** out) {
-    if (!out || !cu_mask || n_words == 0) return fail(MAMDR_EINVAL, "mamdr_stream_create_masked: null argument");
-    hipStream_t s = nullptr;
-    HIP_TRY(hipExtStreamCreateWithCUMask(&s, n_words, cu_mask));
-    *out = s;
-    return MAMDR_OK;
-}
-int mamdr_stream_destroy(void* stream) {
-    if (!stream) return MAMDR_OK;
-    HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)));
-    return MAMDR_OK;
-}
 
 int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     (void)mamdr::env_warn_unknown();

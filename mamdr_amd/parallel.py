@@ -241,35 +241,8 @@ def _lane_stream(device, lane):
     for the second group of a process)."""
     key = (device, lane)
     if key not in _lane_streams:
-        _lane_streams[key] = _masked_stream(device, lane) or torch.cuda.Stream(device=device)
+        _lane_streams[key] = torch.cuda.Stream(device=device)
     return _lane_streams[key]
-
-
-def _masked_stream(device, lane):
-    """MAMDR_LANE_CUS=<n> (a measurement switch, default off): lane k's stream is confined to n of the device's CUs
-    (mamdr_stream_create_masked = hipExtStreamCreateWithCUMask) -- `n` consecutive CU numbers from k * n, or with
-    MAMDR_LANE_CUS=<n>i every (CUs / n)-th CU from k: the lanes' launches then run side by side on partitions of the
-    device instead of interleaving their workgroups on all CUs."""
-    import os
-    spec = os.environ.get("MAMDR_LANE_CUS", "")
-    if not spec or spec == "0":
-        return None
-    import ctypes as C
-    from . import _lib as L
-    inter = spec.endswith("i")
-    n = int(spec.rstrip("i"))
-    try:
-        total = torch.cuda.get_device_properties(torch.device("cuda", int(device))).multi_processor_count
-    except Exception:           # (seen on the GPU box inside a lane thread: "Invalid device id" from torch's cached device count)
-        total = 256
-    parts = max(1, total // n)
-    cus = [(lane % parts) + parts * j for j in range(n)] if inter else [((lane % parts) * n + j) for j in range(n)]
-    words = [0] * ((total + 31) // 32)
-    for c in cus:
-        words[c // 32] |= 1 << (c % 32)
-    out = C.c_void_p()
-    L.check(L.load().mamdr_stream_create_masked(len(words), (C.c_uint32 * len(words))(*words), C.byref(out)))
-    return torch.cuda.ExternalStream(out.value)         # (the calling thread's current device: LaneGroup.run set it)
 
 
 class _Lane0Stdout(object):
