@@ -32,7 +32,7 @@ if has bench; then
 fi
 cd /tmp
 if has prof; then
-    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof10" -o run -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --cpu-budget 0 --no-targets > "$OUT/prof10.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof10" -o run -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --cpu-budget 0 --no-targets --lanes 0 > "$OUT/prof10.log" 2>&1
     timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof30" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 2 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/prof30.log" 2>&1
     timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa6" -o run -- python3 "$REPO/bench.py" --workload amazon6 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa6.log" 2>&1
     timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa13" -o run -- python3 "$REPO/bench.py" --workload amazon13 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa13.log" 2>&1
