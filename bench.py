@@ -858,7 +858,9 @@ def run_lanes(wl_name, steps, warmup, lanes, outer=(0, 1)):
     out.update({"lanes": lanes, "participants": outer[1] * lanes,
                 "semantics": "the %d-participant sharded epoch (SURVEY 8e), %d lane(s) per GPU: lanes = host threads, one engine + "
                              "one HIP stream each; not the single chain `value` times" % (outer[1] * lanes, lanes),
-                "us_per_domain_step": r["ms_per_step"] * 1e3 / r["domain_steps_per_epoch"]})
+                "us_per_domain_step": r["ms_per_step"] * 1e3 / r["domain_steps_per_epoch"],
+                # (every lane's stream on a hardware queue of its own needs this set BEFORE the HIP runtime initialised: ADVICE r05)
+                "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")})
     return out
 
 

@@ -21,8 +21,9 @@ LANES (round 5): the same sharding inside ONE process.  One dependent chain of 1
 over ranks are just as independent on one GPU: `LaneGroup(L).run(fn)` runs `fn(lane)` on L host threads, each lane with
 its own engine on its own HIP stream, and inside those threads `world()` answers (lane, L) and the collectives of this
 module (`all_reduce`, `broadcast`, the phi hand-over) become stream-ordered copies / sums between the lanes' buffers --
-every function below runs unchanged, and a lane run IS the L-rank run (same assignment, same arithmetic, same sums in
-rank order), with the kernels of different lanes overlapping on the device.
+every function below runs unchanged, and a lane run IS the L-rank run (same assignment, same arithmetic; sums in lane order,
+which is the order of a 2-rank gloo / RCCL all-reduce -- tested bit for bit for 2 lanes; rings of more ranks add chunk by
+chunk in orders of their own), with the kernels of different lanes overlapping on the device.
 
 RANKS x LANES (round 6): the two compose.  Under N processes each LaneGroup of L lanes is a slice of ONE world of N * L
 participants -- `world()` answers (rank * L + lane, N * L) -- so a rank's share of an epoch (its DR queries, its DN
@@ -88,16 +89,14 @@ class LaneGroup(object):
             finally:
                 _lane.group, _lane.rank = None, 0
         threads = [threading.Thread(target=body, args=(l,), name="mamdr-lane-%d" % l) for l in range(self.n)]
-        import sys
-        out = sys.stdout
-        sys.stdout = _Lane0Stdout(out)      # every lane prints the same progress lines: lane 0's are the run's
+        _lane_stdout(+1)                    # every lane prints the same progress lines: lane 0's are the run's
         try:
             for t in threads:
                 t.start()
             for t in threads:
                 t.join()
         finally:
-            sys.stdout = out
+            _lane_stdout(-1)
         first = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)] or \
                 [e for e in errors if e is not None]
         if first:
@@ -243,6 +242,30 @@ def _lane_stream(device, lane):
     if key not in _lane_streams:
         _lane_streams[key] = torch.cuda.Stream(device=device)
     return _lane_streams[key]
+
+
+_stdout_lock = threading.Lock()
+_stdout_state = {"count": 0, "saved": None}
+
+
+def _lane_stdout(delta):
+    """the filter that drops the prints of lanes > 0 is installed while ANY LaneGroup runs (counted: two groups running side by
+    side, or nested, install it once and the last one out restores the stream -- ADVICE r05); threads that are no lanes
+    print as before."""
+    import sys
+    with _stdout_lock:
+        st = _stdout_state
+        if delta > 0:
+            if st["count"] == 0:
+                st["saved"] = sys.stdout
+                sys.stdout = _Lane0Stdout(sys.stdout)
+            st["count"] += 1
+        else:
+            st["count"] -= 1
+            if st["count"] == 0:
+                if isinstance(sys.stdout, _Lane0Stdout):
+                    sys.stdout = st["saved"]
+                st["saved"] = None
 
 
 class _Lane0Stdout(object):

@@ -160,13 +160,15 @@ class EpochShuffles(object):
 
     def prefetch(self, passes):
         """start drawing the permutations of the epoch whose passes these are; `prepare` of the SAME passes then only
-        uploads.  Nothing else may draw from the shuffler in between (the stream order is the pass order)."""
+        uploads.  Nothing else may draw from the shuffler in between (the stream order is the pass order): `prepare` checks
+        the shuffler's counter and raises if anything did."""
         import threading
         if not self.sh.shuffle:
             return
         self.cancel()
         passes = list(passes)
         job = self._stage(passes)
+        job["counter_after"] = self.sh.counter      # (checked in prepare: nobody else drew from the stream in between)
         t = threading.Thread(target=self._draw, args=(job,))
         t.start()
         self.pending = (passes, job, t)
@@ -192,6 +194,11 @@ class EpochShuffles(object):
         if self.pending is not None and self.pending[0] == passes:
             _, job, t = self.pending
             self.pending = None
+            if sh.counter != job["counter_after"]:
+                # (a validation / target / closing pass that called the shuffler directly after the prefetch -- the
+                # lookahead draws the NEXT epoch's seeds while this one still runs -- would silently reorder the seed stream)
+                raise RuntimeError("the shuffle stream was drawn from between prefetch() and prepare(): %d draws since" % (
+                    sh.counter - job["counter_after"]))
             import time
             t0 = time.perf_counter()
             t.join()
@@ -212,6 +219,8 @@ class EpochShuffles(object):
         self.queue = job["queue"]
         self.timing["upload"] += t1 - t0
         self.timing["queue"] += time.perf_counter() - t1
+        if self.lookahead is not None and not self.queue:
+            self.lookahead()        # (a rank / lane without passes this epoch plans the next one like its peers: ADVICE r05)
 
     def peek(self, domains):
         """the permutations the next len(domains) calls will hand out, without consuming them (meta.PassWindow gathers

@@ -115,7 +115,8 @@ def test_amazon13_star_config_parses_and_selects_meta_prefix():
     assert cfg["train"]["meta_parms"] == ["emb", "kernel_shared", "bias_shared"] and cfg["train"]["emb_trainable"]
 
 
-def test_bench_gpus2_starts_two_ranks(tmp_path):
+@pytest.mark.parametrize("rank_lanes", [0, 2])
+def test_bench_gpus2_starts_two_ranks(tmp_path, rank_lanes):
     """`python bench.py --gpus 2` without a rendezvous starts two ranks itself (child torch.distributed.run, before
     touching the GPU) and relays ONE JSON line with n_gpus 2.  On this 1-GPU box both ranks share device 0 over
     gloo (MAMDR_BENCH_SHARE_GPU=1); with one GPU per rank the same code path runs RCCL."""
@@ -126,8 +127,10 @@ def test_bench_gpus2_starts_two_ranks(tmp_path):
     env = dict(os.environ, MAMDR_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
+    # rank_lanes 2 (round 6): RANKS x LANES -- every rank also times the epochs on two lanes of its own, one world of 4
+    # participants (lane step on the device + one inter-rank collective per process)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                        "--cpu-budget", "0", "--no-profile", "--no-targets"], env=env, stdout=subprocess.PIPE,
+                        "--cpu-budget", "0", "--no-profile", "--no-targets", "--rank-lanes", str(rank_lanes)], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -135,6 +138,9 @@ def test_bench_gpus2_starts_two_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["backend"] == "gloo" and rec["value"] > 0
     assert rec["config"]["domain_steps_per_epoch"] > 1000 and 1.0 < rec["partition_speedup_bound"] <= 2.0
+    if rank_lanes:
+        assert rec["lanes"]["participants"] == 4 and rec["lanes"]["lanes"] == 2 and rec["lanes"]["value"] > 0
+        assert 2.0 < rec["lanes"]["partition_speedup_bound"] <= 4.0
 
 
 SHARDED_WORKER = r'''
