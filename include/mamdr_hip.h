@@ -419,6 +419,8 @@ int64_t mamdr_graph_optimizer_steps(const mamdr_graph* g);
 /* kernel launches this process has issued through mamdr_graph_* calls so far (measurement: launches per step) */
 int64_t mamdr_graph_launch_count(void);
 int64_t mamdr_graph_dropout_steps(const mamdr_graph* g);
+/* as mamdr_set_counters: the optimizer's step count (with TF's running beta powers) and the dropout stream's position (ABI 18) */
+int mamdr_graph_set_counters(mamdr_graph* g, int64_t optimizer_steps, int64_t dropout_steps);
 int mamdr_graph_bind_table(mamdr_graph* g, int seg, const float* d_rows, int64_t n_rows);     /* deep_mtl_ctr.py:98-121 */
 int mamdr_graph_bind_domain_data(mamdr_graph* g, int domain, int split, const int32_t* d_uid, const int32_t* d_pid,
                                  const int32_t* d_domain, const float* d_label, int64_t n_rows);

@@ -131,6 +131,7 @@ SIGNATURES = {
     "mamdr_graph_launch_count": (_I64, []),
     "mamdr_graph_optimizer_steps": (_I64, [_VP]),
     "mamdr_graph_dropout_steps": (_I64, [_VP]),
+    "mamdr_graph_set_counters": (C.c_int, [_VP, _I64, _I64]),
     "mamdr_graph_bind_table": (C.c_int, [_VP, C.c_int, _VP, _I64]),
     "mamdr_graph_bind_domain_data": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _I64]),
     "mamdr_graph_train_steps": (C.c_int, [_VP, C.c_int, _VP, _I64, _I64, _I32, _U32, _I32, _F, _VP]),

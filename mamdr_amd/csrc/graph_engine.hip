@@ -2481,6 +2481,23 @@ int mamdr_graph_optimizer_reset(mamdr_graph* g) {
     g->b1p = g->b2p = 1.f;
     return MAMDR_OK;
 }
+// the counterpart of mamdr_set_counters for the generic-layer engine: TF's running beta powers for `optimizer_steps` steps
+// (one optimizer object for all D compiled models: deep_mtl_ctr.py:52-55) and the position of the dropout stream
+int mamdr_graph_set_counters(mamdr_graph* g, int64_t optimizer_steps, int64_t dropout_steps) {
+    if (check(g)) return MAMDR_EINVAL;
+    if (optimizer_steps < 0 || optimizer_steps > (int64_t)0x7ffffff0 || dropout_steps < 0 || dropout_steps > (int64_t)0xffffffffLL)
+        return gfail(MAMDR_EINVAL, "mamdr_graph_set_counters(%lld, %lld): out of range", (long long)optimizer_steps, (long long)dropout_steps);
+    g->adam_t = optimizer_steps;
+    float b1 = 1.f, b2 = 1.f;
+    for (int64_t t = 0; t < optimizer_steps; ++t) {
+        b1 *= g->cfg.adam_beta1;
+        b2 *= g->cfg.adam_beta2;
+    }
+    g->b1p = b1;
+    g->b2p = b2;
+    g->global_step = (uint32_t)dropout_steps;
+    return MAMDR_OK;
+}
 int mamdr_graph_set_adam_eps(mamdr_graph* g, float eps) {
     if (check(g)) return MAMDR_EINVAL;
     if (!(eps > 0.f)) return gfail(MAMDR_EINVAL, "adam epsilon %g", (double)eps);

@@ -226,6 +226,10 @@ class GraphEngine(FlatVectorOps):
             return loss, auc, hist.reshape(2, 501), preds.cpu().numpy()
         return loss, auc
 
+    def set_counters(self, optimizer_steps, dropout_steps):
+        """mamdr_graph_set_counters: a run resumed from saved weights / slots written into the bound vectors."""
+        L.check(self.lib.mamdr_graph_set_counters(self.ctx, int(optimizer_steps), int(dropout_steps)), graph=True)
+
     def optimizer_reset(self):
         L.check(self.lib.mamdr_graph_optimizer_reset(self.ctx), graph=True)
 

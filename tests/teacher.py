@@ -184,13 +184,19 @@ class LockStep(object):
         of the lazy table Adam are replayed, which is part of what is being checked).
     `inner`: the object the loop calls (the model, or its meta view for Star); `model`: the oracle model itself."""
 
-    def __init__(self, inner, model, eng, data, lr, bars, aux_of=None, chunk=8, noise_slots=()):
+    def __init__(self, inner, model, eng, data, lr, bars, aux_of=None, chunk=8, noise_slots=(), slots_of=None, t_of=None,
+                 oracle_pass=None):
         """noise_slots: tensors whose GRADIENT is rounding residue by construction (Star: the domain table -- under
         PartitionedNorm a single-domain batch's domain columns are constant, their normalised values and hence the row's
         gradient are what (x - mean) leaves of equal numbers): their Adam slots are averages of noise on both sides and are
         not compared; their weights are (Adam moves them by at most lr per step whatever the noise)."""
         import torch
         self.torch, self.chunk, self.noise_slots = torch, int(chunk), tuple(noise_slots)
+        # (the model's Adam slots / step count / pass call: oracle/tower.OracleModel's by default; oracle/mtl.OracleMTL keeps
+        # them on the model itself and takes the domain as an argument of its pass)
+        self.slots_of = slots_of or (lambda m: (m.opt.m, m.opt.v))
+        self.t_of = t_of or (lambda m: int(m.opt.t))
+        self.oracle_pass = oracle_pass or (lambda d, data, perm, bs: self.inner.train_pass(data, perm, bs))
         self.inner, self.model, self.eng, self.lr, self.bars, self.aux_of = inner, model, eng, lr, bars, aux_of
         self.dom_of = {id(cols): d for d, cols in data.items()}
         self.rows, self.bad = [], []
@@ -203,17 +209,28 @@ class LockStep(object):
 
     def _load(self):
         eng, m = self.eng, self.model
-        eng.sync()
+        self._sync()
+        om, ov = self.slots_of(m)
         for n in m.names:
             off, cnt = eng.segments[n]
             assert cnt == m.params[n].size, (n, cnt, m.params[n].size)
             eng._weights[off:off + cnt].copy_(self._dev(m.params[n]))
-            eng._adam_m[off:off + cnt].copy_(self._dev(m.opt.m[n]))
-            eng._adam_v[off:off + cnt].copy_(self._dev(m.opt.v[n]))
+            eng._adam_m[off:off + cnt].copy_(self._dev(om[n]))
+            eng._adam_v[off:off + cnt].copy_(self._dev(ov[n]))
         if self.aux_of is not None:
             a = self._dev(self.aux_of(m))
             eng.aux[:a.numel()].copy_(a)            # (the library pads its state vector to 16 B)
-        eng.set_counters(int(m.opt.t), int(m.step))
+        eng.set_counters(self.t_of(m), int(m.step))
+
+    def _sync(self):
+        if hasattr(self.eng, "sync"):
+            self.eng.sync()
+
+    def _counters(self):
+        eng, lib = self.eng, self.eng.lib
+        if hasattr(lib, "mamdr_graph_optimizer_steps") and type(eng).__name__ == "GraphEngine":
+            return int(lib.mamdr_graph_optimizer_steps(eng.ctx)), int(lib.mamdr_graph_dropout_steps(eng.ctx))
+        return int(lib.mamdr_optimizer_steps(eng.ctx)), int(lib.mamdr_dropout_steps(eng.ctx))
 
     def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
         """the pass in CHUNKS of `self.chunk` steps, each restarted from the oracle's state: with trainable tables that start
@@ -232,31 +249,35 @@ class LockStep(object):
             losses += self._chunk(data, d, perm, perm_d, batch_size, s0, c)
         return losses
 
+    def run_pass(self, d, data, perm, batch_size):
+        """a pass over domain d outside oracle/loops.py (the test drives the loop itself)."""
+        self.dom_of[id(data)] = d
+        return self.train_pass(data, perm, batch_size)
+
     def _chunk(self, data, d, perm, perm_d, batch_size, s0, n_steps):
         torch, eng, m = self.torch, self.eng, self.model
-        t0, s0c = int(m.opt.t), int(m.step)
+        aux = getattr(eng, "aux", None)
+        t0, s0c = self.t_of(m), int(m.step)
         # launch path A -- what a training run executes: no loss output, i.e. with trainable tables the LAZY table Adam (a
         # non-null loss buffer makes every step synchronise the tables first: include/mamdr_hip.h)
         self._load()
-        eng.train_steps(d, perm_d, first_step=s0, n_steps=n_steps, batch_size=batch_size)
-        eng.sync()
-        snap = [x.clone() for x in (eng._weights, eng._adam_m, eng._adam_v)] + ([eng.aux.clone()] if eng.aux is not None else [])
+        eng.train_steps(d, perm_d, first_step=s0, n_steps=n_steps, batch_size=batch_size, lr=self.lr)
+        self._sync()
+        snap = [x.clone() for x in (eng._weights, eng._adam_m, eng._adam_v)] + ([aux.clone()] if aux is not None else [])
         # launch path B -- the same steps again from the same state with the per-step losses written: same bits at the end
         self._load()
         loss_g = torch.zeros(n_steps, dtype=torch.float32, device=eng.device)
-        eng.train_steps(d, perm_d, first_step=s0, n_steps=n_steps, batch_size=batch_size, loss_out=loss_g)
-        eng.sync()
-        live = [eng._weights, eng._adam_m, eng._adam_v] + ([eng.aux] if eng.aux is not None else [])
+        eng.train_steps(d, perm_d, first_step=s0, n_steps=n_steps, batch_size=batch_size, loss_out=loss_g, lr=self.lr)
+        self._sync()
+        live = [eng._weights, eng._adam_m, eng._adam_v] + ([aux] if aux is not None else [])
         for a, b in zip(snap, live):
             if not torch.equal(a.view(torch.int32), b.view(torch.int32)):
                 self.bad.append(("launch paths differ", len(self.rows), d, n_steps, int((a.view(torch.int32) != b.view(torch.int32)).sum())))
         del snap
         sub = perm[s0 * batch_size:(s0 + n_steps) * batch_size]
-        losses = self.inner.train_pass(data, sub, batch_size)           # the oracle's steps
+        losses = self.oracle_pass(d, data, sub, batch_size)             # the oracle's steps
         assert len(losses) == n_steps
-        lib = eng.lib
-        assert (int(lib.mamdr_optimizer_steps(eng.ctx)), int(lib.mamdr_dropout_steps(eng.ctx))) == (t0 + n_steps, s0c + n_steps) == \
-            (int(m.opt.t), int(m.step))
+        assert self._counters() == (t0 + n_steps, s0c + n_steps) == (self.t_of(m), int(m.step))
         lg, lo = loss_g.cpu().numpy(), np.array(losses, F32)
         rel = np.abs(lg - lo) / np.maximum(np.abs(lo), 1e-6)
         k = len(self.rows)
@@ -270,7 +291,8 @@ class LockStep(object):
             frac, mx = float((diff > 0.05 * klr).float().mean()), float(diff.max()) / klr
             med = float(diff.median()) / klr
             rels = []
-            for got, want in ((eng._adam_m, m.opt.m[n]), (eng._adam_v, m.opt.v[n])):
+            om, ov = self.slots_of(m)
+            for got, want in ((eng._adam_m, om[n]), (eng._adam_v, ov[n])):
                 w = self._dev(want)
                 rels.append(float((got[off:off + cnt] - w).double().norm() / max(float(w.double().norm()), 1e-30)))
             del diff

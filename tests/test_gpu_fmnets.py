@@ -356,3 +356,43 @@ def test_domain_negotiation_auc_parity(kind):
     assert abs(np.mean(got) - np.mean(auc_o)) <= 1e-3 + chaos, (np.mean(got), np.mean(auc_o), chaos)
     assert np.mean(auc_o) > 0.57
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["nfm", "pnn", "ccpm", "autoint"])
+def test_domain_negotiation_teacher_forced(kind):
+    """the chaos-free counterpart of test_domain_negotiation_auc_parity (round 6, tests/teacher.py) on the generic-layer engine:
+    the same five Domain Negotiation epochs on 4 domains at the same learning rate, but every pass starts from the ORACLE's
+    state (weights, Adam slots, step count with TF's beta powers, dropout position) and is compared pass by pass -- per-step
+    losses and end state -- with the bars of tests/test_gpu_teacher.py and no self-divergence term.  (These towers at 5e-3
+    are the most chaotic training in the suite: the free-running test above needs up to 1e-2 of oracle self-divergence; one
+    pass from a common state does not.)"""
+    import teacher
+    from teacher_bars import BARS
+    g, eng, model = make_problem(kind, scale=0.15)
+    D = 4
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    k = [0]
+
+    def perm_fn(d):
+        k[0] += 1
+        return orng.shuffle_perm(sizes[d], 10000, seed=700 + k[0])
+    seqs = ([2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3], [3, 1, 2, 0], [2, 3, 1, 0])
+    LR = 5e-3
+    model.lr = LR
+    bars = dict(BARS, frac=2e-3)
+    # (AutoInt -- attention kernels x 4, lr 5e-3 -- amplifies fastest: one 19-step pass from a common state ends 2.3e-4 apart in
+    # the loss, just over the bar; like Amazon-6's DeepFM it is forced in 8-step chunks.  The others: whole passes.)
+    ls = teacher.LockStep(model, model, eng, g["data"]["train"], LR, bars, chunk=8 if kind == "autoint" else 1 << 20)
+    theta = model.get_flat().copy()
+    trace = []
+    for seq in seqs:
+        trace += oloops.dn_epoch(ls, theta, g["data"]["train"], seq, perm_fn, 256, 0.5)
+    out = ls.summary()
+    print("%s DN teacher-forced: %d passes / %d steps; worst first-step loss rel %.1e, any step %.1e; weights frac %.1e max %.3f k lr "
+          "median %.5f k lr; slots %.1e / %.1e" % (kind, out["passes"], out["steps"], out["loss_first"], out["loss_rel"], out["frac"],
+                                                   out["max_klr"], out["med_klr"], out["m_rel"], out["v_rel"]))
+    for v in ls.bad[:10]:
+        print("  VIOLATION", v)
+    assert not ls.bad, "%d violations (first: %r)" % (len(ls.bad), ls.bad[0])
+    assert out["passes"] == len(trace) == 20 and out["steps"] == sum(t[2] for t in trace)
+    eng.close()

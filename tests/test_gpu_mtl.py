@@ -388,3 +388,42 @@ def test_trainable_tables_gradients_and_adam(kind):
     loss_o, preds = model.evaluate(d, g["data"]["val"][d], 256)
     assert abs(loss_g - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
+def test_alternate_training_teacher_forced(kind):
+    """the chaos-free counterpart of test_alternate_training_auc_parity (round 6, tests/teacher.py): the same four epochs of
+    one full pass per domain (deep_mtl_ctr.py:69-96), but EVERY pass is run on the generic-layer engine from the ORACLE's
+    state at that point -- every tensor, the Adam slots, the optimizer's step count with TF's running beta powers
+    (mamdr_graph_set_counters), the dropout position -- and its per-step losses and end state are compared with the oracle's:
+    no self-divergence term.  Bars as tests/test_gpu_teacher.py (k lr = steps x 2e-3): first-step loss 2e-5, any step 2e-4,
+    <= 2e-3 of a tensor's elements beyond 5 % of k lr (this file's assert_adam_close), none beyond 2.02 k lr, median
+    <= 0.002 k lr, slots m / v relative L2 0.1 / 5e-3; both launch paths of a pass (losses written or not) end in the same bits."""
+    import teacher
+    from teacher_bars import BARS
+    g, eng, model, spec = make_problem(kind, dropout=0.5, scale=0.15)
+    D = g["n_domain"]
+    sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
+    order = [[2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0]]
+    LR = 2e-3
+    model.lr = LR
+    bars = dict(BARS, frac=2e-3)
+    ls = teacher.LockStep(model, model, eng, g["data"]["train"], LR, bars, chunk=1 << 20,
+                          slots_of=lambda m: (m.m, m.v), t_of=lambda m: int(m.t),
+                          oracle_pass=lambda d, data, perm, bs: model.train_pass(d, data, perm, bs))
+    k = 0
+    for seq in order:
+        for d in seq:
+            k += 1
+            perm = orng.shuffle_perm(sizes[d], 10000, seed=500 + k)
+            ls.run_pass(d, g["data"]["train"][d], perm, 256)
+    out = ls.summary()
+    print("%s alternate training teacher-forced: %d passes / %d steps; worst first-step loss rel %.1e, any step %.1e; weights frac "
+          "%.1e max %.3f k lr median %.5f k lr; slots %.1e / %.1e" % (kind, out["passes"], out["steps"], out["loss_first"],
+                                                                      out["loss_rel"], out["frac"], out["max_klr"], out["med_klr"],
+                                                                      out["m_rel"], out["v_rel"]))
+    for v in ls.bad[:10]:
+        print("  VIOLATION", v)
+    assert not ls.bad, "%d violations (first: %r)" % (len(ls.bad), ls.bad[0])
+    assert out["passes"] == 16 and out["steps"] >= 40
+    eng.close()
