@@ -1699,8 +1699,14 @@ void launch_wgrad(mamdr_graph* g, GemmArgs a, int M, int N, int rows, const floa
 }
 
 // 32 x 32 tiles (gemm_tile32) while the 64 x 64 ones would leave CUs idle or nearly so; MAMDR_GRAPH_TILE32_BELOW=<tiles> (0: never)
-int g_tile32_below = 512;
-inline bool use_tile32(int M, int N, int n_group = 1) { return (M / GT) * (N / GT) * n_group < g_tile32_below && N % T32 == 0; }
+// (process-wide like the environment it comes from; re-read at EVERY mamdr_graph_create -- round 6: a value set by one context's
+// environment used to stay in force for every later context of the process, and a test that set MAMDR_GRAPH_TILE32_BELOW=0
+// changed the rounding of every generic-layer run after it in the same session)
+constexpr int TILE32_BELOW_DEFAULT = 512;
+std::atomic<int> g_tile32_below{TILE32_BELOW_DEFAULT};
+inline bool use_tile32(int M, int N, int n_group = 1) {
+    return (M / GT) * (N / GT) * n_group < g_tile32_below.load(std::memory_order_relaxed) && N % T32 == 0;
+}
 void launch_gemm(int mode, const GemmArgs& a, int M, int N, hipStream_t s) {
     const dim3 grid(N / GT, M / GT), block(256);
     if (mode != 2 && use_tile32(M, N)) {
@@ -2206,7 +2212,10 @@ int mamdr_graph_create(const mamdr_graph_config* cfg, void* stream, mamdr_graph*
     g->stream = (hipStream_t)stream;
     if (const char* ev = getenv("MAMDR_GRAPH_NO_GROUP")) g->group_ok = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_GRAPH_NO_DEFER")) g->defer_w = atoi(ev) == 0;
-    if (const char* ev = getenv("MAMDR_GRAPH_TILE32_BELOW")) g_tile32_below = atoi(ev);
+    {
+        const char* ev = getenv("MAMDR_GRAPH_TILE32_BELOW");
+        g_tile32_below.store(ev ? atoi(ev) : TILE32_BELOW_DEFAULT, std::memory_order_relaxed);
+    }
     if (const char* ev = getenv("MAMDR_GRAPH_NO_TAIL_OPT")) g->tail_opt = atoi(ev) == 0;
     g->sink.p = nullptr;
     if (const char* ev = getenv("MAMDR_GRAPH_WQ_BLOCKS")) g->wq_blocks = atoi(ev) > 0 ? atoi(ev) : g->wq_blocks;

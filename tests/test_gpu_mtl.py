@@ -427,3 +427,26 @@ def test_alternate_training_teacher_forced(kind):
     assert not ls.bad, "%d violations (first: %r)" % (len(ls.bad), ls.bad[0])
     assert out["passes"] == 16 and out["steps"] >= 40
     eng.close()
+
+
+def test_environment_of_one_context_does_not_leak_into_the_next(monkeypatch):
+    """MAMDR_GRAPH_TILE32_BELOW is read at EVERY mamdr_graph_create (round 6): a context created without it runs the default
+    tile plan again -- the same bits as before -- although a context with MAMDR_GRAPH_TILE32_BELOW=0 (64 x 64 tiles: another
+    summation order) lived in the process in between.  (It used to stay in force for the rest of the process: the end-to-end
+    runs of a session that had run test_launch_plans_are_bitwise_twins differed from a fresh process's at rounding level.)"""
+    def run():
+        g, eng, model, spec = make_problem("mmoe", batch=256, dropout=0.5, scale=0.1)
+        for d in (0, 1, 2):
+            eng.train_steps(d, perm=None, first_step=0, n_steps=2, lr=1e-3)
+        out = eng.get_weights().cpu().numpy().copy()
+        eng.close()
+        return out
+    monkeypatch.delenv("MAMDR_GRAPH_TILE32_BELOW", raising=False)
+    a = run()
+    monkeypatch.setenv("MAMDR_GRAPH_TILE32_BELOW", "0")
+    b = run()
+    monkeypatch.delenv("MAMDR_GRAPH_TILE32_BELOW", raising=False)
+    c = run()
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))       # (the switch does change the summation order)
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
