@@ -32,10 +32,11 @@ if has bench; then
 fi
 cd /tmp
 if has prof; then
+    # (--lanes 0: the lane leg stretches the kernels it shares the device with; these summaries are the single chain's)
     timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof10" -o run -- python3 "$REPO/bench.py" --steps 5 --warmup 1 --cpu-budget 0 --no-targets --lanes 0 > "$OUT/prof10.log" 2>&1
-    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof30" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 2 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/prof30.log" 2>&1
-    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa6" -o run -- python3 "$REPO/bench.py" --workload amazon6 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa6.log" 2>&1
-    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa13" -o run -- python3 "$REPO/bench.py" --workload amazon13 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile > "$OUT/profa13.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof30" -o run -- python3 "$REPO/bench.py" --workload taobao30 --steps 2 --warmup 1 --cpu-budget 0 --no-targets --no-profile --lanes 0 > "$OUT/prof30.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa6" -o run -- python3 "$REPO/bench.py" --workload amazon6 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile --lanes 0 > "$OUT/profa6.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profa13" -o run -- python3 "$REPO/bench.py" --workload amazon13 --steps 1 --warmup 1 --cpu-budget 0 --no-targets --no-profile --lanes 0 > "$OUT/profa13.log" 2>&1
 fi
 if has pmc; then
     for W in ${PMC_WORKLOADS:-taobao10 taobao30 amazon6 amazon13}; do
@@ -43,7 +44,7 @@ if has pmc; then
             # (Amazon-13's full-row epoch is 39 K steps x 10 kernels of counter records: rocprofv3 itself crashed on it;
             # the bytes a launch moves do not depend on how many rows an epoch has -> 10 % of the rows for that pass)
             RS=1; [ $W = amazon13 ] && RS=0.1
-            MAMDR_BENCH_ROW_SCALE=$RS timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_${W}_$C" -o run -- python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets > "$OUT/pmc_${W}_$C.log" 2>&1
+            MAMDR_BENCH_ROW_SCALE=$RS timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_${W}_$C" -o run -- python3 "$REPO/bench.py" --workload $W --steps 1 --warmup 1 --cpu-budget 0 --no-profile --no-targets --lanes 0 > "$OUT/pmc_${W}_$C.log" 2>&1
         done
     done
 fi
