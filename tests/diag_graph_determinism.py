@@ -1,3 +1,6 @@
+"""Diagnostic (GPU box): the HIP side of an end-to-end case is run-to-run deterministic and does not depend on what ran in the
+process before it -- python tests/diag_graph_determinism.py <case> [prewarm]; prints a hash of every evaluation of the run
+(round 6: the generic-layer engine's MAMDR_GRAPH_TILE32_BELOW leak was found with it)."""
 import sys, os, hashlib, json, tempfile
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch
