@@ -177,7 +177,10 @@ class Ensemble(object):
         hip_c   = |hip - mean_c|
     and per run two statistics over all comparisons of the case: S = the MEAN distance (a systematic offset shows here) and
     M = the LARGEST distance (a single outlying domain shows here).  The HIP run must not be an outlier of the ensemble in
-    either: S_hip <= mean_k S_k + 3 sd_k S_k and M_hip <= mean_k M_k + 3 sd_k M_k (sample sd over the K + 1 members).
+    either: each of its statistics lies inside the one-sided 99.9 % PREDICTION INTERVAL for one more member,
+    mean_k + t(0.999; K) * sd_k * sqrt(1 + 1 / (K + 1)) (Student t with K degrees of freedom over the K + 1 members' values:
+    6.4 sd for six members -- with eighteen such checks in the suite a run that IS a member fails one of them in ~2 % of
+    the sessions; at 3 sd it would in ~25 %).
     (Any rank criterion -- "no further out than the furthest member" -- fails a run that IS a member with probability
     1 / (K + 2) by symmetry, whatever K is affordable; tests/test_teacher_harness.py checks these bars on synthetic draws.)
     Where north_star's plain |hip - oracle| <= 1e-3 holds nothing else is needed; the count of comparisons beyond it is
@@ -213,15 +216,18 @@ class Ensemble(object):
         for name, f in (("mean", np.mean), ("largest", np.max)):
             s_h = float(f(self.h_dist))
             s_k = np.array([float(f(m)) for m in self.m_dist])
-            out[name] = (s_h, s_k, float(s_k.mean() + 3 * s_k.std(ddof=1)))
+            from scipy import stats as _st
+            n = len(s_k)
+            width = float(_st.t.ppf(0.999, n - 1)) * np.sqrt(1.0 + 1.0 / n)
+            out[name] = (s_h, s_k, float(s_k.mean() + width * s_k.std(ddof=1)), width)
         print("  ensemble of %d oracle runs, %d comparisons: |hip - oracle| worst %.1e, %d beyond the plain 1e-3 (the twins against the "
               "same oracle run: %s)" % (len(self.members), self.n_cmp, self.worst, self.beyond, self.m_beyond))
         for name in ("mean", "largest"):
-            s_h, s_k, bar = out[name]
-            print("    %s distance from the ensemble mean: hip %.2e | members (leave-one-out) %s | bar mean + 3 sd = %.2e" % (
-                name, s_h, " ".join("%.2e" % v for v in s_k), bar))
+            s_h, s_k, bar, width = out[name]
+            print("    %s distance from the ensemble mean: hip %.2e | members (leave-one-out) %s | 99.9 %% prediction bound mean + %.1f sd = %.2e" % (
+                name, s_h, " ".join("%.2e" % v for v in s_k), width, bar))
         for name in ("mean", "largest"):
-            s_h, s_k, bar = out[name]
+            s_h, s_k, bar, width = out[name]
             assert s_h <= bar, ("the HIP run is an outlier of the oracle ensemble: %s distance" % name, case, s_h, list(s_k), bar)
 
 
