@@ -101,7 +101,8 @@ __device__ __forceinline__ float pn_fix1(const EmbStepArgs& a, int c, float g, f
 #pragma clang fp contract(off)
     const float m1 = a.pn_sums[c] / a.pn_rows, m2 = a.pn_sums[XDIM + c] / a.pn_rows;
     const float xh = nc_mul(nc_sub(x, a.pn[2 * XDIM + c]), a.pn[3 * XDIM + c]);
-    return nc_mul(a.pn[4 * XDIM + c], nc_sub(nc_sub(g, m1), nc_mul(xh, m2)));
+    // (t in ONE fused multiply-add: k_star_pnb_apply's rounding, star_bodies.h pn_bwd_t)
+    return nc_mul(a.pn[4 * XDIM + c], __builtin_fmaf(-m2, xh, nc_sub(g, m1)));
 }
 
 __device__ __forceinline__ void opt_step(const OptArgsLite& o, float g, float& p, float& m, float& v) {

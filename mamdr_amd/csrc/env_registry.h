@@ -39,6 +39,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"MAMDR_STAR_DENSE_SLICES", "lib", "1: every per-domain Star slice swept every step (diagnostic; same bits)"},
     {"MAMDR_STAR_PNB_KERNEL", "lib", "1: PartitionedNorm backward partials as a launch of their own (same bits)"},
     {"MAMDR_STAR_PNB_FUSED", "lib", "1: PartitionedNorm backward inside k_emb_reduce (measured, not adopted: parity)"},
+    {"MAMDR_STAR_PNB_APPLY", "lib", "1: k_star_pnb_apply as a launch of its own inside a call too (same bits; diagnostic)"},
     // ---- library, generic-layer engine (read at mamdr_graph_create)
     {"MAMDR_GRAPH_NO_GROUP", "lib", "1: one launch per expert instead of grouped launches"},
     {"MAMDR_GRAPH_NO_DEFER", "lib", "1: a pair of weight-gradient launches per layer instead of the queued flat grid"},

@@ -117,6 +117,9 @@ struct mamdr_ctx {
     // where the per-row sum leaves rounding residue, which Adam turns into a random walk of the domain row (in the
     // reference too): the moving statistics then lag differently and validation AUC moves by ~1e-3.
     bool star_pn_fused = false;
+    // k_star_pnb_apply's work spread over the launches around it inside a call (StarPnBwdArgs::fused == 2; same bits).
+    // MAMDR_STAR_PNB_APPLY=1 keeps the launch (diagnostic).
+    bool star_pn_no_apply = true;
     int t4_no_w1l = 0;              // MAMDR_T4_NO_W1L=1: k_tower4 without the W1 image in LDS (diagnostic)
     int fused_max_batch = 1024;     // batches up to this size take the fused path (MAMDR_FUSED=2: every batch size):
                                     // 4 rows x the CU count, set at mamdr_create
@@ -637,6 +640,11 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     // [k_wgrad + k_emb_reduce(t) + k_emb_rows(t+1)], then [k_star_update + k_emb_catchup(t+1)]
     const bool tail = c->tail_fuse && c->cfg.emb_trainable && c->lazy && optimizer == MAMDR_OPT_ADAM && !c->profile &&
                       !loss_out;
+    // ... and (round 6) without k_star_pnb_apply when a catch-up launch follows: the table rows take PartitionedNorm's
+    // backward inside k_emb_reduce, the domain columns' partial sums ride in k_wgrad_reduce and are finished and stepped
+    // in k_star_update_catchup (StarPnBwdArgs::fused == 2; the same roundings in the same order as the launch it replaces)
+    const bool no_apply = tail && next_catchup && !ba.fused && c->star_pn_no_apply;
+    if (no_apply) ba.fused = 2;
     if (tail) {
         {
             Prof p(c, MAMDR_KERNEL_AUX);
@@ -646,8 +654,13 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
         fill_emb_args(c, optimizer, alpha, omb1, omb2, table_two_l2(c), rows, XDIM, tea);
         tea.flags_done = 1;
         tea.apply_now = 1;
+        if (no_apply) {
+            tea.pn_sums = c->star_sums;
+            tea.pn = c->pn;
+            tea.pn_rows = (float)rows;
+        }
         Prof p(c, MAMDR_KERNEL_WGRAD);
-        launch_wgrad_reduce(wa, tea, next_rows, ba.fused ? nullptr : &ba, c->stream);
+        launch_wgrad_reduce(wa, tea, next_rows, ba.fused == 1 ? nullptr : &ba, c->stream);
     } else {
         {
             Prof p(c, MAMDR_KERNEL_WGRAD);
@@ -687,7 +700,8 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     }
     {
         Prof p(c, MAMDR_KERNEL_UPDATE);
-        if (tail && next_catchup) launch_star_update_catchup(ua, *next_catchup, c->stream);
+        ua.dm_elsewhere = no_apply ? 1 : 0;
+        if (tail && next_catchup) launch_star_update_catchup(ua, *next_catchup, no_apply ? &ba : nullptr, c->stream);
         else launch_star_update(ua, c->stream);
     }
     if (tail && next_rows) {
@@ -908,6 +922,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
     if (const char* ev = getenv("MAMDR_NO_TAILFUSE")) c->tail_fuse = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_STAR_PNB_KERNEL")) c->star_pn_in_tower = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_STAR_PNB_FUSED")) c->star_pn_fused = atoi(ev) != 0 && c->star_pn_in_tower;
+    if (const char* ev = getenv("MAMDR_STAR_PNB_APPLY")) c->star_pn_no_apply = atoi(ev) == 0;
     if (const char* ev = getenv("MAMDR_MAX_GROUPS")) c->max_groups = atoi(ev) > 0 ? atoi(ev) : c->max_groups;   // diagnostic
     if (const char* ev = getenv("MAMDR_RPG")) c->rpg_override = atoi(ev) / 8 * 8;
     if (const char* ev = getenv("MAMDR_NO_GATHER_PF")) c->gather_pf = atoi(ev) == 0;

@@ -742,7 +742,11 @@ struct StarPnBwdArgs {
     float* dmpart;             // [chunks][EMB] column sums of dx[:, 256:384]
     float* dmsum;              // [EMB] their total
     int fused;                 // 1: k_star_pnb_final is the only launch (it also finishes dmsum; the table rows get their
-                               // d x inside k_emb_reduce); 0: k_star_pnb_apply rewrites dxe, k_star_dm_final sums dmpart
+                               // d x inside k_emb_reduce); 0: k_star_pnb_apply rewrites dxe, k_star_dm_final sums dmpart;
+                               // 2 (the default inside a call, round 6): k_star_pnb_final is the only launch, the table
+                               // rows get their d x inside k_emb_reduce, the domain columns' partials are formed by
+                               // star_pnb_dom_body in k_wgrad_reduce and summed + stepped by star_dm_step_body in
+                               // k_star_update_catchup -- k_star_pnb_apply's arithmetic and order, without its launch
 };
 struct StarUpdateArgs {
     float* p;                  // Star block of weights / Adam m / Adam v (or accumulator)
@@ -761,6 +765,7 @@ struct StarUpdateArgs {
     int only_live;
     float* alpha_log;          // [log_mask + 1] alphas of this call's steps, slot = step index inside the call
     int log_idx;
+    int dm_elsewhere;          // 1: the live domain row is stepped by star_dm_step_body in the same launch
     float* eff_out;            // nullable: the NEXT step's effective dense block (same domain) -- K_l = Ws_l * Wd_l[d],
                                // b_l = bs_l + bd_l[d], the output unit, row d of the domain table -- from the values
                                // just stepped (k_star_prep then skips that part)
@@ -783,7 +788,7 @@ void launch_star_prep(const StarPrepArgs& a, hipStream_t s);
 void launch_star_pn_bwd(const StarPnBwdArgs& a, bool dm_final, hipStream_t s, bool partial_done = false);
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s);
 // k_star_update + the NEXT step's k_emb_catchup in one launch (lazy table Adam)
-void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& next_catchup, hipStream_t s);
+void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& next_catchup, const StarPnBwdArgs* dm, hipStream_t s);
 
 // outer_kernels.hip (compiled with -ffp-contract=off)
 void launch_interp(float* dst, const float* a, const float* b, float scale, int64_t n, hipStream_t s);

@@ -6,6 +6,39 @@ namespace mamdr {
 
 constexpr int STAR_DM_LANES = 16;              // chunk lanes per column (fixed: it defines the summation order)
 
+// PartitionedNorm's backward, one element: d x = coef * t with t = (g - s1 / B) - xhat * (s2 / B).  The roundings are
+// spelled out -- ONE fused multiply-add for t, and the column sum of d x taken as fma(coef, t, sum) -- because that is
+// what the compiler's contraction has made of k_star_pnb_apply since round 2, and every site that forms d x
+// (k_star_pnb_apply, the table workgroups of k_wgrad_reduce, star_pnb_dom_body) must round alike.
+__device__ __forceinline__ float pn_bwd_t(float g, float m1, float xh, float m2) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(-m2, xh, g - m1);
+}
+
+// The domain columns (256..383) of PartitionedNorm's backward without a pass over the other 256: the per-chunk column
+// sums of d x[:, 256:384] -- k_star_pnb_apply's arithmetic and order for those columns; d x itself has no other reader
+// (the table rows take theirs inside k_emb_reduce, EmbStepArgs::pn_sums).  256 threads = two chunks x 128 columns.
+__device__ __forceinline__ void star_pnb_dom_body(const StarPnBwdArgs& a, int bx) {
+#pragma clang fp contract(off)
+    const int kk = threadIdx.x & (EMB - 1), ch = bx * 2 + (int)(threadIdx.x >> 7);
+    if (ch >= a.n_chunks) return;
+    const int c = 2 * EMB + kk;
+    const int r0 = ch * STAR_CHUNK;
+    const int nb = min(STAR_CHUNK, a.rows - r0);
+    const float B = (float)a.rows;
+    const float m1 = a.sums[c] / B, m2 = a.sums[XDIM + c] / B;
+    const float coef = a.pn[4 * XDIM + c];
+    const float xh = (a.dm_row[kk] - a.pn[2 * XDIM + c]) * a.pn[3 * XDIM + c];
+    float g[STAR_CHUNK];
+#pragma unroll
+    for (int r = 0; r < STAR_CHUNK; ++r) g[r] = a.dxe[(size_t)(r0 + min(r, nb - 1)) * XDIM + c];
+    float colsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < STAR_CHUNK; ++r)
+        if (r < nb) colsum = __builtin_fmaf(coef, pn_bwd_t(g[r], m1, xh, m2), colsum);
+    a.dmpart[(size_t)ch * EMB + kk] = colsum;
+}
+
 // column sums of dx[:, 256:384] (the domain-table row gradient) from the per-chunk partials: thread (column cl,
 // lane j) sums chunks j, j + 16, ... (eight loads in flight), lane 0 then adds the 16 lanes in lane order.  COLS
 // columns per workgroup (COLS x 16 threads): the split over workgroups does not touch the per-column order.
@@ -29,5 +62,6 @@ __device__ __forceinline__ void star_dm_final_body(const StarPnBwdArgs& a, int b
     for (int q = 1; q < STAR_DM_LANES; ++q) g += sh[q * COLS + cl];
     a.dmsum[k] = g;
 }
+
 
 }  // namespace mamdr

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512) void k_star_pnb_final(const StarPnBwdArgs a) {
     // dx = coef ((dxn - s1 / B) - xhat s2 / B) over the batch, and every sample of the batch carries the SAME domain row
     // (one xhat), so the sum is available here in closed form.  In exact arithmetic it vanishes (the normalised input of
     // a constant column is 0): what is left is rounding residue, as on the per-row path and as in the reference.
-    if (a.fused && c >= 2 * EMB) {
+    if (a.fused == 1 && c >= 2 * EMB) {
         const float B = (float)a.rows;
         const float m1 = s1 / B, m2 = s2 / B;
         const float xh = (a.dm_row[c - 2 * EMB] - a.pn[2 * XDIM + c]) * a.pn[3 * XDIM + c];
@@ -363,9 +363,9 @@ __global__ __launch_bounds__(XDIM) void k_star_pnb_apply(const StarPnBwdArgs a) 
 #pragma unroll
     for (int r = 0; r < STAR_CHUNK; ++r) {
         if (r < nb) {
-            const float dx = coef * ((k.g[r] - m1) - k.xh[r] * m2);
-            a.dxe[(size_t)(r0 + r) * XDIM + c] = dx;
-            colsum += dx;
+            const float t = pn_bwd_t(k.g[r], m1, k.xh[r], m2);      // (explicit roundings: star_bodies.h)
+            a.dxe[(size_t)(r0 + r) * XDIM + c] = nc_mul(coef, t);
+            colsum = __builtin_fmaf(coef, t, colsum);
         }
     }
     if (c >= 2 * EMB) a.dmpart[(size_t)ch * EMB + (c - 2 * EMB)] = colsum;
@@ -482,11 +482,23 @@ __device__ __forceinline__ void star_update_body(const StarUpdateArgs& u, const 
     e -= H3 + 1;
     if (e < EMB) {                // domain table row dd: only row d is touched (PN's rounding residue)
         if (live) {
+            if (u.dm_elsewhere) return;          // (star_dm_step_body, in the same launch)
             const float pn = opt_apply(u.opt, u.dmsum[e], u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
             if (u.eff_out) u.eff_out[u.L.dm + dd * EMB + e] = pn;
         }
         else opt_zero(u.opt, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)dd * EMB + e);
     }
+}
+// The live domain row's step where its gradient is finished (StarUpdateArgs::dm_elsewhere): the column sums of
+// d x[:, 256:384] from the per-chunk partials (star_dm_final_body: the same order as k_star_dm_final), then the
+// optimiser step of those 16 elements by the threads that hold the sums.  EMB / 16 workgroups of 256 threads.
+__device__ __forceinline__ void star_dm_step_body(const StarUpdateArgs& u, const StarPnBwdArgs& sd, int bx, float* sh) {
+    star_dm_final_body<16>(sd, bx, sh);
+    if (threadIdx.x >= 16) return;
+    const int e = bx * 16 + (int)threadIdx.x;
+    const float g = sd.dmsum[e];              // (this thread's own store)
+    const float pn = opt_apply(u.opt, g, u.p, u.m, u.v, (size_t)u.SL.dm + (size_t)u.d * EMB + e);
+    if (u.eff_out) u.eff_out[u.L.dm + u.d * EMB + e] = pn;
 }
 constexpr int STAR_UPDATE_N = XDIM * H1 + H1 * H2 + H2 * H3 + (H1 + H2 + H3) + XDIM + (H3 + 1) + EMB;
 constexpr int STAR_UPDATE_BX = (STAR_UPDATE_N + 255) / 256;
@@ -502,13 +514,21 @@ __global__ __launch_bounds__(256) void k_star_update(const StarUpdateArgs u) {
 // the chain rule + optimiser on the Star block and the NEXT step's k_emb_catchup touch disjoint state: one launch,
 // the catch-up workgroups first (their chains are the longer ones).  (This step's k_emb_reduce and the next step's
 // k_emb_rows ride in the k_wgrad launch before it, k_wgrad_reduce.)
-__global__ __launch_bounds__(256) void k_star_update_catchup(const StarUpdateArgs u, const EmbStepArgs nc, const int n_cu) {
+// (n_dmf workgroups between the two: the live domain row, star_dm_step_body -- the step's PartitionedNorm backward left
+// per-chunk partials of its gradient in the launch before this one)
+__global__ __launch_bounds__(256) void k_star_update_catchup(const StarUpdateArgs u, const EmbStepArgs nc, const int n_cu,
+                                                             const StarPnBwdArgs sd, const int n_dmf) {
+    __shared__ float sh[STAR_DM_LANES * 16];
     const int bid = (int)blockIdx.x;
     if (bid < 2 * n_cu) {
         emb_catchup_body(nc, bid % n_cu, bid / n_cu);
         return;
     }
-    const int idx = bid - 2 * n_cu;
+    if (bid < 2 * n_cu + n_dmf) {
+        star_dm_step_body(u, sd, bid - 2 * n_cu, sh);
+        return;
+    }
+    const int idx = bid - 2 * n_cu - n_dmf;
     star_log_alpha(u, idx);
     star_update_body(u, idx % STAR_UPDATE_BX, u.only_live ? u.d : idx / STAR_UPDATE_BX);
 }
@@ -553,10 +573,14 @@ __global__ __launch_bounds__(256) void k_star_catchup(const StarCatchArgs a) {
 void launch_star_update(const StarUpdateArgs& a, hipStream_t s) {
     MAMDR_LAUNCH(k_star_update, dim3(STAR_UPDATE_BX, a.only_live ? 1 : a.n_domain), dim3(256), 0, s, a);
 }
-void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& nc, hipStream_t s) {
+void launch_star_update_catchup(const StarUpdateArgs& a, const EmbStepArgs& nc, const StarPnBwdArgs* dm, hipStream_t s) {
     const int n_cu = (nc.rows + 7) / 8;
-    MAMDR_LAUNCH(k_star_update_catchup, dim3(2 * n_cu + STAR_UPDATE_BX * (a.only_live ? 1 : a.n_domain)), dim3(256), 0, s, a, nc,
-                 n_cu);
+    StarPnBwdArgs sd;
+    memset(&sd, 0, sizeof(sd));
+    if (dm) sd = *dm;
+    const int n_dmf = dm ? EMB / 16 : 0;
+    MAMDR_LAUNCH(k_star_update_catchup, dim3(2 * n_cu + n_dmf + STAR_UPDATE_BX * (a.only_live ? 1 : a.n_domain)), dim3(256), 0, s,
+                 a, nc, n_cu, sd, n_dmf);
 }
 void launch_star_catchup(const StarCatchArgs& a, hipStream_t s) {
     if (a.n_steps <= 0 || a.n_domain <= 1) return;

@@ -1240,7 +1240,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WGRAD_EARLY_PARAMS, const 
     __shared__ __attribute__((aligned(16))) float red[4 * WG_BUF];
     int bid = (int)blockIdx.x;
     if (bid < n_dm) {
-        star_dm_final_body<16>(sd, bid, red);
+        if (sd.fused == 2) star_pnb_dom_body(sd, bid);      // the partials themselves (no k_star_pnb_apply before this launch)
+        else star_dm_final_body<16>(sd, bid, red);
         return;
     }
     bid -= n_dm;
@@ -1394,7 +1395,7 @@ void launch_wgrad_reduce(const WgradArgs& a, const EmbStepArgs& e, const EmbRows
     StarPnBwdArgs sd;
     memset(&sd, 0, sizeof(sd));
     if (star_dm) sd = *star_dm;
-    const int n_dm = star_dm ? EMB / 16 : 0;
+    const int n_dm = star_dm ? (sd.fused == 2 ? (sd.n_chunks + 1) / 2 : EMB / 16) : 0;
     MAMDR_LAUNCH(k_wgrad_reduce, dim3(n_dm + n_wgrad + 2 * ((e.rows + 7) / 8) + n_rows), dim3(256), 0, s, WGRAD_EARLY_ARGS(a), a, e, n_wgrad,
                        nr, n_rows, sd, n_dm);
 }
