@@ -6,8 +6,8 @@ exec < /dev/null
 #   prof = rocprofv3 --kernel-trace --stats of the four BASELINE workloads; pmc = FETCH_SIZE / WRITE_SIZE passes
 #   (separate, --kernel-trace only, the program directly after `--`); gather = trace + counters of tools/gather_hbm.py;
 #   graph = throughput + kernel trace of the generic-layer towers (tools/graph_bench.py);
-#   sq = SQ / TCP counters of the step kernels (MFMA-busy, L2 -> L1 requests, waitcnt share) on Taobao-10 bs 1,024 and
-#   Taobao-30 bs 4,096 -> pmc_sq_latest.json (bench.py puts them beside the roofline fractions); gis = the in-step gather
+#   sq = SQ / TCP counters of the step kernels (MFMA-busy, L2 -> L1 requests, waitcnt share) on Taobao-10 bs 1,024,
+#   Taobao-30 bs 4,096, Amazon-6 bs 1,024 and Amazon-13 bs 8,192 -> pmc_sq_latest.json (bench.py puts them beside the roofline fractions); gis = the in-step gather
 #   phase from a -DMAMDR_STAMPS build (tools/r06_gather_in_step.py) -> gather_in_step.json.
 # Every command is bounded by `timeout` and reads /dev/null: a hung profiler must not eat the GPU budget.
 # Summaries land in gpurun_out/<tag>/; copy what is to be judged into profiles/ by hand.
@@ -60,7 +60,7 @@ if has graph; then
     timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/graph_trace" -o run -- python3 "$REPO/tools/graph_bench.py" 1 all inproc > "$OUT/graph_trace.log" 2>&1
 fi
 if has sq; then
-    for WB in "taobao10 1024" "taobao30 4096"; do
+    for WB in ${SQ_WORKLOADS:-"taobao10 1024" "taobao30 4096" "amazon6 1024" "amazon13 8192"}; do
         set -- $WB
         i=0
         for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" \
@@ -79,7 +79,7 @@ try:
     merged = json.load(open("profiles/pmc_sq_latest.json"))
 except Exception:
     merged = {}
-for w in ("taobao10", "taobao30"):
+for w in ("taobao10", "taobao30", "amazon6", "amazon13"):
     for db in sorted(glob.glob(out + "/sq_%s_g*/**/*.db" % w, recursive=True)):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for k, n, v in sqlite3.connect(db).execute("select kernel_name, counter_name, value from counters_collection"):
@@ -95,7 +95,7 @@ for w in ("taobao10", "taobao30"):
                 ent["launches_in_pass"] = len(next(iter(cs.values())))
 json.dump(merged, open(out + "/pmc_sq_latest.json", "w"), indent=1)
 for k in sorted(merged):
-    if k.startswith(("k_tower", "k_wgrad", "k_update")):
+    if k.startswith(("k_tower", "k_wgrad", "k_update", "k_star", "k_emb")):
         print(k, {n: round(v) for n, v in merged[k].items()})
 PY
     rm -rf "$OUT"/sq_*_g?
