@@ -36,6 +36,43 @@ def test_library_exports_every_declared_symbol():
         _lib.check(_lib.ENOTBUILT)
 
 
+def test_no_kernel_of_the_shipped_library_spills_to_scratch():
+    """Every gfx950 kernel of libmamdr_hip.so has a private segment of 0 bytes (k_pcgrad's 80-byte local table excepted):
+    read from the code objects' own metadata (the clang offload bundles inside the .so -> llvm-readelf --notes).  Round 6 met
+    the failure this guards against: two call sites of one device body made the compiler index the by-value argument
+    structs dynamically -- 296 B of scratch per lane, Amazon-13's step 165 -> 207 us, every parity test still green."""
+    import struct
+    import tempfile
+    from mamdr_amd import _lib
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not found")
+    _lib.load()
+    data = open(_lib.LIB_PATH, "rb").read()
+    sizes = {}
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        i = m.start()
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, sz, ts = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + ts].decode()
+            off += ts
+            if "gfx950" not in triple or not sz:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(data[i + o:i + o + sz])
+                f.flush()
+                notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+            for name, size in re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+                sizes[name] = int(size)
+    assert len(sizes) >= 100, len(sizes)          # (111 kernels at the end of round 6)
+    spilled = {k: v for k, v in sizes.items() if v and "k_pcgrad" not in k}
+    assert not spilled, spilled
+    assert all(v <= 128 for v in sizes.values()), {k: v for k, v in sizes.items() if v > 128}
+
+
 def test_environment_switch_registry_is_complete():
     """ONE table of environment switches (csrc/env_registry.h, mamdr_env_switches): every MAMDR_* name that any source file
     reads from the environment is listed, a name nobody reads is reported (mamdr_env_unknown), and the library never
