@@ -49,7 +49,7 @@ def test_no_kernel_of_the_shipped_library_spills_to_scratch():
         pytest.skip("llvm-readelf not found")
     _lib.load()
     data = open(_lib.LIB_PATH, "rb").read()
-    sizes = {}
+    sizes, vgprs = {}, {}
     for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
         i = m.start()
         n = struct.unpack_from("<Q", data, i + 24)[0]
@@ -67,10 +67,16 @@ def test_no_kernel_of_the_shipped_library_spills_to_scratch():
                 notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
             for name, size in re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes):
                 sizes[name] = int(size)
+            for blk in notes.split("- .agpr_count:")[1:]:
+                vgprs[re.search(r"\.name:\s+(\S+)", blk).group(1)] = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
     assert len(sizes) >= 100, len(sizes)          # (111 kernels at the end of round 6)
     spilled = {k: v for k, v in sizes.items() if v and "k_pcgrad" not in k}
     assert not spilled, spilled
     assert all(v <= 128 for v in sizes.values()), {k: v for k, v in sizes.items() if v > 128}
+    # the 384-wide Star tower runs TWO 8-wave tiles per CU (512 VGPRs per SIMD lane / 4 waves): it must stay within 128
+    # (64.9 -> 72 us at 8,192 rows when it did not)
+    star = [v for k, v in vgprs.items() if "k_towerILb1ELi384ELb0ELb0E" in k]
+    assert len(star) == 1 and star[0] <= 128, star
 
 
 def test_environment_switch_registry_is_complete():
