@@ -2498,7 +2498,7 @@ int mamdr_graph_set_counters(mamdr_graph* g, int64_t optimizer_steps, int64_t dr
         return gfail(MAMDR_EINVAL, "mamdr_graph_set_counters(%lld, %lld): out of range", (long long)optimizer_steps, (long long)dropout_steps);
     g->adam_t = optimizer_steps;
     float b1 = 1.f, b2 = 1.f;
-    for (int64_t t = 0; t < optimizer_steps; ++t) {
+    for (int64_t t = 0; t < optimizer_steps && (b1 != 0.f || b2 != 0.f); ++t) {
         b1 *= g->cfg.adam_beta1;
         b2 *= g->cfg.adam_beta2;
     }

@@ -1114,7 +1114,7 @@ int mamdr_set_counters(mamdr_ctx* c, int64_t optimizer_steps, int64_t dropout_st
     c->flush_t = optimizer_steps;
     c->adam_t = optimizer_steps;
     float b1 = 1.0f, b2 = 1.0f;                 // TF's running products, one fp32 rounding per step (as the step loop forms them)
-    for (int64_t t = 0; t < optimizer_steps; ++t) {
+    for (int64_t t = 0; t < optimizer_steps && (b1 != 0.f || b2 != 0.f); ++t) {      // (both products end at 0: ~1e5 steps)
         b1 = b1 * c->cfg.adam_beta1;
         b2 = b2 * c->cfg.adam_beta2;
     }
