@@ -99,7 +99,7 @@ __device__ __forceinline__ void emb_apply_row4(const EmbStepArgs& a, const EmbTa
 // Star: one element of PartitionedNorm's backward (see EmbStepArgs::pn_sums); c = column of the 384-wide input
 __device__ __forceinline__ float pn_fix1(const EmbStepArgs& a, int c, float g, float x) {
 #pragma clang fp contract(off)
-    const float m1 = a.pn_sums[c] / a.pn_rows, m2 = a.pn_sums[XDIM + c] / a.pn_rows;
+    const float m1 = a.pn_means[c], m2 = a.pn_means[XDIM + c];
     const float xh = nc_mul(nc_sub(x, a.pn[2 * XDIM + c]), a.pn[3 * XDIM + c]);
     // (t in ONE fused multiply-add: k_star_pnb_apply's rounding, star_bodies.h pn_bwd_t)
     return nc_mul(a.pn[4 * XDIM + c], __builtin_fmaf(-m2, xh, nc_sub(g, m1)));

@@ -380,8 +380,8 @@ static void fill_emb_args(const mamdr_ctx* c, int32_t optimizer, float alpha, fl
     ea.t_now = (int)c->adam_t;
     if (c->star && c->star_pn_fused) {         // PartitionedNorm's backward rides in k_emb_reduce (EmbStepArgs::pn_sums)
         ea.pn_sums = c->star_sums;
+        ea.pn_means = c->star_sums + 2 * XDIM + EMB;
         ea.pn = c->pn;
-        ea.pn_rows = (float)rows;
     }
     EmbTable& tu = ea.t[0];
     EmbTable& ti = ea.t[1];
@@ -635,6 +635,7 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
     ba.sums = c->star_sums;
     ba.dmpart = c->star_dmpart;
     ba.dmsum = c->star_sums + 2 * XDIM;
+    ba.means = c->star_sums + 2 * XDIM + EMB;
     ba.fused = c->star_pn_fused ? 1 : 0;
     // lazy table Adam with fused tails: PartitionedNorm's backward first (it only needs the tower's outputs), then
     // [k_wgrad + k_emb_reduce(t) + k_emb_rows(t+1)], then [k_star_update + k_emb_catchup(t+1)]
@@ -656,8 +657,8 @@ static int star_train_step(mamdr_ctx* c, const SplitData& d, int domain, const i
         tea.apply_now = 1;
         if (no_apply) {
             tea.pn_sums = c->star_sums;
+            tea.pn_means = c->star_sums + 2 * XDIM + EMB;
             tea.pn = c->pn;
-            tea.pn_rows = (float)rows;
         }
         Prof p(c, MAMDR_KERNEL_WGRAD);
         launch_wgrad_reduce(wa, tea, next_rows, ba.fused == 1 ? nullptr : &ba, c->stream);
@@ -849,7 +850,7 @@ int mamdr_create(const mamdr_config* cfg, void* stream, mamdr_ctx** out) {
         ALLOC(c->star_alpha, (size_t)STAR_ALPHA_CAP * sizeof(float));
         if (const char* sd = getenv("MAMDR_STAR_DENSE_SLICES")) c->star_dense_slices = atoi(sd) != 0;
         ALLOC(c->star_part, chunks * 2 * XDIM * sizeof(double));    // forward: double sums; backward: float sums
-        ALLOC(c->star_sums, (2 * XDIM + EMB) * sizeof(float));
+        ALLOC(c->star_sums, (4 * XDIM + EMB) * sizeof(float));      // sums | domain-row gradient | s1 / B, s2 / B
         ALLOC(c->star_dmpart, chunks * EMB * sizeof(float));
     }
     if (cfg->emb_trainable || c->star) {

@@ -680,9 +680,10 @@ struct EmbStepArgs {
     // Star tower: dxe holds d loss / d NORMALISED input; PartitionedNorm's backward through the batch statistics,
     // dx = coef (( dxn - s1 / B) - xhat s2 / B), xhat = (x - mean) inv, is applied to every gathered gradient row on the
     // fly (x = the table row itself) -- k_star_pnb_apply's arithmetic without its pass over the batch.  null = dxe is d x
-    const float* pn_sums;      // [2][384] column sums s1, s2 over the batch (k_star_pnb_final)
+    const float* pn_sums;      // [2][384] column sums s1, s2 over the batch (k_star_pnb_final); non-null = the switch
+    const float* pn_means;     // [2][384] s1 / B, s2 / B (k_star_pnb_final forms the quotients once: the same IEEE division
+                               // every consumer did per element)
     const float* pn;           // PartitionedNorm workspace [scale | shift | mean | inv | coef | ...] x 384
-    float pn_rows;             // B
 };
 struct EmbRowsArgs {           // k_emb_rows: row ids + representatives of the batch BEFORE the tower runs
     const int32_t* uid;
@@ -739,6 +740,7 @@ struct StarPnBwdArgs {
     const float* pn;
     float* part;               // [chunks][2][384]
     float* sums;               // [2][384] s1 = sum dxn, s2 = sum dxn * xhat
+    float* means;              // [2][384] s1 / B, s2 / B
     float* dmpart;             // [chunks][EMB] column sums of dx[:, 256:384]
     float* dmsum;              // [EMB] their total
     int fused;                 // 1: k_star_pnb_final is the only launch (it also finishes dmsum; the table rows get their

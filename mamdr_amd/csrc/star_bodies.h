@@ -25,8 +25,7 @@ __device__ __forceinline__ void star_pnb_dom_body(const StarPnBwdArgs& a, int bx
     const int c = 2 * EMB + kk;
     const int r0 = ch * STAR_CHUNK;
     const int nb = min(STAR_CHUNK, a.rows - r0);
-    const float B = (float)a.rows;
-    const float m1 = a.sums[c] / B, m2 = a.sums[XDIM + c] / B;
+    const float m1 = a.means[c], m2 = a.means[XDIM + c];
     const float coef = a.pn[4 * XDIM + c];
     const float xh = (a.dm_row[kk] - a.pn[2 * XDIM + c]) * a.pn[3 * XDIM + c];
     float g[STAR_CHUNK];

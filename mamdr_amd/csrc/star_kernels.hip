@@ -337,6 +337,11 @@ __global__ __launch_bounds__(512) void k_star_pnb_final(const StarPnBwdArgs a) {
     }
     a.sums[c] = s1;
     a.sums[XDIM + c] = s2;
+    {       // the quotients every consumer of d x needs (k_star_pnb_apply forms the same two per thread)
+        const float B = (float)a.rows;
+        a.means[c] = s1 / B;
+        a.means[XDIM + c] = s2 / B;
+    }
     // fused form (a.fused): nobody walks the batch again for d x.  The table rows get PartitionedNorm's backward
     // inside k_emb_reduce (EmbStepArgs::pn_sums); the domain row's gradient is the column sum of
     // dx = coef ((dxn - s1 / B) - xhat s2 / B) over the batch, and every sample of the batch carries the SAME domain row
