@@ -115,11 +115,28 @@ def read_dump(dump):
     return raw[:4 * n * P].reshape(n, 4, P), raw[4 * n * P:].reshape(2, P)
 
 
-def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0, dump=False):
+class PassShaker(object):
+    """The oracle model of a perturbed TWIN: the live weights are changed by one fp32 rounding (relative `perturb` per element)
+    after every training pass -- "another fp32 evaluation of this training" rounds differently in every pass, not only in the
+    initial weights (run_pipeline's twins do the same on the engine level; tests/ensemble.py)."""
+
+    def __init__(self, model, rs, perturb):
+        self.model, self.rs, self.perturb = model, rs, perturb
+
+    def __getattr__(self, name):
+        return getattr(self.model, name)
+
+    def train_pass(self, *a, **k):
+        out = self.model.train_pass(*a, **k)
+        self.model.set_flat(perturbed(self.model.get_flat(), self.rs, self.perturb))
+        return out
+
+
+def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0, dump=False, pseed=99):
     """oracle/loops.mamdr_epoch (model_zoo/mamdr.py:41-108) x epochs, then every domain's validation AUC with the merged
     weights theta + phi_d (specific_base_model.py:64-97).  The per-pass shuffles are plan.PassShuffler's stream -- the
-    one plan.EpochShuffles hands the HIP side.  perturb > 0: the SECOND oracle run of the self-divergence instrument --
-    every trainable initial tensor (theta's and the phi_d's; not the frozen tables) changed at rounding level."""
+    one plan.EpochShuffles hands the HIP side.  perturb > 0: a perturbed TWIN (tests/ensemble.py) -- every trainable initial
+    tensor (theta's and the phi_d's; not the frozen tables) and the live weights after every pass changed at rounding level."""
     from mamdr_amd import plan as mplan
     from oracle import auc as oauc
     from oracle import loops as oloops
@@ -131,12 +148,14 @@ def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0, dump=False):
                                dropout=0.5, lr=1e-3, dropout_seed=DROPOUT_SEED)
     theta = model.get_flat().copy()
     phis = [p.copy() for p in pb["phis0"]]
-    if perturb > 0:
-        prs = np.random.RandomState(99)
+    rec = PassDump(model, "%s_bs%d" % (shape, batch)) if dump else None
+    if perturb > 0:         # (`pseed` draws the twin: the K twins of an ensemble differ in it)
+        prs = np.random.RandomState(pseed)
         theta = perturbed(theta, prs, perturb)
         phis = [perturbed(p, prs, perturb) for p in phis]
+        assert rec is None
+        rec = PassShaker(model, np.random.RandomState(pseed + 7919), perturb)
     shuf = mplan.PassShuffler(pb["sizes"], 10000, SHUFFLE_SEED)
-    rec = PassDump(model, "%s_bs%d" % (shape, batch)) if dump else None
     t0 = time.time()
     trace = []
     for plan in pb["plans"]:
@@ -148,7 +167,7 @@ def job_fullsize_mamdr(shape, batch, meta_lr, epochs, perturb=0.0, dump=False):
         _, preds = model.evaluate(g["data"]["val"][d], batch)
         aucs.append(float(oauc.auc500(g["data"]["val"][d]["label"], preds, batch)))
     out = dict(trace=trace, aucs=aucs, secs=secs, theta=theta)
-    if rec is not None:
+    if dump:
         out["dump"] = rec.close()
     return out
 
@@ -214,7 +233,19 @@ class StarMeta(object):
 
     def train_pass(self, data, perm, batch_size, max_steps=0, accumulate_into=None):
         assert accumulate_into is None
-        return self.m.train_pass(data, perm, batch_size, max_steps)
+        out = self.m.train_pass(data, perm, batch_size, max_steps)
+        if self.shake is not None:
+            # a perturbed twin (tests/ensemble.py): every tensor but the two 180 MB tables changed by one fp32 rounding after
+            # every pass (the tables' touched rows pick the difference up in the next pass; shaking 92 M table elements 28
+            # times would cost more than the oracle's epoch)
+            rs, rel = self.shake
+            for n_ in sorted(self.m.params):
+                a = self.m.params[n_]
+                if a.dtype == F32 and n_ not in ("user_emb", "item_emb"):
+                    a[...] = perturbed(a, rs, rel)
+        return out
+
+    shake = None
 
 
 def problem_amazon13(batch=8192, keras_init=False):
@@ -255,11 +286,12 @@ def star_phi0(pb, d, n_meta, names_meta=None):
     return v
 
 
-def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0, phi0="init"):
+def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0, phi0="init", pseed=99):
     """oracle/loops.mamdr_epoch on oracle/star.OracleStar (dense Adam over every table row and every per-domain slice
-    each step).  perturb > 0: every initial tensor multiplied by (1 + perturb * N(0, 1)) elementwise in fp32 -- a second
-    oracle run whose distance from the first measures the oracle's own sensitivity to rounding-level input changes
-    (the instrument of tests/test_gpu_parity.py's miniature Star test, here at the full table size)."""
+    each step).  perturb > 0: a perturbed TWIN -- every initial tensor multiplied by (1 + perturb * N(0, 1)) elementwise in fp32
+    and the small tensors again after every pass (StarMeta.shake); `pseed` draws the twin.  Its distance from the unperturbed
+    run measures the oracle's own sensitivity to rounding-level changes (the instrument of tests/test_gpu_parity.py's
+    miniature Star test, here at the full table size)."""
     from oracle import auc as oauc
     from oracle import loops as oloops
     from oracle import outer as oouter
@@ -268,13 +300,15 @@ def job_amazon13_star(batch=8192, keras_init=False, perturb=0.0, phi0="init"):
     g, doms, plan = pb["g"], pb["doms"], pb["plan"]
     params = pb["params"]
     if perturb > 0:
-        prs = np.random.RandomState(99)
+        prs = np.random.RandomState(pseed)
         for n_ in sorted(params):
             a = params[n_]
             if a.dtype == F32:
                 params[n_] = perturbed(a, prs, perturb)
     model = ostar.OracleStar(params, emb_trainable=True, lr=1e-3)
     wrapped = StarMeta(model)
+    if perturb > 0:
+        wrapped.shake = (np.random.RandomState(pseed + 7919), perturb)
     theta = wrapped.get_flat().copy()
     if keras_init and phi0 == "init":
         phis = {d: star_phi0(pb, d, theta.size) for d in doms}

@@ -8,7 +8,9 @@ k_wgrad_adam + the pending domain-table step; bs 4096: k_tower + k_wgrad + k_upd
 (oracle/loops.mamdr_epoch, the restatement of model_zoo/mamdr.py:41-108 + specific_base_model.py:64-97) on the same
 plan, shuffles and dropout masks.  Asserted: the traces are equal and |AUC_hip - AUC_oracle| <= 1e-3 on EVERY
 domain's validation split with the merged weights theta + phi_d (north_star: "per-domain AUC matches the reference
-within 1e-3").
+within 1e-3") -- plain, no self-divergence term (round 6); the two two-epoch cases at the configs' own meta learning
+rate, where a rounding-level twin of the ORACLE is already up to 8.5e-4 from it, are asserted against an ensemble of six
+oracle runs instead (tests/ensemble.py).  Every pass of the same epochs is also compared chaos-free: tests/test_gpu_teacher.py.
 """
 import time
 
@@ -20,12 +22,13 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import oracle_jobs                      # noqa: E402  (tests/oracle_jobs.py: the oracle side, in worker processes)
+from ensemble import Ensemble, TWIN_SEEDS      # noqa: E402
 from oracle import tower as otower      # noqa: E402
 
 F32 = np.float32
 
 
-def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3, dump=False):
+def run_case(shape, batch, meta_lr, epochs=1, dump=False, ensemble=False):
     """HIP side on the host path bench.py times (bench.py:439-482): plan.EpochShuffles (every permutation of an epoch from
     one C call, one upload, the NEXT epoch's drawn on the prefetch thread) + parallel.BalancedMAMDR(world 1).epoch, hence
     meta.PassWindow with `peek` -> mamdr_pregather_passes -> k_pass_prep_multi on the fused path.  The oracle (worker
@@ -75,30 +78,37 @@ def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3, dump=False):
         assert hits == 0 and launches == 0
     ora = oracle_jobs.result("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=0.0,
                              **({"dump": True} if dump else {}))
-    # the instrument of the Keras-init Star case, for every full-size case: a second oracle run from initial tensors that
-    # differ at rounding level -- its distance from the first is what ANY two fp32 evaluations of this training differ by
-    orb = oracle_jobs.result("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=PERTURB)
-    assert trace_g == ora["trace"] == orb["trace"]
+    # perturbed oracle twins (tests/ensemble.py): runs whose initial tensors and live weights after every pass differ at
+    # rounding level -- what ANY fp32 evaluation of this training is distributed like.  One twin is printed beside every
+    # case; the two-epoch cases at the configs' own meta learning rate (the chaotic ones: a twin of theirs is up to 8.5e-4
+    # from the oracle) are asserted against the ensemble of K = 5, the others against north_star's PLAIN 1e-3.
+    twins = [oracle_jobs.result("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=PERTURB,
+                                pseed=sd) for sd in (TWIN_SEEDS if ensemble else TWIN_SEEDS[:1])]
+    orb = twins[0]
+    assert all(trace_g == m["trace"] for m in [ora] + twins)
     n_steps = sum(t[2] for t in trace_g)
     print("%s bs %d: %d domain-steps in %d passes (%d pregather launches, %d calls served); oracle %.1f s (waited %.1f s), "
           "hip %.2f s" % (shape, batch, n_steps, len(trace_g), launches, hits, ora["secs"], ora.get("waited_seconds", 0.0),
                           gsecs))
     merged = eng.new_vector()
-    worst, worst_self, beyond, aucs = 0.0, 0.0, 0, []
+    worst, worst_self, beyond, aucs, auc_hip = 0.0, 0.0, 0, [], {}
     for d in range(D):
         eng.merge(merged, theta_g, balanced.phis[d], "plus")
         eng.set_weights(merged)
         _, auc_g = eng.evaluate(d, "val")
+        auc_hip[d] = auc_g
         auc_o, self_div = ora["aucs"][d], abs(ora["aucs"][d] - orb["aucs"][d])
-        print("  domain %2d: val rows %6d  AUC hip %.5f oracle %.5f  diff %+.1e   (oracle self-divergence %.1e)" % (
+        print("  domain %2d: val rows %6d  AUC hip %.5f oracle %.5f  diff %+.1e   (oracle vs its first twin %.1e)" % (
             d, eng.n_rows(d, "val"), auc_g, auc_o, auc_g - auc_o, self_div))
         worst, worst_self = max(worst, abs(auc_g - auc_o)), max(worst_self, self_div)
-        beyond += abs(auc_g - auc_o) > max_auc_diff
+        beyond += abs(auc_g - auc_o) > 1e-3
         aucs.append(auc_o)
-        # north_star's 1e-3, plus twice what the oracle differs from ITSELF on this domain under a rounding-level change
-        assert abs(auc_g - auc_o) <= max_auc_diff + 2 * self_div, (d, auc_g, auc_o, orb["aucs"][d])
-    # ... and the plain bar on (nearly) every domain: at most one domain in ten may need the self-divergence term
-    assert beyond <= D // 10, (beyond, D)
+        if not ensemble:
+            assert abs(auc_g - auc_o) <= 1e-3, (d, auc_g, auc_o)           # north_star's bar, plain
+    if ensemble:        # no factor on a single draw, no allowed share of misses: not an outlier of six oracle runs
+        ens = Ensemble([ora] + twins)
+        ens.check("val", auc_hip, [{d: m["aucs"][d] for d in range(D)} for m in [ora] + twins])
+        ens.aggregate("%s bs %d, %d epochs" % (shape, batch, epochs))
     # theta itself (0.56 MB): the outer updates of both sides applied to inner passes that agree to rounding
     th_g, th_o = eng.unpack(theta_g), ora["theta"]
     o, worst_th = 0, 0.0
@@ -119,23 +129,24 @@ def run_case(shape, batch, meta_lr, epochs=1, max_auc_diff=1e-3, dump=False):
 PERTURB = 2e-7
 
 
-def _job(shape, batch, meta_lr, epochs, dump=False):
+def _job(shape, batch, meta_lr, epochs, dump=False, ensemble=False):
     """dump: the unperturbed oracle run also writes its per-pass states -- the SAME run serves the teacher-forced epoch of
-    tests/test_gpu_teacher.py (one oracle epoch, two tests)."""
+    tests/test_gpu_teacher.py (one oracle epoch, two tests).  ensemble: K = 5 perturbed twins instead of one."""
     def deco(fn):
-        for pt in (0.0, PERTURB):
-            kw = {"dump": True} if (dump and pt == 0.0) else {}
+        fn = pytest.mark.oracle_job("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs, perturb=0.0,
+                                    **({"dump": True} if dump else {}))(fn)
+        for sd in (TWIN_SEEDS if ensemble else TWIN_SEEDS[:1]):
             fn = pytest.mark.oracle_job("fullsize_mamdr", shape=shape, batch=batch, meta_lr=meta_lr, epochs=epochs,
-                                        perturb=pt, **kw)(fn)
+                                        perturb=PERTURB, pseed=sd)(fn)
         return fn
     return deco
 
 
-@_job("taobao10", 1024, 0.1, 2)
+@_job("taobao10", 1024, 0.1, 2, ensemble=True)
 def test_taobao10_bs1024_two_epochs_config_meta_lr():
     """BASELINE.json configs[1] as configured (config/Taobao-10/deepctr_DN+DR.json: meta_learning_rate 0.1): 10
     domains, 92,137 train rows, bs 1024 -> 2 x 1,2xx inner steps on the fused path (oracle AUC ~0.6-0.75 by then)."""
-    run_case("taobao10", 1024, meta_lr=0.1, epochs=2)
+    run_case("taobao10", 1024, meta_lr=0.1, epochs=2, ensemble=True)
 
 
 @_job("taobao10", 1024, 0.5, 1, dump=True)
@@ -152,11 +163,11 @@ def test_taobao30_bs4096_full_epoch_auc_parity():
     run_case("taobao30", 4096, meta_lr=0.5, dump=True)
 
 
-@_job("taobao30", 4096, 0.1, 2)
+@_job("taobao30", 4096, 0.1, 2, ensemble=True)
 def test_taobao30_bs4096_two_epochs_config_meta_lr():
     """BASELINE.json configs[3] as configured (config/Taobao_30/deepctr_DN+DR_bs4096.json: meta_learning_rate 0.1): two
     meta-epochs = 3,0xx inner steps on the slab path (VERDICT r03 weak #4: the one-epoch case above runs at 0.5)."""
-    run_case("taobao30", 4096, meta_lr=0.1, epochs=2)
+    run_case("taobao30", 4096, meta_lr=0.1, epochs=2, ensemble=True)
 
 
 # ------------------------------------------------------------------ configs[2] and configs[4]: trainable FULL-SIZE tables
@@ -312,8 +323,17 @@ def test_amazon13_star_mamdr_epoch_trainable_full_tables():
 KERAS_PERTURB = 2e-7
 
 
+KERAS_ZERO_SEEDS = TWIN_SEEDS[:3]        # the phi0 = 0 diagnostic: an ensemble of four oracle runs (57 s of CPU each)
+
+
+def _keras_seeds(phi0):
+    return KERAS_ZERO_SEEDS if phi0 == "zero" else TWIN_SEEDS[:1]
+
+
 def _keras_jobs(phi0):
-    return [pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=True, perturb=pt, phi0=phi0) for pt in (0.0, KERAS_PERTURB)]
+    return [pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=True, perturb=0.0, phi0=phi0)] + [
+        pytest.mark.oracle_job("amazon13_star", batch=8192, keras_init=True, perturb=KERAS_PERTURB, phi0=phi0, pseed=sd)
+        for sd in _keras_seeds(phi0)]
 
 
 @pytest.mark.parametrize("phi0", [pytest.param("init", marks=_keras_jobs("init")), pytest.param("zero", marks=_keras_jobs("zero"))])
@@ -324,26 +344,35 @@ def test_amazon13_star_mamdr_epoch_at_keras_initial_values(phi0):
     of (x - mean), their kernel rows' gradients are noise and Adam turns noise into +- lr steps: the problem is
     ill-conditioned for ANY fp32 evaluation.  The instrument that shows it: a SECOND ORACLE run
     whose initial tensors are perturbed by 2e-7 relative (one fp32 rounding) -- its distance from the first oracle run
-    is the oracle's self-divergence.  Bar per domain: |AUC_hip - AUC_oracle| <= 1e-3 + 2 x |AUC_oracle - AUC_oracle'|;
-    a HIP side beyond it would be a kernel bug, not conditioning.  The tail tensors (outside theta / phi) are reported
-    the same way: relative L2 distance hip-oracle next to oracle-oracle'.
+    is the oracle's self-divergence, printed beside every domain.  Bar per domain, phi0 "init" (the reference's state):
+    north_star's PLAIN |AUC_hip - AUC_oracle| <= 1e-3 (round 6; the measured distances are 3e-5 - 6e-5, the self-divergence
+    term of rounds 4 - 5 was never needed).  phi0 "zero" (not a state the reference starts from; one domain 2e-3 off with an
+    oracle twin of its own 7.5e-4 off): not an outlier of an ensemble of four oracle runs (tests/ensemble.py).  The tail tensors (outside theta / phi) are reported the same way: relative L2 distance hip-oracle
+    next to oracle-oracle'.
     phi0 "init": phi_d as the reference draws it.  phi0 "zero": the starting point of round 4's diagnostic
     (profiles/r04_star13_phases_keras_init.txt: one domain 2.0e-3 off, then unexplained) under the same instrument."""
     h = _star_case(True, phi0)
     ora = oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=0.0, phi0=phi0)
-    orb = oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=KERAS_PERTURB, phi0=phi0)
-    assert h["trace"] == ora["trace"] == orb["trace"]
+    twins = [oracle_jobs.result("amazon13_star", batch=8192, keras_init=True, perturb=KERAS_PERTURB, phi0=phi0, pseed=sd)
+             for sd in _keras_seeds(phi0)]
+    orb = twins[0]
+    assert all(h["trace"] == m["trace"] for m in [ora] + twins)
     print("amazon13 star MAMDR at Keras init (phi0 %s), bs 8192: %d domain-steps; oracle %.1f s + perturbed oracle %.1f s, hip %.2f s" % (
         phi0, h["n_steps"], ora["secs"], orb["secs"], h["secs"]))
-    worst_excess, aucs = 0.0, []
+    worst, aucs = 0.0, []
     for d in h["doms"]:
         a_h, a_o, a_p = h["aucs"][d], ora["aucs"][d], orb["aucs"][d]
         self_div = abs(a_o - a_p)
         print("  domain %2d: AUC hip %.5f oracle %.5f oracle' %.5f | |hip - oracle| %.1e, oracle self-divergence %.1e" % (
             d, a_h, a_o, a_p, abs(a_h - a_o), self_div))
         aucs.append(a_o)
-        worst_excess = max(worst_excess, abs(a_h - a_o) - 2 * self_div)
-        assert abs(a_h - a_o) <= 1e-3 + 2 * self_div, (d, a_h, a_o, a_p)
+        worst = max(worst, abs(a_h - a_o))
+        if phi0 == "init":
+            assert abs(a_h - a_o) <= 1e-3, (d, a_h, a_o, a_p)
+    if phi0 != "init":
+        ens = Ensemble([ora] + twins)
+        ens.check("val", h["aucs"], [m["aucs"] for m in [ora] + twins])
+        ens.aggregate("amazon13 star at Keras init, phi0 = 0")
     names = sorted(ora["tail"])
     t_h, t_o, t_p = (np.concatenate([x["tail"][n_] for n_ in names]) for x in (h, ora, orb))
     rel_h = float(np.linalg.norm(t_h - t_o) / np.linalg.norm(t_o))
@@ -352,4 +381,4 @@ def test_amazon13_star_mamdr_epoch_at_keras_initial_values(phi0):
     assert rel_h <= 3 * rel_p + 1e-4, (rel_h, rel_p)
     assert float(np.mean(aucs)) > 0.55, aucs
     np.testing.assert_array_equal(h["aux"]["steps"], ora["steps"])
-    print("  largest |hip - oracle| - 2 x self-divergence: %+.1e (bar 1e-3)" % worst_excess)
+    print("  largest |hip - oracle|: %.1e (bar 1e-3, plain)" % worst)

@@ -54,12 +54,12 @@ def test_dumped_passes_replay_bit_for_bit():
 
 
 def test_ensemble_bars_accept_a_member_and_reject_an_offset():
-    """tests/test_gpu_e2e.Ensemble on synthetic AUCs: runs drawn like the members pass (20 of 20 draws); a run with a
+    """tests/ensemble.Ensemble on synthetic AUCs: runs drawn like the members pass (20 of 20 draws); a run with a
     systematic offset of two sigma fails the mean-distance bar; a single comparison twelve sigma out fails the
     largest-distance bar."""
     import pytest
     pytest.importorskip("torch")
-    from test_gpu_e2e import Ensemble
+    from ensemble import Ensemble
     rs = np.random.RandomState(0)
     D, E, K1 = 10, 6, 6
     sigma = 8e-4 * (1 + rs.rand(1, D))                       # (domains differ in size, hence in spread)
