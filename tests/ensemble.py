@@ -16,8 +16,8 @@ class Ensemble(object):
     M = the LARGEST distance (a single outlying domain shows here).  The HIP run must not be an outlier of the ensemble in
     either: each of its statistics lies inside the one-sided 99.9 % PREDICTION INTERVAL for one more member,
     mean_k + t(0.999; K) * sd_k * sqrt(1 + 1 / (K + 1)) (Student t with K degrees of freedom over the K + 1 members' values:
-    6.4 sd for six members -- with eighteen such checks in the suite a run that IS a member fails one of them in ~2 % of
-    the sessions; at 3 sd it would in ~25 %).
+    6.4 sd for six members -- with two dozen such checks in the suite a run that IS a member fails one of them in ~2 % of
+    the sessions; at 3 sd it would in ~30 %).
     (Any rank criterion -- "no further out than the furthest member" -- fails a run that IS a member with probability
     1 / (K + 2) by symmetry, whatever K is affordable; tests/test_teacher_harness.py checks these bars on synthetic draws.)
     Where north_star's plain |hip - oracle| <= 1e-3 holds nothing else is needed; the count of comparisons beyond it is
