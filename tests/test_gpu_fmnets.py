@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+import oracle_jobs                      # noqa: E402
+from ensemble import Ensemble, TWIN_SEEDS      # noqa: E402
 from oracle import auc as oauc          # noqa: E402
 from oracle import fmnets as ofm        # noqa: E402
 from oracle import loops as oloops      # noqa: E402
@@ -284,14 +286,12 @@ def test_accumulate_steps_match_oracle(kind, emb_trainable):
 def test_domain_negotiation_auc_parity(kind):
     """the meta wrappers run on these towers too (deepctr.py's registry is orthogonal to run.py's wrappers): five
     Domain Negotiation epochs (domain_negotiation.py:49-88) on 4 domains, same order / shuffles / masks on both sides.
-    Bar: per-domain validation AUC within 1e-3 of the oracle -- plus twice the ORACLE'S OWN largest AUC shift (over the
-    domains, under +-2e-7 relative perturbations of theta), measured in the test: fp32 training of these towers at this
-    learning rate is chaotic (shifts of 8e-4 .. 5e-3 per domain for PNN, up to 3e-3 for NFM, up to 1e-2 for CCPM -- an
-    argmax over the fields behind every unit), the shift of one domain under one perturbation is itself a noisy sample of
-    that scale, and a bar tighter than the reference arithmetic's own reproducibility would test luck.  One-step
-    gradients, Adam passes and evaluation (above) are what pins the arithmetic; the mean over the domains is held to the
-    same bar without the factor two.  After the FIRST epoch -- before the amplification -- every domain is held to the plain
-    1e-3."""
+    After the FIRST epoch -- before the amplification -- every domain is held to north_star's plain 1e-3.  At the end of the
+    five epochs fp32 training of these towers at this learning rate is chaotic (an oracle twin whose weights differ by one
+    rounding ends 8e-4 .. 5e-3 per domain away for PNN, up to 3e-3 for NFM, up to 1e-2 for CCPM -- an argmax over the fields
+    behind every unit): there the HIP run must not be an outlier of an ensemble of six oracle runs (round 6, tests/ensemble.py;
+    rounds 3 - 5 asserted 1e-3 plus twice one twin's shift).  One-step gradients, Adam passes, evaluation (above) and the
+    teacher-forced epochs (below) are what pins the arithmetic."""
     from mamdr_amd import meta
     g, eng, model = make_problem(kind, scale=0.15)
     D = 4
@@ -309,9 +309,11 @@ def test_domain_negotiation_auc_parity(kind):
     theta0 = model.get_flat().copy()
     params0 = {k: v.copy() for k, v in model.params.items()}
 
-    def oracle_run(theta_start):
+    def oracle_run(theta_start, shake_seed=None):
         twin = ofm.OracleNet({k: v.copy() for k, v in params0.items()}, kind.split("@")[0], dropout=0.5, lr=LR, hidden=HIDDEN,
                              dropout_seed=eng.dropout_seed)
+        if shake_seed is not None:          # a perturbed twin rounds differently in every pass (tests/ensemble.py)
+            twin = oracle_jobs.PassShaker(twin, np.random.RandomState(shake_seed), 2e-7)
         theta = theta_start.copy()
         pf, traces = make_perm_fn(), []
 
@@ -329,9 +331,7 @@ def test_domain_negotiation_auc_parity(kind):
                 first = val_aucs()
         return val_aucs(), traces, first
     auc_o, tr_o, first_o = oracle_run(theta0)
-    auc_p, _, _ = oracle_run((theta0 * F32(1 + 2e-7)).astype(F32))
-    auc_m, _, _ = oracle_run((theta0 * F32(1 - 2e-7)).astype(F32))
-    chaos = max(max(abs(auc_o[d] - auc_p[d]), abs(auc_o[d] - auc_m[d])) for d in range(D))
+    twins = [oracle_run(oracle_jobs.perturbed(theta0, np.random.RandomState(sd), 2e-7), shake_seed=sd + 7919)[0] for sd in TWIN_SEEDS]
     theta_g = eng.get_weights()
     pf_g, tr_g = make_perm_fn(), []
     for k, seq in enumerate(seqs):
@@ -349,11 +349,12 @@ def test_domain_negotiation_auc_parity(kind):
     for d in range(D):
         _, auc_g = eng.evaluate(d, "val")
         got.append(auc_g)
-        print("%s domain %d: AUC hip %.5f oracle %.5f (perturbed oracles %.5f %.5f; largest shift %.1e)"
-              % (kind, d, auc_g, auc_o[d], auc_p[d], auc_m[d], chaos))
-    for d in range(D):
-        assert abs(got[d] - auc_o[d]) <= 1e-3 + 2 * chaos, (d, got[d], auc_o[d], chaos)
-    assert abs(np.mean(got) - np.mean(auc_o)) <= 1e-3 + chaos, (np.mean(got), np.mean(auc_o), chaos)
+        print("%s domain %d: AUC hip %.5f oracle %.5f (perturbed oracles %s)"
+              % (kind, d, auc_g, auc_o[d], " ".join("%.5f" % t[d] for t in twins)))
+    # end of training: not an outlier of the ensemble of six oracle runs (no factor on a single draw; tests/ensemble.py)
+    ens = Ensemble([None] * (1 + len(twins)))
+    ens.check("val", dict(enumerate(got)), [dict(enumerate(m)) for m in [auc_o] + twins])
+    ens.aggregate(kind)
     assert np.mean(auc_o) > 0.57
     eng.close()
 

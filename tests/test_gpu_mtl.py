@@ -13,6 +13,8 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+import oracle_jobs                      # noqa: E402
+from ensemble import Ensemble, TWIN_SEEDS      # noqa: E402
 from oracle import auc as oauc          # noqa: E402
 from oracle import mtl as omtl          # noqa: E402
 from oracle import rng as orng          # noqa: E402
@@ -244,18 +246,23 @@ def test_eval_predictions_match_oracle_at_equal_weights():
 @pytest.mark.parametrize("kind", ["shared_bottom", "mmoe", "ple"])
 def test_alternate_training_auc_parity(kind):
     """DeepMTLCTR.train (deep_mtl_ctr.py:69-96): epochs of one full pass per domain through that domain's model, in a
-    shuffled order; same order / shuffles / dropout masks on both sides; per-domain validation AUC within 1e-3 -- plus
-    twice the ORACLE'S OWN AUC shift under a 2e-7 relative perturbation of its initial weights, measured here (as
-    tests/test_gpu_fmnets.py): the summation order of the batch reductions is the kernels' own, and fp32 training
-    amplifies such last-bit differences (mmoe: up to 1e-3 on this problem after 16 passes)."""
+    shuffled order; same order / shuffles / dropout masks on both sides.  After the first epoch: per-domain validation AUC
+    within north_star's plain 1e-3.  After four: the summation order of the batch reductions is the kernels' own and fp32
+    training amplifies such last-bit differences (mmoe: up to 1e-3 on this problem after 16 passes), so the HIP run must not
+    be an outlier of an ensemble of six oracle runs whose weights differ by one rounding per pass (round 6, tests/ensemble.py;
+    rounds 3 - 5 asserted 1e-3 plus twice one twin's shift)."""
     g, eng, model, spec = make_problem(kind, dropout=0.5, scale=0.15)
     D = g["n_domain"]
     sizes = [g["data"]["train"][d]["uid"].shape[0] for d in range(D)]
     order = [[2, 0, 3, 1], [1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0]]
     LR = 2e-3               # (the configs' 1e-4 needs tens of epochs; the comparison wants a model that has learnt)
-    twin = omtl.OracleMTL({k: (v * F32(1 + 2e-7)).astype(F32) if v.dtype == F32 and "emb" not in k else v.copy()
-                           for k, v in model.params.items()}, spec, emb_trainable=False, dropout=0.5, lr=LR,
-                          dropout_seed=eng.dropout_seed)
+    def shaken(params, rs):           # every trainable tensor changed by one fp32 rounding (tests/ensemble.py)
+        return {k: oracle_jobs.perturbed(v, rs, 2e-7) if v.dtype == F32 and "emb" not in k else v.copy() for k, v in params.items()}
+    twins, twin_rs = [], []
+    for sd in TWIN_SEEDS:
+        twins.append(omtl.OracleMTL(shaken(model.params, np.random.RandomState(sd)), spec, emb_trainable=False, dropout=0.5, lr=LR,
+                                    dropout_seed=eng.dropout_seed))
+        twin_rs.append(np.random.RandomState(sd + 7919))
     model.lr = LR
     k = 0
     for e, seq in enumerate(order):
@@ -264,7 +271,11 @@ def test_alternate_training_auc_parity(kind):
             perm = orng.shuffle_perm(sizes[d], 10000, seed=500 + k)
             eng.train_steps(d, perm=torch.from_numpy(perm).to(eng.device), lr=LR)
             model.train_pass(d, g["data"]["train"][d], perm, 256)
-            twin.train_pass(d, g["data"]["train"][d], perm, 256)
+            for twin, rs in zip(twins, twin_rs):          # ... and again after every pass
+                twin.train_pass(d, g["data"]["train"][d], perm, 256)
+                for n_, v in twin.params.items():
+                    if v.dtype == F32 and "emb" not in n_:
+                        v[...] = oracle_jobs.perturbed(v, rs, 2e-7)
         if e == 0:      # after ONE epoch the rounding-level differences have not been amplified yet: the plain 1e-3 bar
             for d in range(D):
                 _, a1 = eng.evaluate(d, "val")
@@ -272,18 +283,21 @@ def test_alternate_training_auc_parity(kind):
                 o1 = float(oauc.auc500(g["data"]["val"][d]["label"], p1, 256))
                 print("%s domain %d after the first epoch: AUC hip %.5f oracle %.5f" % (kind, d, a1, o1))
                 assert abs(a1 - o1) <= 1e-3, (d, a1, o1)
-    aucs, got, shift = [], [], []
+    aucs, got, tw = [], [], [[] for _ in twins]
     for d in range(D):
         _, auc_g = eng.evaluate(d, "val")
         _, preds = model.evaluate(d, g["data"]["val"][d], 256)
         auc_o = float(oauc.auc500(g["data"]["val"][d]["label"], preds, 256))
-        _, preds_t = twin.evaluate(d, g["data"]["val"][d], 256)
-        shift.append(abs(auc_o - float(oauc.auc500(g["data"]["val"][d]["label"], preds_t, 256))))
-        print("%s domain %d: AUC hip %.5f oracle %.5f (oracle self-divergence %.1e)" % (kind, d, auc_g, auc_o, shift[-1]))
+        for j, twin in enumerate(twins):
+            _, preds_t = twin.evaluate(d, g["data"]["val"][d], 256)
+            tw[j].append(float(oauc.auc500(g["data"]["val"][d]["label"], preds_t, 256)))
+        print("%s domain %d: AUC hip %.5f oracle %.5f (perturbed oracles %s)" % (kind, d, auc_g, auc_o, " ".join("%.5f" % t[d] for t in tw)))
         aucs.append(auc_o)
         got.append(auc_g)
-    for d in range(D):      # the largest shift over the domains: one domain's shift is a noisy sample of the chaos scale
-        assert abs(got[d] - aucs[d]) <= 1e-3 + 2 * max(shift), (d, got[d], aucs[d], shift)
+    # end of training: not an outlier of the ensemble of six oracle runs (no factor on a single draw; tests/ensemble.py)
+    ens = Ensemble([None] * (1 + len(twins)))
+    ens.check("val", dict(enumerate(got)), [dict(enumerate(m)) for m in [aucs] + tw])
+    ens.aggregate(kind)
     assert np.mean(aucs) > 0.6
     eng.close()
 
