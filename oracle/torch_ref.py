@@ -5,7 +5,8 @@ Two uses, both outside the product path (only tests/ and bench.py's cpu_baseline
 * an independent cross-check of oracle/tower.py and oracle/star.py: those derive every gradient by hand in
   numpy fp32; here only the FORWARD is written down (the same published
   tensorflow-gpu==1.12.0 / deepctr==0.9.0 algorithms, requirements.txt:1,6) and torch.autograd differentiates
-  it in float64 (tests/test_oracle_crosscheck.py).  PARITY UNPINNED all the same: neither side is TF.
+  it in float64 (tests/test_oracle_crosscheck.py; the same file holds the mlp tower and the Adam update to scikit-learn's
+  MLPClassifier._backprop / AdamOptimizer, a third-party implementation of both).  PARITY UNPINNED all the same: no side is TF.
 * the CPU baseline of bench.py ("torch-CPU fp32, same step list, torch.set_num_threads(all cores)"):
   `TorchCpuModel.train_on_batch` = gather -> tower forward -> Keras BCE + regularisers -> autograd backward ->
   TF1 dense Adam over every trainable tensor, what `model.train_on_batch` of the compiled Keras model executes

@@ -311,3 +311,109 @@ def test_ccpm_autoint_gradients_vs_float64_autograd(kind, emb_trainable, rate, u
     np.testing.assert_allclose(pred, pred64, rtol=2e-5, atol=2e-7)
     assert sorted(g) == sorted(names)
     _check_grads(g, g64, names)
+
+
+# ---------------------------------------------------------------------------------------------- a third-party anchor
+# scikit-learn ships an independent implementation of BOTH halves of the inner step's dense part: a relu MLP with a
+# logistic output under the mean binary log-loss (sklearn.neural_network.MLPClassifier._backprop) and the Adam update
+# in exactly TensorFlow 1's operation form, lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); p -= lr_t m / (sqrt(v) + eps)
+# (sklearn.neural_network._stochastic_optimizers.AdamOptimizer; TF 1.12 python/training/adam.py documents the same
+# "epsilon hat" form).  It is not the reference's TensorFlow -- the inner step stays "parity unpinned" -- but it is code
+# neither this repository nor its author wrote, float64, and installed here.
+def _sklearn_mlp(params, hidden):
+    sk = pytest.importorskip("sklearn.neural_network")
+    clf = sk.MLPClassifier(hidden_layer_sizes=tuple(hidden), activation="relu", alpha=0.0, solver="adam")
+    L = len(hidden)
+    clf.n_layers_ = L + 2
+    clf.n_outputs_ = 1
+    clf.out_activation_ = "logistic"
+    clf.coefs_ = [params["W%d" % l].astype(np.float64) for l in range(L)] + [params["wo"].astype(np.float64)]
+    clf.intercepts_ = [params["b%d" % l].astype(np.float64) for l in range(L)] + [params["gb"].astype(np.float64)]
+    return clf
+
+
+@pytest.mark.parametrize("hidden", [(256, 128, 64), (64, 32)])
+def test_mlp_tower_loss_and_gradients_vs_sklearn_mlp(hidden):
+    """oracle/tower.loss_and_grads (mlp tower, no dropout) against scikit-learn's MLPClassifier._backprop on the same
+    gathered rows and the same weights: mean BCE and every dense gradient (W_l, b_l, output unit)."""
+    rs = np.random.RandomState(21)
+    n_user, n_item, n_domain, B = 200, 150, 4, 160
+    p = _params(rs, n_user, n_item, n_domain, "mlp", False, hidden=hidden)
+    uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B)
+    loss, g, pred = otower.loss_and_grads(p, uid, pid, dom, label, None, 0.0, False)
+    X = otower.gather(p, uid, pid, dom).astype(np.float64)
+    clf = _sklearn_mlp(p, hidden)
+    units = [X.shape[1]] + list(hidden) + [1]
+    acts = [X] + [np.empty((B, u)) for u in units[1:]]
+    deltas = [np.empty_like(a) for a in acts[1:]]
+    cg = [np.empty((a, b)) for a, b in zip(units[:-1], units[1:])]
+    ig = [np.empty(b) for b in units[1:]]
+    sk_loss, cg, ig = clf._backprop(X, label.astype(np.float64).reshape(-1, 1), None, acts, deltas, cg, ig)
+    reg = float(otower.reg_loss(p))
+    assert abs((float(loss) - reg) - sk_loss) <= 2e-6 * max(1.0, abs(sk_loss)), (float(loss) - reg, sk_loss)
+    np.testing.assert_allclose(pred, acts[-1][:, 0], rtol=2e-5, atol=2e-7)
+    L = len(hidden)
+    for l in range(L):
+        np.testing.assert_allclose(g["W%d" % l], cg[l], rtol=2e-4, atol=2e-6 * np.abs(cg[l]).max(), err_msg="W%d" % l)
+        np.testing.assert_allclose(g["b%d" % l], ig[l], rtol=2e-4, atol=2e-6 * np.abs(ig[l]).max(), err_msg="b%d" % l)
+    np.testing.assert_allclose(g["wo"], cg[L], rtol=2e-4, atol=2e-6 * np.abs(cg[L]).max())
+    np.testing.assert_allclose(g["gb"], ig[L], rtol=2e-4, atol=1e-7)
+
+
+def test_tf1_adam_equals_sklearn_adam_over_several_steps():
+    """oracle/tower.Optimizer.adam (fp32) against scikit-learn's AdamOptimizer (float64) fed the same gradient sequence:
+    parameters after every one of six steps, from zero slots, with gradient scales spanning six decades."""
+    so = pytest.importorskip("sklearn.neural_network._stochastic_optimizers")
+    rs = np.random.RandomState(22)
+    names = ("a", "b")
+    p = {"a": rs.standard_normal((24, 16)).astype(F32), "b": rs.standard_normal(9).astype(F32)}
+    ref = [p[n].astype(np.float64).copy() for n in names]
+    sk = so.AdamOptimizer(ref, learning_rate_init=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-8)
+    opt = otower.Optimizer(p, names)
+    for t in range(6):
+        g = {n: (rs.standard_normal(p[n].shape) * 10.0 ** rs.randint(-6, 1)).astype(F32) for n in names}
+        before = {n: p[n].copy() for n in names}
+        opt.adam(p, g, 1e-3)
+        sk.update_params(ref, [g[n].astype(np.float64) for n in names])
+        for k, n in enumerate(names):
+            step = np.abs(ref[k] - before[n]).max()
+            np.testing.assert_allclose(p[n], ref[k], rtol=0, atol=(t + 1) * (2e-7 * np.abs(before[n]).max() + 1e-4 * step), err_msg=n)
+
+
+def test_oracle_training_steps_follow_sklearn_end_to_end():
+    """Five whole oracle training steps of the mlp tower's dense block (gradients by hand, fp32 TF1 Adam; dropout off, frozen
+    tables) against scikit-learn's own _backprop + AdamOptimizer on the same batches: the loss of every step and the
+    weights after the fifth."""
+    so = pytest.importorskip("sklearn.neural_network._stochastic_optimizers")
+    rs = np.random.RandomState(23)
+    hidden = (256, 128, 64)
+    n_user, n_item, n_domain, B = 200, 150, 4, 128
+    p = _params(rs, n_user, n_item, n_domain, "mlp", False, hidden=hidden)
+    model = otower.OracleModel({k: v.copy() for k, v in p.items()}, emb_trainable=False, dropout=0.0, lr=1e-3)
+    clf = _sklearn_mlp(p, hidden)
+    L = len(hidden)
+    sk_params = clf.coefs_ + clf.intercepts_
+    sk = so.AdamOptimizer(sk_params, learning_rate_init=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-8)
+    dm0 = p["domain_emb"].copy()
+    for step in range(5):
+        uid, pid, dom, label = _batch(rs, n_user, n_item, n_domain, B, single_domain=step % n_domain)
+        # (the domain table trains in the oracle -- the reference's frozen-table configs keep it trainable -- and not in the
+        # scikit-learn net, whose input is a plain matrix: its rows are taken from the oracle's current table)
+        X = otower.gather(model.params, uid, pid, dom).astype(np.float64)
+        units = [X.shape[1]] + list(hidden) + [1]
+        acts = [X] + [np.empty((B, u)) for u in units[1:]]
+        deltas = [np.empty_like(a) for a in acts[1:]]
+        cg = [np.empty((a, b)) for a, b in zip(units[:-1], units[1:])]
+        ig = [np.empty(b) for b in units[1:]]
+        sk_loss, cg, ig = clf._backprop(X, label.astype(np.float64).reshape(-1, 1), None, acts, deltas, cg, ig)
+        reg = float(otower.reg_loss(model.params, model.frozen_sumsq()))
+        loss = model.train_on_batch(uid, pid, dom, label)
+        assert abs((float(loss) - reg) - sk_loss) <= 5e-5 * max(1.0, abs(sk_loss)), (step, float(loss) - reg, sk_loss)
+        sk.update_params(sk_params, cg + ig)
+    assert not np.array_equal(model.params["domain_emb"], dm0)
+    for l in range(L):
+        d = np.abs(model.params["W%d" % l] - clf.coefs_[l])
+        # (five Adam steps move an element by <= 5 lr; elements whose gradient is rounding noise may differ by a step)
+        assert d.max() <= 2.02e-3 and np.mean(d > 1e-4) < 5e-3, (l, float(d.max()), float(np.mean(d > 1e-4)))
+    d = np.abs(model.params["wo"] - clf.coefs_[L])
+    assert d.max() <= 2.02e-3 and np.mean(d > 1e-4) < 2e-2, (float(d.max()), float(np.mean(d > 1e-4)))
