@@ -417,3 +417,26 @@ def test_oracle_training_steps_follow_sklearn_end_to_end():
         assert d.max() <= 2.02e-3 and np.mean(d > 1e-4) < 5e-3, (l, float(d.max()), float(np.mean(d > 1e-4)))
     d = np.abs(model.params["wo"] - clf.coefs_[L])
     assert d.max() <= 2.02e-3 and np.mean(d > 1e-4) < 2e-2, (float(d.max()), float(np.mean(d > 1e-4)))
+
+
+def test_partitioned_norm_statement_equals_torch_batch_norm():
+    """PartitionedNorm in training (partitioned_norm.py:143-174: nn.moments = population variance, eps 1e-3,
+    gamma_shared * gamma_specific[d], beta_shared + beta_specific[d]) as oracle/torch_ref.star_forward writes it down -- the
+    form oracle/star.py's hand-derived backward is held to above -- against PyTorch's own batch_norm kernel with the same
+    affine: forward values and the gradient through the batch statistics (float64)."""
+    import torch.nn.functional as Fn
+    rs = np.random.RandomState(31)
+    B, C = 96, 384
+    x = torch.tensor(rs.standard_normal((B, C)) * 0.3 + 0.1, dtype=torch.float64, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    gs, gd = (torch.tensor(1 + 0.2 * rs.standard_normal(C), dtype=torch.float64) for _ in range(2))
+    bs, bd = (torch.tensor(0.05 * rs.standard_normal(C), dtype=torch.float64) for _ in range(2))
+    w = torch.tensor(rs.standard_normal((B, C)), dtype=torch.float64)
+    mean = x.mean(dim=0)
+    var = ((x - mean) ** 2).mean(dim=0)
+    h = (x - mean) * torch.rsqrt(var + tref.PN_EPS) * (gs * gd) + (bs + bd)          # star_forward's statement
+    ref = Fn.batch_norm(x2, None, None, weight=gs * gd, bias=bs + bd, training=True, eps=float(tref.PN_EPS))
+    np.testing.assert_allclose(h.detach().numpy(), ref.detach().numpy(), rtol=1e-12, atol=1e-13)
+    (h * w).sum().backward()
+    (ref * w).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), x2.grad.numpy(), rtol=1e-9, atol=1e-12)
